@@ -1,0 +1,216 @@
+/*
+ * parakeet_slam.h -- C ABI of the MI355X-native FastSLAM-1.0 particle update.
+ *
+ * This is the drop-in boundary for the hot path of buckbaskin/parakeet_slam:
+ * the per-timestep particle update in src/prkt_core_v2.py (+ src/matrix.py).
+ * The reference has no FFI of its own -- its boundary is the Python class
+ * surface FastSLAM / FilterParticle / Feature -- so each entry point below
+ * names the reference method (file:line) whose arithmetic it replaces; the
+ * Python facade in parakeet_slam_amd/core.py keeps the class surface and calls
+ * these through ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 (PK_OK) or a negative pk_status; the message of
+ *     the most recent failure on the calling thread is pk_last_error().
+ *   - the caller owns every host buffer; the library owns every device buffer.
+ *   - one caller thread per handle (the facade serialises with a mutex; the
+ *     reference itself races here, prkt_ros.py:113-121 vs prkt_core_v2.py:162).
+ *   - all host-side numbers are float64, the reference's arithmetic type.
+ *   - kernels are enqueued on the handle's HIP stream; entry points that return
+ *     data to the host synchronise that stream, the others do not.
+ *   - landmark ids are the reference's: 1..L in preset order, 0 = "no match"
+ *     (prkt_core_v2.py:294-299, :369-381).
+ *
+ * State layout in HBM: see DESIGN.md section 3.
+ */
+#ifndef PARAKEET_SLAM_H_
+#define PARAKEET_SLAM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
+
+#define PK_ABI_VERSION 1
+
+typedef enum pk_status {
+  PK_OK = 0,
+  PK_ERR_INVALID = -1,     /* bad argument (null pointer, size, non-finite input) */
+  PK_ERR_HIP = -2,         /* a HIP runtime call failed; pk_last_error() has the text */
+  PK_ERR_STATE = -3,       /* call order violated (e.g. observe before a map upload) */
+  PK_ERR_UNSUPPORTED = -4, /* valid request the device path does not implement */
+  PK_ERR_NOMEM = -5        /* host or device allocation failed */
+} pk_status;
+
+/* weight_domain of pk_resample */
+#define PK_WEIGHTS_LINEAR 0 /* w = exp(logw): the reference's quantity, underflows like it */
+#define PK_WEIGHTS_LOG 1    /* w = exp(logw - max logw): same ancestors unless the former underflows */
+
+/* kernel slots of pk_timings */
+enum {
+  PK_T_MOTION = 0,
+  PK_T_ASSOC = 1,
+  PK_T_OBSERVE = 2,
+  PK_T_WEIGHTS = 3,
+  PK_T_RESAMPLE = 4,
+  PK_T_SUMMARY = 5,
+  PK_T_MATERIALISE = 6,
+  PK_T_COUNT = 7
+};
+
+typedef struct pk_filter pk_filter; /* opaque */
+
+int pk_abi_version(void);
+const char* pk_status_string(int status);
+const char* pk_last_error(void);
+
+/* Number of HIP devices visible to this process (0 when there is none). */
+int pk_device_count(void);
+
+/* ---- life cycle -------------------------------------------------------------
+ * FastSLAM.__init__ (prkt_core_v2.py:38-57) + FilterParticle.__init__ (:279-292):
+ * P particles at pose (0,0,0), weight 1, Qt = 0.1*I4, empty map of capacity L.
+ * The reference hard-codes P = 50 (:41); here it is a parameter. */
+int pk_create(int64_t num_particles, int32_t num_landmarks, int32_t device, pk_filter** out);
+int pk_destroy(pk_filter* f);
+
+/* Use a caller-provided hipStream_t (e.g. torch's current stream); NULL restores the
+ * handle's own stream. */
+int pk_set_stream(pk_filter* f, void* hip_stream);
+int pk_synchronize(pk_filter* f);
+int64_t pk_num_particles(const pk_filter* f);
+int32_t pk_num_landmarks(const pk_filter* f);
+/* Bytes of HBM the handle holds (maps are double-buffered). */
+int64_t pk_device_bytes(const pk_filter* f);
+
+/* ---- configuration ----------------------------------------------------------
+ * FastSLAM.Qt (prkt_core_v2.py:50-53), row-major 4x4.  The compact device layout
+ * needs Qt = [q00] (+) [3x3 symmetric]; anything else is PK_ERR_UNSUPPORTED. */
+int pk_set_measurement_noise(pk_filter* f, const double Qt[16]);
+
+/* FilterParticle.load_feature_list (prkt_core_v2.py:294-299) for every particle:
+ * means[L*5] (x,y,r,g,b), covs[L*25] row-major 5x5, immutable[L] = Feature.__immutable__
+ * (:883; NULL = all mutable).  update_count starts at 0.  Covariances must be
+ * symmetric and block-diagonal (xy 2x2 (+) rgb 3x3) -- the structure the reference's
+ * update preserves -- else PK_ERR_UNSUPPORTED. */
+int pk_upload_map(pk_filter* f, const double* means, const double* covs, const uint8_t* immutable);
+
+/* Poses as rows (x, y, heading, weight); weight is the linear particle weight
+ * (FilterParticle.weight, :288), stored on the device as its natural log. */
+int pk_upload_poses(pk_filter* f, const double* xyhw);
+int pk_download_poses(pk_filter* f, double* xyhw);
+
+/* Landmark state of particles [p0, p1): means (n*L*5), covs (n*L*25 dense 5x5),
+ * counts (n*L) = Feature.update_count.  Any output/input pointer may be NULL. */
+int pk_download_landmarks(pk_filter* f, int64_t p0, int64_t p1, double* means, double* covs,
+                          int32_t* counts);
+int pk_upload_landmarks(pk_filter* f, int64_t p0, int64_t p1, const double* means,
+                        const double* covs, const int32_t* counts);
+
+/* ---- the step ---------------------------------------------------------------
+ * particles[i].weight = 1 (prkt_core_v2.py:73). */
+int pk_reset_weights(pk_filter* f);
+
+/* FastSLAM.motion_update/motion_model (prkt_core_v2.py:148-208) for every particle.
+ * z != NULL: host array P*3 of standard normals in the reference's draw order
+ *            (drive, heading-1, heading-2 per particle) -- fixed-seed parity mode;
+ * z == NULL: device counter-based generator (Philox4x32-10) keyed by (seed, draw). */
+int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed,
+              uint64_t draw);
+
+/* The per-particle body of FastSLAM.cam_cb (prkt_core_v2.py:82-124): data association
+ * (match_features_to_scan :317-381, probability_of_match :383-455), then per blob in scan
+ * order generate_measurement :859, measurement_jacobian :748, measurement_covariance :804,
+ * inverse matrix.py:11, kalman_gain :821, Feature.update_mean :897 / update_covar :916,
+ * importance_factor :835 or no_match_weight :851, multiplied into the particle weight.
+ *   blobs: B rows (bearing, r, g, b)  (matrix.blob_to_matrix, matrix.py:35-39)
+ *   ids:   NULL -> maximum-likelihood association on the device, per particle;
+ *          else B landmark ids (0 = unmatched) applied to every particle.
+ *   ids_out: NULL or P*B int32 receiving the ids each particle used. */
+int pk_observe(pk_filter* f, const double* blobs, int32_t num_blobs, const int32_t* ids,
+               int32_t* ids_out);
+
+/* FastSLAM.low_variance_resample (prkt_core_v2.py:210-252) with step = u * sum/P, u in
+ * [0,1) standing for random.random() (:226).  ancestors_out: NULL or P int64. */
+int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestors_out);
+
+/* FastSLAM.summary (prkt_core_v2.py:254-276): (mean x, mean y, circular mean heading). */
+int pk_summary(pk_filter* f, double out[3]);
+
+/* One whole cam_cb without host synchronisation: reset weights, motion, observe,
+ * resample.  Arguments as in the calls above. */
+int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed,
+            uint64_t draw, const double* blobs, int32_t num_blobs, const int32_t* ids, double u,
+            int32_t weight_domain);
+
+/* ---- sharded (multi-GPU) resampling: see DESIGN.md section 6 -------------------
+ * Local statistics of the shard: max logw, and (after the global max is known) the
+ * block totals of exp(logw - gmax).  The collective itself is the caller's
+ * (torch.distributed over RCCL); these only read/write host scalars and arrays. */
+int pk_shard_max_logw(pk_filter* f, double* max_logw);
+int64_t pk_shard_num_blocks(const pk_filter* f);
+int pk_shard_block_totals(pk_filter* f, double gmax, int32_t weight_domain, double* totals);
+/* Given every shard's block totals concatenated in rank order (global_totals,
+ * n_global_blocks), this shard's first block index and the global particle count, compute
+ * for every LOCAL particle the half-open range of global output slots it fills.
+ * slot_lo/slot_hi: P_local int64 each. */
+int pk_shard_offspring(pk_filter* f, const double* global_totals, int64_t n_global_blocks,
+                       int64_t first_block, int64_t global_particles, double u, int64_t* slot_lo,
+                       int64_t* slot_hi);
+/* Pack the listed local particles (pose row + map slot) into a device buffer, and the
+ * reverse.  dev_buf is a device pointer owned by the caller (e.g. a torch tensor). */
+int64_t pk_particle_bytes(const pk_filter* f);
+int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* dev_buf);
+/* New generation of the shard: slot k takes local particle src_local[k] (>= 0) or
+ * received record -(src_local[k]) - 1 of dev_buf. */
+int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, int64_t n_received);
+
+/* ---- single-triple probe ------------------------------------------------------
+ * Runs the device functions the kernels are built from on ONE (pose, landmark, blob):
+ * the scalar methods of FilterParticle the reference's unit tests call.
+ * out[PK_PROBE_LEN]:
+ *   [0] probability_of_match :383      [1] prob_position_match :457
+ *   [2..3] closest_point :496          [4] prob_color_match :524
+ *   [5..8] generate_measurement :859   [9..10] measurement_jacobian H[0][0], H[0][1] :748
+ *   [11..26] measurement_covariance Q 4x4 :804
+ *   [27..46] kalman_gain K 5x4 :821    [47] importance_factor :835
+ *   [48..52] updated mean :897         [53..77] updated covariance 5x5 :916
+ *   [78] log importance factor */
+#define PK_PROBE_LEN 79
+int pk_probe(int32_t device, const double pose[3], const double mean[5], const double cov[25],
+             const double blob[4], const double Qt[16], double* out);
+
+/* ---- instrumentation ----------------------------------------------------------
+ * With timing enabled every kernel launch is bracketed by hipEvents on the handle's
+ * stream.  pk_timings synchronises, then returns accumulated milliseconds and launch
+ * counts per PK_T_* slot since the last pk_reset_timings. */
+int pk_enable_timing(pk_filter* f, int32_t on);
+int pk_reset_timings(pk_filter* f);
+int pk_timings(pk_filter* f, double ms[PK_T_COUNT], int64_t launches[PK_T_COUNT]);
+/* Algorithmic HBM bytes of one observe launch (14 scalars read + 14 written per
+ * particle.landmark) and the bytes the layout actually moves (adds update_count, ids). */
+int pk_observe_bytes(const pk_filter* f, int32_t num_blobs, int64_t* algorithmic, int64_t* moved);
+
+/* ---- host-side reproductions of the reference's RNG streams (no GPU needed) ------
+ * numpy.random.seed(s); numpy.random.normal(0,1,n)  (legacy MT19937 + polar method), the
+ * stream prkt_core_v2.py:185-193 draws from; and random.seed(s); random.random() (:226). */
+typedef struct pk_rng pk_rng;
+int pk_rng_create_numpy(uint32_t seed, pk_rng** out);
+int pk_rng_create_python(uint32_t seed, pk_rng** out);
+int pk_rng_destroy(pk_rng* r);
+int pk_rng_standard_normal(pk_rng* r, int64_t n, double* out);
+int pk_rng_random(pk_rng* r, int64_t n, double* out);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARAKEET_SLAM_H_ */

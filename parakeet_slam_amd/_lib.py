@@ -1,0 +1,300 @@
+"""ctypes binding of ``libparakeet_slam.so`` (include/parakeet_slam.h).
+
+The library is the product path.  There is no CPU fallback: if the shared object
+is missing, or no HIP device is visible when a filter is created, this fails
+loudly (``PkError`` / ``OSError``) instead of computing anything on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libparakeet_slam.so")
+
+PK_OK = 0
+PK_ERR_INVALID, PK_ERR_HIP, PK_ERR_STATE, PK_ERR_UNSUPPORTED, PK_ERR_NOMEM = -1, -2, -3, -4, -5
+PK_WEIGHTS_LINEAR, PK_WEIGHTS_LOG = 0, 1
+PK_T_NAMES = ("motion", "assoc", "observe", "weights", "resample", "summary", "materialise")
+PK_T_COUNT = len(PK_T_NAMES)
+PK_PROBE_LEN = 79
+PK_ABI_VERSION = 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_bp = C.POINTER(C.c_uint8)
+_h = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/parakeet_slam.h one to one
+SIGNATURES = {
+    "pk_abi_version": (C.c_int, []),
+    "pk_status_string": (C.c_char_p, [C.c_int]),
+    "pk_last_error": (C.c_char_p, []),
+    "pk_device_count": (C.c_int, []),
+    "pk_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(_h)]),
+    "pk_destroy": (C.c_int, [_h]),
+    "pk_set_stream": (C.c_int, [_h, C.c_void_p]),
+    "pk_synchronize": (C.c_int, [_h]),
+    "pk_num_particles": (C.c_int64, [_h]),
+    "pk_num_landmarks": (C.c_int32, [_h]),
+    "pk_device_bytes": (C.c_int64, [_h]),
+    "pk_set_measurement_noise": (C.c_int, [_h, _dp]),
+    "pk_upload_map": (C.c_int, [_h, _dp, _dp, _bp]),
+    "pk_upload_poses": (C.c_int, [_h, _dp]),
+    "pk_download_poses": (C.c_int, [_h, _dp]),
+    "pk_download_landmarks": (C.c_int, [_h, C.c_int64, C.c_int64, _dp, _dp, _ip]),
+    "pk_upload_landmarks": (C.c_int, [_h, C.c_int64, C.c_int64, _dp, _dp, _ip]),
+    "pk_reset_weights": (C.c_int, [_h]),
+    "pk_motion": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64]),
+    "pk_observe": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
+    "pk_resample": (C.c_int, [_h, C.c_double, C.c_int32, _lp]),
+    "pk_summary": (C.c_int, [_h, _dp]),
+    "pk_step": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64, _dp, C.c_int32,
+                          _ip, C.c_double, C.c_int32]),
+    "pk_shard_max_logw": (C.c_int, [_h, _dp]),
+    "pk_shard_num_blocks": (C.c_int64, [_h]),
+    "pk_shard_block_totals": (C.c_int, [_h, C.c_double, C.c_int32, _dp]),
+    "pk_shard_offspring": (C.c_int, [_h, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _lp, _lp]),
+    "pk_particle_bytes": (C.c_int64, [_h]),
+    "pk_pack_particles": (C.c_int, [_h, _lp, C.c_int64, C.c_void_p]),
+    "pk_adopt_particles": (C.c_int, [_h, _lp, C.c_void_p, C.c_int64]),
+    "pk_probe": (C.c_int, [C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "pk_enable_timing": (C.c_int, [_h, C.c_int32]),
+    "pk_reset_timings": (C.c_int, [_h]),
+    "pk_timings": (C.c_int, [_h, _dp, _lp]),
+    "pk_observe_bytes": (C.c_int, [_h, C.c_int32, _lp, _lp]),
+    "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
+    "pk_rng_create_python": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
+    "pk_rng_destroy": (C.c_int, [_h]),
+    "pk_rng_standard_normal": (C.c_int, [_h, C.c_int64, _dp]),
+    "pk_rng_random": (C.c_int, [_h, C.c_int64, _dp]),
+}
+
+
+class PkError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("parakeet_slam [%d]: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises OSError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(
+            "%s is missing: build it with `python -m parakeet_slam_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the particle update." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.pk_abi_version()
+    if ver != PK_ABI_VERSION:
+        raise OSError("libparakeet_slam.so has ABI %d, the binding expects %d: rebuild" % (ver, PK_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != PK_OK:
+        lib = load()
+        msg = lib.pk_last_error().decode("utf-8", "replace") or lib.pk_status_string(status).decode()
+        raise PkError(status, msg)
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip) if a is not None else None
+
+
+def lptr(a):
+    return a.ctypes.data_as(_lp) if a is not None else None
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class DeviceFilter(object):
+    """Thin, numpy-in / numpy-out wrapper of one ``pk_filter`` handle.
+
+    This is the layer the FastSLAM facade, the parity tests and bench.py share.
+    """
+
+    def __init__(self, num_particles, num_landmarks, device=0):
+        self._lib = load()
+        self._h = _h()
+        check(self._lib.pk_create(int(num_particles), int(num_landmarks), int(device), C.byref(self._h)))
+        self.P = int(num_particles)
+        self.L = int(num_landmarks)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.pk_destroy(self._h)
+            self._h = _h()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ---------------------------------------------------
+    def set_stream(self, stream_ptr):
+        check(self._lib.pk_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        check(self._lib.pk_synchronize(self._h))
+
+    def device_bytes(self):
+        return int(self._lib.pk_device_bytes(self._h))
+
+    def set_measurement_noise(self, Qt):
+        q = f64(Qt, (16,))
+        check(self._lib.pk_set_measurement_noise(self._h, dptr(q)))
+
+    def upload_map(self, means, covs, immutable=None):
+        m = f64(means, (self.L, 5))
+        c = f64(covs, (self.L, 25))
+        im = None
+        if immutable is not None:
+            im = np.ascontiguousarray(immutable, dtype=np.uint8).reshape(self.L)
+        check(self._lib.pk_upload_map(self._h, dptr(m), dptr(c), im.ctypes.data_as(_bp) if im is not None else None))
+
+    def upload_poses(self, xyhw):
+        a = f64(xyhw, (self.P, 4))
+        check(self._lib.pk_upload_poses(self._h, dptr(a)))
+
+    def download_poses(self):
+        out = np.empty((self.P, 4), dtype=np.float64)
+        check(self._lib.pk_download_poses(self._h, dptr(out)))
+        return out
+
+    def download_landmarks(self, p0=0, p1=None, means=True, covs=True, counts=True):
+        p1 = self.P if p1 is None else p1
+        n = p1 - p0
+        m = np.empty((n, self.L, 5)) if means else None
+        c = np.empty((n, self.L, 5, 5)) if covs else None
+        k = np.empty((n, self.L), dtype=np.int32) if counts else None
+        check(self._lib.pk_download_landmarks(self._h, p0, p1, dptr(m), dptr(c), iptr(k)))
+        return m, c, k
+
+    def upload_landmarks(self, p0, p1, means=None, covs=None, counts=None):
+        n = p1 - p0
+        m = f64(means, (n, self.L, 5)) if means is not None else None
+        c = f64(covs, (n, self.L, 25)) if covs is not None else None
+        k = np.ascontiguousarray(counts, dtype=np.int32).reshape(n, self.L) if counts is not None else None
+        check(self._lib.pk_upload_landmarks(self._h, p0, p1, dptr(m), dptr(c), iptr(k)))
+
+    # -- the step ----------------------------------------------------------
+    def reset_weights(self):
+        check(self._lib.pk_reset_weights(self._h))
+
+    def motion(self, v, w, dt, z=None, seed=0, draw=0):
+        zz = f64(z, (self.P, 3)) if z is not None else None
+        check(self._lib.pk_motion(self._h, float(v), float(w), float(dt), dptr(zz), int(seed), int(draw)))
+
+    def observe(self, blobs, ids=None, return_ids=False):
+        b = f64(blobs).reshape(-1, 4)
+        B = b.shape[0]
+        i = np.ascontiguousarray(ids, dtype=np.int32).reshape(B) if ids is not None else None
+        out = np.empty((self.P, B), dtype=np.int32) if return_ids else None
+        check(self._lib.pk_observe(self._h, dptr(b), B, iptr(i), iptr(out)))
+        return out
+
+    def resample(self, u, domain=PK_WEIGHTS_LINEAR, return_ancestors=False):
+        out = np.empty(self.P, dtype=np.int64) if return_ancestors else None
+        check(self._lib.pk_resample(self._h, float(u), int(domain), lptr(out)))
+        return out
+
+    def summary(self):
+        out = np.empty(3, dtype=np.float64)
+        check(self._lib.pk_summary(self._h, dptr(out)))
+        return float(out[0]), float(out[1]), float(out[2])
+
+    def step(self, v, w, dt, blobs, u, z=None, seed=0, draw=0, ids=None, domain=PK_WEIGHTS_LINEAR):
+        b = f64(blobs).reshape(-1, 4)
+        B = b.shape[0]
+        zz = f64(z, (self.P, 3)) if z is not None else None
+        i = np.ascontiguousarray(ids, dtype=np.int32).reshape(B) if ids is not None else None
+        check(self._lib.pk_step(self._h, float(v), float(w), float(dt), dptr(zz), int(seed), int(draw), dptr(b), B,
+                                iptr(i), float(u), int(domain)))
+
+    # -- instrumentation -----------------------------------------------------
+    def enable_timing(self, on=True):
+        check(self._lib.pk_enable_timing(self._h, 1 if on else 0))
+
+    def reset_timings(self):
+        check(self._lib.pk_reset_timings(self._h))
+
+    def timings(self):
+        ms = np.zeros(PK_T_COUNT, dtype=np.float64)
+        n = np.zeros(PK_T_COUNT, dtype=np.int64)
+        check(self._lib.pk_timings(self._h, dptr(ms), lptr(n)))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(PK_T_NAMES)}
+
+    def observe_bytes(self, num_blobs):
+        a = C.c_int64()
+        m = C.c_int64()
+        check(self._lib.pk_observe_bytes(self._h, int(num_blobs), C.byref(a), C.byref(m)))
+        return int(a.value), int(m.value)
+
+
+def probe(pose, mean, cov, blob, Qt=None, device=0):
+    """Evaluate every scalar function of the path on one (pose, landmark, blob) on the GPU."""
+    lib = load()
+    Qt = 0.1 * np.identity(4) if Qt is None else Qt
+    out = np.empty(PK_PROBE_LEN, dtype=np.float64)
+    check(lib.pk_probe(int(device), dptr(f64(pose, (3,))), dptr(f64(mean, (5,))), dptr(f64(cov, (25,))),
+                       dptr(f64(blob, (4,))), dptr(f64(Qt, (16,))), dptr(out)))
+    return dict(
+        probability_of_match=out[0], prob_position_match=out[1], closest_point=out[2:4].copy(),
+        prob_color_match=out[4], zhat=out[5:9].copy(), H0=out[9:11].copy(), Q=out[11:27].reshape(4, 4).copy(),
+        K=out[27:47].reshape(5, 4).copy(), weight=out[47], new_mean=out[48:53].copy(),
+        new_cov=out[53:78].reshape(5, 5).copy(), log_weight=out[78],
+    )
+
+
+class HostRng(object):
+    """Host reproduction of numpy's legacy normal stream / CPython's random() (pk_rng_*)."""
+
+    def __init__(self, seed, kind="numpy"):
+        self._lib = load()
+        self._h = _h()
+        fn = self._lib.pk_rng_create_numpy if kind == "numpy" else self._lib.pk_rng_create_python
+        check(fn(int(seed) & 0xFFFFFFFF, C.byref(self._h)))
+
+    def standard_normal(self, n):
+        out = np.empty(int(n), dtype=np.float64)
+        check(self._lib.pk_rng_standard_normal(self._h, int(n), dptr(out)))
+        return out
+
+    def random(self, n=None):
+        out = np.empty(1 if n is None else int(n), dtype=np.float64)
+        check(self._lib.pk_rng_random(self._h, out.size, dptr(out)))
+        return float(out[0]) if n is None else out
+
+    def __del__(self):
+        try:
+            if self._h.value:
+                self._lib.pk_rng_destroy(self._h)
+                self._h = _h()
+        except Exception:
+            pass

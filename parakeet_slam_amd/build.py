@@ -1,0 +1,76 @@
+"""Build the HIP shared library in-tree (gfx950 only).
+
+    python -m parakeet_slam_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting ``parakeet_slam_amd/libparakeet_slam.so`` travels to the GPU box with
+the snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libparakeet_slam.so")
+OBJDIR = os.path.join(HERE, "csrc", "_obj")
+
+HIP_SOURCES = ["pk_kernels.hip", "pk_api.hip"]
+CXX_SOURCES = ["pk_rng.cpp"]  # host-only, no FMA contraction: must match NumPy/CPython bit for bit
+HEADERS = [
+    "pk_math.hpp", "pk_layout.hpp", "pk_kernels.hpp", "pk_philox.hpp",
+    os.path.join("..", "..", "include", "parakeet_slam.h"),
+]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in HIP_SOURCES + CXX_SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, src + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers + [os.path.abspath(__file__)]):
+            if src.endswith(".hip"):
+                cmd = [hipcc] + HIPCC_FLAGS + ["-c", path, "-o", obj]
+            else:
+                cmd = [hipcc, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                       "-ffp-contract=off", "-Wall", "-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,852 @@
+// C ABI of the FastSLAM particle update (include/parakeet_slam.h) on top of the gfx950
+// kernels.  Host orchestration only: argument checks, host<->device staging, launch
+// order, hipEvent instrumentation.  No arithmetic of the path runs on the host except
+// the three reductions to scalars that the reference also does in Python floats
+// (summary's division and atan2, prkt_core_v2.py:273-275) and the per-blob unit ray
+// direction cos/sin (prkt_core_v2.py:510), which are O(B), not O(P*L).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/parakeet_slam.h"
+#include "pk_kernels.hpp"
+
+using namespace pk;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define PK_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (void)hipGetLastError();                                                               \
+      return fail(e_ == hipErrorOutOfMemory ? PK_ERR_NOMEM : PK_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    }                                                                                        \
+  } while (0)
+
+struct TimedSpan {
+  int slot;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct pk_filter {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  DeviceState d{};
+  NoiseD qt{0.1, 0.1, 0.0, 0.0, 0.1, 0.0, 0.1};
+  bool map_loaded = false;
+  bool src_identity = true;
+  int64_t nblocks = 0;  // weight-scan blocks
+  int64_t device_bytes = 0;
+  // workspaces
+  double* z_dev = nullptr;        // P x 3
+  double* blobs_dev = nullptr;    // Bcap x 4
+  double* blobdir_dev = nullptr;  // Bcap x 2
+  int32_t* first_dev = nullptr;   // Lp
+  int32_t* next_dev = nullptr;    // Bcap
+  int32_t* ids_dev = nullptr;     // P x Bcap_ids
+  int Bcap = 0;
+  int64_t ids_cap = 0;
+  // pinned host staging ring for the per-scan uploads (blobs, ray directions, chains):
+  // lets pk_observe/pk_step return without synchronising the stream
+  static constexpr int kRing = 8;
+  unsigned char* stage[kRing] = {nullptr};
+  hipEvent_t stage_done[kRing] = {nullptr};
+  size_t stage_cap = 0;
+  int stage_next = 0;
+  double* partial = nullptr;  // 4 * 1024
+  double* gmax = nullptr;
+  double* clocal = nullptr;   // P
+  double* totals = nullptr;   // nblocks
+  double* offsets = nullptr;  // nblocks
+  double* sum = nullptr;
+  double* out4 = nullptr;
+  int32_t* anc = nullptr;           // P
+  unsigned char* slot_tmp = nullptr;  // one slot
+  // timing
+  bool timing = false;
+  std::vector<TimedSpan> pending;
+  std::vector<hipEvent_t> pool;
+  double ms[PK_T_COUNT] = {0};
+  int64_t launches[PK_T_COUNT] = {0};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(pk_filter* f, T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(PK_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+  }
+  f->device_bytes += (int64_t)(n * sizeof(T));
+  return PK_OK;
+}
+
+struct Span {
+  pk_filter* f;
+  int slot;
+  hipEvent_t a = nullptr, b = nullptr;
+  Span(pk_filter* f_, int slot_) : f(f_), slot(slot_) {
+    if (!f->timing) return;
+    a = take();
+    b = take();
+    if (a) (void)hipEventRecord(a, f->stream);
+  }
+  hipEvent_t take() {
+    if (!f->pool.empty()) {
+      hipEvent_t e = f->pool.back();
+      f->pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  ~Span() {
+    if (!f->timing || !a || !b) return;
+    (void)hipEventRecord(b, f->stream);
+    f->pending.push_back(TimedSpan{slot, a, b});
+  }
+};
+
+int drain_timings(pk_filter* f) {
+  if (f->pending.empty()) return PK_OK;
+  PK_HIP(hipStreamSynchronize(f->stream));
+  for (auto& t : f->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+      f->ms[t.slot] += ms;
+      f->launches[t.slot] += 1;
+    }
+    f->pool.push_back(t.a);
+    f->pool.push_back(t.b);
+  }
+  f->pending.clear();
+  return PK_OK;
+}
+
+int use_device(pk_filter* f) {
+  PK_HIP(hipSetDevice(f->device));
+  return PK_OK;
+}
+
+int ensure_blob_capacity(pk_filter* f, int B) {
+  if (B <= f->Bcap) return PK_OK;
+  PK_HIP(hipStreamSynchronize(f->stream));
+  if (f->blobs_dev) (void)hipFree(f->blobs_dev);
+  if (f->blobdir_dev) (void)hipFree(f->blobdir_dev);
+  if (f->next_dev) (void)hipFree(f->next_dev);
+  f->blobs_dev = nullptr;
+  f->blobdir_dev = nullptr;
+  f->next_dev = nullptr;
+  f->Bcap = 0;
+  int cap = B + B / 4 + 16;
+  int rc;
+  if ((rc = dev_alloc(f, &f->blobs_dev, (size_t)cap * 4))) return rc;
+  if ((rc = dev_alloc(f, &f->blobdir_dev, (size_t)cap * 2))) return rc;
+  if ((rc = dev_alloc(f, &f->next_dev, (size_t)cap))) return rc;
+  f->Bcap = cap;
+  return PK_OK;
+}
+
+int ensure_ids_capacity(pk_filter* f, int B) {
+  int64_t need = f->d.P * (int64_t)B;
+  if (need <= f->ids_cap) return PK_OK;
+  PK_HIP(hipStreamSynchronize(f->stream));
+  if (f->ids_dev) (void)hipFree(f->ids_dev);
+  f->ids_dev = nullptr;
+  f->ids_cap = 0;
+  int rc;
+  if ((rc = dev_alloc(f, &f->ids_dev, (size_t)need))) return rc;
+  f->ids_cap = need;
+  return PK_OK;
+}
+
+// Next pinned staging block of at least `bytes`; waits for the upload that last used it.
+int take_stage(pk_filter* f, size_t bytes, unsigned char** out, int* slot) {
+  if (bytes > f->stage_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    size_t cap = bytes + bytes / 4 + 4096;
+    for (int i = 0; i < pk_filter::kRing; ++i) {
+      if (f->stage[i]) (void)hipHostFree(f->stage[i]);
+      f->stage[i] = nullptr;
+      PK_HIP(hipHostMalloc((void**)&f->stage[i], cap, hipHostMallocDefault));
+      if (!f->stage_done[i]) PK_HIP(hipEventCreateWithFlags(&f->stage_done[i], hipEventDisableTiming));
+    }
+    f->stage_cap = cap;
+  }
+  int i = f->stage_next;
+  f->stage_next = (i + 1) % pk_filter::kRing;
+  PK_HIP(hipEventSynchronize(f->stage_done[i]));
+  *out = f->stage[i];
+  *slot = i;
+  return PK_OK;
+}
+
+int materialise(pk_filter* f) {
+  if (f->src_identity) return PK_OK;
+  {
+    Span t(f, PK_T_MATERIALISE);
+    launch_materialise(f->stream, f->d);
+  }
+  f->src_identity = true;
+  return PK_OK;
+}
+
+// Pack one landmark (dense 5x5 host form) into the compact fields of a host slot image.
+void pack_landmark(const MapLayout& lay, unsigned char* slot, int l, const double* mean, const double* cov) {
+  double* fl = reinterpret_cast<double*>(slot);
+  const int Lp = lay.Lp;
+  for (int i = 0; i < 5; ++i) fl[(size_t)i * Lp + l] = mean[i];
+  fl[(size_t)F_PXX * Lp + l] = cov[0];
+  fl[(size_t)F_PXY * Lp + l] = 0.5 * (cov[1] + cov[5]);
+  fl[(size_t)F_PYY * Lp + l] = cov[6];
+  fl[(size_t)F_CRR * Lp + l] = cov[12];
+  fl[(size_t)F_CRG * Lp + l] = 0.5 * (cov[13] + cov[17]);
+  fl[(size_t)F_CRB * Lp + l] = 0.5 * (cov[14] + cov[22]);
+  fl[(size_t)F_CGG * Lp + l] = cov[18];
+  fl[(size_t)F_CGB * Lp + l] = 0.5 * (cov[19] + cov[23]);
+  fl[(size_t)F_CBB * Lp + l] = cov[24];
+}
+
+void unpack_landmark(const MapLayout& lay, const unsigned char* slot, int l, double* mean, double* cov) {
+  const double* fl = reinterpret_cast<const double*>(slot);
+  const int Lp = lay.Lp;
+  if (mean)
+    for (int i = 0; i < 5; ++i) mean[i] = fl[(size_t)i * Lp + l];
+  if (cov) {
+    for (int i = 0; i < 25; ++i) cov[i] = 0.0;
+    cov[0] = fl[(size_t)F_PXX * Lp + l];
+    cov[1] = cov[5] = fl[(size_t)F_PXY * Lp + l];
+    cov[6] = fl[(size_t)F_PYY * Lp + l];
+    cov[12] = fl[(size_t)F_CRR * Lp + l];
+    cov[13] = cov[17] = fl[(size_t)F_CRG * Lp + l];
+    cov[14] = cov[22] = fl[(size_t)F_CRB * Lp + l];
+    cov[18] = fl[(size_t)F_CGG * Lp + l];
+    cov[19] = cov[23] = fl[(size_t)F_CGB * Lp + l];
+    cov[24] = fl[(size_t)F_CBB * Lp + l];
+  }
+}
+
+// The compact layout stores Sigma = Pxy (+) C: reject anything else loudly.
+int check_block_diagonal(const double* cov, int l) {
+  double scale = 0.0;
+  for (int i = 0; i < 5; ++i) scale = fmax(scale, fabs(cov[i * 6]));
+  if (!(scale >= 0.0) || !std::isfinite(scale))
+    return fail(PK_ERR_INVALID, "landmark %d: covariance diagonal is not finite", l + 1);
+  const double tol = 1e-9 * (scale > 0 ? scale : 1.0);
+  for (int i = 0; i < 2; ++i)
+    for (int j = 2; j < 5; ++j)
+      if (fabs(cov[i * 5 + j]) > 1e-14 * scale || fabs(cov[j * 5 + i]) > 1e-14 * scale)
+        return fail(PK_ERR_UNSUPPORTED,
+                    "landmark %d: covariance couples position and colour (entry [%d][%d]); the compact "
+                    "device layout holds xy 2x2 (+) rgb 3x3 only",
+                    l + 1, i, j);
+  for (int i = 0; i < 5; ++i)
+    for (int j = i + 1; j < 5; ++j) {
+      if (!std::isfinite(cov[i * 5 + j])) return fail(PK_ERR_INVALID, "landmark %d: covariance not finite", l + 1);
+      if (fabs(cov[i * 5 + j] - cov[j * 5 + i]) > tol)
+        return fail(PK_ERR_UNSUPPORTED, "landmark %d: covariance is not symmetric", l + 1);
+    }
+  return PK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pk_abi_version(void) { return PK_ABI_VERSION; }
+
+const char* pk_status_string(int status) {
+  switch (status) {
+    case PK_OK: return "ok";
+    case PK_ERR_INVALID: return "invalid argument";
+    case PK_ERR_HIP: return "HIP runtime error";
+    case PK_ERR_STATE: return "invalid call order";
+    case PK_ERR_UNSUPPORTED: return "unsupported by the device path";
+    case PK_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char* pk_last_error(void) { return g_last_error.c_str(); }
+
+int pk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int pk_create(int64_t P, int32_t L, int32_t device, pk_filter** out) {
+  if (!out) return fail(PK_ERR_INVALID, "pk_create: out is NULL");
+  *out = nullptr;
+  if (P < 1 || P > 2147483647LL) return fail(PK_ERR_INVALID, "pk_create: num_particles %lld out of range", (long long)P);
+  if (L < 0 || L > (1 << 24)) return fail(PK_ERR_INVALID, "pk_create: num_landmarks %d out of range", L);
+  int ndev = pk_device_count();
+  if (ndev <= 0) return fail(PK_ERR_HIP, "pk_create: no HIP device visible (the HIP path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(PK_ERR_INVALID, "pk_create: device %d of %d", device, ndev);
+  pk_filter* f = new (std::nothrow) pk_filter;
+  if (!f) return fail(PK_ERR_NOMEM, "pk_create: host allocation failed");
+  f->device = device;
+  int rc = PK_OK;
+  auto bail = [&](int code) {
+    pk_destroy(f);
+    return code;
+  };
+  if ((rc = use_device(f))) return bail(rc);
+  if (hipStreamCreateWithFlags(&f->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(PK_ERR_HIP, "hipStreamCreate failed"));
+  f->stream = f->own_stream;
+  DeviceState& d = f->d;
+  d.P = P;
+  d.lay = MapLayout::make(L, sizeof(double));
+  d.cur = 0;
+  d.mcur = 0;
+  f->nblocks = (P + kScanBlock - 1) / kScanBlock;
+  for (int i = 0; i < 2 && !rc; ++i) {
+    if (!rc) rc = dev_alloc(f, &d.x[i], (size_t)P);
+    if (!rc) rc = dev_alloc(f, &d.y[i], (size_t)P);
+    if (!rc) rc = dev_alloc(f, &d.h[i], (size_t)P);
+    if (!rc) rc = dev_alloc(f, &d.logw[i], (size_t)P);
+    if (!rc) rc = dev_alloc(f, &d.src[i], (size_t)P);
+    if (!rc) rc = dev_alloc(f, &d.map[i], (size_t)P * d.lay.slot_bytes);
+  }
+  if (!rc) rc = dev_alloc(f, &d.immutable, (size_t)d.lay.Lp);
+  if (!rc) rc = dev_alloc(f, &f->z_dev, (size_t)P * 3);
+  if (!rc) rc = dev_alloc(f, &f->first_dev, (size_t)d.lay.Lp);
+  if (!rc) rc = dev_alloc(f, &f->partial, (size_t)4 * 1024);
+  if (!rc) rc = dev_alloc(f, &f->gmax, 1);
+  if (!rc) rc = dev_alloc(f, &f->clocal, (size_t)P);
+  if (!rc) rc = dev_alloc(f, &f->totals, (size_t)f->nblocks);
+  if (!rc) rc = dev_alloc(f, &f->offsets, (size_t)f->nblocks);
+  if (!rc) rc = dev_alloc(f, &f->sum, 1);
+  if (!rc) rc = dev_alloc(f, &f->out4, 4);
+  if (!rc) rc = dev_alloc(f, &f->anc, (size_t)P);
+  if (!rc) rc = dev_alloc(f, &f->slot_tmp, d.lay.slot_bytes);
+  if (rc) return bail(rc);
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+    e = hipMemsetAsync(d.x[i], 0, P * sizeof(double), f->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d.y[i], 0, P * sizeof(double), f->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d.h[i], 0, P * sizeof(double), f->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d.logw[i], 0, P * sizeof(double), f->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d.map[i], 0, (size_t)P * d.lay.slot_bytes, f->stream);
+  }
+  if (e == hipSuccess) e = hipMemsetAsync(d.immutable, 0, d.lay.Lp, f->stream);
+  if (e != hipSuccess) return bail(fail(PK_ERR_HIP, "pk_create: memset failed: %s", hipGetErrorString(e)));
+  launch_iota(f->stream, d.src[0], P);
+  launch_iota(f->stream, d.src[1], P);
+  if (hipStreamSynchronize(f->stream) != hipSuccess) return bail(fail(PK_ERR_HIP, "pk_create: sync failed"));
+  f->map_loaded = (L == 0);
+  *out = f;
+  return PK_OK;
+}
+
+int pk_destroy(pk_filter* f) {
+  if (!f) return PK_OK;
+  (void)hipSetDevice(f->device);
+  if (f->stream) (void)hipStreamSynchronize(f->stream);
+  for (auto& t : f->pending) {
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  for (auto e : f->pool) (void)hipEventDestroy(e);
+  DeviceState& d = f->d;
+  for (int i = 0; i < 2; ++i) {
+    (void)hipFree(d.x[i]);
+    (void)hipFree(d.y[i]);
+    (void)hipFree(d.h[i]);
+    (void)hipFree(d.logw[i]);
+    (void)hipFree(d.src[i]);
+    (void)hipFree(d.map[i]);
+  }
+  void* rest[] = {d.immutable, f->z_dev,  f->blobs_dev, f->blobdir_dev, f->first_dev, f->next_dev, f->ids_dev,
+                  f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
+                  f->anc,      f->slot_tmp};
+  for (void* p : rest)
+    if (p) (void)hipFree(p);
+  for (int i = 0; i < pk_filter::kRing; ++i) {
+    if (f->stage[i]) (void)hipHostFree(f->stage[i]);
+    if (f->stage_done[i]) (void)hipEventDestroy(f->stage_done[i]);
+  }
+  if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
+  delete f;
+  return PK_OK;
+}
+
+int pk_set_stream(pk_filter* f, void* hip_stream) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_set_stream: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = drain_timings(f))) return rc;
+  PK_HIP(hipStreamSynchronize(f->stream));
+  f->stream = hip_stream ? (hipStream_t)hip_stream : f->own_stream;
+  return PK_OK;
+}
+
+int pk_synchronize(pk_filter* f) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_synchronize: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+int64_t pk_num_particles(const pk_filter* f) { return f ? f->d.P : -1; }
+int32_t pk_num_landmarks(const pk_filter* f) { return f ? f->d.lay.L : -1; }
+int64_t pk_device_bytes(const pk_filter* f) { return f ? f->device_bytes : -1; }
+
+int pk_set_measurement_noise(pk_filter* f, const double Qt[16]) {
+  if (!f || !Qt) return fail(PK_ERR_INVALID, "pk_set_measurement_noise: NULL argument");
+  for (int i = 0; i < 16; ++i)
+    if (!std::isfinite(Qt[i])) return fail(PK_ERR_INVALID, "Qt is not finite");
+  double scale = 0;
+  for (int i = 0; i < 4; ++i) scale = fmax(scale, fabs(Qt[i * 5]));
+  for (int j = 1; j < 4; ++j)
+    if (fabs(Qt[j]) > 1e-14 * scale || fabs(Qt[j * 4]) > 1e-14 * scale)
+      return fail(PK_ERR_UNSUPPORTED, "Qt couples bearing and colour; the compact device layout needs Qt = [q00] (+) 3x3");
+  for (int i = 1; i < 4; ++i)
+    for (int j = i + 1; j < 4; ++j)
+      if (fabs(Qt[i * 4 + j] - Qt[j * 4 + i]) > 1e-9 * (scale > 0 ? scale : 1.0))
+        return fail(PK_ERR_UNSUPPORTED, "Qt is not symmetric");
+  f->qt = NoiseD{Qt[0], Qt[5], 0.5 * (Qt[6] + Qt[9]), 0.5 * (Qt[7] + Qt[13]), Qt[10], 0.5 * (Qt[11] + Qt[14]), Qt[15]};
+  return PK_OK;
+}
+
+int pk_upload_map(pk_filter* f, const double* means, const double* covs, const uint8_t* immutable) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_upload_map: NULL handle");
+  const MapLayout& lay = f->d.lay;
+  const int L = lay.L;
+  if (L > 0 && (!means || !covs)) return fail(PK_ERR_INVALID, "pk_upload_map: NULL means/covs");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  for (int l = 0; l < L; ++l) {
+    for (int i = 0; i < 5; ++i)
+      if (!std::isfinite(means[l * 5 + i])) return fail(PK_ERR_INVALID, "landmark %d: mean is not finite", l + 1);
+    if ((rc = check_block_diagonal(covs + (size_t)l * 25, l))) return rc;
+  }
+  std::vector<unsigned char> slot(lay.slot_bytes, 0);
+  std::vector<unsigned char> imm((size_t)lay.Lp, 0);
+  for (int l = 0; l < L; ++l) {
+    pack_landmark(lay, slot.data(), l, means + (size_t)l * 5, covs + (size_t)l * 25);
+    imm[l] = immutable ? (immutable[l] != 0) : 0;
+  }
+  PK_HIP(hipMemcpyAsync(f->slot_tmp, slot.data(), lay.slot_bytes, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->d.immutable, imm.data(), imm.size(), hipMemcpyHostToDevice, f->stream));
+  launch_broadcast_slot(f->stream, f->d, f->slot_tmp);
+  PK_HIP(hipStreamSynchronize(f->stream));  // host staging buffers die here
+  f->src_identity = true;
+  f->map_loaded = true;
+  return PK_OK;
+}
+
+int pk_upload_poses(pk_filter* f, const double* xyhw) {
+  if (!f || !xyhw) return fail(PK_ERR_INVALID, "pk_upload_poses: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const int64_t P = f->d.P;
+  std::vector<double> soa((size_t)P * 4);
+  for (int64_t i = 0; i < P; ++i) {
+    soa[i] = xyhw[4 * i];
+    soa[P + i] = xyhw[4 * i + 1];
+    soa[2 * P + i] = xyhw[4 * i + 2];
+    double w = xyhw[4 * i + 3];
+    if (!(w >= 0.0)) return fail(PK_ERR_INVALID, "pk_upload_poses: weight of particle %lld is negative or NaN", (long long)i);
+    soa[3 * P + i] = std::log(w);
+  }
+  const int c = f->d.cur;
+  PK_HIP(hipMemcpyAsync(f->d.x[c], soa.data(), P * 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->d.y[c], soa.data() + P, P * 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->d.h[c], soa.data() + 2 * P, P * 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->d.logw[c], soa.data() + 3 * P, P * 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+int pk_download_poses(pk_filter* f, double* xyhw) {
+  if (!f || !xyhw) return fail(PK_ERR_INVALID, "pk_download_poses: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const int64_t P = f->d.P;
+  std::vector<double> soa((size_t)P * 4);
+  const int c = f->d.cur;
+  PK_HIP(hipMemcpyAsync(soa.data(), f->d.x[c], P * 8, hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipMemcpyAsync(soa.data() + P, f->d.y[c], P * 8, hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipMemcpyAsync(soa.data() + 2 * P, f->d.h[c], P * 8, hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipMemcpyAsync(soa.data() + 3 * P, f->d.logw[c], P * 8, hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  for (int64_t i = 0; i < P; ++i) {
+    xyhw[4 * i] = soa[i];
+    xyhw[4 * i + 1] = soa[P + i];
+    xyhw[4 * i + 2] = soa[2 * P + i];
+    xyhw[4 * i + 3] = std::exp(soa[3 * P + i]);
+  }
+  return PK_OK;
+}
+
+int pk_download_landmarks(pk_filter* f, int64_t p0, int64_t p1, double* means, double* covs, int32_t* counts) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_download_landmarks: NULL handle");
+  if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "pk_download_landmarks: bad particle range");
+  if (!f->map_loaded) return fail(PK_ERR_STATE, "pk_download_landmarks: no map uploaded");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = materialise(f))) return rc;
+  const MapLayout& lay = f->d.lay;
+  const int L = lay.L;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)lay.slot_bytes);
+  std::vector<unsigned char> host((size_t)std::min<int64_t>(chunk, p1 - p0) * lay.slot_bytes);
+  for (int64_t q0 = p0; q0 < p1; q0 += chunk) {
+    int64_t q1 = std::min(p1, q0 + chunk);
+    PK_HIP(hipMemcpyAsync(host.data(), f->d.map[f->d.mcur] + (size_t)q0 * lay.slot_bytes,
+                          (size_t)(q1 - q0) * lay.slot_bytes, hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+    for (int64_t q = q0; q < q1; ++q) {
+      const unsigned char* slot = host.data() + (size_t)(q - q0) * lay.slot_bytes;
+      const int32_t* cnt = reinterpret_cast<const int32_t*>(slot + lay.count_off);
+      for (int l = 0; l < L; ++l) {
+        size_t o = (size_t)(q - p0) * L + l;
+        unpack_landmark(lay, slot, l, means ? means + o * 5 : nullptr, covs ? covs + o * 25 : nullptr);
+        if (counts) counts[o] = cnt[l];
+      }
+    }
+  }
+  return PK_OK;
+}
+
+int pk_upload_landmarks(pk_filter* f, int64_t p0, int64_t p1, const double* means, const double* covs,
+                        const int32_t* counts) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_upload_landmarks: NULL handle");
+  if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "pk_upload_landmarks: bad particle range");
+  if (!f->map_loaded) return fail(PK_ERR_STATE, "pk_upload_landmarks: no map uploaded");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = materialise(f))) return rc;
+  const MapLayout& lay = f->d.lay;
+  const int L = lay.L;
+  if (covs)
+    for (int64_t o = 0; o < (p1 - p0) * L; ++o)
+      if ((rc = check_block_diagonal(covs + (size_t)o * 25, (int)(o % L)))) return rc;
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)lay.slot_bytes);
+  std::vector<unsigned char> host((size_t)std::min<int64_t>(chunk, p1 - p0) * lay.slot_bytes);
+  for (int64_t q0 = p0; q0 < p1; q0 += chunk) {
+    int64_t q1 = std::min(p1, q0 + chunk);
+    unsigned char* dev = f->d.map[f->d.mcur] + (size_t)q0 * lay.slot_bytes;
+    PK_HIP(hipMemcpyAsync(host.data(), dev, (size_t)(q1 - q0) * lay.slot_bytes, hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+    for (int64_t q = q0; q < q1; ++q) {
+      unsigned char* slot = host.data() + (size_t)(q - q0) * lay.slot_bytes;
+      int32_t* cnt = reinterpret_cast<int32_t*>(slot + lay.count_off);
+      for (int l = 0; l < L; ++l) {
+        size_t o = (size_t)(q - p0) * L + l;
+        double m[5], c[25];
+        unpack_landmark(lay, slot, l, m, c);
+        pack_landmark(lay, slot, l, means ? means + o * 5 : m, covs ? covs + o * 25 : c);
+        if (counts) cnt[l] = counts[o];
+      }
+    }
+    PK_HIP(hipMemcpyAsync(dev, host.data(), (size_t)(q1 - q0) * lay.slot_bytes, hipMemcpyHostToDevice, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+  }
+  return PK_OK;
+}
+
+int pk_reset_weights(pk_filter* f) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_reset_weights: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  launch_reset_weights(f->stream, f->d);
+  return PK_OK;
+}
+
+int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed, uint64_t draw) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_motion: NULL handle");
+  if (!std::isfinite(v) || !std::isfinite(w) || !std::isfinite(dt)) return fail(PK_ERR_INVALID, "pk_motion: non-finite control");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const double* zd = nullptr;
+  if (z) {
+    // Parity mode: the caller's (pageable) buffer must be consumed before we return.
+    PK_HIP(hipMemcpyAsync(f->z_dev, z, (size_t)f->d.P * 3 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+    zd = f->z_dev;
+  }
+  Span t(f, PK_T_MOTION);
+  launch_motion(f->stream, f->d, v, w, dt, zd, seed, draw, 0);
+  return PK_OK;
+}
+
+int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_observe: NULL handle");
+  if (B < 0 || (B > 0 && !blobs)) return fail(PK_ERR_INVALID, "pk_observe: bad blobs");
+  if (!f->map_loaded) return fail(PK_ERR_STATE, "pk_observe: no map uploaded (pk_upload_map)");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const MapLayout& lay = f->d.lay;
+  const int L = lay.L;
+  for (int i = 0; i < 4 * B; ++i)
+    if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_observe: blob %d is not finite", i / 4);
+  if (ids)
+    for (int b = 0; b < B; ++b)
+      if (ids[b] < 0 || ids[b] > L) return fail(PK_ERR_INVALID, "pk_observe: ids[%d] = %d outside 0..%d", b, ids[b], L);
+  if ((rc = ensure_blob_capacity(f, B))) return rc;
+  // staging block: blobs (4B doubles) | dir (2B doubles) | first (Lp int32) | next (B int32)
+  const size_t o_dir = (size_t)B * 4 * sizeof(double);
+  const size_t o_first = o_dir + (size_t)B * 2 * sizeof(double);
+  const size_t o_next = o_first + (size_t)lay.Lp * sizeof(int32_t);
+  const size_t total = o_next + (size_t)B * sizeof(int32_t);
+  unsigned char* st = nullptr;
+  int slot = 0;
+  if ((rc = take_stage(f, total, &st, &slot))) return rc;
+  if (B > 0) memcpy(st, blobs, o_dir);
+  if (B > 0) PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_dir, hipMemcpyHostToDevice, f->stream));
+  if (ids) {
+    // landmark -> blob chains shared by all particles, in scan order (prkt_core_v2.py:88)
+    int32_t* first = reinterpret_cast<int32_t*>(st + o_first);
+    int32_t* next = reinterpret_cast<int32_t*>(st + o_next);
+    std::vector<int32_t> last((size_t)lay.Lp, -1);
+    for (int l = 0; l < lay.Lp; ++l) first[l] = -1;
+    int n0 = 0;
+    for (int b = 0; b < B; ++b) {
+      next[b] = -1;
+      int id = ids[b];
+      if (id == 0) {
+        ++n0;
+        continue;
+      }
+      if (first[id - 1] < 0)
+        first[id - 1] = b;
+      else
+        next[last[id - 1]] = b;
+      last[id - 1] = b;
+    }
+    PK_HIP(hipMemcpyAsync(f->first_dev, first, (size_t)lay.Lp * 4, hipMemcpyHostToDevice, f->stream));
+    if (B > 0) PK_HIP(hipMemcpyAsync(f->next_dev, next, (size_t)B * 4, hipMemcpyHostToDevice, f->stream));
+    PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+    {
+      Span t(f, PK_T_OBSERVE);
+      launch_observe(f->stream, f->d, f->blobs_dev, B, f->first_dev, f->next_dev, n0, nullptr, f->qt);
+    }
+    f->src_identity = true;
+    if (ids_out)
+      for (int64_t p = 0; p < f->d.P; ++p) memcpy(ids_out + (size_t)p * B, ids, (size_t)B * 4);
+    return PK_OK;
+  }
+  // maximum-likelihood association on the device
+  double* dir = reinterpret_cast<double*>(st + o_dir);
+  for (int b = 0; b < B; ++b) {
+    // unit((cos b, sin b, 0.0)), utils.py:68-76: scale by 1/length
+    double c = std::cos(blobs[4 * b]), s = std::sin(blobs[4 * b]);
+    double len = std::sqrt(c * c + s * s + 0.0 * 0.0);
+    dir[2 * b] = c * (1.0 / len);
+    dir[2 * b + 1] = s * (1.0 / len);
+  }
+  if ((rc = ensure_ids_capacity(f, B))) return rc;
+  if (B > 0) PK_HIP(hipMemcpyAsync(f->blobdir_dev, dir, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+  {
+    Span t(f, PK_T_ASSOC);
+    launch_assoc(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, f->ids_dev);
+  }
+  {
+    Span t(f, PK_T_OBSERVE);
+    launch_observe(f->stream, f->d, f->blobs_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt);
+  }
+  f->src_identity = true;
+  if (ids_out && B > 0) {
+    PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+  }
+  return PK_OK;
+}
+
+int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestors_out) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_resample: NULL handle");
+  if (!(u >= 0.0 && u < 1.0)) return fail(PK_ERR_INVALID, "pk_resample: u = %g outside [0,1)", u);
+  if (weight_domain != PK_WEIGHTS_LINEAR && weight_domain != PK_WEIGHTS_LOG)
+    return fail(PK_ERR_INVALID, "pk_resample: weight_domain %d", weight_domain);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  DeviceState& d = f->d;
+  {
+    Span t(f, PK_T_WEIGHTS);
+    if (weight_domain == PK_WEIGHTS_LOG) launch_block_max(f->stream, d, f->partial, f->gmax);
+    launch_scan_local(f->stream, d, f->gmax, weight_domain, f->clocal, f->totals);
+    launch_scan_blocks(f->stream, f->totals, f->nblocks, f->offsets, f->sum);
+    launch_ancestors(f->stream, f->clocal, f->totals, f->offsets, f->sum, f->nblocks, d.P, d.P, u, 0, d.P, f->anc);
+  }
+  {
+    Span t(f, PK_T_RESAMPLE);
+    launch_gather_poses(f->stream, d, f->anc);
+  }
+  f->src_identity = false;
+  if (ancestors_out) {
+    std::vector<int32_t> a((size_t)d.P);
+    PK_HIP(hipMemcpyAsync(a.data(), f->anc, (size_t)d.P * 4, hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+    for (int64_t i = 0; i < d.P; ++i) ancestors_out[i] = a[i];
+  }
+  return PK_OK;
+}
+
+int pk_summary(pk_filter* f, double out[3]) {
+  if (!f || !out) return fail(PK_ERR_INVALID, "pk_summary: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  {
+    Span t(f, PK_T_SUMMARY);
+    launch_summary_partials(f->stream, f->d, f->partial, f->out4);
+  }
+  double s[4];
+  PK_HIP(hipMemcpyAsync(s, f->out4, sizeof(s), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  const double n = (double)f->d.P;  // prkt_core_v2.py:262
+  out[0] = s[0] / n;                // :273
+  out[1] = s[1] / n;                // :274
+  out[2] = std::atan2(s[2], s[3]);  // :275
+  return PK_OK;
+}
+
+int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed, uint64_t draw,
+            const double* blobs, int32_t B, const int32_t* ids, double u, int32_t weight_domain) {
+  int rc;
+  if ((rc = pk_reset_weights(f))) return rc;                    // :73
+  if ((rc = pk_motion(f, v, w, dt, z, seed, draw))) return rc;  // :75-77
+  if ((rc = pk_observe(f, blobs, B, ids, nullptr))) return rc;  // :82-124
+  return pk_resample(f, u, weight_domain, nullptr);             // :137
+}
+
+// ---- sharded resampling ---------------------------------------
+int pk_shard_max_logw(pk_filter* f, double* max_logw) {
+  if (!f || !max_logw) return fail(PK_ERR_INVALID, "pk_shard_max_logw: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  launch_block_max(f->stream, f->d, f->partial, f->gmax);
+  PK_HIP(hipMemcpyAsync(max_logw, f->gmax, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+int64_t pk_shard_num_blocks(const pk_filter* f) { return f ? f->nblocks : -1; }
+
+int pk_shard_block_totals(pk_filter* f, double gmax, int32_t weight_domain, double* totals) {
+  if (!f || !totals) return fail(PK_ERR_INVALID, "pk_shard_block_totals: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipMemcpyAsync(f->gmax, &gmax, sizeof(double), hipMemcpyHostToDevice, f->stream));
+  launch_scan_local(f->stream, f->d, f->gmax, weight_domain, f->clocal, f->totals);
+  PK_HIP(hipMemcpyAsync(totals, f->totals, (size_t)f->nblocks * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+int pk_shard_offspring(pk_filter* f, const double*, int64_t, int64_t, int64_t, double, int64_t*, int64_t*) {
+  (void)f;
+  return fail(PK_ERR_UNSUPPORTED, "pk_shard_offspring: not implemented yet");
+}
+int64_t pk_particle_bytes(const pk_filter* f) { return f ? (int64_t)(f->d.lay.slot_bytes + 4 * sizeof(double)) : -1; }
+int pk_pack_particles(pk_filter* f, const int64_t*, int64_t, void*) {
+  (void)f;
+  return fail(PK_ERR_UNSUPPORTED, "pk_pack_particles: not implemented yet");
+}
+int pk_adopt_particles(pk_filter* f, const int64_t*, const void*, int64_t) {
+  (void)f;
+  return fail(PK_ERR_UNSUPPORTED, "pk_adopt_particles: not implemented yet");
+}
+
+// ---- probe ------------------------------------------------------------------------------
+int pk_probe(int32_t device, const double pose[3], const double mean[5], const double cov[25],
+             const double blob[4], const double Qt[16], double* out) {
+  if (!pose || !mean || !cov || !blob || !Qt || !out) return fail(PK_ERR_INVALID, "pk_probe: NULL argument");
+  int ndev = pk_device_count();
+  if (ndev <= 0) return fail(PK_ERR_HIP, "pk_probe: no HIP device visible (the HIP path has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(PK_ERR_INVALID, "pk_probe: device %d of %d", device, ndev);
+  int rc;
+  if ((rc = check_block_diagonal(cov, 0))) return rc;
+  PK_HIP(hipSetDevice(device));
+  double in[53];
+  memcpy(in, pose, 3 * 8);
+  memcpy(in + 3, mean, 5 * 8);
+  memcpy(in + 8, cov, 25 * 8);
+  memcpy(in + 33, blob, 4 * 8);
+  memcpy(in + 37, Qt, 16 * 8);
+  double* dev = nullptr;
+  PK_HIP(hipMalloc((void**)&dev, (53 + PK_PROBE_LEN) * sizeof(double)));
+  hipError_t e = hipMemcpy(dev, in, sizeof(in), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_probe(nullptr, dev, dev + 53);
+    e = hipMemcpy(out, dev + 53, PK_PROBE_LEN * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(PK_ERR_HIP, "pk_probe: %s", hipGetErrorString(e));
+  return PK_OK;
+}
+
+// ---- instrumentation ----------------------------------------------------------------------
+int pk_enable_timing(pk_filter* f, int32_t on) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_enable_timing: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = drain_timings(f))) return rc;
+  f->timing = on != 0;
+  return PK_OK;
+}
+int pk_reset_timings(pk_filter* f) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_reset_timings: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = drain_timings(f))) return rc;
+  for (int i = 0; i < PK_T_COUNT; ++i) {
+    f->ms[i] = 0;
+    f->launches[i] = 0;
+  }
+  return PK_OK;
+}
+int pk_timings(pk_filter* f, double ms[PK_T_COUNT], int64_t launches[PK_T_COUNT]) {
+  if (!f || !ms || !launches) return fail(PK_ERR_INVALID, "pk_timings: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = drain_timings(f))) return rc;
+  for (int i = 0; i < PK_T_COUNT; ++i) {
+    ms[i] = f->ms[i];
+    launches[i] = f->launches[i];
+  }
+  return PK_OK;
+}
+int pk_observe_bytes(const pk_filter* f, int32_t B, int64_t* algorithmic, int64_t* moved) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_observe_bytes: NULL handle");
+  const int64_t P = f->d.P, L = f->d.lay.L;
+  if (algorithmic) *algorithmic = P * L * 28 * (int64_t)sizeof(double);  // 14 read + 14 written
+  if (moved) *moved = P * (L * (28 * (int64_t)sizeof(double) + 8) + (int64_t)B * 32);
+  return PK_OK;
+}
+
+}  // extern "C"

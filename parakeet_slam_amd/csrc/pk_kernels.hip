@@ -1,0 +1,744 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update.
+//
+// The path is HBM-bound streaming over per-particle landmark maps with O(100) fp64
+// flops per 232 bytes, so the rules that matter are coalescing (landmark index fastest,
+// 16-byte loads of two adjacent landmarks), enough bytes in flight per CU, one pass over
+// the map per filter step, and deterministic wave-shuffle reductions.  No MFMA: the
+// algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
+#include "pk_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <climits>
+
+#include "pk_math.hpp"
+#include "pk_philox.hpp"
+
+namespace pk {
+
+constexpr int kWave = 64;
+constexpr int kObsThreads = 256;
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;  // identical in every lane; butterfly order is fixed => deterministic
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+// Sum over a workgroup of NW waves; result valid in every thread.  Fixed order.
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* lds /* >= NW doubles */) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double t = lds[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t += lds[i];
+  return t;
+}
+template <int NW>
+__device__ __forceinline__ double block_max(double v, double* lds) {
+  v = wave_max(v);
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double t = lds[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t = fmax(t, lds[i]);
+  return t;
+}
+
+// ------------------------------------------------------------------ K1 motion
+__global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* __restrict__ y,
+                                                double* __restrict__ h, int64_t P, double v, double w,
+                                                double dt, double sd, double sh,
+                                                const double* __restrict__ z, uint64_t seed,
+                                                uint64_t draw, int64_t goff) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  double z0, z1, z2;
+  if (z) {
+    z0 = z[3 * i];
+    z1 = z[3 * i + 1];
+    z2 = z[3 * i + 2];
+  } else {
+    uint64_t g = (uint64_t)(i + goff);
+    Philox4 a = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw,
+                              (uint32_t)(draw >> 32) & 0x7fffffffu, (uint32_t)seed, (uint32_t)(seed >> 32));
+    Philox4 b = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw,
+                              ((uint32_t)(draw >> 32) & 0x7fffffffu) | 0x80000000u, (uint32_t)seed,
+                              (uint32_t)(seed >> 32));
+    double u1 = u53(a.v[0], a.v[1]), u2 = u53(a.v[2], a.v[3]);
+    double u3 = u53(b.v[0], b.v[1]), u4 = u53(b.v[2], b.v[3]);
+    double r1 = sqrt(-2.0 * log(u1)), r2 = sqrt(-2.0 * log(u3));
+    double s1, c1, s2, c2;
+    sincos(Consts<double>::two_pi * u2, &s1, &c1);
+    sincos(Consts<double>::two_pi * u4, &s2, &c2);
+    z0 = r1 * c1;
+    z1 = r1 * s1;
+    z2 = r2 * c2;
+    (void)s2;
+  }
+  double xi = x[i], yi = y[i], hi = h[i];
+  // normal(0, s, 1) == 0 + s * gauss  (numpy legacy), prkt_core_v2.py:185,190,193
+  motion_model(xi, yi, hi, v, w, dt, 0.0 + sd * z0, 0.0 + sh * z1, 0.0 + sh * z2);
+  x[i] = xi;
+  y[i] = yi;
+  h[i] = hi;
+}
+
+void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt, const double* z_dev,
+                   uint64_t seed, uint64_t draw, int64_t global_offset) {
+  if (d.P == 0) return;
+  double sd = fabs(.05 * v) + fabs(.005 * w) + .0005;  // :185
+  double sh = fabs(.025 * w) + fabs(.005 * v) + .0005;  // :190,:193
+  int blocks = (int)((d.P + 255) / 256);
+  hipLaunchKernelGGL(k_motion, dim3(blocks), dim3(256), 0, s, d.x[d.cur], d.y[d.cur], d.h[d.cur], d.P, v, w,
+                     dt, sd, sh, z_dev, seed, draw, global_offset);
+}
+
+__global__ void k_fill(double* p, int64_t n, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+void launch_reset_weights(hipStream_t s, DeviceState& d) {
+  if (d.P == 0) return;
+  int blocks = (int)((d.P + 255) / 256);
+  hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, d.logw[d.cur], d.P, 0.0);
+}
+
+__global__ void k_iota(int32_t* p, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (int32_t)i;
+}
+void launch_iota(hipStream_t s, int32_t* p, int64_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+}
+
+// ------------------------------------------------------------------ landmark slot access
+struct SlotView {
+  const double* f;  // 14 rows of Lp
+  const int* cnt;
+};
+__device__ __forceinline__ Landmark<double> load_landmark(const double* f, const int* cnt, int Lp, int l) {
+  Landmark<double> m;
+  m.mx = f[F_MX * Lp + l];
+  m.my = f[F_MY * Lp + l];
+  m.mr = f[F_MR * Lp + l];
+  m.mg = f[F_MG * Lp + l];
+  m.mb = f[F_MB * Lp + l];
+  m.pxx = f[F_PXX * Lp + l];
+  m.pxy = f[F_PXY * Lp + l];
+  m.pyy = f[F_PYY * Lp + l];
+  m.crr = f[F_CRR * Lp + l];
+  m.crg = f[F_CRG * Lp + l];
+  m.crb = f[F_CRB * Lp + l];
+  m.cgg = f[F_CGG * Lp + l];
+  m.cgb = f[F_CGB * Lp + l];
+  m.cbb = f[F_CBB * Lp + l];
+  m.count = cnt[l];
+  return m;
+}
+
+// ------------------------------------------------------------------ K2 association
+// One workgroup per particle, lanes over landmarks, uniform loop over blobs (scalar
+// loads).  Two passes: (1) atomicMax of the probability per blob in LDS, (2) the lowest
+// landmark index that attains it -- the reference's strict '>' scan keeps the earliest
+// (prkt_core_v2.py:369-381).  Probability 0 never matches.
+struct AssocArgs {
+  const unsigned char* map;
+  size_t slot_bytes, count_off;
+  const int32_t* src;
+  const double *x, *y, *h;
+  const double* blobs;    // B x 4
+  const double* blobdir;  // B x 2 unit ray direction (closest_point :510)
+  int32_t* ids;           // P x B
+  int L, Lp, B;
+};
+
+__device__ __forceinline__ double match_probability_lazy(const double* f, const int* cnt, int Lp, int l,
+                                                         Landmark<double>& lm, bool& have_cov, double sx,
+                                                         double sy, double pse, const BlobT<double>& z,
+                                                         double ux, double uy) {
+  if (!have_cov) {
+    lm.pxx = f[F_PXX * Lp + l];
+    lm.pxy = f[F_PXY * Lp + l];
+    lm.pyy = f[F_PYY * Lp + l];
+    lm.crr = f[F_CRR * Lp + l];
+    lm.crg = f[F_CRG * Lp + l];
+    lm.crb = f[F_CRB * Lp + l];
+    lm.cgg = f[F_CGG * Lp + l];
+    lm.cgb = f[F_CGB * Lp + l];
+    lm.cbb = f[F_CBB * Lp + l];
+    have_cov = true;
+  }
+  double bp = 500.0 * prob_position_match(lm, sx, sy, pse, z.bearing, ux, uy);
+  double cp = 500.0 * prob_color_match(lm, z.r, z.g, z.b);
+  return bp * cp / 250000.0;
+}
+
+template <int PASS>
+__device__ __forceinline__ void assoc_pass(const AssocArgs& a, const double* f, const int* cnt, double sx,
+                                           double sy, double sh, unsigned long long* best, int* bid) {
+  for (int l = threadIdx.x; l < a.L; l += blockDim.x) {
+    Landmark<double> lm;
+    lm.mx = f[F_MX * a.Lp + l];
+    lm.my = f[F_MY * a.Lp + l];
+    lm.mr = f[F_MR * a.Lp + l];
+    lm.mg = f[F_MG * a.Lp + l];
+    lm.mb = f[F_MB * a.Lp + l];
+    bool have_cov = false;
+    double pse = atan2(lm.my - sy, lm.mx - sx);
+    double eb = pse - sh;  // :408
+    for (int b = 0; b < a.B; ++b) {
+      BlobT<double> z{a.blobs[4 * b], a.blobs[4 * b + 1], a.blobs[4 * b + 2], a.blobs[4 * b + 3]};
+      if (fabs(z.bearing - eb) > 0.5) continue;                                    // :433
+      if (fabs(color_distance2(lm.mr, lm.mg, lm.mb, z.r, z.g, z.b)) > 300.0) continue;  // :441
+      double pr = match_probability_lazy(f, cnt, a.Lp, l, lm, have_cov, sx, sy, pse, z, a.blobdir[2 * b],
+                                         a.blobdir[2 * b + 1]);
+      if (!(pr > 0.0)) continue;
+      unsigned long long bits = (unsigned long long)__double_as_longlong(pr);
+      if (PASS == 0) {
+        atomicMax(&best[b], bits);
+      } else if (bits == best[b]) {
+        atomicMin(&bid[b], l);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_assoc(AssocArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  int* bid = reinterpret_cast<int*>(best + a.B);
+  const int64_t p = blockIdx.x;
+  const unsigned char* slot = a.map + (size_t)a.src[p] * a.slot_bytes;
+  const double* f = reinterpret_cast<const double*>(slot);
+  const int* cnt = reinterpret_cast<const int*>(slot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+    best[b] = 0ull;
+    bid[b] = INT_MAX;
+  }
+  __syncthreads();
+  assoc_pass<0>(a, f, cnt, sx, sy, sh, best, bid);
+  __syncthreads();
+  assoc_pass<1>(a, f, cnt, sx, sy, sh, best, bid);
+  __syncthreads();
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x)
+    a.ids[(size_t)p * a.B + b] = best[b] != 0ull ? bid[b] + 1 : 0;
+}
+
+void launch_assoc(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
+                  int32_t* ids_dev) {
+  if (d.P == 0 || B == 0) return;
+  AssocArgs a;
+  a.map = d.map[d.mcur];
+  a.slot_bytes = d.lay.slot_bytes;
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.h = d.h[d.cur];
+  a.blobs = blobs_dev;
+  a.blobdir = blobdir_dev;
+  a.ids = ids_dev;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  size_t lds = (size_t)B * 12;
+  hipLaunchKernelGGL(k_assoc, dim3((unsigned)d.P), dim3(256), lds, s, a);
+}
+
+// ------------------------------------------------------------------ K3 observe (EKF + weight)
+struct ObserveArgs {
+  const unsigned char* map_src;
+  unsigned char* map_dst;
+  size_t slot_bytes, count_off;
+  int32_t* src;  // in: slot of particle p in map_src; out: identity
+  const double *x, *y;
+  double* logw;
+  const double* blobs;   // B x 4
+  const int32_t* first;  // KNOWN: [L] first blob matched to landmark l, or -1
+  const int32_t* next;   // KNOWN: [B] next blob matched to the same landmark, or -1
+  const int32_t* ids;    // ML: [P x B]
+  const unsigned char* immutable;
+  int n_unmatched;  // KNOWN: blobs with id 0
+  int L, Lp, B;
+  Noise<double> qt;
+};
+
+__device__ __forceinline__ double apply_blobs(Landmark<double>& lm, int l, double sx, double sy,
+                                              const ObserveArgs& a, const int32_t* first,
+                                              const int32_t* next) {
+  double acc = 0.0;
+  int b = first[l];
+  if (b < 0) return acc;
+  const bool imm = a.immutable[l] != 0;
+  while (b >= 0) {
+    const double2 z01 = *reinterpret_cast<const double2*>(a.blobs + 4 * (size_t)b);
+    const double2 z23 = *reinterpret_cast<const double2*>(a.blobs + 4 * (size_t)b + 2);
+    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+    acc += ekf_update(lm, sx, sy, z, a.qt, imm);
+    b = next[b];
+  }
+  return acc;
+}
+
+template <bool KNOWN>
+__global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kObsThreads / kWave];
+  const int64_t p = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int32_t sp = a.src[p];
+  const unsigned char* sslot = a.map_src + (size_t)sp * a.slot_bytes;
+  unsigned char* dslot = a.map_dst + (size_t)p * a.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p];
+  const int Lp = a.Lp;
+
+  const int32_t* first = a.first;
+  const int32_t* next = a.next;
+  int n_unmatched = a.n_unmatched;
+  if (!KNOWN) {
+    // Build the per-particle landmark -> blob chains in LDS from this particle's ids.
+    // Blobs are applied in scan order (prkt_core_v2.py:88): first[l] is the lowest blob
+    // index matched to l, next[b] the following blob matched to the same landmark.
+    int32_t* s_first = reinterpret_cast<int32_t*>(smem);
+    int32_t* s_next = s_first + Lp;
+    int32_t* s_ids = s_next + a.B;
+    const int32_t* gid = a.ids + (size_t)p * a.B;
+    for (int l = tid; l < Lp; l += blockDim.x) s_first[l] = INT_MAX;
+    for (int b = tid; b < a.B; b += blockDim.x) {
+      s_ids[b] = gid[b];
+      s_next[b] = -1;
+    }
+    __syncthreads();
+    int cnt0 = 0;
+    for (int b = tid; b < a.B; b += blockDim.x) {
+      int id = s_ids[b];
+      if (id > 0)
+        atomicMin(&s_first[id - 1], b);
+      else
+        ++cnt0;
+    }
+    __syncthreads();
+    for (int b = tid; b < a.B; b += blockDim.x) {
+      int id = s_ids[b];
+      if (id > 0 && s_first[id - 1] != b) {  // not the first sighting: link from my predecessor
+        int q = b - 1;
+        while (s_ids[q] != id) --q;  // terminates: first[id-1] < b has this id
+        s_next[q] = b;
+      }
+    }
+    for (int l = tid; l < Lp; l += blockDim.x)
+      if (s_first[l] == INT_MAX) s_first[l] = -1;
+    // number of unmatched blobs of this particle (weight *= 0.1 each, :94-95)
+    double c = block_sum<kObsThreads / kWave>((double)cnt0, red);
+    n_unmatched = (int)c;
+    __syncthreads();
+    first = s_first;
+    next = s_next;
+  }
+
+  double acc = 0.0;
+  for (int l0 = 2 * tid; l0 < Lp; l0 += 2 * kObsThreads) {
+    double2 v[F_COUNT_FIELDS];
+#pragma unroll
+    for (int f = 0; f < F_COUNT_FIELDS; ++f) v[f] = *reinterpret_cast<const double2*>(sf + (size_t)f * Lp + l0);
+    int2 c = *reinterpret_cast<const int2*>(sc + l0);
+    Landmark<double> A{v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x,
+                       v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, c.x};
+    Landmark<double> Bq{v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y,
+                        v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, c.y};
+    if (l0 < a.L) acc += apply_blobs(A, l0, sx, sy, a, first, next);
+    if (l0 + 1 < a.L) acc += apply_blobs(Bq, l0 + 1, sx, sy, a, first, next);
+    *reinterpret_cast<double2*>(df + (size_t)F_MX * Lp + l0) = make_double2(A.mx, Bq.mx);
+    *reinterpret_cast<double2*>(df + (size_t)F_MY * Lp + l0) = make_double2(A.my, Bq.my);
+    *reinterpret_cast<double2*>(df + (size_t)F_MR * Lp + l0) = make_double2(A.mr, Bq.mr);
+    *reinterpret_cast<double2*>(df + (size_t)F_MG * Lp + l0) = make_double2(A.mg, Bq.mg);
+    *reinterpret_cast<double2*>(df + (size_t)F_MB * Lp + l0) = make_double2(A.mb, Bq.mb);
+    *reinterpret_cast<double2*>(df + (size_t)F_PXX * Lp + l0) = make_double2(A.pxx, Bq.pxx);
+    *reinterpret_cast<double2*>(df + (size_t)F_PXY * Lp + l0) = make_double2(A.pxy, Bq.pxy);
+    *reinterpret_cast<double2*>(df + (size_t)F_PYY * Lp + l0) = make_double2(A.pyy, Bq.pyy);
+    *reinterpret_cast<double2*>(df + (size_t)F_CRR * Lp + l0) = make_double2(A.crr, Bq.crr);
+    *reinterpret_cast<double2*>(df + (size_t)F_CRG * Lp + l0) = make_double2(A.crg, Bq.crg);
+    *reinterpret_cast<double2*>(df + (size_t)F_CRB * Lp + l0) = make_double2(A.crb, Bq.crb);
+    *reinterpret_cast<double2*>(df + (size_t)F_CGG * Lp + l0) = make_double2(A.cgg, Bq.cgg);
+    *reinterpret_cast<double2*>(df + (size_t)F_CGB * Lp + l0) = make_double2(A.cgb, Bq.cgb);
+    *reinterpret_cast<double2*>(df + (size_t)F_CBB * Lp + l0) = make_double2(A.cbb, Bq.cbb);
+    *reinterpret_cast<int2*>(dc + l0) = make_int2(A.count, Bq.count);
+  }
+  double tot = block_sum<kObsThreads / kWave>(acc, red);
+  if (tid == 0) {
+    a.logw[p] += tot + (double)n_unmatched * Consts<double>::log_no_match;
+    a.src[p] = (int32_t)p;
+  }
+}
+
+void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, int B, const int32_t* first_dev,
+                    const int32_t* next_dev, int n_unmatched, const int32_t* ids_dev, const NoiseD& qt) {
+  if (d.P == 0) return;
+  ObserveArgs a;
+  a.map_src = d.map[d.mcur];
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.slot_bytes = d.lay.slot_bytes;
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.blobs = blobs_dev;
+  a.first = first_dev;
+  a.next = next_dev;
+  a.ids = ids_dev;
+  a.immutable = d.immutable;
+  a.n_unmatched = n_unmatched;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  if (ids_dev == nullptr) {
+    hipLaunchKernelGGL(k_observe<true>, dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
+  } else {
+    size_t lds = sizeof(int32_t) * ((size_t)d.lay.Lp + 2 * (size_t)B);
+    hipLaunchKernelGGL(k_observe<false>, dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
+  }
+  d.mcur ^= 1;
+}
+
+// ------------------------------------------------------------------ K4 weights
+__global__ void __launch_bounds__(256) k_block_max(const double* __restrict__ logw, int64_t P,
+                                                   double* __restrict__ partial) {
+  __shared__ double red[4];
+  double m = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmax(m, logw[i]);
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = m;
+}
+__global__ void __launch_bounds__(256) k_final_max(const double* __restrict__ partial, int n,
+                                                   double* __restrict__ out) {
+  __shared__ double red[4];
+  double m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, partial[i]);
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) out[0] = m;
+}
+constexpr int kRedBlocks = 1024;
+void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev) {
+  int nb = (int)((d.P + 255) / 256);
+  if (nb > kRedBlocks) nb = kRedBlocks;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_block_max, dim3(nb), dim3(256), 0, s, d.logw[d.cur], d.P, partial_dev);
+  hipLaunchKernelGGL(k_final_max, dim3(1), dim3(256), 0, s, partial_dev, nb, gmax_dev);
+}
+
+// Block-local inclusive scan of w = exp(logw - shift) over kScanBlock particles:
+// 4 consecutive particles per thread (sequential), Kogge-Stone over the wave with
+// __shfl_up, sequential over the 4 waves.  The association order is fixed by the block
+// size alone, so shards that are multiples of kScanBlock reproduce the 1-GPU bits.
+__global__ void __launch_bounds__(256) k_scan_local(const double* __restrict__ logw, int64_t P,
+                                                    const double* __restrict__ gmax, int domain,
+                                                    double* __restrict__ clocal, double* __restrict__ totals) {
+  __shared__ double wtot[4];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  double shift = 0.0;
+  if (domain == 1) {
+    shift = gmax[0];
+    if (!(shift > -INFINITY)) shift = 0.0;  // all weights zero: keep exp(-inf) = 0, not NaN
+  }
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * tid;
+  double w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (base + i < P) ? exp(logw[base + i] - shift) : 0.0;
+  double s0 = w[0], s1 = s0 + w[1], s2 = s1 + w[2], s3 = s2 + w[3];
+  double val = s3;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    double t = __shfl_up(val, off, kWave);
+    if (lane >= off) val += t;
+  }
+  if (lane == kWave - 1) wtot[wave] = val;
+  double prev = __shfl_up(val, 1, kWave);  // exclusive prefix inside the wave
+  if (lane == 0) prev = 0.0;
+  __syncthreads();
+  double woff = 0.0;
+  for (int i = 0; i < wave; ++i) woff += wtot[i];
+  const double excl = woff + prev;
+  if (base < P) clocal[base] = excl + s0;
+  if (base + 1 < P) clocal[base + 1] = excl + s1;
+  if (base + 2 < P) clocal[base + 2] = excl + s2;
+  if (base + 3 < P) clocal[base + 3] = excl + s3;
+  if (tid == 255) totals[blockIdx.x] = woff + val;
+}
+void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, int domain, double* clocal_dev,
+                       double* totals_dev) {
+  if (d.P == 0) return;
+  int nb = (int)((d.P + kScanBlock - 1) / kScanBlock);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, d.logw[d.cur], d.P, gmax_dev, domain,
+                     clocal_dev, totals_dev);
+}
+
+// Exclusive scan of the block totals in block order by ONE thread: the canonical
+// (shard-count independent) association of the global prefix sum.
+__global__ void __launch_bounds__(256) k_scan_blocks(const double* __restrict__ totals, int64_t nb,
+                                                     double* __restrict__ offsets, double* __restrict__ sum) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* t = reinterpret_cast<double*>(smem);
+  double run = 0.0;
+  for (int64_t c0 = 0; c0 < nb; c0 += 2048) {
+    int n = (int)((nb - c0 < 2048) ? (nb - c0) : 2048);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = totals[c0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < n; ++i) {
+        double v = t[i];
+        t[i] = run;
+        run += v;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) offsets[c0 + i] = t[i];
+  }
+  if (threadIdx.x == 0) sum[0] = run;
+}
+void launch_scan_blocks(hipStream_t s, const double* totals_dev, int64_t nb, double* offsets_dev,
+                        double* sum_dev) {
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 2048 * sizeof(double), s, totals_dev, nb, offsets_dev,
+                     sum_dev);
+}
+
+// Ancestor of output slot k: first particle j whose inclusive cumulative weight C_j is
+// >= u*r + k*r, r = sum/P  (equivalent to the walk at prkt_core_v2.py:233-250, '<=' at :239).
+__global__ void __launch_bounds__(256) k_ancestors(const double* __restrict__ clocal,
+                                                   const double* __restrict__ totals,
+                                                   const double* __restrict__ offsets,
+                                                   const double* __restrict__ sum, int64_t nb, int64_t Pg,
+                                                   int64_t Pscan, double u, int64_t slot0, int64_t n,
+                                                   int32_t* __restrict__ anc) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double r = __ddiv_rn(sum[0], (double)Pg);                  // range_ :225
+  const double t = __dadd_rn(__dmul_rn(u, r), __dmul_rn((double)(slot0 + k), r));  // step :226 + k*range_
+  // block: first b with offsets[b] + totals[b] >= t
+  int64_t lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (__dadd_rn(offsets[mid], totals[mid]) >= t)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  const int64_t b = lo;
+  const double off = offsets[b];
+  int64_t j0 = b * kScanBlock, j1 = j0 + kScanBlock - 1;
+  if (j1 > Pscan - 1) j1 = Pscan - 1;
+  while (j0 < j1) {
+    int64_t mid = (j0 + j1) >> 1;
+    if (__dadd_rn(off, clocal[mid]) >= t)
+      j1 = mid;
+    else
+      j0 = mid + 1;
+  }
+  anc[k] = (int32_t)j0;
+}
+void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* totals_dev,
+                      const double* offsets_dev, const double* sum_dev, int64_t nb, int64_t P_global,
+                      int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_ancestors, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clocal_dev, totals_dev,
+                     offsets_dev, sum_dev, nb, P_global, P_scan, u, slot0, n, anc_dev);
+}
+
+// ------------------------------------------------------------------ K5 gather
+__global__ void __launch_bounds__(256) k_gather_poses(const double* __restrict__ x, const double* __restrict__ y,
+                                                      const double* __restrict__ h,
+                                                      const double* __restrict__ lw,
+                                                      const int32_t* __restrict__ src, double* __restrict__ x2,
+                                                      double* __restrict__ y2, double* __restrict__ h2,
+                                                      double* __restrict__ lw2, int32_t* __restrict__ src2,
+                                                      const int32_t* __restrict__ anc, int64_t P) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  int32_t a = anc[k];
+  x2[k] = x[a];
+  y2[k] = y[a];
+  h2[k] = h[a];
+  lw2[k] = lw[a];  // weights are NOT reset by the resample (:252)
+  src2[k] = src[a];
+}
+void launch_gather_poses(hipStream_t s, DeviceState& d, const int32_t* anc_dev) {
+  if (d.P == 0) return;
+  int c = d.cur, n = c ^ 1;
+  hipLaunchKernelGGL(k_gather_poses, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
+                     d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], anc_dev, d.P);
+  d.cur = n;
+}
+
+// ------------------------------------------------------------------ K6 summary
+__global__ void __launch_bounds__(256) k_summary_partials(const double* __restrict__ x,
+                                                          const double* __restrict__ y,
+                                                          const double* __restrict__ h, int64_t P,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[4];
+  double sx = 0, sy = 0, ss = 0, sc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    sx += x[i];
+    sy += y[i];
+    double s, c;
+    sincos(h[i], &s, &c);
+    ss += s;
+    sc += c;
+  }
+  sx = block_sum<4>(sx, red);
+  sy = block_sum<4>(sy, red);
+  ss = block_sum<4>(ss, red);
+  sc = block_sum<4>(sc, red);
+  if (threadIdx.x == 0) {
+    partial[4 * blockIdx.x + 0] = sx;
+    partial[4 * blockIdx.x + 1] = sy;
+    partial[4 * blockIdx.x + 2] = ss;
+    partial[4 * blockIdx.x + 3] = sc;
+  }
+}
+__global__ void __launch_bounds__(256) k_summary_final(const double* __restrict__ partial, int n,
+                                                       double* __restrict__ out4) {
+  __shared__ double red[4];
+  double v[4] = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    for (int c = 0; c < 4; ++c) v[c] += partial[4 * i + c];
+  for (int c = 0; c < 4; ++c) {
+    double t = block_sum<4>(v[c], red);
+    if (threadIdx.x == 0) out4[c] = t;
+  }
+}
+void launch_summary_partials(hipStream_t s, DeviceState& d, double* partial_dev, double* out4_dev) {
+  int nb = (int)((d.P + 255) / 256);
+  if (nb > kRedBlocks) nb = kRedBlocks;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_summary_partials, dim3(nb), dim3(256), 0, s, d.x[d.cur], d.y[d.cur], d.h[d.cur], d.P,
+                     partial_dev);
+  hipLaunchKernelGGL(k_summary_final, dim3(1), dim3(256), 0, s, partial_dev, nb, out4_dev);
+}
+
+// ------------------------------------------------------------------ map maintenance
+// dst slot p <- src slot src[p]; then src <- identity.  Streaming 16-byte copy.
+__global__ void __launch_bounds__(256) k_copy_slots(const unsigned char* __restrict__ msrc,
+                                                    unsigned char* __restrict__ mdst, size_t slot_bytes,
+                                                    int32_t* __restrict__ src, int fixed_src) {
+  const int64_t p = blockIdx.x;
+  const int64_t sp = fixed_src ? 0 : src[p];
+  const uint4* s = reinterpret_cast<const uint4*>(msrc + (size_t)sp * slot_bytes);
+  uint4* d = reinterpret_cast<uint4*>(mdst + (size_t)p * slot_bytes);
+  const size_t n = slot_bytes / 16;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  if (!fixed_src) {
+    __syncthreads();
+    if (threadIdx.x == 0) src[p] = (int32_t)p;
+  }
+}
+void launch_materialise(hipStream_t s, DeviceState& d) {
+  if (d.P == 0) return;
+  hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)d.P), dim3(256), 0, s, d.map[d.mcur], d.map[d.mcur ^ 1],
+                     d.lay.slot_bytes, d.src[d.cur], 0);
+  d.mcur ^= 1;
+}
+void launch_broadcast_slot(hipStream_t s, DeviceState& d, const unsigned char* slot_dev) {
+  if (d.P == 0) return;
+  hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)d.P), dim3(256), 0, s, slot_dev, d.map[d.mcur],
+                     d.lay.slot_bytes, d.src[d.cur], 1);
+  launch_iota(s, d.src[d.cur], d.P);
+}
+
+// ------------------------------------------------------------------ probe
+// in: pose[3] mean[5] cov[25] blob[4] Qt[16] (53 doubles); out: PK_PROBE_LEN doubles.
+__global__ void k_probe(const double* __restrict__ in, double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double sx = in[0], sy = in[1], sh = in[2];
+  const double* mean = in + 3;
+  const double* cov = in + 8;
+  const double* blob = in + 33;
+  const double* Qt = in + 37;
+  Landmark<double> f{mean[0], mean[1], mean[2], mean[3], mean[4], cov[0], cov[1], cov[6],
+                     cov[12], cov[13], cov[14], cov[18], cov[19], cov[24], 0};
+  BlobT<double> z{blob[0], blob[1], blob[2], blob[3]};
+  Noise<double> qt{Qt[0], Qt[5], Qt[6], Qt[7], Qt[10], Qt[11], Qt[15]};
+  // unit((cos b, sin b, 0)) utils.py:68-76
+  double sb, cb;
+  sincos(z.bearing, &sb, &cb);
+  double len = sqrt(cb * cb + sb * sb + 0.0);
+  double ux = cb * (1.0 / len), uy = sb * (1.0 / len);
+  for (int i = 0; i < 79; ++i) out[i] = 0.0;
+  out[0] = probability_of_match(f, sx, sy, sh, z, ux, uy);
+  double pse = atan2(f.my - sy, f.mx - sx);
+  out[1] = prob_position_match(f, sx, sy, pse, z.bearing, ux, uy, out + 2);
+  out[4] = prob_color_match(f, z.r, z.g, z.b);
+  EkfAux<double> aux;
+  Landmark<double> g = f;
+  double lw = ekf_update(g, sx, sy, z, qt, false, &aux);
+  out[5] = aux.zhat0;
+  out[6] = f.mr;
+  out[7] = f.mg;
+  out[8] = f.mb;
+  out[9] = aux.h0;
+  out[10] = aux.h1;
+  double* Q = out + 11;
+  Q[0] = aux.q00;
+  Q[5] = aux.qc.a;
+  Q[6] = aux.qc.b;
+  Q[7] = aux.qc.c;
+  Q[9] = aux.qc.b;
+  Q[10] = aux.qc.d;
+  Q[11] = aux.qc.e;
+  Q[13] = aux.qc.c;
+  Q[14] = aux.qc.e;
+  Q[15] = aux.qc.f;
+  double* K = out + 27;  // 5x4 row-major
+  K[0] = aux.k0;
+  K[4] = aux.k1;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) K[(2 + i) * 4 + 1 + j] = aux.kc[i * 3 + j];
+  out[47] = exp(lw);
+  out[48] = g.mx;
+  out[49] = g.my;
+  out[50] = g.mr;
+  out[51] = g.mg;
+  out[52] = g.mb;
+  double* S = out + 53;
+  S[0] = g.pxx;
+  S[1] = g.pxy;
+  S[5] = g.pxy;
+  S[6] = g.pyy;
+  S[12] = g.crr;
+  S[13] = g.crg;
+  S[14] = g.crb;
+  S[17] = g.crg;
+  S[18] = g.cgg;
+  S[19] = g.cgb;
+  S[22] = g.crb;
+  S[23] = g.cgb;
+  S[24] = g.cbb;
+  out[78] = lw;
+}
+void launch_probe(hipStream_t s, const double* in_dev, double* out_dev) {
+  hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, s, in_dev, out_dev);
+}
+
+}  // namespace pk

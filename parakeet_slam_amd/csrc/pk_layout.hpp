@@ -1,0 +1,42 @@
+// HBM layout of the particle state.
+//
+// Poses are struct-of-arrays over particles: x[P], y[P], h[P], logw[P] plus the map
+// indirection src[P] (which map slot a particle's landmarks currently live in).
+//
+// Maps: one contiguous *slot* per particle,
+//     slot = [ 14 fields ][ Lp ] of T   followed by   [ Lp ] of int32 update counts
+// with the landmark index fastest, so that a workgroup that owns one particle streams
+// 14 perfectly coalesced rows.  Lp = L rounded up to even (16-byte vector loads of two
+// adjacent landmarks); slot_bytes is rounded up to 256 B.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace pk {
+
+enum Field : int {
+  F_MX = 0, F_MY, F_MR, F_MG, F_MB,
+  F_PXX, F_PXY, F_PYY,
+  F_CRR, F_CRG, F_CRB, F_CGG, F_CGB, F_CBB,
+  F_COUNT_FIELDS = 14
+};
+
+struct MapLayout {
+  int L;              // landmarks per particle
+  int Lp;             // padded to even
+  size_t slot_bytes;  // multiple of 256
+  size_t count_off;   // byte offset of the int32 counts inside a slot
+
+  static MapLayout make(int L, size_t scalar) {
+    MapLayout m;
+    m.L = L;
+    m.Lp = (L + 1) & ~1;
+    if (m.Lp == 0) m.Lp = 2;
+    m.count_off = (size_t)F_COUNT_FIELDS * m.Lp * scalar;
+    size_t raw = m.count_off + (size_t)m.Lp * sizeof(int32_t);
+    m.slot_bytes = (raw + 255) & ~(size_t)255;
+    return m;
+  }
+};
+
+}  // namespace pk
