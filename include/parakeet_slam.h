@@ -187,10 +187,10 @@ int pk_probe(int32_t device, const double pose[3], const double mean[5], const d
              const double blob[4], const double Qt[16], double* out);
 
 /* ---- instrumentation ----------------------------------------------------------
- * With timing enabled every kernel launch is bracketed by hipEvents on the handle's
- * stream.  pk_timings synchronises, then returns accumulated milliseconds and launch
+ * Kernel launches of the enabled PK_T_* slots are bracketed by hipEvents on the handle's
+ * stream: `mask` bit i enables slot i, a negative mask enables all, 0 disables.  pk_timings synchronises, then returns accumulated milliseconds and launch
  * counts per PK_T_* slot since the last pk_reset_timings. */
-int pk_enable_timing(pk_filter* f, int32_t on);
+int pk_enable_timing(pk_filter* f, int32_t mask);
 int pk_reset_timings(pk_filter* f);
 int pk_timings(pk_filter* f, double ms[PK_T_COUNT], int64_t launches[PK_T_COUNT]);
 /* Algorithmic HBM bytes of one observe launch (14 scalars read + 14 written per

@@ -238,8 +238,10 @@ class DeviceFilter(object):
                                 iptr(i), float(u), int(domain)))
 
     # -- instrumentation -----------------------------------------------------
-    def enable_timing(self, on=True):
-        check(self._lib.pk_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, mask=True):
+        """mask: True = every kernel slot, False/0 = off, int = bitmask over PK_T_NAMES."""
+        m = -1 if mask is True else (0 if mask is False else int(mask))
+        check(self._lib.pk_enable_timing(self._h, m))
 
     def reset_timings(self):
         check(self._lib.pk_reset_timings(self._h))

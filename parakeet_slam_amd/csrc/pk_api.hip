@@ -86,7 +86,7 @@ struct pk_filter {
   int32_t* anc = nullptr;           // P
   unsigned char* slot_tmp = nullptr;  // one slot
   // timing
-  bool timing = false;
+  uint32_t timing_mask = 0;  // bit i: PK_T_* slot i is bracketed by hipEvents
   std::vector<TimedSpan> pending;
   std::vector<hipEvent_t> pool;
   double ms[PK_T_COUNT] = {0};
@@ -113,7 +113,7 @@ struct Span {
   int slot;
   hipEvent_t a = nullptr, b = nullptr;
   Span(pk_filter* f_, int slot_) : f(f_), slot(slot_) {
-    if (!f->timing) return;
+    if (!((f->timing_mask >> slot_) & 1u)) return;
     a = take();
     b = take();
     if (a) (void)hipEventRecord(a, f->stream);
@@ -129,7 +129,7 @@ struct Span {
     return e;
   }
   ~Span() {
-    if (!f->timing || !a || !b) return;
+    if (!a || !b) return;
     (void)hipEventRecord(b, f->stream);
     f->pending.push_back(TimedSpan{slot, a, b});
   }
@@ -816,7 +816,7 @@ int pk_enable_timing(pk_filter* f, int32_t on) {
   int rc;
   if ((rc = use_device(f))) return rc;
   if ((rc = drain_timings(f))) return rc;
-  f->timing = on != 0;
+  f->timing_mask = on < 0 ? 0xffffffffu : (uint32_t)on;
   return PK_OK;
 }
 int pk_reset_timings(pk_filter* f) {
