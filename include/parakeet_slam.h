@@ -136,6 +136,11 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
 int pk_observe(pk_filter* f, const double* blobs, int32_t num_blobs, const int32_t* ids,
                int32_t* ids_out);
 
+/* Data association alone (FilterParticle.match_features_to_scan, prkt_core_v2.py:317-351):
+ * ids_out[P*B] receives, per particle, the landmark id each blob matches (0 = none).
+ * No state changes. */
+int pk_associate(pk_filter* f, const double* blobs, int32_t num_blobs, int32_t* ids_out);
+
 /* FastSLAM.low_variance_resample (prkt_core_v2.py:210-252) with step = u * sum/P, u in
  * [0,1) standing for random.random() (:226).  ancestors_out: NULL or P int64. */
 int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestors_out);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pk_reset_weights": (C.c_int, [_h]),
     "pk_motion": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64]),
     "pk_observe": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
+    "pk_associate": (C.c_int, [_h, _dp, C.c_int32, _ip]),
     "pk_resample": (C.c_int, [_h, C.c_double, C.c_int32, _lp]),
     "pk_summary": (C.c_int, [_h, _dp]),
     "pk_step": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64, _dp, C.c_int32,
@@ -217,6 +218,12 @@ class DeviceFilter(object):
         i = np.ascontiguousarray(ids, dtype=np.int32).reshape(B) if ids is not None else None
         out = np.empty((self.P, B), dtype=np.int32) if return_ids else None
         check(self._lib.pk_observe(self._h, dptr(b), B, iptr(i), iptr(out)))
+        return out
+
+    def associate(self, blobs):
+        b = f64(blobs).reshape(-1, 4)
+        out = np.zeros((self.P, b.shape[0]), dtype=np.int32)
+        check(self._lib.pk_associate(self._h, dptr(b), b.shape[0], iptr(out)))
         return out
 
     def resample(self, u, domain=PK_WEIGHTS_LINEAR, return_ancestors=False):

@@ -1,0 +1,527 @@
+"""FastSLAM / FilterParticle / Feature: the reference's class surface over the HIP library.
+
+This mirrors ``/root/reference/src/prkt_core_v2.py`` name for name (same constructor
+arguments, attributes, method names, argument meaning and error behaviour) so that its
+only caller, ``prkt_ros.py`` (left untouched), can ``from parakeet_slam_amd import
+FastSLAM, Feature`` instead of ``from prkt_core_v2 import ...`` -- see INTEGRATION.md.
+
+What is different on purpose:
+  * all per-particle state lives in HBM behind one ``pk_filter`` handle; ``particles`` is
+    a list-like of lazily materialised ``FilterParticle`` snapshots;
+  * ``num_particles`` is a constructor keyword (the reference hard-codes 50, :41);
+  * one lock serialises ``cam_cb`` / ``motion_update`` / ``summary`` (the reference races
+    between the rospy callback thread and the main loop);
+  * the particle update itself (motion sample, data association, EKF, weights, resample,
+    summary) runs ONLY on the GPU.  There is no CPU fallback: without the shared library
+    or without a HIP device, construction raises.
+"""
+from __future__ import annotations
+
+import copy as _copy
+import math
+import random as _pyrandom
+import threading
+
+import numpy as np
+
+from . import _lib, msgs
+from .msgs import Blob, Odometry, Twist, heading_to_quaternion, quaternion_to_heading
+
+NO_MATCH_WEIGHT = 0.1  # prkt_core_v2.py:851-857
+
+
+def _default_Qt():
+    # prkt_core_v2.py:50-53
+    return np.array([[.1, 0, 0, 0], [0, .1, 0, 0], [0, 0, .1, 0], [0, 0, 0, .1]])
+
+
+def _blob_row(blob):
+    """matrix.blob_to_matrix (matrix.py:35-39)."""
+    if isinstance(blob, (np.ndarray, list, tuple)):
+        return np.asarray(blob, dtype=np.float64).reshape(4)
+    return np.array([blob.bearing, blob.color.r, blob.color.g, blob.color.b], dtype=np.float64)
+
+
+def _state_pose(state):
+    return (float(state.pose.pose.position.x), float(state.pose.pose.position.y),
+            float(quaternion_to_heading(state.pose.pose.orientation)))
+
+
+def _make_state(x, y, h):
+    st = Odometry()
+    st.pose.pose.position.x = float(x)
+    st.pose.pose.position.y = float(y)
+    st.pose.pose.orientation = heading_to_quaternion(float(h))
+    return st
+
+
+# =============================================================================
+class Feature(object):
+    """prkt_core_v2.py:881-930.  A landmark EKF: mean (x, y, r, g, b), covar 5x5."""
+
+    def __init__(self, mean=None, covar=None):
+        self.__immutable__ = False
+        if mean is None:
+            mean = np.array([0, 0, 0, 0, 0])
+        if covar is None:
+            covar = np.identity(5, dtype=np.int64)
+        self.mean = np.array(mean)
+        self.covar = np.array(covar)
+        self.identity = np.identity(self.covar.shape[0])
+        self.update_count = 0
+
+    # The two methods below are the reference's object-level API (:897-930) for a caller
+    # that already holds K and H as matrices.  cam_cb never calls them: inside the filter
+    # the same update runs fused in the HIP kernel k_observe.  They are two NumPy products,
+    # exactly as matrix.py defines them, kept so scripts that poke a lone Feature still run.
+    def update_mean(self, kalman_gain, measure, expected_measure):
+        if self.__immutable__:
+            return None
+        delz = _blob_row(measure) - _blob_row(expected_measure)
+        self.mean = self.mean + np.dot(kalman_gain, delz)
+        self.update_count += 1
+
+    def update_covar(self, kalman_gain, bigH):
+        if self.__immutable__:
+            return None
+        adjust = np.subtract(self.identity, np.dot(kalman_gain, bigH))
+        self.covar = np.dot(adjust, self.covar)
+        self.update_count += 1
+
+
+# =============================================================================
+class _FeatureSet(dict):
+    """feature_set of a particle that lives on the GPU: downloaded on first touch."""
+
+    def __init__(self, loader):
+        super().__init__()
+        self._loader = loader
+
+    def _load(self):
+        if self._loader is not None:
+            ld, self._loader = self._loader, None
+            for k, v in ld().items():
+                dict.__setitem__(self, k, v)
+
+    def __getitem__(self, k):
+        self._load()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._load()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._load()
+        return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._load()
+        return dict.__contains__(self, k)
+
+    def keys(self):
+        self._load()
+        return dict.keys(self)
+
+    def values(self):
+        self._load()
+        return dict.values(self)
+
+    def items(self):
+        self._load()
+        return dict.items(self)
+
+    def get(self, k, default=None):
+        self._load()
+        return dict.get(self, k, default)
+
+    def __deepcopy__(self, memo):
+        self._load()
+        out = {}
+        for k, v in dict.items(self):
+            out[k] = _copy.deepcopy(v, memo)
+        return out
+
+
+class FilterParticle(object):
+    """prkt_core_v2.py:278-877.  A robot pose hypothesis with its own landmark map.
+
+    A standalone instance is a host object; its scalar methods evaluate the device
+    functions of the HIP path on the GPU through ``pk_probe`` / a one-particle filter.
+    ``FastSLAM.particles[i]`` yields snapshots of the particles that live in HBM.
+    """
+
+    Qt = _default_Qt()
+    _device = 0
+
+    def __init__(self, state=None):
+        if state is None:
+            state = _make_state(0.0, 0.0, 0.0)
+        self.state = state
+        self.feature_set = {}
+        self.potential_features = {}
+        self.weight = 1
+        self.hypothesis_set = {}
+        self.next_id = 1
+
+    # -- bookkeeping (:294-315) ----------------------------------------------
+    def load_feature_list(self, features):
+        for feature in features:
+            self.feature_set[self.next_id] = feature
+            self.next_id += 1
+
+    def get_feature_by_id(self, id_):
+        if id_ < 0:
+            return self.potential_features[int(id_)]
+        return self.feature_set[id_]
+
+    # -- device evaluation helpers ---------------------------------------------
+    def _probe(self, pose, mean, cov, blob, Qt=None):
+        return _lib.probe(pose, np.asarray(mean, dtype=np.float64), np.asarray(cov, dtype=np.float64), blob,
+                          self.Qt if Qt is None else Qt, device=self._device)
+
+    def _one_particle_filter(self, state):
+        if len(self.potential_features):
+            raise NotImplementedError(
+                "potential (negative-id) features are outside the device path: the reference never "
+                "creates one (SURVEY.md section 2, row 1b)")
+        ids = sorted(self.feature_set.keys())
+        f = _lib.DeviceFilter(1, len(ids), device=self._device)
+        if ids:
+            means = np.array([np.asarray(self.feature_set[i].mean, dtype=np.float64) for i in ids])
+            covs = np.array([np.asarray(self.feature_set[i].covar, dtype=np.float64) for i in ids])
+            imm = np.array([bool(self.feature_set[i].__immutable__) for i in ids], dtype=np.uint8)
+            f.upload_map(means, covs.reshape(len(ids), 25), imm)
+        x, y, h = _state_pose(state)
+        f.upload_poses(np.array([[x, y, h, 1.0]]))
+        return f, ids
+
+    # -- a3: association (:317-381) ----------------------------------------------
+    def match_features_to_scan(self, scan):
+        blobs = list(scan.observes)
+        if not blobs:
+            return []
+        f, ids = self._one_particle_filter(self.state)
+        try:
+            got = f.associate(np.array([_blob_row(b) for b in blobs]))[0]
+        finally:
+            f.close()
+        return [((ids[g - 1] if g > 0 else 0), b) for g, b in zip(got, blobs)]
+
+    def match_one(self, state, blob):
+        f, ids = self._one_particle_filter(state)
+        try:
+            g = int(f.associate(_blob_row(blob)[None, :])[0, 0])
+        finally:
+            f.close()
+        return ids[g - 1] if g > 0 else 0
+
+    # -- a4..a6 (:383-544) ---------------------------------------------------------
+    def probability_of_match(self, state, blob, feature):
+        r = self._probe(_state_pose(state), feature.mean, feature.covar, _blob_row(blob))
+        return float(r["probability_of_match"])
+
+    def prob_position_match(self, f_mean, f_covar, s_x, s_y, bearing):
+        cov = np.identity(5)
+        cov[:2, :2] = np.asarray(f_covar, dtype=np.float64)[0:2, 0:2]
+        mean = np.zeros(5)
+        mean[:2] = np.asarray(f_mean, dtype=np.float64)[:2]
+        r = self._probe((float(s_x), float(s_y), 0.0), mean, cov, (float(bearing), 0.0, 0.0, 0.0))
+        return float(r["prob_position_match"])
+
+    def closest_point(self, f_x, f_y, s_x, s_y, obs_bearing):
+        r = self._probe((float(s_x), float(s_y), 0.0), (float(f_x), float(f_y), 0, 0, 0), np.identity(5),
+                        (float(obs_bearing), 0.0, 0.0, 0.0))
+        return (float(r["closest_point"][0]), float(r["closest_point"][1]))
+
+    def prob_color_match(self, f_mean, f_covar, blob):
+        cov = np.identity(5)
+        cov[2:, 2:] = np.asarray(f_covar, dtype=np.float64)[2:, 2:]
+        z = _blob_row(blob)
+        r = self._probe((0.0, 0.0, 0.0), np.asarray(f_mean, dtype=np.float64), cov, z)
+        return float(r["prob_color_match"])
+
+    # -- a7..a11 (:748-877) ----------------------------------------------------------
+    def _probe_feature(self, feature_id, blob=None, Qt=None):
+        f = self.get_feature_by_id(feature_id)
+        z = _blob_row(blob) if blob is not None else np.array([0.0, f.mean[2], f.mean[3], f.mean[4]], dtype=np.float64)
+        return self._probe(_state_pose(self.state), f.mean, f.covar, z, Qt)
+
+    def generate_measurement(self, featureid):
+        r = self._probe_feature(featureid)
+        f = self.get_feature_by_id(featureid)
+        bobby = Blob()
+        bobby.bearing = float(r["zhat"][0])
+        bobby.color.r = f.mean[2]
+        bobby.color.g = f.mean[3]
+        bobby.color.b = f.mean[4]
+        return bobby
+
+    def measurement_jacobian(self, feature_id):
+        r = self._probe_feature(feature_id)
+        H = np.zeros((4, 5))
+        H[0, 0], H[0, 1] = r["H0"]
+        H[1, 2] = H[2, 3] = H[3, 4] = 1.0
+        return H
+
+    def measurement_covariance(self, bigH, feature_id, Qt):
+        """Q = H Sigma H' + Qt (:804-819).  H is re-derived on the device from the particle
+        state, which is what ``measurement_jacobian`` returned."""
+        return self._probe_feature(feature_id, Qt=Qt)["Q"]
+
+    def kalman_gain(self, feature_id, bigH, Qinv):
+        """K = Sigma H' Q^-1 (:821-833); Qt is recovered from the caller's Q^-1."""
+        Q0 = self._probe_feature(feature_id, Qt=np.zeros((4, 4)))["Q"]
+        Qt = np.linalg.inv(np.asarray(Qinv, dtype=np.float64)) - Q0
+        Qt = 0.5 * (Qt + Qt.T)
+        Qt[0, 1:] = 0.0
+        Qt[1:, 0] = 0.0
+        return self._probe_feature(feature_id, Qt=Qt)["K"]
+
+    def importance_factor(self, bigQ, blob, pseudoblob):
+        """(2 pi ||Q||_F)^-1/2 exp(-1/2 d' Q^-1 d) (:835-849) for caller-supplied matrices.
+        Inside the filter this factor is computed by k_observe; this scalar helper exists
+        for scripts that call it directly and is a few NumPy flops, as in the reference."""
+        v1 = pow(2.0 * math.pi * np.linalg.norm(bigQ), -0.5)
+        delz = _blob_row(blob) - _blob_row(pseudoblob)
+        return v1 * math.exp(-0.5 * np.dot(np.dot(delz.T, np.linalg.inv(bigQ)), delz))
+
+    def no_match_weight(self):
+        return NO_MATCH_WEIGHT
+
+    # -- new-landmark machinery (:546-746): out of scope, dead in the reference ----------
+    def add_orphaned_reading(self, state, blob):
+        self.hypothesis_set[self.next_id] = ((state, blob,))
+        self.next_id += 1
+
+    def add_hypothesis(self, state, blob):
+        # find_nearest_reading only ever returns ids <= 0 (:576-590), so the reference always
+        # ends here
+        self.add_orphaned_reading(state, blob)
+
+
+# =============================================================================
+class _ParticleList(list):
+    """``FastSLAM.particles``: list-like view of the particles held in HBM."""
+
+    def __init__(self, owner):
+        super().__init__()
+        self._o = owner
+
+    def __len__(self):
+        return self._o.num_particles
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self._o._particle_view(i)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._o._particle_view(j) for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("particle index out of range")
+        return self._o._particle_view(i)
+
+    def __setitem__(self, i, particle):
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("particle index out of range")
+        self._o._store_particle(i, particle)
+
+    def __repr__(self):
+        return "<%d particles on GPU %d>" % (len(self), self._o._device)
+
+
+class FastSLAM(object):
+    """prkt_core_v2.py:37-276 on an MI355X.
+
+    FastSLAM(preset_features=[], num_particles=50, device=0, weight_domain="linear",
+             rng="global", seed=0, publish_debug=None)
+
+    rng="global": motion noise from ``numpy.random`` and the resample draw from
+    ``random.random()`` -- the reference's own streams, so ``np.random.seed(s);
+    random.seed(s)`` reproduces the reference bit for bit in the draws;
+    rng="device": Philox noise generated on the GPU (no host->device upload).
+    """
+
+    def __init__(self, preset_features=[], num_particles=50, device=0, weight_domain="linear", rng="global",
+                 seed=0, publish_debug=None):
+        self._lock = threading.RLock()
+        self.last_control = Twist()
+        self.last_update = msgs.now()
+        self.num_particles = int(num_particles)
+        self._device = int(device)
+        self._features = list(preset_features)
+        self._ids = list(range(1, len(self._features) + 1))  # load_feature_list :294-299
+        L = len(self._features)
+        self._filter = _lib.DeviceFilter(self.num_particles, L, device=self._device)
+        if L:
+            means = np.array([np.asarray(f.mean, dtype=np.float64).reshape(5) for f in self._features])
+            covs = np.array([np.asarray(f.covar, dtype=np.float64).reshape(25) for f in self._features])
+            imm = np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8)
+            self._filter.upload_map(means, covs, imm)
+        self.Qt = _default_Qt()
+        self._domain = {"linear": _lib.PK_WEIGHTS_LINEAR, "log": _lib.PK_WEIGHTS_LOG}[weight_domain]
+        if rng not in ("global", "device"):
+            raise ValueError("rng must be 'global' or 'device'")
+        self._rng = rng
+        self._seed = int(seed)
+        self._draw = 0
+        self._gen = 0
+        self._pose_cache = None
+        self.particles = _ParticleList(self)
+        self.last_ids = None
+        r = msgs.ros()
+        self._publish = (r is not None) if publish_debug is None else bool(publish_debug)
+        if r is not None:
+            self.aged_particles_pub = r.Publisher('/aged_particles', Odometry, queue_size=1)
+            self.resampled_particles_pub = r.Publisher('/resampled_particles', Odometry, queue_size=1)
+            self.particle_track_pub = r.Publisher('/particle_track', Odometry, queue_size=1)
+        else:
+            self.aged_particles_pub = self.resampled_particles_pub = self.particle_track_pub = None
+            self._publish = False
+
+    # ------------------------------------------------------------------ views
+    def _touch(self):
+        self._gen += 1
+        self._pose_cache = None
+
+    def _poses(self):
+        if self._pose_cache is None:
+            self._pose_cache = self._filter.download_poses()
+        return self._pose_cache
+
+    def _particle_view(self, i):
+        with self._lock:
+            x, y, h, w = self._poses()[i]
+            p = FilterParticle(_make_state(x, y, h))
+            p.weight = float(w)
+            p.Qt = self.Qt
+            p._device = self._device
+            p.next_id = len(self._ids) + 1
+            filt, ids, feats, lock = self._filter, self._ids, self._features, self._lock
+
+            def loader():
+                with lock:
+                    m, c, k = filt.download_landmarks(i, i + 1)
+                out = {}
+                for j, id_ in enumerate(ids):
+                    f = Feature(mean=m[0, j], covar=c[0, j])
+                    f.update_count = int(k[0, j])
+                    f.__immutable__ = bool(feats[j].__immutable__)
+                    out[id_] = f
+                return out
+
+            p.feature_set = _FeatureSet(loader)
+            return p
+
+    def _store_particle(self, i, particle):
+        """``fs.particles[i] = particle`` (the reference does this at :162): write the pose,
+        weight and landmark estimates of a host particle into slot i."""
+        with self._lock:
+            poses = self._filter.download_poses()
+            x, y, h = _state_pose(particle.state)
+            poses[i] = (x, y, h, float(particle.weight))
+            self._filter.upload_poses(poses)
+            L = len(self._ids)
+            if L and len(particle.feature_set) == L:
+                fs_ = [particle.feature_set[k] for k in self._ids]
+                means = np.array([np.asarray(f.mean, dtype=np.float64) for f in fs_]).reshape(1, L, 5)
+                covs = np.array([np.asarray(f.covar, dtype=np.float64) for f in fs_]).reshape(1, L, 25)
+                cnts = np.array([int(f.update_count) for f in fs_], dtype=np.int32).reshape(1, L)
+                self._filter.upload_landmarks(i, i + 1, means, covs, cnts)
+            self._touch()
+
+    def _publish_all(self, pub, poses):
+        if not self._publish or pub is None:
+            return
+        for x, y, h, _w in poses:
+            st = _make_state(x, y, h)
+            st.header.frame_id = 'odom'
+            pub.publish(st)
+
+    # ------------------------------------------------------------------ a12
+    def cam_cb(self, ros_view):
+        """One filter step (:59-137)."""
+        with self._lock:
+            self._filter.reset_weights()  # :73
+            self._motion_update(self.last_control)  # :75-77
+            scan = ros_view.last_sensor_reading  # :82
+            observes = list(scan.observes)
+            blobs = np.array([_blob_row(b) for b in observes], dtype=np.float64).reshape(-1, 4)
+            self._filter.set_measurement_noise(self.Qt)
+            self._filter.observe(blobs)  # :84-124 association + EKF + weights
+            self._touch()
+            if self._publish:
+                self._publish_all(self.particle_track_pub, self._poses())  # :126-127
+            self.low_variance_resample()  # :137
+
+    def odom_motion_update(self, odom):
+        pass  # :140-146 alpha feature, empty in the reference
+
+    # ------------------------------------------------------------------ a2
+    def _noise(self, n):
+        if self._rng == "global":
+            # numpy.random.normal(0, s, 1) x 3 per particle, particle-major (:185-193), is the
+            # same stream as one standard_normal(3 P) call scaled by s (legacy loc + scale*gauss)
+            return np.random.standard_normal((n, 3))
+        return None
+
+    def _motion_update(self, new_twist):
+        dt = msgs.now() - self.last_update  # :158
+        v = float(self.last_control.linear.x)  # moves with the PREVIOUS control (:163)
+        w = float(self.last_control.angular.z)
+        self._filter.motion(v, w, dt.to_sec(), z=self._noise(self.num_particles), seed=self._seed, draw=self._draw)
+        self._draw += 1
+        self._touch()
+        self.last_update = self.last_update + dt  # :165
+        self.last_control = new_twist  # :166
+
+    def motion_update(self, new_twist):
+        with self._lock:
+            self._motion_update(new_twist)
+
+    def motion_model(self, particle, twist, dt):
+        """Move ONE particle (:168-208) and return the moved copy.  Runs the same kernel on a
+        one-particle filter."""
+        dt = dt.to_sec()
+        x, y, h = _state_pose(particle.state)
+        f = _lib.DeviceFilter(1, 0, device=self._device)
+        try:
+            f.upload_poses(np.array([[x, y, h, 1.0]]))
+            z = self._noise(1)
+            f.motion(float(twist.linear.x), float(twist.angular.z), dt, z=z, seed=self._seed, draw=self._draw)
+            self._draw += 1
+            nx, ny, nh, _ = f.download_poses()[0]
+        finally:
+            f.close()
+        new_particle = _copy.deepcopy(particle)
+        new_particle.state = _copy.deepcopy(particle.state)
+        new_particle.state.pose.pose.position.x = nx
+        new_particle.state.pose.pose.position.y = ny
+        new_particle.state.pose.pose.orientation = heading_to_quaternion(nh)
+        return new_particle
+
+    # ------------------------------------------------------------------ a13
+    def low_variance_resample(self):
+        with self._lock:
+            if self._publish:
+                self._publish_all(self.aged_particles_pub, self._poses())  # :237
+            u = _pyrandom.random()  # :226
+            self.last_ancestors = self._filter.resample(u, domain=self._domain, return_ancestors=self._publish)
+            self._touch()
+            if self._publish:
+                self._publish_all(self.resampled_particles_pub, self._poses())  # :242
+
+    # ------------------------------------------------------------------ a14
+    def summary(self):
+        with self._lock:
+            return self._filter.summary()
+
+    def close(self):
+        self._filter.close()

@@ -254,6 +254,17 @@ void unpack_landmark(const MapLayout& lay, const unsigned char* slot, int l, dou
   }
 }
 
+// unit((cos b, sin b, 0.0)) of closest_point (prkt_core_v2.py:510, utils.py:68-76): the ray
+// direction of each blob, scaled by 1/length exactly like utils.scale(vector, 1.0/length).
+void blob_directions(const double* blobs, int B, double* dir) {
+  for (int b = 0; b < B; ++b) {
+    double c = std::cos(blobs[4 * b]), s = std::sin(blobs[4 * b]);
+    double len = std::sqrt(c * c + s * s + 0.0 * 0.0);
+    dir[2 * b] = c * (1.0 / len);
+    dir[2 * b + 1] = s * (1.0 / len);
+  }
+}
+
 // The compact layout stores Sigma = Pxy (+) C: reject anything else loudly.
 int check_block_diagonal(const double* cov, int l) {
   double scale = 0.0;
@@ -662,13 +673,7 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
   }
   // maximum-likelihood association on the device
   double* dir = reinterpret_cast<double*>(st + o_dir);
-  for (int b = 0; b < B; ++b) {
-    // unit((cos b, sin b, 0.0)), utils.py:68-76: scale by 1/length
-    double c = std::cos(blobs[4 * b]), s = std::sin(blobs[4 * b]);
-    double len = std::sqrt(c * c + s * s + 0.0 * 0.0);
-    dir[2 * b] = c * (1.0 / len);
-    dir[2 * b + 1] = s * (1.0 / len);
-  }
+  blob_directions(blobs, B, dir);
   if ((rc = ensure_ids_capacity(f, B))) return rc;
   if (B > 0) PK_HIP(hipMemcpyAsync(f->blobdir_dev, dir, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
   PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
@@ -685,6 +690,36 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
     PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
     PK_HIP(hipStreamSynchronize(f->stream));
   }
+  return PK_OK;
+}
+
+int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out) {
+  if (!f || !ids_out) return fail(PK_ERR_INVALID, "pk_associate: NULL argument");
+  if (B < 0 || (B > 0 && !blobs)) return fail(PK_ERR_INVALID, "pk_associate: bad blobs");
+  if (!f->map_loaded) return fail(PK_ERR_STATE, "pk_associate: no map uploaded (pk_upload_map)");
+  if (B == 0) return PK_OK;
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  for (int i = 0; i < 4 * B; ++i)
+    if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_associate: blob %d is not finite", i / 4);
+  if ((rc = ensure_blob_capacity(f, B))) return rc;
+  if ((rc = ensure_ids_capacity(f, B))) return rc;
+  const size_t o_dir = (size_t)B * 4 * sizeof(double);
+  unsigned char* st = nullptr;
+  int slot = 0;
+  if ((rc = take_stage(f, o_dir + (size_t)B * 2 * sizeof(double), &st, &slot))) return rc;
+  memcpy(st, blobs, o_dir);
+  double* dir = reinterpret_cast<double*>(st + o_dir);
+  blob_directions(blobs, B, dir);
+  PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_dir, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->blobdir_dev, dir, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+  {
+    Span t(f, PK_T_ASSOC);
+    launch_assoc(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, f->ids_dev);
+  }
+  PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
   return PK_OK;
 }
 
@@ -792,18 +827,19 @@ int pk_probe(int32_t device, const double pose[3], const double mean[5], const d
   int rc;
   if ((rc = check_block_diagonal(cov, 0))) return rc;
   PK_HIP(hipSetDevice(device));
-  double in[53];
+  double in[55];
   memcpy(in, pose, 3 * 8);
   memcpy(in + 3, mean, 5 * 8);
   memcpy(in + 8, cov, 25 * 8);
   memcpy(in + 33, blob, 4 * 8);
   memcpy(in + 37, Qt, 16 * 8);
+  blob_directions(blob, 1, in + 53);
   double* dev = nullptr;
-  PK_HIP(hipMalloc((void**)&dev, (53 + PK_PROBE_LEN) * sizeof(double)));
+  PK_HIP(hipMalloc((void**)&dev, (55 + PK_PROBE_LEN) * sizeof(double)));
   hipError_t e = hipMemcpy(dev, in, sizeof(in), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    launch_probe(nullptr, dev, dev + 53);
-    e = hipMemcpy(out, dev + 53, PK_PROBE_LEN * sizeof(double), hipMemcpyDeviceToHost);
+    launch_probe(nullptr, dev, dev + 55);
+    e = hipMemcpy(out, dev + 55, PK_PROBE_LEN * sizeof(double), hipMemcpyDeviceToHost);
   }
   (void)hipFree(dev);
   if (e != hipSuccess) return fail(PK_ERR_HIP, "pk_probe: %s", hipGetErrorString(e));

@@ -668,7 +668,7 @@ void launch_broadcast_slot(hipStream_t s, DeviceState& d, const unsigned char* s
 }
 
 // ------------------------------------------------------------------ probe
-// in: pose[3] mean[5] cov[25] blob[4] Qt[16] (53 doubles); out: PK_PROBE_LEN doubles.
+// in: pose[3] mean[5] cov[25] blob[4] Qt[16] dir[2] (55 doubles); out: PK_PROBE_LEN doubles.
 __global__ void k_probe(const double* __restrict__ in, double* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double sx = in[0], sy = in[1], sh = in[2];
@@ -680,11 +680,7 @@ __global__ void k_probe(const double* __restrict__ in, double* __restrict__ out)
                      cov[12], cov[13], cov[14], cov[18], cov[19], cov[24], 0};
   BlobT<double> z{blob[0], blob[1], blob[2], blob[3]};
   Noise<double> qt{Qt[0], Qt[5], Qt[6], Qt[7], Qt[10], Qt[11], Qt[15]};
-  // unit((cos b, sin b, 0)) utils.py:68-76
-  double sb, cb;
-  sincos(z.bearing, &sb, &cb);
-  double len = sqrt(cb * cb + sb * sb + 0.0);
-  double ux = cb * (1.0 / len), uy = sb * (1.0 / len);
+  const double ux = in[53], uy = in[54];  // unit((cos b, sin b, 0)), host side like the kernels' input
   for (int i = 0; i < 79; ++i) out[i] = 0.0;
   out[0] = probability_of_match(f, sx, sy, sh, z, ux, uy);
   double pse = atan2(f.my - sy, f.mx - sx);

@@ -1,0 +1,288 @@
+"""The FastSLAM / FilterParticle / Feature facade on the GPU.
+
+First block: the reference's own unit tests (src/test_prkt_ros2.py) restated against the
+facade -- same inputs, same assertions, file:line cited per test.  Second block: whole
+cam_cb trajectories through the facade against golden vectors captured from the reference
+with the same numpy / random seeds.
+"""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pk():
+    import parakeet_slam_amd as m
+    from parakeet_slam_amd import msgs
+
+    m.msgs = msgs
+    return m
+
+
+def blob(pk, bearing=0.0, r=0, g=0, b=0):
+    return pk.msgs.Blob(bearing, r, g, b) if pk.msgs.Blob is pk.msgs._Blob else _ros_blob(pk, bearing, r, g, b)
+
+
+def _ros_blob(pk, bearing, r, g, b):
+    z = pk.msgs.Blob()
+    z.bearing = bearing
+    z.color.r, z.color.g, z.color.b = r, g, b
+    return z
+
+
+# ---------------------------------------------------------------- reference unit tests
+def test_fastslam_initialization(pk):
+    # test_prkt_ros2.py:39-44
+    fs = pk.FastSLAM()
+    assert isinstance(fs.last_control, pk.msgs.Twist)
+    assert isinstance(fs.particles, list)
+    assert isinstance(fs.Qt, np.ndarray) and fs.Qt.shape == (4, 4)
+    assert fs.num_particles == 50 and len(fs.particles) == 50  # prkt_core_v2.py:41
+    assert fs.summary() == (0.0, 0.0, 0.0)
+    fs.close()
+
+
+def test_motion_model(pk):
+    # test_prkt_ros2.py:46-69
+    fs = pk.FastSLAM()
+    fpold = pk.FilterParticle()
+    fpold.state.pose.pose.position.y = 2.0
+    twist = pk.msgs.Twist()
+    twist.linear.x = 1
+    dt = pk.msgs.Duration.from_sec(.1)
+    fpnew = fs.motion_model(fpold, twist, dt)
+    dy_expected = twist.linear.x * dt.secs
+    dy_measured = fpnew.state.pose.pose.position.y - fpold.state.pose.pose.position.y
+    assert abs(dy_measured - dy_expected) < .01
+    dx = fpnew.state.pose.pose.position.x - fpold.state.pose.pose.position.x
+    assert abs(dx - 0.1) < 0.3  # moved forward by about v*dt
+    twist.linear.x = 2
+    fpnew = fs.motion_model(fpold, twist, dt)
+    dy_measured = fpnew.state.pose.pose.position.y - fpold.state.pose.pose.position.y
+    assert abs(dy_measured - twist.linear.x * dt.secs) < .02
+    assert fpold.state.pose.pose.position.y == 2.0  # input particle untouched (deepcopy :181)
+    fs.close()
+
+
+def test_filter_particle_initialization(pk):
+    # test_prkt_ros2.py:73-80
+    p = pk.FilterParticle()
+    assert isinstance(p.feature_set, dict)
+    assert isinstance(p.potential_features, dict)
+    assert isinstance(p.hypothesis_set, dict)
+    assert p.weight == 1 and p.next_id == 1
+
+
+def test_get_feature_by_id(pk):
+    # test_prkt_ros2.py:82-96
+    p = pk.FilterParticle()
+    f0 = pk.Feature()
+    f0.arbitrary_id = 'tangled'
+    p.feature_set[2] = f0
+    assert p.get_feature_by_id(2).arbitrary_id == 'tangled'
+    f1 = pk.Feature()
+    f1.arbitrary_id = 'snow white'
+    p.potential_features[-3] = f1
+    assert p.get_feature_by_id(-3).arbitrary_id == 'snow white'
+    with pytest.raises(KeyError):
+        p.get_feature_by_id(7)
+
+
+def test_probability_of_match_gates(pk):
+    # test_prkt_ros2.py:98-124: exact 0.0 from the colour gate and from the bearing gate
+    p = pk.FilterParticle()
+    state = pk.msgs.Odometry()
+    feature = pk.Feature(mean=np.array([1, 0, 0, 0, 0]))
+    assert p.probability_of_match(state, blob(pk, 0.0, r=255), feature) == 0.0
+    assert p.probability_of_match(state, blob(pk, math.pi), feature) == 0.0
+    assert p.probability_of_match(state, blob(pk, 0.0), feature) > 0.0
+
+
+def test_prob_position_match(pk):
+    # test_prkt_ros2.py:126-152
+    p = pk.FilterParticle()
+    f_mean = np.array([1, 0, 0, 0, 0])
+    f_covar = np.array([[.1, 0], [0, .1]])
+    r1 = p.prob_position_match(f_mean, f_covar, 0.0, 0.0, 0.0)
+    assert r1 > 1.59 and abs(r1 - 1.0 / (2 * math.pi * 0.1)) < 1e-12
+    r2 = p.prob_position_match(f_mean, f_covar, 0.0, 0.0, 1.0)
+    assert r2 < 0.05 and r1 > r2
+    r2 = p.prob_position_match(f_mean, f_covar, 0.0, 0.0, -1.0)
+    assert 0.0 < r2 < 0.05
+    r3 = p.prob_position_match(f_mean, f_covar, 0.0, 0.0, math.pi)
+    assert r2 > r3 and r3 == 0.0  # early-out prkt_core_v2.py:474
+
+
+def test_closest_point(pk):
+    # test_prkt_ros2.py:154-189
+    p = pk.FilterParticle()
+    assert p.closest_point(1.0, 0.0, 0.0, 0.0, 0.0) == (1.0, 0.0)
+    cx, cy = p.closest_point(1.0, 0.0, 0.0, 0.0, math.pi / 2)
+    assert cx < .00001 and cy < .00001
+    for b in (math.pi, math.pi * 3.0 / 4.0, -math.pi * 3.0 / 4.0):
+        assert p.closest_point(1.0, 0.0, 0.0, 0.0, b) == (0.0, 0.0)  # behind-ray clamp :515-516
+
+
+def test_prob_color_match(pk):
+    # test_prkt_ros2.py:191-222
+    p = pk.FilterParticle()
+    f_mean = np.array([0, 0, 255, 0, 0])
+    f_covar = np.diag([0, 0, 5, 5, 5])
+    z = blob(pk, 0.0, 255, 0, 0)
+    r1 = p.prob_color_match(f_mean, f_covar, z)
+    assert r1 > 0.005 and abs(r1 - 1.0 / math.sqrt((2 * math.pi) ** 3 * 125)) < 1e-14
+    z.color.r = 250
+    r2 = p.prob_color_match(f_mean, f_covar, z)
+    assert r2 < r1
+    z.color.b = 5
+    r3 = p.prob_color_match(f_mean, f_covar, z)
+    assert r3 < r2
+    z.color.r = 200
+    assert p.prob_color_match(f_mean, f_covar, z) < r2
+
+
+def test_add_orphaned_reading(pk):
+    # test_prkt_ros2.py:372-381
+    p = pk.FilterParticle()
+    n = len(p.hypothesis_set)
+    p.add_orphaned_reading(pk.msgs.Odometry(), blob(pk))
+    assert len(p.hypothesis_set) > n
+
+
+def test_generate_measurement(pk):
+    # test_prkt_ros2.py:403-423
+    p = pk.FilterParticle()
+    odom = pk.msgs.Odometry()
+    odom.pose.pose.position.x = -1
+    odom.pose.pose.position.y = -1
+    p.state = odom
+    feature = pk.Feature()
+    feature.mean[2] = 73
+    feature.mean[3] = 165
+    feature.mean[4] = 255
+    p.feature_set[3] = feature
+    z = p.generate_measurement(3)
+    assert (z.color.r, z.color.g, z.color.b) == (73, 165, 255)
+    assert z.bearing == math.pi / 4
+
+
+def test_feature_initialization(pk):
+    # test_prkt_ros2.py:426-431
+    f = pk.Feature()
+    assert isinstance(f.mean, np.ndarray) and isinstance(f.covar, np.ndarray) and isinstance(f.identity, np.ndarray)
+    assert f.update_count == 0 and f.__immutable__ is False
+
+
+def test_ekf_pieces_against_survey_vector(pk):
+    # the commented-out tests :383-401, pinned with the SURVEY 8a known answer
+    p = pk.FilterParticle(pk.core._make_state(0.5, -0.25, 0.3))
+    p.feature_set[1] = pk.Feature(mean=np.array([3, 4, 100, 150, 200.0]), covar=0.25 * np.identity(5))
+    z = blob(pk, 0.9, 101, 149, 202)
+    H = p.measurement_jacobian(1)
+    assert np.allclose(H[0, :2], [0.174807197943, 0.102827763496], rtol=1e-11)
+    assert np.array_equal(H[1:, 2:], np.identity(3))
+    Q = p.measurement_covariance(H, 1, 0.1 * np.identity(4))
+    assert np.allclose(np.diag(Q), [0.11028277635, .35, .35, .35], rtol=1e-10)
+    K = p.kalman_gain(1, H, np.linalg.inv(Q))
+    assert np.allclose(K[:2, 0], [0.39627039627, 0.2331002331], rtol=1e-9)
+    assert np.allclose(K[2:, 1:], 0.714285714286 * np.identity(3), rtol=1e-11, atol=1e-14)
+    w = p.importance_factor(Q, z, p.generate_measurement(1))
+    assert abs(w - 8.819701295333626e-05) / 8.8e-5 < 1e-10
+    assert p.match_one(p.state, z) == 1
+    assert p.match_one(p.state, blob(pk, 0.9, 10, 10, 10)) == 0
+
+
+# ---------------------------------------------------------------- whole steps
+class View(object):
+    def __init__(self, pk, rows):
+        class Scan(object):
+            pass
+
+        self.last_sensor_reading = Scan()
+        self.last_sensor_reading.observes = [blob(pk, *r) for r in rows]
+
+
+@pytest.mark.parametrize("name", ["step_small", "step_refscene", "step_config1"])
+def test_cam_cb_trajectory(pk, name):
+    g = load_golden(name)
+    P, L = int(g["P"]), int(g["L"])
+    seed = int(g["seed"])
+    np.random.seed(seed)
+    random.seed(seed)
+    pk.msgs.Time.set_now(0.0)
+    feats = []
+    for l in range(L):
+        f = pk.Feature(mean=g["means0"][l], covar=g["covs0"][l])
+        f.__immutable__ = bool(g["immutable"][l])
+        feats.append(f)
+    fs = pk.FastSLAM(feats, num_particles=P)
+    tw = pk.msgs.Twist()
+    tw.linear.x = float(g["v"])
+    tw.angular.z = float(g["w"])
+    fs.last_control = tw
+    lsel = g["lsel"] if "lsel" in g.files else np.arange(L)
+    t = 0.0
+    for s in range(len(g["u"])):
+        t += float(g["dts"][s])
+        pk.msgs.Time.set_now(t)
+        fs.cam_cb(View(pk, g["blobs"][s]))
+        got = np.array([[p.state.pose.pose.position.x, p.state.pose.pose.position.y,
+                         pk.msgs.quaternion_to_heading(p.state.pose.pose.orientation), p.weight]
+                        for p in fs.particles])
+        ref = g["post_resample"][s]
+        assert np.allclose(got[:, :3], ref[:, :3], rtol=1e-9, atol=1e-12), (name, s)
+        assert relerr(got[:, 3], ref[:, 3]) < 1e-9
+        assert np.allclose(fs.summary(), g["summary"][s], rtol=1e-9, atol=1e-12)
+        for i in (0, P // 2, P - 1):
+            fsi = fs.particles[i].feature_set
+            assert sorted(fsi.keys()) == list(range(1, L + 1))
+            for jj, l in enumerate(lsel):
+                f = fsi[int(l) + 1]
+                assert relerr(f.mean, g["mean"][s][i, jj]) < 1e-9
+                assert np.allclose(f.covar, g["cov"][s][i, jj], rtol=1e-9, atol=1e-13)
+                assert f.update_count == g["count"][s][i, jj]
+    fs.close()
+
+
+def test_particle_assignment_and_motion_update(pk):
+    pk.msgs.Time.set_now(0.0)
+    f = pk.Feature(mean=np.array([5.0, 1, 10, 20, 30]), covar=0.25 * np.identity(5))
+    fs = pk.FastSLAM([f], num_particles=8)
+    p = fs.particles[3]
+    p.state.pose.pose.position.x = 1.5
+    p.state.pose.pose.orientation = pk.msgs.heading_to_quaternion(0.7)
+    p.weight = 0.25
+    p.feature_set[1].mean = np.array([6.0, 2, 11, 21, 31])
+    fs.particles[3] = p
+    q = fs.particles[3]
+    assert q.state.pose.pose.position.x == 1.5 and abs(q.weight - 0.25) < 1e-15
+    assert abs(pk.msgs.quaternion_to_heading(q.state.pose.pose.orientation) - 0.7) < 1e-15
+    assert np.array_equal(q.feature_set[1].mean, [6.0, 2, 11, 21, 31])
+    assert np.array_equal(fs.particles[2].feature_set[1].mean, [5.0, 1, 10, 20, 30])
+    # motion_update moves with the PREVIOUS control and then stores the new one (:163-166)
+    tw = pk.msgs.Twist()
+    tw.linear.x = 1.0
+    pk.msgs.Time.set_now(1.0)
+    fs.motion_update(tw)
+    xs = np.array([p.state.pose.pose.position.x for p in fs.particles])
+    assert np.all(np.abs(np.delete(xs, 3)) < 0.02)  # previous control was zero
+    pk.msgs.Time.set_now(2.0)
+    fs.motion_update(tw)
+    xs2 = np.array([p.state.pose.pose.position.x for p in fs.particles])
+    assert np.all(np.abs(np.delete(xs2 - xs, 3) - 1.0) < 0.5)
+    assert fs.last_control is tw
+    fs.close()
+
+
+def test_unsupported_covariance_is_loud(pk):
+    cov = 0.25 * np.identity(5)
+    cov[0, 3] = cov[3, 0] = 0.01
+    with pytest.raises(pk.PkError) as ei:
+        pk.FastSLAM([pk.Feature(mean=np.zeros(5), covar=cov)], num_particles=4)
+    assert ei.value.status == -4
