@@ -131,6 +131,8 @@ def main():
     else:
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
+    if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only
+        filt.set_option("observe_landmarks_per_lane", int(os.environ["PK_OBSERVE_NV"]))
     rnd = random.Random(7)
     us = [rnd.random() for _ in range(K + W)]
 

@@ -89,6 +89,13 @@ int32_t pk_num_landmarks(const pk_filter* f);
 /* Bytes of HBM the handle holds (maps are double-buffered). */
 int64_t pk_device_bytes(const pk_filter* f);
 
+/* Tuning knobs that never change results:
+ *   "assoc_kernel" = 0 (colour-grid association kernel, default) or 1 (brute-force reference
+ *                    kernel that gate-tests every landmark x blob pair);
+ *   "assoc_dup"    = 1 (default: 9x column-duplicated blob index list when it fits in LDS) or 0;
+ *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
+int pk_set_option(pk_filter* f, const char* name, int64_t value);
+
 /* ---- configuration ----------------------------------------------------------
  * FastSLAM.Qt (prkt_core_v2.py:50-53), row-major 4x4.  The compact device layout
  * needs Qt = [q00] (+) [3x3 symmetric]; anything else is PK_ERR_UNSUPPORTED. */

@@ -41,6 +41,7 @@ SIGNATURES = {
     "pk_num_particles": (C.c_int64, [_h]),
     "pk_num_landmarks": (C.c_int32, [_h]),
     "pk_device_bytes": (C.c_int64, [_h]),
+    "pk_set_option": (C.c_int, [_h, C.c_char_p, C.c_int64]),
     "pk_set_measurement_noise": (C.c_int, [_h, _dp]),
     "pk_upload_map": (C.c_int, [_h, _dp, _dp, _bp]),
     "pk_upload_poses": (C.c_int, [_h, _dp]),
@@ -166,6 +167,9 @@ class DeviceFilter(object):
 
     def device_bytes(self):
         return int(self._lib.pk_device_bytes(self._h))
+
+    def set_option(self, name, value):
+        check(self._lib.pk_set_option(self._h, name.encode(), int(value)))
 
     def set_measurement_noise(self, Qt):
         q = f64(Qt, (16,))

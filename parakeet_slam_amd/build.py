@@ -45,6 +45,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_stamps(verbose=True):
+    """Diagnostic build with in-kernel cycle stamps (-DPK_STAMPS) -> libparakeet_slam_stamps.so.
+    Never loaded by the package; scripts/gpu_stamps.py uses it to read per-phase shares."""
+    hipcc = _hipcc()
+    out = os.path.join(HERE, "libparakeet_slam_stamps.so")
+    srcs = [os.path.join(CSRC, x) for x in HIP_SOURCES + CXX_SOURCES]
+    cmd = [hipcc] + HIPCC_FLAGS + ["-DPK_STAMPS", "-shared", "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=True):
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
@@ -72,5 +85,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--stamps" in sys.argv:
+        print(build_stamps())
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

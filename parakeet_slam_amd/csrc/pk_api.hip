@@ -19,6 +19,10 @@
 
 using namespace pk;
 
+#ifdef PK_STAMPS
+namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); }
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -69,6 +73,10 @@ struct pk_filter {
   int32_t* ids_dev = nullptr;     // P x Bcap_ids
   int Bcap = 0;
   int64_t ids_cap = 0;
+  unsigned char* grid_dev = nullptr;  // association tables (cell offsets | fp32 colours | order)
+  size_t grid_cap = 0;
+  int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
+  int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
   // pinned host staging ring for the per-scan uploads (blobs, ray directions, chains):
   // lets pk_observe/pk_step return without synchronising the stream
   static constexpr int kRing = 8;
@@ -265,6 +273,176 @@ void blob_directions(const double* blobs, int B, double* dir) {
   }
 }
 
+// Bucket the blobs of one scan into a 3-D colour grid (cell edge kGridCell > sqrt(300), the
+// colour gate radius of prkt_core_v2.py:441) and lay out what k_assoc_grid reads:
+//   tables: start u16[ncell+1] (padded to 16 bytes) | rec32 float4[B] | idx9 u16[n9] | order u16[B]
+//   exact:  double[B][6] = bearing, r, g, b, ux, uy      (rec32, exact, order in cell order)
+// With dup, idx9 lists for every (r, g) column and b cell the blobs (cell-order index) within
+// one cell in r and g, and `start` = offsets into idx9; otherwise n9 = 0 and `start` = cell
+// offsets into rec32.  Returns n9 through *n9_out (0 when the duplicated list is not built).
+void build_blob_grid(const double* blobs, const double* dir, int B, bool want_dup, BlobGrid& g,
+                     unsigned char* tables, double* exact, int* n9_out) {
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, M = 0.0, Mb = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = hi[k] = B ? blobs[1 + k] : 0.0;
+    for (int b = 0; b < B; ++b) {
+      double v = blobs[4 * b + 1 + k];
+      lo[k] = std::fmin(lo[k], v);
+      hi[k] = std::fmax(hi[k], v);
+      M = std::fmax(M, std::fabs(v));
+    }
+  }
+  for (int b = 0; b < B; ++b) Mb = std::fmax(Mb, std::fabs(blobs[4 * b]));
+  g.inv_h = 1.0 / kGridCell;
+  g.ncell = 1;
+  for (int k = 0; k < 3; ++k) {
+    g.lo[k] = lo[k];
+    double span = std::floor((hi[k] - lo[k]) * g.inv_h) + 1.0;
+    g.G[k] = span > (double)kGridMax ? kGridMax : (int)span;
+    g.ncell *= g.G[k];
+  }
+  // fp32 pre-filter bounds.  Colour: with d the exact channel difference of a pair inside the
+  // gate and d' its fp32 evaluation from fp32-rounded colours, |d' - d| <= eta = 2^-24 (2M + 35);
+  // then sum d'^2 <= 300 + 60 eta + 3 eta^2 (+ fp32 summation error).  Bearing: a pair inside
+  // the gate has |expected| <= Mb + 0.5, so |d' - d| <= 2^-24 (2 Mb + 1.5).  Both doubled.
+  const double eta = 2.0 * std::ldexp(2.0 * M + 35.0, -24);
+  const double thr = (300.0 + 60.0 * eta + 3.0 * eta * eta + 1e-3) * (1.0 + 1e-6);
+  g.thr32 = thr < 3.0e38 ? (float)thr : INFINITY;
+  const double thrb = (0.5 + 2.0 * std::ldexp(2.0 * Mb + 1.5, -24) + 1e-6) * (1.0 + 1e-6);
+  g.thrb32 = thrb < 3.0e38 ? (float)thrb : INFINITY;
+  auto cell_of = [&](int b) {
+    int c[3];
+    for (int k = 0; k < 3; ++k) {
+      double q = std::floor((blobs[4 * b + 1 + k] - g.lo[k]) * g.inv_h);
+      c[k] = q < 0.0 ? 0 : (q > (double)(g.G[k] - 1) ? g.G[k] - 1 : (int)q);
+    }
+    return (c[0] * g.G[1] + c[1]) * g.G[2] + c[2];
+  };
+  std::vector<int> cell((size_t)std::max(B, 1)), cs((size_t)g.ncell + 1, 0), fill;
+  for (int b = 0; b < B; ++b) {
+    cell[b] = cell_of(b);
+    ++cs[cell[b] + 1];
+  }
+  for (int c = 0; c < g.ncell; ++c) cs[c + 1] += cs[c];
+  fill = cs;
+  const size_t cs_bytes = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
+  memset(tables, 0, cs_bytes);
+  uint16_t* start = reinterpret_cast<uint16_t*>(tables);
+  float* rec32 = reinterpret_cast<float*>(tables + cs_bytes);
+  uint16_t* idx9 = reinterpret_cast<uint16_t*>(tables + cs_bytes + (size_t)B * 16);
+  // duplicated column lists: size known before laying out `order`
+  int n9 = 0;
+  std::vector<int> col_start;
+  if (want_dup) {
+    col_start.assign((size_t)g.ncell + 1, 0);
+    long total = 0;
+    for (int r = 0; r < g.G[0]; ++r)
+      for (int gg = 0; gg < g.G[1]; ++gg)
+        for (int k = 0; k < g.G[2]; ++k) {
+          col_start[(r * g.G[1] + gg) * g.G[2] + k] = (int)total;
+          for (int r2 = std::max(r - 1, 0); r2 <= std::min(r + 1, g.G[0] - 1); ++r2)
+            for (int g2 = std::max(gg - 1, 0); g2 <= std::min(gg + 1, g.G[1] - 1); ++g2) {
+              const int c = (r2 * g.G[1] + g2) * g.G[2] + k;
+              total += cs[c + 1] - cs[c];
+            }
+        }
+    col_start[g.ncell] = (int)total;
+    if (total <= 65535) n9 = (int)((total + 7) & ~7L);
+  }
+  uint16_t* order = reinterpret_cast<uint16_t*>(tables + cs_bytes + (size_t)B * 16 + (size_t)n9 * 2);
+  for (int b = 0; b < B; ++b) {  // ascending b inside a cell
+    const int pos = fill[cell[b]]++;
+    order[pos] = (uint16_t)b;
+    rec32[4 * pos] = (float)blobs[4 * b + 1];
+    rec32[4 * pos + 1] = (float)blobs[4 * b + 2];
+    rec32[4 * pos + 2] = (float)blobs[4 * b + 3];
+    rec32[4 * pos + 3] = (float)blobs[4 * b];
+    double* e = exact + 6 * (size_t)pos;
+    e[0] = blobs[4 * b];
+    e[1] = blobs[4 * b + 1];
+    e[2] = blobs[4 * b + 2];
+    e[3] = blobs[4 * b + 3];
+    e[4] = dir[2 * b];
+    e[5] = dir[2 * b + 1];
+  }
+  if (n9 > 0) {
+    int w = 0;
+    for (int r = 0; r < g.G[0]; ++r)
+      for (int gg = 0; gg < g.G[1]; ++gg)
+        for (int k = 0; k < g.G[2]; ++k) {
+          start[(r * g.G[1] + gg) * g.G[2] + k] = (uint16_t)w;
+          for (int r2 = std::max(r - 1, 0); r2 <= std::min(r + 1, g.G[0] - 1); ++r2)
+            for (int g2 = std::max(gg - 1, 0); g2 <= std::min(gg + 1, g.G[1] - 1); ++g2) {
+              const int c = (r2 * g.G[1] + g2) * g.G[2] + k;
+              for (int t = cs[c]; t < cs[c + 1]; ++t) idx9[w++] = (uint16_t)t;
+            }
+        }
+    start[g.ncell] = (uint16_t)w;
+    for (; w < n9; ++w) idx9[w] = 0;
+  } else {
+    for (int c = 0; c <= g.ncell; ++c) start[c] = (uint16_t)cs[c];
+  }
+  *n9_out = n9;
+}
+
+// Upload one scan for maximum-likelihood association and enqueue the association kernel.
+int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize) {
+  int rc;
+  if (B > 65535) return fail(PK_ERR_UNSUPPORTED, "maximum-likelihood association handles at most 65535 blobs per scan (got %d)", B);
+  if ((rc = ensure_blob_capacity(f, B))) return rc;
+  if ((rc = ensure_ids_capacity(f, B))) return rc;
+  BlobGrid g{};
+  const int ncell_max = kGridMax * kGridMax * kGridMax;
+  const size_t tab_max = (blob_grid_table_bytes(ncell_max, B, 9 * B + 8) + 15) & ~(size_t)15;
+  // staging: blobs (4B) | dir (2B) | exact (6B) doubles | tables
+  const size_t o_dir = (size_t)B * 4 * sizeof(double);
+  const size_t o_exact = o_dir + (size_t)B * 2 * sizeof(double);
+  const size_t o_tab = o_exact + (size_t)B * 6 * sizeof(double);
+  unsigned char* st = nullptr;
+  int slot = 0;
+  if ((rc = take_stage(f, o_tab + tab_max + 16, &st, &slot))) return rc;
+  memcpy(st, blobs, o_dir);
+  double* dir = reinterpret_cast<double*>(st + o_dir);
+  blob_directions(blobs, B, dir);
+  PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_dir, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->blobdir_dev, dir, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+  // the grid kernel keeps landmark indices as u16 and its tables in LDS
+  bool use_grid = f->assoc_kernel == 0 && f->d.lay.L <= 65535;
+  size_t tab_bytes = 0;
+  int n9 = 0;
+  if (use_grid) {
+    // duplicated column lists when they fit in LDS (about 48 B per blob), else the 9-range walk
+    bool dup = f->assoc_dup && assoc_grid_lds_bytes(ncell_max, B, 9 * B + 8) <= kMaxDynLds;
+    build_blob_grid(blobs, dir, B, dup, g, st + o_tab, reinterpret_cast<double*>(st + o_exact), &n9);
+    tab_bytes = (blob_grid_table_bytes(g.ncell, B, n9) + 15) & ~(size_t)15;
+    if (assoc_grid_lds_bytes(g.ncell, B, n9) > kMaxDynLds) use_grid = false;  // scan too large for LDS tables
+  }
+  if (use_grid) {
+    const size_t need = tab_max + (size_t)B * 6 * sizeof(double) + 64;
+    if (need > f->grid_cap) {
+      PK_HIP(hipStreamSynchronize(f->stream));
+      if (f->grid_dev) (void)hipFree(f->grid_dev);
+      f->grid_dev = nullptr;
+      f->grid_cap = 0;
+      if ((rc = dev_alloc(f, &f->grid_dev, need + need / 4))) return rc;
+      f->grid_cap = need + need / 4;
+    }
+    // device block: exact records first (16-byte aligned), then the tables
+    const size_t ex_bytes = ((size_t)B * 6 * sizeof(double) + 15) & ~(size_t)15;
+    PK_HIP(hipMemcpyAsync(f->grid_dev, st + o_exact, (size_t)B * 6 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    PK_HIP(hipMemcpyAsync(f->grid_dev + ex_bytes, st + o_tab, tab_bytes, hipMemcpyHostToDevice, f->stream));
+    PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+    Span t(f, PK_T_ASSOC);
+    launch_assoc_grid(f->stream, f->d, B, g, n9, f->grid_dev + ex_bytes, reinterpret_cast<const double*>(f->grid_dev),
+                      f->ids_dev, finalize);
+    return PK_OK;
+  }
+  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+  Span t(f, PK_T_ASSOC);
+  launch_assoc_brute(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, f->ids_dev);
+  return PK_OK;
+}
+
 // The compact layout stores Sigma = Pxy (+) C: reject anything else loudly.
 int check_block_diagonal(const double* cov, int l) {
   double scale = 0.0;
@@ -400,6 +578,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.src[i]);
     (void)hipFree(d.map[i]);
   }
+  if (f->grid_dev) (void)hipFree(f->grid_dev);
   void* rest[] = {d.immutable, f->z_dev,  f->blobs_dev, f->blobdir_dev, f->first_dev, f->next_dev, f->ids_dev,
                   f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
                   f->anc,      f->slot_tmp};
@@ -628,18 +807,17 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
   if (ids)
     for (int b = 0; b < B; ++b)
       if (ids[b] < 0 || ids[b] > L) return fail(PK_ERR_INVALID, "pk_observe: ids[%d] = %d outside 0..%d", b, ids[b], L);
-  if ((rc = ensure_blob_capacity(f, B))) return rc;
-  // staging block: blobs (4B doubles) | dir (2B doubles) | first (Lp int32) | next (B int32)
-  const size_t o_dir = (size_t)B * 4 * sizeof(double);
-  const size_t o_first = o_dir + (size_t)B * 2 * sizeof(double);
-  const size_t o_next = o_first + (size_t)lay.Lp * sizeof(int32_t);
-  const size_t total = o_next + (size_t)B * sizeof(int32_t);
-  unsigned char* st = nullptr;
-  int slot = 0;
-  if ((rc = take_stage(f, total, &st, &slot))) return rc;
-  if (B > 0) memcpy(st, blobs, o_dir);
-  if (B > 0) PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_dir, hipMemcpyHostToDevice, f->stream));
   if (ids) {
+    if ((rc = ensure_blob_capacity(f, B))) return rc;
+    // staging block: blobs (4B doubles) | first (Lp int32) | next (B int32)
+    const size_t o_first = (size_t)B * 4 * sizeof(double);
+    const size_t o_next = o_first + (size_t)lay.Lp * sizeof(int32_t);
+    const size_t total = o_next + (size_t)B * sizeof(int32_t);
+    unsigned char* st = nullptr;
+    int slot = 0;
+    if ((rc = take_stage(f, total, &st, &slot))) return rc;
+    if (B > 0) memcpy(st, blobs, o_first);
+    if (B > 0) PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_first, hipMemcpyHostToDevice, f->stream));
     // landmark -> blob chains shared by all particles, in scan order (prkt_core_v2.py:88)
     int32_t* first = reinterpret_cast<int32_t*>(st + o_first);
     int32_t* next = reinterpret_cast<int32_t*>(st + o_next);
@@ -664,7 +842,7 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
     PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
     {
       Span t(f, PK_T_OBSERVE);
-      launch_observe(f->stream, f->d, f->blobs_dev, B, f->first_dev, f->next_dev, n0, nullptr, f->qt);
+      launch_observe(f->stream, f->d, f->blobs_dev, nullptr, B, f->first_dev, f->next_dev, n0, nullptr, f->qt);
     }
     f->src_identity = true;
     if (ids_out)
@@ -672,18 +850,10 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
     return PK_OK;
   }
   // maximum-likelihood association on the device
-  double* dir = reinterpret_cast<double*>(st + o_dir);
-  blob_directions(blobs, B, dir);
-  if ((rc = ensure_ids_capacity(f, B))) return rc;
-  if (B > 0) PK_HIP(hipMemcpyAsync(f->blobdir_dev, dir, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
-  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
-  {
-    Span t(f, PK_T_ASSOC);
-    launch_assoc(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, f->ids_dev);
-  }
+  if ((rc = enqueue_association(f, blobs, B, false))) return rc;
   {
     Span t(f, PK_T_OBSERVE);
-    launch_observe(f->stream, f->d, f->blobs_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt);
+    launch_observe(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt);
   }
   f->src_identity = true;
   if (ids_out && B > 0) {
@@ -702,25 +872,29 @@ int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out)
   if ((rc = use_device(f))) return rc;
   for (int i = 0; i < 4 * B; ++i)
     if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_associate: blob %d is not finite", i / 4);
-  if ((rc = ensure_blob_capacity(f, B))) return rc;
-  if ((rc = ensure_ids_capacity(f, B))) return rc;
-  const size_t o_dir = (size_t)B * 4 * sizeof(double);
-  unsigned char* st = nullptr;
-  int slot = 0;
-  if ((rc = take_stage(f, o_dir + (size_t)B * 2 * sizeof(double), &st, &slot))) return rc;
-  memcpy(st, blobs, o_dir);
-  double* dir = reinterpret_cast<double*>(st + o_dir);
-  blob_directions(blobs, B, dir);
-  PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_dir, hipMemcpyHostToDevice, f->stream));
-  PK_HIP(hipMemcpyAsync(f->blobdir_dev, dir, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
-  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
-  {
-    Span t(f, PK_T_ASSOC);
-    launch_assoc(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, f->ids_dev);
-  }
+  if ((rc = enqueue_association(f, blobs, B, true))) return rc;
   PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
   PK_HIP(hipStreamSynchronize(f->stream));
   return PK_OK;
+}
+
+int pk_set_option(pk_filter* f, const char* name, int64_t value) {
+  if (!f || !name) return fail(PK_ERR_INVALID, "pk_set_option: NULL argument");
+  if (!strcmp(name, "assoc_kernel")) {
+    if (value != 0 && value != 1) return fail(PK_ERR_INVALID, "assoc_kernel: 0 (colour grid) or 1 (brute force)");
+    f->assoc_kernel = (int)value;
+    return PK_OK;
+  }
+  if (!strcmp(name, "assoc_dup")) {
+    f->assoc_dup = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "observe_landmarks_per_lane")) {
+    if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "observe_landmarks_per_lane: 0 (default), 1 or 2");
+    g_observe_nv = (int)value;
+    return PK_OK;
+  }
+  return fail(PK_ERR_INVALID, "pk_set_option: unknown option '%s'", name);
 }
 
 int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestors_out) {
@@ -845,6 +1019,13 @@ int pk_probe(int32_t device, const double pose[3], const double mean[5], const d
   if (e != hipSuccess) return fail(PK_ERR_HIP, "pk_probe: %s", hipGetErrorString(e));
   return PK_OK;
 }
+
+#ifdef PK_STAMPS
+__attribute__((visibility("default"))) int pk_debug_stamps(unsigned long long* out, int reset) {
+  pk::debug_read_stamps(out, reset != 0);
+  return PK_OK;
+}
+#endif
 
 // ---- instrumentation ----------------------------------------------------------------------
 int pk_enable_timing(pk_filter* f, int32_t on) {

@@ -218,7 +218,7 @@ __device__ __forceinline__ void assoc_pass(const AssocArgs& a, const double* f, 
   }
 }
 
-__global__ void __launch_bounds__(256) k_assoc(AssocArgs a) {
+__global__ void __launch_bounds__(256) k_assoc_brute(AssocArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
   int* bid = reinterpret_cast<int*>(best + a.B);
@@ -240,8 +240,8 @@ __global__ void __launch_bounds__(256) k_assoc(AssocArgs a) {
     a.ids[(size_t)p * a.B + b] = best[b] != 0ull ? bid[b] + 1 : 0;
 }
 
-void launch_assoc(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
-                  int32_t* ids_dev) {
+void launch_assoc_brute(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
+                        int32_t* ids_dev) {
   if (d.P == 0 || B == 0) return;
   AssocArgs a;
   a.map = d.map[d.mcur];
@@ -258,7 +258,435 @@ void launch_assoc(hipStream_t s, DeviceState& d, const double* blobs_dev, const 
   a.Lp = d.lay.Lp;
   a.B = B;
   size_t lds = (size_t)B * 12;
-  hipLaunchKernelGGL(k_assoc, dim3((unsigned)d.P), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k_assoc_brute, dim3((unsigned)d.P), dim3(256), lds, s, a);
+}
+
+
+// ------------------------------------------------------------------ K2 (grid)
+// Persistent workgroups: the scan tables are staged in LDS once per workgroup and reused for
+// every particle the workgroup processes.  Blobs are handled in cell order (index t); the
+// scan order b = order[t] only matters on write-out.
+//
+// Per particle:
+//   S1 (lanes over landmarks, means only = 40 B/landmark of HBM):
+//      phase 1 (LDS only): the blobs that can pass the colour gate of a landmark lie in the
+//        <= 27 colour cells around it.  With the 9x column-duplicated index list (DUP) that
+//        neighbourhood is ONE contiguous range; otherwise it is walked as nine ranges.  Each
+//        blob there is tested against both gates in fp32 with conservative thresholds (one
+//        ds_read_b128: r, g, b, bearing); the few survivors are kept in registers.
+//      phase 2 (global, convergent): the exact float64 records of all survivors of all lanes
+//        are loaded together, then the exact gates (:433, :441) decide.  A landmark that
+//        passes both gates of blob t is appended to t's candidate list (4 slots + a count).
+//   S2 (lanes over blobs): 0 candidates -> id 0.  1 candidate -> that landmark, TENTATIVELY:
+//      the match stands iff its probability is > 0, which k_observe decides with the landmark
+//      state it has in registers anyway (the reference's strict '>' from 0.0, :369-381).
+//      2..4 candidates -> queued for S3; more -> queued for S4.
+//   S3 (lanes over contested blobs): evaluate their probabilities exactly in landmark order,
+//      keep the largest, the earliest landmark on a tie, none if all are 0.
+//   S4 (rare; lanes over blobs with > 4 gate-passers): the reference's own loop -- every
+//      landmark in order, strict '>' -- so any number of contenders and ties come out right.
+struct AssocGridArgs {
+  AssocArgs a;  // a.blobs / a.blobdir unused here
+  BlobGrid g;
+  const unsigned char* tables;  // see blob_grid_table_bytes
+  const double* exact;          // [B][6] in cell order: bearing, r, g, b, ux, uy
+  int64_t P;
+  int finalize;  // 1: also settle single-candidate blobs here (pk_associate), not in k_observe
+  int n9;        // DUP: entries of the duplicated index list (padded to 8)
+};
+
+// tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
+// `start` is cell_start (offsets into rec32) or, with DUP, col_start (offsets into idx9).
+__host__ __device__ inline size_t grid_cs_bytes(int ncell) { return ((size_t)(ncell + 1) * 2 + 15) & ~(size_t)15; }
+size_t blob_grid_table_bytes(int ncell, int B, int n9) {
+  return grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + (size_t)B * 2;
+}
+
+__device__ __forceinline__ Landmark<double> load_landmark_nocount(const double* f, int Lp, int l) {
+  Landmark<double> m;
+  m.mx = f[F_MX * Lp + l];
+  m.my = f[F_MY * Lp + l];
+  m.mr = f[F_MR * Lp + l];
+  m.mg = f[F_MG * Lp + l];
+  m.mb = f[F_MB * Lp + l];
+  m.pxx = f[F_PXX * Lp + l];
+  m.pxy = f[F_PXY * Lp + l];
+  m.pyy = f[F_PYY * Lp + l];
+  m.crr = f[F_CRR * Lp + l];
+  m.crg = f[F_CRG * Lp + l];
+  m.crb = f[F_CRB * Lp + l];
+  m.cgg = f[F_CGG * Lp + l];
+  m.cgb = f[F_CGB * Lp + l];
+  m.cbb = f[F_CBB * Lp + l];
+  m.count = 0;
+  return m;
+}
+
+// probability_of_match (:383-455) of landmark l for the blob record rec = (bearing, r, g, b, ux, uy)
+__device__ __forceinline__ double full_match_probability(const double* f, int Lp, int l, double sx, double sy,
+                                                         double sh, const double* rec) {
+  const Landmark<double> lm = load_landmark_nocount(f, Lp, l);
+  BlobT<double> z{rec[0], rec[1], rec[2], rec[3]};
+  return probability_of_match(lm, sx, sy, sh, z, rec[4], rec[5]);
+}
+
+constexpr int kCand = 4;
+
+// Diagnostic build only (-DPK_STAMPS, never shipped): per-phase cycle sums of k_assoc_grid.
+#ifdef PK_STAMPS
+__device__ unsigned long long pk_stamp_acc[16];
+#define PK_STAMP(var) \
+  unsigned long long var; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
+#define PK_STAMP_ADD(slot, a, b) \
+  if ((threadIdx.x & 63) == 0) atomicAdd(&pk_stamp_acc[slot], (b) - (a));
+#else
+#define PK_STAMP(var)
+#define PK_STAMP_ADD(slot, a, b)
+#endif
+
+template <int THREADS, bool DUP>
+__global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int n_few, n_many;
+  __shared__ unsigned long long s3_best[THREADS / 4];
+  __shared__ int s3_win[THREADS / 4];
+  const AssocArgs& a = ga.a;
+  const BlobGrid& g = ga.g;
+  const int B = a.B;
+  const size_t cs_bytes = grid_cs_bytes(g.ncell);
+  const size_t tab_bytes = cs_bytes + (size_t)B * 16 + (DUP ? (size_t)ga.n9 * 2 : 0);  // the part kept in LDS
+  const unsigned short* start = reinterpret_cast<const unsigned short*>(smem);
+  const float4* rec32 = reinterpret_cast<const float4*>(smem + cs_bytes);
+  const unsigned short* idx9 = reinterpret_cast<const unsigned short*>(smem + cs_bytes + (size_t)B * 16);
+  int* ccount = reinterpret_cast<int*>(smem + tab_bytes);  // [B] gate-passing landmarks of blob t; then the result
+  unsigned short* cand = reinterpret_cast<unsigned short*>(ccount + B);  // [B][4] first four of them (arrival order)
+  unsigned short* queue = cand + 4 * (size_t)B;  // [B] contested blobs (2..4 from the front, > 4 from the end)
+  int* result = ccount;
+  const unsigned short* order =
+      reinterpret_cast<const unsigned short*>(ga.tables + cs_bytes + (size_t)B * 16 + (size_t)ga.n9 * 2);  // global
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(ga.tables);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (size_t i = threadIdx.x; i < tab_bytes / 16; i += THREADS) dst[i] = src[i];
+  }
+  for (int64_t p = blockIdx.x; p < ga.P; p += gridDim.x) {
+    const unsigned char* slot = a.map + (size_t)a.src[p] * a.slot_bytes;
+    const double* f = reinterpret_cast<const double*>(slot);
+    const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
+    PK_STAMP(ts0)
+    for (int t = threadIdx.x; t < B; t += THREADS) ccount[t] = 0;
+    if (threadIdx.x == 0) {
+      n_few = 0;
+      n_many = 0;
+    }
+    __syncthreads();
+    PK_STAMP(ts1)
+    PK_STAMP_ADD(0, ts0, ts1)
+    // ---- S1 ------------------------------------------------------------------------------
+    // software pipeline: the means of the NEXT landmark are in flight while this one is searched
+    int l = threadIdx.x;
+    double nmx = 0, nmy = 0, nmr = 0, nmg = 0, nmb = 0;
+    if (l < a.L) {
+      nmx = f[F_MX * a.Lp + l];
+      nmy = f[F_MY * a.Lp + l];
+      nmr = f[F_MR * a.Lp + l];
+      nmg = f[F_MG * a.Lp + l];
+      nmb = f[F_MB * a.Lp + l];
+    }
+    for (; l < a.L; l += THREADS) {
+      const double mx = nmx, my = nmy, mr = nmr, mg = nmg, mb = nmb;
+      const int ln = l + THREADS;
+      if (ln < a.L) {
+        nmx = f[F_MX * a.Lp + ln];
+        nmy = f[F_MY * a.Lp + ln];
+        nmr = f[F_MR * a.Lp + ln];
+        nmg = f[F_MG * a.Lp + ln];
+        nmb = f[F_MB * a.Lp + ln];
+      }
+      PK_STAMP(ta0)
+      const double eb = atan2(my - sy, mx - sx) - sh;  // :408
+      const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
+      // same cell function as the host (floor((v - lo) * inv_h)): inside the colour gate
+      // |dv| <= 17.3205 < 17.5, so the cell indices of blob and landmark differ by at most
+      // one.  -1 / G mean "outside the grid": only the edge cell can hold a neighbour.
+      int c[3];
+      const double m3[3] = {mr, mg, mb};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double q = floor(__dmul_rn(__dsub_rn(m3[k], g.lo[k]), g.inv_h));
+        q = fmin(fmax(q, -1.0), (double)g.G[k]);
+        c[k] = (int)q;
+      }
+      const int k0 = max(c[2] - 1, 0), k1 = min(c[2] + 1, g.G[2] - 1);
+      int pc[kCand];
+      int npc = 0;
+      PK_STAMP(ta1)
+      PK_STAMP_ADD(1, ta0, ta1)
+      auto prefilter = [&](int t) {
+        const float4 q = rec32[t];
+        const float d0 = q.x - mr32, d1 = q.y - mg32, d2 = q.z - mb32;
+        const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
+        // conservative fp32 gates; NaN/inf fall through to the exact float64 tests
+        return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
+      };
+      auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
+        if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
+          const int n = atomicAdd(&ccount[tt], 1);
+          if (n < 4) cand[4 * tt + n] = (unsigned short)l;
+        }
+      };
+      // ---- phase 1 (LDS only) ---------------------------------------------------------
+      if (DUP) {
+        // column (r, g) clamped into the grid: its list holds every blob within one cell in r
+        // and g, ordered by the b cell, so [k0, k1] is one contiguous range
+        const int r = min(max(c[0], 0), g.G[0] - 1), gg = min(max(c[1], 0), g.G[1] - 1);
+        const int base = (r * g.G[1] + gg) * g.G[2];
+        int i = 0, i1 = 0;
+        if (k0 <= k1) {
+          i = start[base + k0];
+          i1 = start[base + k1 + 1];
+        }
+        int tnext = i < i1 ? (int)idx9[i] : 0;
+        for (; i < i1; ++i) {
+          const int t = tnext;
+          if (i + 1 < i1) tnext = idx9[i + 1];
+          if (prefilter(t)) {
+#pragma unroll
+            for (int k = 0; k < kCand; ++k)
+              if (npc == k) pc[k] = t;
+            ++npc;
+          }
+        }
+      } else {
+        // flattened walk over the 9 (r, g) columns x [k0, k1]; j = next column, [t, t1) = open range
+        int j = (k0 <= k1) ? 0 : 9, t = 0, t1 = 0;
+        for (;;) {
+          if (t >= t1) {
+            if (j >= 9) break;
+            const int jr = (j * 11) >> 5;  // j / 3 for j < 9
+            const int r = c[0] - 1 + jr, gg = c[1] - 1 + (j - 3 * jr);
+            ++j;
+            if ((unsigned)r >= (unsigned)g.G[0] || (unsigned)gg >= (unsigned)g.G[1]) continue;
+            const int base = (r * g.G[1] + gg) * g.G[2];
+            t = start[base + k0];
+            t1 = start[base + k1 + 1];
+            if (t >= t1) continue;
+          }
+          if (prefilter(t)) {
+#pragma unroll
+            for (int k = 0; k < kCand; ++k)
+              if (npc == k) pc[k] = t;
+            ++npc;
+          }
+          ++t;
+        }
+      }
+      PK_STAMP(ta2)
+      PK_STAMP_ADD(2, ta1, ta2)
+      // ---- phase 2 (global, convergent): all survivors' exact records in one batch -----
+      if (__any(npc > 0)) {
+        double2 z01[kCand], z23[kCand];
+#pragma unroll
+        for (int k = 0; k < kCand; ++k)
+          if (npc > k) {
+            const double* rec = ga.exact + 6 * (size_t)pc[k];
+            z01[k] = *reinterpret_cast<const double2*>(rec);
+            z23[k] = *reinterpret_cast<const double2*>(rec + 2);
+          }
+#pragma unroll
+        for (int k = 0; k < kCand; ++k)
+          if (npc > k) exact_gates(pc[k], z01[k], z23[k]);
+      }
+      PK_STAMP(ta3)
+      PK_STAMP_ADD(3, ta2, ta3)
+      if (npc > kCand) {
+        // more fp32 survivors than register slots (dense colour clusters): walk again and take
+        // the ones beyond the first kCand as they come (nine-range walk works for both layouts
+        // only without DUP; with DUP repeat the single range)
+        int seen = 0;
+        auto late = [&](int t) {
+          if (prefilter(t)) {
+            if (seen >= kCand) {
+              const double* rec = ga.exact + 6 * (size_t)t;
+              exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
+            }
+            ++seen;
+          }
+        };
+        if (DUP) {
+          const int r = min(max(c[0], 0), g.G[0] - 1), gg = min(max(c[1], 0), g.G[1] - 1);
+          const int base = (r * g.G[1] + gg) * g.G[2];
+          for (int i = start[base + k0], i1 = start[base + k1 + 1]; i < i1; ++i) late(idx9[i]);
+        } else {
+          for (int j = 0; j < 9; ++j) {
+            const int jr = (j * 11) >> 5;
+            const int r = c[0] - 1 + jr, gg = c[1] - 1 + (j - 3 * jr);
+            if ((unsigned)r >= (unsigned)g.G[0] || (unsigned)gg >= (unsigned)g.G[1]) continue;
+            const int base = (r * g.G[1] + gg) * g.G[2];
+            for (int t = start[base + k0], t1 = start[base + k1 + 1]; t < t1; ++t) late(t);
+          }
+        }
+      }
+    }
+    PK_STAMP(ts2)
+    __syncthreads();
+    PK_STAMP(ts3)
+    PK_STAMP_ADD(4, ts1, ts2)
+    PK_STAMP_ADD(5, ts2, ts3)
+    // ---- S2 ------------------------------------------------------------------------------
+    for (int t = threadIdx.x; t < B; t += THREADS) {
+      const int n = ccount[t];
+      if ((n == 1 && ga.finalize) || (n >= 2 && n <= 4)) queue[atomicAdd(&n_few, 1)] = (unsigned short)t;
+      if (n > 4) queue[B - 1 - atomicAdd(&n_many, 1)] = (unsigned short)t;
+    }
+    __syncthreads();
+    // blobs with exactly one gate-passer keep it (tentatively); none -> -1
+    for (int t = threadIdx.x; t < B; t += THREADS) {
+      const int n = ccount[t];
+      result[t] = n == 1 ? (int)cand[4 * t] : (n == 0 ? -1 : -(n + 1));  // contested: -(n+1) until settled
+    }
+    __syncthreads();
+    PK_STAMP(ts4)
+    PK_STAMP_ADD(6, ts3, ts4)
+    // ---- S3: 2..4 contenders (or 1 when finalising): four lanes per blob, one candidate each.
+    // atomicMax on the probability bits, then atomicMin on the landmark index among the lanes
+    // that attain it: the largest probability wins, the earliest landmark on a tie (:377),
+    // nobody if all are 0.
+    for (int base = 0; base < n_few; base += THREADS / 4) {
+      const int slot = threadIdx.x >> 2, k = threadIdx.x & 3;
+      const int qi = base + slot;
+      if (k == 0) {
+        s3_best[slot] = 0ull;
+        s3_win[slot] = INT_MAX;
+      }
+      __syncthreads();
+      int t = 0, lcand = 0;
+      unsigned long long bits = 0ull;
+      bool valid = false;
+      if (qi < n_few) {
+        t = queue[qi];
+        const int n = result[t] >= 0 ? 1 : -result[t] - 1;
+        valid = k < n;
+      }
+      if (valid) {
+        lcand = cand[4 * t + k];
+        const double pr = full_match_probability(f, a.Lp, lcand, sx, sy, sh, ga.exact + 6 * (size_t)t);
+        if (pr > 0.0) {
+          bits = (unsigned long long)__double_as_longlong(pr);
+          atomicMax(&s3_best[slot], bits);
+        }
+      }
+      __syncthreads();
+      if (valid && bits != 0ull && bits == s3_best[slot]) atomicMin(&s3_win[slot], lcand);
+      __syncthreads();
+      if (k == 0 && qi < n_few) result[t] = s3_win[slot] == INT_MAX ? -1 : s3_win[slot];
+    }
+    PK_STAMP(ts5)
+    PK_STAMP_ADD(7, ts4, ts5)
+    // ---- S4: more than four contenders: the reference's sequential scan ------------------------
+    for (int i = threadIdx.x; i < n_many; i += THREADS) {
+      const int t = queue[B - 1 - i];
+      const double* rec = ga.exact + 6 * (size_t)t;
+      const double zb = rec[0], zr = rec[1], zg = rec[2], zbl = rec[3];
+      int best = -1;
+      double pm = 0.0;
+      for (int l2 = 0; l2 < a.L; ++l2) {
+        if (fabs(color_distance2(f[F_MR * a.Lp + l2], f[F_MG * a.Lp + l2], f[F_MB * a.Lp + l2], zr, zg, zbl)) > 300.0)
+          continue;
+        const double mx = f[F_MX * a.Lp + l2], my = f[F_MY * a.Lp + l2];
+        const double eb = atan2(my - sy, mx - sx) - sh;
+        if (fabs(zb - eb) > 0.5) continue;
+        const double pr = full_match_probability(f, a.Lp, l2, sx, sy, sh, rec);
+        if (pr > pm) {
+          pm = pr;
+          best = l2;
+        }
+      }
+      result[t] = best;
+    }
+    PK_STAMP(ts6)
+    PK_STAMP_ADD(8, ts5, ts6)
+    __syncthreads();
+    for (int t = threadIdx.x; t < B; t += THREADS) a.ids[(size_t)p * B + order[t]] = result[t] + 1;
+    __syncthreads();
+    PK_STAMP(ts7)
+    PK_STAMP_ADD(9, ts6, ts7)
+  }
+}
+
+#ifdef PK_STAMPS
+void debug_read_stamps(unsigned long long* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_stamp_acc), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pk_stamp_acc), z, sizeof(z));
+  }
+}
+#endif
+
+size_t assoc_grid_lds_bytes(int ncell, int B, int n9) {
+  // start | rec32 16 B | idx9 | count/result 4 B | 4 candidates 8 B | queue 2 B   per blob
+  return grid_cs_bytes(ncell) + (size_t)B * 30 + (size_t)n9 * 2 + 16;
+}
+
+template <int THREADS, bool DUP>
+static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t lds, int64_t P) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
+    attr_set = true;
+  }
+  // persistent grid: as many workgroups as LDS and the 2048-thread CU limit allow
+  int per_cu = (int)((160 * 1024) / (lds + 64));
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  const int by_threads = 2048 / THREADS;
+  per_cu = per_cu > by_threads ? by_threads : per_cu;
+  int64_t blocks = 256 * (int64_t)per_cu;
+  if (blocks > P) blocks = P;
+  hipLaunchKernelGGL((k_assoc_grid<THREADS, DUP>), dim3((unsigned)blocks), dim3(THREADS), lds, s, ga);
+}
+
+void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev, bool finalize) {
+  if (d.P == 0 || B == 0) return;
+  AssocGridArgs ga;
+  AssocArgs& a = ga.a;
+  a.map = d.map[d.mcur];
+  a.slot_bytes = d.lay.slot_bytes;
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.h = d.h[d.cur];
+  a.blobs = nullptr;
+  a.blobdir = nullptr;
+  a.ids = ids_dev;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  ga.g = grid;
+  ga.tables = tables_dev;
+  ga.exact = exact_dev;
+  ga.P = d.P;
+  ga.finalize = finalize ? 1 : 0;
+  ga.n9 = n9;
+  const size_t lds = assoc_grid_lds_bytes(grid.ncell, B, n9);
+  // bigger workgroups when the LDS tables are large, so that a CU still holds >= 16 waves
+  const bool big = lds > 40 * 1024;
+  if (n9 > 0) {
+    if (big)
+      launch_assoc_grid_t<512, true>(s, ga, lds, d.P);
+    else
+      launch_assoc_grid_t<256, true>(s, ga, lds, d.P);
+  } else {
+    if (big)
+      launch_assoc_grid_t<512, false>(s, ga, lds, d.P);
+    else
+      launch_assoc_grid_t<256, false>(s, ga, lds, d.P);
+  }
 }
 
 // ------------------------------------------------------------------ K3 observe (EKF + weight)
@@ -270,33 +698,85 @@ struct ObserveArgs {
   const double *x, *y;
   double* logw;
   const double* blobs;   // B x 4
+  const double* blobdir; // ML: B x 2 unit ray directions (closest_point :510)
   const int32_t* first;  // KNOWN: [L] first blob matched to landmark l, or -1
   const int32_t* next;   // KNOWN: [B] next blob matched to the same landmark, or -1
-  const int32_t* ids;    // ML: [P x B]
+  int32_t* ids;          // ML: [P x B]; a tentative id whose probability is 0 is reset to 0
   const unsigned char* immutable;
   int n_unmatched;  // KNOWN: blobs with id 0
   int L, Lp, B;
   Noise<double> qt;
 };
 
+// Is probability_of_match(...) > 0 for a pair that already passed both gates (:433, :441)?
+// The association kernel leaves this to us for blobs with a single gate-passing landmark,
+// because the landmark's covariance is in registers here.  pr = (500 exp(a1)) (500 exp(a2))
+// / 250000 with a1, a2 the two log-pdfs; whenever a1 + a2 is far from the float64 underflow
+// edge the answer is known without evaluating a single exp/log; otherwise evaluate it
+// exactly as the reference does.  pse = atan2(f.my - sy, f.mx - sx).
+__device__ __forceinline__ bool match_is_positive(const Landmark<double>& f, double sx, double sy, double pse,
+                                                  const BlobT<double>& z, double ux, double uy) {
+  if (fabs(pse - z.bearing) > Consts<double>::half_pi) return false;  // :473-475 -> bp = 0
+  double nx, ny;
+  closest_point(f.mx, f.my, sx, sy, ux, uy, nx, ny);
+  const double ex = nx - f.mx, ey = ny - f.my;
+  const double det2 = f.pxx * f.pyy - f.pxy * f.pxy;
+  const double maha2 = (f.pyy * ex * ex - 2.0 * f.pxy * ex * ey + f.pxx * ey * ey) / det2;
+  double det3;
+  const Sym3<double> inv = sym3_inverse(Sym3<double>{f.crr, f.crg, f.crb, f.cgg, f.cgb, f.cbb}, det3);
+  const double maha3 = sym3_quad(inv, z.r - f.mr, z.g - f.mg, z.b - f.mb);
+  // log det <= 138.2 for det <= 1e60, so a1 + a2 >= -0.5 (9.2 + 276.4 + 800) > -543: no underflow
+  if (det2 > 0.0 && det2 < 1e60 && det3 > 0.0 && det3 < 1e60 && maha2 >= 0.0 && maha3 >= 0.0 &&
+      maha2 + maha3 < 800.0)
+    return true;
+  const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + log(det2) + maha2));
+  const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + log(det3) + maha3));
+  return bp * cp / 250000.0 > 0.0;
+}
+
+__device__ __forceinline__ BlobT<double> load_blob(const double* blobs, int b) {
+  const double2 z01 = *reinterpret_cast<const double2*>(blobs + 4 * (size_t)b);
+  const double2 z23 = *reinterpret_cast<const double2*>(blobs + 4 * (size_t)b + 2);
+  return BlobT<double>{z01.x, z01.y, z23.x, z23.y};
+}
+
+// All blobs matched to landmark l, in scan order (prkt_core_v2.py:88).
+// ML: the ids are tentative.  Association saw the state BEFORE any update (:84), so first
+// settle every blob of the chain against the untouched state (s_ids[b] = 0 drops it), then
+// apply the surviving ones sequentially.
+template <bool KNOWN>
 __device__ __forceinline__ double apply_blobs(Landmark<double>& lm, int l, double sx, double sy,
                                               const ObserveArgs& a, const int32_t* first,
-                                              const int32_t* next) {
+                                              const int32_t* next, int32_t* s_ids, int32_t* gid) {
   double acc = 0.0;
-  int b = first[l];
-  if (b < 0) return acc;
+  const int b0 = first[l];
+  if (b0 < 0) return acc;
   const bool imm = a.immutable[l] != 0;
-  while (b >= 0) {
-    const double2 z01 = *reinterpret_cast<const double2*>(a.blobs + 4 * (size_t)b);
-    const double2 z23 = *reinterpret_cast<const double2*>(a.blobs + 4 * (size_t)b + 2);
-    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
-    acc += ekf_update(lm, sx, sy, z, a.qt, imm);
-    b = next[b];
+  const double pse = atan2(lm.my - sy, lm.mx - sx);
+  if (!KNOWN) {
+    for (int b = b0; b >= 0; b = next[b]) {
+      const BlobT<double> z = load_blob(a.blobs, b);
+      const double2 dir = *reinterpret_cast<const double2*>(a.blobdir + 2 * (size_t)b);
+      if (!match_is_positive(lm, sx, sy, pse, z, dir.x, dir.y)) {
+        s_ids[b] = 0;
+        gid[b] = 0;
+      }
+    }
+  }
+  bool fresh = true;  // lm still equals the state pse was computed from
+  for (int b = b0; b >= 0; b = next[b]) {
+    if (!KNOWN && s_ids[b] == 0) {
+      acc += Consts<double>::log_no_match;  // unseen feature: weight *= 0.1 (:94-95)
+      continue;
+    }
+    const BlobT<double> z = load_blob(a.blobs, b);
+    acc += ekf_update(lm, sx, sy, z, a.qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+    fresh = imm;
   }
   return acc;
 }
 
-template <bool KNOWN>
+template <bool KNOWN, int NV>
 __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kObsThreads / kWave];
@@ -315,6 +795,8 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   const int32_t* first = a.first;
   const int32_t* next = a.next;
   int n_unmatched = a.n_unmatched;
+  int32_t* gid_mut = KNOWN ? nullptr : a.ids + (size_t)p * a.B;
+  int32_t* s_ids_mut = nullptr;
   if (!KNOWN) {
     // Build the per-particle landmark -> blob chains in LDS from this particle's ids.
     // Blobs are applied in scan order (prkt_core_v2.py:88): first[l] is the lowest blob
@@ -322,7 +804,8 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
     int32_t* s_first = reinterpret_cast<int32_t*>(smem);
     int32_t* s_next = s_first + Lp;
     int32_t* s_ids = s_next + a.B;
-    const int32_t* gid = a.ids + (size_t)p * a.B;
+    s_ids_mut = s_ids;
+    const int32_t* gid = gid_mut;
     for (int l = tid; l < Lp; l += blockDim.x) s_first[l] = INT_MAX;
     for (int b = tid; b < a.B; b += blockDim.x) {
       s_ids[b] = gid[b];
@@ -357,32 +840,56 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   }
 
   double acc = 0.0;
-  for (int l0 = 2 * tid; l0 < Lp; l0 += 2 * kObsThreads) {
-    double2 v[F_COUNT_FIELDS];
+  if (NV == 2) {
+    // two adjacent landmarks per lane: 16-byte loads/stores, 14 rows x 1 KiB per wave instruction
+    for (int l0 = 2 * tid; l0 < Lp; l0 += 2 * kObsThreads) {
+      double2 v[F_COUNT_FIELDS];
 #pragma unroll
-    for (int f = 0; f < F_COUNT_FIELDS; ++f) v[f] = *reinterpret_cast<const double2*>(sf + (size_t)f * Lp + l0);
-    int2 c = *reinterpret_cast<const int2*>(sc + l0);
-    Landmark<double> A{v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x,
-                       v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, c.x};
-    Landmark<double> Bq{v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y,
-                        v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, c.y};
-    if (l0 < a.L) acc += apply_blobs(A, l0, sx, sy, a, first, next);
-    if (l0 + 1 < a.L) acc += apply_blobs(Bq, l0 + 1, sx, sy, a, first, next);
-    *reinterpret_cast<double2*>(df + (size_t)F_MX * Lp + l0) = make_double2(A.mx, Bq.mx);
-    *reinterpret_cast<double2*>(df + (size_t)F_MY * Lp + l0) = make_double2(A.my, Bq.my);
-    *reinterpret_cast<double2*>(df + (size_t)F_MR * Lp + l0) = make_double2(A.mr, Bq.mr);
-    *reinterpret_cast<double2*>(df + (size_t)F_MG * Lp + l0) = make_double2(A.mg, Bq.mg);
-    *reinterpret_cast<double2*>(df + (size_t)F_MB * Lp + l0) = make_double2(A.mb, Bq.mb);
-    *reinterpret_cast<double2*>(df + (size_t)F_PXX * Lp + l0) = make_double2(A.pxx, Bq.pxx);
-    *reinterpret_cast<double2*>(df + (size_t)F_PXY * Lp + l0) = make_double2(A.pxy, Bq.pxy);
-    *reinterpret_cast<double2*>(df + (size_t)F_PYY * Lp + l0) = make_double2(A.pyy, Bq.pyy);
-    *reinterpret_cast<double2*>(df + (size_t)F_CRR * Lp + l0) = make_double2(A.crr, Bq.crr);
-    *reinterpret_cast<double2*>(df + (size_t)F_CRG * Lp + l0) = make_double2(A.crg, Bq.crg);
-    *reinterpret_cast<double2*>(df + (size_t)F_CRB * Lp + l0) = make_double2(A.crb, Bq.crb);
-    *reinterpret_cast<double2*>(df + (size_t)F_CGG * Lp + l0) = make_double2(A.cgg, Bq.cgg);
-    *reinterpret_cast<double2*>(df + (size_t)F_CGB * Lp + l0) = make_double2(A.cgb, Bq.cgb);
-    *reinterpret_cast<double2*>(df + (size_t)F_CBB * Lp + l0) = make_double2(A.cbb, Bq.cbb);
-    *reinterpret_cast<int2*>(dc + l0) = make_int2(A.count, Bq.count);
+      for (int f = 0; f < F_COUNT_FIELDS; ++f) v[f] = *reinterpret_cast<const double2*>(sf + (size_t)f * Lp + l0);
+      int2 c = *reinterpret_cast<const int2*>(sc + l0);
+      Landmark<double> A{v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x,
+                         v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, c.x};
+      Landmark<double> Bq{v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y,
+                          v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, c.y};
+      if (l0 < a.L) acc += apply_blobs<KNOWN>(A, l0, sx, sy, a, first, next, s_ids_mut, gid_mut);
+      if (l0 + 1 < a.L) acc += apply_blobs<KNOWN>(Bq, l0 + 1, sx, sy, a, first, next, s_ids_mut, gid_mut);
+      *reinterpret_cast<double2*>(df + (size_t)F_MX * Lp + l0) = make_double2(A.mx, Bq.mx);
+      *reinterpret_cast<double2*>(df + (size_t)F_MY * Lp + l0) = make_double2(A.my, Bq.my);
+      *reinterpret_cast<double2*>(df + (size_t)F_MR * Lp + l0) = make_double2(A.mr, Bq.mr);
+      *reinterpret_cast<double2*>(df + (size_t)F_MG * Lp + l0) = make_double2(A.mg, Bq.mg);
+      *reinterpret_cast<double2*>(df + (size_t)F_MB * Lp + l0) = make_double2(A.mb, Bq.mb);
+      *reinterpret_cast<double2*>(df + (size_t)F_PXX * Lp + l0) = make_double2(A.pxx, Bq.pxx);
+      *reinterpret_cast<double2*>(df + (size_t)F_PXY * Lp + l0) = make_double2(A.pxy, Bq.pxy);
+      *reinterpret_cast<double2*>(df + (size_t)F_PYY * Lp + l0) = make_double2(A.pyy, Bq.pyy);
+      *reinterpret_cast<double2*>(df + (size_t)F_CRR * Lp + l0) = make_double2(A.crr, Bq.crr);
+      *reinterpret_cast<double2*>(df + (size_t)F_CRG * Lp + l0) = make_double2(A.crg, Bq.crg);
+      *reinterpret_cast<double2*>(df + (size_t)F_CRB * Lp + l0) = make_double2(A.crb, Bq.crb);
+      *reinterpret_cast<double2*>(df + (size_t)F_CGG * Lp + l0) = make_double2(A.cgg, Bq.cgg);
+      *reinterpret_cast<double2*>(df + (size_t)F_CGB * Lp + l0) = make_double2(A.cgb, Bq.cgb);
+      *reinterpret_cast<double2*>(df + (size_t)F_CBB * Lp + l0) = make_double2(A.cbb, Bq.cbb);
+      *reinterpret_cast<int2*>(dc + l0) = make_int2(A.count, Bq.count);
+    }
+  } else {
+    // one landmark per lane: half the registers, twice the waves in flight
+    for (int l = tid; l < Lp; l += kObsThreads) {
+      Landmark<double> A = load_landmark(sf, sc, Lp, l);
+      if (l < a.L) acc += apply_blobs<KNOWN>(A, l, sx, sy, a, first, next, s_ids_mut, gid_mut);
+      df[(size_t)F_MX * Lp + l] = A.mx;
+      df[(size_t)F_MY * Lp + l] = A.my;
+      df[(size_t)F_MR * Lp + l] = A.mr;
+      df[(size_t)F_MG * Lp + l] = A.mg;
+      df[(size_t)F_MB * Lp + l] = A.mb;
+      df[(size_t)F_PXX * Lp + l] = A.pxx;
+      df[(size_t)F_PXY * Lp + l] = A.pxy;
+      df[(size_t)F_PYY * Lp + l] = A.pyy;
+      df[(size_t)F_CRR * Lp + l] = A.crr;
+      df[(size_t)F_CRG * Lp + l] = A.crg;
+      df[(size_t)F_CRB * Lp + l] = A.crb;
+      df[(size_t)F_CGG * Lp + l] = A.cgg;
+      df[(size_t)F_CGB * Lp + l] = A.cgb;
+      df[(size_t)F_CBB * Lp + l] = A.cbb;
+      dc[l] = A.count;
+    }
   }
   double tot = block_sum<kObsThreads / kWave>(acc, red);
   if (tid == 0) {
@@ -391,8 +898,11 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   }
 }
 
-void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, int B, const int32_t* first_dev,
-                    const int32_t* next_dev, int n_unmatched, const int32_t* ids_dev, const NoiseD& qt) {
+int g_observe_nv = 0;  // tuning: 0 = default per variant, 1 / 2 = landmarks per lane
+
+void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
+                    const int32_t* first_dev, const int32_t* next_dev, int n_unmatched, int32_t* ids_dev,
+                    const NoiseD& qt) {
   if (d.P == 0) return;
   ObserveArgs a;
   a.map_src = d.map[d.mcur];
@@ -404,6 +914,7 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, int 
   a.y = d.y[d.cur];
   a.logw = d.logw[d.cur];
   a.blobs = blobs_dev;
+  a.blobdir = blobdir_dev;
   a.first = first_dev;
   a.next = next_dev;
   a.ids = ids_dev;
@@ -414,10 +925,16 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, int 
   a.B = B;
   a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
   if (ids_dev == nullptr) {
-    hipLaunchKernelGGL(k_observe<true>, dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
+    if (g_observe_nv == 1)
+      hipLaunchKernelGGL((k_observe<true, 1>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_observe<true, 2>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
   } else {
     size_t lds = sizeof(int32_t) * ((size_t)d.lay.Lp + 2 * (size_t)B);
-    hipLaunchKernelGGL(k_observe<false>, dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
+    if (g_observe_nv == 2)
+      hipLaunchKernelGGL((k_observe<false, 2>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
+    else
+      hipLaunchKernelGGL((k_observe<false, 1>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
   }
   d.mcur ^= 1;
 }

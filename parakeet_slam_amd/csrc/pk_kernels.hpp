@@ -35,13 +35,39 @@ void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt,
                    uint64_t seed, uint64_t draw, int64_t global_offset);
 void launch_reset_weights(hipStream_t s, DeviceState& d);
 // K2: maximum-likelihood association -> ids[P*B]
-void launch_assoc(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev,
-                  int B, int32_t* ids_dev);
+// (a) reference kernel: every (landmark, blob) pair is gate-tested
+void launch_assoc_brute(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev,
+                        int B, int32_t* ids_dev);
+// (b) production kernel: blobs bucketed on the host into a 3-D colour grid whose cell edge
+// exceeds the colour gate radius sqrt(300), so a landmark only meets the blobs of its 27
+// neighbouring cells.  Tables (device): start u16[ncell+1] (16-byte padded) | rec32
+// float4[B] = (r, g, b, bearing) in cell order | idx9 u16[n9] | order u16[B]; exact records
+// double[B][6] = (bearing, r, g, b, ux, uy) in cell order.  With n9 > 0, idx9 lists for every
+// (r, g) column the blobs within one cell in r and g, ordered by b cell, and `start` indexes
+// it: a landmark's whole 27-cell neighbourhood is then one contiguous range.
+struct BlobGrid {
+  double lo[3];
+  double inv_h;
+  int G[3];
+  int ncell;
+  float thr32;   // conservative fp32 pre-filter threshold for the colour gate (300)
+  float thrb32;  // conservative fp32 pre-filter threshold for the bearing gate (0.5)
+};
+constexpr double kGridCell = 17.5;  // > sqrt(300) = 17.3205 (prkt_core_v2.py:441)
+constexpr int kGridMax = 16;
+size_t blob_grid_table_bytes(int ncell, int B, int n9);
+size_t assoc_grid_lds_bytes(int ncell, int B, int n9);
+constexpr size_t kMaxDynLds = 160 * 1024 - 256;
+void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev,
+                       bool finalize);
 // K3: EKF update + log-weight.  known: first/next chains shared by all particles (device
 // arrays, built on the host); otherwise built per particle in LDS from ids_dev.
-void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, int B,
+// ML ids are TENTATIVE: k_observe keeps a match only if its probability is > 0 (needs blobdir).
+void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
                     const int32_t* first_dev, const int32_t* next_dev, int n_unmatched,
-                    const int32_t* ids_dev, const NoiseD& qt);
+                    int32_t* ids_dev, const NoiseD& qt);
+extern int g_observe_nv;
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);
 void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, int domain,

@@ -164,9 +164,11 @@ struct EkfAux {
 template <typename T>
 __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<T>& z,
                                         const Noise<T>& qt, bool immutable,
-                                        EkfAux<T>* aux = nullptr) {
+                                        EkfAux<T>* aux = nullptr, const T* zhat0_known = nullptr) {
   T dx = f.mx - sx, dy = f.my - sy;
-  T zhat0 = atan2(dy, dx);  // :871 world frame: the heading is NOT subtracted here
+  // :871 world frame: the heading is NOT subtracted here.  A caller that already holds
+  // atan2(dy, dx) for this very state passes it in (one float64 atan2 saved).
+  T zhat0 = zhat0_known ? *zhat0_known : atan2(dy, dx);
   T q = dx * dx + dy * dy;  // :785
   T h0, h1;                 // :789/:795 -- (dy/q, dx/q): the reference's signs, not the textbook's
   if (q == T(0)) {          // ZeroDivisionError branch :790,:796

@@ -1,0 +1,27 @@
+"""Diagnostic: per-phase cycle shares of k_assoc_grid from the -DPK_STAMPS build."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from parakeet_slam_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "parakeet_slam_amd", "libparakeet_slam_stamps.so")
+sys.argv = [sys.argv[0]] + sys.argv[1:]
+import bench
+P = int(os.environ.get("ST_P", 10000)); L = int(os.environ.get("ST_L", 500))
+means, covs, scans = bench.synthetic_inputs(L, 6)
+f = _lib.DeviceFilter(P, L)
+f.upload_map(means, covs.reshape(L, 25))
+so = _lib.load()
+so.pk_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+buf = (ctypes.c_ulonglong * 16)()
+for s in range(3):
+    f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
+f.synchronize(); so.pk_debug_stamps(buf, 1)
+for s in range(3, 6):
+    f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
+f.synchronize(); so.pk_debug_stamps(buf, 1)
+v = np.array(list(buf), dtype=np.float64)
+names = ["init+sync", "S1 atan2+cell", "S1 phase1 walk", "S1 phase2 exact", "S1 total", "S1 barrier wait", "S2", "S3", "S4", "writeout"]
+tot = v[0] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9]
+for i, n in enumerate(names):
+    print("%-18s %12.4g  %5.1f%%" % (n, v[i], 100 * v[i] / tot))

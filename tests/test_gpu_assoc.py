@@ -1,0 +1,169 @@
+"""GPU: maximum-likelihood data association (match_features_to_scan, prkt_core_v2.py:317-381).
+The colour-grid kernel, the brute-force reference kernel and the NumPy oracle must return
+identical ids, including on inputs built to stress the grid: ties between identical
+landmarks, many blobs on one landmark, colours far outside / at the edge of the blob grid,
+clustered colours (everything in one cell), and more than one landmark per thread."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.fastslam_oracle import OracleFilter, synthetic_scan, synthetic_world
+
+pytestmark = pytest.mark.gpu
+
+
+def device_ids(lib, P, means, covs, poses, blobs, kernel):
+    L = means.shape[0]
+    f = lib.DeviceFilter(P, L)
+    f.set_option("assoc_kernel", kernel)
+    f.upload_map(means, covs.reshape(L, 25))
+    f.upload_poses(poses)
+    ids = f.associate(blobs)
+    f.close()
+    return ids
+
+
+def oracle_ids(P, means, covs, poses, blobs):
+    o = OracleFilter(P, means, covs)
+    o.x, o.y, o.h = poses[:, 0].copy(), poses[:, 1].copy(), poses[:, 2].copy()
+    return o.associate(blobs)
+
+
+def check(lib, P, means, covs, poses, blobs, expect_unmatched=None):
+    ref = oracle_ids(P, means, covs, poses, blobs)
+    g = device_ids(lib, P, means, covs, poses, blobs, 0)
+    b = device_ids(lib, P, means, covs, poses, blobs, 1)
+    assert np.array_equal(b, ref), "brute-force kernel differs from the oracle"
+    assert np.array_equal(g, ref), "grid kernel differs from the oracle"
+    if expect_unmatched is not None:
+        assert (ref == 0).any() == expect_unmatched
+    return ref
+
+
+def rand_poses(rs, P, spread=0.3):
+    poses = np.zeros((P, 4))
+    poses[:, 0] = rs.normal(0, spread, P)
+    poses[:, 1] = rs.normal(0, spread, P)
+    poses[:, 2] = rs.normal(0, 0.05, P)
+    poses[:, 3] = 1.0
+    return poses
+
+
+@pytest.mark.parametrize("L", [1, 7, 50, 300, 700])
+def test_synthetic_ring(lib, L):
+    rs = np.random.RandomState(L)
+    means, covs = synthetic_world(L)
+    P = 64
+    poses = rand_poses(rs, P)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    ids = check(lib, P, means, covs, poses, blobs)
+    assert (ids > 0).mean() > 0.5
+
+
+def test_ties_between_identical_landmarks_keep_the_earliest(lib):
+    means, covs = synthetic_world(12)
+    means = np.vstack([means, means[3:6], means[3:6]])  # landmarks 13-15 and 16-18 duplicate 4-6
+    covs = np.vstack([covs, covs[3:6], covs[3:6]])
+    poses = rand_poses(np.random.RandomState(1), 32)
+    blobs = synthetic_scan(means[:12], (0.0, 0.0, 0.0))
+    ids = check(lib, 32, means, covs, poses, blobs)
+    assert set(np.unique(ids[:, 3:6])) <= {0, 4, 5, 6}  # never the later duplicates
+
+
+def test_many_blobs_on_one_landmark_and_strays(lib):
+    rs = np.random.RandomState(2)
+    means, covs = synthetic_world(40)
+    scan = synthetic_scan(means, (0.0, 0.0, 0.0))
+    dup = np.repeat(scan[5:6], 9, axis=0)
+    dup[:, 0] += rs.uniform(-0.05, 0.05, 9)
+    dup[:, 1:] += rs.uniform(-3, 3, (9, 3))
+    strays = np.column_stack([rs.uniform(-3, 3, 6), rs.uniform(0, 255, (6, 3))])
+    blobs = np.vstack([scan, dup, strays])
+    ids = check(lib, 48, means, covs, rand_poses(rs, 48), blobs)
+    assert (ids[:, 40:49] == 6).mean() > 0.9
+
+
+def test_all_colours_equal_everything_contested(lib):
+    # every blob passes the colour gate of every landmark: the contested second sweep decides
+    rs = np.random.RandomState(3)
+    L = 90
+    means, covs = synthetic_world(L)
+    means[:, 2:] = 100.0
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    check(lib, 40, means, covs, rand_poses(rs, 40, 0.1), blobs)
+
+
+def test_colours_outside_and_at_the_edge_of_the_grid(lib):
+    rs = np.random.RandomState(4)
+    L = 60
+    means, covs = synthetic_world(L)
+    means[:20, 2:] = rs.uniform(-500, -400, (20, 3))      # far below every other colour
+    means[20:40, 2:] = rs.uniform(900, 1500, (20, 3))      # beyond 16 cells: clamped cells
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    blobs[::3, 1:] += rs.uniform(-9.9, 9.9, (len(blobs[::3]), 3))  # cross cell borders, stay in the gate
+    blobs[1::3, 1] += 17.3  # just inside the gate along one channel (17.3^2 = 299.29)
+    far = blobs[:5].copy()
+    far[:, 1:] += 1e6  # landmark colours far outside the blob range never match
+    means2 = means.copy()
+    means2[55:, 2:] += 1e7
+    check(lib, 32, means2, covs, rand_poses(rs, 32, 0.1), np.vstack([blobs, far]), expect_unmatched=True)
+
+
+def test_gate_boundaries(lib):
+    # bearing gate 0.5 rad (:433) and colour gate 300 (:441) straddled on both sides
+    means = np.array([[10.0, 0.0, 100, 100, 100], [0.0, 10.0, 30, 200, 60]])
+    covs = np.broadcast_to(0.25 * np.identity(5), (2, 5, 5)).copy()
+    poses = np.array([[0.0, 0.0, 0.0, 1.0]])
+    eps = 1e-9
+    rows = []
+    for db in (0.5 - eps, 0.5 + eps, -0.5 + eps, -0.5 - eps):
+        rows.append([0.0 + db, 100, 100, 100])
+    for dc in (math.sqrt(300) - 1e-9, math.sqrt(300) + 1e-9):
+        rows.append([math.pi / 2, 30 + dc, 200, 60])
+        rows.append([math.pi / 2, 30, 200 - dc, 60])
+    ids = check(lib, 1, means, covs, poses, np.array(rows))
+    assert list(ids[0]) == [1, 0, 1, 0, 2, 2, 0, 0]
+
+
+def test_probability_underflow_means_no_match(lib):
+    # tiny covariance far from the ray: pdf underflows to exactly 0 -> strict '>' never matches
+    means = np.array([[20.0, 0.0, 50, 50, 50]])
+    covs = 1e-6 * np.identity(5)[None]
+    poses = np.array([[0.0, 0.0, 0.0, 1.0]])
+    blobs = np.array([[0.3, 50, 50, 50], [0.0, 50, 50, 50]])
+    ids = check(lib, 1, means, covs, poses, blobs)
+    assert list(ids[0]) == [0, 1]
+
+
+def test_large_scan_many_landmarks_per_thread(lib):
+    rs = np.random.RandomState(6)
+    L = 1500
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.05, 0.02, 0.02))
+    g = device_ids(lib, 6, means, covs, rand_poses(rs, 6), blobs, 0)
+    b = device_ids(lib, 6, means, covs, rand_poses(np.random.RandomState(6), 6), blobs, 1)
+    assert np.array_equal(g, b)
+    ref = oracle_ids(2, means, covs, rand_poses(np.random.RandomState(6), 6)[:2], blobs)
+    assert np.array_equal(g[:2], ref)
+
+
+def test_observe_with_both_kernels_gives_identical_state(lib):
+    rs = np.random.RandomState(7)
+    L, P = 120, 200
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    poses = rand_poses(rs, P)
+    out = []
+    for k in (0, 1):
+        f = lib.DeviceFilter(P, L)
+        f.set_option("assoc_kernel", k)
+        f.upload_map(means, covs.reshape(L, 25))
+        f.upload_poses(poses)
+        ids = f.observe(blobs, return_ids=True)
+        out.append((ids, f.download_poses(), f.download_landmarks()))
+        f.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a, b)
