@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--assoc", choices=["ml", "known"], default="ml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (collectives included) even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,7 +126,13 @@ def main():
     means, covs, scans = synthetic_inputs(L, K + W)
     ids = np.arange(1, L + 1, dtype=np.int32) if args.assoc == "known" else None
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
+        import torch.distributed as dist
+
+        if not dist.is_initialized():  # --force-sharded with a single rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            dist.init_process_group("nccl", rank=0, world_size=1)
         from parakeet_slam_amd.sharded import ShardedFilter
 
         filt = ShardedFilter(P, L, device=local_rank)
@@ -199,6 +207,9 @@ def main():
                 "blobs": L,
                 "assoc": args.assoc,
                 "global_particles": P * world,
+                "parallelism": "particles sharded over %d GPU(s); RCCL all-reduce(max) + all-gather(block weight "
+                "totals) + all-to-all(migrating particles) per resample" % world if (world > 1 or args.force_sharded)
+                else "single GPU",
             },
             "roofline": {
                 "kernel": "k_observe (fused EKF update + log-weight)",

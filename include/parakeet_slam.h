@@ -155,6 +155,10 @@ int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestor
 /* FastSLAM.summary (prkt_core_v2.py:254-276): (mean x, mean y, circular mean heading). */
 int pk_summary(pk_filter* f, double out[3]);
 
+/* The four sums FastSLAM.summary reduces (prkt_core_v2.py:267-271): sum x, sum y, sum sin h,
+ * sum cos h -- what a sharded filter all-reduces before dividing / atan2. */
+int pk_pose_sums(pk_filter* f, double out[4]);
+
 /* One whole cam_cb without host synchronisation: reset weights, motion, observe,
  * resample.  Arguments as in the calls above. */
 int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed,
@@ -162,25 +166,38 @@ int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64
             int32_t weight_domain);
 
 /* ---- sharded (multi-GPU) resampling: see DESIGN.md section 6 -------------------
- * Local statistics of the shard: max logw, and (after the global max is known) the
- * block totals of exp(logw - gmax).  The collective itself is the caller's
- * (torch.distributed over RCCL); these only read/write host scalars and arrays. */
+ * Particles are sharded contiguously over one process per GPU; global particle index =
+ * global_offset + local index.  The collectives themselves are the caller's
+ * (torch.distributed over RCCL); the entry points below only read/write host scalars and
+ * arrays, plus one caller-owned device buffer for the particles that migrate.
+ * pk_set_shard: index of local particle 0 in the whole filter (keys the Philox counters so
+ * the motion noise does not depend on the shard count). */
+int pk_set_shard(pk_filter* f, int64_t global_offset);
+/* max over the shard of log(weight). */
 int pk_shard_max_logw(pk_filter* f, double* max_logw);
+/* Number of weight-scan blocks of the shard (1024 particles each) and their totals of
+ * exp(logw - gmax) (PK_WEIGHTS_LOG) or exp(logw) (PK_WEIGHTS_LINEAR); also leaves the
+ * block-local inclusive scans on the device for pk_shard_offspring. */
 int64_t pk_shard_num_blocks(const pk_filter* f);
 int pk_shard_block_totals(pk_filter* f, double gmax, int32_t weight_domain, double* totals);
-/* Given every shard's block totals concatenated in rank order (global_totals,
- * n_global_blocks), this shard's first block index and the global particle count, compute
- * for every LOCAL particle the half-open range of global output slots it fills.
- * slot_lo/slot_hi: P_local int64 each. */
+/* Given every shard's block totals concatenated in rank order, this shard's first block and
+ * the global particle count: slot_hi[0] = number of output slots filled by all earlier
+ * shards, slot_hi[1 + j] = that number after local particle j; i.e. local particle j is the
+ * ancestor of the global output slots [slot_hi[j], slot_hi[j + 1]).  Same arithmetic as
+ * pk_resample, so G shards reproduce the 1-GPU ancestors when shards are multiples of 1024.
+ * last_shard: this is the highest rank (its last particle absorbs the clamped tail). */
 int pk_shard_offspring(pk_filter* f, const double* global_totals, int64_t n_global_blocks,
-                       int64_t first_block, int64_t global_particles, double u, int64_t* slot_lo,
+                       int64_t first_block, int64_t global_particles, double u, int32_t last_shard,
                        int64_t* slot_hi);
-/* Pack the listed local particles (pose row + map slot) into a device buffer, and the
- * reverse.  dev_buf is a device pointer owned by the caller (e.g. a torch tensor). */
+/* Bytes of one migrating particle record: (x, y, heading, log weight) + its landmark slot. */
 int64_t pk_particle_bytes(const pk_filter* f);
+/* Pack the listed local particles into dev_buf (device pointer owned by the caller, e.g. a
+ * torch tensor), n records of pk_particle_bytes. */
 int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* dev_buf);
-/* New generation of the shard: slot k takes local particle src_local[k] (>= 0) or
- * received record -(src_local[k]) - 1 of dev_buf. */
+/* New generation of the shard: slot k takes local particle src[k] (>= 0) or received record
+ * -(src[k]) - 1 of dev_buf.  Poses are gathered now; adopted landmark slots are read in place
+ * from dev_buf by the next pk_observe / pk_associate / download, so dev_buf must stay alive
+ * and unchanged until one of those has run. */
 int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, int64_t n_received);
 
 /* ---- single-triple probe ------------------------------------------------------

@@ -54,12 +54,14 @@ SIGNATURES = {
     "pk_associate": (C.c_int, [_h, _dp, C.c_int32, _ip]),
     "pk_resample": (C.c_int, [_h, C.c_double, C.c_int32, _lp]),
     "pk_summary": (C.c_int, [_h, _dp]),
+    "pk_pose_sums": (C.c_int, [_h, _dp]),
     "pk_step": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64, _dp, C.c_int32,
                           _ip, C.c_double, C.c_int32]),
     "pk_shard_max_logw": (C.c_int, [_h, _dp]),
     "pk_shard_num_blocks": (C.c_int64, [_h]),
     "pk_shard_block_totals": (C.c_int, [_h, C.c_double, C.c_int32, _dp]),
-    "pk_shard_offspring": (C.c_int, [_h, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _lp, _lp]),
+    "pk_set_shard": (C.c_int, [_h, C.c_int64]),
+    "pk_shard_offspring": (C.c_int, [_h, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, _lp]),
     "pk_particle_bytes": (C.c_int64, [_h]),
     "pk_pack_particles": (C.c_int, [_h, _lp, C.c_int64, C.c_void_p]),
     "pk_adopt_particles": (C.c_int, [_h, _lp, C.c_void_p, C.c_int64]),
@@ -240,6 +242,11 @@ class DeviceFilter(object):
         check(self._lib.pk_summary(self._h, dptr(out)))
         return float(out[0]), float(out[1]), float(out[2])
 
+    def pose_sums(self):
+        out = np.empty(4, dtype=np.float64)
+        check(self._lib.pk_pose_sums(self._h, dptr(out)))
+        return out
+
     def step(self, v, w, dt, blobs, u, z=None, seed=0, draw=0, ids=None, domain=PK_WEIGHTS_LINEAR):
         b = f64(blobs).reshape(-1, 4)
         B = b.shape[0]
@@ -247,6 +254,41 @@ class DeviceFilter(object):
         i = np.ascontiguousarray(ids, dtype=np.int32).reshape(B) if ids is not None else None
         check(self._lib.pk_step(self._h, float(v), float(w), float(dt), dptr(zz), int(seed), int(draw), dptr(b), B,
                                 iptr(i), float(u), int(domain)))
+
+    # -- sharded resample (see sharded.py) ---------------------------------------
+    def set_shard(self, global_offset):
+        check(self._lib.pk_set_shard(self._h, int(global_offset)))
+
+    def shard_max_logw(self):
+        v = C.c_double()
+        check(self._lib.pk_shard_max_logw(self._h, C.byref(v)))
+        return float(v.value)
+
+    def shard_num_blocks(self):
+        return int(self._lib.pk_shard_num_blocks(self._h))
+
+    def shard_block_totals(self, gmax, domain):
+        out = np.empty(self.shard_num_blocks(), dtype=np.float64)
+        check(self._lib.pk_shard_block_totals(self._h, float(gmax), int(domain), dptr(out)))
+        return out
+
+    def shard_offspring(self, global_totals, first_block, global_particles, u, last_shard):
+        t = f64(global_totals)
+        out = np.empty(self.P + 1, dtype=np.int64)
+        check(self._lib.pk_shard_offspring(self._h, dptr(t), t.size, int(first_block), int(global_particles), float(u),
+                                           1 if last_shard else 0, lptr(out)))
+        return out
+
+    def particle_bytes(self):
+        return int(self._lib.pk_particle_bytes(self._h))
+
+    def pack_particles(self, local_idx, dev_ptr):
+        idx = np.ascontiguousarray(local_idx, dtype=np.int64)
+        check(self._lib.pk_pack_particles(self._h, lptr(idx), idx.size, C.c_void_p(dev_ptr)))
+
+    def adopt_particles(self, src, dev_ptr, n_received):
+        s_ = np.ascontiguousarray(src, dtype=np.int64).reshape(self.P)
+        check(self._lib.pk_adopt_particles(self._h, lptr(s_), C.c_void_p(dev_ptr), int(n_received)))
 
     # -- instrumentation -----------------------------------------------------
     def enable_timing(self, mask=True):

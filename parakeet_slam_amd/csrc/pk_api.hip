@@ -73,6 +73,12 @@ struct pk_filter {
   int32_t* ids_dev = nullptr;     // P x Bcap_ids
   int Bcap = 0;
   int64_t ids_cap = 0;
+  double* g_totals = nullptr;   // sharded resample: every shard's block totals
+  double* g_offsets = nullptr;
+  int64_t gblocks_cap = 0;
+  int64_t* hi_dev = nullptr;    // P + 1
+  int64_t* idx_dev = nullptr;   // P
+  int64_t* srcs_dev = nullptr;  // P
   unsigned char* grid_dev = nullptr;  // association tables (cell offsets | fp32 colours | order)
   size_t grid_cap = 0;
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
@@ -422,6 +428,8 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize)
     if (need > f->grid_cap) {
       PK_HIP(hipStreamSynchronize(f->stream));
       if (f->grid_dev) (void)hipFree(f->grid_dev);
+  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev})
+    if (q) (void)hipFree(q);
       f->grid_dev = nullptr;
       f->grid_cap = 0;
       if ((rc = dev_alloc(f, &f->grid_dev, need + need / 4))) return rc;
@@ -579,6 +587,8 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->grid_dev) (void)hipFree(f->grid_dev);
+  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev})
+    if (q) (void)hipFree(q);
   void* rest[] = {d.immutable, f->z_dev,  f->blobs_dev, f->blobdir_dev, f->first_dev, f->next_dev, f->ids_dev,
                   f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
                   f->anc,      f->slot_tmp};
@@ -944,6 +954,19 @@ int pk_summary(pk_filter* f, double out[3]) {
   return PK_OK;
 }
 
+int pk_pose_sums(pk_filter* f, double out[4]) {
+  if (!f || !out) return fail(PK_ERR_INVALID, "pk_pose_sums: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  {
+    Span t(f, PK_T_SUMMARY);
+    launch_summary_partials(f->stream, f->d, f->partial, f->out4);
+  }
+  PK_HIP(hipMemcpyAsync(out, f->out4, 4 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
 int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed, uint64_t draw,
             const double* blobs, int32_t B, const int32_t* ids, double u, int32_t weight_domain) {
   int rc;
@@ -977,18 +1000,86 @@ int pk_shard_block_totals(pk_filter* f, double gmax, int32_t weight_domain, doub
   return PK_OK;
 }
 
-int pk_shard_offspring(pk_filter* f, const double*, int64_t, int64_t, int64_t, double, int64_t*, int64_t*) {
-  (void)f;
-  return fail(PK_ERR_UNSUPPORTED, "pk_shard_offspring: not implemented yet");
+int pk_set_shard(pk_filter* f, int64_t global_offset) {
+  if (!f || global_offset < 0) return fail(PK_ERR_INVALID, "pk_set_shard: bad argument");
+  f->d.global_offset = global_offset;
+  return PK_OK;
 }
-int64_t pk_particle_bytes(const pk_filter* f) { return f ? (int64_t)(f->d.lay.slot_bytes + 4 * sizeof(double)) : -1; }
-int pk_pack_particles(pk_filter* f, const int64_t*, int64_t, void*) {
-  (void)f;
-  return fail(PK_ERR_UNSUPPORTED, "pk_pack_particles: not implemented yet");
+
+int pk_shard_offspring(pk_filter* f, const double* global_totals, int64_t n_global_blocks, int64_t first_block,
+                       int64_t global_particles, double u, int32_t last_shard, int64_t* slot_hi) {
+  if (!f || !global_totals || !slot_hi) return fail(PK_ERR_INVALID, "pk_shard_offspring: NULL argument");
+  if (!(u >= 0.0 && u < 1.0)) return fail(PK_ERR_INVALID, "pk_shard_offspring: u = %g outside [0,1)", u);
+  if (first_block < 0 || first_block + f->nblocks > n_global_blocks || global_particles < f->d.P)
+    return fail(PK_ERR_INVALID, "pk_shard_offspring: shard [%lld, +%lld) does not fit %lld global blocks",
+                (long long)first_block, (long long)f->nblocks, (long long)n_global_blocks);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (n_global_blocks > f->gblocks_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    if (f->g_totals) (void)hipFree(f->g_totals);
+    if (f->g_offsets) (void)hipFree(f->g_offsets);
+    f->g_totals = f->g_offsets = nullptr;
+    f->gblocks_cap = 0;
+    if ((rc = dev_alloc(f, &f->g_totals, (size_t)n_global_blocks))) return rc;
+    if ((rc = dev_alloc(f, &f->g_offsets, (size_t)n_global_blocks + 1))) return rc;
+    f->gblocks_cap = n_global_blocks;
+  }
+  if (!f->hi_dev && (rc = dev_alloc(f, &f->hi_dev, (size_t)f->d.P + 1))) return rc;
+  PK_HIP(hipMemcpyAsync(f->g_totals, global_totals, (size_t)n_global_blocks * sizeof(double), hipMemcpyHostToDevice,
+                        f->stream));
+  {
+    Span t(f, PK_T_WEIGHTS);
+    launch_scan_blocks(f->stream, f->g_totals, n_global_blocks, f->g_offsets, f->sum);
+    launch_offspring(f->stream, f->clocal, f->g_offsets, f->sum, first_block, f->d.P, global_particles, u,
+                     last_shard ? 1 : 0, f->hi_dev);
+  }
+  PK_HIP(hipMemcpyAsync(slot_hi, f->hi_dev, ((size_t)f->d.P + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
 }
-int pk_adopt_particles(pk_filter* f, const int64_t*, const void*, int64_t) {
-  (void)f;
-  return fail(PK_ERR_UNSUPPORTED, "pk_adopt_particles: not implemented yet");
+
+int64_t pk_particle_bytes(const pk_filter* f) { return f ? (int64_t)(f->d.lay.slot_bytes + kPoseRecordBytes) : -1; }
+
+int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* dev_buf) {
+  if (!f || n < 0 || (n > 0 && (!local_idx || !dev_buf))) return fail(PK_ERR_INVALID, "pk_pack_particles: bad argument");
+  if (n > f->d.P) return fail(PK_ERR_INVALID, "pk_pack_particles: %lld records from %lld particles", (long long)n, (long long)f->d.P);
+  for (int64_t i = 0; i < n; ++i)
+    if (local_idx[i] < 0 || local_idx[i] >= f->d.P) return fail(PK_ERR_INVALID, "pk_pack_particles: index %lld out of range", (long long)local_idx[i]);
+  if (n == 0) return PK_OK;
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (!f->idx_dev && (rc = dev_alloc(f, &f->idx_dev, (size_t)f->d.P))) return rc;
+  PK_HIP(hipMemcpyAsync(f->idx_dev, local_idx, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, f->stream));
+  {
+    Span t(f, PK_T_RESAMPLE);
+    launch_pack(f->stream, f->d, f->idx_dev, n, static_cast<unsigned char*>(dev_buf));
+  }
+  PK_HIP(hipStreamSynchronize(f->stream));  // the collective that ships dev_buf runs on another stream
+  return PK_OK;
+}
+
+int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, int64_t n_received) {
+  if (!f || !src || n_received < 0 || (n_received > 0 && !dev_buf)) return fail(PK_ERR_INVALID, "pk_adopt_particles: bad argument");
+  const int64_t P = f->d.P;
+  for (int64_t k = 0; k < P; ++k)
+    if (src[k] >= P || src[k] < -n_received) return fail(PK_ERR_INVALID, "pk_adopt_particles: src[%lld] = %lld out of range", (long long)k, (long long)src[k]);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first
+    f->src_identity = false;
+    if ((rc = materialise(f))) return rc;
+  }
+  if (!f->srcs_dev && (rc = dev_alloc(f, &f->srcs_dev, (size_t)P))) return rc;
+  PK_HIP(hipMemcpyAsync(f->srcs_dev, src, (size_t)P * sizeof(int64_t), hipMemcpyHostToDevice, f->stream));
+  {
+    Span t(f, PK_T_RESAMPLE);
+    launch_adopt(f->stream, f->d, f->srcs_dev, static_cast<const unsigned char*>(dev_buf));
+  }
+  if (n_received == 0) f->d.alt = nullptr;
+  f->src_identity = false;
+  PK_HIP(hipStreamSynchronize(f->stream));  // src was pageable host memory
+  return PK_OK;
 }
 
 // ---- probe ------------------------------------------------------------------------------

@@ -104,7 +104,7 @@ void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt,
   double sh = fabs(.025 * w) + fabs(.005 * v) + .0005;  // :190,:193
   int blocks = (int)((d.P + 255) / 256);
   hipLaunchKernelGGL(k_motion, dim3(blocks), dim3(256), 0, s, d.x[d.cur], d.y[d.cur], d.h[d.cur], d.P, v, w,
-                     dt, sd, sh, z_dev, seed, draw, global_offset);
+                     dt, sd, sh, z_dev, seed, draw, global_offset + d.global_offset);
 }
 
 __global__ void k_fill(double* p, int64_t n, double v) {
@@ -157,8 +157,8 @@ __device__ __forceinline__ Landmark<double> load_landmark(const double* f, const
 // landmark index that attains it -- the reference's strict '>' scan keeps the earliest
 // (prkt_core_v2.py:369-381).  Probability 0 never matches.
 struct AssocArgs {
-  const unsigned char* map;
-  size_t slot_bytes, count_off;
+  SlotSource ss;
+  size_t count_off;
   const int32_t* src;
   const double *x, *y, *h;
   const double* blobs;    // B x 4
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) k_assoc_brute(AssocArgs a) {
   unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
   int* bid = reinterpret_cast<int*>(best + a.B);
   const int64_t p = blockIdx.x;
-  const unsigned char* slot = a.map + (size_t)a.src[p] * a.slot_bytes;
+  const unsigned char* slot = a.ss.at(a.src[p]);
   const double* f = reinterpret_cast<const double*>(slot);
   const int* cnt = reinterpret_cast<const int*>(slot + a.count_off);
   const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
@@ -244,8 +244,7 @@ void launch_assoc_brute(hipStream_t s, DeviceState& d, const double* blobs_dev, 
                         int32_t* ids_dev) {
   if (d.P == 0 || B == 0) return;
   AssocArgs a;
-  a.map = d.map[d.mcur];
-  a.slot_bytes = d.lay.slot_bytes;
+  a.ss = slot_source(d);
   a.count_off = d.lay.count_off;
   a.src = d.src[d.cur];
   a.x = d.x[d.cur];
@@ -371,7 +370,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
     for (size_t i = threadIdx.x; i < tab_bytes / 16; i += THREADS) dst[i] = src[i];
   }
   for (int64_t p = blockIdx.x; p < ga.P; p += gridDim.x) {
-    const unsigned char* slot = a.map + (size_t)a.src[p] * a.slot_bytes;
+    const unsigned char* slot = a.ss.at(a.src[p]);
     const double* f = reinterpret_cast<const double*>(slot);
     const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
     PK_STAMP(ts0)
@@ -635,8 +634,9 @@ template <int THREADS, bool DUP>
 static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t lds, int64_t P) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();  // leave no sticky error behind for other users of the runtime
     attr_set = true;
   }
   // persistent grid: as many workgroups as LDS and the 2048-thread CU limit allow
@@ -654,8 +654,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   if (d.P == 0 || B == 0) return;
   AssocGridArgs ga;
   AssocArgs& a = ga.a;
-  a.map = d.map[d.mcur];
-  a.slot_bytes = d.lay.slot_bytes;
+  a.ss = slot_source(d);
   a.count_off = d.lay.count_off;
   a.src = d.src[d.cur];
   a.x = d.x[d.cur];
@@ -691,7 +690,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 
 // ------------------------------------------------------------------ K3 observe (EKF + weight)
 struct ObserveArgs {
-  const unsigned char* map_src;
+  SlotSource ss;
   unsigned char* map_dst;
   size_t slot_bytes, count_off;
   int32_t* src;  // in: slot of particle p in map_src; out: identity
@@ -783,7 +782,7 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   const int64_t p = blockIdx.x;
   const int tid = threadIdx.x;
   const int32_t sp = a.src[p];
-  const unsigned char* sslot = a.map_src + (size_t)sp * a.slot_bytes;
+  const unsigned char* sslot = a.ss.at(sp);
   unsigned char* dslot = a.map_dst + (size_t)p * a.slot_bytes;
   const double* sf = reinterpret_cast<const double*>(sslot);
   double* df = reinterpret_cast<double*>(dslot);
@@ -905,7 +904,7 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
                     const NoiseD& qt) {
   if (d.P == 0) return;
   ObserveArgs a;
-  a.map_src = d.map[d.mcur];
+  a.ss = slot_source(d);
   a.map_dst = d.map[d.mcur ^ 1];
   a.slot_bytes = d.lay.slot_bytes;
   a.count_off = d.lay.count_off;
@@ -937,6 +936,7 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
       hipLaunchKernelGGL((k_observe<false, 1>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
   }
   d.mcur ^= 1;
+  d.alt = nullptr;  // every slot was rewritten into the particle's own map buffer
 }
 
 // ------------------------------------------------------------------ K4 weights
@@ -1002,7 +1002,9 @@ __global__ void __launch_bounds__(256) k_scan_local(const double* __restrict__ l
   if (base + 1 < P) clocal[base + 1] = excl + s1;
   if (base + 2 < P) clocal[base + 2] = excl + s2;
   if (base + 3 < P) clocal[base + 3] = excl + s3;
-  if (tid == 255) totals[blockIdx.x] = woff + val;
+  // the block total IS the inclusive value of its last particle (bit for bit): shards hand
+  // over at block boundaries and both sides must see the same cumulative weight there
+  if (tid == 255) totals[blockIdx.x] = excl + s3;
 }
 void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, int domain, double* clocal_dev,
                        double* totals_dev) {
@@ -1157,14 +1159,12 @@ void launch_summary_partials(hipStream_t s, DeviceState& d, double* partial_dev,
 
 // ------------------------------------------------------------------ map maintenance
 // dst slot p <- src slot src[p]; then src <- identity.  Streaming 16-byte copy.
-__global__ void __launch_bounds__(256) k_copy_slots(const unsigned char* __restrict__ msrc,
-                                                    unsigned char* __restrict__ mdst, size_t slot_bytes,
+__global__ void __launch_bounds__(256) k_copy_slots(SlotSource ss, unsigned char* __restrict__ mdst,
                                                     int32_t* __restrict__ src, int fixed_src) {
   const int64_t p = blockIdx.x;
-  const int64_t sp = fixed_src ? 0 : src[p];
-  const uint4* s = reinterpret_cast<const uint4*>(msrc + (size_t)sp * slot_bytes);
-  uint4* d = reinterpret_cast<uint4*>(mdst + (size_t)p * slot_bytes);
-  const size_t n = slot_bytes / 16;
+  const uint4* s = reinterpret_cast<const uint4*>(fixed_src ? ss.map : ss.at(src[p]));
+  uint4* d = reinterpret_cast<uint4*>(mdst + (size_t)p * ss.slot_bytes);
+  const size_t n = ss.slot_bytes / 16;
   for (size_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
   if (!fixed_src) {
     __syncthreads();
@@ -1173,15 +1173,133 @@ __global__ void __launch_bounds__(256) k_copy_slots(const unsigned char* __restr
 }
 void launch_materialise(hipStream_t s, DeviceState& d) {
   if (d.P == 0) return;
-  hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)d.P), dim3(256), 0, s, d.map[d.mcur], d.map[d.mcur ^ 1],
-                     d.lay.slot_bytes, d.src[d.cur], 0);
+  hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)d.P), dim3(256), 0, s, slot_source(d), d.map[d.mcur ^ 1],
+                     d.src[d.cur], 0);
   d.mcur ^= 1;
+  d.alt = nullptr;
 }
 void launch_broadcast_slot(hipStream_t s, DeviceState& d, const unsigned char* slot_dev) {
   if (d.P == 0) return;
-  hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)d.P), dim3(256), 0, s, slot_dev, d.map[d.mcur],
-                     d.lay.slot_bytes, d.src[d.cur], 1);
+  SlotSource one{slot_dev, d.lay.slot_bytes, nullptr, 0, 0};
+  hipLaunchKernelGGL(k_copy_slots, dim3((unsigned)d.P), dim3(256), 0, s, one, d.map[d.mcur], d.src[d.cur], 1);
   launch_iota(s, d.src[d.cur], d.P);
+  d.alt = nullptr;
+}
+
+
+// ------------------------------------------------------------------ sharded resample
+// Owner-computes offspring: with C_j the global inclusive cumulative weight of local
+// particle j and t_k = u r + k r the comb (same expressions as k_ancestors), particle j fills
+// the output slots [hi_{j-1}, hi_j), hi_j = #{k : t_k <= C_j}.  hi[0] is the count at the
+// shard's lower boundary, hi[1 + j] that of particle j.  Every shard evaluates the same
+// formula on the same block offsets, so the slot ranges tile [0, P) without communication.
+__global__ void __launch_bounds__(256) k_offspring(const double* __restrict__ clocal,
+                                                   const double* __restrict__ offsets,
+                                                   const double* __restrict__ sum, int64_t first_block,
+                                                   int64_t Pl, int64_t Pg, double u, int last_shard,
+                                                   int64_t* __restrict__ hi) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. Pl
+  if (i > Pl) return;
+  const double r = __ddiv_rn(sum[0], (double)Pg);
+  const double ur = __dmul_rn(u, r);
+  double C;
+  if (i == 0) {
+    if (first_block == 0) {
+      hi[0] = 0;
+      return;
+    }
+    C = offsets[first_block];
+  } else {
+    const int64_t j = i - 1;
+    if (last_shard && j == Pl - 1) {  // the tail is clamped to the last particle, as k_ancestors does
+      hi[i] = Pg;
+      return;
+    }
+    C = __dadd_rn(offsets[first_block + j / kScanBlock], clocal[j]);
+  }
+  int64_t lo = 0, up = Pg;  // first k with t_k > C
+  while (lo < up) {
+    const int64_t mid = (lo + up) >> 1;
+    const double t = __dadd_rn(ur, __dmul_rn((double)mid, r));
+    if (t > C)
+      up = mid;
+    else
+      lo = mid + 1;
+  }
+  hi[i] = lo;
+}
+void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,
+                      int64_t first_block, int64_t P_local, int64_t P_global, double u, int last_shard,
+                      int64_t* hi_dev) {
+  hipLaunchKernelGGL(k_offspring, dim3((unsigned)((P_local + 1 + 255) / 256)), dim3(256), 0, s, clocal_dev,
+                     offsets_dev, sum_dev, first_block, P_local, P_global, u, last_shard, hi_dev);
+}
+
+// record = (x, y, h, logw) + map slot
+__global__ void __launch_bounds__(256) k_pack(SlotSource ss, const int32_t* __restrict__ src,
+                                              const double* __restrict__ x, const double* __restrict__ y,
+                                              const double* __restrict__ h, const double* __restrict__ lw,
+                                              const int64_t* __restrict__ idx, unsigned char* __restrict__ buf) {
+  const int64_t i = blockIdx.x;
+  const int64_t j = idx[i];
+  unsigned char* rec = buf + (size_t)i * (kPoseRecordBytes + ss.slot_bytes);
+  if (threadIdx.x == 0) {
+    double* hd = reinterpret_cast<double*>(rec);
+    hd[0] = x[j];
+    hd[1] = y[j];
+    hd[2] = h[j];
+    hd[3] = lw[j];
+  }
+  const uint4* s = reinterpret_cast<const uint4*>(ss.at(src[j]));
+  uint4* d = reinterpret_cast<uint4*>(rec + kPoseRecordBytes);
+  const size_t n = ss.slot_bytes / 16;
+  for (size_t k = threadIdx.x; k < n; k += blockDim.x) d[k] = s[k];
+}
+void launch_pack(hipStream_t s, DeviceState& d, const int64_t* idx_dev, int64_t n, unsigned char* buf_dev) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)n), dim3(256), 0, s, slot_source(d), d.src[d.cur], d.x[d.cur],
+                     d.y[d.cur], d.h[d.cur], d.logw[d.cur], idx_dev, buf_dev);
+}
+
+// New generation of the shard: slot k <- local particle srcs[k] (>= 0) or received record
+// -(srcs[k]) - 1.  Poses are gathered now; maps stay where they are (own buffer / record)
+// until the next observe rewrites them.
+__global__ void __launch_bounds__(256) k_adopt(const double* __restrict__ x, const double* __restrict__ y,
+                                               const double* __restrict__ h, const double* __restrict__ lw,
+                                               const int32_t* __restrict__ src, double* __restrict__ x2,
+                                               double* __restrict__ y2, double* __restrict__ h2,
+                                               double* __restrict__ lw2, int32_t* __restrict__ src2,
+                                               const int64_t* __restrict__ srcs, const unsigned char* __restrict__ buf,
+                                               size_t stride, int64_t P) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const int64_t a = srcs[k];
+  if (a >= 0) {
+    x2[k] = x[a];
+    y2[k] = y[a];
+    h2[k] = h[a];
+    lw2[k] = lw[a];
+    src2[k] = src[a];
+  } else {
+    const double* hd = reinterpret_cast<const double*>(buf + (size_t)(-(a + 1)) * stride);
+    x2[k] = hd[0];
+    y2[k] = hd[1];
+    h2[k] = hd[2];
+    lw2[k] = hd[3];
+    src2[k] = (int32_t)a;
+  }
+}
+void launch_adopt(hipStream_t s, DeviceState& d, const int64_t* src_dev, const unsigned char* buf_dev) {
+  if (d.P == 0) return;
+  const int c = d.cur, n = c ^ 1;
+  const size_t stride = kPoseRecordBytes + d.lay.slot_bytes;
+  hipLaunchKernelGGL(k_adopt, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
+                     d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], src_dev, buf_dev, stride,
+                     d.P);
+  d.cur = n;
+  d.alt = buf_dev;
+  d.alt_stride = stride;
+  d.alt_off = kPoseRecordBytes;
 }
 
 // ------------------------------------------------------------------ probe

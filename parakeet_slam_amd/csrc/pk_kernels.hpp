@@ -26,7 +26,27 @@ struct DeviceState {
   unsigned char* map[2];
   int mcur;  // live map buffer
   unsigned char* immutable;  // [L]
+  // Particles adopted from another shard (multi-GPU resample) are read in place from the
+  // receive buffer until the next observe rewrites them: src[p] < 0 means record -src[p]-1 of
+  // `alt`, whose map slot starts alt_off bytes into a record of alt_stride bytes.
+  const unsigned char* alt = nullptr;
+  size_t alt_stride = 0, alt_off = 0;
+  int64_t global_offset = 0;  // index of local particle 0 in the whole filter (Philox counters)
 };
+
+// Where the landmark slot of a particle lives: its own map buffer or the adoption buffer.
+struct SlotSource {
+  const unsigned char* map;
+  size_t slot_bytes;
+  const unsigned char* alt;
+  size_t alt_stride, alt_off;
+  __host__ __device__ const unsigned char* at(int32_t src) const {
+    return src >= 0 ? map + (size_t)src * slot_bytes : alt + (size_t)(-(src + 1)) * alt_stride + alt_off;
+  }
+};
+inline SlotSource slot_source(const DeviceState& d) {
+  return SlotSource{d.map[d.mcur], d.lay.slot_bytes, d.alt, d.alt_stride, d.alt_off};
+}
 
 constexpr int kScanBlock = 1024;  // particles per weight-scan block (256 threads x 4)
 
@@ -57,7 +77,7 @@ constexpr double kGridCell = 17.5;  // > sqrt(300) = 17.3205 (prkt_core_v2.py:44
 constexpr int kGridMax = 16;
 size_t blob_grid_table_bytes(int ncell, int B, int n9);
 size_t assoc_grid_lds_bytes(int ncell, int B, int n9);
-constexpr size_t kMaxDynLds = 160 * 1024 - 256;
+constexpr size_t kMaxDynLds = 156 * 1024;  // 160 KiB per workgroup minus the kernels' static __shared__
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev,
                        bool finalize);
@@ -87,6 +107,13 @@ void launch_summary_partials(hipStream_t s, DeviceState& d, double* partial_dev,
 void launch_materialise(hipStream_t s, DeviceState& d);
 void launch_broadcast_slot(hipStream_t s, DeviceState& d, const unsigned char* slot_dev);
 void launch_probe(hipStream_t s, const double* in_dev, double* out_dev);
+// sharded resample
+constexpr size_t kPoseRecordBytes = 4 * sizeof(double);  // x, y, h, logw in front of the map slot
+void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,
+                      int64_t first_block, int64_t P_local, int64_t P_global, double u, int last_shard,
+                      int64_t* hi_dev);
+void launch_pack(hipStream_t s, DeviceState& d, const int64_t* idx_dev, int64_t n, unsigned char* buf_dev);
+void launch_adopt(hipStream_t s, DeviceState& d, const int64_t* src_dev, const unsigned char* buf_dev);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
 
 }  // namespace pk

@@ -1,0 +1,141 @@
+"""Shared pieces of the sharded-resample tests (CPU gloo and single-GPU gloo)."""
+import math
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle.fastslam_oracle import OracleFilter, synthetic_scan, synthetic_world, truth_step  # noqa: E402
+
+SCAN_BLOCK = 1024
+
+
+class OracleShard(object):
+    """TEST-ONLY compute backend for ShardedFilter: the NumPy oracle for the per-particle work
+    plus a NumPy restatement of the shard_* protocol (block totals in 1024-particle blocks,
+    sequential scan of the global totals, owner-computes offspring).  Lets the exchange logic
+    run under gloo on a machine without a GPU.  Never used by the product."""
+
+    def __init__(self, P, means, covs):
+        self.P = P
+        self.o = OracleFilter(P, means, covs)
+        self.L = self.o.L
+        self.off = 0
+        self.device = -1
+
+    def set_shard(self, off):
+        self.off = off
+
+    def upload_map(self, *a, **k):
+        pass
+
+    def reset_weights(self):
+        self.o.reset_weights()
+
+    def motion(self, v, w, dt, z=None, seed=0, draw=0):
+        self.o.motion(v, w, dt, z)
+
+    def observe(self, blobs, ids=None, return_ids=False):
+        return self.o.observe(blobs, ids)
+
+    def download_poses(self):
+        return np.stack([self.o.x, self.o.y, self.o.h, self.o.weights()], 1)
+
+    def pose_sums(self):
+        return np.array([self.o.x.sum(), self.o.y.sum(), np.sin(self.o.h).sum(), np.cos(self.o.h).sum()])
+
+    # ---- protocol ----
+    def shard_max_logw(self):
+        return float(self.o.logw.max())
+
+    def _w(self, gmax, domain):
+        return np.exp(self.o.logw - (gmax if domain == 1 and gmax > -np.inf else 0.0))
+
+    def shard_block_totals(self, gmax, domain):
+        w = self._w(gmax, domain)
+        nb = (self.P + SCAN_BLOCK - 1) // SCAN_BLOCK
+        self.clocal = np.empty(self.P)
+        tot = np.empty(nb)
+        for b in range(nb):
+            c = np.cumsum(w[b * SCAN_BLOCK:(b + 1) * SCAN_BLOCK])
+            self.clocal[b * SCAN_BLOCK:b * SCAN_BLOCK + len(c)] = c
+            tot[b] = c[-1]
+        return tot
+
+    def shard_offspring(self, gtotals, first_block, P_global, u, last_shard):
+        offs = np.concatenate([[0.0], np.cumsum(gtotals)])
+        S = offs[-1]
+        r = S / float(P_global)
+        t = u * r + np.arange(P_global, dtype=np.float64) * r
+        C = offs[first_block + np.arange(self.P) // SCAN_BLOCK] + self.clocal
+        hi = np.empty(self.P + 1, dtype=np.int64)
+        hi[0] = 0 if first_block == 0 else np.searchsorted(t, offs[first_block], side="right")
+        hi[1:] = np.searchsorted(t, C, side="right")
+        if last_shard:
+            hi[-1] = P_global
+        return hi
+
+    def particle_bytes(self):
+        return 8 * (4 + self.L * 30 + self.L)
+
+    def alloc_records(self, n):
+        return np.zeros(max(n, 1) * self.particle_bytes(), dtype=np.uint8)
+
+    def _record(self, j):
+        o = self.o
+        return np.concatenate([[o.x[j], o.y[j], o.h[j], o.logw[j]], o.mean[j].ravel(), o.cov[j].ravel(),
+                               o.count[j].astype(np.float64)])
+
+    def pack_records(self, idx, buf):
+        rb = self.particle_bytes()
+        for i, j in enumerate(idx):
+            buf[i * rb:(i + 1) * rb] = self._record(int(j)).view(np.uint8)
+
+    def adopt_records(self, src, buf, n_received):
+        o, L, rb = self.o, self.L, self.particle_bytes()
+        x, y, h, lw = o.x.copy(), o.y.copy(), o.h.copy(), o.logw.copy()
+        mean, cov, cnt = o.mean.copy(), o.cov.copy(), o.count.copy()
+        for k, a in enumerate(src):
+            if a >= 0:
+                o.x[k], o.y[k], o.h[k], o.logw[k] = x[a], y[a], h[a], lw[a]
+                o.mean[k], o.cov[k], o.count[k] = mean[a], cov[a], cnt[a]
+            else:
+                r = -(a + 1)
+                rec = buf[r * rb:(r + 1) * rb].view(np.float64)
+                o.x[k], o.y[k], o.h[k], o.logw[k] = rec[:4]
+                o.mean[k] = rec[4:4 + 5 * L].reshape(L, 5)
+                o.cov[k] = rec[4 + 5 * L:4 + 30 * L].reshape(L, 5, 5)
+                o.count[k] = rec[4 + 30 * L:].astype(np.int64)
+
+
+def scenario(L, steps, seed=5):
+    means, covs = synthetic_world(L)
+    pose = (0.0, 0.0, 0.0)
+    scans = []
+    for _ in range(steps):
+        pose = truth_step(pose, 0.2, 0.1, 0.1)
+        scans.append(synthetic_scan(means, pose))
+    return means, covs, scans
+
+
+def noise(P_global, steps, seed):
+    rs = np.random.RandomState(seed)
+    return rs.standard_normal((steps, P_global, 3)), rs.uniform(0, 1, steps)
+
+
+def init_gloo(rank, world, store_path):
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", init_method="file://" + store_path, rank=rank, world_size=world)
+
+
+def store_file():
+    fd, path = tempfile.mkstemp(prefix="pk_gloo_")
+    os.close(fd)
+    os.unlink(path)
+    return path

@@ -1,0 +1,140 @@
+"""GPU (one device is enough): two processes, one HIP filter each on cuda:0, gloo between
+them -- the sharded resample of the real library against ONE filter holding all particles.
+With shards of 1024 particles the result must be bit-identical (same scan blocks, same
+sequential scan of the block totals, same comb).  Also: nccl (= RCCL) code path with one rank."""
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from sharded_common import init_gloo, noise, scenario, store_file
+
+pytestmark = pytest.mark.gpu
+
+
+def single_run(P, L, steps, skew, assoc_ids):
+    from parakeet_slam_amd import _lib
+
+    means, covs, scans = scenario(L, steps)
+    z, us = noise(P, steps, 11)
+    f = _lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    out = []
+    for s in range(steps):
+        f.reset_weights()
+        f.motion(0.2, 0.1, 0.1, z=z[s])
+        f.observe(scans[s], ids=assoc_ids)
+        if skew:
+            poses = f.download_poses()
+            poses[:, 3] *= np.exp(np.linspace(0.0, skew, P))
+            f.upload_poses(poses)
+        anc = f.resample(float(us[s]), domain=1, return_ancestors=True)
+        m, c, k = f.download_landmarks()
+        out.append((anc, f.download_poses(), m, c, k, f.summary()))
+    f.close()
+    return out
+
+
+def worker(rank, world, store, P_local, L, steps, skew, use_ml, q):
+    try:
+        init_gloo(rank, world, store)
+        from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
+
+        means, covs, scans = scenario(L, steps)
+        P = P_local * world
+        z, us = noise(P, steps, 11)
+        sf = ShardedFilter(P_local, L, device=0, comm=TorchComm())
+        sf.upload_map(means, covs.reshape(L, 25))
+        lo, hi = rank * P_local, (rank + 1) * P_local
+        res = []
+        for s in range(steps):
+            sf.reset_weights()
+            sf.motion(0.2, 0.1, 0.1, z=z[s, lo:hi])
+            sf.observe(scans[s], ids=None if use_ml else np.arange(1, L + 1))
+            if skew:
+                poses = sf.f.download_poses()
+                poses[:, 3] *= np.exp(np.linspace(0.0, skew, P))[lo:hi]
+                sf.f.upload_poses(poses)
+            anc = sf.resample(float(us[s]), domain=1, return_ancestors=True)
+            mig = sf.last_migrated
+            sm = sf.summary()
+            m, c, k = sf.download_landmarks()
+            res.append((anc, sf.download_poses(), m, c, k, sm, mig))
+        q.put((rank, res))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "ERR " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("skew,use_ml", [(0.0, False), (5.0, False), (2.0, True)])
+def test_two_shards_on_one_gpu_match_single_filter(skew, use_ml):
+    world, P_local, L, steps = 2, 1024, 12, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    store = store_file()
+    procs = [ctx.Process(target=worker, args=(r, world, store, P_local, L, steps, skew, use_ml, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, res = q.get(timeout=600)
+        assert not isinstance(res, str), res
+        got[r] = res
+    for p in procs:
+        p.join(timeout=60)
+    ref = single_run(world * P_local, L, steps, skew, None if use_ml else np.arange(1, L + 1))
+    moved = 0
+    for s in range(steps):
+        assert np.array_equal(np.concatenate([got[r][s][0] for r in range(world)]), ref[s][0]), "ancestors"
+        for fld in (1, 2, 3, 4):
+            whole = np.concatenate([got[r][s][fld] for r in range(world)])
+            assert np.array_equal(whole, ref[s][fld]), (s, fld)
+        for r in range(world):
+            assert np.allclose(got[r][s][5], ref[s][5], rtol=1e-12, atol=1e-13)
+        moved += sum(got[r][s][6] for r in range(world))
+    if skew >= 5.0:
+        assert moved > 100
+
+
+def _nccl_single(q):
+    try:
+        import os
+
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29581")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
+
+        comm = TorchComm(0)
+        assert comm.on_device
+        assert comm.allreduce_max(3.5) == 3.5
+        assert np.array_equal(comm.allgather(np.arange(4.0)), np.arange(4.0))
+        assert np.array_equal(comm.alltoall_i64([np.array([5, 6, 7])])[0], [5, 6, 7])
+        L = 8
+        means, covs, scans = scenario(L, 2)
+        sf = ShardedFilter(2048, L, device=0, comm=comm)
+        sf.upload_map(means, covs.reshape(L, 25))
+        for s in range(2):
+            sf.step(0.2, 0.1, 0.1, scans[s], 0.37, seed=3, draw=s, domain=1)
+        sm = sf.summary()
+        dist.destroy_process_group()
+        q.put(("ok", sm))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put(("ERR", traceback.format_exc()))
+
+
+def test_rccl_code_path_with_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single, args=(q,))
+    p.start()
+    status, payload = q.get(timeout=600)
+    p.join(timeout=60)
+    assert status == "ok", payload
+    assert np.isfinite(payload).all()

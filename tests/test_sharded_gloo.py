@@ -1,0 +1,135 @@
+"""CPU, world_size 2 and 4 over gloo: the multi-GPU path of the resample.
+
+The exchange logic (plan, metadata all-to-all, record all-to-all, adoption) is the product's
+own (parakeet_slam_amd/sharded.py); the per-particle arithmetic is supplied by the test-only
+OracleShard so this runs without a GPU.  Claims checked: G shards give the SAME ancestors,
+poses, weights and landmark maps as one filter holding all particles, including when weights
+are so skewed that nearly every particle migrates."""
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from sharded_common import OracleShard, init_gloo, noise, scenario, store_file
+from oracle.fastslam_oracle import OracleFilter
+
+
+def reference_run(P, L, steps, skew):
+    means, covs, scans = scenario(L, steps)
+    z, us = noise(P, steps, 11)
+    o = OracleFilter(P, means, covs)
+    out = []
+    for s in range(steps):
+        o.reset_weights()
+        o.motion(0.2, 0.1, 0.1, z[s])
+        o.observe(scans[s], ids=np.arange(1, L + 1))
+        if skew:
+            o.logw += np.linspace(0.0, skew, P)  # heavier weights at high indices: mass moves down-rank
+        # canonical blocked scan (same association as the device / OracleShard)
+        sh = OracleShard(P, means, covs)
+        sh.o = o
+        tot = sh.shard_block_totals(float(o.logw.max()), 1)
+        hi = sh.shard_offspring(tot, 0, P, float(us[s]), True)
+        anc = np.searchsorted(np.maximum.accumulate(hi[1:]), np.arange(P), side="right")
+        o.gather(anc)
+        out.append((anc.copy(), o.x.copy(), o.y.copy(), o.h.copy(), o.logw.copy(), o.mean.copy(), o.count.copy()))
+    return out
+
+
+def worker(rank, world, store, P_local, L, steps, skew, q):
+    try:
+        init_gloo(rank, world, store)
+        from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
+
+        means, covs, scans = scenario(L, steps)
+        P = P_local * world
+        z, us = noise(P, steps, 11)
+        sf = ShardedFilter(P_local, L, comm=TorchComm(), shard=OracleShard(P_local, means, covs))
+        res = []
+        lo, hi = rank * P_local, (rank + 1) * P_local
+        for s in range(steps):
+            sf.reset_weights()
+            sf.motion(0.2, 0.1, 0.1, z=z[s, lo:hi])
+            sf.observe(scans[s], ids=np.arange(1, L + 1))
+            if skew:
+                sf.f.o.logw += np.linspace(0.0, skew, P)[lo:hi]
+            anc = sf.resample(float(us[s]), domain=1, return_ancestors=True)
+            o = sf.f.o
+            res.append((anc, o.x.copy(), o.y.copy(), o.h.copy(), o.logw.copy(), o.mean.copy(), o.count.copy(),
+                        sf.last_migrated, sf.summary()))
+        q.put((rank, res))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "ERR " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,P_local,skew", [(2, 1024, 0.0), (2, 1024, 6.0), (4, 1024, 3.0), (2, 300, 2.0)])
+def test_shards_reproduce_single_filter(world, P_local, skew):
+    L, steps = 6, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    store = store_file()
+    procs = [ctx.Process(target=worker, args=(r, world, store, P_local, L, steps, skew, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, res = q.get(timeout=300)
+        assert not isinstance(res, str), res
+        got[r] = res
+    for p in procs:
+        p.join(timeout=60)
+    P = world * P_local
+    ref = reference_run(P, L, steps, skew)
+    migrated = 0
+    for s in range(steps):
+        anc = np.concatenate([got[r][s][0] for r in range(world)])
+        if P_local % 1024 == 0:
+            assert np.array_equal(anc, ref[s][0]), "ancestors differ from the single-filter run"
+        for fld in range(1, 7):
+            whole = np.concatenate([got[r][s][fld] for r in range(world)])
+            if P_local % 1024 == 0:
+                assert np.array_equal(whole, ref[s][fld]), (s, fld)
+        migrated += sum(got[r][s][7] for r in range(world))
+        # summaries agree across ranks and with the concatenated state
+        x = np.concatenate([got[r][s][1] for r in range(world)])
+        h = np.concatenate([got[r][s][3] for r in range(world)])
+        for r in range(world):
+            sm = got[r][s][8]
+            assert abs(sm[0] - x.mean()) < 1e-12 and abs(sm[2] - np.arctan2(np.sin(h).sum(), np.cos(h).sum())) < 1e-12
+        # every output slot got exactly one ancestor, ancestors are monotone (systematic resampling)
+        assert np.all(np.diff(anc) >= 0) and anc.min() >= 0 and anc.max() < P
+    if skew >= 3.0:
+        assert migrated > 0, "the skewed case must actually move particles between ranks"
+
+
+def test_plan_exchange_covers_every_slot():
+    from parakeet_slam_amd.sharded import fill_from_received, plan_exchange
+
+    rs = np.random.RandomState(0)
+    world, P_local = 4, 50
+    P = world * P_local
+    for trial in range(50):
+        w = np.exp(rs.normal(0, rs.uniform(0.1, 5), P))
+        c = np.cumsum(w)
+        r = c[-1] / P
+        t = rs.uniform() * r + np.arange(P) * r
+        hi_all = np.searchsorted(t, c, side="right")
+        hi_all[-1] = P
+        anc = np.searchsorted(hi_all, np.arange(P), side="right")
+        plans = []
+        for rank in range(world):
+            hi = np.concatenate([[0 if rank == 0 else hi_all[rank * P_local - 1]], hi_all[rank * P_local:(rank + 1) * P_local]])
+            plans.append(plan_exchange(hi, rank, world, P_local))
+        for rank in range(world):
+            local_src = plans[rank][0].copy()
+            ranges, owners = [], []
+            for src in range(world):
+                idx, lo, up = plans[src][1][rank]
+                ranges.append((lo, up))
+                owners.extend((src * P_local + idx).tolist())
+            local_src, n = fill_from_received(local_src, rank, P_local, ranges)
+            glob = np.where(local_src >= 0, rank * P_local + local_src, 0)
+            for k in np.nonzero(local_src < 0)[0]:
+                glob[k] = owners[-(local_src[k] + 1)]
+            assert np.array_equal(glob, anc[rank * P_local:(rank + 1) * P_local]), (trial, rank)
