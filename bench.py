@@ -94,6 +94,10 @@ def cpu_baseline(L, budget_s=20.0):
 
 
 def main():
+    # Exactly ONE line may reach stdout (the JSON).  RCCL and friends print banners to fd 1,
+    # so park the real stdout and point fd 1 at stderr until the result is ready.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -228,7 +232,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(L, args.cpu_budget)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         import torch.distributed as dist
 
