@@ -31,6 +31,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def measured_traffic(P, L, variant):
+    """HBM bytes per k_observe launch from the committed rocprofv3 PMC run (profiles/*/pmc_traffic.json,
+    made by scripts/gpu_pmc_traffic.sh) when it was taken on this very configuration, else None."""
+    best = None
+    for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        if os.path.exists(path):
+            d = json.load(open(path))
+            if d["config"]["particles"] == P and d["config"]["landmarks"] == L and variant in d["bytes_per_launch"]:
+                best = d["bytes_per_launch"][variant]
+    return best
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_UPDATE = 224  # SURVEY 8d: 14 fp64 read + 14 written per particle.landmark
 
@@ -222,7 +235,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(P, L, "observe_known" if args.assoc == "known" else "observe_ml"),
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH + WRITE)*1024, "
+                "see profiles/*/pmc_traffic.json",
                 "avg_launch_ms": obs_avg_s * 1e3,
                 "launches": obs_n,
                 "algorithmic_bytes_per_launch": alg_bytes,

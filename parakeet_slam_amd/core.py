@@ -523,5 +523,35 @@ class FastSLAM(object):
         with self._lock:
             return self._filter.summary()
 
+    # ------------------------------------------------------------------ snapshot / restore
+    def save_state(self, path):
+        """Whole filter state -> .npz (poses, weights, every particle's landmark means /
+        covariances / update counts, Qt, controls).  The reference has no checkpointing
+        (SURVEY section 5); this is the state round trip tests and long runs want."""
+        with self._lock:
+            poses = self._filter.download_poses()
+            m, c, k = self._filter.download_landmarks()
+            np.savez_compressed(
+                path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
+                immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),
+                last_control=np.array([float(self.last_control.linear.x), float(self.last_control.angular.z)]),
+                last_update=float(self.last_update.to_sec()), draw=self._draw)
+
+    def load_state(self, path):
+        with self._lock:
+            d = np.load(path)
+            P, L = self.num_particles, len(self._ids)
+            if d["poses"].shape != (P, 4) or d["means"].shape != (P, L, 5):
+                raise ValueError("snapshot is for %s particles x %s landmarks, this filter has %d x %d"
+                                 % (d["poses"].shape[0], d["means"].shape[1], P, L))
+            self._filter.upload_poses(d["poses"])
+            if L:
+                self._filter.upload_landmarks(0, P, d["means"], d["covs"].reshape(P, L, 25), d["counts"])
+            self.Qt = d["Qt"].copy()
+            self.last_control.linear.x = float(d["last_control"][0])
+            self.last_control.angular.z = float(d["last_control"][1])
+            self._draw = int(d["draw"])
+            self._touch()
+
     def close(self):
         self._filter.close()

@@ -286,3 +286,36 @@ def test_unsupported_covariance_is_loud(pk):
     with pytest.raises(pk.PkError) as ei:
         pk.FastSLAM([pk.Feature(mean=np.zeros(5), covar=cov)], num_particles=4)
     assert ei.value.status == -4
+
+
+def test_snapshot_round_trip(pk, tmp_path):
+    g = load_golden("step_small")
+    P, L = int(g["P"]), int(g["L"])
+    np.random.seed(3)
+    random.seed(3)
+    pk.msgs.Time.set_now(0.0)
+    feats = [pk.Feature(mean=g["means0"][l], covar=g["covs0"][l]) for l in range(L)]
+    a = pk.FastSLAM(feats, num_particles=P)
+    tw = pk.msgs.Twist()
+    tw.linear.x, tw.angular.z = 0.2, 0.1
+    a.last_control = tw
+    pk.msgs.Time.set_now(0.1)
+    a.cam_cb(View(pk, g["blobs"][0]))
+    path = str(tmp_path / "snap.npz")
+    a.save_state(path)
+    b = pk.FastSLAM([pk.Feature(mean=g["means0"][l], covar=g["covs0"][l]) for l in range(L)], num_particles=P)
+    b.load_state(path)
+    pa, pb = a._filter.download_poses(), b._filter.download_poses()
+    assert np.array_equal(pa[:, :3], pb[:, :3]) and np.allclose(pa[:, 3], pb[:, 3], rtol=1e-15)
+    for x, y in zip(a._filter.download_landmarks(), b._filter.download_landmarks()):
+        assert np.array_equal(x, y)
+    # both continue identically
+    for fs in (a, b):
+        np.random.seed(9)
+        random.seed(9)
+        pk.msgs.Time.set_now(0.2)
+        fs.last_update = pk.msgs.Time(0.1)
+        fs.cam_cb(View(pk, g["blobs"][1]))
+    assert np.allclose(a.summary(), b.summary(), rtol=1e-13, atol=1e-15)
+    a.close()
+    b.close()
