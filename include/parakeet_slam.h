@@ -93,6 +93,8 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "assoc_kernel" = 0 (colour-grid association kernel, default) or 1 (brute-force reference
  *                    kernel that gate-tests every landmark x blob pair);
  *   "assoc_dup"    = 1 (default: 9x column-duplicated blob index list when it fits in LDS) or 0;
+ *   "fast_observe" = 1 (default: for L <= 512 contested associations are settled inside the
+ *                    EKF kernel with the landmark state in registers) or 0 (general path);
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
 int pk_set_option(pk_filter* f, const char* name, int64_t value);
 

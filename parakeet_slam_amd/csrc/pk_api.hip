@@ -83,6 +83,9 @@ struct pk_filter {
   size_t grid_cap = 0;
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
+  int fast_observe = 1;  // L <= 512: association hand-off + k_observe_fast
+  FastHandoff fh{};      // device buffers of the hand-off
+  int64_t fh_cap_l = 0, fh_cap_b = 0;
   // pinned host staging ring for the per-scan uploads (blobs, ray directions, chains):
   // lets pk_observe/pk_step return without synchronising the stream
   static constexpr int kRing = 8;
@@ -392,7 +395,36 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
 }
 
 // Upload one scan for maximum-likelihood association and enqueue the association kernel.
-int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize) {
+struct AssocLaunch {
+  bool fast = false;             // hand-off written: k_observe_fast can run
+  const double* exact = nullptr;
+  const unsigned short* order = nullptr;
+};
+
+int ensure_handoff(pk_filter* f, int B) {
+  const int64_t need_l = f->d.P * (int64_t)f->d.lay.Lp, need_b = f->d.P * (int64_t)std::max(B, 1);
+  int rc;
+  if (need_l > f->fh_cap_l) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    if (f->fh.lmpass) (void)hipFree(f->fh.lmpass);
+    f->fh.lmpass = nullptr;
+    f->fh_cap_l = 0;
+    if ((rc = dev_alloc(f, &f->fh.lmpass, (size_t)need_l))) return rc;
+    f->fh_cap_l = need_l;
+  }
+  if (need_b > f->fh_cap_b) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    if (f->fh.bcount) (void)hipFree(f->fh.bcount);
+    f->fh.bcount = nullptr;
+    f->fh_cap_b = 0;
+    if ((rc = dev_alloc(f, &f->fh.bcount, (size_t)need_b))) return rc;
+    f->fh_cap_b = need_b;
+  }
+  if (!f->fh.pflag && (rc = dev_alloc(f, &f->fh.pflag, (size_t)f->d.P))) return rc;
+  return PK_OK;
+}
+
+int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize, bool want_fast, AssocLaunch* out) {
   int rc;
   if (B > 65535) return fail(PK_ERR_UNSUPPORTED, "maximum-likelihood association handles at most 65535 blobs per scan (got %d)", B);
   if ((rc = ensure_blob_capacity(f, B))) return rc;
@@ -428,6 +460,8 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize)
     if (need > f->grid_cap) {
       PK_HIP(hipStreamSynchronize(f->stream));
       if (f->grid_dev) (void)hipFree(f->grid_dev);
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag})
+    if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev})
     if (q) (void)hipFree(q);
       f->grid_dev = nullptr;
@@ -440,9 +474,20 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize)
     PK_HIP(hipMemcpyAsync(f->grid_dev, st + o_exact, (size_t)B * 6 * sizeof(double), hipMemcpyHostToDevice, f->stream));
     PK_HIP(hipMemcpyAsync(f->grid_dev + ex_bytes, st + o_tab, tab_bytes, hipMemcpyHostToDevice, f->stream));
     PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+    FastHandoff fh{};
+    if (want_fast && !finalize && f->fast_observe && f->d.lay.L <= kFastMaxL && B > 0) {
+      if ((rc = ensure_handoff(f, B))) return rc;
+      fh = f->fh;
+    }
     Span t(f, PK_T_ASSOC);
     launch_assoc_grid(f->stream, f->d, B, g, n9, f->grid_dev + ex_bytes, reinterpret_cast<const double*>(f->grid_dev),
-                      f->ids_dev, finalize);
+                      f->ids_dev, finalize, fh);
+    if (out) {
+      out->fast = fh.lmpass != nullptr;
+      out->exact = reinterpret_cast<const double*>(f->grid_dev);
+      const size_t cs_b = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
+      out->order = reinterpret_cast<const unsigned short*>(f->grid_dev + ex_bytes + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
+    }
     return PK_OK;
   }
   PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
@@ -587,6 +632,8 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->grid_dev) (void)hipFree(f->grid_dev);
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag})
+    if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev})
     if (q) (void)hipFree(q);
   void* rest[] = {d.immutable, f->z_dev,  f->blobs_dev, f->blobdir_dev, f->first_dev, f->next_dev, f->ids_dev,
@@ -814,6 +861,8 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
   const int L = lay.L;
   for (int i = 0; i < 4 * B; ++i)
     if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_observe: blob %d is not finite", i / 4);
+  static const int32_t no_ids = 0;
+  if (!ids && B == 0) ids = &no_ids;  // an empty scan needs no association: every landmark keeps its state
   if (ids)
     for (int b = 0; b < B; ++b)
       if (ids[b] < 0 || ids[b] > L) return fail(PK_ERR_INVALID, "pk_observe: ids[%d] = %d outside 0..%d", b, ids[b], L);
@@ -860,10 +909,17 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
     return PK_OK;
   }
   // maximum-likelihood association on the device
-  if ((rc = enqueue_association(f, blobs, B, false))) return rc;
+  AssocLaunch al;
+  if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
   {
     Span t(f, PK_T_OBSERVE);
-    launch_observe(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt);
+    if (al.fast) {
+      launch_observe_fast(f->stream, f->d, B, al.exact, al.order, f->fh, f->qt);
+      launch_observe(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt,
+                     f->fh.pflag, true);
+    } else {
+      launch_observe(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt);
+    }
   }
   f->src_identity = true;
   if (ids_out && B > 0) {
@@ -882,7 +938,7 @@ int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out)
   if ((rc = use_device(f))) return rc;
   for (int i = 0; i < 4 * B; ++i)
     if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_associate: blob %d is not finite", i / 4);
-  if ((rc = enqueue_association(f, blobs, B, true))) return rc;
+  if ((rc = enqueue_association(f, blobs, B, true, false, nullptr))) return rc;
   PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
   PK_HIP(hipStreamSynchronize(f->stream));
   return PK_OK;
@@ -893,6 +949,10 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   if (!strcmp(name, "assoc_kernel")) {
     if (value != 0 && value != 1) return fail(PK_ERR_INVALID, "assoc_kernel: 0 (colour grid) or 1 (brute force)");
     f->assoc_kernel = (int)value;
+    return PK_OK;
+  }
+  if (!strcmp(name, "fast_observe")) {
+    f->fast_observe = value != 0;
     return PK_OK;
   }
   if (!strcmp(name, "assoc_dup")) {

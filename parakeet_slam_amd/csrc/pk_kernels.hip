@@ -11,6 +11,7 @@
 
 #include <cfloat>
 #include <climits>
+#include <type_traits>
 
 #include "pk_math.hpp"
 #include "pk_philox.hpp"
@@ -292,6 +293,13 @@ struct AssocGridArgs {
   int64_t P;
   int finalize;  // 1: also settle single-candidate blobs here (pk_associate), not in k_observe
   int n9;        // DUP: entries of the duplicated index list (padded to 8)
+  // Fast hand-off to k_observe_fast (L <= 512): per landmark the (<= 4) blobs that pass its
+  // gates, per blob how many landmarks pass; a particle where some landmark passes more than
+  // four blobs is flagged and settled the general way (S2..S4 + ids) instead.
+  uint2* lmpass;          // [P][Lp]  four 16-bit fields = blob (cell order) or 0xFFFF
+  unsigned char* bcount;  // [P][B]   saturating count
+  unsigned char* pflag;   // [P]      1 = general path
+  const unsigned char* only_flagged;  // GENERAL instance: skip particles whose flag is 0
 };
 
 // tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
@@ -344,10 +352,12 @@ __device__ unsigned long long pk_stamp_acc[16];
 #define PK_STAMP_ADD(slot, a, b)
 #endif
 
-template <int THREADS, bool DUP>
+// GENERAL = false: S1 + hand-off only (light on registers); particles it flags are redone by
+// the GENERAL = true instance launched with only_flagged.
+template <int THREADS, bool DUP, bool GENERAL>
 __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ int n_few, n_many;
+  __shared__ int n_few, n_many, wg_flag;
   __shared__ unsigned long long s3_best[THREADS / 4];
   __shared__ int s3_win[THREADS / 4];
   const AssocArgs& a = ga.a;
@@ -370,6 +380,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
     for (size_t i = threadIdx.x; i < tab_bytes / 16; i += THREADS) dst[i] = src[i];
   }
   for (int64_t p = blockIdx.x; p < ga.P; p += gridDim.x) {
+    if (GENERAL && ga.only_flagged && !ga.only_flagged[p]) continue;  // workgroup-uniform
     const unsigned char* slot = a.ss.at(a.src[p]);
     const double* f = reinterpret_cast<const double*>(slot);
     const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
@@ -378,6 +389,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
     if (threadIdx.x == 0) {
       n_few = 0;
       n_many = 0;
+      wg_flag = 0;
     }
     __syncthreads();
     PK_STAMP(ts1)
@@ -429,10 +441,17 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         // conservative fp32 gates; NaN/inf fall through to the exact float64 tests
         return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
       };
+      unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;  // the blobs that pass this landmark's gates (first four)
+      int npass = 0;
       auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
         if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
           const int n = atomicAdd(&ccount[tt], 1);
           if (n < 4) cand[4 * tt + n] = (unsigned short)l;
+          if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
+          if (npass == 1) pass01 = (pass01 & 0x0000FFFFu) | ((unsigned)tt << 16);
+          if (npass == 2) pass23 = (pass23 & 0xFFFF0000u) | (unsigned)tt;
+          if (npass == 3) pass23 = (pass23 & 0x0000FFFFu) | ((unsigned)tt << 16);
+          ++npass;
         }
       };
       // ---- phase 1 (LDS only) ---------------------------------------------------------
@@ -527,12 +546,25 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
           }
         }
       }
+      if (!GENERAL) {
+        ga.lmpass[(size_t)p * a.Lp + l] = make_uint2(pass01, pass23);
+        if (npass > kFastSlots) wg_flag = 1;
+      }
     }
     PK_STAMP(ts2)
     __syncthreads();
     PK_STAMP(ts3)
     PK_STAMP_ADD(4, ts1, ts2)
     PK_STAMP_ADD(5, ts2, ts3)
+    if (!GENERAL) {
+      for (int t = threadIdx.x; t < B; t += THREADS) {
+        const int n = ccount[t];
+        ga.bcount[(size_t)p * B + t] = (unsigned char)(n > 255 ? 255 : n);
+      }
+      if (threadIdx.x == 0) ga.pflag[p] = (unsigned char)(wg_flag != 0);
+      __syncthreads();
+      continue;  // k_observe_fast (or, if flagged, the GENERAL instance) takes it from here
+    }
     // ---- S2 ------------------------------------------------------------------------------
     for (int t = threadIdx.x; t < B; t += THREADS) {
       const int n = ccount[t];
@@ -630,11 +662,11 @@ size_t assoc_grid_lds_bytes(int ncell, int B, int n9) {
   return grid_cs_bytes(ncell) + (size_t)B * 30 + (size_t)n9 * 2 + 16;
 }
 
-template <int THREADS, bool DUP>
+template <int THREADS, bool DUP, bool GENERAL>
 static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t lds, int64_t P) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
       (void)hipGetLastError();  // leave no sticky error behind for other users of the runtime
     attr_set = true;
@@ -646,11 +678,12 @@ static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t l
   per_cu = per_cu > by_threads ? by_threads : per_cu;
   int64_t blocks = 256 * (int64_t)per_cu;
   if (blocks > P) blocks = P;
-  hipLaunchKernelGGL((k_assoc_grid<THREADS, DUP>), dim3((unsigned)blocks), dim3(THREADS), lds, s, ga);
+  hipLaunchKernelGGL((k_assoc_grid<THREADS, DUP, GENERAL>), dim3((unsigned)blocks), dim3(THREADS), lds, s, ga);
 }
 
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
-                       const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev, bool finalize) {
+                       const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev, bool finalize,
+                       const FastHandoff& fh) {
   if (d.P == 0 || B == 0) return;
   AssocGridArgs ga;
   AssocArgs& a = ga.a;
@@ -672,19 +705,33 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   ga.P = d.P;
   ga.finalize = finalize ? 1 : 0;
   ga.n9 = n9;
+  ga.lmpass = fh.lmpass;
+  ga.bcount = fh.bcount;
+  ga.pflag = fh.pflag;
+  ga.only_flagged = nullptr;
   const size_t lds = assoc_grid_lds_bytes(grid.ncell, B, n9);
   // bigger workgroups when the LDS tables are large, so that a CU still holds >= 16 waves
   const bool big = lds > 40 * 1024;
-  if (n9 > 0) {
-    if (big)
-      launch_assoc_grid_t<512, true>(s, ga, lds, d.P);
-    else
-      launch_assoc_grid_t<256, true>(s, ga, lds, d.P);
+  auto go = [&](auto general) {
+    constexpr bool G = decltype(general)::value;
+    if (n9 > 0) {
+      if (big)
+        launch_assoc_grid_t<512, true, G>(s, ga, lds, d.P);
+      else
+        launch_assoc_grid_t<256, true, G>(s, ga, lds, d.P);
+    } else {
+      if (big)
+        launch_assoc_grid_t<512, false, G>(s, ga, lds, d.P);
+      else
+        launch_assoc_grid_t<256, false, G>(s, ga, lds, d.P);
+    }
+  };
+  if (fh.lmpass) {
+    go(std::false_type{});  // S1 + hand-off for every particle
+    ga.only_flagged = fh.pflag;
+    go(std::true_type{});   // the flagged ones (a landmark with > 2 gate-passing blobs) the general way
   } else {
-    if (big)
-      launch_assoc_grid_t<512, false>(s, ga, lds, d.P);
-    else
-      launch_assoc_grid_t<256, false>(s, ga, lds, d.P);
+    go(std::true_type{});
   }
 }
 
@@ -703,6 +750,7 @@ struct ObserveArgs {
   int32_t* ids;          // ML: [P x B]; a tentative id whose probability is 0 is reset to 0
   const unsigned char* immutable;
   int n_unmatched;  // KNOWN: blobs with id 0
+  const unsigned char* only_flagged;  // when set: skip particles whose flag is 0 (k_observe_fast did them)
   int L, Lp, B;
   Noise<double> qt;
 };
@@ -780,6 +828,7 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kObsThreads / kWave];
   const int64_t p = blockIdx.x;
+  if (a.only_flagged && !a.only_flagged[p]) return;  // workgroup-uniform
   const int tid = threadIdx.x;
   const int32_t sp = a.src[p];
   const unsigned char* sslot = a.ss.at(sp);
@@ -897,11 +946,212 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------ K3 (fast ML variant, L <= 512)
+// One workgroup per particle, two adjacent landmarks per lane, the particle's whole map in
+// registers from the single coalesced load to the single coalesced store.  Input is the
+// association kernel's hand-off: per landmark the (<= 2) blobs that pass its gates, per blob
+// the number of landmarks that pass.  A blob passed by one landmark is matched iff its
+// probability is > 0 (strict '>' from 0.0, :369-381); a blob passed by several is given to
+// the landmark with the largest probability, the earliest on a tie -- LDS atomicMax on the
+// probability bits, then atomicMin on the landmark index among those that attain it --
+// evaluated here because the covariances are already in registers.  Blobs nobody passes or
+// wins multiply the weight by 0.1 (:94-95).  Updates of one landmark are applied in scan
+// order (:88) and every probability refers to the state before any update (:84).
+struct FastArgs {
+  SlotSource ss;
+  unsigned char* map_dst;
+  size_t count_off;
+  int32_t* src;
+  const double *x, *y;
+  double* logw;
+  const double* exact;          // [B][6] cell order: bearing, r, g, b, ux, uy
+  const unsigned short* order;  // [B] cell order -> scan order
+  const uint2* lmpass;
+  const unsigned char* bcount;
+  const unsigned char* pflag;
+  const unsigned char* immutable;
+  int L, Lp, B;
+  Noise<double> qt;
+};
+
+struct FastSlot {
+  int t;                    // blob (cell order) or -1
+  int b;                    // its scan index
+  unsigned long long bits;  // contested candidate: probability bits (0: not positive)
+  unsigned flags;           // bit 0 contested, bit 1 apply the update, bit 2 unmatched (single, probability 0)
+};
+
+__device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<double>& lm, double sx, double sy,
+                                             double pse, uint2 packed, const unsigned char* bc,
+                                             unsigned long long* best, FastSlot (&sl)[kFastSlots]) {
+  const unsigned w[2] = {packed.x, packed.y};
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+    sl[k].t = t == 0xFFFF ? -1 : t;
+    sl[k].b = 0;
+    sl[k].bits = 0ull;
+    sl[k].flags = 0u;
+    if (sl[k].t < 0) continue;
+    sl[k].b = a.order[t];
+    const double* rec = a.exact + 6 * (size_t)t;
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+    if (bc[t] >= 2) {
+      sl[k].flags = 1u;
+      const double bp = 500.0 * prob_position_match(lm, sx, sy, pse, z.bearing, dir.x, dir.y);  // :439
+      const double cp = 500.0 * prob_color_match(lm, z.r, z.g, z.b);                          // :446
+      const double pr = bp * cp / 250000.0;                                                  // :455
+      if (pr > 0.0) {
+        sl[k].bits = (unsigned long long)__double_as_longlong(pr);
+        atomicMax(&best[t], sl[k].bits);
+      }
+    } else {
+      sl[k].flags = match_is_positive(lm, sx, sy, pse, z, dir.x, dir.y) ? 2u : 4u;
+    }
+  }
+}
+
+__device__ __forceinline__ double fast_apply(const FastArgs& a, Landmark<double>& lm, int l, double sx, double sy,
+                                             double pse, FastSlot (&sl)[kFastSlots], const int* win) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k)
+    if (sl[k].t >= 0 && (sl[k].flags & 1u) && sl[k].bits != 0ull && win[sl[k].t] == l) sl[k].flags |= 2u;
+  // scan order (:88): sort the (<= 4) slots by b, empty slots last (5-comparator network)
+  auto key = [](const FastSlot& x) { return x.t < 0 ? INT_MAX : x.b; };
+  auto cswap = [&](FastSlot& u, FastSlot& v) {
+    if (key(u) > key(v)) {
+      const FastSlot tmp = u;
+      u = v;
+      v = tmp;
+    }
+  };
+  cswap(sl[0], sl[1]);
+  cswap(sl[2], sl[3]);
+  cswap(sl[0], sl[2]);
+  cswap(sl[1], sl[3]);
+  cswap(sl[1], sl[2]);
+  const bool imm = a.immutable[l] != 0;
+  bool fresh = true;
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].t < 0) continue;
+    if (sl[k].flags & 4u) acc += Consts<double>::log_no_match;
+    if (!(sl[k].flags & 2u)) continue;
+    const double* rec = a.exact + 6 * (size_t)sl[k].t;
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+    acc += ekf_update(lm, sx, sy, z, a.qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+    fresh = imm;
+  }
+  return acc;
+}
+
+constexpr int kFastThreads = 512;  // one landmark per lane: L <= 512 in one pass
+
+__global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kFastThreads / kWave];
+  const int64_t p = blockIdx.x;
+  if (a.pflag[p]) return;  // workgroup-uniform: the general kernel takes this particle
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp;
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  int* win = reinterpret_cast<int*>(best + B);
+  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
+  const unsigned char* sslot = a.ss.at(a.src[p]);
+  unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p];
+  const int l = tid;
+  const bool active = l < Lp, has = l < a.L;
+  Landmark<double> A{};
+  uint2 lp = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  if (active) {
+    A = load_landmark(sf, sc, Lp, l);
+    lp = a.lmpass[(size_t)p * Lp + l];
+  }
+  for (int t = tid; t < B; t += kFastThreads) {
+    best[t] = 0ull;
+    win[t] = INT_MAX;
+    bc[t] = a.bcount[(size_t)p * B + t];
+  }
+  __syncthreads();
+  int nun = 0;  // blobs no landmark passes
+  for (int t = tid; t < B; t += kFastThreads) nun += bc[t] == 0;
+  FastSlot sa[kFastSlots];
+  const double pseA = has ? atan2(A.my - sy, A.mx - sx) : 0.0;
+  fast_prepare(a, A, sx, sy, pseA, has ? lp : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, sa);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k)
+    if (sa[k].t >= 0 && sa[k].bits != 0ull && sa[k].bits == best[sa[k].t]) atomicMin(&win[sa[k].t], l);
+  __syncthreads();
+  for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
+  double acc = (double)nun * Consts<double>::log_no_match;
+  if (has) acc += fast_apply(a, A, l, sx, sy, pseA, sa, win);
+  if (active) {
+    df[(size_t)F_MX * Lp + l] = A.mx;
+    df[(size_t)F_MY * Lp + l] = A.my;
+    df[(size_t)F_MR * Lp + l] = A.mr;
+    df[(size_t)F_MG * Lp + l] = A.mg;
+    df[(size_t)F_MB * Lp + l] = A.mb;
+    df[(size_t)F_PXX * Lp + l] = A.pxx;
+    df[(size_t)F_PXY * Lp + l] = A.pxy;
+    df[(size_t)F_PYY * Lp + l] = A.pyy;
+    df[(size_t)F_CRR * Lp + l] = A.crr;
+    df[(size_t)F_CRG * Lp + l] = A.crg;
+    df[(size_t)F_CRB * Lp + l] = A.crb;
+    df[(size_t)F_CGG * Lp + l] = A.cgg;
+    df[(size_t)F_CGB * Lp + l] = A.cgb;
+    df[(size_t)F_CBB * Lp + l] = A.cbb;
+    dc[l] = A.count;
+  }
+  const double tot = block_sum<kFastThreads / kWave>(acc, red);
+  if (tid == 0) {
+    a.logw[p] += tot;
+    a.src[p] = (int32_t)p;
+  }
+}
+
+void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
+                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt) {
+  if (d.P == 0) return;
+  FastArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = fh.lmpass;
+  a.bcount = fh.bcount;
+  a.pflag = fh.pflag;
+  a.immutable = d.immutable;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  const size_t lds = (size_t)B * 13 + 16;
+  hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
+}
+
 int g_observe_nv = 0;  // tuning: 0 = default per variant, 1 / 2 = landmarks per lane
 
 void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
                     const int32_t* first_dev, const int32_t* next_dev, int n_unmatched, int32_t* ids_dev,
-                    const NoiseD& qt) {
+                    const NoiseD& qt, const unsigned char* only_flagged, bool flip) {
   if (d.P == 0) return;
   ObserveArgs a;
   a.ss = slot_source(d);
@@ -919,6 +1169,7 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
   a.ids = ids_dev;
   a.immutable = d.immutable;
   a.n_unmatched = n_unmatched;
+  a.only_flagged = only_flagged;
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
@@ -935,8 +1186,10 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
     else
       hipLaunchKernelGGL((k_observe<false, 1>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
   }
-  d.mcur ^= 1;
-  d.alt = nullptr;  // every slot was rewritten into the particle's own map buffer
+  if (flip) {
+    d.mcur ^= 1;
+    d.alt = nullptr;  // every slot was rewritten into the particle's own map buffer
+  }
 }
 
 // ------------------------------------------------------------------ K4 weights

@@ -78,15 +78,29 @@ constexpr int kGridMax = 16;
 size_t blob_grid_table_bytes(int ncell, int B, int n9);
 size_t assoc_grid_lds_bytes(int ncell, int B, int n9);
 constexpr size_t kMaxDynLds = 156 * 1024;  // 160 KiB per workgroup minus the kernels' static __shared__
+// Hand-off from the association kernel to k_observe_fast (all three NULL = not used).
+struct FastHandoff {
+  uint2* lmpass = nullptr;          // [P][Lp]
+  unsigned char* bcount = nullptr;  // [P][B]
+  unsigned char* pflag = nullptr;   // [P]
+};
+constexpr int kFastSlots = 4;  // gate-passing blobs a landmark can hand over; more -> general path
+constexpr int kFastMaxL = 512;  // k_observe_fast keeps a particle's whole map in registers (2 landmarks/lane)
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev,
-                       bool finalize);
+                       bool finalize, const FastHandoff& fh);
+// ML observe for L <= kFastMaxL straight from the hand-off: contested blobs are settled here,
+// with the landmark state in registers.  Particles flagged in fh.pflag are skipped (the general
+// k_observe, launched with only_flagged, takes them).
+void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
+                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt);
 // K3: EKF update + log-weight.  known: first/next chains shared by all particles (device
 // arrays, built on the host); otherwise built per particle in LDS from ids_dev.
 // ML ids are TENTATIVE: k_observe keeps a match only if its probability is > 0 (needs blobdir).
 void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
                     const int32_t* first_dev, const int32_t* next_dev, int n_unmatched,
-                    int32_t* ids_dev, const NoiseD& qt);
+                    int32_t* ids_dev, const NoiseD& qt, const unsigned char* only_flagged = nullptr,
+                    bool flip = true);
 extern int g_observe_nv;
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);

@@ -167,3 +167,92 @@ def test_observe_with_both_kernels_gives_identical_state(lib):
     assert np.array_equal(out[0][1], out[1][1])
     for a, b in zip(out[0][2], out[1][2]):
         assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- fast hand-off path (L <= 512)
+def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None):
+    L = means.shape[0]
+    f = lib.DeviceFilter(P, L)
+    f.set_option("fast_observe", fast)
+    f.upload_map(means, covs.reshape(L, 25), immutable)
+    f.upload_poses(poses)
+    f.observe(blobs)  # no ids requested: the production route
+    out = (f.download_poses(), f.download_landmarks())
+    f.close()
+    return out
+
+
+def oracle_state(P, means, covs, poses, blobs, immutable=None):
+    o = OracleFilter(P, means, covs, immutable)
+    o.x, o.y, o.h = poses[:, 0].copy(), poses[:, 1].copy(), poses[:, 2].copy()
+    o.observe(blobs)
+    return o
+
+
+def check_fast(lib, P, means, covs, poses, blobs, immutable=None):
+    fast = observe_state(lib, P, means, covs, poses, blobs, 1, immutable)
+    gen = observe_state(lib, P, means, covs, poses, blobs, 0, immutable)
+    o = oracle_state(P, means, covs, poses, blobs, immutable)
+    for got in (fast, gen):
+        w = got[0][:, 3]
+        assert np.allclose(w, o.weights(), rtol=1e-9, atol=0)
+        m, c, k = got[1]
+        assert np.allclose(m, o.mean, rtol=1e-10, atol=1e-12)
+        assert np.allclose(c, o.cov, rtol=1e-9, atol=1e-13)
+        assert np.array_equal(k, o.count)
+    # the two device routes agree far tighter than either agrees with NumPy
+    assert np.allclose(fast[0], gen[0], rtol=1e-11, atol=0)
+    assert np.allclose(fast[1][0], gen[1][0], rtol=1e-12, atol=1e-14)
+    assert np.array_equal(fast[1][2], gen[1][2])
+
+
+@pytest.mark.parametrize("L", [1, 2, 7, 50, 255, 500, 512])
+def test_fast_observe_synthetic(lib, L):
+    rs = np.random.RandomState(100 + L)
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    check_fast(lib, 40, means, covs, rand_poses(rs, 40), blobs)
+
+
+def test_fast_observe_contested_and_ties(lib):
+    rs = np.random.RandomState(5)
+    means, covs = synthetic_world(60)
+    means = np.vstack([means, means[10:14]])  # duplicates: exact ties, earliest must win
+    covs = np.vstack([covs, covs[10:14]])
+    means[20:40, 2:] = 120.0  # colour clash: many contested blobs
+    blobs = synthetic_scan(means[:60], (0.0, 0.0, 0.0))
+    check_fast(lib, 64, means, covs, rand_poses(rs, 64, 0.1), blobs)
+
+
+def test_fast_observe_flagged_particles_take_the_general_route(lib):
+    # ten blobs on one landmark: more than two gate-passing blobs for it -> particle flagged
+    rs = np.random.RandomState(6)
+    means, covs = synthetic_world(40)
+    scan = synthetic_scan(means, (0.0, 0.0, 0.0))
+    dup = np.repeat(scan[5:6], 9, axis=0)
+    dup[:, 0] += rs.uniform(-0.05, 0.05, 9)
+    dup[:, 1:] += rs.uniform(-3, 3, (9, 3))
+    strays = np.column_stack([rs.uniform(-3, 3, 6), rs.uniform(0, 255, (6, 3))])
+    imm = np.zeros(40, dtype=np.uint8)
+    imm[7] = 1
+    check_fast(lib, 48, means, covs, rand_poses(rs, 48), np.vstack([scan, dup, strays]), imm)
+
+
+def test_fast_observe_two_blobs_on_one_landmark_in_scan_order(lib):
+    rs = np.random.RandomState(8)
+    means, covs = synthetic_world(30)
+    scan = synthetic_scan(means, (0.0, 0.0, 0.0))
+    second = scan[[3, 11, 20]].copy()
+    second[:, 0] += 0.03
+    second[:, 1:] += rs.uniform(-2, 2, (3, 3))
+    blobs = np.vstack([second[:1], scan, second[1:]])  # one duplicate BEFORE, two AFTER in scan order
+    check_fast(lib, 32, means, covs, rand_poses(rs, 32, 0.05), blobs)
+
+
+def test_fast_observe_underflow_and_empty_scan(lib):
+    means = np.array([[20.0, 0.0, 50, 50, 50], [0.0, 20.0, 200, 50, 50]])
+    covs = np.stack([1e-6 * np.identity(5), 0.25 * np.identity(5)])
+    poses = np.array([[0.0, 0.0, 0.0, 1.0]] * 4)
+    check_fast(lib, 4, means, covs, poses, np.array([[0.3, 50, 50, 50], [0.0, 50, 50, 50], [1.5708, 200, 50, 50]]))
+    got = observe_state(lib, 4, means, covs, poses, np.zeros((0, 4)), 1)
+    assert np.array_equal(got[0][:, 3], np.ones(4))
