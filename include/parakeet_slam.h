@@ -191,7 +191,8 @@ int pk_shard_block_totals(pk_filter* f, double gmax, int32_t weight_domain, doub
 int pk_shard_offspring(pk_filter* f, const double* global_totals, int64_t n_global_blocks,
                        int64_t first_block, int64_t global_particles, double u, int32_t last_shard,
                        int64_t* slot_hi);
-/* Bytes of one migrating particle record: (x, y, heading, log weight) + its landmark slot. */
+/* Bytes of one migrating particle record: header (x, y, heading, log weight, slot_lo, slot_hi)
+ * + its landmark slot. */
 int64_t pk_particle_bytes(const pk_filter* f);
 /* Pack the listed local particles into dev_buf (device pointer owned by the caller, e.g. a
  * torch tensor), n records of pk_particle_bytes. */
@@ -201,6 +202,23 @@ int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* d
  * from dev_buf by the next pk_observe / pk_associate / download, so dev_buf must stay alive
  * and unchanged until one of those has run. */
 int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, int64_t n_received);
+
+/* Device-resident variants of the same protocol: every buffer is a DEVICE pointer owned by the
+ * caller (torch tensors the collectives run on), nothing is copied to the host and nothing
+ * synchronises the stream.  plan: leaves the offspring table on the device and writes
+ * dev_ranges[2 d], [2 d + 1] = the contiguous local particles [j0, j1) whose offspring overlap
+ * rank d's output slots.  pack: records of those particles for every rank but `rank`, in rank
+ * order (`ranges` is the host copy of dev_ranges); each record header carries the destination
+ * slots [lo, hi) it fills, so no per-particle metadata travels separately.  adopt: builds the
+ * new generation from the local table and the received records (source-rank order). */
+int pk_shard_max_logw_dev(pk_filter* f, double* dev_out);
+int pk_shard_block_totals_dev(pk_filter* f, const double* dev_gmax, int32_t weight_domain,
+                              double* dev_totals);
+int pk_shard_plan_dev(pk_filter* f, const double* dev_global_totals, int64_t n_global_blocks,
+                      int64_t first_block, int64_t global_particles, double u, int32_t last_shard,
+                      int32_t world, int64_t* dev_ranges);
+int pk_shard_pack_dev(pk_filter* f, const int64_t* ranges, int32_t world, int32_t rank, void* dev_buf);
+int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received);
 
 /* ---- single-triple probe ------------------------------------------------------
  * Runs the device functions the kernels are built from on ONE (pose, landmark, blob):

@@ -62,6 +62,12 @@ SIGNATURES = {
     "pk_shard_block_totals": (C.c_int, [_h, C.c_double, C.c_int32, _dp]),
     "pk_set_shard": (C.c_int, [_h, C.c_int64]),
     "pk_shard_offspring": (C.c_int, [_h, _dp, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, _lp]),
+    "pk_shard_max_logw_dev": (C.c_int, [_h, C.c_void_p]),
+    "pk_shard_block_totals_dev": (C.c_int, [_h, C.c_void_p, C.c_int32, C.c_void_p]),
+    "pk_shard_plan_dev": (C.c_int, [_h, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_int32,
+                                    C.c_void_p]),
+    "pk_shard_pack_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p]),
+    "pk_shard_adopt_dev": (C.c_int, [_h, C.c_int32, C.c_void_p, C.c_int64]),
     "pk_particle_bytes": (C.c_int64, [_h]),
     "pk_pack_particles": (C.c_int, [_h, _lp, C.c_int64, C.c_void_p]),
     "pk_adopt_particles": (C.c_int, [_h, _lp, C.c_void_p, C.c_int64]),
@@ -278,6 +284,24 @@ class DeviceFilter(object):
         check(self._lib.pk_shard_offspring(self._h, dptr(t), t.size, int(first_block), int(global_particles), float(u),
                                            1 if last_shard else 0, lptr(out)))
         return out
+
+    def shard_max_logw_dev(self, out_ptr):
+        check(self._lib.pk_shard_max_logw_dev(self._h, C.c_void_p(out_ptr)))
+
+    def shard_block_totals_dev(self, gmax_ptr, domain, totals_ptr):
+        check(self._lib.pk_shard_block_totals_dev(self._h, C.c_void_p(gmax_ptr), int(domain), C.c_void_p(totals_ptr)))
+
+    def shard_plan_dev(self, gtotals_ptr, n_blocks, first_block, global_particles, u, last_shard, world, ranges_ptr):
+        check(self._lib.pk_shard_plan_dev(self._h, C.c_void_p(gtotals_ptr), int(n_blocks), int(first_block),
+                                          int(global_particles), float(u), 1 if last_shard else 0, int(world),
+                                          C.c_void_p(ranges_ptr)))
+
+    def shard_pack_dev(self, ranges, world, rank, buf_ptr):
+        r = np.ascontiguousarray(ranges, dtype=np.int64)
+        check(self._lib.pk_shard_pack_dev(self._h, lptr(r), int(world), int(rank), C.c_void_p(buf_ptr)))
+
+    def shard_adopt_dev(self, rank, recv_ptr, n_received):
+        check(self._lib.pk_shard_adopt_dev(self._h, int(rank), C.c_void_p(recv_ptr), int(n_received)))
 
     def particle_bytes(self):
         return int(self._lib.pk_particle_bytes(self._h))

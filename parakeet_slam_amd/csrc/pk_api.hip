@@ -79,6 +79,8 @@ struct pk_filter {
   int64_t* hi_dev = nullptr;    // P + 1
   int64_t* idx_dev = nullptr;   // P
   int64_t* srcs_dev = nullptr;  // P
+  int64_t* rlohi_dev = nullptr; // (lo, hi) of the received records
+  int64_t rlohi_cap = 0;
   unsigned char* grid_dev = nullptr;  // association tables (cell offsets | fp32 colours | order)
   size_t grid_cap = 0;
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
@@ -462,7 +464,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       if (f->grid_dev) (void)hipFree(f->grid_dev);
   for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag})
     if (q) (void)hipFree(q);
-  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev})
+  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
       f->grid_dev = nullptr;
       f->grid_cap = 0;
@@ -634,7 +636,7 @@ int pk_destroy(pk_filter* f) {
   if (f->grid_dev) (void)hipFree(f->grid_dev);
   for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag})
     if (q) (void)hipFree(q);
-  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev})
+  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
   void* rest[] = {d.immutable, f->z_dev,  f->blobs_dev, f->blobdir_dev, f->first_dev, f->next_dev, f->ids_dev,
                   f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
@@ -1139,6 +1141,100 @@ int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, in
   if (n_received == 0) f->d.alt = nullptr;
   f->src_identity = false;
   PK_HIP(hipStreamSynchronize(f->stream));  // src was pageable host memory
+  return PK_OK;
+}
+
+// ---- device-resident variants: every buffer is a device pointer owned by the caller (torch
+// tensors), nothing synchronises the stream; see DESIGN.md section 6 --------------------------
+int pk_shard_max_logw_dev(pk_filter* f, double* dev_out) {
+  if (!f || !dev_out) return fail(PK_ERR_INVALID, "pk_shard_max_logw_dev: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  Span t(f, PK_T_WEIGHTS);
+  launch_block_max(f->stream, f->d, f->partial, dev_out);
+  return PK_OK;
+}
+
+int pk_shard_block_totals_dev(pk_filter* f, const double* dev_gmax, int32_t weight_domain, double* dev_totals) {
+  if (!f || !dev_totals || (weight_domain == PK_WEIGHTS_LOG && !dev_gmax))
+    return fail(PK_ERR_INVALID, "pk_shard_block_totals_dev: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  Span t(f, PK_T_WEIGHTS);
+  launch_scan_local(f->stream, f->d, dev_gmax ? dev_gmax : f->gmax, weight_domain, f->clocal, dev_totals);
+  return PK_OK;
+}
+
+int pk_shard_plan_dev(pk_filter* f, const double* dev_global_totals, int64_t n_global_blocks, int64_t first_block,
+                      int64_t global_particles, double u, int32_t last_shard, int32_t world, int64_t* dev_ranges) {
+  if (!f || !dev_global_totals || !dev_ranges || world < 1) return fail(PK_ERR_INVALID, "pk_shard_plan_dev: bad argument");
+  if (!(u >= 0.0 && u < 1.0)) return fail(PK_ERR_INVALID, "pk_shard_plan_dev: u = %g outside [0,1)", u);
+  if (first_block < 0 || first_block + f->nblocks > n_global_blocks || global_particles != (int64_t)world * f->d.P)
+    return fail(PK_ERR_INVALID, "pk_shard_plan_dev: shard geometry (%lld blocks from %lld of %lld, %lld particles x %d)",
+                (long long)f->nblocks, (long long)first_block, (long long)n_global_blocks, (long long)f->d.P, world);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (n_global_blocks > f->gblocks_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    if (f->g_totals) (void)hipFree(f->g_totals);
+    if (f->g_offsets) (void)hipFree(f->g_offsets);
+    f->g_totals = f->g_offsets = nullptr;
+    f->gblocks_cap = 0;
+    if ((rc = dev_alloc(f, &f->g_totals, (size_t)n_global_blocks))) return rc;
+    if ((rc = dev_alloc(f, &f->g_offsets, (size_t)n_global_blocks + 1))) return rc;
+    f->gblocks_cap = n_global_blocks;
+  }
+  if (!f->hi_dev && (rc = dev_alloc(f, &f->hi_dev, (size_t)f->d.P + 1))) return rc;
+  Span t(f, PK_T_WEIGHTS);
+  launch_scan_blocks(f->stream, dev_global_totals, n_global_blocks, f->g_offsets, f->sum);
+  launch_offspring(f->stream, f->clocal, f->g_offsets, f->sum, first_block, f->d.P, global_particles, u,
+                   last_shard ? 1 : 0, f->hi_dev);
+  launch_shard_ranges(f->stream, f->hi_dev, f->d.P, world, dev_ranges);
+  return PK_OK;
+}
+
+int pk_shard_pack_dev(pk_filter* f, const int64_t* ranges, int32_t world, int32_t rank, void* dev_buf) {
+  if (!f || !ranges || world < 1 || rank < 0 || rank >= world) return fail(PK_ERR_INVALID, "pk_shard_pack_dev: bad argument");
+  if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_pack_dev: call pk_shard_plan_dev first");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const int64_t P = f->d.P;
+  const size_t stride = kPoseRecordBytes + f->d.lay.slot_bytes;
+  int64_t rec = 0;
+  Span t(f, PK_T_RESAMPLE);
+  for (int d = 0; d < world; ++d) {
+    if (d == rank) continue;
+    const int64_t j0 = ranges[2 * d], j1 = ranges[2 * d + 1];
+    if (j0 < 0 || j1 < j0 || j1 > P) return fail(PK_ERR_INVALID, "pk_shard_pack_dev: range [%lld, %lld) for rank %d", (long long)j0, (long long)j1, d);
+    if (j1 > j0 && !dev_buf) return fail(PK_ERR_INVALID, "pk_shard_pack_dev: NULL buffer");
+    launch_pack_range(f->stream, f->d, f->hi_dev, j0, j1 - j0, (int64_t)d * P, (int64_t)(d + 1) * P,
+                      static_cast<unsigned char*>(dev_buf) + (size_t)rec * stride);
+    rec += j1 - j0;
+  }
+  return PK_OK;
+}
+
+int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
+  if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_dev: bad argument");
+  if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: call pk_shard_plan_dev first");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first
+    f->src_identity = false;
+    if ((rc = materialise(f))) return rc;
+  }
+  if (n_received > f->rlohi_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    if (f->rlohi_dev) (void)hipFree(f->rlohi_dev);
+    f->rlohi_dev = nullptr;
+    f->rlohi_cap = 0;
+    if ((rc = dev_alloc(f, &f->rlohi_dev, (size_t)(2 * n_received + 2 * n_received / 4 + 16)))) return rc;
+    f->rlohi_cap = n_received + n_received / 4;
+  }
+  Span t(f, PK_T_RESAMPLE);
+  launch_adopt_dev(f->stream, f->d, f->hi_dev, (int64_t)rank * f->d.P, static_cast<const unsigned char*>(dev_recv),
+                   n_received, f->rlohi_dev);
+  f->src_identity = false;
   return PK_OK;
 }
 

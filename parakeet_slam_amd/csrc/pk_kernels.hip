@@ -1502,6 +1502,8 @@ __global__ void __launch_bounds__(256) k_pack(SlotSource ss, const int32_t* __re
     hd[1] = y[j];
     hd[2] = h[j];
     hd[3] = lw[j];
+    hd[4] = 0.0;
+    hd[5] = 0.0;
   }
   const uint4* s = reinterpret_cast<const uint4*>(ss.at(src[j]));
   uint4* d = reinterpret_cast<uint4*>(rec + kPoseRecordBytes);
@@ -1551,6 +1553,145 @@ void launch_adopt(hipStream_t s, DeviceState& d, const int64_t* src_dev, const u
                      d.P);
   d.cur = n;
   d.alt = buf_dev;
+  d.alt_stride = stride;
+  d.alt_off = kPoseRecordBytes;
+}
+
+
+// ---- device-resident exchange ------------------------------------------------------------
+// ranges[2 d], ranges[2 d + 1] = [j0, j1): the local particles whose offspring overlap the
+// output slots [d P, (d + 1) P) of rank d (hi from k_offspring, monotone).
+__global__ void k_shard_ranges(const int64_t* __restrict__ hi, int64_t P, int world, int64_t* __restrict__ ranges) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= world) return;
+  const int64_t start = (int64_t)d * P, end = start + P;
+  int64_t lo = 0, up = P;  // first j with hi[j + 1] > start
+  while (lo < up) {
+    const int64_t mid = (lo + up) >> 1;
+    if (hi[mid + 1] > start)
+      up = mid;
+    else
+      lo = mid + 1;
+  }
+  const int64_t j0 = lo;
+  lo = 0;
+  up = P;  // first j with hi[j] >= end
+  while (lo < up) {
+    const int64_t mid = (lo + up) >> 1;
+    if (hi[mid] >= end)
+      up = mid;
+    else
+      lo = mid + 1;
+  }
+  ranges[2 * d] = j0;
+  ranges[2 * d + 1] = lo < j0 ? j0 : lo;
+}
+void launch_shard_ranges(hipStream_t s, const int64_t* hi_dev, int64_t P_local, int world, int64_t* ranges_dev) {
+  hipLaunchKernelGGL(k_shard_ranges, dim3((world + 63) / 64), dim3(64), 0, s, hi_dev, P_local, world, ranges_dev);
+}
+
+// Records of the contiguous local particles [j0, j0 + n) for one destination; the header
+// carries the destination slots [lo, hi) each copy fills (empty for particles without
+// offspring there: they ride along, the receiver skips them).
+__global__ void __launch_bounds__(256) k_pack_range(SlotSource ss, const int32_t* __restrict__ src,
+                                                    const double* __restrict__ x, const double* __restrict__ y,
+                                                    const double* __restrict__ h, const double* __restrict__ lw,
+                                                    const int64_t* __restrict__ hi, int64_t j0, int64_t slot_start,
+                                                    int64_t slot_end, unsigned char* __restrict__ buf) {
+  const int64_t i = blockIdx.x;
+  const int64_t j = j0 + i;
+  unsigned char* rec = buf + (size_t)i * (kPoseRecordBytes + ss.slot_bytes);
+  if (threadIdx.x == 0) {
+    double* hd = reinterpret_cast<double*>(rec);
+    hd[0] = x[j];
+    hd[1] = y[j];
+    hd[2] = h[j];
+    hd[3] = lw[j];
+    int64_t lo = hi[j] > slot_start ? hi[j] : slot_start;
+    int64_t up = hi[j + 1] < slot_end ? hi[j + 1] : slot_end;
+    if (up < lo) up = lo;
+    reinterpret_cast<int64_t*>(rec)[4] = lo;
+    reinterpret_cast<int64_t*>(rec)[5] = up;
+  }
+  const uint4* s = reinterpret_cast<const uint4*>(ss.at(src[j]));
+  uint4* d = reinterpret_cast<uint4*>(rec + kPoseRecordBytes);
+  const size_t n = ss.slot_bytes / 16;
+  for (size_t k = threadIdx.x; k < n; k += blockDim.x) d[k] = s[k];
+}
+void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t j0, int64_t n, int64_t slot_start,
+                       int64_t slot_end, unsigned char* buf_dev) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pack_range, dim3((unsigned)n), dim3(256), 0, s, slot_source(d), d.src[d.cur], d.x[d.cur],
+                     d.y[d.cur], d.h[d.cur], d.logw[d.cur], hi_dev, j0, slot_start, slot_end, buf_dev);
+}
+
+__global__ void __launch_bounds__(256) k_extract_lohi(const unsigned char* __restrict__ buf, size_t stride, int64_t n,
+                                                      int64_t* __restrict__ rlohi) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t* hd = reinterpret_cast<const int64_t*>(buf + (size_t)r * stride);
+  rlohi[2 * r] = hd[4];
+  rlohi[2 * r + 1] = hd[5];
+}
+
+// New generation from the device-side plan: local slot k (global slot K) takes the local
+// particle j with hi[j] <= K < hi[j + 1] if K lies in this shard's offspring range, else the
+// received record whose [lo, hi) holds K (records arrive in slot order).
+__global__ void __launch_bounds__(256) k_adopt_dev(const double* __restrict__ x, const double* __restrict__ y,
+                                                   const double* __restrict__ h, const double* __restrict__ lw,
+                                                   const int32_t* __restrict__ src, double* __restrict__ x2,
+                                                   double* __restrict__ y2, double* __restrict__ h2,
+                                                   double* __restrict__ lw2, int32_t* __restrict__ src2,
+                                                   const int64_t* __restrict__ hi, int64_t slot_start,
+                                                   const unsigned char* __restrict__ buf, size_t stride,
+                                                   const int64_t* __restrict__ rlohi, int64_t n_recv, int64_t P) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const int64_t K = slot_start + k;
+  if (K >= hi[0] && K < hi[P]) {
+    int64_t lo = 0, up = P - 1;  // first j with hi[j + 1] > K
+    while (lo < up) {
+      const int64_t mid = (lo + up) >> 1;
+      if (hi[mid + 1] > K)
+        up = mid;
+      else
+        lo = mid + 1;
+    }
+    x2[k] = x[lo];
+    y2[k] = y[lo];
+    h2[k] = h[lo];
+    lw2[k] = lw[lo];
+    src2[k] = src[lo];
+  } else {
+    int64_t lo = 0, up = n_recv - 1;  // first record with hi_r > K
+    while (lo < up) {
+      const int64_t mid = (lo + up) >> 1;
+      if (rlohi[2 * mid + 1] > K)
+        up = mid;
+      else
+        lo = mid + 1;
+    }
+    const double* hd = reinterpret_cast<const double*>(buf + (size_t)lo * stride);
+    x2[k] = hd[0];
+    y2[k] = hd[1];
+    h2[k] = hd[2];
+    lw2[k] = hd[3];
+    src2[k] = (int32_t)(-(lo + 1));
+  }
+}
+void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
+                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev) {
+  if (d.P == 0) return;
+  const int c = d.cur, n = c ^ 1;
+  const size_t stride = kPoseRecordBytes + d.lay.slot_bytes;
+  if (n_recv > 0)
+    hipLaunchKernelGGL(k_extract_lohi, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, buf_dev, stride, n_recv,
+                       rlohi_dev);
+  hipLaunchKernelGGL(k_adopt_dev, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
+                     d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], hi_dev, slot_start, buf_dev,
+                     stride, rlohi_dev, n_recv, d.P);
+  d.cur = n;
+  d.alt = n_recv > 0 ? buf_dev : nullptr;
   d.alt_stride = stride;
   d.alt_off = kPoseRecordBytes;
 }

@@ -122,12 +122,20 @@ void launch_materialise(hipStream_t s, DeviceState& d);
 void launch_broadcast_slot(hipStream_t s, DeviceState& d, const unsigned char* slot_dev);
 void launch_probe(hipStream_t s, const double* in_dev, double* out_dev);
 // sharded resample
-constexpr size_t kPoseRecordBytes = 4 * sizeof(double);  // x, y, h, logw in front of the map slot
+// record header in front of the map slot: x, y, h, logw, slot_lo, slot_hi (the last two int64:
+// the global output slots this copy fills at its destination; 0, 0 when the caller plans on the host)
+constexpr size_t kPoseRecordBytes = 6 * sizeof(double);
 void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,
                       int64_t first_block, int64_t P_local, int64_t P_global, double u, int last_shard,
                       int64_t* hi_dev);
 void launch_pack(hipStream_t s, DeviceState& d, const int64_t* idx_dev, int64_t n, unsigned char* buf_dev);
 void launch_adopt(hipStream_t s, DeviceState& d, const int64_t* src_dev, const unsigned char* buf_dev);
+// device-resident variant of the exchange (no per-particle host metadata)
+void launch_shard_ranges(hipStream_t s, const int64_t* hi_dev, int64_t P_local, int world, int64_t* ranges_dev);
+void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t j0, int64_t n, int64_t slot_start,
+                       int64_t slot_end, unsigned char* buf_dev);
+void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
+                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
 
 }  // namespace pk

@@ -11,8 +11,13 @@ all particles).  Per step a ShardedFilter therefore does:
   3. every shard scans the SAME global block totals in the SAME order, so the comb
      u r + k r lands on identical cumulative sums everywhere: each shard knows, for each of
      its own particles, which global output slots it fills -- no further communication
+     about weights.  An all-gather of (2 x world) particle-range bounds sizes step 4.
   4. all-to-all of the particles whose slots belong to another shard   (pose + landmark map;
-     the only bandwidth-relevant traffic, and only for migrating particles)
+     the only bandwidth-relevant traffic, and only for migrating particles); each record's
+     header names the slots it fills, so no per-particle metadata travels separately
+
+All per-step tensors live on the GPU and the kernels that fill / consume them are enqueued on
+the same stream as the collectives; the host synchronises once per resample.
 
 The draw u is replicated (same value on every rank), as the north star asks.  With shards
 that are multiples of 1024 particles the ancestors are bit-identical to the 1-GPU run.
@@ -102,89 +107,64 @@ def fill_from_received(local_src, rank, p_local, recv_ranges):
 
 # --------------------------------------------------------------------------- communicators
 class TorchComm(object):
-    """torch.distributed wrapper: 'nccl' (= RCCL) with device tensors, 'gloo' with host tensors."""
+    """torch.distributed on torch tensors, in place.  'nccl' (= RCCL over xGMI) runs on the device
+    tensors directly; 'gloo' (tests) stages device tensors through the host."""
 
-    def __init__(self, device=None):
+    def __init__(self):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.backend = dist.get_backend()
-        self.on_device = self.backend == "nccl"
-        self.device = torch.device("cuda", device if device is not None else torch.cuda.current_device()) \
-            if self.on_device else torch.device("cpu")
+        self.direct = dist.get_backend() == "nccl"
 
-    def allreduce_max(self, v):
-        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+    def _stage(self, t):
+        return t if (self.direct or not t.is_cuda) else t.cpu()
 
-    def allreduce_sum(self, a):
-        t = self.torch.as_tensor(np.asarray(a, dtype=np.float64)).to(self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+    def all_reduce_max_(self, t):
+        h = self._stage(t)
+        self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX)
+        if h is not t:
+            t.copy_(h)
 
-    def allgather(self, a):
-        t = self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
-        out = self.torch.empty(self.world * t.numel(), dtype=self.torch.float64, device=self.device)
-        self.dist.all_gather_into_tensor(out, t) if self.on_device else self.dist.all_gather(
-            list(out.view(self.world, -1).unbind(0)), t)
-        return out.cpu().numpy()
+    def all_reduce_sum_(self, t):
+        h = self._stage(t)
+        self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+        if h is not t:
+            t.copy_(h)
 
-    def alltoall_i64(self, per_dest):
-        """per_dest: list of int64 arrays (one per destination) -> list per source."""
-        if not self.on_device:
-            gathered = [None] * self.world
-            self.dist.all_gather_object(gathered, [np.asarray(a, dtype=np.int64) for a in per_dest])
-            return [gathered[src][self.rank] for src in range(self.world)]
+    def all_gather_(self, out, t):
+        """out: world * t.numel() elements, rank-major."""
+        h_in = self._stage(t)
+        if self.direct:
+            self.dist.all_gather_into_tensor(out, t)
+            return
+        h_out = out if not out.is_cuda else self.torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather(list(h_out.view(self.world, -1).unbind(0)), h_in)
+        if h_out is not out:
+            out.copy_(h_out)
+
+    def all_to_all_records(self, send, send_counts, recv_counts, record_bytes):
+        """send: uint8 tensor with the packed records in destination-rank order.  Returns a uint8
+        tensor on the same device with the received records in source-rank order."""
         torch = self.torch
-        counts = torch.tensor([len(a) for a in per_dest], dtype=torch.int64, device=self.device)
-        rcounts = torch.empty_like(counts)
-        self.dist.all_to_all_single(rcounts, counts)
-        rc = rcounts.cpu().tolist()
-        send = torch.as_tensor(np.concatenate([np.asarray(a, dtype=np.int64) for a in per_dest])
-                               if sum(len(a) for a in per_dest) else np.empty(0, np.int64)).to(self.device)
-        recv = torch.empty(int(sum(rc)), dtype=torch.int64, device=self.device)
-        self.dist.all_to_all_single(recv, send, rc, [len(a) for a in per_dest])
-        out, o = [], 0
-        r = recv.cpu().numpy()
-        for c in rc:
-            out.append(r[o:o + c])
-            o += c
-        return out
-
-    def alltoall_records(self, send_buf, send_counts, recv_counts, record_bytes):
-        """send_buf: torch uint8 tensor on the GPU with the packed records in destination order
-        (a NumPy uint8 array from the CPU test backend).  Returns the received records in source
-        order, same kind of buffer."""
-        torch = self.torch
-        n_recv = int(sum(recv_counts))
-        if isinstance(send_buf, np.ndarray):
-            parts, o = [], 0
-            for c in send_counts:
-                parts.append(send_buf[o:o + c * record_bytes].copy())
-                o += c * record_bytes
-            gathered = [None] * self.world
-            self.dist.all_gather_object(gathered, parts)
-            if not n_recv:
-                return np.empty(0, np.uint8)
-            return np.concatenate([gathered[src][self.rank] for src in range(self.world)])
-        recv = torch.empty(max(n_recv, 1) * record_bytes, dtype=torch.uint8, device=send_buf.device)
-        if self.on_device:
-            self.dist.all_to_all_single(recv[: n_recv * record_bytes], send_buf[: int(sum(send_counts)) * record_bytes],
-                                        [c * record_bytes for c in recv_counts], [c * record_bytes for c in send_counts])
+        n_recv, n_send = int(sum(recv_counts)), int(sum(send_counts))
+        recv = torch.empty(max(n_recv, 1) * record_bytes, dtype=torch.uint8, device=send.device)
+        if self.direct:
+            self.dist.all_to_all_single(recv[: n_recv * record_bytes], send[: n_send * record_bytes],
+                                        [c * record_bytes for c in recv_counts],
+                                        [c * record_bytes for c in send_counts])
             return recv
-        host = send_buf.cpu().numpy()
+        host = send[: n_send * record_bytes].cpu()
         parts, o = [], 0
         for c in send_counts:
-            parts.append(host[o:o + c * record_bytes])
+            parts.append(host[o:o + c * record_bytes].numpy().copy())
             o += c * record_bytes
         gathered = [None] * self.world
         self.dist.all_gather_object(gathered, parts)
-        got = np.concatenate([gathered[src][self.rank] for src in range(self.world)]) if n_recv else np.empty(0, np.uint8)
         if n_recv:
-            recv[: n_recv * record_bytes] = torch.as_tensor(got).to(send_buf.device)
+            got = np.concatenate([gathered[src][self.rank] for src in range(self.world)])
+            recv[: n_recv * record_bytes] = torch.from_numpy(got).to(send.device)
         return recv
 
     def barrier(self):
@@ -194,32 +174,48 @@ class TorchComm(object):
 # --------------------------------------------------------------------------- the filter
 class HipShard(_lib.DeviceFilter):
     """The product backend of a shard: the HIP library plus torch-allocated device buffers for
-    the migrating particle records (torch is plumbing here: device memory for the collective)."""
+    the small per-step exchange tensors and the migrating particle records (torch is plumbing
+    here: device memory the collectives can run on)."""
 
     def __init__(self, num_particles, num_landmarks, device=0):
         import torch
 
         super().__init__(num_particles, num_landmarks, device=device)
-        # One stream for the kernels, the record buffers and the collectives: torch orders
-        # RCCL work and allocator reuse against the *current* stream, so the library must run
-        # on it too, or its kernels would race the all-to-all that fills the buffers they read.
+        # One stream for the kernels, the buffers and the collectives: torch orders RCCL work
+        # and allocator reuse against the *current* stream, so the library must run on it too,
+        # or its kernels would race the all-to-all that fills the buffers they read.
         self.torch = torch
-        self.stream = torch.cuda.Stream(device=torch.device("cuda", device))
+        self.tdev = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(device=self.tdev)
         self.set_stream(self.stream.cuda_stream)
 
     def on_stream(self):
         return self.torch.cuda.stream(self.stream)
 
+    def new_f64(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.tdev)
+
+    def new_i64(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.int64, device=self.tdev)
+
     def alloc_records(self, n):
-        torch = self.torch
-        return torch.empty(max(int(n), 1) * self.particle_bytes(), dtype=torch.uint8,
-                           device=torch.device("cuda", self.device))
+        return self.torch.empty(max(int(n), 1) * self.particle_bytes(), dtype=self.torch.uint8, device=self.tdev)
 
-    def pack_records(self, local_idx, buf):
-        self.pack_particles(local_idx, int(buf.data_ptr()))
+    def max_logw_into(self, t):
+        self.shard_max_logw_dev(t.data_ptr())
 
-    def adopt_records(self, src, buf, n_received):
-        self.adopt_particles(src, int(buf.data_ptr()) if (buf is not None and n_received) else 0, n_received)
+    def block_totals_into(self, gmax_t, domain, totals_t):
+        self.shard_block_totals_dev(gmax_t.data_ptr() if gmax_t is not None else 0, domain, totals_t.data_ptr())
+
+    def plan_into(self, gtotals_t, first_block, global_particles, u, last_shard, world, ranges_t):
+        self.shard_plan_dev(gtotals_t.data_ptr(), gtotals_t.numel(), first_block, global_particles, u, last_shard, world,
+                            ranges_t.data_ptr())
+
+    def pack_into(self, ranges, world, rank, buf):
+        self.shard_pack_dev(ranges, world, rank, buf.data_ptr())
+
+    def adopt_from(self, rank, recv, n_received):
+        self.shard_adopt_dev(rank, recv.data_ptr() if (recv is not None and n_received) else 0, n_received)
 
 
 class ShardedFilter(object):
@@ -227,17 +223,28 @@ class ShardedFilter(object):
     and the tests use, with the resample made global across ranks."""
 
     def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None):
-        self.comm = comm if comm is not None else TorchComm(device)
+        self.comm = comm if comm is not None else TorchComm()
         self.rank, self.world = self.comm.rank, self.comm.world
         self.P = int(particles_per_rank)
         self.L = int(num_landmarks)
         self.P_global = self.P * self.world
         # the compute backend is the HIP library; tests may inject an object with the same
-        # shard_* / pack / adopt methods to exercise the exchange logic without a GPU
+        # *_into / pack_into / adopt_from methods to exercise the exchange logic without a GPU
         self.f = shard if shard is not None else HipShard(self.P, self.L, device=device)
         self.f.set_shard(self.rank * self.P)
+        self.nb = (self.P + SCAN_BLOCK - 1) // SCAN_BLOCK
+        f = self.f
+        self._gmax = f.new_f64(1)
+        self._totals = f.new_f64(self.nb)
+        self._gtotals = f.new_f64(self.nb * self.world)
+        self._ranges = f.new_i64(2 * self.world)
+        self._all_ranges = f.new_i64(2 * self.world * self.world)
+        self._sums = f.new_f64(4)
         self._recv_keepalive = None
         self.last_migrated = 0
+
+    def _ctx(self):
+        return self.f.on_stream() if hasattr(self.f, "on_stream") else _nullcontext()
 
     # -- pass-throughs -------------------------------------------------------------
     def upload_map(self, *a, **k):
@@ -257,7 +264,7 @@ class ShardedFilter(object):
 
     def observe(self, blobs, ids=None, return_ids=False):
         out = self.f.observe(blobs, ids=ids, return_ids=return_ids)
-        self._recv_keepalive = None  # adopted slots were rewritten into the shard's own map
+        self._recv_keepalive = None  # adopted slots were rewritten into the shard's own map (stream-ordered free)
         return out
 
     def download_poses(self):
@@ -285,45 +292,70 @@ class ShardedFilter(object):
 
     # -- the coupled part ----------------------------------------------------------
     def resample(self, u, domain=_lib.PK_WEIGHTS_LINEAR, return_ancestors=False):
-        """Global systematic resample (prkt_core_v2.py:210-252) with a replicated draw u."""
-        ctx = self.f.on_stream() if hasattr(self.f, "on_stream") else _nullcontext()
-        with ctx:
+        """Global systematic resample (prkt_core_v2.py:210-252) with a replicated draw u.
+        One host synchronisation per call: reading the (2 x world x world) table of particle
+        ranges that sizes the all-to-all."""
+        with self._ctx():
             return self._resample(u, domain, return_ancestors)
 
     def _resample(self, u, domain, return_ancestors):
-        f, comm = self.f, self.comm
-        gmax = comm.allreduce_max(f.shard_max_logw()) if domain == _lib.PK_WEIGHTS_LOG else 0.0
-        totals = f.shard_block_totals(gmax, domain)
-        nb = totals.size
-        gtotals = comm.allgather(totals) if self.world > 1 else totals
-        hi = f.shard_offspring(gtotals, self.rank * nb, self.P_global, u, self.rank == self.world - 1)
-        local_src, sends = plan_exchange(hi, self.rank, self.world, self.P)
-        rec_bytes = f.particle_bytes()
-        send_counts = [len(s[0]) for s in sends]
-        recv_lo = comm.alltoall_i64([s[1] for s in sends]) if self.world > 1 else [np.empty(0, np.int64)]
-        recv_hi = comm.alltoall_i64([s[2] for s in sends]) if self.world > 1 else [np.empty(0, np.int64)]
-        recv_counts = [len(a) for a in recv_lo]
-        local_src, n_recv = fill_from_received(local_src, self.rank, self.P, list(zip(recv_lo, recv_hi)))
-        n_send = int(sum(send_counts))
+        f, comm, W, R = self.f, self.comm, self.world, self.rank
+        gmax = None
+        if domain == _lib.PK_WEIGHTS_LOG:
+            gmax = self._gmax
+            f.max_logw_into(gmax)
+            if W > 1:
+                comm.all_reduce_max_(gmax)
+        f.block_totals_into(gmax, domain, self._totals)
+        if W > 1:
+            comm.all_gather_(self._gtotals, self._totals)
+            gtot = self._gtotals
+        else:
+            gtot = self._totals
+        f.plan_into(gtot, R * self.nb, self.P_global, u, R == W - 1, W, self._ranges)
+        if W > 1:
+            comm.all_gather_(self._all_ranges, self._ranges)
+            allr = self._all_ranges.cpu().numpy().reshape(W, W, 2)  # [source][destination] -> (j0, j1)
+        else:
+            allr = self._ranges.cpu().numpy().reshape(1, 1, 2)
+        counts = allr[:, :, 1] - allr[:, :, 0]
+        send_counts = [int(counts[R, d]) if d != R else 0 for d in range(W)]
+        recv_counts = [int(counts[s, R]) if s != R else 0 for s in range(W)]
+        n_send, n_recv = sum(send_counts), sum(recv_counts)
         self.last_migrated = n_send
         recv = None
-        if self.world > 1:  # every rank takes part in the exchange, even with nothing to move
-            send_buf = f.alloc_records(n_send)
+        if W > 1:  # every rank takes part in the exchange, even with nothing to move
+            send = f.alloc_records(n_send)
             if n_send:
-                f.pack_records(np.concatenate([s[0] for s in sends]), send_buf)
-            recv = comm.alltoall_records(send_buf, send_counts, recv_counts, rec_bytes)
-        f.adopt_records(local_src, recv, n_recv)
+                f.pack_into(allr[R].reshape(-1), W, R, send)
+            recv = comm.all_to_all_records(send, send_counts, recv_counts, f.particle_bytes())
+        f.adopt_from(R, recv, n_recv)
         self._recv_keepalive = recv if n_recv else None
         if return_ancestors:
-            return self._global_ancestors(hi, local_src)
+            return self._global_ancestors(u, domain)
         return None
 
-    def _global_ancestors(self, hi, local_src):
-        # global ancestor index of every local output slot, for tests: reconstruct from all hi
-        allhi = self.comm.allgather(hi[1:].astype(np.float64)).astype(np.int64) if self.world > 1 else hi[1:]
-        allhi = np.maximum.accumulate(allhi)
+    def _global_ancestors(self, u, domain):
+        """Tests only: global ancestor index of every local output slot, from the host-array
+        variant of the same plan (pk_shard_offspring)."""
+        gt = self._gtotals if self.world > 1 else self._totals
+        hi = self.f.shard_offspring(gt.cpu().numpy(), self.rank * self.nb, self.P_global, u, self.rank == self.world - 1)
+        allhi = self.f.new_f64(self.P * self.world)
+        mine = self.f.new_f64(self.P)
+        mine.copy_(self._to_dev(hi[1:].astype(np.float64), mine))
+        if self.world > 1:
+            self.comm.all_gather_(allhi, mine)
+        else:
+            allhi = mine
+        allhi = np.maximum.accumulate(allhi.cpu().numpy().astype(np.int64))
         slots = np.arange(self.rank * self.P, (self.rank + 1) * self.P)
         return np.searchsorted(allhi, slots, side="right").astype(np.int64)
+
+    @staticmethod
+    def _to_dev(a, like):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(a)).to(like.device)
 
     def step(self, v, w, dt, blobs, u, z=None, seed=0, draw=0, ids=None, domain=_lib.PK_WEIGHTS_LINEAR):
         self.reset_weights()
@@ -335,8 +367,9 @@ class ShardedFilter(object):
         """FastSLAM.summary (prkt_core_v2.py:254-276) over all shards: all-reduce of four sums."""
         s = self.f.pose_sums()
         if self.world > 1:
-            ctx = self.f.on_stream() if hasattr(self.f, "on_stream") else _nullcontext()
-            with ctx:
-                s = self.comm.allreduce_sum(s)
+            with self._ctx():
+                self._sums.copy_(self._to_dev(np.asarray(s, dtype=np.float64), self._sums))
+                self.comm.all_reduce_sum_(self._sums)
+                s = self._sums.cpu().numpy()
         n = float(self.P_global)
         return float(s[0] / n), float(s[1] / n), float(np.arctan2(s[2], s[3]))

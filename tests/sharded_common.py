@@ -80,37 +80,83 @@ class OracleShard(object):
             hi[-1] = P_global
         return hi
 
+    # ---- tensor-based protocol (mirrors HipShard; torch CPU tensors stand in for HBM) ----
+    def new_f64(self, n):
+        import torch
+
+        return torch.zeros(int(n), dtype=torch.float64)
+
+    def new_i64(self, n):
+        import torch
+
+        return torch.zeros(int(n), dtype=torch.int64)
+
     def particle_bytes(self):
-        return 8 * (4 + self.L * 30 + self.L)
+        return 8 * (6 + self.L * 30 + self.L)
 
     def alloc_records(self, n):
-        return np.zeros(max(n, 1) * self.particle_bytes(), dtype=np.uint8)
+        import torch
 
-    def _record(self, j):
+        return torch.zeros(max(int(n), 1) * self.particle_bytes(), dtype=torch.uint8)
+
+    def max_logw_into(self, t):
+        t[0] = self.shard_max_logw()
+
+    def block_totals_into(self, gmax_t, domain, totals_t):
+        import torch
+
+        totals_t.copy_(torch.from_numpy(self.shard_block_totals(float(gmax_t[0]) if gmax_t is not None else 0.0, domain)))
+
+    def plan_into(self, gtotals_t, first_block, P_global, u, last_shard, world, ranges_t):
+        self.hi = self.shard_offspring(gtotals_t.numpy(), first_block, P_global, u, last_shard)
+        hi, P = self.hi, self.P
+        for d in range(world):
+            start, end = d * P, (d + 1) * P
+            j0 = int(np.searchsorted(hi[1:], start, side="right"))
+            j1 = int(np.searchsorted(hi[:-1], end, side="left"))
+            ranges_t[2 * d] = j0
+            ranges_t[2 * d + 1] = max(j1, j0)
+
+    def _record(self, j, lo, up):
         o = self.o
-        return np.concatenate([[o.x[j], o.y[j], o.h[j], o.logw[j]], o.mean[j].ravel(), o.cov[j].ravel(),
-                               o.count[j].astype(np.float64)])
+        head = np.array([o.x[j], o.y[j], o.h[j], o.logw[j], 0.0, 0.0])
+        head[4:6] = np.array([lo, up], dtype=np.int64).view(np.float64)
+        return np.concatenate([head, o.mean[j].ravel(), o.cov[j].ravel(), o.count[j].astype(np.float64)])
 
-    def pack_records(self, idx, buf):
-        rb = self.particle_bytes()
-        for i, j in enumerate(idx):
-            buf[i * rb:(i + 1) * rb] = self._record(int(j)).view(np.uint8)
+    def pack_into(self, ranges, world, rank, buf):
+        rb, P, hi = self.particle_bytes(), self.P, self.hi
+        out = buf.numpy()
+        i = 0
+        for d in range(world):
+            if d == rank:
+                continue
+            for j in range(int(ranges[2 * d]), int(ranges[2 * d + 1])):
+                lo = max(int(hi[j]), d * P)
+                up = max(min(int(hi[j + 1]), (d + 1) * P), lo)
+                out[i * rb:(i + 1) * rb] = self._record(j, lo, up).view(np.uint8)
+                i += 1
 
-    def adopt_records(self, src, buf, n_received):
-        o, L, rb = self.o, self.L, self.particle_bytes()
+    def adopt_from(self, rank, recv, n_received):
+        o, L, rb, P, hi = self.o, self.L, self.particle_bytes(), self.P, self.hi
+        buf = recv.numpy() if recv is not None else None
+        recs = [buf[r * rb:(r + 1) * rb].view(np.float64) for r in range(n_received)]
+        rhi = np.array([int(r[4:6].view(np.int64)[1]) for r in recs], dtype=np.int64)
         x, y, h, lw = o.x.copy(), o.y.copy(), o.h.copy(), o.logw.copy()
         mean, cov, cnt = o.mean.copy(), o.cov.copy(), o.count.copy()
-        for k, a in enumerate(src):
-            if a >= 0:
+        for k in range(P):
+            K = rank * P + k
+            if hi[0] <= K < hi[P]:
+                a = int(np.searchsorted(hi[1:], K, side="right"))
                 o.x[k], o.y[k], o.h[k], o.logw[k] = x[a], y[a], h[a], lw[a]
                 o.mean[k], o.cov[k], o.count[k] = mean[a], cov[a], cnt[a]
             else:
-                r = -(a + 1)
-                rec = buf[r * rb:(r + 1) * rb].view(np.float64)
+                rec = recs[int(np.searchsorted(rhi, K, side="right"))]
+                lo_, up_ = rec[4:6].view(np.int64)
+                assert lo_ <= K < up_
                 o.x[k], o.y[k], o.h[k], o.logw[k] = rec[:4]
-                o.mean[k] = rec[4:4 + 5 * L].reshape(L, 5)
-                o.cov[k] = rec[4 + 5 * L:4 + 30 * L].reshape(L, 5, 5)
-                o.count[k] = rec[4 + 30 * L:].astype(np.int64)
+                o.mean[k] = rec[6:6 + 5 * L].reshape(L, 5)
+                o.cov[k] = rec[6 + 5 * L:6 + 30 * L].reshape(L, 5, 5)
+                o.count[k] = rec[6 + 30 * L:].astype(np.int64)
 
 
 def scenario(L, steps, seed=5):

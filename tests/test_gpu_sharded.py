@@ -109,11 +109,16 @@ def _nccl_single(q):
         dist.init_process_group("nccl", rank=0, world_size=1)
         from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
 
-        comm = TorchComm(0)
-        assert comm.on_device
-        assert comm.allreduce_max(3.5) == 3.5
-        assert np.array_equal(comm.allgather(np.arange(4.0)), np.arange(4.0))
-        assert np.array_equal(comm.alltoall_i64([np.array([5, 6, 7])])[0], [5, 6, 7])
+        comm = TorchComm()
+        assert comm.direct
+        t = torch.tensor([3.5], dtype=torch.float64, device="cuda")
+        comm.all_reduce_max_(t)
+        assert float(t.item()) == 3.5
+        out = torch.empty(4, dtype=torch.float64, device="cuda")
+        comm.all_gather_(out, torch.arange(4.0, dtype=torch.float64, device="cuda"))
+        assert np.array_equal(out.cpu().numpy(), np.arange(4.0))
+        rec = comm.all_to_all_records(torch.arange(16, dtype=torch.uint8, device="cuda"), [2], [2], 8)
+        assert np.array_equal(rec.cpu().numpy()[:16], np.arange(16))
         L = 8
         means, covs, scans = scenario(L, 2)
         sf = ShardedFilter(2048, L, device=0, comm=comm)

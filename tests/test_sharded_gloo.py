@@ -29,7 +29,7 @@ def reference_run(P, L, steps, skew):
         sh.o = o
         tot = sh.shard_block_totals(float(o.logw.max()), 1)
         hi = sh.shard_offspring(tot, 0, P, float(us[s]), True)
-        anc = np.searchsorted(np.maximum.accumulate(hi[1:]), np.arange(P), side="right")
+        anc = np.minimum(np.searchsorted(np.maximum.accumulate(hi[1:]), np.arange(P), side="right"), P - 1)
         o.gather(anc)
         out.append((anc.copy(), o.x.copy(), o.y.copy(), o.h.copy(), o.logw.copy(), o.mean.copy(), o.count.copy()))
     return out
