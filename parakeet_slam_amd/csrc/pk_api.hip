@@ -66,12 +66,10 @@ struct pk_filter {
   int64_t device_bytes = 0;
   // workspaces
   double* z_dev = nullptr;        // P x 3
-  double* blobs_dev = nullptr;    // Bcap x 4
-  double* blobdir_dev = nullptr;  // Bcap x 2
-  int32_t* first_dev = nullptr;   // Lp
-  int32_t* next_dev = nullptr;    // Bcap
-  int32_t* ids_dev = nullptr;     // P x Bcap_ids
-  int Bcap = 0;
+  unsigned char* scan_dev = nullptr;  // per-scan block: ctl | blobs | chains or association tables
+  size_t scan_cap = 0;
+  bool gmax_fused = false;  // ctl holds the max of the current log-weights (set by observe)
+  int32_t* ids_dev = nullptr;     // P x B
   int64_t ids_cap = 0;
   double* g_totals = nullptr;   // sharded resample: every shard's block totals
   double* g_offsets = nullptr;
@@ -81,8 +79,6 @@ struct pk_filter {
   int64_t* srcs_dev = nullptr;  // P
   int64_t* rlohi_dev = nullptr; // (lo, hi) of the received records
   int64_t rlohi_cap = 0;
-  unsigned char* grid_dev = nullptr;  // association tables (cell offsets | fp32 colours | order)
-  size_t grid_cap = 0;
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
   int fast_observe = 1;  // L <= 512: association hand-off + k_observe_fast
@@ -175,22 +171,22 @@ int use_device(pk_filter* f) {
   return PK_OK;
 }
 
-int ensure_blob_capacity(pk_filter* f, int B) {
-  if (B <= f->Bcap) return PK_OK;
+// One device block per scan, filled by ONE host->device copy:
+//   [ctl 16 B: running max key (u64), flagged-particle count (u32)] [blobs 4B f64] then either
+//   known ids:  [first Lp i32] [next B i32]
+//   ML:         [dir 2B f64] [exact 6B f64] [association tables]
+// The copy also zeroes ctl, which is how every observe starts with a fresh max / count.
+constexpr size_t kCtlBytes = 16;
+int ensure_scan_capacity(pk_filter* f, size_t bytes) {
+  if (bytes <= f->scan_cap) return PK_OK;
   PK_HIP(hipStreamSynchronize(f->stream));
-  if (f->blobs_dev) (void)hipFree(f->blobs_dev);
-  if (f->blobdir_dev) (void)hipFree(f->blobdir_dev);
-  if (f->next_dev) (void)hipFree(f->next_dev);
-  f->blobs_dev = nullptr;
-  f->blobdir_dev = nullptr;
-  f->next_dev = nullptr;
-  f->Bcap = 0;
-  int cap = B + B / 4 + 16;
+  if (f->scan_dev) (void)hipFree(f->scan_dev);
+  f->scan_dev = nullptr;
+  f->scan_cap = 0;
+  const size_t cap = bytes + bytes / 4 + 4096;
   int rc;
-  if ((rc = dev_alloc(f, &f->blobs_dev, (size_t)cap * 4))) return rc;
-  if ((rc = dev_alloc(f, &f->blobdir_dev, (size_t)cap * 2))) return rc;
-  if ((rc = dev_alloc(f, &f->next_dev, (size_t)cap))) return rc;
-  f->Bcap = cap;
+  if ((rc = dev_alloc(f, &f->scan_dev, cap))) return rc;
+  f->scan_cap = cap;
   return PK_OK;
 }
 
@@ -398,7 +394,9 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
 
 // Upload one scan for maximum-likelihood association and enqueue the association kernel.
 struct AssocLaunch {
-  bool fast = false;             // hand-off written: k_observe_fast can run
+  bool fast = false;  // hand-off written: k_observe_fast can run
+  const double* blobs = nullptr;
+  const double* dir = nullptr;
   const double* exact = nullptr;
   const unsigned short* order = nullptr;
 };
@@ -426,26 +424,30 @@ int ensure_handoff(pk_filter* f, int B) {
   return PK_OK;
 }
 
+inline unsigned long long* ctl_gmax_key(pk_filter* f) { return reinterpret_cast<unsigned long long*>(f->scan_dev); }
+inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8); }
+
+// Upload one scan for maximum-likelihood association (one copy) and enqueue the association.
 int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize, bool want_fast, AssocLaunch* out) {
   int rc;
   if (B > 65535) return fail(PK_ERR_UNSUPPORTED, "maximum-likelihood association handles at most 65535 blobs per scan (got %d)", B);
-  if ((rc = ensure_blob_capacity(f, B))) return rc;
   if ((rc = ensure_ids_capacity(f, B))) return rc;
   BlobGrid g{};
   const int ncell_max = kGridMax * kGridMax * kGridMax;
   const size_t tab_max = (blob_grid_table_bytes(ncell_max, B, 9 * B + 8) + 15) & ~(size_t)15;
-  // staging: blobs (4B) | dir (2B) | exact (6B) doubles | tables
-  const size_t o_dir = (size_t)B * 4 * sizeof(double);
+  // block: ctl | blobs (4B) | dir (2B) | exact (6B) doubles | tables
+  const size_t o_blobs = kCtlBytes;
+  const size_t o_dir = o_blobs + (size_t)B * 4 * sizeof(double);
   const size_t o_exact = o_dir + (size_t)B * 2 * sizeof(double);
   const size_t o_tab = o_exact + (size_t)B * 6 * sizeof(double);
   unsigned char* st = nullptr;
   int slot = 0;
   if ((rc = take_stage(f, o_tab + tab_max + 16, &st, &slot))) return rc;
-  memcpy(st, blobs, o_dir);
+  if ((rc = ensure_scan_capacity(f, o_tab + tab_max + 16))) return rc;
+  memset(st, 0, kCtlBytes);
+  memcpy(st + o_blobs, blobs, (size_t)B * 4 * sizeof(double));
   double* dir = reinterpret_cast<double*>(st + o_dir);
   blob_directions(blobs, B, dir);
-  PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_dir, hipMemcpyHostToDevice, f->stream));
-  PK_HIP(hipMemcpyAsync(f->blobdir_dev, dir, (size_t)B * 2 * sizeof(double), hipMemcpyHostToDevice, f->stream));
   // the grid kernel keeps landmark indices as u16 and its tables in LDS
   bool use_grid = f->assoc_kernel == 0 && f->d.lay.L <= 65535;
   size_t tab_bytes = 0;
@@ -457,44 +459,35 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
     tab_bytes = (blob_grid_table_bytes(g.ncell, B, n9) + 15) & ~(size_t)15;
     if (assoc_grid_lds_bytes(g.ncell, B, n9) > kMaxDynLds) use_grid = false;  // scan too large for LDS tables
   }
+  PK_HIP(hipMemcpyAsync(f->scan_dev, st, use_grid ? o_tab + tab_bytes : o_exact, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+  f->gmax_fused = false;
+  const double* blobs_dev = reinterpret_cast<const double*>(f->scan_dev + o_blobs);
+  const double* dir_dev = reinterpret_cast<const double*>(f->scan_dev + o_dir);
+  if (out) {
+    out->blobs = blobs_dev;
+    out->dir = dir_dev;
+  }
   if (use_grid) {
-    const size_t need = tab_max + (size_t)B * 6 * sizeof(double) + 64;
-    if (need > f->grid_cap) {
-      PK_HIP(hipStreamSynchronize(f->stream));
-      if (f->grid_dev) (void)hipFree(f->grid_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag})
-    if (q) (void)hipFree(q);
-  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
-    if (q) (void)hipFree(q);
-      f->grid_dev = nullptr;
-      f->grid_cap = 0;
-      if ((rc = dev_alloc(f, &f->grid_dev, need + need / 4))) return rc;
-      f->grid_cap = need + need / 4;
-    }
-    // device block: exact records first (16-byte aligned), then the tables
-    const size_t ex_bytes = ((size_t)B * 6 * sizeof(double) + 15) & ~(size_t)15;
-    PK_HIP(hipMemcpyAsync(f->grid_dev, st + o_exact, (size_t)B * 6 * sizeof(double), hipMemcpyHostToDevice, f->stream));
-    PK_HIP(hipMemcpyAsync(f->grid_dev + ex_bytes, st + o_tab, tab_bytes, hipMemcpyHostToDevice, f->stream));
-    PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
     FastHandoff fh{};
     if (want_fast && !finalize && f->fast_observe && f->d.lay.L <= kFastMaxL && B > 0) {
       if ((rc = ensure_handoff(f, B))) return rc;
       fh = f->fh;
+      fh.n_flagged = ctl_n_flagged(f);
     }
     Span t(f, PK_T_ASSOC);
-    launch_assoc_grid(f->stream, f->d, B, g, n9, f->grid_dev + ex_bytes, reinterpret_cast<const double*>(f->grid_dev),
+    launch_assoc_grid(f->stream, f->d, B, g, n9, f->scan_dev + o_tab, reinterpret_cast<const double*>(f->scan_dev + o_exact),
                       f->ids_dev, finalize, fh);
     if (out) {
       out->fast = fh.lmpass != nullptr;
-      out->exact = reinterpret_cast<const double*>(f->grid_dev);
+      out->exact = reinterpret_cast<const double*>(f->scan_dev + o_exact);
       const size_t cs_b = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
-      out->order = reinterpret_cast<const unsigned short*>(f->grid_dev + ex_bytes + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
+      out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
     }
     return PK_OK;
   }
-  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
   Span t(f, PK_T_ASSOC);
-  launch_assoc_brute(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, f->ids_dev);
+  launch_assoc_brute(f->stream, f->d, blobs_dev, dir_dev, B, f->ids_dev);
   return PK_OK;
 }
 
@@ -586,7 +579,6 @@ int pk_create(int64_t P, int32_t L, int32_t device, pk_filter** out) {
   }
   if (!rc) rc = dev_alloc(f, &d.immutable, (size_t)d.lay.Lp);
   if (!rc) rc = dev_alloc(f, &f->z_dev, (size_t)P * 3);
-  if (!rc) rc = dev_alloc(f, &f->first_dev, (size_t)d.lay.Lp);
   if (!rc) rc = dev_alloc(f, &f->partial, (size_t)4 * 1024);
   if (!rc) rc = dev_alloc(f, &f->gmax, 1);
   if (!rc) rc = dev_alloc(f, &f->clocal, (size_t)P);
@@ -633,12 +625,12 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.src[i]);
     (void)hipFree(d.map[i]);
   }
-  if (f->grid_dev) (void)hipFree(f->grid_dev);
+  if (f->scan_dev) (void)hipFree(f->scan_dev);
   for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
-  void* rest[] = {d.immutable, f->z_dev,  f->blobs_dev, f->blobdir_dev, f->first_dev, f->next_dev, f->ids_dev,
+  void* rest[] = {d.immutable, f->z_dev,  f->ids_dev,
                   f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
                   f->anc,      f->slot_tmp};
   for (void* p : rest)
@@ -738,6 +730,7 @@ int pk_upload_poses(pk_filter* f, const double* xyhw) {
   PK_HIP(hipMemcpyAsync(f->d.h[c], soa.data() + 2 * P, P * 8, hipMemcpyHostToDevice, f->stream));
   PK_HIP(hipMemcpyAsync(f->d.logw[c], soa.data() + 3 * P, P * 8, hipMemcpyHostToDevice, f->stream));
   PK_HIP(hipStreamSynchronize(f->stream));
+  f->gmax_fused = false;
   return PK_OK;
 }
 
@@ -833,6 +826,7 @@ int pk_reset_weights(pk_filter* f) {
   int rc;
   if ((rc = use_device(f))) return rc;
   launch_reset_weights(f->stream, f->d);
+  f->gmax_fused = false;
   return PK_OK;
 }
 
@@ -853,7 +847,8 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
   return PK_OK;
 }
 
-int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out) {
+static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out,
+                        bool reset) {
   if (!f) return fail(PK_ERR_INVALID, "pk_observe: NULL handle");
   if (B < 0 || (B > 0 && !blobs)) return fail(PK_ERR_INVALID, "pk_observe: bad blobs");
   if (!f->map_loaded) return fail(PK_ERR_STATE, "pk_observe: no map uploaded (pk_upload_map)");
@@ -868,17 +863,20 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
   if (ids)
     for (int b = 0; b < B; ++b)
       if (ids[b] < 0 || ids[b] > L) return fail(PK_ERR_INVALID, "pk_observe: ids[%d] = %d outside 0..%d", b, ids[b], L);
+  ObserveExtras ex;
+  ex.reset = reset;
   if (ids) {
-    if ((rc = ensure_blob_capacity(f, B))) return rc;
-    // staging block: blobs (4B doubles) | first (Lp int32) | next (B int32)
-    const size_t o_first = (size_t)B * 4 * sizeof(double);
+    // block: ctl | blobs (4B doubles) | first (Lp int32) | next (B int32)
+    const size_t o_blobs = kCtlBytes;
+    const size_t o_first = o_blobs + (size_t)B * 4 * sizeof(double);
     const size_t o_next = o_first + (size_t)lay.Lp * sizeof(int32_t);
     const size_t total = o_next + (size_t)B * sizeof(int32_t);
     unsigned char* st = nullptr;
     int slot = 0;
     if ((rc = take_stage(f, total, &st, &slot))) return rc;
-    if (B > 0) memcpy(st, blobs, o_first);
-    if (B > 0) PK_HIP(hipMemcpyAsync(f->blobs_dev, st, o_first, hipMemcpyHostToDevice, f->stream));
+    if ((rc = ensure_scan_capacity(f, total))) return rc;
+    memset(st, 0, kCtlBytes);
+    if (B > 0) memcpy(st + o_blobs, blobs, (size_t)B * 4 * sizeof(double));
     // landmark -> blob chains shared by all particles, in scan order (prkt_core_v2.py:88)
     int32_t* first = reinterpret_cast<int32_t*>(st + o_first);
     int32_t* next = reinterpret_cast<int32_t*>(st + o_next);
@@ -898,14 +896,17 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
         next[last[id - 1]] = b;
       last[id - 1] = b;
     }
-    PK_HIP(hipMemcpyAsync(f->first_dev, first, (size_t)lay.Lp * 4, hipMemcpyHostToDevice, f->stream));
-    if (B > 0) PK_HIP(hipMemcpyAsync(f->next_dev, next, (size_t)B * 4, hipMemcpyHostToDevice, f->stream));
+    PK_HIP(hipMemcpyAsync(f->scan_dev, st, total, hipMemcpyHostToDevice, f->stream));
     PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+    ex.gmax_key = ctl_gmax_key(f);
     {
       Span t(f, PK_T_OBSERVE);
-      launch_observe(f->stream, f->d, f->blobs_dev, nullptr, B, f->first_dev, f->next_dev, n0, nullptr, f->qt);
+      launch_observe(f->stream, f->d, reinterpret_cast<const double*>(f->scan_dev + o_blobs), nullptr, B,
+                     reinterpret_cast<const int32_t*>(f->scan_dev + o_first),
+                     reinterpret_cast<const int32_t*>(f->scan_dev + o_next), n0, nullptr, f->qt, ex);
     }
     f->src_identity = true;
+    f->gmax_fused = true;
     if (ids_out)
       for (int64_t p = 0; p < f->d.P; ++p) memcpy(ids_out + (size_t)p * B, ids, (size_t)B * 4);
     return PK_OK;
@@ -913,22 +914,32 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
   // maximum-likelihood association on the device
   AssocLaunch al;
   if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
+  ex.gmax_key = ctl_gmax_key(f);
   {
     Span t(f, PK_T_OBSERVE);
     if (al.fast) {
-      launch_observe_fast(f->stream, f->d, B, al.exact, al.order, f->fh, f->qt);
-      launch_observe(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt,
-                     f->fh.pflag, true);
+      ObserveExtras e1 = ex;
+      e1.flip = false;
+      launch_observe_fast(f->stream, f->d, B, al.exact, al.order, f->fh, f->qt, e1);
+      ObserveExtras e2 = ex;
+      e2.only_flagged = f->fh.pflag;
+      e2.n_flagged = ctl_n_flagged(f);
+      launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
     } else {
-      launch_observe(f->stream, f->d, f->blobs_dev, f->blobdir_dev, B, nullptr, nullptr, 0, f->ids_dev, f->qt);
+      launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, ex);
     }
   }
   f->src_identity = true;
+  f->gmax_fused = true;
   if (ids_out && B > 0) {
     PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
     PK_HIP(hipStreamSynchronize(f->stream));
   }
   return PK_OK;
+}
+
+int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out) {
+  return observe_impl(f, blobs, B, ids, ids_out, false);
 }
 
 int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out) {
@@ -979,16 +990,19 @@ int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestor
   DeviceState& d = f->d;
   {
     Span t(f, PK_T_WEIGHTS);
-    if (weight_domain == PK_WEIGHTS_LOG) launch_block_max(f->stream, d, f->partial, f->gmax);
-    launch_scan_local(f->stream, d, f->gmax, weight_domain, f->clocal, f->totals);
+    const unsigned long long* key = nullptr;
+    if (weight_domain == PK_WEIGHTS_LOG) {
+      if (f->gmax_fused)
+        key = ctl_gmax_key(f);  // the observe kernels kept the max of the weights they wrote
+      else
+        launch_block_max(f->stream, d, f->partial, f->gmax);
+    }
+    launch_scan_local(f->stream, d, f->gmax, weight_domain, f->clocal, f->totals, key);
     launch_scan_blocks(f->stream, f->totals, f->nblocks, f->offsets, f->sum);
-    launch_ancestors(f->stream, f->clocal, f->totals, f->offsets, f->sum, f->nblocks, d.P, d.P, u, 0, d.P, f->anc);
-  }
-  {
-    Span t(f, PK_T_RESAMPLE);
-    launch_gather_poses(f->stream, d, f->anc);
+    launch_ancestors(f->stream, f->clocal, f->totals, f->offsets, f->sum, f->nblocks, d.P, d.P, u, 0, d.P, f->anc, &d);
   }
   f->src_identity = false;
+  f->gmax_fused = false;
   if (ancestors_out) {
     std::vector<int32_t> a((size_t)d.P);
     PK_HIP(hipMemcpyAsync(a.data(), f->anc, (size_t)d.P * 4, hipMemcpyDeviceToHost, f->stream));
@@ -1032,10 +1046,9 @@ int pk_pose_sums(pk_filter* f, double out[4]) {
 int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed, uint64_t draw,
             const double* blobs, int32_t B, const int32_t* ids, double u, int32_t weight_domain) {
   int rc;
-  if ((rc = pk_reset_weights(f))) return rc;                    // :73
-  if ((rc = pk_motion(f, v, w, dt, z, seed, draw))) return rc;  // :75-77
-  if ((rc = pk_observe(f, blobs, B, ids, nullptr))) return rc;  // :82-124
-  return pk_resample(f, u, weight_domain, nullptr);             // :137
+  if ((rc = pk_motion(f, v, w, dt, z, seed, draw))) return rc;              // :75-77
+  if ((rc = observe_impl(f, blobs, B, ids, nullptr, true))) return rc;    // :73 (reset fused) + :82-124
+  return pk_resample(f, u, weight_domain, nullptr);                         // :137
 }
 
 // ---- sharded resampling ---------------------------------------
@@ -1140,6 +1153,7 @@ int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, in
   }
   if (n_received == 0) f->d.alt = nullptr;
   f->src_identity = false;
+  f->gmax_fused = false;
   PK_HIP(hipStreamSynchronize(f->stream));  // src was pageable host memory
   return PK_OK;
 }
@@ -1235,6 +1249,7 @@ int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t
   launch_adopt_dev(f->stream, f->d, f->hi_dev, (int64_t)rank * f->d.P, static_cast<const unsigned char*>(dev_recv),
                    n_received, f->rlohi_dev);
   f->src_identity = false;
+  f->gmax_fused = false;
   return PK_OK;
 }
 

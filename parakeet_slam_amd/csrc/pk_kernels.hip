@@ -11,6 +11,7 @@
 
 #include <cfloat>
 #include <climits>
+#include <cstring>
 #include <type_traits>
 
 #include "pk_math.hpp"
@@ -57,6 +58,20 @@ __device__ __forceinline__ double block_max(double v, double* lds) {
 #pragma unroll
   for (int i = 1; i < NW; ++i) t = fmax(t, lds[i]);
   return t;
+}
+
+// Order-preserving map double -> uint64 (max of keys == max of doubles), for the running max
+// of the log-weights that the observe kernels keep with one atomicMax per particle.
+__host__ __device__ inline unsigned long long double_to_key(double x) {
+  unsigned long long b;
+  memcpy(&b, &x, 8);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double key_to_double(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double x;
+  memcpy(&x, &b, 8);
+  return x;
 }
 
 // ------------------------------------------------------------------ K1 motion
@@ -300,6 +315,7 @@ struct AssocGridArgs {
   unsigned char* bcount;  // [P][B]   saturating count
   unsigned char* pflag;   // [P]      1 = general path
   const unsigned char* only_flagged;  // GENERAL instance: skip particles whose flag is 0
+  unsigned* n_flagged;                // count of flagged particles (zeroed by the scan upload)
 };
 
 // tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
@@ -363,6 +379,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
   const AssocArgs& a = ga.a;
   const BlobGrid& g = ga.g;
   const int B = a.B;
+  if (GENERAL && ga.only_flagged && *ga.n_flagged == 0u) return;  // nothing was flagged
   const size_t cs_bytes = grid_cs_bytes(g.ncell);
   const size_t tab_bytes = cs_bytes + (size_t)B * 16 + (DUP ? (size_t)ga.n9 * 2 : 0);  // the part kept in LDS
   const unsigned short* start = reinterpret_cast<const unsigned short*>(smem);
@@ -561,7 +578,10 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         const int n = ccount[t];
         ga.bcount[(size_t)p * B + t] = (unsigned char)(n > 255 ? 255 : n);
       }
-      if (threadIdx.x == 0) ga.pflag[p] = (unsigned char)(wg_flag != 0);
+      if (threadIdx.x == 0) {
+        ga.pflag[p] = (unsigned char)(wg_flag != 0);
+        if (wg_flag) atomicAdd(ga.n_flagged, 1u);
+      }
       __syncthreads();
       continue;  // k_observe_fast (or, if flagged, the GENERAL instance) takes it from here
     }
@@ -708,6 +728,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   ga.lmpass = fh.lmpass;
   ga.bcount = fh.bcount;
   ga.pflag = fh.pflag;
+  ga.n_flagged = fh.n_flagged;
   ga.only_flagged = nullptr;
   const size_t lds = assoc_grid_lds_bytes(grid.ncell, B, n9);
   // bigger workgroups when the LDS tables are large, so that a CU still holds >= 16 waves
@@ -751,6 +772,9 @@ struct ObserveArgs {
   const unsigned char* immutable;
   int n_unmatched;  // KNOWN: blobs with id 0
   const unsigned char* only_flagged;  // when set: skip particles whose flag is 0 (k_observe_fast did them)
+  const unsigned* n_flagged;          // with only_flagged: number of flagged particles (0 -> nothing to do)
+  int reset;                          // 1: the weight restarts from 1 (prkt_core_v2.py:73) instead of accumulating
+  unsigned long long* gmax_key;       // running max of the new log-weights (double_to_key), or NULL
   int L, Lp, B;
   Noise<double> qt;
 };
@@ -828,7 +852,7 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kObsThreads / kWave];
   const int64_t p = blockIdx.x;
-  if (a.only_flagged && !a.only_flagged[p]) return;  // workgroup-uniform
+  if (a.only_flagged && (*a.n_flagged == 0u || !a.only_flagged[p])) return;  // workgroup-uniform
   const int tid = threadIdx.x;
   const int32_t sp = a.src[p];
   const unsigned char* sslot = a.ss.at(sp);
@@ -941,7 +965,9 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   }
   double tot = block_sum<kObsThreads / kWave>(acc, red);
   if (tid == 0) {
-    a.logw[p] += tot + (double)n_unmatched * Consts<double>::log_no_match;
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot + (double)n_unmatched * Consts<double>::log_no_match;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key, double_to_key(v));
     a.src[p] = (int32_t)p;
   }
 }
@@ -972,6 +998,8 @@ struct FastArgs {
   const unsigned char* pflag;
   const unsigned char* immutable;
   int L, Lp, B;
+  int reset;
+  unsigned long long* gmax_key;
   Noise<double> qt;
 };
 
@@ -1117,13 +1145,16 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   }
   const double tot = block_sum<kFastThreads / kWave>(acc, red);
   if (tid == 0) {
-    a.logw[p] += tot;
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key, double_to_key(v));
     a.src[p] = (int32_t)p;
   }
 }
 
 void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
-                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt) {
+                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                         const ObserveExtras& ex) {
   if (d.P == 0) return;
   FastArgs a;
   a.ss = slot_source(d);
@@ -1142,6 +1173,8 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
   a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
   const size_t lds = (size_t)B * 13 + 16;
   hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
@@ -1151,7 +1184,7 @@ int g_observe_nv = 0;  // tuning: 0 = default per variant, 1 / 2 = landmarks per
 
 void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
                     const int32_t* first_dev, const int32_t* next_dev, int n_unmatched, int32_t* ids_dev,
-                    const NoiseD& qt, const unsigned char* only_flagged, bool flip) {
+                    const NoiseD& qt, const ObserveExtras& ex) {
   if (d.P == 0) return;
   ObserveArgs a;
   a.ss = slot_source(d);
@@ -1169,7 +1202,10 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
   a.ids = ids_dev;
   a.immutable = d.immutable;
   a.n_unmatched = n_unmatched;
-  a.only_flagged = only_flagged;
+  a.only_flagged = ex.only_flagged;
+  a.n_flagged = ex.n_flagged;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
@@ -1186,7 +1222,7 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
     else
       hipLaunchKernelGGL((k_observe<false, 1>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
   }
-  if (flip) {
+  if (ex.flip) {
     d.mcur ^= 1;
     d.alt = nullptr;  // every slot was rewritten into the particle's own map buffer
   }
@@ -1225,12 +1261,13 @@ void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double
 // size alone, so shards that are multiples of kScanBlock reproduce the 1-GPU bits.
 __global__ void __launch_bounds__(256) k_scan_local(const double* __restrict__ logw, int64_t P,
                                                     const double* __restrict__ gmax, int domain,
-                                                    double* __restrict__ clocal, double* __restrict__ totals) {
+                                                    double* __restrict__ clocal, double* __restrict__ totals,
+                                                    const unsigned long long* __restrict__ gmax_key) {
   __shared__ double wtot[4];
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   double shift = 0.0;
   if (domain == 1) {
-    shift = gmax[0];
+    shift = gmax_key ? key_to_double(gmax_key[0]) : gmax[0];
     if (!(shift > -INFINITY)) shift = 0.0;  // all weights zero: keep exp(-inf) = 0, not NaN
   }
   const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * tid;
@@ -1260,11 +1297,11 @@ __global__ void __launch_bounds__(256) k_scan_local(const double* __restrict__ l
   if (tid == 255) totals[blockIdx.x] = excl + s3;
 }
 void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, int domain, double* clocal_dev,
-                       double* totals_dev) {
+                       double* totals_dev, const unsigned long long* gmax_key_dev) {
   if (d.P == 0) return;
   int nb = (int)((d.P + kScanBlock - 1) / kScanBlock);
   hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, d.logw[d.cur], d.P, gmax_dev, domain,
-                     clocal_dev, totals_dev);
+                     clocal_dev, totals_dev, gmax_key_dev);
 }
 
 // Exclusive scan of the block totals in block order by ONE thread: the canonical
@@ -1304,7 +1341,12 @@ __global__ void __launch_bounds__(256) k_ancestors(const double* __restrict__ cl
                                                    const double* __restrict__ offsets,
                                                    const double* __restrict__ sum, int64_t nb, int64_t Pg,
                                                    int64_t Pscan, double u, int64_t slot0, int64_t n,
-                                                   int32_t* __restrict__ anc) {
+                                                   int32_t* __restrict__ anc, const double* __restrict__ gx,
+                                                   const double* __restrict__ gy, const double* __restrict__ gh,
+                                                   const double* __restrict__ glw, const int32_t* __restrict__ gsrc,
+                                                   double* __restrict__ gx2, double* __restrict__ gy2,
+                                                   double* __restrict__ gh2, double* __restrict__ glw2,
+                                                   int32_t* __restrict__ gsrc2) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const double r = __ddiv_rn(sum[0], (double)Pg);                  // range_ :225
@@ -1330,13 +1372,32 @@ __global__ void __launch_bounds__(256) k_ancestors(const double* __restrict__ cl
       j0 = mid + 1;
   }
   anc[k] = (int32_t)j0;
+  if (gx) {  // fused k_gather_poses (single-GPU resample)
+    const int32_t a = (int32_t)j0;
+    gx2[k] = gx[a];
+    gy2[k] = gy[a];
+    gh2[k] = gh[a];
+    glw2[k] = glw[a];
+    gsrc2[k] = gsrc[a];
+  }
 }
 void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* totals_dev,
                       const double* offsets_dev, const double* sum_dev, int64_t nb, int64_t P_global,
-                      int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev) {
+                      int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev, DeviceState* gather) {
   if (n == 0) return;
+  if (gather) {
+    DeviceState& d = *gather;
+    const int c = d.cur, m = c ^ 1;
+    hipLaunchKernelGGL(k_ancestors, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clocal_dev, totals_dev,
+                       offsets_dev, sum_dev, nb, P_global, P_scan, u, slot0, n, anc_dev, d.x[c], d.y[c], d.h[c],
+                       d.logw[c], d.src[c], d.x[m], d.y[m], d.h[m], d.logw[m], d.src[m]);
+    d.cur = m;
+    return;
+  }
   hipLaunchKernelGGL(k_ancestors, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clocal_dev, totals_dev,
-                     offsets_dev, sum_dev, nb, P_global, P_scan, u, slot0, n, anc_dev);
+                     offsets_dev, sum_dev, nb, P_global, P_scan, u, slot0, n, anc_dev, (const double*)nullptr,
+                     (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const int32_t*)nullptr,
+                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
 }
 
 // ------------------------------------------------------------------ K5 gather

@@ -83,6 +83,15 @@ struct FastHandoff {
   uint2* lmpass = nullptr;          // [P][Lp]
   unsigned char* bcount = nullptr;  // [P][B]
   unsigned char* pflag = nullptr;   // [P]
+  unsigned* n_flagged = nullptr;    // number of flagged particles of this scan
+};
+// Optional behaviour of one observe launch.
+struct ObserveExtras {
+  const unsigned char* only_flagged = nullptr;  // general kernel: only the particles flagged by the fast path
+  const unsigned* n_flagged = nullptr;
+  bool flip = true;                             // swap the map buffers after this launch
+  bool reset = false;                           // weights restart from 1 (fused pk_reset_weights)
+  unsigned long long* gmax_key = nullptr;       // keep the running max of the new log-weights here
 };
 constexpr int kFastSlots = 4;  // gate-passing blobs a landmark can hand over; more -> general path
 constexpr int kFastMaxL = 512;  // k_observe_fast keeps a particle's whole map in registers (2 landmarks/lane)
@@ -93,26 +102,27 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 // with the landmark state in registers.  Particles flagged in fh.pflag are skipped (the general
 // k_observe, launched with only_flagged, takes them).
 void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
-                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt);
+                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                         const ObserveExtras& ex = ObserveExtras());
 // K3: EKF update + log-weight.  known: first/next chains shared by all particles (device
 // arrays, built on the host); otherwise built per particle in LDS from ids_dev.
 // ML ids are TENTATIVE: k_observe keeps a match only if its probability is > 0 (needs blobdir).
 void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
                     const int32_t* first_dev, const int32_t* next_dev, int n_unmatched,
-                    int32_t* ids_dev, const NoiseD& qt, const unsigned char* only_flagged = nullptr,
-                    bool flip = true);
+                    int32_t* ids_dev, const NoiseD& qt, const ObserveExtras& ex = ObserveExtras());
 extern int g_observe_nv;
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);
 void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, int domain,
-                       double* clocal_dev, double* totals_dev);
+                       double* clocal_dev, double* totals_dev, const unsigned long long* gmax_key_dev = nullptr);
 // exclusive scan of the (global) block totals, sequential in block order: offsets[nb], sum[1]
 void launch_scan_blocks(hipStream_t s, const double* totals_dev, int64_t nb, double* offsets_dev,
                         double* sum_dev);
 // ancestors of the local output slots [slot0, slot0 + n)
 void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* totals_dev,
                       const double* offsets_dev, const double* sum_dev, int64_t nb, int64_t P_global,
-                      int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev);
+                      int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev,
+                      DeviceState* gather = nullptr);  // gather: also gather the poses (fused K5)
 // K5: pose gather + map indirection
 void launch_gather_poses(hipStream_t s, DeviceState& d, const int32_t* anc_dev);
 // K6
