@@ -172,11 +172,11 @@ int use_device(pk_filter* f) {
 }
 
 // One device block per scan, filled by ONE host->device copy:
-//   [ctl 16 B: running max key (u64), flagged-particle count (u32)] [blobs 4B f64] then either
+//   [ctl: kGmaxKeys running-max keys (u64), flagged-particle count (u32)] [blobs 4B f64] then either
 //   known ids:  [first Lp i32] [next B i32]
 //   ML:         [dir 2B f64] [exact 6B f64] [association tables]
 // The copy also zeroes ctl, which is how every observe starts with a fresh max / count.
-constexpr size_t kCtlBytes = 16;
+constexpr size_t kCtlBytes = 8 * kGmaxKeys + 16;  // running-max keys, then the flagged-particle count
 int ensure_scan_capacity(pk_filter* f, size_t bytes) {
   if (bytes <= f->scan_cap) return PK_OK;
   PK_HIP(hipStreamSynchronize(f->stream));
@@ -425,7 +425,7 @@ int ensure_handoff(pk_filter* f, int B) {
 }
 
 inline unsigned long long* ctl_gmax_key(pk_filter* f) { return reinterpret_cast<unsigned long long*>(f->scan_dev); }
-inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8); }
+inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys); }
 
 // Upload one scan for maximum-likelihood association (one copy) and enqueue the association.
 int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize, bool want_fast, AssocLaunch* out) {

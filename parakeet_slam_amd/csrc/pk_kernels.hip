@@ -311,7 +311,7 @@ struct AssocGridArgs {
   // Fast hand-off to k_observe_fast (L <= 512): per landmark the (<= 4) blobs that pass its
   // gates, per blob how many landmarks pass; a particle where some landmark passes more than
   // four blobs is flagged and settled the general way (S2..S4 + ids) instead.
-  uint2* lmpass;          // [P][Lp]  four 16-bit fields = blob (cell order) or 0xFFFF
+  uint4* lmpass;          // [P][Lp]  x,y: four 16-bit fields = blob (cell order) or 0xFFFF; z,w: atan2(my-sy, mx-sx)
   unsigned char* bcount;  // [P][B]   saturating count
   unsigned char* pflag;   // [P]      1 = general path
   const unsigned char* only_flagged;  // GENERAL instance: skip particles whose flag is 0
@@ -433,7 +433,8 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         nmb = f[F_MB * a.Lp + ln];
       }
       PK_STAMP(ta0)
-      const double eb = atan2(my - sy, mx - sx) - sh;  // :408
+      const double pse = atan2(my - sy, mx - sx);
+      const double eb = pse - sh;  // :408
       const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
       // same cell function as the host (floor((v - lo) * inv_h)): inside the colour gate
       // |dv| <= 17.3205 < 17.5, so the cell indices of blob and landmark differ by at most
@@ -564,7 +565,8 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         }
       }
       if (!GENERAL) {
-        ga.lmpass[(size_t)p * a.Lp + l] = make_uint2(pass01, pass23);
+        const unsigned long long pb = (unsigned long long)__double_as_longlong(pse);
+        ga.lmpass[(size_t)p * a.Lp + l] = make_uint4(pass01, pass23, (unsigned)pb, (unsigned)(pb >> 32));
         if (npass > kFastSlots) wg_flag = 1;
       }
     }
@@ -967,7 +969,7 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   if (tid == 0) {
     const double v = (a.reset ? 0.0 : a.logw[p]) + tot + (double)n_unmatched * Consts<double>::log_no_match;
     a.logw[p] = v;
-    if (a.gmax_key) atomicMax(a.gmax_key, double_to_key(v));
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));  // sharded: same-address atomics serialise
     a.src[p] = (int32_t)p;
   }
 }
@@ -993,7 +995,7 @@ struct FastArgs {
   double* logw;
   const double* exact;          // [B][6] cell order: bearing, r, g, b, ux, uy
   const unsigned short* order;  // [B] cell order -> scan order
-  const uint2* lmpass;
+  const uint4* lmpass;
   const unsigned char* bcount;
   const unsigned char* pflag;
   const unsigned char* immutable;
@@ -1010,15 +1012,29 @@ struct FastSlot {
   unsigned flags;           // bit 0 contested, bit 1 apply the update, bit 2 unmatched (single, probability 0)
 };
 
+// What probability_of_match needs from the landmark alone, computed once per landmark instead
+// of once per blob: determinant / inverse of the 2x2 position block and of the 3x3 colour block.
+struct FastLm {
+  double det2, idet2, det3;
+  Sym3<double> inv3;
+};
+
 __device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<double>& lm, double sx, double sy,
                                              double pse, uint2 packed, const unsigned char* bc,
                                              unsigned long long* best, FastSlot (&sl)[kFastSlots]) {
+  FastLm q;
+  q.det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+  q.idet2 = 1.0 / q.det2;
+  q.inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, q.det3);
+  const bool dets_sane = q.det2 > 0.0 && q.det2 < 1e60 && q.det3 > 0.0 && q.det3 < 1e60;
+  double ldet2 = 0.0, ldet3 = 0.0;  // log determinants, evaluated once per landmark on first use
+  bool have_logs = false;
   const unsigned w[2] = {packed.x, packed.y};
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
     const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
     sl[k].t = t == 0xFFFF ? -1 : t;
-    sl[k].b = 0;
+    sl[k].b = INT_MAX;
     sl[k].bits = 0ull;
     sl[k].flags = 0u;
     if (sl[k].t < 0) continue;
@@ -1027,18 +1043,38 @@ __device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<d
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
     const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
-    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
-    if (bc[t] >= 2) {
+    // the quantities both branches need (prob_position_match :457-494, prob_color_match :524-544)
+    const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
+    double nx, ny;
+    closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+    const double ex = nx - lm.mx, ey = ny - lm.my;
+    const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / q.det2;
+    const double maha3 = sym3_quad(q.inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+    const bool contested = bc[t] >= 2;
+    // pr = (500 exp(a1)) (500 exp(a2)) / 250000 is certainly > 0 when a1 + a2 is far from the
+    // float64 underflow edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 here
+    const bool surely_positive = angle_ok && dets_sane && maha2 >= 0.0 && maha3 >= 0.0 && maha2 + maha3 < 800.0;
+    double pr = 0.0;
+    if (contested || (angle_ok && !surely_positive)) {
+      if (angle_ok) {
+        if (!have_logs) {
+          ldet2 = log(q.det2);
+          ldet3 = log(q.det3);
+          have_logs = true;
+        }
+        const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + ldet2 + maha2));  // :439
+        const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + ldet3 + maha3));  // :446
+        pr = bp * cp / 250000.0;                                                                 // :455
+      }
+    }
+    if (contested) {
       sl[k].flags = 1u;
-      const double bp = 500.0 * prob_position_match(lm, sx, sy, pse, z.bearing, dir.x, dir.y);  // :439
-      const double cp = 500.0 * prob_color_match(lm, z.r, z.g, z.b);                          // :446
-      const double pr = bp * cp / 250000.0;                                                  // :455
       if (pr > 0.0) {
         sl[k].bits = (unsigned long long)__double_as_longlong(pr);
         atomicMax(&best[t], sl[k].bits);
       }
     } else {
-      sl[k].flags = match_is_positive(lm, sx, sy, pse, z, dir.x, dir.y) ? 2u : 4u;
+      sl[k].flags = (surely_positive || pr > 0.0) ? 2u : 4u;
     }
   }
 }
@@ -1047,12 +1083,16 @@ __device__ __forceinline__ double fast_apply(const FastArgs& a, Landmark<double>
                                              double pse, FastSlot (&sl)[kFastSlots], const int* win) {
   double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < kFastSlots; ++k)
-    if (sl[k].t >= 0 && (sl[k].flags & 1u) && sl[k].bits != 0ull && win[sl[k].t] == l) sl[k].flags |= 2u;
-  // scan order (:88): sort the (<= 4) slots by b, empty slots last (5-comparator network)
-  auto key = [](const FastSlot& x) { return x.t < 0 ? INT_MAX : x.b; };
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].t < 0) continue;
+    if ((sl[k].flags & 1u) && sl[k].bits != 0ull && win[sl[k].t] == l) sl[k].flags |= 2u;
+    if (sl[k].flags & 4u) acc += Consts<double>::log_no_match;  // single candidate, probability 0 (:94-95)
+    if (!(sl[k].flags & 2u)) sl[k].b = INT_MAX;                 // not applied: sorts to the back
+  }
+  // the blobs to apply first, in scan order (:88) -- so that nearly every lane of the wave
+  // applies its (usually only) update in the same iteration (5-comparator network)
   auto cswap = [&](FastSlot& u, FastSlot& v) {
-    if (key(u) > key(v)) {
+    if (u.b > v.b) {
       const FastSlot tmp = u;
       u = v;
       v = tmp;
@@ -1067,9 +1107,7 @@ __device__ __forceinline__ double fast_apply(const FastArgs& a, Landmark<double>
   bool fresh = true;
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
-    if (sl[k].t < 0) continue;
-    if (sl[k].flags & 4u) acc += Consts<double>::log_no_match;
-    if (!(sl[k].flags & 2u)) continue;
+    if (sl[k].b == INT_MAX) continue;
     const double* rec = a.exact + 6 * (size_t)sl[k].t;
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
@@ -1102,7 +1140,7 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   const int l = tid;
   const bool active = l < Lp, has = l < a.L;
   Landmark<double> A{};
-  uint2 lp = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
   if (active) {
     A = load_landmark(sf, sc, Lp, l);
     lp = a.lmpass[(size_t)p * Lp + l];
@@ -1116,8 +1154,9 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   int nun = 0;  // blobs no landmark passes
   for (int t = tid; t < B; t += kFastThreads) nun += bc[t] == 0;
   FastSlot sa[kFastSlots];
-  const double pseA = has ? atan2(A.my - sy, A.mx - sx) : 0.0;
-  fast_prepare(a, A, sx, sy, pseA, has ? lp : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, sa);
+  // atan2(my - sy, mx - sx) of the untouched state, handed over by the association kernel
+  const double pseA = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
+  fast_prepare(a, A, sx, sy, pseA, has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, sa);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k)
@@ -1147,7 +1186,7 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   if (tid == 0) {
     const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
     a.logw[p] = v;
-    if (a.gmax_key) atomicMax(a.gmax_key, double_to_key(v));
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));  // sharded: same-address atomics serialise
     a.src[p] = (int32_t)p;
   }
 }
@@ -1267,7 +1306,13 @@ __global__ void __launch_bounds__(256) k_scan_local(const double* __restrict__ l
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   double shift = 0.0;
   if (domain == 1) {
-    shift = gmax_key ? key_to_double(gmax_key[0]) : gmax[0];
+    if (gmax_key) {  // max over the sharded running-max keys (kGmaxKeys == blockDim.x)
+      const double mine = key_to_double(gmax_key[tid]);
+      shift = block_max<4>(mine, wtot);
+      __syncthreads();
+    } else {
+      shift = gmax[0];
+    }
     if (!(shift > -INFINITY)) shift = 0.0;  // all weights zero: keep exp(-inf) = 0, not NaN
   }
   const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * tid;

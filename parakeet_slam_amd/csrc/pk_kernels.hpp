@@ -80,11 +80,12 @@ size_t assoc_grid_lds_bytes(int ncell, int B, int n9);
 constexpr size_t kMaxDynLds = 156 * 1024;  // 160 KiB per workgroup minus the kernels' static __shared__
 // Hand-off from the association kernel to k_observe_fast (all three NULL = not used).
 struct FastHandoff {
-  uint2* lmpass = nullptr;          // [P][Lp]
+  uint4* lmpass = nullptr;          // [P][Lp]
   unsigned char* bcount = nullptr;  // [P][B]
   unsigned char* pflag = nullptr;   // [P]
   unsigned* n_flagged = nullptr;    // number of flagged particles of this scan
 };
+constexpr int kGmaxKeys = 256;  // the running max of the log-weights is kept in this many keys (one scan-block thread each)
 // Optional behaviour of one observe launch.
 struct ObserveExtras {
   const unsigned char* only_flagged = nullptr;  // general kernel: only the particles flagged by the fast path
