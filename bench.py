@@ -229,7 +229,10 @@ def main():
                 else "single GPU",
             },
             "roofline": {
-                "kernel": "k_observe (fused EKF update + log-weight)",
+                "kernel": ("k_observe<known ids> (fused EKF update + log-weight)" if args.assoc == "known" else
+                           "k_observe_fast (EKF update + log-weight + settling of contested associations; "
+                           "includes the near-empty general k_observe launch for flagged particles)"
+                           if L <= 512 else "k_observe<ML general> (fused EKF update + log-weight)"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -324,7 +324,8 @@ class ShardedFilter(object):
         n_send, n_recv = sum(send_counts), sum(recv_counts)
         self.last_migrated = n_send
         recv = None
-        if W > 1:  # every rank takes part in the exchange, even with nothing to move
+        moving = int(counts.sum() - np.trace(counts))  # same number on every rank (all-gathered table)
+        if W > 1 and moving > 0:  # every rank takes part in the exchange, even with nothing of its own to move
             send = f.alloc_records(n_send)
             if n_send:
                 f.pack_into(allr[R].reshape(-1), W, R, send)
