@@ -143,10 +143,6 @@ void launch_iota(hipStream_t s, int32_t* p, int64_t n) {
 }
 
 // ------------------------------------------------------------------ landmark slot access
-struct SlotView {
-  const double* f;  // 14 rows of Lp
-  const int* cnt;
-};
 __device__ __forceinline__ Landmark<double> load_landmark(const double* f, const int* cnt, int Lp, int l) {
   Landmark<double> m;
   m.mx = f[F_MX * Lp + l];
@@ -1443,31 +1439,6 @@ void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* tot
                      offsets_dev, sum_dev, nb, P_global, P_scan, u, slot0, n, anc_dev, (const double*)nullptr,
                      (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const int32_t*)nullptr,
                      (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
-}
-
-// ------------------------------------------------------------------ K5 gather
-__global__ void __launch_bounds__(256) k_gather_poses(const double* __restrict__ x, const double* __restrict__ y,
-                                                      const double* __restrict__ h,
-                                                      const double* __restrict__ lw,
-                                                      const int32_t* __restrict__ src, double* __restrict__ x2,
-                                                      double* __restrict__ y2, double* __restrict__ h2,
-                                                      double* __restrict__ lw2, int32_t* __restrict__ src2,
-                                                      const int32_t* __restrict__ anc, int64_t P) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= P) return;
-  int32_t a = anc[k];
-  x2[k] = x[a];
-  y2[k] = y[a];
-  h2[k] = h[a];
-  lw2[k] = lw[a];  // weights are NOT reset by the resample (:252)
-  src2[k] = src[a];
-}
-void launch_gather_poses(hipStream_t s, DeviceState& d, const int32_t* anc_dev) {
-  if (d.P == 0) return;
-  int c = d.cur, n = c ^ 1;
-  hipLaunchKernelGGL(k_gather_poses, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
-                     d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], anc_dev, d.P);
-  d.cur = n;
 }
 
 // ------------------------------------------------------------------ K6 summary

@@ -124,8 +124,6 @@ void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* tot
                       const double* offsets_dev, const double* sum_dev, int64_t nb, int64_t P_global,
                       int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev,
                       DeviceState* gather = nullptr);  // gather: also gather the poses (fused K5)
-// K5: pose gather + map indirection
-void launch_gather_poses(hipStream_t s, DeviceState& d, const int32_t* anc_dev);
 // K6
 void launch_summary_partials(hipStream_t s, DeviceState& d, double* partial_dev, double* out4_dev);
 // map maintenance
