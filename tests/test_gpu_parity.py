@@ -142,3 +142,65 @@ def test_resample_fixture(lib):
             got = f.download_poses()
             assert np.array_equal(got[:, 0], np.arange(P)[g["a_" + nm]].astype(float)), nm
         f.close()
+
+
+# ---------------------------------------------------------------- device noise (throughput mode)
+def philox4x32_10(c, k):
+    """NumPy restatement of pk_philox.hpp (Philox4x32-10): c (n,4) uint32 counters, k (2,) key."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c = c.astype(np.uint64).copy()
+    k0, k1 = int(k[0]), int(k[1])
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c[:, 0]
+        p1 = M1 * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ np.uint64(k0)) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ np.uint64(k1)) & mask
+        n3 = p0 & mask
+        c = np.stack([n0, n1, n2, n3], axis=1)
+        k0 = (k0 + W0) & 0xFFFFFFFF
+        k1 = (k1 + W1) & 0xFFFFFFFF
+    return c
+
+
+def device_normals(n, seed, draw, offset=0):
+    g = np.arange(n, dtype=np.uint64) + np.uint64(offset)
+    lo, hi = g & np.uint64(0xFFFFFFFF), g >> np.uint64(32)
+    d_lo, d_hi = np.uint64(draw & 0xFFFFFFFF), np.uint64((draw >> 32) & 0x7FFFFFFF)
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    a = philox4x32_10(np.stack([lo, hi, np.full(n, d_lo), np.full(n, d_hi)], 1), key)
+    b = philox4x32_10(np.stack([lo, hi, np.full(n, d_lo), np.full(n, d_hi | np.uint64(0x80000000))], 1), key)
+
+    def u53(x, y):
+        return ((x >> np.uint64(5)).astype(np.float64) * 67108864.0 + (y >> np.uint64(6)).astype(np.float64) + 0.5) / 9007199254740992.0
+
+    u1, u2, u3, u4 = u53(a[:, 0], a[:, 1]), u53(a[:, 2], a[:, 3]), u53(b[:, 0], b[:, 1]), u53(b[:, 2], b[:, 3])
+    r1, r2 = np.sqrt(-2.0 * np.log(u1)), np.sqrt(-2.0 * np.log(u3))
+    return np.stack([r1 * np.cos(2 * np.pi * u2), r1 * np.sin(2 * np.pi * u2), r2 * np.cos(2 * np.pi * u4)], 1)
+
+
+def test_device_noise_matches_numpy_philox_and_is_shard_invariant(lib):
+    from oracle.fastslam_oracle import OracleFilter
+
+    P, seed, draw = 1000, 0x1234ABCD5678, 17
+    f = lib.DeviceFilter(P, 1)
+    f.motion(0.7, -0.3, 0.2, seed=seed, draw=draw)
+    got = f.download_poses()
+    o = OracleFilter(P, [[1, 1, 1, 1, 1.0]], [np.identity(5)])
+    o.motion(0.7, -0.3, 0.2, device_normals(P, seed, draw))
+    assert np.allclose(got[:, 0], o.x, rtol=1e-12, atol=1e-15)
+    assert np.allclose(got[:, 1], o.y, rtol=1e-12, atol=1e-15)
+    assert np.allclose(got[:, 2], o.h, rtol=1e-12, atol=1e-15)
+    # counters use the GLOBAL particle index: two shards reproduce the one-filter noise bit for bit
+    halves = []
+    for r in range(2):
+        h = lib.DeviceFilter(P // 2, 1)
+        h.set_shard(r * (P // 2))
+        h.motion(0.7, -0.3, 0.2, seed=seed, draw=draw)
+        halves.append(h.download_poses())
+        h.close()
+    assert np.array_equal(np.vstack(halves), got)
+    z = device_normals(200000, 99, 3)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.01
+    f.close()
