@@ -1,0 +1,581 @@
+// K2 maximum-likelihood data association: brute-force reference kernel and the colour-grid kernel.
+//
+// Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update; see DESIGN.md
+// section 4.  No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
+#include "pk_device.hpp"
+
+namespace pk {
+
+// ------------------------------------------------------------------ K2 association
+// One workgroup per particle, lanes over landmarks, uniform loop over blobs (scalar
+// loads).  Two passes: (1) atomicMax of the probability per blob in LDS, (2) the lowest
+// landmark index that attains it -- the reference's strict '>' scan keeps the earliest
+// (prkt_core_v2.py:369-381).  Probability 0 never matches.
+struct AssocArgs {
+  SlotSource ss;
+  size_t count_off;
+  const int32_t* src;
+  const double *x, *y, *h;
+  const double* blobs;    // B x 4
+  const double* blobdir;  // B x 2 unit ray direction (closest_point :510)
+  int32_t* ids;           // P x B
+  int L, Lp, B;
+};
+
+__device__ __forceinline__ double match_probability_lazy(const double* f, const int* cnt, int Lp, int l,
+                                                         Landmark<double>& lm, bool& have_cov, double sx,
+                                                         double sy, double pse, const BlobT<double>& z,
+                                                         double ux, double uy) {
+  if (!have_cov) {
+    lm.pxx = f[F_PXX * Lp + l];
+    lm.pxy = f[F_PXY * Lp + l];
+    lm.pyy = f[F_PYY * Lp + l];
+    lm.crr = f[F_CRR * Lp + l];
+    lm.crg = f[F_CRG * Lp + l];
+    lm.crb = f[F_CRB * Lp + l];
+    lm.cgg = f[F_CGG * Lp + l];
+    lm.cgb = f[F_CGB * Lp + l];
+    lm.cbb = f[F_CBB * Lp + l];
+    have_cov = true;
+  }
+  double bp = 500.0 * prob_position_match(lm, sx, sy, pse, z.bearing, ux, uy);
+  double cp = 500.0 * prob_color_match(lm, z.r, z.g, z.b);
+  return bp * cp / 250000.0;
+}
+
+template <int PASS>
+__device__ __forceinline__ void assoc_pass(const AssocArgs& a, const double* f, const int* cnt, double sx,
+                                           double sy, double sh, unsigned long long* best, int* bid) {
+  for (int l = threadIdx.x; l < a.L; l += blockDim.x) {
+    Landmark<double> lm;
+    lm.mx = f[F_MX * a.Lp + l];
+    lm.my = f[F_MY * a.Lp + l];
+    lm.mr = f[F_MR * a.Lp + l];
+    lm.mg = f[F_MG * a.Lp + l];
+    lm.mb = f[F_MB * a.Lp + l];
+    bool have_cov = false;
+    double pse = atan2(lm.my - sy, lm.mx - sx);
+    double eb = pse - sh;  // :408
+    for (int b = 0; b < a.B; ++b) {
+      BlobT<double> z{a.blobs[4 * b], a.blobs[4 * b + 1], a.blobs[4 * b + 2], a.blobs[4 * b + 3]};
+      if (fabs(z.bearing - eb) > 0.5) continue;                                    // :433
+      if (fabs(color_distance2(lm.mr, lm.mg, lm.mb, z.r, z.g, z.b)) > 300.0) continue;  // :441
+      double pr = match_probability_lazy(f, cnt, a.Lp, l, lm, have_cov, sx, sy, pse, z, a.blobdir[2 * b],
+                                         a.blobdir[2 * b + 1]);
+      if (!(pr > 0.0)) continue;
+      unsigned long long bits = (unsigned long long)__double_as_longlong(pr);
+      if (PASS == 0) {
+        atomicMax(&best[b], bits);
+      } else if (bits == best[b]) {
+        atomicMin(&bid[b], l);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_assoc_brute(AssocArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  int* bid = reinterpret_cast<int*>(best + a.B);
+  const int64_t p = blockIdx.x;
+  const unsigned char* slot = a.ss.at(a.src[p]);
+  const double* f = reinterpret_cast<const double*>(slot);
+  const int* cnt = reinterpret_cast<const int*>(slot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x) {
+    best[b] = 0ull;
+    bid[b] = INT_MAX;
+  }
+  __syncthreads();
+  assoc_pass<0>(a, f, cnt, sx, sy, sh, best, bid);
+  __syncthreads();
+  assoc_pass<1>(a, f, cnt, sx, sy, sh, best, bid);
+  __syncthreads();
+  for (int b = threadIdx.x; b < a.B; b += blockDim.x)
+    a.ids[(size_t)p * a.B + b] = best[b] != 0ull ? bid[b] + 1 : 0;
+}
+
+void launch_assoc_brute(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
+                        int32_t* ids_dev) {
+  if (d.P == 0 || B == 0) return;
+  AssocArgs a;
+  a.ss = slot_source(d);
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.h = d.h[d.cur];
+  a.blobs = blobs_dev;
+  a.blobdir = blobdir_dev;
+  a.ids = ids_dev;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  size_t lds = (size_t)B * 12;
+  hipLaunchKernelGGL(k_assoc_brute, dim3((unsigned)d.P), dim3(256), lds, s, a);
+}
+
+
+// ------------------------------------------------------------------ K2 (grid)
+// Persistent workgroups: the scan tables are staged in LDS once per workgroup and reused for
+// every particle the workgroup processes.  Blobs are handled in cell order (index t); the
+// scan order b = order[t] only matters on write-out.
+//
+// Per particle:
+//   S1 (lanes over landmarks, means only = 40 B/landmark of HBM):
+//      phase 1 (LDS only): the blobs that can pass the colour gate of a landmark lie in the
+//        <= 27 colour cells around it.  With the 9x column-duplicated index list (DUP) that
+//        neighbourhood is ONE contiguous range; otherwise it is walked as nine ranges.  Each
+//        blob there is tested against both gates in fp32 with conservative thresholds (one
+//        ds_read_b128: r, g, b, bearing); the few survivors are kept in registers.
+//      phase 2 (global, convergent): the exact float64 records of all survivors of all lanes
+//        are loaded together, then the exact gates (:433, :441) decide.  A landmark that
+//        passes both gates of blob t is appended to t's candidate list (4 slots + a count).
+//   S2 (lanes over blobs): 0 candidates -> id 0.  1 candidate -> that landmark, TENTATIVELY:
+//      the match stands iff its probability is > 0, which k_observe decides with the landmark
+//      state it has in registers anyway (the reference's strict '>' from 0.0, :369-381).
+//      2..4 candidates -> queued for S3; more -> queued for S4.
+//   S3 (lanes over contested blobs): evaluate their probabilities exactly in landmark order,
+//      keep the largest, the earliest landmark on a tie, none if all are 0.
+//   S4 (rare; lanes over blobs with > 4 gate-passers): the reference's own loop -- every
+//      landmark in order, strict '>' -- so any number of contenders and ties come out right.
+struct AssocGridArgs {
+  AssocArgs a;  // a.blobs / a.blobdir unused here
+  BlobGrid g;
+  const unsigned char* tables;  // see blob_grid_table_bytes
+  const double* exact;          // [B][6] in cell order: bearing, r, g, b, ux, uy
+  int64_t P;
+  int finalize;  // 1: also settle single-candidate blobs here (pk_associate), not in k_observe
+  int n9;        // DUP: entries of the duplicated index list (padded to 8)
+  // Fast hand-off to k_observe_fast (L <= 512): per landmark the (<= 4) blobs that pass its
+  // gates, per blob how many landmarks pass; a particle where some landmark passes more than
+  // four blobs is flagged and settled the general way (S2..S4 + ids) instead.
+  uint4* lmpass;          // [P][Lp]  x,y: four 16-bit fields = blob (cell order) or 0xFFFF; z,w: atan2(my-sy, mx-sx)
+  unsigned char* bcount;  // [P][B]   saturating count
+  unsigned char* pflag;   // [P]      1 = general path
+  const unsigned char* only_flagged;  // GENERAL instance: skip particles whose flag is 0
+  unsigned* n_flagged;                // count of flagged particles (zeroed by the scan upload)
+};
+
+// tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
+// `start` is cell_start (offsets into rec32) or, with DUP, col_start (offsets into idx9).
+__host__ __device__ inline size_t grid_cs_bytes(int ncell) { return ((size_t)(ncell + 1) * 2 + 15) & ~(size_t)15; }
+size_t blob_grid_table_bytes(int ncell, int B, int n9) {
+  return grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + (size_t)B * 2;
+}
+
+
+// probability_of_match (:383-455) of landmark l for the blob record rec = (bearing, r, g, b, ux, uy)
+__device__ __forceinline__ double full_match_probability(const double* f, int Lp, int l, double sx, double sy,
+                                                         double sh, const double* rec) {
+  const Landmark<double> lm = load_landmark_nocount(f, Lp, l);
+  BlobT<double> z{rec[0], rec[1], rec[2], rec[3]};
+  return probability_of_match(lm, sx, sy, sh, z, rec[4], rec[5]);
+}
+
+constexpr int kCand = 4;
+
+// Diagnostic build only (-DPK_STAMPS, never shipped): per-phase cycle sums of k_assoc_grid.
+#ifdef PK_STAMPS
+__device__ unsigned long long pk_stamp_acc[16];
+#define PK_STAMP(var) \
+  unsigned long long var; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
+#define PK_STAMP_ADD(slot, a, b) \
+  if ((threadIdx.x & 63) == 0) atomicAdd(&pk_stamp_acc[slot], (b) - (a));
+#else
+#define PK_STAMP(var)
+#define PK_STAMP_ADD(slot, a, b)
+#endif
+
+// GENERAL = false: S1 + hand-off only (light on registers); particles it flags are redone by
+// the GENERAL = true instance launched with only_flagged.
+template <int THREADS, bool DUP, bool GENERAL>
+__global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int n_few, n_many, wg_flag;
+  __shared__ unsigned long long s3_best[THREADS / 4];
+  __shared__ int s3_win[THREADS / 4];
+  const AssocArgs& a = ga.a;
+  const BlobGrid& g = ga.g;
+  const int B = a.B;
+  if (GENERAL && ga.only_flagged && *ga.n_flagged == 0u) return;  // nothing was flagged
+  const size_t cs_bytes = grid_cs_bytes(g.ncell);
+  const size_t tab_bytes = cs_bytes + (size_t)B * 16 + (DUP ? (size_t)ga.n9 * 2 : 0);  // the part kept in LDS
+  const unsigned short* start = reinterpret_cast<const unsigned short*>(smem);
+  const float4* rec32 = reinterpret_cast<const float4*>(smem + cs_bytes);
+  const unsigned short* idx9 = reinterpret_cast<const unsigned short*>(smem + cs_bytes + (size_t)B * 16);
+  int* ccount = reinterpret_cast<int*>(smem + tab_bytes);  // [B] gate-passing landmarks of blob t; then the result
+  unsigned short* cand = reinterpret_cast<unsigned short*>(ccount + B);  // [B][4] first four of them (arrival order)
+  unsigned short* queue = cand + 4 * (size_t)B;  // [B] contested blobs (2..4 from the front, > 4 from the end)
+  int* result = ccount;
+  const unsigned short* order =
+      reinterpret_cast<const unsigned short*>(ga.tables + cs_bytes + (size_t)B * 16 + (size_t)ga.n9 * 2);  // global
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(ga.tables);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (size_t i = threadIdx.x; i < tab_bytes / 16; i += THREADS) dst[i] = src[i];
+  }
+  for (int64_t p = blockIdx.x; p < ga.P; p += gridDim.x) {
+    if (GENERAL && ga.only_flagged && !ga.only_flagged[p]) continue;  // workgroup-uniform
+    const unsigned char* slot = a.ss.at(a.src[p]);
+    const double* f = reinterpret_cast<const double*>(slot);
+    const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
+    PK_STAMP(ts0)
+    for (int t = threadIdx.x; t < B; t += THREADS) ccount[t] = 0;
+    if (threadIdx.x == 0) {
+      n_few = 0;
+      n_many = 0;
+      wg_flag = 0;
+    }
+    __syncthreads();
+    PK_STAMP(ts1)
+    PK_STAMP_ADD(0, ts0, ts1)
+    // ---- S1 ------------------------------------------------------------------------------
+    // software pipeline: the means of the NEXT landmark are in flight while this one is searched
+    int l = threadIdx.x;
+    double nmx = 0, nmy = 0, nmr = 0, nmg = 0, nmb = 0;
+    if (l < a.L) {
+      nmx = f[F_MX * a.Lp + l];
+      nmy = f[F_MY * a.Lp + l];
+      nmr = f[F_MR * a.Lp + l];
+      nmg = f[F_MG * a.Lp + l];
+      nmb = f[F_MB * a.Lp + l];
+    }
+    for (; l < a.L; l += THREADS) {
+      const double mx = nmx, my = nmy, mr = nmr, mg = nmg, mb = nmb;
+      const int ln = l + THREADS;
+      if (ln < a.L) {
+        nmx = f[F_MX * a.Lp + ln];
+        nmy = f[F_MY * a.Lp + ln];
+        nmr = f[F_MR * a.Lp + ln];
+        nmg = f[F_MG * a.Lp + ln];
+        nmb = f[F_MB * a.Lp + ln];
+      }
+      PK_STAMP(ta0)
+      const double pse = atan2(my - sy, mx - sx);
+      const double eb = pse - sh;  // :408
+      const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
+      // same cell function as the host (floor((v - lo) * inv_h)): inside the colour gate
+      // |dv| <= 17.3205 < 17.5, so the cell indices of blob and landmark differ by at most
+      // one.  -1 / G mean "outside the grid": only the edge cell can hold a neighbour.
+      int c[3];
+      const double m3[3] = {mr, mg, mb};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double q = floor(__dmul_rn(__dsub_rn(m3[k], g.lo[k]), g.inv_h));
+        q = fmin(fmax(q, -1.0), (double)g.G[k]);
+        c[k] = (int)q;
+      }
+      const int k0 = max(c[2] - 1, 0), k1 = min(c[2] + 1, g.G[2] - 1);
+      int pc[kCand];
+      int npc = 0;
+      PK_STAMP(ta1)
+      PK_STAMP_ADD(1, ta0, ta1)
+      auto prefilter = [&](int t) {
+        const float4 q = rec32[t];
+        const float d0 = q.x - mr32, d1 = q.y - mg32, d2 = q.z - mb32;
+        const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
+        // conservative fp32 gates; NaN/inf fall through to the exact float64 tests
+        return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
+      };
+      unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;  // the blobs that pass this landmark's gates (first four)
+      int npass = 0;
+      auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
+        if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
+          const int n = atomicAdd(&ccount[tt], 1);
+          if (n < 4) cand[4 * tt + n] = (unsigned short)l;
+          if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
+          if (npass == 1) pass01 = (pass01 & 0x0000FFFFu) | ((unsigned)tt << 16);
+          if (npass == 2) pass23 = (pass23 & 0xFFFF0000u) | (unsigned)tt;
+          if (npass == 3) pass23 = (pass23 & 0x0000FFFFu) | ((unsigned)tt << 16);
+          ++npass;
+        }
+      };
+      // ---- phase 1 (LDS only) ---------------------------------------------------------
+      if (DUP) {
+        // column (r, g) clamped into the grid: its list holds every blob within one cell in r
+        // and g, ordered by the b cell, so [k0, k1] is one contiguous range
+        const int r = min(max(c[0], 0), g.G[0] - 1), gg = min(max(c[1], 0), g.G[1] - 1);
+        const int base = (r * g.G[1] + gg) * g.G[2];
+        int i = 0, i1 = 0;
+        if (k0 <= k1) {
+          i = start[base + k0];
+          i1 = start[base + k1 + 1];
+        }
+        int tnext = i < i1 ? (int)idx9[i] : 0;
+        for (; i < i1; ++i) {
+          const int t = tnext;
+          if (i + 1 < i1) tnext = idx9[i + 1];
+          if (prefilter(t)) {
+#pragma unroll
+            for (int k = 0; k < kCand; ++k)
+              if (npc == k) pc[k] = t;
+            ++npc;
+          }
+        }
+      } else {
+        // flattened walk over the 9 (r, g) columns x [k0, k1]; j = next column, [t, t1) = open range
+        int j = (k0 <= k1) ? 0 : 9, t = 0, t1 = 0;
+        for (;;) {
+          if (t >= t1) {
+            if (j >= 9) break;
+            const int jr = (j * 11) >> 5;  // j / 3 for j < 9
+            const int r = c[0] - 1 + jr, gg = c[1] - 1 + (j - 3 * jr);
+            ++j;
+            if ((unsigned)r >= (unsigned)g.G[0] || (unsigned)gg >= (unsigned)g.G[1]) continue;
+            const int base = (r * g.G[1] + gg) * g.G[2];
+            t = start[base + k0];
+            t1 = start[base + k1 + 1];
+            if (t >= t1) continue;
+          }
+          if (prefilter(t)) {
+#pragma unroll
+            for (int k = 0; k < kCand; ++k)
+              if (npc == k) pc[k] = t;
+            ++npc;
+          }
+          ++t;
+        }
+      }
+      PK_STAMP(ta2)
+      PK_STAMP_ADD(2, ta1, ta2)
+      // ---- phase 2 (global, convergent): all survivors' exact records in one batch -----
+      if (__any(npc > 0)) {
+        double2 z01[kCand], z23[kCand];
+#pragma unroll
+        for (int k = 0; k < kCand; ++k)
+          if (npc > k) {
+            const double* rec = ga.exact + 6 * (size_t)pc[k];
+            z01[k] = *reinterpret_cast<const double2*>(rec);
+            z23[k] = *reinterpret_cast<const double2*>(rec + 2);
+          }
+#pragma unroll
+        for (int k = 0; k < kCand; ++k)
+          if (npc > k) exact_gates(pc[k], z01[k], z23[k]);
+      }
+      PK_STAMP(ta3)
+      PK_STAMP_ADD(3, ta2, ta3)
+      if (npc > kCand) {
+        // more fp32 survivors than register slots (dense colour clusters): walk again and take
+        // the ones beyond the first kCand as they come (nine-range walk works for both layouts
+        // only without DUP; with DUP repeat the single range)
+        int seen = 0;
+        auto late = [&](int t) {
+          if (prefilter(t)) {
+            if (seen >= kCand) {
+              const double* rec = ga.exact + 6 * (size_t)t;
+              exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
+            }
+            ++seen;
+          }
+        };
+        if (DUP) {
+          const int r = min(max(c[0], 0), g.G[0] - 1), gg = min(max(c[1], 0), g.G[1] - 1);
+          const int base = (r * g.G[1] + gg) * g.G[2];
+          for (int i = start[base + k0], i1 = start[base + k1 + 1]; i < i1; ++i) late(idx9[i]);
+        } else {
+          for (int j = 0; j < 9; ++j) {
+            const int jr = (j * 11) >> 5;
+            const int r = c[0] - 1 + jr, gg = c[1] - 1 + (j - 3 * jr);
+            if ((unsigned)r >= (unsigned)g.G[0] || (unsigned)gg >= (unsigned)g.G[1]) continue;
+            const int base = (r * g.G[1] + gg) * g.G[2];
+            for (int t = start[base + k0], t1 = start[base + k1 + 1]; t < t1; ++t) late(t);
+          }
+        }
+      }
+      if (!GENERAL) {
+        const unsigned long long pb = (unsigned long long)__double_as_longlong(pse);
+        ga.lmpass[(size_t)p * a.Lp + l] = make_uint4(pass01, pass23, (unsigned)pb, (unsigned)(pb >> 32));
+        if (npass > kFastSlots) wg_flag = 1;
+      }
+    }
+    PK_STAMP(ts2)
+    __syncthreads();
+    PK_STAMP(ts3)
+    PK_STAMP_ADD(4, ts1, ts2)
+    PK_STAMP_ADD(5, ts2, ts3)
+    if (!GENERAL) {
+      for (int t = threadIdx.x; t < B; t += THREADS) {
+        const int n = ccount[t];
+        ga.bcount[(size_t)p * B + t] = (unsigned char)(n > 255 ? 255 : n);
+      }
+      if (threadIdx.x == 0) {
+        ga.pflag[p] = (unsigned char)(wg_flag != 0);
+        if (wg_flag) atomicAdd(ga.n_flagged, 1u);
+      }
+      __syncthreads();
+      continue;  // k_observe_fast (or, if flagged, the GENERAL instance) takes it from here
+    }
+    // ---- S2 ------------------------------------------------------------------------------
+    for (int t = threadIdx.x; t < B; t += THREADS) {
+      const int n = ccount[t];
+      if ((n == 1 && ga.finalize) || (n >= 2 && n <= 4)) queue[atomicAdd(&n_few, 1)] = (unsigned short)t;
+      if (n > 4) queue[B - 1 - atomicAdd(&n_many, 1)] = (unsigned short)t;
+    }
+    __syncthreads();
+    // blobs with exactly one gate-passer keep it (tentatively); none -> -1
+    for (int t = threadIdx.x; t < B; t += THREADS) {
+      const int n = ccount[t];
+      result[t] = n == 1 ? (int)cand[4 * t] : (n == 0 ? -1 : -(n + 1));  // contested: -(n+1) until settled
+    }
+    __syncthreads();
+    PK_STAMP(ts4)
+    PK_STAMP_ADD(6, ts3, ts4)
+    // ---- S3: 2..4 contenders (or 1 when finalising): four lanes per blob, one candidate each.
+    // atomicMax on the probability bits, then atomicMin on the landmark index among the lanes
+    // that attain it: the largest probability wins, the earliest landmark on a tie (:377),
+    // nobody if all are 0.
+    for (int base = 0; base < n_few; base += THREADS / 4) {
+      const int slot = threadIdx.x >> 2, k = threadIdx.x & 3;
+      const int qi = base + slot;
+      if (k == 0) {
+        s3_best[slot] = 0ull;
+        s3_win[slot] = INT_MAX;
+      }
+      __syncthreads();
+      int t = 0, lcand = 0;
+      unsigned long long bits = 0ull;
+      bool valid = false;
+      if (qi < n_few) {
+        t = queue[qi];
+        const int n = result[t] >= 0 ? 1 : -result[t] - 1;
+        valid = k < n;
+      }
+      if (valid) {
+        lcand = cand[4 * t + k];
+        const double pr = full_match_probability(f, a.Lp, lcand, sx, sy, sh, ga.exact + 6 * (size_t)t);
+        if (pr > 0.0) {
+          bits = (unsigned long long)__double_as_longlong(pr);
+          atomicMax(&s3_best[slot], bits);
+        }
+      }
+      __syncthreads();
+      if (valid && bits != 0ull && bits == s3_best[slot]) atomicMin(&s3_win[slot], lcand);
+      __syncthreads();
+      if (k == 0 && qi < n_few) result[t] = s3_win[slot] == INT_MAX ? -1 : s3_win[slot];
+    }
+    PK_STAMP(ts5)
+    PK_STAMP_ADD(7, ts4, ts5)
+    // ---- S4: more than four contenders: the reference's sequential scan ------------------------
+    for (int i = threadIdx.x; i < n_many; i += THREADS) {
+      const int t = queue[B - 1 - i];
+      const double* rec = ga.exact + 6 * (size_t)t;
+      const double zb = rec[0], zr = rec[1], zg = rec[2], zbl = rec[3];
+      int best = -1;
+      double pm = 0.0;
+      for (int l2 = 0; l2 < a.L; ++l2) {
+        if (fabs(color_distance2(f[F_MR * a.Lp + l2], f[F_MG * a.Lp + l2], f[F_MB * a.Lp + l2], zr, zg, zbl)) > 300.0)
+          continue;
+        const double mx = f[F_MX * a.Lp + l2], my = f[F_MY * a.Lp + l2];
+        const double eb = atan2(my - sy, mx - sx) - sh;
+        if (fabs(zb - eb) > 0.5) continue;
+        const double pr = full_match_probability(f, a.Lp, l2, sx, sy, sh, rec);
+        if (pr > pm) {
+          pm = pr;
+          best = l2;
+        }
+      }
+      result[t] = best;
+    }
+    PK_STAMP(ts6)
+    PK_STAMP_ADD(8, ts5, ts6)
+    __syncthreads();
+    for (int t = threadIdx.x; t < B; t += THREADS) a.ids[(size_t)p * B + order[t]] = result[t] + 1;
+    __syncthreads();
+    PK_STAMP(ts7)
+    PK_STAMP_ADD(9, ts6, ts7)
+  }
+}
+
+#ifdef PK_STAMPS
+void debug_read_stamps(unsigned long long* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_stamp_acc), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pk_stamp_acc), z, sizeof(z));
+  }
+}
+#endif
+
+size_t assoc_grid_lds_bytes(int ncell, int B, int n9) {
+  // start | rec32 16 B | idx9 | count/result 4 B | 4 candidates 8 B | queue 2 B   per blob
+  return grid_cs_bytes(ncell) + (size_t)B * 30 + (size_t)n9 * 2 + 16;
+}
+
+template <int THREADS, bool DUP, bool GENERAL>
+static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t lds, int64_t P) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();  // leave no sticky error behind for other users of the runtime
+    attr_set = true;
+  }
+  // persistent grid: as many workgroups as LDS and the 2048-thread CU limit allow
+  int per_cu = (int)((160 * 1024) / (lds + 64));
+  per_cu = per_cu < 1 ? 1 : per_cu;
+  const int by_threads = 2048 / THREADS;
+  per_cu = per_cu > by_threads ? by_threads : per_cu;
+  int64_t blocks = 256 * (int64_t)per_cu;
+  if (blocks > P) blocks = P;
+  hipLaunchKernelGGL((k_assoc_grid<THREADS, DUP, GENERAL>), dim3((unsigned)blocks), dim3(THREADS), lds, s, ga);
+}
+
+void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev, bool finalize,
+                       const FastHandoff& fh) {
+  if (d.P == 0 || B == 0) return;
+  AssocGridArgs ga;
+  AssocArgs& a = ga.a;
+  a.ss = slot_source(d);
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.h = d.h[d.cur];
+  a.blobs = nullptr;
+  a.blobdir = nullptr;
+  a.ids = ids_dev;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  ga.g = grid;
+  ga.tables = tables_dev;
+  ga.exact = exact_dev;
+  ga.P = d.P;
+  ga.finalize = finalize ? 1 : 0;
+  ga.n9 = n9;
+  ga.lmpass = fh.lmpass;
+  ga.bcount = fh.bcount;
+  ga.pflag = fh.pflag;
+  ga.n_flagged = fh.n_flagged;
+  ga.only_flagged = nullptr;
+  const size_t lds = assoc_grid_lds_bytes(grid.ncell, B, n9);
+  // bigger workgroups when the LDS tables are large, so that a CU still holds >= 16 waves
+  const bool big = lds > 40 * 1024;
+  auto go = [&](auto general) {
+    constexpr bool G = decltype(general)::value;
+    if (n9 > 0) {
+      if (big)
+        launch_assoc_grid_t<512, true, G>(s, ga, lds, d.P);
+      else
+        launch_assoc_grid_t<256, true, G>(s, ga, lds, d.P);
+    } else {
+      if (big)
+        launch_assoc_grid_t<512, false, G>(s, ga, lds, d.P);
+      else
+        launch_assoc_grid_t<256, false, G>(s, ga, lds, d.P);
+    }
+  };
+  if (fh.lmpass) {
+    go(std::false_type{});  // S1 + hand-off for every particle
+    ga.only_flagged = fh.pflag;
+    go(std::true_type{});   // the flagged ones (a landmark with > 2 gate-passing blobs) the general way
+  } else {
+    go(std::true_type{});
+  }
+}
+
+}  // namespace pk

@@ -1,0 +1,518 @@
+// K3 EKF update + log-weight: general kernel (known ids / per-particle ids) and the fast ML variant.
+//
+// Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update; see DESIGN.md
+// section 4.  No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
+#include "pk_device.hpp"
+
+namespace pk {
+
+// ------------------------------------------------------------------ K3 observe (EKF + weight)
+struct ObserveArgs {
+  SlotSource ss;
+  unsigned char* map_dst;
+  size_t slot_bytes, count_off;
+  int32_t* src;  // in: slot of particle p in map_src; out: identity
+  const double *x, *y;
+  double* logw;
+  const double* blobs;   // B x 4
+  const double* blobdir; // ML: B x 2 unit ray directions (closest_point :510)
+  const int32_t* first;  // KNOWN: [L] first blob matched to landmark l, or -1
+  const int32_t* next;   // KNOWN: [B] next blob matched to the same landmark, or -1
+  int32_t* ids;          // ML: [P x B]; a tentative id whose probability is 0 is reset to 0
+  const unsigned char* immutable;
+  int n_unmatched;  // KNOWN: blobs with id 0
+  const unsigned char* only_flagged;  // when set: skip particles whose flag is 0 (k_observe_fast did them)
+  const unsigned* n_flagged;          // with only_flagged: number of flagged particles (0 -> nothing to do)
+  int reset;                          // 1: the weight restarts from 1 (prkt_core_v2.py:73) instead of accumulating
+  unsigned long long* gmax_key;       // running max of the new log-weights (double_to_key), or NULL
+  int L, Lp, B;
+  Noise<double> qt;
+};
+
+// Is probability_of_match(...) > 0 for a pair that already passed both gates (:433, :441)?
+// The association kernel leaves this to us for blobs with a single gate-passing landmark,
+// because the landmark's covariance is in registers here.  pr = (500 exp(a1)) (500 exp(a2))
+// / 250000 with a1, a2 the two log-pdfs; whenever a1 + a2 is far from the float64 underflow
+// edge the answer is known without evaluating a single exp/log; otherwise evaluate it
+// exactly as the reference does.  pse = atan2(f.my - sy, f.mx - sx).
+__device__ __forceinline__ bool match_is_positive(const Landmark<double>& f, double sx, double sy, double pse,
+                                                  const BlobT<double>& z, double ux, double uy) {
+  if (fabs(pse - z.bearing) > Consts<double>::half_pi) return false;  // :473-475 -> bp = 0
+  double nx, ny;
+  closest_point(f.mx, f.my, sx, sy, ux, uy, nx, ny);
+  const double ex = nx - f.mx, ey = ny - f.my;
+  const double det2 = f.pxx * f.pyy - f.pxy * f.pxy;
+  const double maha2 = (f.pyy * ex * ex - 2.0 * f.pxy * ex * ey + f.pxx * ey * ey) / det2;
+  double det3;
+  const Sym3<double> inv = sym3_inverse(Sym3<double>{f.crr, f.crg, f.crb, f.cgg, f.cgb, f.cbb}, det3);
+  const double maha3 = sym3_quad(inv, z.r - f.mr, z.g - f.mg, z.b - f.mb);
+  // log det <= 138.2 for det <= 1e60, so a1 + a2 >= -0.5 (9.2 + 276.4 + 800) > -543: no underflow
+  if (det2 > 0.0 && det2 < 1e60 && det3 > 0.0 && det3 < 1e60 && maha2 >= 0.0 && maha3 >= 0.0 &&
+      maha2 + maha3 < 800.0)
+    return true;
+  const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + log(det2) + maha2));
+  const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + log(det3) + maha3));
+  return bp * cp / 250000.0 > 0.0;
+}
+
+__device__ __forceinline__ BlobT<double> load_blob(const double* blobs, int b) {
+  const double2 z01 = *reinterpret_cast<const double2*>(blobs + 4 * (size_t)b);
+  const double2 z23 = *reinterpret_cast<const double2*>(blobs + 4 * (size_t)b + 2);
+  return BlobT<double>{z01.x, z01.y, z23.x, z23.y};
+}
+
+// All blobs matched to landmark l, in scan order (prkt_core_v2.py:88).
+// ML: the ids are tentative.  Association saw the state BEFORE any update (:84), so first
+// settle every blob of the chain against the untouched state (s_ids[b] = 0 drops it), then
+// apply the surviving ones sequentially.
+template <bool KNOWN>
+__device__ __forceinline__ double apply_blobs(Landmark<double>& lm, int l, double sx, double sy,
+                                              const ObserveArgs& a, const int32_t* first,
+                                              const int32_t* next, int32_t* s_ids, int32_t* gid) {
+  double acc = 0.0;
+  const int b0 = first[l];
+  if (b0 < 0) return acc;
+  const bool imm = a.immutable[l] != 0;
+  const double pse = atan2(lm.my - sy, lm.mx - sx);
+  if (!KNOWN) {
+    for (int b = b0; b >= 0; b = next[b]) {
+      const BlobT<double> z = load_blob(a.blobs, b);
+      const double2 dir = *reinterpret_cast<const double2*>(a.blobdir + 2 * (size_t)b);
+      if (!match_is_positive(lm, sx, sy, pse, z, dir.x, dir.y)) {
+        s_ids[b] = 0;
+        gid[b] = 0;
+      }
+    }
+  }
+  bool fresh = true;  // lm still equals the state pse was computed from
+  for (int b = b0; b >= 0; b = next[b]) {
+    if (!KNOWN && s_ids[b] == 0) {
+      acc += Consts<double>::log_no_match;  // unseen feature: weight *= 0.1 (:94-95)
+      continue;
+    }
+    const BlobT<double> z = load_blob(a.blobs, b);
+    acc += ekf_update(lm, sx, sy, z, a.qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+    fresh = imm;
+  }
+  return acc;
+}
+
+template <bool KNOWN, int NV>
+__global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kObsThreads / kWave];
+  const int64_t p = blockIdx.x;
+  if (a.only_flagged && (*a.n_flagged == 0u || !a.only_flagged[p])) return;  // workgroup-uniform
+  const int tid = threadIdx.x;
+  const int32_t sp = a.src[p];
+  const unsigned char* sslot = a.ss.at(sp);
+  unsigned char* dslot = a.map_dst + (size_t)p * a.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p];
+  const int Lp = a.Lp;
+
+  const int32_t* first = a.first;
+  const int32_t* next = a.next;
+  int n_unmatched = a.n_unmatched;
+  int32_t* gid_mut = KNOWN ? nullptr : a.ids + (size_t)p * a.B;
+  int32_t* s_ids_mut = nullptr;
+  if (!KNOWN) {
+    // Build the per-particle landmark -> blob chains in LDS from this particle's ids.
+    // Blobs are applied in scan order (prkt_core_v2.py:88): first[l] is the lowest blob
+    // index matched to l, next[b] the following blob matched to the same landmark.
+    int32_t* s_first = reinterpret_cast<int32_t*>(smem);
+    int32_t* s_next = s_first + Lp;
+    int32_t* s_ids = s_next + a.B;
+    s_ids_mut = s_ids;
+    const int32_t* gid = gid_mut;
+    for (int l = tid; l < Lp; l += blockDim.x) s_first[l] = INT_MAX;
+    for (int b = tid; b < a.B; b += blockDim.x) {
+      s_ids[b] = gid[b];
+      s_next[b] = -1;
+    }
+    __syncthreads();
+    int cnt0 = 0;
+    for (int b = tid; b < a.B; b += blockDim.x) {
+      int id = s_ids[b];
+      if (id > 0)
+        atomicMin(&s_first[id - 1], b);
+      else
+        ++cnt0;
+    }
+    __syncthreads();
+    for (int b = tid; b < a.B; b += blockDim.x) {
+      int id = s_ids[b];
+      if (id > 0 && s_first[id - 1] != b) {  // not the first sighting: link from my predecessor
+        int q = b - 1;
+        while (s_ids[q] != id) --q;  // terminates: first[id-1] < b has this id
+        s_next[q] = b;
+      }
+    }
+    for (int l = tid; l < Lp; l += blockDim.x)
+      if (s_first[l] == INT_MAX) s_first[l] = -1;
+    // number of unmatched blobs of this particle (weight *= 0.1 each, :94-95)
+    double c = block_sum<kObsThreads / kWave>((double)cnt0, red);
+    n_unmatched = (int)c;
+    __syncthreads();
+    first = s_first;
+    next = s_next;
+  }
+
+  double acc = 0.0;
+  if (NV == 2) {
+    // two adjacent landmarks per lane: 16-byte loads/stores, 14 rows x 1 KiB per wave instruction
+    for (int l0 = 2 * tid; l0 < Lp; l0 += 2 * kObsThreads) {
+      double2 v[F_COUNT_FIELDS];
+#pragma unroll
+      for (int f = 0; f < F_COUNT_FIELDS; ++f) v[f] = *reinterpret_cast<const double2*>(sf + (size_t)f * Lp + l0);
+      int2 c = *reinterpret_cast<const int2*>(sc + l0);
+      Landmark<double> A{v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x,
+                         v[8].x, v[9].x, v[10].x, v[11].x, v[12].x, v[13].x, c.x};
+      Landmark<double> Bq{v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y,
+                          v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, c.y};
+      if (l0 < a.L) acc += apply_blobs<KNOWN>(A, l0, sx, sy, a, first, next, s_ids_mut, gid_mut);
+      if (l0 + 1 < a.L) acc += apply_blobs<KNOWN>(Bq, l0 + 1, sx, sy, a, first, next, s_ids_mut, gid_mut);
+      *reinterpret_cast<double2*>(df + (size_t)F_MX * Lp + l0) = make_double2(A.mx, Bq.mx);
+      *reinterpret_cast<double2*>(df + (size_t)F_MY * Lp + l0) = make_double2(A.my, Bq.my);
+      *reinterpret_cast<double2*>(df + (size_t)F_MR * Lp + l0) = make_double2(A.mr, Bq.mr);
+      *reinterpret_cast<double2*>(df + (size_t)F_MG * Lp + l0) = make_double2(A.mg, Bq.mg);
+      *reinterpret_cast<double2*>(df + (size_t)F_MB * Lp + l0) = make_double2(A.mb, Bq.mb);
+      *reinterpret_cast<double2*>(df + (size_t)F_PXX * Lp + l0) = make_double2(A.pxx, Bq.pxx);
+      *reinterpret_cast<double2*>(df + (size_t)F_PXY * Lp + l0) = make_double2(A.pxy, Bq.pxy);
+      *reinterpret_cast<double2*>(df + (size_t)F_PYY * Lp + l0) = make_double2(A.pyy, Bq.pyy);
+      *reinterpret_cast<double2*>(df + (size_t)F_CRR * Lp + l0) = make_double2(A.crr, Bq.crr);
+      *reinterpret_cast<double2*>(df + (size_t)F_CRG * Lp + l0) = make_double2(A.crg, Bq.crg);
+      *reinterpret_cast<double2*>(df + (size_t)F_CRB * Lp + l0) = make_double2(A.crb, Bq.crb);
+      *reinterpret_cast<double2*>(df + (size_t)F_CGG * Lp + l0) = make_double2(A.cgg, Bq.cgg);
+      *reinterpret_cast<double2*>(df + (size_t)F_CGB * Lp + l0) = make_double2(A.cgb, Bq.cgb);
+      *reinterpret_cast<double2*>(df + (size_t)F_CBB * Lp + l0) = make_double2(A.cbb, Bq.cbb);
+      *reinterpret_cast<int2*>(dc + l0) = make_int2(A.count, Bq.count);
+    }
+  } else {
+    // one landmark per lane: half the registers, twice the waves in flight
+    for (int l = tid; l < Lp; l += kObsThreads) {
+      Landmark<double> A = load_landmark(sf, sc, Lp, l);
+      if (l < a.L) acc += apply_blobs<KNOWN>(A, l, sx, sy, a, first, next, s_ids_mut, gid_mut);
+      df[(size_t)F_MX * Lp + l] = A.mx;
+      df[(size_t)F_MY * Lp + l] = A.my;
+      df[(size_t)F_MR * Lp + l] = A.mr;
+      df[(size_t)F_MG * Lp + l] = A.mg;
+      df[(size_t)F_MB * Lp + l] = A.mb;
+      df[(size_t)F_PXX * Lp + l] = A.pxx;
+      df[(size_t)F_PXY * Lp + l] = A.pxy;
+      df[(size_t)F_PYY * Lp + l] = A.pyy;
+      df[(size_t)F_CRR * Lp + l] = A.crr;
+      df[(size_t)F_CRG * Lp + l] = A.crg;
+      df[(size_t)F_CRB * Lp + l] = A.crb;
+      df[(size_t)F_CGG * Lp + l] = A.cgg;
+      df[(size_t)F_CGB * Lp + l] = A.cgb;
+      df[(size_t)F_CBB * Lp + l] = A.cbb;
+      dc[l] = A.count;
+    }
+  }
+  double tot = block_sum<kObsThreads / kWave>(acc, red);
+  if (tid == 0) {
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot + (double)n_unmatched * Consts<double>::log_no_match;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));  // sharded: same-address atomics serialise
+    a.src[p] = (int32_t)p;
+  }
+}
+
+
+// ------------------------------------------------------------------ K3 (fast ML variant, L <= 512)
+// One workgroup per particle, two adjacent landmarks per lane, the particle's whole map in
+// registers from the single coalesced load to the single coalesced store.  Input is the
+// association kernel's hand-off: per landmark the (<= 2) blobs that pass its gates, per blob
+// the number of landmarks that pass.  A blob passed by one landmark is matched iff its
+// probability is > 0 (strict '>' from 0.0, :369-381); a blob passed by several is given to
+// the landmark with the largest probability, the earliest on a tie -- LDS atomicMax on the
+// probability bits, then atomicMin on the landmark index among those that attain it --
+// evaluated here because the covariances are already in registers.  Blobs nobody passes or
+// wins multiply the weight by 0.1 (:94-95).  Updates of one landmark are applied in scan
+// order (:88) and every probability refers to the state before any update (:84).
+struct FastArgs {
+  SlotSource ss;
+  unsigned char* map_dst;
+  size_t count_off;
+  int32_t* src;
+  const double *x, *y;
+  double* logw;
+  const double* exact;          // [B][6] cell order: bearing, r, g, b, ux, uy
+  const unsigned short* order;  // [B] cell order -> scan order
+  const uint4* lmpass;
+  const unsigned char* bcount;
+  const unsigned char* pflag;
+  const unsigned char* immutable;
+  int L, Lp, B;
+  int reset;
+  unsigned long long* gmax_key;
+  Noise<double> qt;
+};
+
+struct FastSlot {
+  int t;                    // blob (cell order) or -1
+  int b;                    // its scan index
+  unsigned long long bits;  // contested candidate: probability bits (0: not positive)
+  unsigned flags;           // bit 0 contested, bit 1 apply the update, bit 2 unmatched (single, probability 0)
+};
+
+// What probability_of_match needs from the landmark alone, computed once per landmark instead
+// of once per blob: determinant / inverse of the 2x2 position block and of the 3x3 colour block.
+struct FastLm {
+  double det2, idet2, det3;
+  Sym3<double> inv3;
+};
+
+__device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<double>& lm, double sx, double sy,
+                                             double pse, uint2 packed, const unsigned char* bc,
+                                             unsigned long long* best, FastSlot (&sl)[kFastSlots]) {
+  FastLm q;
+  q.det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+  q.idet2 = 1.0 / q.det2;
+  q.inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, q.det3);
+  const bool dets_sane = q.det2 > 0.0 && q.det2 < 1e60 && q.det3 > 0.0 && q.det3 < 1e60;
+  double ldet2 = 0.0, ldet3 = 0.0;  // log determinants, evaluated once per landmark on first use
+  bool have_logs = false;
+  const unsigned w[2] = {packed.x, packed.y};
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+    sl[k].t = t == 0xFFFF ? -1 : t;
+    sl[k].b = INT_MAX;
+    sl[k].bits = 0ull;
+    sl[k].flags = 0u;
+    if (sl[k].t < 0) continue;
+    sl[k].b = a.order[t];
+    const double* rec = a.exact + 6 * (size_t)t;
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+    // the quantities both branches need (prob_position_match :457-494, prob_color_match :524-544)
+    const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
+    double nx, ny;
+    closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+    const double ex = nx - lm.mx, ey = ny - lm.my;
+    const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / q.det2;
+    const double maha3 = sym3_quad(q.inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+    const bool contested = bc[t] >= 2;
+    // pr = (500 exp(a1)) (500 exp(a2)) / 250000 is certainly > 0 when a1 + a2 is far from the
+    // float64 underflow edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 here
+    const bool surely_positive = angle_ok && dets_sane && maha2 >= 0.0 && maha3 >= 0.0 && maha2 + maha3 < 800.0;
+    double pr = 0.0;
+    if (contested || (angle_ok && !surely_positive)) {
+      if (angle_ok) {
+        if (!have_logs) {
+          ldet2 = log(q.det2);
+          ldet3 = log(q.det3);
+          have_logs = true;
+        }
+        const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + ldet2 + maha2));  // :439
+        const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + ldet3 + maha3));  // :446
+        pr = bp * cp / 250000.0;                                                                 // :455
+      }
+    }
+    if (contested) {
+      sl[k].flags = 1u;
+      if (pr > 0.0) {
+        sl[k].bits = (unsigned long long)__double_as_longlong(pr);
+        atomicMax(&best[t], sl[k].bits);
+      }
+    } else {
+      sl[k].flags = (surely_positive || pr > 0.0) ? 2u : 4u;
+    }
+  }
+}
+
+__device__ __forceinline__ double fast_apply(const FastArgs& a, Landmark<double>& lm, int l, double sx, double sy,
+                                             double pse, FastSlot (&sl)[kFastSlots], const int* win) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].t < 0) continue;
+    if ((sl[k].flags & 1u) && sl[k].bits != 0ull && win[sl[k].t] == l) sl[k].flags |= 2u;
+    if (sl[k].flags & 4u) acc += Consts<double>::log_no_match;  // single candidate, probability 0 (:94-95)
+    if (!(sl[k].flags & 2u)) sl[k].b = INT_MAX;                 // not applied: sorts to the back
+  }
+  // the blobs to apply first, in scan order (:88) -- so that nearly every lane of the wave
+  // applies its (usually only) update in the same iteration (5-comparator network)
+  auto cswap = [&](FastSlot& u, FastSlot& v) {
+    if (u.b > v.b) {
+      const FastSlot tmp = u;
+      u = v;
+      v = tmp;
+    }
+  };
+  cswap(sl[0], sl[1]);
+  cswap(sl[2], sl[3]);
+  cswap(sl[0], sl[2]);
+  cswap(sl[1], sl[3]);
+  cswap(sl[1], sl[2]);
+  const bool imm = a.immutable[l] != 0;
+  bool fresh = true;
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].b == INT_MAX) continue;
+    const double* rec = a.exact + 6 * (size_t)sl[k].t;
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+    acc += ekf_update(lm, sx, sy, z, a.qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+    fresh = imm;
+  }
+  return acc;
+}
+
+constexpr int kFastThreads = 512;  // one landmark per lane: L <= 512 in one pass
+
+__global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kFastThreads / kWave];
+  const int64_t p = blockIdx.x;
+  if (a.pflag[p]) return;  // workgroup-uniform: the general kernel takes this particle
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp;
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  int* win = reinterpret_cast<int*>(best + B);
+  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
+  const unsigned char* sslot = a.ss.at(a.src[p]);
+  unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p];
+  const int l = tid;
+  const bool active = l < Lp, has = l < a.L;
+  Landmark<double> A{};
+  uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+  if (active) {
+    A = load_landmark(sf, sc, Lp, l);
+    lp = a.lmpass[(size_t)p * Lp + l];
+  }
+  for (int t = tid; t < B; t += kFastThreads) {
+    best[t] = 0ull;
+    win[t] = INT_MAX;
+    bc[t] = a.bcount[(size_t)p * B + t];
+  }
+  __syncthreads();
+  int nun = 0;  // blobs no landmark passes
+  for (int t = tid; t < B; t += kFastThreads) nun += bc[t] == 0;
+  FastSlot sa[kFastSlots];
+  // atan2(my - sy, mx - sx) of the untouched state, handed over by the association kernel
+  const double pseA = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
+  fast_prepare(a, A, sx, sy, pseA, has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, sa);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k)
+    if (sa[k].t >= 0 && sa[k].bits != 0ull && sa[k].bits == best[sa[k].t]) atomicMin(&win[sa[k].t], l);
+  __syncthreads();
+  for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
+  double acc = (double)nun * Consts<double>::log_no_match;
+  if (has) acc += fast_apply(a, A, l, sx, sy, pseA, sa, win);
+  if (active) {
+    df[(size_t)F_MX * Lp + l] = A.mx;
+    df[(size_t)F_MY * Lp + l] = A.my;
+    df[(size_t)F_MR * Lp + l] = A.mr;
+    df[(size_t)F_MG * Lp + l] = A.mg;
+    df[(size_t)F_MB * Lp + l] = A.mb;
+    df[(size_t)F_PXX * Lp + l] = A.pxx;
+    df[(size_t)F_PXY * Lp + l] = A.pxy;
+    df[(size_t)F_PYY * Lp + l] = A.pyy;
+    df[(size_t)F_CRR * Lp + l] = A.crr;
+    df[(size_t)F_CRG * Lp + l] = A.crg;
+    df[(size_t)F_CRB * Lp + l] = A.crb;
+    df[(size_t)F_CGG * Lp + l] = A.cgg;
+    df[(size_t)F_CGB * Lp + l] = A.cgb;
+    df[(size_t)F_CBB * Lp + l] = A.cbb;
+    dc[l] = A.count;
+  }
+  const double tot = block_sum<kFastThreads / kWave>(acc, red);
+  if (tid == 0) {
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));  // sharded: same-address atomics serialise
+    a.src[p] = (int32_t)p;
+  }
+}
+
+void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
+                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                         const ObserveExtras& ex) {
+  if (d.P == 0) return;
+  FastArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = fh.lmpass;
+  a.bcount = fh.bcount;
+  a.pflag = fh.pflag;
+  a.immutable = d.immutable;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  const size_t lds = (size_t)B * 13 + 16;
+  hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
+}
+
+int g_observe_nv = 0;  // tuning: 0 = default per variant, 1 / 2 = landmarks per lane
+
+void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
+                    const int32_t* first_dev, const int32_t* next_dev, int n_unmatched, int32_t* ids_dev,
+                    const NoiseD& qt, const ObserveExtras& ex) {
+  if (d.P == 0) return;
+  ObserveArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.slot_bytes = d.lay.slot_bytes;
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.blobs = blobs_dev;
+  a.blobdir = blobdir_dev;
+  a.first = first_dev;
+  a.next = next_dev;
+  a.ids = ids_dev;
+  a.immutable = d.immutable;
+  a.n_unmatched = n_unmatched;
+  a.only_flagged = ex.only_flagged;
+  a.n_flagged = ex.n_flagged;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  if (ids_dev == nullptr) {
+    if (g_observe_nv == 1)
+      hipLaunchKernelGGL((k_observe<true, 1>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_observe<true, 2>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
+  } else {
+    size_t lds = sizeof(int32_t) * ((size_t)d.lay.Lp + 2 * (size_t)B);
+    if (g_observe_nv == 2)
+      hipLaunchKernelGGL((k_observe<false, 2>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
+    else
+      hipLaunchKernelGGL((k_observe<false, 1>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
+  }
+  if (ex.flip) {
+    d.mcur ^= 1;
+    d.alt = nullptr;  // every slot was rewritten into the particle's own map buffer
+  }
+}
+
+}  // namespace pk

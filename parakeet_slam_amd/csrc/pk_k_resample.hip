@@ -1,0 +1,442 @@
+// K4 weights -> scans -> ancestors (+ pose gather), and the sharded (multi-GPU) resample kernels.
+//
+// Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update; see DESIGN.md
+// section 4.  No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
+#include "pk_device.hpp"
+
+namespace pk {
+
+// ------------------------------------------------------------------ K4 weights
+__global__ void __launch_bounds__(256) k_block_max(const double* __restrict__ logw, int64_t P,
+                                                   double* __restrict__ partial) {
+  __shared__ double red[4];
+  double m = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmax(m, logw[i]);
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = m;
+}
+__global__ void __launch_bounds__(256) k_final_max(const double* __restrict__ partial, int n,
+                                                   double* __restrict__ out) {
+  __shared__ double red[4];
+  double m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, partial[i]);
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0) out[0] = m;
+}
+void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev) {
+  int nb = (int)((d.P + 255) / 256);
+  if (nb > kRedBlocks) nb = kRedBlocks;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_block_max, dim3(nb), dim3(256), 0, s, d.logw[d.cur], d.P, partial_dev);
+  hipLaunchKernelGGL(k_final_max, dim3(1), dim3(256), 0, s, partial_dev, nb, gmax_dev);
+}
+
+// Block-local inclusive scan of w = exp(logw - shift) over kScanBlock particles:
+// 4 consecutive particles per thread (sequential), Kogge-Stone over the wave with
+// __shfl_up, sequential over the 4 waves.  The association order is fixed by the block
+// size alone, so shards that are multiples of kScanBlock reproduce the 1-GPU bits.
+__global__ void __launch_bounds__(256) k_scan_local(const double* __restrict__ logw, int64_t P,
+                                                    const double* __restrict__ gmax, int domain,
+                                                    double* __restrict__ clocal, double* __restrict__ totals,
+                                                    const unsigned long long* __restrict__ gmax_key) {
+  __shared__ double wtot[4];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  double shift = 0.0;
+  if (domain == 1) {
+    if (gmax_key) {  // max over the sharded running-max keys (kGmaxKeys == blockDim.x)
+      const double mine = key_to_double(gmax_key[tid]);
+      shift = block_max<4>(mine, wtot);
+      __syncthreads();
+    } else {
+      shift = gmax[0];
+    }
+    if (!(shift > -INFINITY)) shift = 0.0;  // all weights zero: keep exp(-inf) = 0, not NaN
+  }
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * tid;
+  double w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (base + i < P) ? exp(logw[base + i] - shift) : 0.0;
+  double s0 = w[0], s1 = s0 + w[1], s2 = s1 + w[2], s3 = s2 + w[3];
+  double val = s3;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    double t = __shfl_up(val, off, kWave);
+    if (lane >= off) val += t;
+  }
+  if (lane == kWave - 1) wtot[wave] = val;
+  double prev = __shfl_up(val, 1, kWave);  // exclusive prefix inside the wave
+  if (lane == 0) prev = 0.0;
+  __syncthreads();
+  double woff = 0.0;
+  for (int i = 0; i < wave; ++i) woff += wtot[i];
+  const double excl = woff + prev;
+  if (base < P) clocal[base] = excl + s0;
+  if (base + 1 < P) clocal[base + 1] = excl + s1;
+  if (base + 2 < P) clocal[base + 2] = excl + s2;
+  if (base + 3 < P) clocal[base + 3] = excl + s3;
+  // the block total IS the inclusive value of its last particle (bit for bit): shards hand
+  // over at block boundaries and both sides must see the same cumulative weight there
+  if (tid == 255) totals[blockIdx.x] = excl + s3;
+}
+void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, int domain, double* clocal_dev,
+                       double* totals_dev, const unsigned long long* gmax_key_dev) {
+  if (d.P == 0) return;
+  int nb = (int)((d.P + kScanBlock - 1) / kScanBlock);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, d.logw[d.cur], d.P, gmax_dev, domain,
+                     clocal_dev, totals_dev, gmax_key_dev);
+}
+
+// Exclusive scan of the block totals in block order by ONE thread: the canonical
+// (shard-count independent) association of the global prefix sum.
+__global__ void __launch_bounds__(256) k_scan_blocks(const double* __restrict__ totals, int64_t nb,
+                                                     double* __restrict__ offsets, double* __restrict__ sum) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* t = reinterpret_cast<double*>(smem);
+  double run = 0.0;
+  for (int64_t c0 = 0; c0 < nb; c0 += 2048) {
+    int n = (int)((nb - c0 < 2048) ? (nb - c0) : 2048);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = totals[c0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < n; ++i) {
+        double v = t[i];
+        t[i] = run;
+        run += v;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) offsets[c0 + i] = t[i];
+  }
+  if (threadIdx.x == 0) sum[0] = run;
+}
+void launch_scan_blocks(hipStream_t s, const double* totals_dev, int64_t nb, double* offsets_dev,
+                        double* sum_dev) {
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 2048 * sizeof(double), s, totals_dev, nb, offsets_dev,
+                     sum_dev);
+}
+
+// Ancestor of output slot k: first particle j whose inclusive cumulative weight C_j is
+// >= u*r + k*r, r = sum/P  (equivalent to the walk at prkt_core_v2.py:233-250, '<=' at :239).
+__global__ void __launch_bounds__(256) k_ancestors(const double* __restrict__ clocal,
+                                                   const double* __restrict__ totals,
+                                                   const double* __restrict__ offsets,
+                                                   const double* __restrict__ sum, int64_t nb, int64_t Pg,
+                                                   int64_t Pscan, double u, int64_t slot0, int64_t n,
+                                                   int32_t* __restrict__ anc, const double* __restrict__ gx,
+                                                   const double* __restrict__ gy, const double* __restrict__ gh,
+                                                   const double* __restrict__ glw, const int32_t* __restrict__ gsrc,
+                                                   double* __restrict__ gx2, double* __restrict__ gy2,
+                                                   double* __restrict__ gh2, double* __restrict__ glw2,
+                                                   int32_t* __restrict__ gsrc2) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double r = __ddiv_rn(sum[0], (double)Pg);                  // range_ :225
+  const double t = __dadd_rn(__dmul_rn(u, r), __dmul_rn((double)(slot0 + k), r));  // step :226 + k*range_
+  // block: first b with offsets[b] + totals[b] >= t
+  int64_t lo = 0, hi = nb - 1;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (__dadd_rn(offsets[mid], totals[mid]) >= t)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  const int64_t b = lo;
+  const double off = offsets[b];
+  int64_t j0 = b * kScanBlock, j1 = j0 + kScanBlock - 1;
+  if (j1 > Pscan - 1) j1 = Pscan - 1;
+  while (j0 < j1) {
+    int64_t mid = (j0 + j1) >> 1;
+    if (__dadd_rn(off, clocal[mid]) >= t)
+      j1 = mid;
+    else
+      j0 = mid + 1;
+  }
+  anc[k] = (int32_t)j0;
+  if (gx) {  // fused k_gather_poses (single-GPU resample)
+    const int32_t a = (int32_t)j0;
+    gx2[k] = gx[a];
+    gy2[k] = gy[a];
+    gh2[k] = gh[a];
+    glw2[k] = glw[a];
+    gsrc2[k] = gsrc[a];
+  }
+}
+void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* totals_dev,
+                      const double* offsets_dev, const double* sum_dev, int64_t nb, int64_t P_global,
+                      int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev, DeviceState* gather) {
+  if (n == 0) return;
+  if (gather) {
+    DeviceState& d = *gather;
+    const int c = d.cur, m = c ^ 1;
+    hipLaunchKernelGGL(k_ancestors, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clocal_dev, totals_dev,
+                       offsets_dev, sum_dev, nb, P_global, P_scan, u, slot0, n, anc_dev, d.x[c], d.y[c], d.h[c],
+                       d.logw[c], d.src[c], d.x[m], d.y[m], d.h[m], d.logw[m], d.src[m]);
+    d.cur = m;
+    return;
+  }
+  hipLaunchKernelGGL(k_ancestors, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clocal_dev, totals_dev,
+                     offsets_dev, sum_dev, nb, P_global, P_scan, u, slot0, n, anc_dev, (const double*)nullptr,
+                     (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const int32_t*)nullptr,
+                     (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
+}
+
+// ------------------------------------------------------------------ sharded resample
+// Owner-computes offspring: with C_j the global inclusive cumulative weight of local
+// particle j and t_k = u r + k r the comb (same expressions as k_ancestors), particle j fills
+// the output slots [hi_{j-1}, hi_j), hi_j = #{k : t_k <= C_j}.  hi[0] is the count at the
+// shard's lower boundary, hi[1 + j] that of particle j.  Every shard evaluates the same
+// formula on the same block offsets, so the slot ranges tile [0, P) without communication.
+__global__ void __launch_bounds__(256) k_offspring(const double* __restrict__ clocal,
+                                                   const double* __restrict__ offsets,
+                                                   const double* __restrict__ sum, int64_t first_block,
+                                                   int64_t Pl, int64_t Pg, double u, int last_shard,
+                                                   int64_t* __restrict__ hi) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. Pl
+  if (i > Pl) return;
+  const double r = __ddiv_rn(sum[0], (double)Pg);
+  const double ur = __dmul_rn(u, r);
+  double C;
+  if (i == 0) {
+    if (first_block == 0) {
+      hi[0] = 0;
+      return;
+    }
+    C = offsets[first_block];
+  } else {
+    const int64_t j = i - 1;
+    if (last_shard && j == Pl - 1) {  // the tail is clamped to the last particle, as k_ancestors does
+      hi[i] = Pg;
+      return;
+    }
+    C = __dadd_rn(offsets[first_block + j / kScanBlock], clocal[j]);
+  }
+  int64_t lo = 0, up = Pg;  // first k with t_k > C
+  while (lo < up) {
+    const int64_t mid = (lo + up) >> 1;
+    const double t = __dadd_rn(ur, __dmul_rn((double)mid, r));
+    if (t > C)
+      up = mid;
+    else
+      lo = mid + 1;
+  }
+  hi[i] = lo;
+}
+void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,
+                      int64_t first_block, int64_t P_local, int64_t P_global, double u, int last_shard,
+                      int64_t* hi_dev) {
+  hipLaunchKernelGGL(k_offspring, dim3((unsigned)((P_local + 1 + 255) / 256)), dim3(256), 0, s, clocal_dev,
+                     offsets_dev, sum_dev, first_block, P_local, P_global, u, last_shard, hi_dev);
+}
+
+// record = (x, y, h, logw) + map slot
+__global__ void __launch_bounds__(256) k_pack(SlotSource ss, const int32_t* __restrict__ src,
+                                              const double* __restrict__ x, const double* __restrict__ y,
+                                              const double* __restrict__ h, const double* __restrict__ lw,
+                                              const int64_t* __restrict__ idx, unsigned char* __restrict__ buf) {
+  const int64_t i = blockIdx.x;
+  const int64_t j = idx[i];
+  unsigned char* rec = buf + (size_t)i * (kPoseRecordBytes + ss.slot_bytes);
+  if (threadIdx.x == 0) {
+    double* hd = reinterpret_cast<double*>(rec);
+    hd[0] = x[j];
+    hd[1] = y[j];
+    hd[2] = h[j];
+    hd[3] = lw[j];
+    hd[4] = 0.0;
+    hd[5] = 0.0;
+  }
+  const uint4* s = reinterpret_cast<const uint4*>(ss.at(src[j]));
+  uint4* d = reinterpret_cast<uint4*>(rec + kPoseRecordBytes);
+  const size_t n = ss.slot_bytes / 16;
+  for (size_t k = threadIdx.x; k < n; k += blockDim.x) d[k] = s[k];
+}
+void launch_pack(hipStream_t s, DeviceState& d, const int64_t* idx_dev, int64_t n, unsigned char* buf_dev) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)n), dim3(256), 0, s, slot_source(d), d.src[d.cur], d.x[d.cur],
+                     d.y[d.cur], d.h[d.cur], d.logw[d.cur], idx_dev, buf_dev);
+}
+
+// New generation of the shard: slot k <- local particle srcs[k] (>= 0) or received record
+// -(srcs[k]) - 1.  Poses are gathered now; maps stay where they are (own buffer / record)
+// until the next observe rewrites them.
+__global__ void __launch_bounds__(256) k_adopt(const double* __restrict__ x, const double* __restrict__ y,
+                                               const double* __restrict__ h, const double* __restrict__ lw,
+                                               const int32_t* __restrict__ src, double* __restrict__ x2,
+                                               double* __restrict__ y2, double* __restrict__ h2,
+                                               double* __restrict__ lw2, int32_t* __restrict__ src2,
+                                               const int64_t* __restrict__ srcs, const unsigned char* __restrict__ buf,
+                                               size_t stride, int64_t P) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const int64_t a = srcs[k];
+  if (a >= 0) {
+    x2[k] = x[a];
+    y2[k] = y[a];
+    h2[k] = h[a];
+    lw2[k] = lw[a];
+    src2[k] = src[a];
+  } else {
+    const double* hd = reinterpret_cast<const double*>(buf + (size_t)(-(a + 1)) * stride);
+    x2[k] = hd[0];
+    y2[k] = hd[1];
+    h2[k] = hd[2];
+    lw2[k] = hd[3];
+    src2[k] = (int32_t)a;
+  }
+}
+void launch_adopt(hipStream_t s, DeviceState& d, const int64_t* src_dev, const unsigned char* buf_dev) {
+  if (d.P == 0) return;
+  const int c = d.cur, n = c ^ 1;
+  const size_t stride = kPoseRecordBytes + d.lay.slot_bytes;
+  hipLaunchKernelGGL(k_adopt, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
+                     d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], src_dev, buf_dev, stride,
+                     d.P);
+  d.cur = n;
+  d.alt = buf_dev;
+  d.alt_stride = stride;
+  d.alt_off = kPoseRecordBytes;
+}
+
+
+// ---- device-resident exchange ------------------------------------------------------------
+// ranges[2 d], ranges[2 d + 1] = [j0, j1): the local particles whose offspring overlap the
+// output slots [d P, (d + 1) P) of rank d (hi from k_offspring, monotone).
+__global__ void k_shard_ranges(const int64_t* __restrict__ hi, int64_t P, int world, int64_t* __restrict__ ranges) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= world) return;
+  const int64_t start = (int64_t)d * P, end = start + P;
+  int64_t lo = 0, up = P;  // first j with hi[j + 1] > start
+  while (lo < up) {
+    const int64_t mid = (lo + up) >> 1;
+    if (hi[mid + 1] > start)
+      up = mid;
+    else
+      lo = mid + 1;
+  }
+  const int64_t j0 = lo;
+  lo = 0;
+  up = P;  // first j with hi[j] >= end
+  while (lo < up) {
+    const int64_t mid = (lo + up) >> 1;
+    if (hi[mid] >= end)
+      up = mid;
+    else
+      lo = mid + 1;
+  }
+  ranges[2 * d] = j0;
+  ranges[2 * d + 1] = lo < j0 ? j0 : lo;
+}
+void launch_shard_ranges(hipStream_t s, const int64_t* hi_dev, int64_t P_local, int world, int64_t* ranges_dev) {
+  hipLaunchKernelGGL(k_shard_ranges, dim3((world + 63) / 64), dim3(64), 0, s, hi_dev, P_local, world, ranges_dev);
+}
+
+// Records of the contiguous local particles [j0, j0 + n) for one destination; the header
+// carries the destination slots [lo, hi) each copy fills (empty for particles without
+// offspring there: they ride along, the receiver skips them).
+__global__ void __launch_bounds__(256) k_pack_range(SlotSource ss, const int32_t* __restrict__ src,
+                                                    const double* __restrict__ x, const double* __restrict__ y,
+                                                    const double* __restrict__ h, const double* __restrict__ lw,
+                                                    const int64_t* __restrict__ hi, int64_t j0, int64_t slot_start,
+                                                    int64_t slot_end, unsigned char* __restrict__ buf) {
+  const int64_t i = blockIdx.x;
+  const int64_t j = j0 + i;
+  unsigned char* rec = buf + (size_t)i * (kPoseRecordBytes + ss.slot_bytes);
+  if (threadIdx.x == 0) {
+    double* hd = reinterpret_cast<double*>(rec);
+    hd[0] = x[j];
+    hd[1] = y[j];
+    hd[2] = h[j];
+    hd[3] = lw[j];
+    int64_t lo = hi[j] > slot_start ? hi[j] : slot_start;
+    int64_t up = hi[j + 1] < slot_end ? hi[j + 1] : slot_end;
+    if (up < lo) up = lo;
+    reinterpret_cast<int64_t*>(rec)[4] = lo;
+    reinterpret_cast<int64_t*>(rec)[5] = up;
+  }
+  const uint4* s = reinterpret_cast<const uint4*>(ss.at(src[j]));
+  uint4* d = reinterpret_cast<uint4*>(rec + kPoseRecordBytes);
+  const size_t n = ss.slot_bytes / 16;
+  for (size_t k = threadIdx.x; k < n; k += blockDim.x) d[k] = s[k];
+}
+void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t j0, int64_t n, int64_t slot_start,
+                       int64_t slot_end, unsigned char* buf_dev) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_pack_range, dim3((unsigned)n), dim3(256), 0, s, slot_source(d), d.src[d.cur], d.x[d.cur],
+                     d.y[d.cur], d.h[d.cur], d.logw[d.cur], hi_dev, j0, slot_start, slot_end, buf_dev);
+}
+
+__global__ void __launch_bounds__(256) k_extract_lohi(const unsigned char* __restrict__ buf, size_t stride, int64_t n,
+                                                      int64_t* __restrict__ rlohi) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t* hd = reinterpret_cast<const int64_t*>(buf + (size_t)r * stride);
+  rlohi[2 * r] = hd[4];
+  rlohi[2 * r + 1] = hd[5];
+}
+
+// New generation from the device-side plan: local slot k (global slot K) takes the local
+// particle j with hi[j] <= K < hi[j + 1] if K lies in this shard's offspring range, else the
+// received record whose [lo, hi) holds K (records arrive in slot order).
+__global__ void __launch_bounds__(256) k_adopt_dev(const double* __restrict__ x, const double* __restrict__ y,
+                                                   const double* __restrict__ h, const double* __restrict__ lw,
+                                                   const int32_t* __restrict__ src, double* __restrict__ x2,
+                                                   double* __restrict__ y2, double* __restrict__ h2,
+                                                   double* __restrict__ lw2, int32_t* __restrict__ src2,
+                                                   const int64_t* __restrict__ hi, int64_t slot_start,
+                                                   const unsigned char* __restrict__ buf, size_t stride,
+                                                   const int64_t* __restrict__ rlohi, int64_t n_recv, int64_t P) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const int64_t K = slot_start + k;
+  if (K >= hi[0] && K < hi[P]) {
+    int64_t lo = 0, up = P - 1;  // first j with hi[j + 1] > K
+    while (lo < up) {
+      const int64_t mid = (lo + up) >> 1;
+      if (hi[mid + 1] > K)
+        up = mid;
+      else
+        lo = mid + 1;
+    }
+    x2[k] = x[lo];
+    y2[k] = y[lo];
+    h2[k] = h[lo];
+    lw2[k] = lw[lo];
+    src2[k] = src[lo];
+  } else {
+    int64_t lo = 0, up = n_recv - 1;  // first record with hi_r > K
+    while (lo < up) {
+      const int64_t mid = (lo + up) >> 1;
+      if (rlohi[2 * mid + 1] > K)
+        up = mid;
+      else
+        lo = mid + 1;
+    }
+    const double* hd = reinterpret_cast<const double*>(buf + (size_t)lo * stride);
+    x2[k] = hd[0];
+    y2[k] = hd[1];
+    h2[k] = hd[2];
+    lw2[k] = hd[3];
+    src2[k] = (int32_t)(-(lo + 1));
+  }
+}
+void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
+                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev) {
+  if (d.P == 0) return;
+  const int c = d.cur, n = c ^ 1;
+  const size_t stride = kPoseRecordBytes + d.lay.slot_bytes;
+  if (n_recv > 0)
+    hipLaunchKernelGGL(k_extract_lohi, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, buf_dev, stride, n_recv,
+                       rlohi_dev);
+  hipLaunchKernelGGL(k_adopt_dev, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
+                     d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], hi_dev, slot_start, buf_dev,
+                     stride, rlohi_dev, n_recv, d.P);
+  d.cur = n;
+  d.alt = n_recv > 0 ? buf_dev : nullptr;
+  d.alt_stride = stride;
+  d.alt_off = kPoseRecordBytes;
+}
+
+}  // namespace pk

@@ -1,4 +1,4 @@
-// Host-visible launchers of the gfx950 kernels (defined in pk_kernels.hip).
+// Host-visible launchers of the gfx950 kernels (defined in pk_k_motion / pk_k_assoc / pk_k_observe / pk_k_resample .hip).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -26,7 +26,3 @@ tot = v[0] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9]
 for i, n in enumerate(names):
     print("%-18s %12.4g  %5.1f%%" % (n, v[i], 100 * v[i] / tot))
 
-names2 = ["F load+init+sync", "F prepare", "F barrier", "F winners+sync", "F apply", "F store+reduce"]
-tot2 = v[10:16].sum()
-for i, n in enumerate(names2):
-    print("%-18s %12.4g  %5.1f%%" % (n, v[10 + i], 100 * v[10 + i] / max(tot2, 1)))
