@@ -1,0 +1,89 @@
+"""GPU: error behaviour and degenerate sizes of the C ABI (status codes instead of the Python
+exceptions of the reference; nothing crosses the boundary silently)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_call_order_and_argument_errors(lib):
+    f = lib.DeviceFilter(16, 3)
+    blobs = np.array([[0.1, 1, 2, 3.0]])
+    with pytest.raises(lib.PkError) as e:
+        f.observe(blobs)
+    assert e.value.status == lib.PK_ERR_STATE  # no map yet
+    means = np.array([[5.0, 0, 1, 2, 3], [0, 5.0, 100, 2, 3], [-5.0, 0, 1, 200, 3]])
+    covs = np.broadcast_to(0.25 * np.identity(5), (3, 5, 5)).copy()
+    f.upload_map(means, covs.reshape(3, 25))
+    with pytest.raises(lib.PkError) as e:
+        f.observe(blobs, ids=[4])
+    assert e.value.status == lib.PK_ERR_INVALID  # id beyond L
+    with pytest.raises(lib.PkError) as e:
+        f.observe(np.array([[np.nan, 1, 2, 3.0]]))
+    assert e.value.status == lib.PK_ERR_INVALID
+    with pytest.raises(lib.PkError) as e:
+        f.resample(1.0)
+    assert e.value.status == lib.PK_ERR_INVALID  # u must be in [0, 1)
+    bad = covs.copy()
+    bad[1, 0, 1] = 0.1  # asymmetric
+    with pytest.raises(lib.PkError) as e:
+        f.upload_map(means, bad.reshape(3, 25))
+    assert e.value.status == lib.PK_ERR_UNSUPPORTED
+    Qt = 0.1 * np.identity(4)
+    Qt[0, 2] = Qt[2, 0] = 0.01  # bearing-colour coupling
+    with pytest.raises(lib.PkError) as e:
+        f.set_measurement_noise(Qt)
+    assert e.value.status == lib.PK_ERR_UNSUPPORTED
+    poses = np.zeros((16, 4))
+    poses[3, 3] = -1.0
+    with pytest.raises(lib.PkError):
+        f.upload_poses(poses)
+    # the handle is still usable after every refused call
+    f.observe(blobs)
+    assert np.isfinite(f.download_poses()).all()
+    f.close()
+    with pytest.raises(lib.PkError):
+        lib.DeviceFilter(0, 3)
+    with pytest.raises(lib.PkError):
+        lib.DeviceFilter(4, 3, device=99)
+
+
+def test_filter_without_landmarks(lib):
+    # FastSLAM() with no preset features (prkt_core_v2.py:38): every blob is unseen -> weight *= 0.1 each (:94-95)
+    f = lib.DeviceFilter(32, 0)
+    blobs = np.array([[0.1, 1, 2, 3.0], [1.0, 4, 5, 6.0], [-2.0, 7, 8, 9.0]])
+    ids = f.observe(blobs, return_ids=True)
+    assert ids.shape == (32, 3) and not ids.any()
+    assert np.allclose(f.download_poses()[:, 3], 1e-3, rtol=1e-13)
+    anc = f.resample(0.25, return_ancestors=True)
+    assert np.array_equal(anc, np.arange(32))
+    assert f.summary() == (0.0, 0.0, 0.0)
+    f.close()
+
+
+def test_single_particle_single_landmark(lib):
+    f = lib.DeviceFilter(1, 1)
+    f.upload_map(np.array([[4.0, 3.0, 10, 20, 30]]), 0.25 * np.identity(5).reshape(1, 25))
+    f.step(0.2, 0.1, 0.1, np.array([[np.arctan2(3, 4), 10, 20, 30.0]]), 0.99, z=np.zeros((1, 3)))
+    m, c, k = f.download_landmarks()
+    assert k[0, 0] == 2 and np.all(np.diag(c[0, 0]) < 0.25)
+    f.close()
+
+
+def test_many_blobs_few_landmarks_and_odd_counts(lib):
+    from oracle.fastslam_oracle import OracleFilter
+
+    rs = np.random.RandomState(0)
+    L, B, P = 3, 700, 9  # odd L (padded slot), B >> L, P not a multiple of anything
+    means = np.column_stack([rs.uniform(-10, 10, (L, 2)), rs.uniform(0, 255, (L, 3))])
+    covs = np.broadcast_to(0.25 * np.identity(5), (L, 5, 5)).copy()
+    blobs = np.column_stack([rs.uniform(-3, 3, B), rs.uniform(0, 255, (B, 3))])
+    own = np.column_stack([np.arctan2(means[:, 1], means[:, 0]), means[:, 2:]])
+    blobs[[5, 300, 699]] = own
+    f = lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    ids = f.observe(blobs, return_ids=True)
+    o = OracleFilter(P, means, covs)
+    assert np.array_equal(ids, o.observe(blobs))
+    assert np.allclose(f.download_poses()[:, 3], o.weights(), rtol=1e-9, atol=0)
+    f.close()
