@@ -1165,7 +1165,10 @@ int pk_shard_max_logw_dev(pk_filter* f, double* dev_out) {
   int rc;
   if ((rc = use_device(f))) return rc;
   Span t(f, PK_T_WEIGHTS);
-  launch_block_max(f->stream, f->d, f->partial, dev_out);
+  if (f->gmax_fused)
+    launch_keys_max(f->stream, ctl_gmax_key(f), dev_out);  // the observe kernels kept the running max
+  else
+    launch_block_max(f->stream, f->d, f->partial, dev_out);
   return PK_OK;
 }
 

@@ -24,6 +24,17 @@ __global__ void __launch_bounds__(256) k_final_max(const double* __restrict__ pa
   m = block_max<4>(m, red);
   if (threadIdx.x == 0) out[0] = m;
 }
+// max over the sharded running-max keys the observe kernels kept (kGmaxKeys == blockDim.x)
+__global__ void __launch_bounds__(256) k_keys_max(const unsigned long long* __restrict__ keys,
+                                                  double* __restrict__ out) {
+  __shared__ double red[4];
+  const double m = block_max<4>(key_to_double(keys[threadIdx.x]), red);
+  if (threadIdx.x == 0) out[0] = m;
+}
+void launch_keys_max(hipStream_t s, const unsigned long long* keys_dev, double* gmax_dev) {
+  hipLaunchKernelGGL(k_keys_max, dim3(1), dim3(kGmaxKeys), 0, s, keys_dev, gmax_dev);
+}
+
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev) {
   int nb = (int)((d.P + 255) / 256);
   if (nb > kRedBlocks) nb = kRedBlocks;

@@ -114,6 +114,7 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
 extern int g_observe_nv;
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);
+void launch_keys_max(hipStream_t s, const unsigned long long* keys_dev, double* gmax_dev);
 void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, int domain,
                        double* clocal_dev, double* totals_dev, const unsigned long long* gmax_key_dev = nullptr);
 // exclusive scan of the (global) block totals, sequential in block order: offsets[nb], sum[1]
