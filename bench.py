@@ -55,6 +55,10 @@ def synthetic_inputs(L, steps, v=0.2, w=0.1, dt=0.1):
     phi = -math.pi + 2.0 * math.pi * np.arange(L) / float(L) + 0.01
     rho = rs.uniform(8.0, 30.0, size=L)
     col = rs.uniform(0.0, 255.0, size=(L, 3))
+    if os.environ.get("PK_BENCH_LATTICE"):  # experiment: colours on a lattice, no blob passes two landmarks' gates
+        n = int(math.ceil(L ** (1.0 / 3.0)))
+        idx = np.arange(L)
+        col = np.stack([idx % n, (idx // n) % n, idx // (n * n)], axis=1) * (255.0 / max(n - 1, 1))
     means = np.empty((L, 5))
     means[:, 0] = rho * np.cos(phi)
     means[:, 1] = rho * np.sin(phi)
@@ -73,37 +77,97 @@ def synthetic_inputs(L, steps, v=0.2, w=0.1, dt=0.1):
     return means, covs, scans
 
 
-def cpu_baseline(L, budget_s=20.0):
-    """NumPy oracle ("port" of the reference step, validated against the reference in
-    tests/) timed on a bounded particle sample of the same workload, 1 host thread."""
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def _cpu_run(job):
+    """One oracle filter of Ps particles stepped nsteps times; returns its wall time."""
     from oracle.fastslam_oracle import OracleFilter
 
-    means, covs, scans = synthetic_inputs(L, 4)
-    rs = np.random.RandomState(7)
-    rnd = random.Random(7)
+    try:  # one thread per process, whatever BLAS/OpenMP pools NumPy was built with
+        from threadpoolctl import threadpool_limits
 
-    def run(Ps, nsteps):
-        f = OracleFilter(Ps, means, covs)
-        t0 = time.perf_counter()
-        for s in range(nsteps):
-            f.step(0.2, 0.1, 0.1, rs.standard_normal((Ps, 3)), scans[s], rnd.random())
-        return time.perf_counter() - t0
+        threadpool_limits(1)
+    except Exception:
+        pass
+    L, Ps, nsteps, seed = job
+    means, covs, scans = synthetic_inputs(L, nsteps)
+    rs = np.random.RandomState(seed)
+    rnd = random.Random(seed)
+    f = OracleFilter(Ps, means, covs)
+    t0 = time.perf_counter()
+    for s in range(nsteps):
+        f.step(0.2, 0.1, 0.1, rs.standard_normal((Ps, 3)), scans[s], rnd.random())
+    return time.perf_counter() - t0
 
-    probe_p = 2
-    t = run(probe_p, 1)
-    per_particle_step = t / probe_p
+
+def cpu_baseline(L, budget_s=20.0):
+    """NumPy oracle ("port" of the reference step, validated against the reference in tests/)
+    timed on a bounded particle sample of the same workload: first on ONE host thread, then on
+    every host core with the sample's particles split over a fork()ed process pool (particles
+    are independent until the weight sum).  Must run BEFORE the GPU is initialised
+    (fork).  `value` is the all-core figure; the 1-thread figure rides along."""
+    import multiprocessing as mp
+
+    cores = min(usable_cores(), 64)
     nsteps = 2
-    Ps = int(max(2, min(4096, budget_s / (per_particle_step * nsteps))))
-    t = run(Ps, nsteps)
-    return {
-        "value": Ps * L * nsteps / t,
+    half = budget_s / 2.0
+    Ps = 4
+    t1 = _cpu_run((L, Ps, nsteps, 7))
+    while t1 < half / 1.5 and Ps < 4096:  # the oracle vectorises over particles: grow until the sample fills the budget
+        Ps = int(min(4096, max(Ps + 1, Ps * min(8.0, 0.8 * half / t1))))
+        t1 = _cpu_run((L, Ps, nsteps, 7))
+    single = Ps * L * nsteps / t1
+    out = {
+        "value": single,
         "unit": "particle*landmark EKF updates/s",
         "cores": 1,
         "kind": "port",
-        "steps_per_s": nsteps / t,
+        "steps_per_s": nsteps / t1,
+        "single_thread_value": single,
         "sample": "%d particles x %d landmarks x %d blobs, %d full steps (ML association), NumPy oracle, "
-        "%.1f s on 1 of %d host cores" % (Ps, L, L, nsteps, t, os.cpu_count() or 1),
+        "%.1f s on 1 of %d host cores" % (Ps, L, L, nsteps, t1, os.cpu_count() or 1),
     }
+    if cores > 1:
+        try:
+            with mp.get_context("fork").Pool(cores) as pool:
+                # page the workers in; a pool that is much slower than one thread alone (cores
+                # fewer than reported) times out and leaves the 1-thread figure
+                pool.map_async(_cpu_run, [(L, 2, 1, 7)] * cores).get(timeout=60)
+                t0 = time.perf_counter()
+                pool.map_async(_cpu_run, [(L, Ps, nsteps, 7 + i) for i in range(cores)],
+                               chunksize=1).get(timeout=max(30.0, 6.0 * t1))
+                tw = time.perf_counter() - t0
+            out.update({
+                "value": cores * Ps * L * nsteps / tw,
+                "cores": cores,
+                "steps_per_s": nsteps / tw,
+                "sample": "%d particles (%d per process x %d processes) x %d landmarks x %d blobs, %d full steps "
+                "(ML association), NumPy oracle, %.1f s wall on all %d host cores; one thread alone: %.3g updates/s "
+                "(%d particles, %.1f s)" % (cores * Ps, Ps, cores, L, L, nsteps, tw, cores, single, Ps, t1),
+            })
+        except Exception as e:  # a pool that cannot start leaves the 1-thread figure
+            out["pool_error"] = repr(e)
+    return out
 
 
 def main():
@@ -132,6 +196,13 @@ def main():
 
     import torch
 
+    if torch.cuda.device_count() == 0:  # does not initialise the GPU
+        raise SystemExit("bench.py needs a GPU: the particle update has no CPU fallback")
+    # CPU baseline first: it fork()s a process pool, which must happen before any HIP call.
+    # Rank 0 at N=1 only (the other ranks would just wait on it).
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.landmarks, args.cpu_budget)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the particle update has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -198,6 +269,24 @@ def main():
     tm["assoc"] = filt.timings()["assoc"]
     filt.enable_timing(0)
 
+    # what a plain device-to-device copy reaches on THIS box (read + write bytes / time), outside the
+    # timed region: the practical ceiling next to the 8 TB/s vendor figure
+    copy_gbs = None
+    if rank == 0:
+        n = 1 << 27  # 2 x 1 GiB of float64
+        a = torch.empty(n, dtype=torch.float64, device="cuda").normal_()
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * 8 * n * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+
     if world > 1:
         import torch.distributed as dist
 
@@ -251,6 +340,8 @@ def main():
                 "traffic": measured_traffic(P, L, "observe_known" if args.assoc == "known" else "observe_ml"),
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH + WRITE)*1024, "
                 "see profiles/*/pmc_traffic.json",
+                "copy_measured": copy_gbs,
+                "frac_of_copy": achieved / copy_gbs if copy_gbs else None,
                 "avg_launch_ms": obs_avg_s * 1e3,
                 "launches": obs_n,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -258,8 +349,8 @@ def main():
             "kernel_ms_per_step": {"observe": obs_ms / max(obs_n, 1), "assoc": assoc_ms / max(assoc_n, 1)},
             "summary": list(summary),
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, args.cpu_budget)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -256,33 +256,48 @@ struct FastArgs {
 struct FastSlot {
   int t;                    // blob (cell order) or -1
   int b;                    // its scan index
+  int q;                    // entry of the probability queue holding this slot's value, or -1
   unsigned long long bits;  // contested candidate: probability bits (0: not positive)
   unsigned flags;           // bit 0 contested, bit 1 apply the update, bit 2 unmatched (single, probability 0)
 };
 
-// What probability_of_match needs from the landmark alone, computed once per landmark instead
-// of once per blob: determinant / inverse of the 2x2 position block and of the 3x3 colour block.
-struct FastLm {
-  double det2, idet2, det3;
-  Sym3<double> inv3;
+// probability_of_match (:439-455) from the two Mahalanobis terms and determinants
+__device__ __forceinline__ double pr_from_parts(double det2, double det3, double maha2, double maha3) {
+  const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + log(det2) + maha2));  // :439
+  const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + log(det3) + maha3));  // :446
+  return bp * cp / 250000.0;                                                                      // :455
+}
+
+// The few (landmark, blob) pairs whose probability VALUE is needed -- contested blobs, and pairs
+// too close to the float64 underflow edge to call positive without evaluating -- are queued in
+// LDS and evaluated densely by the first lanes of the workgroup (two log + two exp each), instead
+// of dragging every wave through that code for a handful of its lanes.
+constexpr int kFastQueue = 512;
+struct FastQueue {
+  double* det2;   // [kFastQueue]
+  double* det3;
+  double* maha2;  // overwritten with the probability bits by the evaluation pass
+  double* maha3;
+  int* meta;      // blob t | contested << 16
+  int* n;         // entries pushed (may exceed kFastQueue: the excess is evaluated in place)
 };
+__host__ __device__ inline size_t fast_queue_bytes() { return (size_t)kFastQueue * (4 * 8 + 4) + 16; }
 
 __device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<double>& lm, double sx, double sy,
                                              double pse, uint2 packed, const unsigned char* bc,
-                                             unsigned long long* best, FastSlot (&sl)[kFastSlots]) {
-  FastLm q;
-  q.det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
-  q.idet2 = 1.0 / q.det2;
-  q.inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, q.det3);
-  const bool dets_sane = q.det2 > 0.0 && q.det2 < 1e60 && q.det3 > 0.0 && q.det3 < 1e60;
-  double ldet2 = 0.0, ldet3 = 0.0;  // log determinants, evaluated once per landmark on first use
-  bool have_logs = false;
+                                             unsigned long long* best, const FastQueue& fq,
+                                             FastSlot (&sl)[kFastSlots]) {
+  const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+  double det3;
+  const Sym3<double> inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+  const bool dets_sane = det2 > 0.0 && det2 < 1e60 && det3 > 0.0 && det3 < 1e60;
   const unsigned w[2] = {packed.x, packed.y};
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
     const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
     sl[k].t = t == 0xFFFF ? -1 : t;
     sl[k].b = INT_MAX;
+    sl[k].q = -1;
     sl[k].bits = 0ull;
     sl[k].flags = 0u;
     if (sl[k].t < 0) continue;
@@ -291,39 +306,83 @@ __device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<d
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
     const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
-    // the quantities both branches need (prob_position_match :457-494, prob_color_match :524-544)
+    // prob_position_match :457-494, prob_color_match :524-544
     const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
     double nx, ny;
     closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
     const double ex = nx - lm.mx, ey = ny - lm.my;
-    const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / q.det2;
-    const double maha3 = sym3_quad(q.inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+    const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / det2;
+    const double maha3 = sym3_quad(inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
     const bool contested = bc[t] >= 2;
     // pr = (500 exp(a1)) (500 exp(a2)) / 250000 is certainly > 0 when a1 + a2 is far from the
     // float64 underflow edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 here
     const bool surely_positive = angle_ok && dets_sane && maha2 >= 0.0 && maha3 >= 0.0 && maha2 + maha3 < 800.0;
-    double pr = 0.0;
-    if (contested || (angle_ok && !surely_positive)) {
-      if (angle_ok) {
-        if (!have_logs) {
-          ldet2 = log(q.det2);
-          ldet3 = log(q.det3);
-          have_logs = true;
+    if (contested) sl[k].flags = 1u;
+    if (!angle_ok) {  // bp = 0 (:475): probability 0
+      if (!contested) sl[k].flags = 4u;
+      continue;
+    }
+    if (!contested && surely_positive) {
+      sl[k].flags = 2u;
+      continue;
+    }
+    const int qi = atomicAdd(fq.n, 1);
+    if (qi < kFastQueue) {
+      fq.det2[qi] = det2;
+      fq.det3[qi] = det3;
+      fq.maha2[qi] = maha2;
+      fq.maha3[qi] = maha3;
+      fq.meta[qi] = t | (contested ? 0x10000 : 0);
+      sl[k].q = qi;
+    } else {  // queue full (dense clusters of look-alike landmarks): evaluate in place
+      // (opaque copies: keeps the compiler from hoisting the two log() out of this rare branch
+      // into the code every lane runs)
+      double d2 = det2, d3 = det3;
+      asm volatile("" : "+v"(d2), "+v"(d3));
+      const double pr = pr_from_parts(d2, d3, maha2, maha3);
+      if (contested) {
+        if (pr > 0.0) {
+          sl[k].bits = (unsigned long long)__double_as_longlong(pr);
+          atomicMax(&best[t], sl[k].bits);
         }
-        const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + ldet2 + maha2));  // :439
-        const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + ldet3 + maha3));  // :446
-        pr = bp * cp / 250000.0;                                                                 // :455
+      } else {
+        sl[k].flags = pr > 0.0 ? 2u : 4u;
       }
     }
-    if (contested) {
-      sl[k].flags = 1u;
-      if (pr > 0.0) {
-        sl[k].bits = (unsigned long long)__double_as_longlong(pr);
-        atomicMax(&best[t], sl[k].bits);
-      }
-    } else {
-      sl[k].flags = (surely_positive || pr > 0.0) ? 2u : 4u;
+  }
+}
+
+// Dense evaluation of the queued probabilities, lanes over queue entries.
+__device__ __forceinline__ void fast_evaluate_queue(const FastQueue& fq, unsigned long long* best, int tid,
+                                                    int nthreads) {
+  const int n = min(*fq.n, kFastQueue);
+  // entries dealt round-robin to the first four waves (one per SIMD): the pass is a serial
+  // section of the workgroup, so its latency counts, not its lane efficiency
+  if (tid >= 256) return;
+  for (int i = ((tid & 63) << 2) + (tid >> 6); i < n; i += 256) {
+    const double pr = pr_from_parts(fq.det2[i], fq.det3[i], fq.maha2[i], fq.maha3[i]);
+    const unsigned long long bits = pr > 0.0 ? (unsigned long long)__double_as_longlong(pr) : 0ull;
+    reinterpret_cast<unsigned long long*>(fq.maha2)[i] = bits;
+    const int m = fq.meta[i];
+    if ((m & 0x10000) && bits != 0ull) atomicMax(&best[m & 0xFFFF], bits);
+  }
+}
+
+// Read the queued results back into the owner's slots; contested candidates that attain the
+// blob's best probability bid for it with their landmark index (earliest wins, :377).
+__device__ __forceinline__ void fast_collect(const FastQueue& fq, const unsigned long long* best, int* win, int l,
+                                             FastSlot (&sl)[kFastSlots]) {
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].t < 0) continue;
+    if (sl[k].q >= 0) {
+      const unsigned long long bits = reinterpret_cast<const unsigned long long*>(fq.maha2)[sl[k].q];
+      if (sl[k].flags & 1u)
+        sl[k].bits = bits;
+      else
+        sl[k].flags = bits != 0ull ? 2u : 4u;
     }
+    if ((sl[k].flags & 1u) && sl[k].bits != 0ull && sl[k].bits == best[sl[k].t]) atomicMin(&win[sl[k].t], l);
   }
 }
 
@@ -375,7 +434,14 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   if (a.pflag[p]) return;  // workgroup-uniform: the general kernel takes this particle
   const int tid = threadIdx.x;
   const int B = a.B, Lp = a.Lp;
-  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem);
+  FastQueue fq;
+  fq.det2 = reinterpret_cast<double*>(smem);
+  fq.det3 = fq.det2 + kFastQueue;
+  fq.maha2 = fq.det3 + kFastQueue;
+  fq.maha3 = fq.maha2 + kFastQueue;
+  fq.meta = reinterpret_cast<int*>(fq.maha3 + kFastQueue);
+  fq.n = fq.meta + kFastQueue;
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + fast_queue_bytes());
   int* win = reinterpret_cast<int*>(best + B);
   unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
   const unsigned char* sslot = a.ss.at(a.src[p]);
@@ -390,25 +456,27 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   Landmark<double> A{};
   uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
   if (active) {
+    lp = a.lmpass[(size_t)p * Lp + l];  // first: the blob records it points to are the next dependent loads
     A = load_landmark(sf, sc, Lp, l);
-    lp = a.lmpass[(size_t)p * Lp + l];
   }
   for (int t = tid; t < B; t += kFastThreads) {
     best[t] = 0ull;
     win[t] = INT_MAX;
     bc[t] = a.bcount[(size_t)p * B + t];
   }
+  if (tid == 0) *fq.n = 0;
   __syncthreads();
   int nun = 0;  // blobs no landmark passes
   for (int t = tid; t < B; t += kFastThreads) nun += bc[t] == 0;
   FastSlot sa[kFastSlots];
   // atan2(my - sy, mx - sx) of the untouched state, handed over by the association kernel
   const double pseA = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
-  fast_prepare(a, A, sx, sy, pseA, has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, sa);
+  fast_prepare(a, A, sx, sy, pseA, has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, fq,
+               sa);
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kFastSlots; ++k)
-    if (sa[k].t >= 0 && sa[k].bits != 0ull && sa[k].bits == best[sa[k].t]) atomicMin(&win[sa[k].t], l);
+  fast_evaluate_queue(fq, best, tid, kFastThreads);
+  __syncthreads();
+  fast_collect(fq, best, win, l, sa);
   __syncthreads();
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
@@ -463,7 +531,7 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
   a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
-  const size_t lds = (size_t)B * 13 + 16;
+  const size_t lds = fast_queue_bytes() + (size_t)B * 13 + 16;
   hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
 }
 

@@ -1,0 +1,14 @@
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+nproc; python -c "import os;print(os.cpu_count(), len(os.sched_getaffinity(0)))"; cat /sys/fs/cgroup/cpu.max 2>/dev/null
+timeout 900 python -m pytest tests/test_gpu_assoc.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+timeout 300 python bench.py --steps 50 --warmup 5 > gpurun_out/b_single.json 2> gpurun_out/b1.err; tail -2 gpurun_out/b1.err
+PK_BENCH_LATTICE=1 timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/b_lattice.json 2> gpurun_out/b.err; tail -2 gpurun_out/b.err
+python - <<'PY'
+import json,glob
+for n in ['gpurun_out/b_single.json','gpurun_out/b_lattice.json']:
+    try:
+        d=json.load(open(n))
+        print(n, 'ms/step', round(d['ms_per_step'],3), 'value %.3g'%d['value'], {k: round(v,4) for k,v in d['kernel_ms_per_step'].items()}, 'frac', round(d['roofline']['frac'],3), 'copy', d['roofline'].get('copy_measured'), d.get('cpu_baseline',{}))
+    except Exception as e: print(n, 'ERR', e, open(n).read()[:300])
+PY

@@ -224,6 +224,19 @@ def test_fast_observe_contested_and_ties(lib):
     check_fast(lib, 64, means, covs, rand_poses(rs, 64, 0.1), blobs)
 
 
+def test_fast_observe_more_contested_pairs_than_the_probability_queue_holds(lib):
+    # every landmark exists twice and the copies' covariances differ, so each blob is contested by
+    # two landmarks: 2 x 500 queued probabilities > the 512-entry LDS queue of k_observe_fast;
+    # the excess is evaluated in place and must give the same winners
+    rs = np.random.RandomState(9)
+    base, bcov = synthetic_world(250)
+    means = np.vstack([base, base])
+    covs = np.vstack([bcov, bcov * rs.uniform(0.5, 2.0, (250, 1, 1))])
+    means[250:, :2] += rs.normal(0, 0.05, (250, 2))
+    blobs = synthetic_scan(base, (0.01, 0.0, 0.0))
+    check_fast(lib, 24, means, covs, rand_poses(rs, 24, 0.1), blobs)
+
+
 def test_fast_observe_flagged_particles_take_the_general_route(lib):
     # ten blobs on one landmark: more than two gate-passing blobs for it -> particle flagged
     rs = np.random.RandomState(6)
