@@ -93,8 +93,10 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "assoc_kernel" = 0 (colour-grid association kernel, default) or 1 (brute-force reference
  *                    kernel that gate-tests every landmark x blob pair);
  *   "assoc_dup"    = 1 (default: 9x column-duplicated blob index list when it fits in LDS) or 0;
- *   "fast_observe" = 1 (default: for L <= 512 contested associations are settled inside the
- *                    EKF kernel with the landmark state in registers) or 0 (general path);
+ *   "fast_observe" = 1 (default: contested associations are settled inside the EKF kernel --
+ *                    k_observe_fast with the landmark state in registers for L <= 512,
+ *                    k_observe_sweep in two sweeps over landmark chunks above that), 0 (general
+ *                    path: association kernel writes ids) or 2 (k_observe_sweep for every L);
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
 int pk_set_option(pk_filter* f, const char* name, int64_t value);
 

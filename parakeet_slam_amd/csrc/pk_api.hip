@@ -81,7 +81,9 @@ struct pk_filter {
   int64_t rlohi_cap = 0;
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
-  int fast_observe = 1;  // L <= 512: association hand-off + k_observe_fast
+  int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
+  uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
+  size_t sweep_cap = 0;
   FastHandoff fh{};      // device buffers of the hand-off
   int64_t fh_cap_l = 0, fh_cap_b = 0;
   // pinned host staging ring for the per-scan uploads (blobs, ray directions, chains):
@@ -470,7 +472,8 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   }
   if (use_grid) {
     FastHandoff fh{};
-    if (want_fast && !finalize && f->fast_observe && f->d.lay.L <= kFastMaxL && B > 0) {
+    const bool sweep = f->d.lay.L > kFastMaxL || f->fast_observe == 2;
+    if (want_fast && !finalize && f->fast_observe && B > 0 && (!sweep || observe_sweep_plan(f->d, B).grid > 0)) {
       if ((rc = ensure_handoff(f, B))) return rc;
       fh = f->fh;
       fh.n_flagged = ctl_n_flagged(f);
@@ -626,7 +629,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -920,7 +923,21 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     if (al.fast) {
       ObserveExtras e1 = ex;
       e1.flip = false;
-      launch_observe_fast(f->stream, f->d, B, al.exact, al.order, f->fh, f->qt, e1);
+      if (f->d.lay.L > kFastMaxL || f->fast_observe == 2) {
+        const SweepPlan plan = observe_sweep_plan(f->d, B);
+        const size_t need = (size_t)plan.grid * plan.results_per_wg;
+        if (need > f->sweep_cap) {
+          PK_HIP(hipStreamSynchronize(f->stream));
+          if (f->sweep_results) (void)hipFree(f->sweep_results);
+          f->sweep_results = nullptr;
+          f->sweep_cap = 0;
+          if ((rc = dev_alloc(f, &f->sweep_results, need))) return rc;
+          f->sweep_cap = need;
+        }
+        launch_observe_sweep(f->stream, f->d, B, al.exact, al.order, f->fh, f->qt, e1, plan, f->sweep_results);
+      } else {
+        launch_observe_fast(f->stream, f->d, B, al.exact, al.order, f->fh, f->qt, e1);
+      }
       ObserveExtras e2 = ex;
       e2.only_flagged = f->fh.pflag;
       e2.n_flagged = ctl_n_flagged(f);
@@ -965,7 +982,8 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     return PK_OK;
   }
   if (!strcmp(name, "fast_observe")) {
-    f->fast_observe = value != 0;
+    if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "fast_observe: 0 (general kernels), 1 (default) or 2 (always the sweep kernel)");
+    f->fast_observe = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "assoc_dup")) {

@@ -535,6 +535,343 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
   hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
 }
 
+// ------------------------------------------------------------------ K3 (sweep ML variant, any L)
+// The same hand-off as k_observe_fast, for maps that do not fit one landmark per lane: persistent
+// workgroups, each particle's landmarks in chunks of kSweepThreads, two sweeps.
+//   sweep 1 (read only): landmarks that pass a CONTESTED blob (one that several landmarks pass)
+//     load their state and queue the pair's probability inputs in LDS; the queue is evaluated
+//     densely (two log + two exp per pair), atomicMax of the probability bits per blob in LDS,
+//     and every positive (blob, landmark, probability) goes to a result list (per-workgroup
+//     scratch in global memory, L2 resident).  After the last chunk the pairs that attain their
+//     blob's best probability bid with their landmark index: atomicMin -> the earliest wins (:377).
+//   sweep 2: every landmark again (the second read comes from L2 / Infinity Cache: one
+//     particle's map is <= a few hundred KB), uncontested blobs settled by the strict '>' from 0.0
+//     as in k_observe_fast, contested ones applied by their winner, updates in scan order (:88),
+//     coalesced store of all 14 rows into the other map buffer.
+// A particle the association kernel flagged (a landmark passing more than kFastSlots blobs) is
+// skipped here and taken by the general kernels.
+constexpr int kSweepThreads = 256;  // 3 workgroups per CU at <= 168 VGPRs
+
+struct SweepArgs {
+  SlotSource ss;
+  unsigned char* map_dst;
+  size_t count_off;
+  int32_t* src;
+  const double *x, *y;
+  double* logw;
+  const double* exact;          // [B][6] cell order: bearing, r, g, b, ux, uy
+  const unsigned short* order;  // [B] cell order -> scan order
+  const uint4* lmpass;
+  const unsigned char* bcount;
+  const unsigned char* pflag;
+  const unsigned char* immutable;
+  uint4* results;               // [gridDim.x][4 * Lp]: probability bits (lo, hi), blob t, landmark l
+  int64_t P;
+  int L, Lp, B;
+  int qcap;                     // entries of the LDS probability queue
+  int reset;
+  unsigned long long* gmax_key;
+  Noise<double> qt;
+};
+
+__host__ __device__ inline size_t sweep_lds_bytes(int B, int qcap) {
+  return (size_t)qcap * 36 + 16 + (((size_t)B * 13 + 15) & ~(size_t)15);
+}
+
+SweepPlan observe_sweep_plan(const DeviceState& d, int B) {
+  SweepPlan pl{};
+  const size_t fixed = sweep_lds_bytes(B, 0);
+  // workgroups per CU: three (the register budget of the kernel) when the blob tables leave room
+  // for a queue of >= 256 entries each, else two, else one
+  int per_cu = 3;
+  size_t budget = (kMaxDynLds / 3) & ~(size_t)255;
+  if (fixed + 256 * 36 > budget) {
+    per_cu = 2;
+    budget = (kMaxDynLds / 2) & ~(size_t)255;
+  }
+  if (fixed + 256 * 36 > budget) {
+    per_cu = 1;
+    budget = kMaxDynLds;
+  }
+  if (fixed + 64 * 36 > budget) return pl;  // scan too large for the LDS tables: grid = 0
+  long q = (long)((budget - fixed) / 36);
+  q = q > 1024 ? 1024 : q;  // kSweepThreads lanes x kFastSlots
+  q &= ~63L;
+  pl.qcap = (int)q;
+  pl.lds = sweep_lds_bytes(B, pl.qcap);
+  int64_t g = 256 * (int64_t)per_cu;
+  pl.grid = (int)(g < d.P ? g : d.P);
+  pl.results_per_wg = 4 * (size_t)d.lay.Lp;
+  return pl;
+}
+
+__global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kSweepThreads / kWave];
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp, qcap = a.qcap;
+  double* q_det2 = reinterpret_cast<double*>(smem);
+  double* q_det3 = q_det2 + qcap;
+  double* q_maha2 = q_det3 + qcap;
+  double* q_maha3 = q_maha2 + qcap;
+  unsigned* q_meta = reinterpret_cast<unsigned*>(q_maha3 + qcap);  // blob t | landmark l << 16
+  int* q_n = reinterpret_cast<int*>(q_meta + qcap);                // [2] alternating per chunk, [2] = result count
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + (size_t)qcap * 36 + 16);
+  int* win = reinterpret_cast<int*>(best + B);
+  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
+  uint4* results = a.results + (size_t)blockIdx.x * 4 * (size_t)Lp;
+
+  for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
+    if (a.pflag[p]) continue;  // workgroup-uniform: the general kernels take this particle
+    const unsigned char* sslot = a.ss.at(a.src[p]);
+    unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+    const double* sf = reinterpret_cast<const double*>(sslot);
+    double* df = reinterpret_cast<double*>(dslot);
+    const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+    int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+    const double sx = a.x[p], sy = a.y[p];
+    const uint4* lmp = a.lmpass + (size_t)p * Lp;
+    for (int t = tid; t < B; t += kSweepThreads) {
+      best[t] = 0ull;
+      win[t] = INT_MAX;
+      bc[t] = a.bcount[(size_t)p * B + t];
+    }
+    if (tid < 3) q_n[tid] = 0;
+    __syncthreads();
+
+    // ---- sweep 1: probabilities of the contested pairs ------------------------------------
+    int par = 0;
+    for (int base = 0; base < a.L; base += kSweepThreads, par ^= 1) {
+      int l = base + tid;
+      asm volatile("" : "+v"(l));
+      uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+      if (l < a.L) lp = lmp[l];
+      const unsigned w[2] = {lp.x, lp.y};
+      int ct[kFastSlots];
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < kFastSlots; ++k) {
+        const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+        ct[k] = (t != 0xFFFF && bc[t] >= 2) ? t : -1;
+        any |= ct[k] >= 0;
+      }
+      if (any) {
+        const Landmark<double> lm = load_landmark_nocount(sf, Lp, l);
+        const double pse = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
+        const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+        double det3;
+        const Sym3<double> inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+#pragma unroll
+        for (int k = 0; k < kFastSlots; ++k) {
+          const int t = ct[k];
+          if (t < 0) continue;
+          const double* rec = a.exact + 6 * (size_t)t;
+          const double2 z01 = *reinterpret_cast<const double2*>(rec);
+          const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+          const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+          if (fabs(pse - z01.x) > Consts<double>::half_pi) continue;  // :473-475 -> probability 0
+          double nx, ny;
+          closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+          const double ex = nx - lm.mx, ey = ny - lm.my;
+          const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / det2;
+          const double maha3 = sym3_quad(inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+          const int qi = atomicAdd(&q_n[par], 1);
+          if (qi < qcap) {
+            q_det2[qi] = det2;
+            q_det3[qi] = det3;
+            q_maha2[qi] = maha2;
+            q_maha3[qi] = maha3;
+            q_meta[qi] = (unsigned)t | ((unsigned)l << 16);
+          } else {  // queue full: evaluate in place (opaque copies keep the logs out of the common path)
+            double d2 = det2, d3 = det3;
+            asm volatile("" : "+v"(d2), "+v"(d3));
+            const double pr = pr_from_parts(d2, d3, maha2, maha3);
+            if (pr > 0.0) {
+              const unsigned long long bits = (unsigned long long)__double_as_longlong(pr);
+              atomicMax(&best[t], bits);
+              results[atomicAdd(&q_n[2], 1)] = make_uint4((unsigned)bits, (unsigned)(bits >> 32), (unsigned)t, (unsigned)l);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one slot's temporaries at a time
+        }
+      }
+      __syncthreads();
+      const int n = min(q_n[par], qcap);
+      for (int i = tid; i < n; i += kSweepThreads) {
+        const double pr = pr_from_parts(q_det2[i], q_det3[i], q_maha2[i], q_maha3[i]);
+        if (pr > 0.0) {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(pr);
+          const unsigned m = q_meta[i];
+          atomicMax(&best[m & 0xFFFFu], bits);
+          results[atomicAdd(&q_n[2], 1)] = make_uint4((unsigned)bits, (unsigned)(bits >> 32), m & 0xFFFFu, m >> 16);
+        }
+      }
+      if (tid == 0) q_n[par ^ 1] = 0;  // the other counter: last read before the previous barrier
+      __syncthreads();
+    }
+    // the pairs that attain their blob's best probability bid with their landmark index
+    {
+      const int nres = q_n[2];
+      for (int i = tid; i < nres; i += kSweepThreads) {
+        const uint4 e = results[i];
+        const unsigned long long bits = ((unsigned long long)e.y << 32) | e.x;
+        if (bits == best[e.z]) atomicMin(&win[e.z], (int)e.w);
+      }
+    }
+    __syncthreads();
+    int nun = 0;  // blobs nobody passes, and contested blobs whose probabilities are all 0
+    for (int t = tid; t < B; t += kSweepThreads) nun += (bc[t] == 0) || (bc[t] >= 2 && best[t] == 0ull);
+    double acc = (double)nun * Consts<double>::log_no_match;
+
+    // ---- sweep 2: settle the uncontested blobs, apply, store ----------------------------------
+    for (int base = 0; base < Lp; base += kSweepThreads) {
+      int l = base + tid;
+      asm volatile("" : "+v"(l));  // opaque: no strength-reduced row pointers kept live across the chunk loop
+      if (l >= Lp) continue;
+      Landmark<double> A = load_landmark(sf, sc, Lp, l);
+      if (l < a.L) {
+        const uint4 lp = lmp[l];
+        const double pse = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
+        const unsigned w[2] = {lp.x, lp.y};
+        // per slot: scan index << 16 | blob when the update is applied, else 0xFFFFFFFF
+        unsigned key[kFastSlots];
+        bool have_inv = false;
+        double det2 = 0.0, det3 = 0.0;
+        Sym3<double> inv3{};
+#pragma unroll
+        for (int k = 0; k < kFastSlots; ++k) key[k] = 0xFFFFFFFFu;
+#pragma unroll 1
+        for (int k = 0; k < kFastSlots; ++k) {  // rolled: one copy of the settling code
+          const int t = (int)(((k < 2 ? w[0] : w[1]) >> (16 * (k & 1))) & 0xFFFFu);
+          if (t == 0xFFFF) continue;
+          bool apply;
+          if (bc[t] >= 2) {
+            apply = win[t] == l;
+          } else {
+            const double* rec = a.exact + 6 * (size_t)t;
+            const double2 z01 = *reinterpret_cast<const double2*>(rec);
+            const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+            const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+            if (!have_inv) {
+              det2 = A.pxx * A.pyy - A.pxy * A.pxy;
+              inv3 = sym3_inverse(Sym3<double>{A.crr, A.crg, A.crb, A.cgg, A.cgb, A.cbb}, det3);
+              have_inv = true;
+            }
+            apply = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
+            if (apply) {
+              double nx, ny;
+              closest_point(A.mx, A.my, sx, sy, dir.x, dir.y, nx, ny);
+              const double ex = nx - A.mx, ey = ny - A.my;
+              const double maha2 = (A.pyy * ex * ex - 2.0 * A.pxy * ex * ey + A.pxx * ey * ey) / det2;
+              const double maha3 = sym3_quad(inv3, z01.y - A.mr, z23.x - A.mg, z23.y - A.mb);
+              // pr = (500 exp(a1)) (500 exp(a2)) / 250000 is certainly > 0 far from the underflow
+              // edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 here
+              const bool sure = det2 > 0.0 && det2 < 1e60 && det3 > 0.0 && det3 < 1e60 && maha2 >= 0.0 &&
+                                maha3 >= 0.0 && maha2 + maha3 < 800.0;
+              if (!sure) {
+                double d2 = det2, d3 = det3;
+                asm volatile("" : "+v"(d2), "+v"(d3));
+                apply = pr_from_parts(d2, d3, maha2, maha3) > 0.0;
+              }
+            }
+            if (!apply) acc += Consts<double>::log_no_match;  // probability 0: unseen feature (:94-95)
+          }
+          if (apply) {
+            const unsigned kv = ((unsigned)a.order[t] << 16) | (unsigned)t;
+            if (k == 0) key[0] = kv;
+            if (k == 1) key[1] = kv;
+            if (k == 2) key[2] = kv;
+            if (k == 3) key[3] = kv;
+          }
+        }
+        // apply in scan order (:88): 5-comparator network on the keys, the unused slots sort last
+        auto cswap = [](unsigned& u, unsigned& v) {
+          const unsigned lo = min(u, v), hi = max(u, v);
+          u = lo;
+          v = hi;
+        };
+        cswap(key[0], key[1]);
+        cswap(key[2], key[3]);
+        cswap(key[0], key[2]);
+        cswap(key[1], key[3]);
+        cswap(key[1], key[2]);
+        const bool imm = a.immutable[l] != 0;
+        bool fresh = true;
+#pragma unroll 1
+        for (int k = 0; k < kFastSlots; ++k) {  // rolled: one copy of the update code
+          const unsigned kk = k == 0 ? key[0] : (k == 1 ? key[1] : (k == 2 ? key[2] : key[3]));
+          if (kk == 0xFFFFFFFFu) break;
+          const double* rec = a.exact + 6 * (size_t)(kk & 0xFFFFu);
+          const double2 z01 = *reinterpret_cast<const double2*>(rec);
+          const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+          BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+          acc += ekf_update(A, sx, sy, z, a.qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+          fresh = imm;
+        }
+      }
+      df[(size_t)F_MX * Lp + l] = A.mx;
+      df[(size_t)F_MY * Lp + l] = A.my;
+      df[(size_t)F_MR * Lp + l] = A.mr;
+      df[(size_t)F_MG * Lp + l] = A.mg;
+      df[(size_t)F_MB * Lp + l] = A.mb;
+      df[(size_t)F_PXX * Lp + l] = A.pxx;
+      df[(size_t)F_PXY * Lp + l] = A.pxy;
+      df[(size_t)F_PYY * Lp + l] = A.pyy;
+      df[(size_t)F_CRR * Lp + l] = A.crr;
+      df[(size_t)F_CRG * Lp + l] = A.crg;
+      df[(size_t)F_CRB * Lp + l] = A.crb;
+      df[(size_t)F_CGG * Lp + l] = A.cgg;
+      df[(size_t)F_CGB * Lp + l] = A.cgb;
+      df[(size_t)F_CBB * Lp + l] = A.cbb;
+      dc[l] = A.count;
+    }
+    const double tot = block_sum<kSweepThreads / kWave>(acc, red);  // two barriers: LDS is free for the next particle
+    if (tid == 0) {
+      const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+      a.logw[p] = v;
+      if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));
+      a.src[p] = (int32_t)p;
+    }
+  }
+}
+
+void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
+                          const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                          const ObserveExtras& ex, const SweepPlan& plan, uint4* results_dev) {
+  if (d.P == 0 || plan.grid == 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_observe_sweep), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  SweepArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = fh.lmpass;
+  a.bcount = fh.bcount;
+  a.pflag = fh.pflag;
+  a.immutable = d.immutable;
+  a.results = results_dev;
+  a.P = d.P;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.qcap = plan.qcap;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  hipLaunchKernelGGL(k_observe_sweep, dim3((unsigned)plan.grid), dim3(kSweepThreads), plan.lds, s, a);
+}
+
 int g_observe_nv = 0;  // tuning: 0 = default per variant, 1 / 2 = landmarks per lane
 
 void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,

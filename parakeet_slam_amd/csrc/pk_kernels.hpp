@@ -111,6 +111,18 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
 void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
                     const int32_t* first_dev, const int32_t* next_dev, int n_unmatched,
                     int32_t* ids_dev, const NoiseD& qt, const ObserveExtras& ex = ObserveExtras());
+// ML observe for any L from the same hand-off, two sweeps over the particle's landmarks in
+// chunks (persistent workgroups; see k_observe_sweep).  plan.grid == 0: scan too large for its LDS tables.
+struct SweepPlan {
+  int grid = 0;               // persistent workgroups
+  size_t lds = 0;             // dynamic LDS per workgroup
+  int qcap = 0;               // entries of the LDS probability queue
+  size_t results_per_wg = 0;  // uint4 entries of global scratch per workgroup
+};
+SweepPlan observe_sweep_plan(const DeviceState& d, int B);
+void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
+                          const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                          const ObserveExtras& ex, const SweepPlan& plan, uint4* results_dev);
 extern int g_observe_nv;
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);

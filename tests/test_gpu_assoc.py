@@ -190,10 +190,17 @@ def oracle_state(P, means, covs, poses, blobs, immutable=None):
 
 
 def check_fast(lib, P, means, covs, poses, blobs, immutable=None):
+    """fast_observe = 1: k_observe_fast (L <= 512) / k_observe_sweep (above); 2: k_observe_sweep for
+    every L; 0: the general kernels.  All three against the oracle, and against each other."""
     fast = observe_state(lib, P, means, covs, poses, blobs, 1, immutable)
     gen = observe_state(lib, P, means, covs, poses, blobs, 0, immutable)
+    sweep = observe_state(lib, P, means, covs, poses, blobs, 2, immutable)
     o = oracle_state(P, means, covs, poses, blobs, immutable)
-    for got in (fast, gen):
+    assert np.allclose(sweep[0], gen[0], rtol=1e-11, atol=0)
+    assert np.allclose(sweep[1][0], gen[1][0], rtol=1e-12, atol=1e-14)
+    assert np.allclose(sweep[1][1], gen[1][1], rtol=1e-11, atol=1e-15)
+    assert np.array_equal(sweep[1][2], gen[1][2])
+    for got in (fast, gen, sweep):
         w = got[0][:, 3]
         assert np.allclose(w, o.weights(), rtol=1e-9, atol=0)
         m, c, k = got[1]
@@ -212,6 +219,61 @@ def test_fast_observe_synthetic(lib, L):
     means, covs = synthetic_world(L)
     blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
     check_fast(lib, 40, means, covs, rand_poses(rs, 40), blobs)
+
+
+def max_passers(means, blobs, poses):
+    """Most blobs any landmark of any particle lets through both gates (:433, :441); above
+    kFastSlots = 4 the particle is flagged and leaves the hand-off kernels for the general route."""
+    m = 0
+    for x, y, h, _ in poses:
+        eb = np.arctan2(means[:, 1] - y, means[:, 0] - x) - h
+        ok = (np.abs(blobs[:, 0][None, :] - eb[:, None]) <= 0.5) & (
+            ((blobs[None, :, 1:] - means[:, None, 2:]) ** 2).sum(-1) <= 300)
+        m = max(m, int(ok.sum(1).max()))
+    return m
+
+
+@pytest.mark.parametrize("L,P,flagged", [(513, 24, False), (700, 16, False), (1400, 6, False), (1500, 6, True)])
+def test_sweep_observe_large_maps(lib, L, P, flagged):
+    # L > 512: the hand-off is settled by k_observe_sweep (landmark chunks, two sweeps); in the
+    # last case some landmark passes five blobs, so the particles take the general route instead
+    rs = np.random.RandomState(200 + L)
+    means, covs = synthetic_world(L)
+    n = len(means[3::7])
+    means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))  # look-alikes three bearings apart: contested blobs
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    poses = rand_poses(rs, P)
+    assert (max_passers(means, blobs, poses) > 4) == flagged
+    check_fast(lib, P, means, covs, poses, blobs)
+
+
+def test_sweep_observe_everything_contested_across_chunks(lib):
+    # three bearing neighbours share each colour: every blob is contested by three landmarks, the
+    # rivals sit in other landmark chunks (permuted order), and there are more contested pairs
+    # (2700) than queue entries
+    rs = np.random.RandomState(11)
+    L = 900
+    means, covs = synthetic_world(L)
+    g = np.arange(L // 3)
+    lattice = np.stack([g % 7, (g // 7) % 7, g // 49], axis=1) * 36.0 + 10.0  # groups two gates apart
+    means[:, 2:] = np.repeat(lattice, 3, axis=0) + rs.uniform(-2, 2, (L, 3))
+    covs = covs * rs.uniform(0.5, 2.0, (L, 1, 1))
+    perm = rs.permutation(L)  # neighbours in bearing are far apart in landmark index
+    means, covs = means[perm], covs[perm]
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    poses = rand_poses(rs, 6, 0.1)
+    assert max_passers(means, blobs, poses) <= 4
+    check_fast(lib, 6, means, covs, poses, blobs)
+
+
+def test_sweep_observe_ties_across_chunks_keep_the_earliest(lib):
+    # exact duplicates 600 landmarks apart: equal probabilities from different chunks, earliest wins (:377)
+    rs = np.random.RandomState(12)
+    base, bcov = synthetic_world(600)
+    means = np.vstack([base, base[:50]])
+    covs = np.vstack([bcov, bcov[:50]])
+    blobs = synthetic_scan(base, (0.01, 0.0, 0.0))
+    check_fast(lib, 6, means, covs, rand_poses(rs, 6, 0.1), blobs)
 
 
 def test_fast_observe_contested_and_ties(lib):
