@@ -356,7 +356,7 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
             }
         }
     col_start[g.ncell] = (int)total;
-    if (total <= 65535) n9 = (int)((total + 7) & ~7L);
+    if (total + 3 <= 65535) n9 = (int)((total + 3 + 7) & ~7L);  // the walk reads up to three entries past a range
   }
   uint16_t* order = reinterpret_cast<uint16_t*>(tables + cs_bytes + (size_t)B * 16 + (size_t)n9 * 2);
   for (int b = 0; b < B; ++b) {  // ascending b inside a cell
@@ -436,7 +436,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   if ((rc = ensure_ids_capacity(f, B))) return rc;
   BlobGrid g{};
   const int ncell_max = kGridMax * kGridMax * kGridMax;
-  const size_t tab_max = (blob_grid_table_bytes(ncell_max, B, 9 * B + 8) + 15) & ~(size_t)15;
+  const size_t tab_max = (blob_grid_table_bytes(ncell_max, B, 9 * B + 16) + 15) & ~(size_t)15;
   // block: ctl | blobs (4B) | dir (2B) | exact (6B) doubles | tables
   const size_t o_blobs = kCtlBytes;
   const size_t o_dir = o_blobs + (size_t)B * 4 * sizeof(double);
@@ -456,7 +456,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   int n9 = 0;
   if (use_grid) {
     // duplicated column lists when they fit in LDS (about 48 B per blob), else the 9-range walk
-    bool dup = f->assoc_dup && assoc_grid_lds_bytes(ncell_max, B, 9 * B + 8) <= kMaxDynLds;
+    bool dup = f->assoc_dup && assoc_grid_lds_bytes(ncell_max, B, 9 * B + 16) <= kMaxDynLds;
     build_blob_grid(blobs, dir, B, dup, g, st + o_tab, reinterpret_cast<double*>(st + o_exact), &n9);
     tab_bytes = (blob_grid_table_bytes(g.ncell, B, n9) + 15) & ~(size_t)15;
     if (assoc_grid_lds_bytes(g.ncell, B, n9) > kMaxDynLds) use_grid = false;  // scan too large for LDS tables
@@ -988,6 +988,10 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "assoc_dup")) {
     f->assoc_dup = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "sweep_debug")) {
+    g_sweep_debug = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "observe_landmarks_per_lane")) {

@@ -272,13 +272,13 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
       int npc = 0;
       PK_STAMP(ta1)
       PK_STAMP_ADD(1, ta0, ta1)
-      auto prefilter = [&](int t) {
-        const float4 q = rec32[t];
+      auto prefilter_q = [&](const float4& q) {
         const float d0 = q.x - mr32, d1 = q.y - mg32, d2 = q.z - mb32;
         const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
         // conservative fp32 gates; NaN/inf fall through to the exact float64 tests
         return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
       };
+      auto prefilter = [&](int t) { return prefilter_q(rec32[t]); };
       unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;  // the blobs that pass this landmark's gates (first four)
       int npass = 0;
       auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
@@ -303,15 +303,24 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
           i = start[base + k0];
           i1 = start[base + k1 + 1];
         }
-        int tnext = i < i1 ? (int)idx9[i] : 0;
-        for (; i < i1; ++i) {
-          const int t = tnext;
-          if (i + 1 < i1) tnext = idx9[i + 1];
-          if (prefilter(t)) {
+        // four list entries per round trip: the index reads and then the record reads are
+        // independent, so a walk of n blobs costs ceil(n / 4) dependent LDS latencies, not n
+        // (idx9 is padded: reading up to three entries past i1 stays inside the list)
+        for (; i < i1; i += 4) {
+          int t4[4];
+          float4 q4[4];
 #pragma unroll
-            for (int k = 0; k < kCand; ++k)
-              if (npc == k) pc[k] = t;
-            ++npc;
+          for (int j = 0; j < 4; ++j) t4[j] = idx9[i + j];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) q4[j] = rec32[t4[j]];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (i + j < i1 && prefilter_q(q4[j])) {
+#pragma unroll
+              for (int k = 0; k < kCand; ++k)
+                if (npc == k) pc[k] = t4[j];
+              ++npc;
+            }
           }
         }
       } else {
@@ -513,11 +522,26 @@ static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t l
       (void)hipGetLastError();  // leave no sticky error behind for other users of the runtime
     attr_set = true;
   }
-  // persistent grid: as many workgroups as LDS and the 2048-thread CU limit allow
-  int per_cu = (int)((160 * 1024) / (lds + 64));
-  per_cu = per_cu < 1 ? 1 : per_cu;
-  const int by_threads = 2048 / THREADS;
-  per_cu = per_cu > by_threads ? by_threads : per_cu;
+  // persistent grid = the workgroups that are resident at once (registers, LDS and the wave limit all
+  // count: a workgroup that has to wait for a slot would run its particles after the others finished)
+  static size_t asked_lds = ~(size_t)0;
+  static int asked_per_cu = 0;
+  if (asked_lds != lds) {
+    asked_lds = lds;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked_per_cu,
+                                                     reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL>),
+                                                     THREADS, lds) != hipSuccess) {
+      (void)hipGetLastError();
+      asked_per_cu = 0;
+    }
+  }
+  int per_cu = asked_per_cu;
+  if (per_cu < 1) {  // fall back to the LDS / thread-count estimate
+    per_cu = (int)((160 * 1024) / (lds + 64));
+    per_cu = per_cu < 1 ? 1 : per_cu;
+    const int by_threads = 2048 / THREADS;
+    per_cu = per_cu > by_threads ? by_threads : per_cu;
+  }
   int64_t blocks = 256 * (int64_t)per_cu;
   if (blocks > P) blocks = P;
   hipLaunchKernelGGL((k_assoc_grid<THREADS, DUP, GENERAL>), dim3((unsigned)blocks), dim3(THREADS), lds, s, ga);
@@ -553,18 +577,21 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   ga.n_flagged = fh.n_flagged;
   ga.only_flagged = nullptr;
   const size_t lds = assoc_grid_lds_bytes(grid.ncell, B, n9);
-  // bigger workgroups when the LDS tables are large, so that a CU still holds >= 16 waves
+  // bigger workgroups when the LDS tables are large (fewer copies of them per CU)
   const bool big = lds > 40 * 1024;
   auto go = [&](auto general) {
     constexpr bool G = decltype(general)::value;
+    // one workgroup per CU when the tables are that large: the hand-off instance fits three waves per
+    // SIMD in its registers (768 threads), the general one two (512)
+    constexpr int kBigThreads = G ? 512 : 768;
     if (n9 > 0) {
       if (big)
-        launch_assoc_grid_t<512, true, G>(s, ga, lds, d.P);
+        launch_assoc_grid_t<kBigThreads, true, G>(s, ga, lds, d.P);
       else
         launch_assoc_grid_t<256, true, G>(s, ga, lds, d.P);
     } else {
       if (big)
-        launch_assoc_grid_t<512, false, G>(s, ga, lds, d.P);
+        launch_assoc_grid_t<kBigThreads, false, G>(s, ga, lds, d.P);
       else
         launch_assoc_grid_t<256, false, G>(s, ga, lds, d.P);
     }

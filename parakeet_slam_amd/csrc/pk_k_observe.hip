@@ -550,6 +550,7 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
 //     coalesced store of all 14 rows into the other map buffer.
 // A particle the association kernel flagged (a landmark passing more than kFastSlots blobs) is
 // skipped here and taken by the general kernels.
+int g_sweep_debug = 0;
 constexpr int kSweepThreads = 256;  // 3 workgroups per CU at <= 168 VGPRs
 
 struct SweepArgs {
@@ -569,6 +570,7 @@ struct SweepArgs {
   int64_t P;
   int L, Lp, B;
   int qcap;                     // entries of the LDS probability queue
+  int dbg;                      // timing experiments only: 1 = skip sweep 1, 2 = skip sweep 2
   int reset;
   unsigned long long* gmax_key;
   Noise<double> qt;
@@ -641,7 +643,7 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
 
     // ---- sweep 1: probabilities of the contested pairs ------------------------------------
     int par = 0;
-    for (int base = 0; base < a.L; base += kSweepThreads, par ^= 1) {
+    for (int base = 0; base < ((a.dbg & 1) ? 0 : a.L); base += kSweepThreads, par ^= 1) {
       int l = base + tid;
       asm volatile("" : "+v"(l));
       uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
@@ -724,7 +726,7 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
     double acc = (double)nun * Consts<double>::log_no_match;
 
     // ---- sweep 2: settle the uncontested blobs, apply, store ----------------------------------
-    for (int base = 0; base < Lp; base += kSweepThreads) {
+    for (int base = 0; base < ((a.dbg & 2) ? 0 : Lp); base += kSweepThreads) {
       int l = base + tid;
       asm volatile("" : "+v"(l));  // opaque: no strength-reduced row pointers kept live across the chunk loop
       if (l >= Lp) continue;
@@ -866,10 +868,24 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   a.Lp = d.lay.Lp;
   a.B = B;
   a.qcap = plan.qcap;
+  a.dbg = g_sweep_debug;
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
   a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
-  hipLaunchKernelGGL(k_observe_sweep, dim3((unsigned)plan.grid), dim3(kSweepThreads), plan.lds, s, a);
+  // never more workgroups than are resident at once (results_dev is sized for plan.grid)
+  static size_t asked_lds = ~(size_t)0;
+  static int asked_per_cu = 0;
+  if (asked_lds != plan.lds) {
+    asked_lds = plan.lds;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked_per_cu, reinterpret_cast<const void*>(k_observe_sweep),
+                                                     kSweepThreads, plan.lds) != hipSuccess) {
+      (void)hipGetLastError();
+      asked_per_cu = 0;
+    }
+  }
+  int grid = plan.grid;
+  if (asked_per_cu > 0 && 256 * asked_per_cu < grid) grid = 256 * asked_per_cu;
+  hipLaunchKernelGGL(k_observe_sweep, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
 }
 
 int g_observe_nv = 0;  // tuning: 0 = default per variant, 1 / 2 = landmarks per lane

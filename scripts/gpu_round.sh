@@ -12,3 +12,5 @@ rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_default
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_default -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_default.log 2>&1
 cd $GRAFT_REPO_ROOT
 f=$(find gpurun_out/prof_default -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats_default.csv && head -6 "$f"
+# config 3 kernel trace (ML route: k_assoc_grid hand-off + k_observe_sweep)
+bash scripts/gpu_prof_c3.sh > gpurun_out/prof_c3_head.txt 2>&1; tail -8 gpurun_out/prof_c3_head.txt | cut -c1-160
