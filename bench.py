@@ -227,8 +227,6 @@ def main():
     else:
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
-    if os.environ.get("PK_SWEEP_DEBUG"):  # timing experiments only (results are wrong)
-        filt.set_option("sweep_debug", int(os.environ["PK_SWEEP_DEBUG"]))
     if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only
         filt.set_option("observe_landmarks_per_lane", int(os.environ["PK_OBSERVE_NV"]))
     rnd = random.Random(7)

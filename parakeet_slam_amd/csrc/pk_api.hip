@@ -990,10 +990,6 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     f->assoc_dup = value != 0;
     return PK_OK;
   }
-  if (!strcmp(name, "sweep_debug")) {
-    g_sweep_debug = (int)value;
-    return PK_OK;
-  }
   if (!strcmp(name, "observe_landmarks_per_lane")) {
     if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "observe_landmarks_per_lane: 0 (default), 1 or 2");
     g_observe_nv = (int)value;

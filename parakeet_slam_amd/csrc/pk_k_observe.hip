@@ -550,7 +550,6 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
 //     coalesced store of all 14 rows into the other map buffer.
 // A particle the association kernel flagged (a landmark passing more than kFastSlots blobs) is
 // skipped here and taken by the general kernels.
-int g_sweep_debug = 0;
 constexpr int kSweepThreads = 256;  // 3 workgroups per CU at <= 168 VGPRs
 
 struct SweepArgs {
@@ -570,7 +569,6 @@ struct SweepArgs {
   int64_t P;
   int L, Lp, B;
   int qcap;                     // entries of the LDS probability queue
-  int dbg;                      // timing experiments only: 1 = skip sweep 1, 2 = skip sweep 2
   int reset;
   unsigned long long* gmax_key;
   Noise<double> qt;
@@ -643,7 +641,7 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
 
     // ---- sweep 1: probabilities of the contested pairs ------------------------------------
     int par = 0;
-    for (int base = 0; base < ((a.dbg & 1) ? 0 : a.L); base += kSweepThreads, par ^= 1) {
+    for (int base = 0; base < a.L; base += kSweepThreads, par ^= 1) {
       int l = base + tid;
       asm volatile("" : "+v"(l));
       uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
@@ -726,7 +724,7 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
     double acc = (double)nun * Consts<double>::log_no_match;
 
     // ---- sweep 2: settle the uncontested blobs, apply, store ----------------------------------
-    for (int base = 0; base < ((a.dbg & 2) ? 0 : Lp); base += kSweepThreads) {
+    for (int base = 0; base < Lp; base += kSweepThreads) {
       int l = base + tid;
       asm volatile("" : "+v"(l));  // opaque: no strength-reduced row pointers kept live across the chunk loop
       if (l >= Lp) continue;
@@ -868,7 +866,6 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   a.Lp = d.lay.Lp;
   a.B = B;
   a.qcap = plan.qcap;
-  a.dbg = g_sweep_debug;
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
   a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};

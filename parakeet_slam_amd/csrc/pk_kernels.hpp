@@ -124,7 +124,6 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
                           const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
                           const ObserveExtras& ex, const SweepPlan& plan, uint4* results_dev);
 extern int g_observe_nv;
-extern int g_sweep_debug;
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);
 void launch_keys_max(hipStream_t s, const unsigned long long* keys_dev, double* gmax_dev);
