@@ -269,6 +269,37 @@ def main():
     tm["assoc"] = filt.timings()["assoc"]
     filt.enable_timing(0)
 
+    # the same filter stepped with SUPPLIED ids (no association): the HBM-bound form of the EKF
+    # kernel, reported beside the headline so both routes' rooflines come from one run
+    known = None
+    if args.assoc == "ml":
+        kids = np.arange(1, L + 1, dtype=np.int32)
+        kn = min(K, 20)
+        for s in range(W, W + 2):
+            filt.step(0.2, 0.1, 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
+        filt.enable_timing(0b0000100)
+        filt.reset_timings()
+        barrier()
+        k0 = time.perf_counter()
+        for s in range(W, W + kn):
+            filt.step(0.2, 0.1, 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
+        barrier()
+        k1 = time.perf_counter()
+        kms, kcnt = filt.timings()["observe"]
+        filt.enable_timing(0)
+        kavg = (kms / max(kcnt, 1)) * 1e-3
+        known = {
+            "ms_per_step": (k1 - k0) / kn * 1e3,
+            "value": float(P) * L * kn / (k1 - k0),
+            "steps": kn,
+            "kernel": "k_observe<known ids> (fused EKF update + log-weight)",
+            "avg_launch_ms": kavg * 1e3,
+            "achieved": float(P) * L * BYTES_PER_UPDATE / kavg / 1e9 if kavg > 0 else 0.0,
+            "frac": float(P) * L * BYTES_PER_UPDATE / kavg / 1e9 / HBM_PEAK_GBS if kavg > 0 else 0.0,
+            "unit": "GB/s",
+            "traffic": measured_traffic(P, L, "observe_known"),
+        }
+
     # what a plain device-to-device copy reaches on THIS box (read + write bytes / time), outside the
     # timed region: the practical ceiling next to the 8 TB/s vendor figure
     copy_gbs = None
@@ -349,6 +380,8 @@ def main():
             "kernel_ms_per_step": {"observe": obs_ms / max(obs_n, 1), "assoc": assoc_ms / max(assoc_n, 1)},
             "summary": list(summary),
         }
+        if known is not None and world == 1:
+            out["supplied_ids_route"] = known
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()

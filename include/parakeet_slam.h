@@ -96,7 +96,8 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "fast_observe" = 1 (default: contested associations are settled inside the EKF kernel --
  *                    k_observe_fast with the landmark state in registers for L <= 512,
  *                    k_observe_sweep in two sweeps over landmark chunks above that), 0 (general
- *                    path: association kernel writes ids) or 2 (k_observe_sweep for every L);
+ *                    path: association kernel writes ids), 2 (k_observe_sweep for every L) or 3 (the same with
+ *                    eight hand-off slots per landmark, the default only for scans of >= 3000 blobs);
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
 int pk_set_option(pk_filter* f, const char* name, int64_t value);
 

@@ -403,8 +403,8 @@ struct AssocLaunch {
   const unsigned short* order = nullptr;
 };
 
-int ensure_handoff(pk_filter* f, int B) {
-  const int64_t need_l = f->d.P * (int64_t)f->d.lay.Lp, need_b = f->d.P * (int64_t)std::max(B, 1);
+int ensure_handoff(pk_filter* f, int B, int slots) {
+  const int64_t need_l = f->d.P * (int64_t)f->d.lay.Lp * (slots == kSweepSlots ? 2 : 1), need_b = f->d.P * (int64_t)std::max(B, 1);
   int rc;
   if (need_l > f->fh_cap_l) {
     PK_HIP(hipStreamSynchronize(f->stream));
@@ -472,9 +472,14 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   }
   if (use_grid) {
     FastHandoff fh{};
-    const bool sweep = f->d.lay.L > kFastMaxL || f->fast_observe == 2;
+    const bool sweep = f->d.lay.L > kFastMaxL || f->fast_observe >= 2;
     if (want_fast && !finalize && f->fast_observe && B > 0 && (!sweep || observe_sweep_plan(f->d, B).grid > 0)) {
-      if ((rc = ensure_handoff(f, B))) return rc;
+      // eight hand-off slots per landmark for the large scans (a landmark's colour neighbourhood gets
+      // busier with B: at B = 5 000 random colours some landmark of every particle passes 5-7 blobs),
+      // four (16-byte entries) otherwise; "fast_observe" = 3 forces eight
+      const int slots = (sweep && (B >= 3000 || f->fast_observe == 3)) ? kSweepSlots : kFastSlots;
+      if ((rc = ensure_handoff(f, B, slots))) return rc;
+      f->fh.slots = slots;
       fh = f->fh;
       fh.n_flagged = ctl_n_flagged(f);
     }
@@ -923,7 +928,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     if (al.fast) {
       ObserveExtras e1 = ex;
       e1.flip = false;
-      if (f->d.lay.L > kFastMaxL || f->fast_observe == 2) {
+      if (f->d.lay.L > kFastMaxL || f->fast_observe >= 2) {
         const SweepPlan plan = observe_sweep_plan(f->d, B);
         const size_t need = (size_t)plan.grid * plan.results_per_wg;
         if (need > f->sweep_cap) {
@@ -982,7 +987,8 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     return PK_OK;
   }
   if (!strcmp(name, "fast_observe")) {
-    if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "fast_observe: 0 (general kernels), 1 (default) or 2 (always the sweep kernel)");
+    if (value < 0 || value > 3)
+      return fail(PK_ERR_INVALID, "fast_observe: 0 (general kernels), 1 (default), 2 (always the sweep kernel) or 3 (... with eight slots)");
     f->fast_observe = (int)value;
     return PK_OK;
   }

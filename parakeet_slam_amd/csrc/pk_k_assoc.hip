@@ -150,7 +150,9 @@ struct AssocGridArgs {
   // Fast hand-off to k_observe_fast (L <= 512): per landmark the (<= 4) blobs that pass its
   // gates, per blob how many landmarks pass; a particle where some landmark passes more than
   // four blobs is flagged and settled the general way (S2..S4 + ids) instead.
-  uint4* lmpass;          // [P][Lp]  x,y: four 16-bit fields = blob (cell order) or 0xFFFF; z,w: atan2(my-sy, mx-sx)
+  // SLOTS = 4: [P][Lp]     x,y: four 16-bit fields = blob (cell order) or 0xFFFF; z,w: atan2(my-sy, mx-sx)
+  // SLOTS = 8: [P][Lp][2]  first uint4: eight 16-bit blob fields; second: x,y = atan2(my-sy, mx-sx)
+  uint4* lmpass;
   unsigned char* bcount;  // [P][B]   saturating count
   unsigned char* pflag;   // [P]      1 = general path
   const unsigned char* only_flagged;  // GENERAL instance: skip particles whose flag is 0
@@ -190,7 +192,7 @@ __device__ unsigned long long pk_stamp_acc[16];
 
 // GENERAL = false: S1 + hand-off only (light on registers); particles it flags are redone by
 // the GENERAL = true instance launched with only_flagged.
-template <int THREADS, bool DUP, bool GENERAL>
+template <int THREADS, bool DUP, bool GENERAL, int SLOTS>
 __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int n_few, n_many, wg_flag;
@@ -279,16 +281,19 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
       };
       auto prefilter = [&](int t) { return prefilter_q(rec32[t]); };
-      unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;  // the blobs that pass this landmark's gates (first four)
+      unsigned pass[SLOTS / 2];  // the blobs that pass this landmark's gates (first SLOTS), two per word
+#pragma unroll
+      for (int j = 0; j < SLOTS / 2; ++j) pass[j] = 0xFFFFFFFFu;
       int npass = 0;
       auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
         if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
           const int n = atomicAdd(&ccount[tt], 1);
-          if (n < 4) cand[4 * tt + n] = (unsigned short)l;
-          if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
-          if (npass == 1) pass01 = (pass01 & 0x0000FFFFu) | ((unsigned)tt << 16);
-          if (npass == 2) pass23 = (pass23 & 0xFFFF0000u) | (unsigned)tt;
-          if (npass == 3) pass23 = (pass23 & 0x0000FFFFu) | ((unsigned)tt << 16);
+          if (GENERAL && n < 4) cand[4 * tt + n] = (unsigned short)l;  // the hand-off instance keeps no candidate lists
+#pragma unroll
+          for (int j = 0; j < SLOTS; ++j)
+            if (npass == j)
+              pass[j >> 1] = (j & 1) ? ((pass[j >> 1] & 0x0000FFFFu) | ((unsigned)tt << 16))
+                                     : ((pass[j >> 1] & 0xFFFF0000u) | (unsigned)tt);
           ++npass;
         }
       };
@@ -324,27 +329,30 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
           }
         }
       } else {
-        // flattened walk over the 9 (r, g) columns x [k0, k1]; j = next column, [t, t1) = open range
-        int j = (k0 <= k1) ? 0 : 9, t = 0, t1 = 0;
-        for (;;) {
-          if (t >= t1) {
-            if (j >= 9) break;
+        // the 9 (r, g) columns x [k0, k1]: nine contiguous record ranges, four records per round trip
+        // (reads past a range end stay inside rec32 or return the next table's bytes: masked out)
+        if (k0 <= k1) {
+          for (int j = 0; j < 9; ++j) {
             const int jr = (j * 11) >> 5;  // j / 3 for j < 9
             const int r = c[0] - 1 + jr, gg = c[1] - 1 + (j - 3 * jr);
-            ++j;
             if ((unsigned)r >= (unsigned)g.G[0] || (unsigned)gg >= (unsigned)g.G[1]) continue;
             const int base = (r * g.G[1] + gg) * g.G[2];
-            t = start[base + k0];
-            t1 = start[base + k1 + 1];
-            if (t >= t1) continue;
-          }
-          if (prefilter(t)) {
+            const int t1 = start[base + k1 + 1];
+            for (int t = start[base + k0]; t < t1; t += 4) {
+              float4 q4[4];
 #pragma unroll
-            for (int k = 0; k < kCand; ++k)
-              if (npc == k) pc[k] = t;
-            ++npc;
+              for (int i = 0; i < 4; ++i) q4[i] = rec32[min(t + i, B - 1)];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (t + i < t1 && prefilter_q(q4[i])) {
+#pragma unroll
+                  for (int k = 0; k < kCand; ++k)
+                    if (npc == k) pc[k] = t + i;
+                  ++npc;
+                }
+              }
+            }
           }
-          ++t;
         }
       }
       PK_STAMP(ta2)
@@ -395,8 +403,14 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
       }
       if (!GENERAL) {
         const unsigned long long pb = (unsigned long long)__double_as_longlong(pse);
-        ga.lmpass[(size_t)p * a.Lp + l] = make_uint4(pass01, pass23, (unsigned)pb, (unsigned)(pb >> 32));
-        if (npass > kFastSlots) wg_flag = 1;
+        if (SLOTS == 4) {
+          ga.lmpass[(size_t)p * a.Lp + l] = make_uint4(pass[0], pass[1], (unsigned)pb, (unsigned)(pb >> 32));
+        } else {
+          uint4* e = ga.lmpass + 2 * ((size_t)p * a.Lp + l);
+          e[0] = make_uint4(pass[0], pass[1], pass[SLOTS / 2 - 2], pass[SLOTS / 2 - 1]);
+          e[1] = make_uint4((unsigned)pb, (unsigned)(pb >> 32), 0u, 0u);
+        }
+        if (npass > SLOTS) wg_flag = 1;
       }
     }
     PK_STAMP(ts2)
@@ -513,11 +527,11 @@ size_t assoc_grid_lds_bytes(int ncell, int B, int n9) {
   return grid_cs_bytes(ncell) + (size_t)B * 30 + (size_t)n9 * 2 + 16;
 }
 
-template <int THREADS, bool DUP, bool GENERAL>
+template <int THREADS, bool DUP, bool GENERAL, int SLOTS>
 static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t lds, int64_t P) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL, SLOTS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
       (void)hipGetLastError();  // leave no sticky error behind for other users of the runtime
     attr_set = true;
@@ -529,7 +543,7 @@ static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t l
   if (asked_lds != lds) {
     asked_lds = lds;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked_per_cu,
-                                                     reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL>),
+                                                     reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL, SLOTS>),
                                                      THREADS, lds) != hipSuccess) {
       (void)hipGetLastError();
       asked_per_cu = 0;
@@ -544,7 +558,7 @@ static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t l
   }
   int64_t blocks = 256 * (int64_t)per_cu;
   if (blocks > P) blocks = P;
-  hipLaunchKernelGGL((k_assoc_grid<THREADS, DUP, GENERAL>), dim3((unsigned)blocks), dim3(THREADS), lds, s, ga);
+  hipLaunchKernelGGL((k_assoc_grid<THREADS, DUP, GENERAL, SLOTS>), dim3((unsigned)blocks), dim3(THREADS), lds, s, ga);
 }
 
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
@@ -576,32 +590,40 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   ga.pflag = fh.pflag;
   ga.n_flagged = fh.n_flagged;
   ga.only_flagged = nullptr;
-  const size_t lds = assoc_grid_lds_bytes(grid.ncell, B, n9);
-  // bigger workgroups when the LDS tables are large (fewer copies of them per CU)
-  const bool big = lds > 40 * 1024;
-  auto go = [&](auto general) {
+  auto go = [&](auto general, auto slots) {
     constexpr bool G = decltype(general)::value;
+    constexpr int S = decltype(slots)::value;
+    // the hand-off instance needs the tables and the per-blob counts only (20 B per blob, not 30)
+    const size_t lds = G ? assoc_grid_lds_bytes(grid.ncell, B, n9) : assoc_grid_lds_bytes(grid.ncell, B, n9) - (size_t)B * 10;
+    // bigger workgroups when the LDS tables are large (fewer copies of them per CU)
+    const bool big = lds > 40 * 1024;
     // one workgroup per CU when the tables are that large: the hand-off instance fits three waves per
     // SIMD in its registers (768 threads), the general one two (512)
     constexpr int kBigThreads = G ? 512 : 768;
     if (n9 > 0) {
       if (big)
-        launch_assoc_grid_t<kBigThreads, true, G>(s, ga, lds, d.P);
+        launch_assoc_grid_t<kBigThreads, true, G, S>(s, ga, lds, d.P);
       else
-        launch_assoc_grid_t<256, true, G>(s, ga, lds, d.P);
+        launch_assoc_grid_t<256, true, G, S>(s, ga, lds, d.P);
     } else {
       if (big)
-        launch_assoc_grid_t<kBigThreads, false, G>(s, ga, lds, d.P);
+        launch_assoc_grid_t<kBigThreads, false, G, S>(s, ga, lds, d.P);
       else
-        launch_assoc_grid_t<256, false, G>(s, ga, lds, d.P);
+        launch_assoc_grid_t<256, false, G, S>(s, ga, lds, d.P);
     }
   };
+  using Slots4 = std::integral_constant<int, kFastSlots>;
+  using Slots8 = std::integral_constant<int, kSweepSlots>;
   if (fh.lmpass) {
-    go(std::false_type{});  // S1 + hand-off for every particle
+    // gate tests + hand-off for every particle
+    if (fh.slots == kSweepSlots)
+      go(std::false_type{}, Slots8{});
+    else
+      go(std::false_type{}, Slots4{});
     ga.only_flagged = fh.pflag;
-    go(std::true_type{});   // the flagged ones (a landmark with > 2 gate-passing blobs) the general way
+    go(std::true_type{}, Slots4{});  // the flagged ones (a landmark with more gate-passing blobs than slots) the general way
   } else {
-    go(std::true_type{});
+    go(std::true_type{}, Slots4{});
   }
 }
 

@@ -565,7 +565,7 @@ struct SweepArgs {
   const unsigned char* bcount;
   const unsigned char* pflag;
   const unsigned char* immutable;
-  uint4* results;               // [gridDim.x][4 * Lp]: probability bits (lo, hi), blob t, landmark l
+  uint4* results;               // [gridDim.x][kSweepSlots * Lp]: probability bits (lo, hi), blob t, landmark l
   int64_t P;
   int L, Lp, B;
   int qcap;                     // entries of the LDS probability queue
@@ -601,10 +601,12 @@ SweepPlan observe_sweep_plan(const DeviceState& d, int B) {
   pl.lds = sweep_lds_bytes(B, pl.qcap);
   int64_t g = 256 * (int64_t)per_cu;
   pl.grid = (int)(g < d.P ? g : d.P);
-  pl.results_per_wg = 4 * (size_t)d.lay.Lp;
+  pl.results_per_wg = kSweepSlots * (size_t)d.lay.Lp;
   return pl;
 }
 
+// SLOTS = kFastSlots (hand-off entry 16 B: four blob fields + atan2) or kSweepSlots (32 B: eight + atan2)
+template <int SLOTS>
 __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kSweepThreads / kWave];
@@ -619,7 +621,7 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
   unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + (size_t)qcap * 36 + 16);
   int* win = reinterpret_cast<int*>(best + B);
   unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
-  uint4* results = a.results + (size_t)blockIdx.x * 4 * (size_t)Lp;
+  uint4* results = a.results + (size_t)blockIdx.x * SLOTS * (size_t)Lp;
 
   for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
     if (a.pflag[p]) continue;  // workgroup-uniform: the general kernels take this particle
@@ -630,7 +632,20 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
     const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
     int* dc = reinterpret_cast<int*>(dslot + a.count_off);
     const double sx = a.x[p], sy = a.y[p];
-    const uint4* lmp = a.lmpass + (size_t)p * Lp;
+    const uint4* lmp = a.lmpass + (SLOTS == 4 ? 1 : 2) * (size_t)p * Lp;  // entries as written by k_assoc_grid
+    // blob fields of landmark l (unused words all ones) and its atan2(my - sy, mx - sx)
+    auto entry_blobs = [&](int l) {
+      if (SLOTS == 4) {
+        const uint4 e = lmp[l];
+        return make_uint4(e.x, e.y, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      }
+      return lmp[2 * l];
+    };
+    auto entry_pse = [&](int l) {
+      const uint4 e = SLOTS == 4 ? lmp[l] : lmp[2 * l + 1];
+      const unsigned lo = SLOTS == 4 ? e.z : e.x, hi = SLOTS == 4 ? e.w : e.y;
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
     for (int t = tid; t < B; t += kSweepThreads) {
       best[t] = 0ull;
       win[t] = INT_MAX;
@@ -644,27 +659,30 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
     for (int base = 0; base < a.L; base += kSweepThreads, par ^= 1) {
       int l = base + tid;
       asm volatile("" : "+v"(l));
-      uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-      if (l < a.L) lp = lmp[l];
-      const unsigned w[2] = {lp.x, lp.y};
-      int ct[kFastSlots];
+      uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (l < a.L) lp = entry_blobs(l);
+      // slot k of this landmark: blob (cell order) or 0xFFFF; the slots are filled from the front
+      auto slot_of = [&](int k) {
+        const unsigned w = k < 2 ? lp.x : (k < 4 ? lp.y : (k < 6 ? lp.z : lp.w));
+        return (int)((w >> (16 * (k & 1))) & 0xFFFFu);
+      };
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < kFastSlots; ++k) {
-        const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
-        ct[k] = (t != 0xFFFF && bc[t] >= 2) ? t : -1;
-        any |= ct[k] >= 0;
+      for (int k = 0; k < SLOTS; ++k) {
+        const int t = slot_of(k);
+        any |= t != 0xFFFF && bc[t] >= 2;
       }
       if (any) {
         const Landmark<double> lm = load_landmark_nocount(sf, Lp, l);
-        const double pse = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
+        const double pse = entry_pse(l);
         const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
         double det3;
         const Sym3<double> inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
-#pragma unroll
-        for (int k = 0; k < kFastSlots; ++k) {
-          const int t = ct[k];
-          if (t < 0) continue;
+#pragma unroll 1
+        for (int k = 0; k < SLOTS; ++k) {  // rolled: one copy of the code, a lane leaves at its first empty slot
+          const int t = slot_of(k);
+          if (t == 0xFFFF) break;
+          if (bc[t] < 2) continue;
           const double* rec = a.exact + 6 * (size_t)t;
           const double2 z01 = *reinterpret_cast<const double2*>(rec);
           const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
@@ -692,7 +710,6 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
               results[atomicAdd(&q_n[2], 1)] = make_uint4((unsigned)bits, (unsigned)(bits >> 32), (unsigned)t, (unsigned)l);
             }
           }
-          __builtin_amdgcn_sched_barrier(0);  // one slot's temporaries at a time
         }
       }
       __syncthreads();
@@ -730,20 +747,20 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
       if (l >= Lp) continue;
       Landmark<double> A = load_landmark(sf, sc, Lp, l);
       if (l < a.L) {
-        const uint4 lp = lmp[l];
-        const double pse = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
-        const unsigned w[2] = {lp.x, lp.y};
+        const uint4 lp = entry_blobs(l);
+        const double pse = entry_pse(l);
         // per slot: scan index << 16 | blob when the update is applied, else 0xFFFFFFFF
-        unsigned key[kFastSlots];
+        unsigned key[SLOTS];
         bool have_inv = false;
         double det2 = 0.0, det3 = 0.0;
         Sym3<double> inv3{};
 #pragma unroll
-        for (int k = 0; k < kFastSlots; ++k) key[k] = 0xFFFFFFFFu;
+        for (int k = 0; k < SLOTS; ++k) key[k] = 0xFFFFFFFFu;
 #pragma unroll 1
-        for (int k = 0; k < kFastSlots; ++k) {  // rolled: one copy of the settling code
-          const int t = (int)(((k < 2 ? w[0] : w[1]) >> (16 * (k & 1))) & 0xFFFFu);
-          if (t == 0xFFFF) continue;
+        for (int k = 0; k < SLOTS; ++k) {  // rolled: one copy of the settling code
+          const unsigned wk = k < 2 ? lp.x : (k < 4 ? lp.y : (k < 6 ? lp.z : lp.w));
+          const int t = (int)((wk >> (16 * (k & 1))) & 0xFFFFu);
+          if (t == 0xFFFF) break;  // the slots are filled from the front
           bool apply;
           if (bc[t] >= 2) {
             apply = win[t] == l;
@@ -778,29 +795,22 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
           }
           if (apply) {
             const unsigned kv = ((unsigned)a.order[t] << 16) | (unsigned)t;
-            if (k == 0) key[0] = kv;
-            if (k == 1) key[1] = kv;
-            if (k == 2) key[2] = kv;
-            if (k == 3) key[3] = kv;
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j)
+              if (k == j) key[j] = kv;
           }
         }
-        // apply in scan order (:88): 5-comparator network on the keys, the unused slots sort last
-        auto cswap = [](unsigned& u, unsigned& v) {
-          const unsigned lo = min(u, v), hi = max(u, v);
-          u = lo;
-          v = hi;
-        };
-        cswap(key[0], key[1]);
-        cswap(key[2], key[3]);
-        cswap(key[0], key[2]);
-        cswap(key[1], key[3]);
-        cswap(key[1], key[2]);
+        // apply in scan order (:88): take the smallest remaining key each time (usually one or two)
         const bool imm = a.immutable[l] != 0;
         bool fresh = true;
-#pragma unroll 1
-        for (int k = 0; k < kFastSlots; ++k) {  // rolled: one copy of the update code
-          const unsigned kk = k == 0 ? key[0] : (k == 1 ? key[1] : (k == 2 ? key[2] : key[3]));
+        for (;;) {
+          unsigned kk = key[0];
+#pragma unroll
+          for (int j = 1; j < SLOTS; ++j) kk = min(kk, key[j]);
           if (kk == 0xFFFFFFFFu) break;
+#pragma unroll
+          for (int j = 0; j < SLOTS; ++j)
+            if (key[j] == kk) key[j] = 0xFFFFFFFFu;  // keys are distinct: one slot per blob
           const double* rec = a.exact + 6 * (size_t)(kk & 0xFFFFu);
           const double2 z01 = *reinterpret_cast<const double2*>(rec);
           const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
@@ -841,9 +851,10 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   if (d.P == 0 || plan.grid == 0) return;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_observe_sweep), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kMaxDynLds) != hipSuccess)
-      (void)hipGetLastError();
+    for (const void* fn : {reinterpret_cast<const void*>(k_observe_sweep<kFastSlots>),
+                           reinterpret_cast<const void*>(k_observe_sweep<kSweepSlots>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
+        (void)hipGetLastError();
     attr_set = true;
   }
   SweepArgs a;
@@ -874,7 +885,7 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   static int asked_per_cu = 0;
   if (asked_lds != plan.lds) {
     asked_lds = plan.lds;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked_per_cu, reinterpret_cast<const void*>(k_observe_sweep),
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked_per_cu, reinterpret_cast<const void*>(k_observe_sweep<kSweepSlots>),
                                                      kSweepThreads, plan.lds) != hipSuccess) {
       (void)hipGetLastError();
       asked_per_cu = 0;
@@ -882,7 +893,10 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   }
   int grid = plan.grid;
   if (asked_per_cu > 0 && 256 * asked_per_cu < grid) grid = 256 * asked_per_cu;
-  hipLaunchKernelGGL(k_observe_sweep, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
+  if (fh.slots == kSweepSlots)
+    hipLaunchKernelGGL(k_observe_sweep<kSweepSlots>, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
+  else
+    hipLaunchKernelGGL(k_observe_sweep<kFastSlots>, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
 }
 
 int g_observe_nv = 0;  // tuning: 0 = default per variant, 1 / 2 = landmarks per lane

@@ -80,7 +80,8 @@ size_t assoc_grid_lds_bytes(int ncell, int B, int n9);
 constexpr size_t kMaxDynLds = 156 * 1024;  // 160 KiB per workgroup minus the kernels' static __shared__
 // Hand-off from the association kernel to k_observe_fast (all three NULL = not used).
 struct FastHandoff {
-  uint4* lmpass = nullptr;          // [P][Lp]
+  uint4* lmpass = nullptr;          // [P][Lp] (slots = 4) or [P][Lp][2] (slots = 8): see k_assoc_grid
+  int slots = 4;                    // gate-passing blobs a landmark can hand over: kFastSlots or kSweepSlots
   unsigned char* bcount = nullptr;  // [P][B]
   unsigned char* pflag = nullptr;   // [P]
   unsigned* n_flagged = nullptr;    // number of flagged particles of this scan
@@ -94,7 +95,8 @@ struct ObserveExtras {
   bool reset = false;                           // weights restart from 1 (fused pk_reset_weights)
   unsigned long long* gmax_key = nullptr;       // keep the running max of the new log-weights here
 };
-constexpr int kFastSlots = 4;  // gate-passing blobs a landmark can hand over; more -> general path
+constexpr int kFastSlots = 4;   // gate-passing blobs a landmark can hand over to k_observe_fast; more -> general path
+constexpr int kSweepSlots = 8;  // ... to k_observe_sweep (large maps: a landmark's colour neighbourhood is busier)
 constexpr int kFastMaxL = 512;  // k_observe_fast keeps a particle's whole map in registers (2 landmarks/lane)
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev,

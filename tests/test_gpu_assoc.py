@@ -170,10 +170,11 @@ def test_observe_with_both_kernels_gives_identical_state(lib):
 
 
 # ---------------------------------------------------------------- fast hand-off path (L <= 512)
-def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None):
+def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1):
     L = means.shape[0]
     f = lib.DeviceFilter(P, L)
     f.set_option("fast_observe", fast)
+    f.set_option("assoc_dup", dup)
     f.upload_map(means, covs.reshape(L, 25), immutable)
     f.upload_poses(poses)
     f.observe(blobs)  # no ids requested: the production route
@@ -191,16 +192,19 @@ def oracle_state(P, means, covs, poses, blobs, immutable=None):
 
 def check_fast(lib, P, means, covs, poses, blobs, immutable=None):
     """fast_observe = 1: k_observe_fast (L <= 512) / k_observe_sweep (above); 2: k_observe_sweep for
-    every L; 0: the general kernels.  All three against the oracle, and against each other."""
+    every L; 3: the same with eight hand-off slots per landmark; 0: the general kernels.  All
+    four against the oracle, and against each other."""
     fast = observe_state(lib, P, means, covs, poses, blobs, 1, immutable)
     gen = observe_state(lib, P, means, covs, poses, blobs, 0, immutable)
     sweep = observe_state(lib, P, means, covs, poses, blobs, 2, immutable)
+    sweep8 = observe_state(lib, P, means, covs, poses, blobs, 3, immutable)
     o = oracle_state(P, means, covs, poses, blobs, immutable)
-    assert np.allclose(sweep[0], gen[0], rtol=1e-11, atol=0)
-    assert np.allclose(sweep[1][0], gen[1][0], rtol=1e-12, atol=1e-14)
-    assert np.allclose(sweep[1][1], gen[1][1], rtol=1e-11, atol=1e-15)
-    assert np.array_equal(sweep[1][2], gen[1][2])
-    for got in (fast, gen, sweep):
+    for sw in (sweep, sweep8):
+        assert np.allclose(sw[0], gen[0], rtol=1e-11, atol=0)
+        assert np.allclose(sw[1][0], gen[1][0], rtol=1e-12, atol=1e-14)
+        assert np.allclose(sw[1][1], gen[1][1], rtol=1e-11, atol=1e-15)
+        assert np.array_equal(sw[1][2], gen[1][2])
+    for got in (fast, gen, sweep, sweep8):
         w = got[0][:, 3]
         assert np.allclose(w, o.weights(), rtol=1e-9, atol=0)
         m, c, k = got[1]
@@ -233,18 +237,42 @@ def max_passers(means, blobs, poses):
     return m
 
 
-@pytest.mark.parametrize("L,P,flagged", [(513, 24, False), (700, 16, False), (1400, 6, False), (1500, 6, True)])
-def test_sweep_observe_large_maps(lib, L, P, flagged):
-    # L > 512: the hand-off is settled by k_observe_sweep (landmark chunks, two sweeps); in the
-    # last case some landmark passes five blobs, so the particles take the general route instead
+@pytest.mark.parametrize("L,P,most", [(513, 24, 4), (700, 16, 4), (1400, 6, 4), (1500, 6, 5)])
+def test_sweep_observe_large_maps(lib, L, P, most):
+    # L > 512: the hand-off (up to eight gate-passing blobs per landmark) is settled by
+    # k_observe_sweep (landmark chunks, two sweeps); in the last case some landmark passes five
     rs = np.random.RandomState(200 + L)
     means, covs = synthetic_world(L)
     n = len(means[3::7])
     means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))  # look-alikes three bearings apart: contested blobs
     blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
     poses = rand_poses(rs, P)
-    assert (max_passers(means, blobs, poses) > 4) == flagged
+    assert max_passers(means, blobs, poses) == most
     check_fast(lib, P, means, covs, poses, blobs)
+
+
+def test_sweep_observe_up_to_eight_blobs_per_landmark_and_beyond(lib):
+    # groups of seven look-alike bearing neighbours: every landmark passes seven blobs (hand-off,
+    # eight slots); then twelve blobs on one landmark: more than eight -> particle flagged -> general route
+    rs = np.random.RandomState(13)
+    L = 700
+    means, covs = synthetic_world(L)
+    g = np.arange(L // 7)
+    lattice = np.stack([g % 5, (g // 5) % 5, g // 25], axis=1) * 50.0 + 10.0
+    means[:, 2:] = np.repeat(lattice, 7, axis=0) + rs.uniform(-2, 2, (L, 3))
+    covs = covs * rs.uniform(0.5, 2.0, (L, 1, 1))
+    perm = rs.permutation(L)
+    means, covs = means[perm], covs[perm]
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    poses = rand_poses(rs, 5, 0.1)
+    assert 5 <= max_passers(means, blobs, poses) <= 8
+    check_fast(lib, 5, means, covs, poses, blobs)
+    dup = np.repeat(blobs[5:6], 12, axis=0)
+    dup[:, 0] += rs.uniform(-0.05, 0.05, 12)
+    dup[:, 1:] += rs.uniform(-1, 1, (12, 3))
+    blobs2 = np.vstack([blobs, dup])
+    assert max_passers(means, blobs2, poses) > 8
+    check_fast(lib, 5, means, covs, poses, blobs2)
 
 
 def test_sweep_observe_everything_contested_across_chunks(lib):
@@ -274,6 +302,34 @@ def test_sweep_observe_ties_across_chunks_keep_the_earliest(lib):
     covs = np.vstack([bcov, bcov[:50]])
     blobs = synthetic_scan(base, (0.01, 0.0, 0.0))
     check_fast(lib, 6, means, covs, rand_poses(rs, 6, 0.1), blobs)
+
+
+@pytest.mark.parametrize("L", [60, 500, 900])
+def test_nine_range_walk_without_the_duplicated_index_list(lib, L):
+    # assoc_dup = 0: the association kernels walk the nine (r, g) columns of the colour grid instead
+    # of one duplicated list (what scans too large for the list in LDS get); ids and state unchanged
+    rs = np.random.RandomState(300 + L)
+    means, covs = synthetic_world(L)
+    n = len(means[3::7])
+    means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    poses = rand_poses(rs, 12)
+    P = 12
+    o = oracle_state(P, means, covs, poses, blobs)
+    for fast in (0, 1):
+        got = observe_state(lib, P, means, covs, poses, blobs, fast, dup=0)
+        ref = observe_state(lib, P, means, covs, poses, blobs, fast, dup=1)
+        assert np.array_equal(got[0], ref[0])
+        for x, y in zip(got[1], ref[1]):
+            assert np.array_equal(x, y)
+        assert np.allclose(got[0][:, 3], o.weights(), rtol=1e-9, atol=0)
+        assert np.allclose(got[1][0], o.mean, rtol=1e-10, atol=1e-12)
+    f = lib.DeviceFilter(P, L)
+    f.set_option("assoc_dup", 0)
+    f.upload_map(means, covs.reshape(L, 25))
+    f.upload_poses(poses)
+    assert np.array_equal(f.associate(blobs), oracle_ids(P, means, covs, poses, blobs))
+    f.close()
 
 
 def test_fast_observe_contested_and_ties(lib):
