@@ -44,6 +44,15 @@ def measured_traffic(P, L, variant):
     return best
 
 
+ROUTE_KERNEL = {
+    "known_ids": "k_observe<known ids> (fused EKF update + log-weight)",
+    "ml_fused": "k_step_fused (association gates + settling of contested blobs + EKF update + log-weight in ONE kernel)",
+    "ml_handoff": "k_observe_fast (EKF update + log-weight + settling of contested associations; includes the "
+                  "near-empty general k_observe launch for flagged particles; the association kernel is separate)",
+    "ml_sweep": "k_observe_sweep (two sweeps over landmark chunks: settling of contested associations, EKF update + "
+                "log-weight; the association kernel is separate)",
+    "ml_general": "k_observe<ML general> (fused EKF update + log-weight)",
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_UPDATE = 224  # 14 fp64 read + 14 written per particle.landmark
 
@@ -257,6 +266,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    route = filt.observe_route() if hasattr(filt, "observe_route") else ("known_ids" if args.assoc == "known" else "ml")
     tm = filt.timings()
     filt.enable_timing(0)
     summary = filt.summary()
@@ -359,16 +369,15 @@ def main():
                 else "single GPU",
             },
             "roofline": {
-                "kernel": ("k_observe<known ids> (fused EKF update + log-weight)" if args.assoc == "known" else
-                           "k_observe_fast (EKF update + log-weight + settling of contested associations; "
-                           "includes the near-empty general k_observe launch for flagged particles)"
-                           if L <= 512 else "k_observe<ML general> (fused EKF update + log-weight)"),
+                "kernel": ROUTE_KERNEL.get(route, route),
+                "route": route,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(P, L, "observe_known" if args.assoc == "known" else "observe_ml"),
+                "traffic": measured_traffic(P, L, {"known_ids": "observe_known", "ml_fused": "step_fused",
+                                                   "ml_handoff": "observe_ml"}.get(route, "none")),
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH + WRITE)*1024, "
                 "see profiles/*/pmc_traffic.json",
                 "copy_measured": copy_gbs,

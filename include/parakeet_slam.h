@@ -98,6 +98,9 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    k_observe_sweep in two sweeps over landmark chunks above that), 0 (general
  *                    path: association kernel writes ids), 2 (k_observe_sweep for every L) or 3 (the same with
  *                    eight hand-off slots per landmark, the default only for scans of >= 3000 blobs);
+ *   "fused_step"   = 1 (default: with "fast_observe" = 1, L <= 512 and scan tables that fit LDS twice
+ *                    per CU, gates + settling + EKF update of a particle run in ONE kernel,
+ *                    k_step_fused, without the hand-off through HBM) or 0;
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
 int pk_set_option(pk_filter* f, const char* name, int64_t value);
 
@@ -248,6 +251,17 @@ int pk_timings(pk_filter* f, double ms[PK_T_COUNT], int64_t launches[PK_T_COUNT]
 /* Algorithmic HBM bytes of one observe launch (14 scalars read + 14 written per
  * particle.landmark) and the bytes the layout actually moves (adds update_count, ids). */
 int pk_observe_bytes(const pk_filter* f, int32_t num_blobs, int64_t* algorithmic, int64_t* moved);
+/* Which kernels the last pk_observe / pk_step used for association + EKF update (instrumentation):
+ * PK_ROUTE_NONE before the first call. */
+enum {
+  PK_ROUTE_NONE = 0,
+  PK_ROUTE_KNOWN_IDS = 1,    /* ids supplied: k_observe */
+  PK_ROUTE_ML_GENERAL = 2,   /* association kernel writes ids, k_observe builds chains from them */
+  PK_ROUTE_ML_HANDOFF = 3,   /* k_assoc_grid hand-off + k_observe_fast (L <= 512) */
+  PK_ROUTE_ML_SWEEP = 4,     /* k_assoc_grid hand-off + k_observe_sweep (L > 512) */
+  PK_ROUTE_ML_FUSED = 5      /* k_step_fused: gates + settling + EKF update in one kernel */
+};
+int pk_observe_route(const pk_filter* f);
 
 /* ---- host-side reproductions of the reference's RNG streams (no GPU needed) ------
  * numpy.random.seed(s); numpy.random.normal(0,1,n)  (legacy MT19937 + polar method), the

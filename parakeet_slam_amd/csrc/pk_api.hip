@@ -81,6 +81,8 @@ struct pk_filter {
   int64_t rlohi_cap = 0;
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
+  int route = PK_ROUTE_NONE;  // kernels used by the last observe
+  int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
   uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
   size_t sweep_cap = 0;
@@ -396,6 +398,10 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
 
 // Upload one scan for maximum-likelihood association and enqueue the association kernel.
 struct AssocLaunch {
+  bool fused = false;  // nothing launched yet: k_step_fused does gates + EKF in one kernel
+  BlobGrid grid{};
+  int n9 = 0;
+  const unsigned char* tables = nullptr;
   bool fast = false;  // hand-off written: k_observe_fast can run
   const double* blobs = nullptr;
   const double* dir = nullptr;
@@ -403,8 +409,9 @@ struct AssocLaunch {
   const unsigned short* order = nullptr;
 };
 
-int ensure_handoff(pk_filter* f, int B, int slots) {
-  const int64_t need_l = f->d.P * (int64_t)f->d.lay.Lp * (slots == kSweepSlots ? 2 : 1), need_b = f->d.P * (int64_t)std::max(B, 1);
+int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true) {
+  const int64_t need_l = lists ? f->d.P * (int64_t)f->d.lay.Lp * (slots == kSweepSlots ? 2 : 1) : 0;
+  const int64_t need_b = lists ? f->d.P * (int64_t)std::max(B, 1) : 0;
   int rc;
   if (need_l > f->fh_cap_l) {
     PK_HIP(hipStreamSynchronize(f->stream));
@@ -473,6 +480,18 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   if (use_grid) {
     FastHandoff fh{};
     const bool sweep = f->d.lay.L > kFastMaxL || f->fast_observe >= 2;
+    if (out && want_fast && !finalize && f->fast_observe == 1 && f->fused_step && !sweep && B > 0 && n9 > 0 &&
+        fused_lds_bytes(g.ncell, B, n9) <= kFusedMaxLds) {
+      if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
+      out->fused = true;
+      out->grid = g;
+      out->n9 = n9;
+      out->tables = f->scan_dev + o_tab;
+      out->exact = reinterpret_cast<const double*>(f->scan_dev + o_exact);
+      const size_t cs_b = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
+      out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
+      return PK_OK;
+    }
     if (want_fast && !finalize && f->fast_observe && B > 0 && (!sweep || observe_sweep_plan(f->d, B).grid > 0)) {
       // eight hand-off slots per landmark for the large scans (a landmark's colour neighbourhood gets
       // busier with B: at B = 5 000 random colours some landmark of every particle passes 5-7 blobs),
@@ -915,6 +934,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     }
     f->src_identity = true;
     f->gmax_fused = true;
+    f->route = PK_ROUTE_KNOWN_IDS;
     if (ids_out)
       for (int64_t p = 0; p < f->d.P; ++p) memcpy(ids_out + (size_t)p * B, ids, (size_t)B * 4);
     return PK_OK;
@@ -923,7 +943,28 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   AssocLaunch al;
   if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
   ex.gmax_key = ctl_gmax_key(f);
-  {
+  f->route = al.fused ? PK_ROUTE_ML_FUSED
+             : !al.fast ? PK_ROUTE_ML_GENERAL
+             : (f->d.lay.L > kFastMaxL || f->fast_observe >= 2) ? PK_ROUTE_ML_SWEEP : PK_ROUTE_ML_HANDOFF;
+  if (al.fused) {
+    FastHandoff fh = f->fh;
+    fh.n_flagged = ctl_n_flagged(f);
+    fh.flags_only = true;
+    {
+      Span t(f, PK_T_OBSERVE);
+      ObserveExtras e1 = ex;
+      e1.flip = false;
+      launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
+    }
+    // the particles it flagged (a landmark passing more than kFastSlots blobs): general kernels,
+    // both timed in the association slot
+    Span t(f, PK_T_ASSOC);
+    launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fh);
+    ObserveExtras e2 = ex;
+    e2.only_flagged = f->fh.pflag;
+    e2.n_flagged = ctl_n_flagged(f);
+    launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
+  } else {
     Span t(f, PK_T_OBSERVE);
     if (al.fast) {
       ObserveExtras e1 = ex;
@@ -990,6 +1031,10 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     if (value < 0 || value > 3)
       return fail(PK_ERR_INVALID, "fast_observe: 0 (general kernels), 1 (default), 2 (always the sweep kernel) or 3 (... with eight slots)");
     f->fast_observe = (int)value;
+    return PK_OK;
+  }
+  if (!strcmp(name, "fused_step")) {
+    f->fused_step = value != 0;
     return PK_OK;
   }
   if (!strcmp(name, "assoc_dup")) {
@@ -1347,6 +1392,7 @@ int pk_timings(pk_filter* f, double ms[PK_T_COUNT], int64_t launches[PK_T_COUNT]
   }
   return PK_OK;
 }
+int pk_observe_route(const pk_filter* f) { return f ? f->route : PK_ROUTE_NONE; }
 int pk_observe_bytes(const pk_filter* f, int32_t B, int64_t* algorithmic, int64_t* moved) {
   if (!f) return fail(PK_ERR_INVALID, "pk_observe_bytes: NULL handle");
   const int64_t P = f->d.P, L = f->d.lay.L;

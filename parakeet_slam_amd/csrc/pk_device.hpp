@@ -16,6 +16,11 @@ constexpr int kWave = 64;
 constexpr int kObsThreads = 256;
 constexpr int kRedBlocks = 1024;
 
+// Workgroup barrier that orders LDS traffic only: global loads that are still in flight stay in
+// flight (__syncthreads() carries a workgroup-scope fence and waits for them, vmcnt(0)).  Only for
+// phases that exchange data through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ------------------------------------------------------------------ reductions
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

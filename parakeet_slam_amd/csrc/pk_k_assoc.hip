@@ -161,7 +161,6 @@ struct AssocGridArgs {
 
 // tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
 // `start` is cell_start (offsets into rec32) or, with DUP, col_start (offsets into idx9).
-__host__ __device__ inline size_t grid_cs_bytes(int ncell) { return ((size_t)(ncell + 1) * 2 + 15) & ~(size_t)15; }
 size_t blob_grid_table_bytes(int ncell, int B, int n9) {
   return grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + (size_t)B * 2;
 }
@@ -614,7 +613,10 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   };
   using Slots4 = std::integral_constant<int, kFastSlots>;
   using Slots8 = std::integral_constant<int, kSweepSlots>;
-  if (fh.lmpass) {
+  if (fh.flags_only) {
+    ga.only_flagged = fh.pflag;
+    go(std::true_type{}, Slots4{});  // k_step_fused did the others
+  } else if (fh.lmpass) {
     // gate tests + hand-off for every particle
     if (fh.slots == kSweepSlots)
       go(std::false_type{}, Slots8{});

@@ -535,6 +535,242 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
   hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
 }
 
+// ------------------------------------------------------------------ K2 + K3 fused (ML, L <= 512, small scan tables)
+// One workgroup per particle, one landmark per lane, from the association gates to the coalesced
+// store of the updated map: what k_assoc_grid<hand-off> and k_observe_fast do in two launches,
+// without the hand-off through HBM (no lmpass / bcount arrays, the means are read once).
+//   1. the scan tables (cell starts, fp32 records, duplicated index list) are copied to LDS; the lane
+//      loads its landmark's five means;
+//   2. gates: atan2, colour cell, 4-wide walk of the duplicated list with the conservative fp32
+//      screen, exact float64 gates (:433, :441) on the survivors; the (<= 4) passing blobs stay in
+//      registers, the per-blob counts are LDS atomics;
+//   3. a particle in which some landmark passes more than kFastSlots blobs is flagged for the general
+//      kernels and left untouched;
+//   4. everything is settled and applied exactly as in k_observe_fast (the covariance rows were
+//      requested together with the means and arrived during the gates).
+struct FusedArgs {
+  FastArgs f;                   // lmpass, bcount unused
+  BlobGrid g;
+  const unsigned char* tables;  // start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9]
+  const double* h;
+  unsigned char* pflag_out;     // [P] 1 = general route
+  unsigned* n_flagged;
+  int n9;
+};
+
+size_t fused_lds_bytes(int ncell, int B, int n9) {
+  const size_t tab = (grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + 15) & ~(size_t)15;
+  return tab + (((size_t)B * 4 + 15) & ~(size_t)15) + fast_queue_bytes() + (size_t)B * 13 + 16;
+}
+
+__global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kFastThreads / kWave];
+  __shared__ int wg_flag;
+  const FastArgs& a = fa.f;
+  const BlobGrid& g = fa.g;
+  const int64_t p = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp;
+  const size_t cs_bytes = grid_cs_bytes(g.ncell);
+  const size_t tab_bytes = (cs_bytes + (size_t)B * 16 + (size_t)fa.n9 * 2 + 15) & ~(size_t)15;
+  const unsigned short* start = reinterpret_cast<const unsigned short*>(smem);
+  const float4* rec32 = reinterpret_cast<const float4*>(smem + cs_bytes);
+  const unsigned short* idx9 = reinterpret_cast<const unsigned short*>(smem + cs_bytes + (size_t)B * 16);
+  int* ccount = reinterpret_cast<int*>(smem + tab_bytes);
+  unsigned char* qbase = smem + tab_bytes + (((size_t)B * 4 + 15) & ~(size_t)15);
+  FastQueue fq;
+  fq.det2 = reinterpret_cast<double*>(qbase);
+  fq.det3 = fq.det2 + kFastQueue;
+  fq.maha2 = fq.det3 + kFastQueue;
+  fq.maha3 = fq.maha2 + kFastQueue;
+  fq.meta = reinterpret_cast<int*>(fq.maha3 + kFastQueue);
+  fq.n = fq.meta + kFastQueue;
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(qbase + fast_queue_bytes());
+  int* win = reinterpret_cast<int*>(best + B);
+  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
+
+  const unsigned char* sslot = a.ss.at(a.src[p]);
+  unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p], sh = fa.h[p];
+  const int l = tid;
+  const bool active = l < Lp, has = l < a.L;
+  // ---- 1. tables -> LDS, own state ------------------------------------------------------------
+  // The table words are requested first and the whole state right behind them: vmcnt retires in
+  // order, so the LDS copy waits for the table words only, and every barrier of this kernel orders
+  // LDS alone -- the covariance rows arrive while the gates are worked out.
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(fa.tables);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (size_t i = tid; i < tab_bytes / 16; i += kFastThreads) dst[i] = src[i];
+  }
+  Landmark<double> A{};
+  if (active) A = load_landmark(sf, sc, Lp, l);
+  for (int t = tid; t < B; t += kFastThreads) {
+    ccount[t] = 0;
+    best[t] = 0ull;
+    win[t] = INT_MAX;
+  }
+  if (tid == 0) {
+    *fq.n = 0;
+    wg_flag = 0;
+  }
+  lds_barrier();
+  // ---- 2. gates ----------------------------------------------------------------------------------
+  unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;
+  double pseA = 0.0;
+  if (has) {
+    const double mx = A.mx, my = A.my, mr = A.mr, mg = A.mg, mb = A.mb;
+    pseA = atan2(my - sy, mx - sx);
+    const double eb = pseA - sh;  // :408
+    const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
+    int c[3];
+    const double m3[3] = {mr, mg, mb};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // same cell function as the host, see k_assoc_grid
+      double q = floor(__dmul_rn(__dsub_rn(m3[k], g.lo[k]), g.inv_h));
+      q = fmin(fmax(q, -1.0), (double)g.G[k]);
+      c[k] = (int)q;
+    }
+    const int k0 = max(c[2] - 1, 0), k1 = min(c[2] + 1, g.G[2] - 1);
+    const int r = min(max(c[0], 0), g.G[0] - 1), gg = min(max(c[1], 0), g.G[1] - 1);
+    const int base = (r * g.G[1] + gg) * g.G[2];
+    int i0 = 0, i1 = 0;
+    if (k0 <= k1) {
+      i0 = start[base + k0];
+      i1 = start[base + k1 + 1];
+    }
+    int npass = 0;
+    auto prefilter_q = [&](const float4& q) {
+      const float d0 = q.x - mr32, d1 = q.y - mg32, d2 = q.z - mb32;
+      const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
+      return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
+    };
+    auto exact_gates = [&](int tt) {
+      const double* rec = a.exact + 6 * (size_t)tt;
+      const double2 z01 = *reinterpret_cast<const double2*>(rec);
+      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+      if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
+        atomicAdd(&ccount[tt], 1);
+        if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
+        if (npass == 1) pass01 = (pass01 & 0x0000FFFFu) | ((unsigned)tt << 16);
+        if (npass == 2) pass23 = (pass23 & 0xFFFF0000u) | (unsigned)tt;
+        if (npass == 3) pass23 = (pass23 & 0x0000FFFFu) | ((unsigned)tt << 16);
+        ++npass;
+      }
+    };
+    for (int i = i0; i < i1; i += 4) {
+      int t4[4];
+      float4 q4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t4[j] = idx9[i + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q4[j] = rec32[t4[j]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j < i1 && prefilter_q(q4[j])) exact_gates(t4[j]);
+    }
+    if (npass > kFastSlots) wg_flag = 1;
+  }
+  lds_barrier();
+  // ---- 3. flagged particles go the general way ----------------------------------------------------
+  if (wg_flag) {  // workgroup-uniform
+    if (tid == 0) {
+      fa.pflag_out[p] = 1;
+      atomicAdd(fa.n_flagged, 1u);
+    }
+    return;
+  }
+  if (tid == 0) fa.pflag_out[p] = 0;
+  int nun = 0;  // blobs no landmark passes
+  for (int t = tid; t < B; t += kFastThreads) {
+    const int n = ccount[t];
+    bc[t] = (unsigned char)(n > 255 ? 255 : n);
+    nun += n == 0;
+  }
+  // ---- 4. exactly k_observe_fast from here ----------------------------------------------------------
+  lds_barrier();
+  FastSlot sa[kFastSlots];
+  fast_prepare(a, A, sx, sy, pseA, make_uint2(pass01, pass23), bc, best, fq, sa);
+  lds_barrier();
+  fast_evaluate_queue(fq, best, tid, kFastThreads);
+  lds_barrier();
+  fast_collect(fq, best, win, l, sa);
+  lds_barrier();
+  for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
+  double acc = (double)nun * Consts<double>::log_no_match;
+  if (has) acc += fast_apply(a, A, l, sx, sy, pseA, sa, win);
+  if (active) {
+    df[(size_t)F_MX * Lp + l] = A.mx;
+    df[(size_t)F_MY * Lp + l] = A.my;
+    df[(size_t)F_MR * Lp + l] = A.mr;
+    df[(size_t)F_MG * Lp + l] = A.mg;
+    df[(size_t)F_MB * Lp + l] = A.mb;
+    df[(size_t)F_PXX * Lp + l] = A.pxx;
+    df[(size_t)F_PXY * Lp + l] = A.pxy;
+    df[(size_t)F_PYY * Lp + l] = A.pyy;
+    df[(size_t)F_CRR * Lp + l] = A.crr;
+    df[(size_t)F_CRG * Lp + l] = A.crg;
+    df[(size_t)F_CRB * Lp + l] = A.crb;
+    df[(size_t)F_CGG * Lp + l] = A.cgg;
+    df[(size_t)F_CGB * Lp + l] = A.cgb;
+    df[(size_t)F_CBB * Lp + l] = A.cbb;
+    dc[l] = A.count;
+  }
+  const double tot = block_sum<kFastThreads / kWave>(acc, red);
+  if (tid == 0) {
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));
+    a.src[p] = (int32_t)p;
+  }
+}
+
+void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
+                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex) {
+  if (d.P == 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  FusedArgs fa;
+  FastArgs& a = fa.f;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = nullptr;
+  a.bcount = nullptr;
+  a.pflag = nullptr;
+  a.immutable = d.immutable;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  fa.g = grid;
+  fa.tables = tables_dev;
+  fa.h = d.h[d.cur];
+  fa.pflag_out = fh.pflag;
+  fa.n_flagged = fh.n_flagged;
+  fa.n9 = n9;
+  hipLaunchKernelGGL(k_step_fused, dim3((unsigned)d.P), dim3(kFastThreads), fused_lds_bytes(grid.ncell, B, n9), s, fa);
+}
+
 // ------------------------------------------------------------------ K3 (sweep ML variant, any L)
 // The same hand-off as k_observe_fast, for maps that do not fit one landmark per lane: persistent
 // workgroups, each particle's landmarks in chunks of kSweepThreads, two sweeps.

@@ -75,6 +75,7 @@ struct BlobGrid {
 };
 constexpr double kGridCell = 17.5;  // > sqrt(300) = 17.3205 (prkt_core_v2.py:441)
 constexpr int kGridMax = 16;
+__host__ __device__ inline size_t grid_cs_bytes(int ncell) { return ((size_t)(ncell + 1) * 2 + 15) & ~(size_t)15; }
 size_t blob_grid_table_bytes(int ncell, int B, int n9);
 size_t assoc_grid_lds_bytes(int ncell, int B, int n9);
 constexpr size_t kMaxDynLds = 156 * 1024;  // 160 KiB per workgroup minus the kernels' static __shared__
@@ -82,6 +83,7 @@ constexpr size_t kMaxDynLds = 156 * 1024;  // 160 KiB per workgroup minus the ke
 struct FastHandoff {
   uint4* lmpass = nullptr;          // [P][Lp] (slots = 4) or [P][Lp][2] (slots = 8): see k_assoc_grid
   int slots = 4;                    // gate-passing blobs a landmark can hand over: kFastSlots or kSweepSlots
+  bool flags_only = false;          // pflag / n_flagged come from k_step_fused: run the general instance on the flagged only
   unsigned char* bcount = nullptr;  // [P][B]
   unsigned char* pflag = nullptr;   // [P]
   unsigned* n_flagged = nullptr;    // number of flagged particles of this scan
@@ -125,6 +127,14 @@ SweepPlan observe_sweep_plan(const DeviceState& d, int B);
 void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
                           const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
                           const ObserveExtras& ex, const SweepPlan& plan, uint4* results_dev);
+// K2 + K3 fused for L <= kFastMaxL and scan tables small enough for two workgroups per CU: gates,
+// settling and EKF update of a particle in one workgroup, no hand-off through HBM.  Writes fh.pflag /
+// fh.n_flagged (particles left to the general kernels).
+size_t fused_lds_bytes(int ncell, int B, int n9);
+constexpr size_t kFusedMaxLds = 78 * 1024;
+void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
+                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex);
 extern int g_observe_nv;
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);

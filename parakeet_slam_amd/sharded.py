@@ -287,6 +287,9 @@ class ShardedFilter(object):
     def timings(self):
         return self.f.timings()
 
+    def observe_route(self):
+        return self.f.observe_route() if hasattr(self.f, "observe_route") else "none"
+
     def close(self):
         self.f.close()
 

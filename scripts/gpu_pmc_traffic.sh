@@ -17,7 +17,10 @@ ids = np.arange(1, L + 1, dtype=np.int32)
 for s in range(3):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, ids=ids, domain=1)   # k_observe<true,2>
 for s in range(3, 6):
-    f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)            # k_assoc_grid + k_observe<false,1>
+    f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)            # k_step_fused
+f.set_option("fused_step", 0)
+for s in range(3, 6):
+    f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)            # k_assoc_grid hand-off + k_observe_fast
 f.download_landmarks(0, 1)                                                     # k_copy_slots: P slots copied
 f.synchronize()
 print("slot_bytes", f.particle_bytes() - 32)
@@ -35,7 +38,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob('gpurun_out/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            key = 'observe_known' if 'k_observe<true' in k else 'observe_ml' if 'k_observe_fast' in k else 'assoc_grid' if ('k_assoc_grid' in k and 'false>' in k) else 'copy_slots' if 'k_copy_slots' in k else None
+            key = 'observe_known' if 'k_observe<true' in k else 'step_fused' if 'k_step_fused' in k else 'observe_ml' if 'k_observe_fast' in k else 'assoc_grid' if ('k_assoc_grid' in k and ', false, ' in k) else 'copy_slots' if 'k_copy_slots' in k else None
             if key: res[key][c].append(float(r['Counter_Value']))
 out = {}
 for k, v in res.items():

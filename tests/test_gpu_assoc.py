@@ -170,11 +170,12 @@ def test_observe_with_both_kernels_gives_identical_state(lib):
 
 
 # ---------------------------------------------------------------- fast hand-off path (L <= 512)
-def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1):
+def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1, fused=1):
     L = means.shape[0]
     f = lib.DeviceFilter(P, L)
     f.set_option("fast_observe", fast)
     f.set_option("assoc_dup", dup)
+    f.set_option("fused_step", fused)
     f.upload_map(means, covs.reshape(L, 25), immutable)
     f.upload_poses(poses)
     f.observe(blobs)  # no ids requested: the production route
@@ -191,10 +192,14 @@ def oracle_state(P, means, covs, poses, blobs, immutable=None):
 
 
 def check_fast(lib, P, means, covs, poses, blobs, immutable=None):
-    """fast_observe = 1: k_observe_fast (L <= 512) / k_observe_sweep (above); 2: k_observe_sweep for
-    every L; 3: the same with eight hand-off slots per landmark; 0: the general kernels.  All
-    four against the oracle, and against each other."""
+    """fast_observe = 1: k_step_fused, or with fused_step = 0 the hand-off + k_observe_fast
+    (L <= 512) / k_observe_sweep (above); 2: k_observe_sweep for every L; 3: the same with eight
+    hand-off slots per landmark; 0: the general kernels.  All against the oracle and each other."""
     fast = observe_state(lib, P, means, covs, poses, blobs, 1, immutable)
+    two = observe_state(lib, P, means, covs, poses, blobs, 1, immutable, fused=0)
+    assert np.array_equal(fast[0], two[0])  # same arithmetic, one kernel or two
+    for x, y in zip(fast[1], two[1]):
+        assert np.array_equal(x, y)
     gen = observe_state(lib, P, means, covs, poses, blobs, 0, immutable)
     sweep = observe_state(lib, P, means, covs, poses, blobs, 2, immutable)
     sweep8 = observe_state(lib, P, means, covs, poses, blobs, 3, immutable)
