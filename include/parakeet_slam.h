@@ -150,6 +150,10 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
  *   ids_out: NULL or P*B int32 receiving the ids each particle used. */
 int pk_observe(pk_filter* f, const double* blobs, int32_t num_blobs, const int32_t* ids,
                int32_t* ids_out);
+/* pk_reset_weights + pk_observe in one pass over the particles: every weight restarts from 1
+ * (prkt_core_v2.py:73) before the scan is applied -- what cam_cb does, and what pk_step uses. */
+int pk_observe_fresh(pk_filter* f, const double* blobs, int32_t num_blobs, const int32_t* ids,
+                     int32_t* ids_out);
 
 /* Data association alone (FilterParticle.match_features_to_scan, prkt_core_v2.py:317-351):
  * ids_out[P*B] receives, per particle, the landmark id each blob matches (0 = none).

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pk_reset_weights": (C.c_int, [_h]),
     "pk_motion": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64]),
     "pk_observe": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
+    "pk_observe_fresh": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
     "pk_associate": (C.c_int, [_h, _dp, C.c_int32, _ip]),
     "pk_resample": (C.c_int, [_h, C.c_double, C.c_int32, _lp]),
     "pk_summary": (C.c_int, [_h, _dp]),
@@ -225,12 +226,14 @@ class DeviceFilter(object):
         zz = f64(z, (self.P, 3)) if z is not None else None
         check(self._lib.pk_motion(self._h, float(v), float(w), float(dt), dptr(zz), int(seed), int(draw)))
 
-    def observe(self, blobs, ids=None, return_ids=False):
+    def observe(self, blobs, ids=None, return_ids=False, fresh=False):
+        """fresh: the weights restart from 1 first (prkt_core_v2.py:73), fused into the same kernels."""
         b = f64(blobs).reshape(-1, 4)
         B = b.shape[0]
         i = np.ascontiguousarray(ids, dtype=np.int32).reshape(B) if ids is not None else None
         out = np.empty((self.P, B), dtype=np.int32) if return_ids else None
-        check(self._lib.pk_observe(self._h, dptr(b), B, iptr(i), iptr(out)))
+        fn = self._lib.pk_observe_fresh if fresh else self._lib.pk_observe
+        check(fn(self._h, dptr(b), B, iptr(i), iptr(out)))
         return out
 
     def associate(self, blobs):

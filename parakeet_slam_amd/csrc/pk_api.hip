@@ -1005,6 +1005,10 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
   return observe_impl(f, blobs, B, ids, ids_out, false);
 }
 
+int pk_observe_fresh(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out) {
+  return observe_impl(f, blobs, B, ids, ids_out, true);
+}
+
 int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out) {
   if (!f || !ids_out) return fail(PK_ERR_INVALID, "pk_associate: NULL argument");
   if (B < 0 || (B > 0 && !blobs)) return fail(PK_ERR_INVALID, "pk_associate: bad blobs");

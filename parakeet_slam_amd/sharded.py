@@ -262,8 +262,9 @@ class ShardedFilter(object):
     def motion(self, v, w, dt, z=None, seed=0, draw=0):
         return self.f.motion(v, w, dt, z=z, seed=seed, draw=draw)
 
-    def observe(self, blobs, ids=None, return_ids=False):
-        out = self.f.observe(blobs, ids=ids, return_ids=return_ids)
+    def observe(self, blobs, ids=None, return_ids=False, fresh=False):
+        out = self.f.observe(blobs, ids=ids, return_ids=return_ids, fresh=fresh) if fresh else \
+            self.f.observe(blobs, ids=ids, return_ids=return_ids)
         self._recv_keepalive = None  # adopted slots were rewritten into the shard's own map (stream-ordered free)
         return out
 
@@ -362,9 +363,8 @@ class ShardedFilter(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(like.device)
 
     def step(self, v, w, dt, blobs, u, z=None, seed=0, draw=0, ids=None, domain=_lib.PK_WEIGHTS_LINEAR):
-        self.reset_weights()
         self.motion(v, w, dt, z=z, seed=seed, draw=draw)
-        self.observe(blobs, ids=ids)
+        self.observe(blobs, ids=ids, fresh=True)  # weight reset (:73) fused into the observe kernels
         self.resample(u, domain=domain)
 
     def summary(self):

@@ -40,7 +40,9 @@ class OracleShard(object):
     def motion(self, v, w, dt, z=None, seed=0, draw=0):
         self.o.motion(v, w, dt, z)
 
-    def observe(self, blobs, ids=None, return_ids=False):
+    def observe(self, blobs, ids=None, return_ids=False, fresh=False):
+        if fresh:
+            self.o.reset_weights()
         return self.o.observe(blobs, ids)
 
     def download_poses(self):

@@ -204,3 +204,40 @@ def test_device_noise_matches_numpy_philox_and_is_shard_invariant(lib):
     z = device_normals(200000, 99, 3)
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.01
     f.close()
+
+
+@pytest.mark.parametrize("ids_given", [False, True])
+def test_observe_fresh_equals_reset_then_observe(lib, ids_given):
+    """pk_observe_fresh = pk_reset_weights + pk_observe (prkt_core_v2.py:73 fused into the kernels)."""
+    from oracle.fastslam_oracle import synthetic_scan, synthetic_world
+
+    rs = np.random.RandomState(5)
+    L, P = 90, 70
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.03, 0.01, -0.02))
+    poses = np.column_stack([rs.normal(0, 0.2, P), rs.normal(0, 0.2, P), rs.normal(0, 0.05, P), rs.uniform(0.1, 2.0, P)])
+    ids = np.arange(1, L + 1, dtype=np.int32) if ids_given else None
+    out = []
+    for fresh in (False, True):
+        f = lib.DeviceFilter(P, L)
+        f.upload_map(means, covs.reshape(L, 25))
+        f.upload_poses(poses)
+        if fresh:
+            f.observe(blobs, ids=ids, fresh=True)
+        else:
+            f.reset_weights()
+            f.observe(blobs, ids=ids)
+        out.append((f.download_poses(), f.download_landmarks(), f.observe_route()))
+        f.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    assert out[0][2] == out[1][2] == ("known_ids" if ids_given else "ml_fused")
+    # and without the reset the old weights stay in the product
+    f = lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    f.upload_poses(poses)
+    f.observe(blobs, ids=ids)
+    w = f.download_poses()[:, 3]
+    f.close()
+    assert np.allclose(w, poses[:, 3] * out[1][0][:, 3], rtol=1e-12)
