@@ -987,9 +987,15 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
         const double pse = entry_pse(l);
         // per slot: scan index << 16 | blob when the update is applied, else 0xFFFFFFFF
         unsigned key[SLOTS];
-        bool have_inv = false;
-        double det2 = 0.0, det3 = 0.0;
-        Sym3<double> inv3{};
+        // Division-free sufficient test for "probability certainly > 0" (all an uncontested blob
+        // needs, :369-381).  With P, C positive definite (Sylvester's criterion),
+        //   maha2 = e' P^-1 e <= |e|^2 / lmin(P) <= |e|^2 tr(P) / det(P)
+        //   maha3 = d' C^-1 d <= |d|^2 / lmin(C) <= |d|^2 m2(C) / det(C),  m2 = sum of principal 2x2 minors
+        // so maha2 + maha3 < 800 follows from |e|^2 tr det3 + |d|^2 m2 det2 < 800 det2 det3, and then
+        // pr = (500 exp(a1)) (500 exp(a2)) / 250000 has a1 + a2 > -543 (log det <= 138.2 for det <= 1e60):
+        // no underflow.  Pairs that fail it are evaluated exactly as the reference does.
+        bool have_q = false, spd = false;
+        double det2 = 0.0, det3 = 0.0, tr2 = 0.0, m2 = 0.0, lim = 0.0;
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) key[k] = 0xFFFFFFFFu;
 #pragma unroll 1
@@ -1005,26 +1011,34 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
             const double2 z01 = *reinterpret_cast<const double2*>(rec);
             const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
             const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
-            if (!have_inv) {
+            if (!have_q) {
               det2 = A.pxx * A.pyy - A.pxy * A.pxy;
-              inv3 = sym3_inverse(Sym3<double>{A.crr, A.crg, A.crb, A.cgg, A.cgb, A.cbb}, det3);
-              have_inv = true;
+              const double c00 = A.cgg * A.cbb - A.cgb * A.cgb;
+              const double c11 = A.crr * A.cbb - A.crb * A.crb;
+              const double c22 = A.crr * A.cgg - A.crg * A.crg;
+              det3 = A.crr * c00 + A.crg * (A.crb * A.cgb - A.crg * A.cbb) + A.crb * (A.crg * A.cgb - A.crb * A.cgg);
+              tr2 = A.pxx + A.pyy;
+              m2 = c00 + c11 + c22;
+              spd = A.pxx > 0.0 && det2 > 0.0 && det2 < 1e60 && A.crr > 0.0 && c22 > 0.0 && det3 > 0.0 && det3 < 1e60 &&
+                    tr2 < 1e100 && m2 < 1e100;
+              lim = 800.0 * det2 * det3;
+              have_q = true;
             }
             apply = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
             if (apply) {
               double nx, ny;
               closest_point(A.mx, A.my, sx, sy, dir.x, dir.y, nx, ny);
               const double ex = nx - A.mx, ey = ny - A.my;
-              const double maha2 = (A.pyy * ex * ex - 2.0 * A.pxy * ex * ey + A.pxx * ey * ey) / det2;
-              const double maha3 = sym3_quad(inv3, z01.y - A.mr, z23.x - A.mg, z23.y - A.mb);
-              // pr = (500 exp(a1)) (500 exp(a2)) / 250000 is certainly > 0 far from the underflow
-              // edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 here
-              const bool sure = det2 > 0.0 && det2 < 1e60 && det3 > 0.0 && det3 < 1e60 && maha2 >= 0.0 &&
-                                maha3 >= 0.0 && maha2 + maha3 < 800.0;
-              if (!sure) {
-                double d2 = det2, d3 = det3;
-                asm volatile("" : "+v"(d2), "+v"(d3));
-                apply = pr_from_parts(d2, d3, maha2, maha3) > 0.0;
+              const double d1 = z01.y - A.mr, d2c = z23.x - A.mg, d3c = z23.y - A.mb;
+              const bool sure = spd && (ex * ex + ey * ey) * tr2 * det3 + (d1 * d1 + d2c * d2c + d3c * d3c) * m2 * det2 < lim;
+              if (!sure) {  // rare: tiny or indefinite covariances, far-off closest points
+                double e2 = ex, e3 = ey;
+                asm volatile("" : "+v"(e2), "+v"(e3));  // opaque: keeps the divisions out of the code every lane runs
+                double det3b;
+                const Sym3<double> inv3 = sym3_inverse(Sym3<double>{A.crr, A.crg, A.crb, A.cgg, A.cgb, A.cbb}, det3b);
+                const double maha2 = (A.pyy * e2 * e2 - 2.0 * A.pxy * e2 * e3 + A.pxx * e3 * e3) / det2;
+                const double maha3 = sym3_quad(inv3, d1, d2c, d3c);
+                apply = pr_from_parts(det2, det3b, maha2, maha3) > 0.0;
               }
             }
             if (!apply) acc += Consts<double>::log_no_match;  // probability 0: unseen feature (:94-95)
