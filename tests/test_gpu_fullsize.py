@@ -52,10 +52,14 @@ def run_steps(lib, steps, opts, ids=None, seed=7, return_filter=False):
 
 
 def test_routes_agree_at_full_size(lib):
-    fast = run_steps(lib, 3, {"fast_observe": 1})
+    fast = run_steps(lib, 3, {"fast_observe": 1})  # k_step_fused
+    two = run_steps(lib, 3, {"fast_observe": 1, "fused_step": 0})  # hand-off + k_observe_fast
+    sweep = run_steps(lib, 3, {"fast_observe": 2})  # hand-off + k_observe_sweep
     gen = run_steps(lib, 3, {"fast_observe": 0})
     brute = run_steps(lib, 3, {"fast_observe": 0, "assoc_kernel": 1})
-    for other in (gen, brute):
+    for x, y in zip(fast[:4], two[:4]):
+        assert np.array_equal(x, y), "one kernel or two: same device functions, same bits"
+    for other in (sweep, gen, brute):
         for s in range(3):
             assert np.array_equal(fast[4][s][1], other[4][s][1]), "ancestors differ between association routes"
             assert np.allclose(fast[4][s][0], other[4][s][0], rtol=1e-10, atol=0)
@@ -142,3 +146,48 @@ def test_config3_slice_known_vs_ml(lib):
     assert np.array_equal(out[0][0], out[1][0]), "near the true pose ML association must recover the identity"
     assert np.allclose(out[0][1], out[1][1], rtol=1e-10)
     assert np.allclose(out[0][2][0], out[1][2][0], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("Lb,Pb", [(2000, 384), (5000, 96)])
+def test_large_map_slices_production_route_vs_general_vs_known(lib, Lb, Pb):
+    """Map sizes of BASELINE.json configs[2] and configs[4] (a slice of their particles): the
+    production ML route (hand-off + k_observe_sweep, eight slots per landmark at 5 000 blobs), the
+    general ML route and supplied ids leave the same state for particles near the true pose."""
+    means, covs = synthetic_world(Lb)
+    pose = truth_step((0, 0, 0), 0.2, 0.1, 0.1)
+    blobs = synthetic_scan(means, pose)
+    poses = np.zeros((Pb, 4))
+    poses[:, :3] = pose
+    poses[:, 0] += np.random.RandomState(2).normal(0, 0.01, Pb)
+    poses[:, 1] += np.random.RandomState(3).normal(0, 0.01, Pb)
+    poses[:, 3] = 1.0
+    out = {}
+    ml_ids = None
+    for name, opts, ids in (("sweep", {"fast_observe": 1}, None), ("general", {"fast_observe": 0}, None),
+                            ("known", {}, np.arange(1, Lb + 1))):
+        f = lib.DeviceFilter(Pb, Lb)
+        for k, v in opts.items():
+            f.set_option(k, v)
+        f.upload_map(means, covs.reshape(Lb, 25))
+        f.upload_poses(poses)
+        if name == "general":
+            ml_ids = f.observe(blobs, return_ids=True)
+        else:
+            f.observe(blobs, ids=ids)
+        out[name] = (f.download_poses(), f.download_landmarks(0, 24), f.observe_route())
+        f.close()
+    assert out["sweep"][2] == "ml_sweep" and out["general"][2] == "ml_general" and out["known"][2] == "known_ids"
+
+    def same(a, b, rows):
+        assert np.allclose(a[0][rows], b[0][rows], rtol=1e-10, atol=0)
+        r24 = rows[:24] if rows.dtype == bool else rows
+        assert np.allclose(a[1][0][r24], b[1][0][r24], rtol=1e-11, atol=1e-12)
+        assert np.allclose(a[1][1][r24], b[1][1][r24], rtol=1e-10, atol=1e-14)
+        assert np.array_equal(a[1][2][r24], b[1][2][r24])
+
+    same(out["sweep"], out["general"], np.ones(Pb, dtype=bool))
+    # where maximum likelihood recovers the identity (many of the particles this close to the true pose),
+    # the supplied-ids kernel must leave the same state too
+    ident = (ml_ids == np.arange(1, Lb + 1)[None, :]).all(axis=1)
+    assert ident.sum() >= 8
+    same(out["sweep"], out["known"], ident)
