@@ -98,6 +98,10 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    k_observe_sweep in two sweeps over landmark chunks above that), 0 (general
  *                    path: association kernel writes ids), 2 (k_observe_sweep for every L) or 3 (the same with
  *                    eight hand-off slots per landmark, the default only for scans of >= 3000 blobs);
+ *   "timing_stride" = 1 (default) .. n: with pk_enable_timing, bracket only every n-th launch of a
+ *                    slot (two event records cost the stream a few microseconds each time);
+ *   "upload_kernel" = 1 (default: the per-scan block is read from pinned host memory by a small
+ *                    kernel in stream order) or 0 (hipMemcpyAsync);
  *   "fused_step"   = 1 (default: with "fast_observe" = 1, L <= 512 and scan tables that fit LDS twice
  *                    per CU, gates + settling + EKF update of a particle run in ONE kernel,
  *                    k_step_fused, without the hand-off through HBM) or 0;

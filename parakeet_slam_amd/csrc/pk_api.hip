@@ -82,6 +82,7 @@ struct pk_filter {
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
   int route = PK_ROUTE_NONE;  // kernels used by the last observe
+  int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
   int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
   uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
@@ -106,6 +107,8 @@ struct pk_filter {
   unsigned char* slot_tmp = nullptr;  // one slot
   // timing
   uint32_t timing_mask = 0;  // bit i: PK_T_* slot i is bracketed by hipEvents
+  int timing_stride = 1;     // ... every timing_stride-th time the slot comes up (sampling keeps the probe cheap)
+  int64_t timing_seen[PK_T_COUNT] = {0};
   std::vector<TimedSpan> pending;
   std::vector<hipEvent_t> pool;
   double ms[PK_T_COUNT] = {0};
@@ -133,6 +136,7 @@ struct Span {
   hipEvent_t a = nullptr, b = nullptr;
   Span(pk_filter* f_, int slot_) : f(f_), slot(slot_) {
     if (!((f->timing_mask >> slot_) & 1u)) return;
+    if (f->timing_seen[slot_]++ % f->timing_stride != 0) return;
     a = take();
     b = take();
     if (a) (void)hipEventRecord(a, f->stream);
@@ -207,6 +211,20 @@ int ensure_ids_capacity(pk_filter* f, int B) {
   return PK_OK;
 }
 
+// One scan block host -> device in stream order.  The staging ring is pinned and device-mapped, so
+// a small kernel reads it directly (k_upload); sizes are padded to 16 bytes on both sides.  Falls
+// back to the copy engine when the mapping is not available.
+int upload_scan(pk_filter* f, const unsigned char* st, size_t bytes) {
+  void* dev_view = nullptr;
+  if (f->upload_kernel && hipHostGetDevicePointer(&dev_view, const_cast<unsigned char*>(st), 0) == hipSuccess && dev_view) {
+    launch_upload(f->stream, f->scan_dev, dev_view, bytes);
+    return PK_OK;
+  }
+  (void)hipGetLastError();
+  PK_HIP(hipMemcpyAsync(f->scan_dev, st, bytes, hipMemcpyHostToDevice, f->stream));
+  return PK_OK;
+}
+
 // Next pinned staging block of at least `bytes`; waits for the upload that last used it.
 int take_stage(pk_filter* f, size_t bytes, unsigned char** out, int* slot) {
   if (bytes > f->stage_cap) {
@@ -215,7 +233,7 @@ int take_stage(pk_filter* f, size_t bytes, unsigned char** out, int* slot) {
     for (int i = 0; i < pk_filter::kRing; ++i) {
       if (f->stage[i]) (void)hipHostFree(f->stage[i]);
       f->stage[i] = nullptr;
-      PK_HIP(hipHostMalloc((void**)&f->stage[i], cap, hipHostMallocDefault));
+      PK_HIP(hipHostMalloc((void**)&f->stage[i], cap, hipHostMallocMapped));
       if (!f->stage_done[i]) PK_HIP(hipEventCreateWithFlags(&f->stage_done[i], hipEventDisableTiming));
     }
     f->stage_cap = cap;
@@ -468,7 +486,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
     tab_bytes = (blob_grid_table_bytes(g.ncell, B, n9) + 15) & ~(size_t)15;
     if (assoc_grid_lds_bytes(g.ncell, B, n9) > kMaxDynLds) use_grid = false;  // scan too large for LDS tables
   }
-  PK_HIP(hipMemcpyAsync(f->scan_dev, st, use_grid ? o_tab + tab_bytes : o_exact, hipMemcpyHostToDevice, f->stream));
+  if ((rc = upload_scan(f, st, use_grid ? o_tab + tab_bytes : o_exact))) return rc;
   PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
   f->gmax_fused = false;
   const double* blobs_dev = reinterpret_cast<const double*>(f->scan_dev + o_blobs);
@@ -923,7 +941,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
         next[last[id - 1]] = b;
       last[id - 1] = b;
     }
-    PK_HIP(hipMemcpyAsync(f->scan_dev, st, total, hipMemcpyHostToDevice, f->stream));
+    if ((rc = upload_scan(f, st, total))) return rc;
     PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
     ex.gmax_key = ctl_gmax_key(f);
     {
@@ -1035,6 +1053,15 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     if (value < 0 || value > 3)
       return fail(PK_ERR_INVALID, "fast_observe: 0 (general kernels), 1 (default), 2 (always the sweep kernel) or 3 (... with eight slots)");
     f->fast_observe = (int)value;
+    return PK_OK;
+  }
+  if (!strcmp(name, "timing_stride")) {
+    if (value < 1 || value > 1000000) return fail(PK_ERR_INVALID, "timing_stride: 1 .. 1000000");
+    f->timing_stride = (int)value;
+    return PK_OK;
+  }
+  if (!strcmp(name, "upload_kernel")) {
+    f->upload_kernel = value != 0;
     return PK_OK;
   }
   if (!strcmp(name, "fused_step")) {
@@ -1382,6 +1409,7 @@ int pk_reset_timings(pk_filter* f) {
   for (int i = 0; i < PK_T_COUNT; ++i) {
     f->ms[i] = 0;
     f->launches[i] = 0;
+    f->timing_seen[i] = 0;
   }
   return PK_OK;
 }

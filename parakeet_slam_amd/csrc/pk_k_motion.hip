@@ -75,6 +75,23 @@ void launch_iota(hipStream_t s, int32_t* p, int64_t n) {
   hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
 }
 
+// Per-scan upload: a few workgroups read the pinned host block over PCIe and write it to HBM.
+// For the <= 100 KB of a scan this takes a few microseconds in stream order, where a
+// hipMemcpyAsync (copy engine hand-over on both sides) left the kernels of the step waiting
+// for ~25 us.  n16 = number of 16-byte words.
+__global__ void __launch_bounds__(256) k_upload(uint4* __restrict__ dst, const uint4* __restrict__ src, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+void launch_upload(hipStream_t s, void* dst_dev, const void* src_host_mapped, size_t bytes) {
+  const int64_t n16 = (int64_t)((bytes + 15) / 16);
+  if (n16 == 0) return;
+  int64_t nb = (n16 + 255) / 256;
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(k_upload, dim3((unsigned)nb), dim3(256), 0, s, static_cast<uint4*>(dst_dev),
+                     static_cast<const uint4*>(src_host_mapped), n16);
+}
+
 // ------------------------------------------------------------------ K6 summary
 __global__ void __launch_bounds__(256) k_summary_partials(const double* __restrict__ x,
                                                           const double* __restrict__ y,

@@ -171,5 +171,7 @@ void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
                       const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
+// scan block: pinned (device-mapped) host memory -> HBM by a kernel, in stream order
+void launch_upload(hipStream_t s, void* dst_dev, const void* src_host_mapped, size_t bytes);
 
 }  // namespace pk
