@@ -158,6 +158,13 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t num_blobs, const int32
  * (prkt_core_v2.py:73) before the scan is applied -- what cam_cb does, and what pk_step uses. */
 int pk_observe_fresh(pk_filter* f, const double* blobs, int32_t num_blobs, const int32_t* ids,
                      int32_t* ids_out);
+/* The same in two halves, for callers that have host work to hide: pk_stage_scan does the HOST
+ * part of a maximum-likelihood observe (checks, ray directions, association tables, all into a
+ * pinned staging slot; no kernel is launched), pk_observe_staged enqueues the upload and the
+ * kernels for the scan staged last (fresh != 0: weights restart from 1 first).  Any other
+ * observe / associate call in between discards the staged scan. */
+int pk_stage_scan(pk_filter* f, const double* blobs, int32_t num_blobs);
+int pk_observe_staged(pk_filter* f, int32_t fresh);
 
 /* Data association alone (FilterParticle.match_features_to_scan, prkt_core_v2.py:317-351):
  * ids_out[P*B] receives, per particle, the landmark id each blob matches (0 = none).

@@ -52,6 +52,8 @@ SIGNATURES = {
     "pk_motion": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64]),
     "pk_observe": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
     "pk_observe_fresh": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
+    "pk_stage_scan": (C.c_int, [_h, _dp, C.c_int32]),
+    "pk_observe_staged": (C.c_int, [_h, C.c_int32]),
     "pk_associate": (C.c_int, [_h, _dp, C.c_int32, _ip]),
     "pk_resample": (C.c_int, [_h, C.c_double, C.c_int32, _lp]),
     "pk_summary": (C.c_int, [_h, _dp]),
@@ -235,6 +237,15 @@ class DeviceFilter(object):
         fn = self._lib.pk_observe_fresh if fresh else self._lib.pk_observe
         check(fn(self._h, dptr(b), B, iptr(i), iptr(out)))
         return out
+
+    def stage_scan(self, blobs):
+        """Host half of an ML observe (tables into a pinned staging slot), no kernel launched."""
+        b = f64(blobs).reshape(-1, 4)
+        check(self._lib.pk_stage_scan(self._h, dptr(b), b.shape[0]))
+
+    def observe_staged(self, fresh=False):
+        """Device half: upload + kernels for the scan staged last."""
+        check(self._lib.pk_observe_staged(self._h, 1 if fresh else 0))
 
     def associate(self, blobs):
         b = f64(blobs).reshape(-1, 4)

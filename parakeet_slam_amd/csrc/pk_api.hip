@@ -81,6 +81,17 @@ struct pk_filter {
   int64_t rlohi_cap = 0;
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
+  // host half of an ML scan upload done ahead of time (pk_stage_scan): tables built in a staging slot
+  struct Staged {
+    bool valid = false;
+    int B = 0;
+    unsigned char* st = nullptr;
+    int slot = 0;
+    BlobGrid g{};
+    int n9 = 0;
+    bool use_grid = false;
+    size_t tab_bytes = 0;
+  } staged;
   int route = PK_ROUTE_NONE;  // kernels used by the last observe
   int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
   int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
@@ -454,15 +465,17 @@ int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true) {
 inline unsigned long long* ctl_gmax_key(pk_filter* f) { return reinterpret_cast<unsigned long long*>(f->scan_dev); }
 inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys); }
 
-// Upload one scan for maximum-likelihood association (one copy) and enqueue the association.
-int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize, bool want_fast, AssocLaunch* out) {
+// Host half of the ML scan upload: blobs, ray directions, exact records and the association tables
+// are laid out in a pinned staging slot (no device work; may synchronise only to grow buffers).
+// block: ctl | blobs (4B) | dir (2B) | exact (6B) doubles | tables
+int stage_ml_scan(pk_filter* f, const double* blobs, int B) {
   int rc;
   if (B > 65535) return fail(PK_ERR_UNSUPPORTED, "maximum-likelihood association handles at most 65535 blobs per scan (got %d)", B);
   if ((rc = ensure_ids_capacity(f, B))) return rc;
-  BlobGrid g{};
+  pk_filter::Staged& sg = f->staged;
+  sg.valid = false;
   const int ncell_max = kGridMax * kGridMax * kGridMax;
   const size_t tab_max = (blob_grid_table_bytes(ncell_max, B, 9 * B + 16) + 15) & ~(size_t)15;
-  // block: ctl | blobs (4B) | dir (2B) | exact (6B) doubles | tables
   const size_t o_blobs = kCtlBytes;
   const size_t o_dir = o_blobs + (size_t)B * 4 * sizeof(double);
   const size_t o_exact = o_dir + (size_t)B * 2 * sizeof(double);
@@ -472,20 +485,46 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   if ((rc = take_stage(f, o_tab + tab_max + 16, &st, &slot))) return rc;
   if ((rc = ensure_scan_capacity(f, o_tab + tab_max + 16))) return rc;
   memset(st, 0, kCtlBytes);
-  memcpy(st + o_blobs, blobs, (size_t)B * 4 * sizeof(double));
+  memmove(st + o_blobs, blobs, (size_t)B * 4 * sizeof(double));
   double* dir = reinterpret_cast<double*>(st + o_dir);
   blob_directions(blobs, B, dir);
   // the grid kernel keeps landmark indices as u16 and its tables in LDS
-  bool use_grid = f->assoc_kernel == 0 && f->d.lay.L <= 65535;
-  size_t tab_bytes = 0;
-  int n9 = 0;
-  if (use_grid) {
+  sg.use_grid = f->assoc_kernel == 0 && f->d.lay.L <= 65535;
+  sg.tab_bytes = 0;
+  sg.n9 = 0;
+  sg.g = BlobGrid{};
+  if (sg.use_grid) {
     // duplicated column lists when they fit in LDS (about 48 B per blob), else the 9-range walk
     bool dup = f->assoc_dup && assoc_grid_lds_bytes(ncell_max, B, 9 * B + 16) <= kMaxDynLds;
-    build_blob_grid(blobs, dir, B, dup, g, st + o_tab, reinterpret_cast<double*>(st + o_exact), &n9);
-    tab_bytes = (blob_grid_table_bytes(g.ncell, B, n9) + 15) & ~(size_t)15;
-    if (assoc_grid_lds_bytes(g.ncell, B, n9) > kMaxDynLds) use_grid = false;  // scan too large for LDS tables
+    build_blob_grid(blobs, dir, B, dup, sg.g, st + o_tab, reinterpret_cast<double*>(st + o_exact), &sg.n9);
+    sg.tab_bytes = (blob_grid_table_bytes(sg.g.ncell, B, sg.n9) + 15) & ~(size_t)15;
+    if (assoc_grid_lds_bytes(sg.g.ncell, B, sg.n9) > kMaxDynLds) sg.use_grid = false;  // scan too large for LDS tables
   }
+  sg.B = B;
+  sg.st = st;
+  sg.slot = slot;
+  sg.valid = true;
+  return PK_OK;
+}
+
+// Upload one scan for maximum-likelihood association (one block) and enqueue the association.
+// `blobs` may be the staged copy itself (pk_observe_staged).
+int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize, bool want_fast, AssocLaunch* out) {
+  int rc;
+  pk_filter::Staged& sg = f->staged;
+  const size_t o_blobs = kCtlBytes;
+  const size_t o_dir = o_blobs + (size_t)B * 4 * sizeof(double);
+  const size_t o_exact = o_dir + (size_t)B * 2 * sizeof(double);
+  const size_t o_tab = o_exact + (size_t)B * 6 * sizeof(double);
+  if (!(sg.valid && sg.B == B && blobs == reinterpret_cast<const double*>(sg.st + o_blobs)))
+    if ((rc = stage_ml_scan(f, blobs, B))) return rc;
+  sg.valid = false;  // consumed
+  unsigned char* st = sg.st;
+  const int slot = sg.slot;
+  const BlobGrid g = sg.g;
+  const int n9 = sg.n9;
+  const bool use_grid = sg.use_grid;
+  const size_t tab_bytes = sg.tab_bytes;
   if ((rc = upload_scan(f, st, use_grid ? o_tab + tab_bytes : o_exact))) return rc;
   PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
   f->gmax_fused = false;
@@ -911,6 +950,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   ObserveExtras ex;
   ex.reset = reset;
   if (ids) {
+    f->staged.valid = false;  // a staged ML scan does not survive another observe
     // block: ctl | blobs (4B doubles) | first (Lp int32) | next (B int32)
     const size_t o_blobs = kCtlBytes;
     const size_t o_first = o_blobs + (size_t)B * 4 * sizeof(double);
@@ -1025,6 +1065,24 @@ int pk_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids,
 
 int pk_observe_fresh(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out) {
   return observe_impl(f, blobs, B, ids, ids_out, true);
+}
+
+int pk_stage_scan(pk_filter* f, const double* blobs, int32_t B) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_stage_scan: NULL handle");
+  if (B < 1 || !blobs) return fail(PK_ERR_INVALID, "pk_stage_scan: needs at least one blob");
+  if (!f->map_loaded) return fail(PK_ERR_STATE, "pk_stage_scan: no map uploaded (pk_upload_map)");
+  for (int i = 0; i < 4 * B; ++i)
+    if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_stage_scan: blob %d is not finite", i / 4);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  return stage_ml_scan(f, blobs, B);
+}
+
+int pk_observe_staged(pk_filter* f, int32_t fresh) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_observe_staged: NULL handle");
+  if (!f->staged.valid) return fail(PK_ERR_STATE, "pk_observe_staged: no staged scan (pk_stage_scan)");
+  const double* blobs = reinterpret_cast<const double*>(f->staged.st + kCtlBytes);
+  return observe_impl(f, blobs, f->staged.B, nullptr, nullptr, fresh != 0);
 }
 
 int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out) {

@@ -217,6 +217,22 @@ class HipShard(_lib.DeviceFilter):
     def adopt_from(self, rank, recv, n_received):
         self.shard_adopt_dev(rank, recv.data_ptr() if (recv is not None and n_received) else 0, n_received)
 
+    def start_host_read(self, t):
+        """Begin copying a small device tensor to pinned host memory on the shard's stream; returns a
+        handle for finish_host_read.  Lets the caller do host work before it has to wait."""
+        torch = self.torch
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.tdev))
+        return host, ev
+
+    @staticmethod
+    def finish_host_read(handle):
+        host, ev = handle
+        ev.synchronize()
+        return host.numpy()
+
 
 class ShardedFilter(object):
     """One shard of a FastSLAM filter: same methods as ``_lib.DeviceFilter`` for what bench.py
@@ -241,6 +257,7 @@ class ShardedFilter(object):
         self._all_ranges = f.new_i64(2 * self.world * self.world)
         self._sums = f.new_f64(4)
         self._recv_keepalive = None
+        self._pending = None  # a resample whose exchange has been planned on the GPU but not carried out yet
         self.last_migrated = 0
 
     def _ctx(self):
@@ -257,26 +274,32 @@ class ShardedFilter(object):
         return self.f.set_option(name, value)
 
     def reset_weights(self):
+        self._complete()
         return self.f.reset_weights()
 
     def motion(self, v, w, dt, z=None, seed=0, draw=0):
+        self._complete()
         return self.f.motion(v, w, dt, z=z, seed=seed, draw=draw)
 
     def observe(self, blobs, ids=None, return_ids=False, fresh=False):
+        self._complete()
         out = self.f.observe(blobs, ids=ids, return_ids=return_ids, fresh=fresh) if fresh else \
             self.f.observe(blobs, ids=ids, return_ids=return_ids)
         self._recv_keepalive = None  # adopted slots were rewritten into the shard's own map (stream-ordered free)
         return out
 
     def download_poses(self):
+        self._complete()
         return self.f.download_poses()
 
     def download_landmarks(self, *a, **k):
+        self._complete()
         out = self.f.download_landmarks(*a, **k)
         self._recv_keepalive = None
         return out
 
     def synchronize(self):
+        self._complete()
         return self.f.synchronize()
 
     def enable_timing(self, mask=True):
@@ -292,17 +315,27 @@ class ShardedFilter(object):
         return self.f.observe_route() if hasattr(self.f, "observe_route") else "none"
 
     def close(self):
+        self._pending = None
         self.f.close()
 
     # -- the coupled part ----------------------------------------------------------
-    def resample(self, u, domain=_lib.PK_WEIGHTS_LINEAR, return_ancestors=False):
+    def resample(self, u, domain=_lib.PK_WEIGHTS_LINEAR, return_ancestors=False, defer=False):
         """Global systematic resample (prkt_core_v2.py:210-252) with a replicated draw u.
         One host synchronisation per call: reading the (2 x world x world) table of particle
-        ranges that sizes the all-to-all."""
+        ranges that sizes the all-to-all.  defer=True returns once the plan is enqueued; the
+        exchange is carried out by the next call that needs the particles (step() stages the
+        next scan on the host in between)."""
+        self._complete()
         with self._ctx():
-            return self._resample(u, domain, return_ancestors)
+            self._plan(u, domain)
+        if defer and not return_ancestors:
+            return None
+        self._complete()
+        if return_ancestors:
+            return self._global_ancestors(u, domain)
+        return None
 
-    def _resample(self, u, domain, return_ancestors):
+    def _plan(self, u, domain):
         f, comm, W, R = self.f, self.comm, self.world, self.rank
         gmax = None
         if domain == _lib.PK_WEIGHTS_LOG:
@@ -319,26 +352,38 @@ class ShardedFilter(object):
         f.plan_into(gtot, R * self.nb, self.P_global, u, R == W - 1, W, self._ranges)
         if W > 1:
             comm.all_gather_(self._all_ranges, self._ranges)
-            allr = self._all_ranges.cpu().numpy().reshape(W, W, 2)  # [source][destination] -> (j0, j1)
+            table = self._all_ranges
         else:
-            allr = self._ranges.cpu().numpy().reshape(1, 1, 2)
-        counts = allr[:, :, 1] - allr[:, :, 0]
-        send_counts = [int(counts[R, d]) if d != R else 0 for d in range(W)]
-        recv_counts = [int(counts[s, R]) if s != R else 0 for s in range(W)]
-        n_send, n_recv = sum(send_counts), sum(recv_counts)
-        self.last_migrated = n_send
-        recv = None
-        moving = int(counts.sum() - np.trace(counts))  # same number on every rank (all-gathered table)
-        if W > 1 and moving > 0:  # every rank takes part in the exchange, even with nothing of its own to move
-            send = f.alloc_records(n_send)
-            if n_send:
-                f.pack_into(allr[R].reshape(-1), W, R, send)
-            recv = comm.all_to_all_records(send, send_counts, recv_counts, f.particle_bytes())
-        f.adopt_from(R, recv, n_recv)
-        self._recv_keepalive = recv if n_recv else None
-        if return_ancestors:
-            return self._global_ancestors(u, domain)
-        return None
+            table = self._ranges
+        # the one host read of the step, started now and waited for in _complete()
+        handle = f.start_host_read(table) if hasattr(f, "start_host_read") else None
+        self._pending = (table, handle)
+
+    def _complete(self):
+        """Carry out the exchange of a planned resample: read the range table, all-to-all of the
+        migrating particles, adoption."""
+        if self._pending is None:
+            return
+        table, handle = self._pending
+        self._pending = None
+        with self._ctx():
+            f, comm, W, R = self.f, self.comm, self.world, self.rank
+            host = f.finish_host_read(handle) if handle is not None else table.cpu().numpy()
+            allr = np.asarray(host).reshape(W, W, 2)  # [source][destination] -> (j0, j1)
+            counts = allr[:, :, 1] - allr[:, :, 0]
+            send_counts = [int(counts[R, d]) if d != R else 0 for d in range(W)]
+            recv_counts = [int(counts[s, R]) if s != R else 0 for s in range(W)]
+            n_send, n_recv = sum(send_counts), sum(recv_counts)
+            self.last_migrated = n_send
+            recv = None
+            moving = int(counts.sum() - np.trace(counts))  # same number on every rank (all-gathered table)
+            if W > 1 and moving > 0:  # every rank takes part in the exchange, even with nothing of its own to move
+                send = f.alloc_records(n_send)
+                if n_send:
+                    f.pack_into(allr[R].reshape(-1), W, R, send)
+                recv = comm.all_to_all_records(send, send_counts, recv_counts, f.particle_bytes())
+            f.adopt_from(R, recv, n_recv)
+            self._recv_keepalive = recv if n_recv else None
 
     def _global_ancestors(self, u, domain):
         """Tests only: global ancestor index of every local output slot, from the host-array
@@ -363,12 +408,24 @@ class ShardedFilter(object):
         return torch.from_numpy(np.ascontiguousarray(a)).to(like.device)
 
     def step(self, v, w, dt, blobs, u, z=None, seed=0, draw=0, ids=None, domain=_lib.PK_WEIGHTS_LINEAR):
-        self.motion(v, w, dt, z=z, seed=seed, draw=draw)
-        self.observe(blobs, ids=ids, fresh=True)  # weight reset (:73) fused into the observe kernels
-        self.resample(u, domain=domain)
+        """One cam_cb.  The host half of the scan upload (association tables) is done BEFORE the
+        previous step's exchange is completed, i.e. while the GPU is still busy with that step."""
+        staged = False
+        if ids is None and hasattr(self.f, "stage_scan") and len(blobs) > 0:
+            self.f.stage_scan(blobs)
+            staged = True
+        self._complete()
+        self.f.motion(v, w, dt, z=z, seed=seed, draw=draw)
+        if staged:
+            self.f.observe_staged(fresh=True)  # weight reset (:73) fused into the observe kernels
+            self._recv_keepalive = None
+        else:
+            self.observe(blobs, ids=ids, fresh=True)
+        self.resample(u, domain=domain, defer=True)
 
     def summary(self):
         """FastSLAM.summary (prkt_core_v2.py:254-276) over all shards: all-reduce of four sums."""
+        self._complete()
         s = self.f.pose_sums()
         if self.world > 1:
             with self._ctx():

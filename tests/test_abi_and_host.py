@@ -24,7 +24,7 @@ def declared_functions():
 
 def test_header_declares_expected_entry_points():
     names = declared_functions()
-    for must in ("pk_create", "pk_destroy", "pk_upload_map", "pk_motion", "pk_observe", "pk_observe_fresh", "pk_observe_route", "pk_associate",
+    for must in ("pk_create", "pk_destroy", "pk_upload_map", "pk_motion", "pk_observe", "pk_observe_fresh", "pk_stage_scan", "pk_observe_staged", "pk_observe_route", "pk_associate",
                  "pk_resample", "pk_summary", "pk_step", "pk_probe", "pk_timings", "pk_download_poses",
                  "pk_download_landmarks", "pk_rng_standard_normal", "pk_shard_block_totals"):
         assert must in names

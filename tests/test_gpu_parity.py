@@ -241,3 +241,40 @@ def test_observe_fresh_equals_reset_then_observe(lib, ids_given):
     w = f.download_poses()[:, 3]
     f.close()
     assert np.allclose(w, poses[:, 3] * out[1][0][:, 3], rtol=1e-12)
+
+
+def test_staged_observe_equals_observe(lib):
+    """pk_stage_scan + pk_observe_staged = pk_observe_fresh; an observe in between discards the staged scan."""
+    from oracle.fastslam_oracle import synthetic_scan, synthetic_world
+
+    rs = np.random.RandomState(6)
+    L, P = 120, 50
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.02, 0.0, 0.01))
+    poses = np.column_stack([rs.normal(0, 0.2, P), rs.normal(0, 0.2, P), rs.normal(0, 0.05, P), np.ones(P)])
+    out = []
+    for staged in (False, True):
+        f = lib.DeviceFilter(P, L)
+        f.upload_map(means, covs.reshape(L, 25))
+        f.upload_poses(poses)
+        if staged:
+            f.stage_scan(blobs)
+            f.motion(0.2, 0.1, 0.1, seed=1, draw=0)  # other work between the two halves
+            f.observe_staged(fresh=True)
+        else:
+            f.motion(0.2, 0.1, 0.1, seed=1, draw=0)
+            f.observe(blobs, fresh=True)
+        out.append((f.download_poses(), f.download_landmarks()))
+        f.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+    f = lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    with pytest.raises(Exception):
+        f.observe_staged()  # nothing staged
+    f.stage_scan(blobs)
+    f.observe(blobs, ids=np.arange(1, L + 1))  # discards it
+    with pytest.raises(Exception):
+        f.observe_staged()
+    f.close()
