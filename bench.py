@@ -186,8 +186,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=10000, help="particles per GPU")
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--assoc", choices=["ml", "known"], default="ml")

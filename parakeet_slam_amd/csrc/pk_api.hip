@@ -1156,8 +1156,12 @@ int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestor
         launch_block_max(f->stream, d, f->partial, f->gmax);
     }
     launch_scan_local(f->stream, d, f->gmax, weight_domain, f->clocal, f->totals, key);
-    launch_scan_blocks(f->stream, f->totals, f->nblocks, f->offsets, f->sum);
-    launch_ancestors(f->stream, f->clocal, f->totals, f->offsets, f->sum, f->nblocks, d.P, d.P, u, 0, d.P, f->anc, &d);
+    if (f->nblocks <= kAncestorsScanMaxBlocks) {  // k_ancestors scans the few block totals itself: one launch less
+      launch_ancestors(f->stream, f->clocal, f->totals, nullptr, nullptr, f->nblocks, d.P, d.P, u, 0, d.P, f->anc, &d);
+    } else {
+      launch_scan_blocks(f->stream, f->totals, f->nblocks, f->offsets, f->sum);
+      launch_ancestors(f->stream, f->clocal, f->totals, f->offsets, f->sum, f->nblocks, d.P, d.P, u, 0, d.P, f->anc, &d);
+    }
   }
   f->src_identity = false;
   f->gmax_fused = false;

@@ -128,12 +128,13 @@ void launch_scan_blocks(hipStream_t s, const double* totals_dev, int64_t nb, dou
                      sum_dev);
 }
 
+constexpr int kAncMaxBlocks = 256;  // up to this many scan blocks k_ancestors scans the totals itself
 // Ancestor of output slot k: first particle j whose inclusive cumulative weight C_j is
 // >= u*r + k*r, r = sum/P  (equivalent to the walk at prkt_core_v2.py:233-250, '<=' at :239).
 __global__ void __launch_bounds__(256) k_ancestors(const double* __restrict__ clocal,
                                                    const double* __restrict__ totals,
-                                                   const double* __restrict__ offsets,
-                                                   const double* __restrict__ sum, int64_t nb, int64_t Pg,
+                                                   const double* offsets,
+                                                   const double* sum, int64_t nb, int64_t Pg,
                                                    int64_t Pscan, double u, int64_t slot0, int64_t n,
                                                    int32_t* __restrict__ anc, const double* __restrict__ gx,
                                                    const double* __restrict__ gy, const double* __restrict__ gh,
@@ -141,6 +142,23 @@ __global__ void __launch_bounds__(256) k_ancestors(const double* __restrict__ cl
                                                    double* __restrict__ gx2, double* __restrict__ gy2,
                                                    double* __restrict__ gh2, double* __restrict__ glw2,
                                                    int32_t* __restrict__ gsrc2) {
+  // offsets == NULL (few blocks): the exclusive scan of the block totals is done here, by one
+  // thread per workgroup, sequentially in block order -- the same additions in the same order as
+  // k_scan_blocks, without its launch
+  __shared__ double s_off[kAncMaxBlocks + 1];
+  if (offsets == nullptr) {
+    if (threadIdx.x == 0) {
+      double run = 0.0;
+      for (int64_t b = 0; b < nb; ++b) {
+        s_off[b] = run;
+        run += totals[b];
+      }
+      s_off[nb] = run;
+    }
+    __syncthreads();
+    offsets = s_off;
+    sum = s_off + nb;
+  }
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const double r = __ddiv_rn(sum[0], (double)Pg);                  // range_ :225

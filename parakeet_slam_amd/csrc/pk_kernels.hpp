@@ -144,7 +144,9 @@ void launch_scan_local(hipStream_t s, DeviceState& d, const double* gmax_dev, in
 // exclusive scan of the (global) block totals, sequential in block order: offsets[nb], sum[1]
 void launch_scan_blocks(hipStream_t s, const double* totals_dev, int64_t nb, double* offsets_dev,
                         double* sum_dev);
-// ancestors of the local output slots [slot0, slot0 + n)
+// ancestors of the local output slots [slot0, slot0 + n); offsets_dev == sum_dev == NULL with
+// nb <= kAncestorsScanMaxBlocks: the kernel scans the block totals itself (same order, same bits)
+constexpr int64_t kAncestorsScanMaxBlocks = 256;
 void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* totals_dev,
                       const double* offsets_dev, const double* sum_dev, int64_t nb, int64_t P_global,
                       int64_t P_scan, double u, int64_t slot0, int64_t n, int32_t* anc_dev,
