@@ -57,6 +57,32 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 BYTES_PER_UPDATE = 224  # 14 fp64 read + 14 written per particle.landmark
 
 
+def synthetic_controls(steps, w=0.1, dt=0.1):
+    """Angular velocity per step.  The reference evaluates |atan2(fy - sy, fx - sx) - blob.bearing|
+    > pi/2 with the robot-frame bearing (prkt_core_v2.py:473-475, frames mixed): once the robot's
+    heading passes pi/2 EVERY blob gets probability 0 and no EKF update happens any more -- a
+    degenerate workload (measured: the step gets 25 % faster).  So SURVEY 8d's control
+    (v, w) = (0.2, 0.1) is kept for the first 60 steps of 0.1 s and the robot then turns back
+    and forth between -0.6 and +0.6 rad."""
+    out, h, sign = [], 0.0, 1.0
+    for _ in range(steps):
+        if abs(h + sign * w * dt) > 0.6:
+            sign = -sign
+        out.append(sign * w)
+        h += sign * w * dt
+    return out
+
+
+def truth_pose(steps, v=0.2, w=0.1, dt=0.1):
+    """Noise-free pose after `steps` steps of the synthetic trajectory."""
+    x = y = h = 0.0
+    for ws in synthetic_controls(steps, w, dt):
+        h1 = h + ws * dt / 2
+        x, y = x + v * dt * math.cos(h1), y + v * dt * math.sin(h1)
+        h = math.atan2(math.sin(h1 + ws * dt / 2), math.cos(h1 + ws * dt / 2))
+    return [x, y, h]
+
+
 def synthetic_inputs(L, steps, v=0.2, w=0.1, dt=0.1):
     """World + noise-free scans along the true trajectory.  Restated here so the
     timed path does not import the oracle."""
@@ -75,10 +101,10 @@ def synthetic_inputs(L, steps, v=0.2, w=0.1, dt=0.1):
     covs = np.broadcast_to(0.25 * np.identity(5), (L, 5, 5)).copy()
     x = y = h = 0.0
     scans = []
-    for _ in range(steps):
-        h1 = h + w * dt / 2
+    for ws in synthetic_controls(steps, w, dt):
+        h1 = h + ws * dt / 2
         x, y = x + v * dt * math.cos(h1), y + v * dt * math.sin(h1)
-        h = math.atan2(math.sin(h1 + w * dt / 2), math.cos(h1 + w * dt / 2))
+        h = math.atan2(math.sin(h1 + ws * dt / 2), math.cos(h1 + ws * dt / 2))
         blobs = np.empty((L, 4))
         blobs[:, 0] = np.arctan2(means[:, 1] - y, means[:, 0] - x) - h
         blobs[:, 1:] = col
@@ -186,8 +212,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--particles", type=int, default=10000, help="particles per GPU")
     ap.add_argument("--landmarks", type=int, default=500)
     ap.add_argument("--assoc", choices=["ml", "known"], default="ml")
@@ -220,7 +246,9 @@ def main():
 
     P, L = args.particles, args.landmarks
     K, W = args.steps, args.warmup
-    means, covs, scans = synthetic_inputs(L, K + W)
+    EXTRA = 32  # untimed steps after the timed region (association share, supplied-ids route)
+    means, covs, scans = synthetic_inputs(L, K + W + EXTRA)
+    ws = synthetic_controls(K + W + EXTRA)
     ids = np.arange(1, L + 1, dtype=np.int32) if args.assoc == "known" else None
 
     if world > 1 or args.force_sharded:
@@ -239,7 +267,7 @@ def main():
     if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only
         filt.set_option("observe_landmarks_per_lane", int(os.environ["PK_OBSERVE_NV"]))
     rnd = random.Random(7)
-    us = [rnd.random() for _ in range(K + W)]
+    us = [rnd.random() for _ in range(K + W + EXTRA)]
 
     def barrier():
         if world > 1:
@@ -250,7 +278,7 @@ def main():
         filt.synchronize()
 
     def one_step(s):
-        filt.step(0.2, 0.1, 0.1, scans[s], us[s], seed=7, draw=s, ids=ids, domain=_lib.PK_WEIGHTS_LOG)
+        filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=ids, domain=_lib.PK_WEIGHTS_LOG)
 
     for s in range(W):
         one_step(s)
@@ -277,7 +305,7 @@ def main():
     # the association kernel's share, from a few extra (untimed) steps
     filt.enable_timing(0b0000010)
     filt.reset_timings()
-    for s in range(W, W + min(K, 10)):
+    for s in range(W + K, W + K + 10):
         one_step(s)
     barrier()
     tm["assoc"] = filt.timings()["assoc"]
@@ -288,15 +316,15 @@ def main():
     known = None
     if args.assoc == "ml":
         kids = np.arange(1, L + 1, dtype=np.int32)
-        kn = min(K, 20)
-        for s in range(W, W + 2):
-            filt.step(0.2, 0.1, 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
+        kn = 20
+        for s in range(W + K + 10, W + K + 12):
+            filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
         filt.enable_timing(0b0000100)
         filt.reset_timings()
         barrier()
         k0 = time.perf_counter()
-        for s in range(W, W + kn):
-            filt.step(0.2, 0.1, 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
+        for s in range(W + K + 12, W + K + 12 + kn):
+            filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
         barrier()
         k1 = time.perf_counter()
         kms, kcnt = filt.timings()["observe"]
@@ -393,6 +421,7 @@ def main():
             },
             "kernel_ms_per_step": {"observe": obs_ms / max(obs_n, 1), "assoc": assoc_ms / max(assoc_n, 1)},
             "summary": list(summary),
+            "truth": truth_pose(K + W),  # the filter's summary() must sit on it: the scans stayed matchable to the end
         }
         if known is not None and world == 1:
             out["supplied_ids_route"] = known
