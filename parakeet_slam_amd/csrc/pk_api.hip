@@ -968,6 +968,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     std::vector<int32_t> last((size_t)lay.Lp, -1);
     for (int l = 0; l < lay.Lp; ++l) first[l] = -1;
     int n0 = 0;
+    ex.single_sightings = true;
     for (int b = 0; b < B; ++b) {
       next[b] = -1;
       int id = ids[b];
@@ -975,10 +976,12 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
         ++n0;
         continue;
       }
-      if (first[id - 1] < 0)
+      if (first[id - 1] < 0) {
         first[id - 1] = b;
-      else
+      } else {
         next[last[id - 1]] = b;
+        ex.single_sightings = false;
+      }
       last[id - 1] = b;
     }
     if ((rc = upload_scan(f, st, total))) return rc;

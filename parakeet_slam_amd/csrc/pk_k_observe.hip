@@ -223,6 +223,59 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
 }
 
 
+// ------------------------------------------------------------------ K3 (known ids, one sighting per landmark)
+// The common supplied-ids scan on a map of <= 1024 landmarks: no landmark is matched by more than
+// one blob.  One landmark per lane and no loop at all: straight-line code that the compiler fits
+// in 96 VGPRs (the looped k_observe needs 163-194), so 16-20 waves per CU stream the map instead
+// of 8-12.  One workgroup of THREADS >= Lp lanes per particle.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_observe_single(ObserveArgs a) {
+  __shared__ double red[THREADS / kWave];
+  const int64_t p = blockIdx.x;
+  const int l = threadIdx.x;
+  const unsigned char* sslot = a.ss.at(a.src[p]);
+  unsigned char* dslot = a.map_dst + (size_t)p * a.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p];
+  const int Lp = a.Lp;
+  double acc = 0.0;
+  if (l < Lp) {
+    Landmark<double> A = load_landmark(sf, sc, Lp, l);
+    if (l < a.L) {
+      const int b = a.first[l];
+      if (b >= 0) {
+        const BlobT<double> z = load_blob(a.blobs, b);
+        acc = ekf_update(A, sx, sy, z, a.qt, a.immutable[l] != 0);
+      }
+    }
+    df[(size_t)F_MX * Lp + l] = A.mx;
+    df[(size_t)F_MY * Lp + l] = A.my;
+    df[(size_t)F_MR * Lp + l] = A.mr;
+    df[(size_t)F_MG * Lp + l] = A.mg;
+    df[(size_t)F_MB * Lp + l] = A.mb;
+    df[(size_t)F_PXX * Lp + l] = A.pxx;
+    df[(size_t)F_PXY * Lp + l] = A.pxy;
+    df[(size_t)F_PYY * Lp + l] = A.pyy;
+    df[(size_t)F_CRR * Lp + l] = A.crr;
+    df[(size_t)F_CRG * Lp + l] = A.crg;
+    df[(size_t)F_CRB * Lp + l] = A.crb;
+    df[(size_t)F_CGG * Lp + l] = A.cgg;
+    df[(size_t)F_CGB * Lp + l] = A.cgb;
+    df[(size_t)F_CBB * Lp + l] = A.cbb;
+    dc[l] = A.count;
+  }
+  const double tot = block_sum<THREADS / kWave>(acc, red);
+  if (l == 0) {
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot + (double)a.n_unmatched * Consts<double>::log_no_match;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));
+    a.src[p] = (int32_t)p;
+  }
+}
+
 // ------------------------------------------------------------------ K3 (fast ML variant, L <= 512)
 // One workgroup per particle, two adjacent landmarks per lane, the particle's whole map in
 // registers from the single coalesced load to the single coalesced store.  Input is the
@@ -1179,7 +1232,14 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
   a.Lp = d.lay.Lp;
   a.B = B;
   a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
-  if (ids_dev == nullptr) {
+  if (ids_dev == nullptr && ex.single_sightings && !ex.only_flagged && d.lay.Lp <= 1024 && g_observe_nv == 0) {
+    if (d.lay.Lp <= 256)
+      hipLaunchKernelGGL((k_observe_single<256>), dim3((unsigned)d.P), dim3(256), 0, s, a);
+    else if (d.lay.Lp <= 512)
+      hipLaunchKernelGGL((k_observe_single<512>), dim3((unsigned)d.P), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_observe_single<1024>), dim3((unsigned)d.P), dim3(1024), 0, s, a);
+  } else if (ids_dev == nullptr) {
     if (g_observe_nv == 1)
       hipLaunchKernelGGL((k_observe<true, 1>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
     else

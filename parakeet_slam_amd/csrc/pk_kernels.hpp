@@ -96,6 +96,7 @@ struct ObserveExtras {
   bool flip = true;                             // swap the map buffers after this launch
   bool reset = false;                           // weights restart from 1 (fused pk_reset_weights)
   unsigned long long* gmax_key = nullptr;       // keep the running max of the new log-weights here
+  bool single_sightings = false;                // known ids: no landmark is matched by more than one blob
 };
 constexpr int kFastSlots = 4;   // gate-passing blobs a landmark can hand over to k_observe_fast; more -> general path
 constexpr int kSweepSlots = 8;  // ... to k_observe_sweep (large maps: a landmark's colour neighbourhood is busier)
