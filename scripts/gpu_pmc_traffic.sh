@@ -38,7 +38,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob('gpurun_out/pmc_%s/**/*counter_collection.csv' % c, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            key = 'observe_known' if 'k_observe<true' in k else 'step_fused' if 'k_step_fused' in k else 'observe_ml' if 'k_observe_fast' in k else 'assoc_grid' if ('k_assoc_grid' in k and ', false, ' in k) else 'copy_slots' if 'k_copy_slots' in k else None
+            key = 'observe_known' if ('k_observe<true' in k or 'k_observe_single' in k) else 'step_fused' if 'k_step_fused' in k else 'observe_ml' if 'k_observe_fast' in k else 'assoc_grid' if ('k_assoc_grid' in k and ', false, ' in k) else 'copy_slots' if 'k_copy_slots' in k else None
             if key: res[key][c].append(float(r['Counter_Value']))
 out = {}
 for k, v in res.items():
