@@ -1,4 +1,5 @@
-// K3 EKF update + log-weight: general kernel (known ids / per-particle ids) and the fast ML variant.
+// K3 EKF update + log-weight: the general kernel (known ids / per-particle ids), the single-sighting
+// kernel, the hand-off ML variants (k_observe_fast, k_observe_sweep) and K2 + K3 in one (k_step_fused).
 //
 // Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update; see DESIGN.md
 // section 4.  No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
@@ -593,7 +594,7 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
 // store of the updated map: what k_assoc_grid<hand-off> and k_observe_fast do in two launches,
 // without the hand-off through HBM (no lmpass / bcount arrays, the means are read once).
 //   1. the scan tables (cell starts, fp32 records, duplicated index list) are copied to LDS; the lane
-//      loads its landmark's five means;
+//      requests its landmark's 14 rows;
 //   2. gates: atan2, colour cell, 4-wide walk of the duplicated list with the conservative fp32
 //      screen, exact float64 gates (:433, :441) on the survivors; the (<= 4) passing blobs stay in
 //      registers, the per-blob counts are LDS atomics;
