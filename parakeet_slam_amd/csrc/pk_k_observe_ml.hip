@@ -1,0 +1,937 @@
+// K3 for maximum-likelihood association, settling the association hand-off inside the EKF kernel:
+// k_observe_fast (L <= 512, whole map in registers), k_observe_sweep (any L, landmark chunks, two
+// sweeps) and k_step_fused (K2 + K3 in one kernel: gates, settling, update).
+//
+// Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update; see DESIGN.md
+// section 4.  No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
+#include "pk_device.hpp"
+
+namespace pk {
+
+// ------------------------------------------------------------------ K3 (fast ML variant, L <= 512)
+// One workgroup per particle, two adjacent landmarks per lane, the particle's whole map in
+// registers from the single coalesced load to the single coalesced store.  Input is the
+// association kernel's hand-off: per landmark the (<= 4) blobs that pass its gates, per blob
+// the number of landmarks that pass.  A blob passed by one landmark is matched iff its
+// probability is > 0 (strict '>' from 0.0, :369-381); a blob passed by several is given to
+// the landmark with the largest probability, the earliest on a tie -- LDS atomicMax on the
+// probability bits, then atomicMin on the landmark index among those that attain it --
+// evaluated here because the covariances are already in registers.  Blobs nobody passes or
+// wins multiply the weight by 0.1 (:94-95).  Updates of one landmark are applied in scan
+// order (:88) and every probability refers to the state before any update (:84).
+struct FastArgs {
+  SlotSource ss;
+  unsigned char* map_dst;
+  size_t count_off;
+  int32_t* src;
+  const double *x, *y;
+  double* logw;
+  const double* exact;          // [B][6] cell order: bearing, r, g, b, ux, uy
+  const unsigned short* order;  // [B] cell order -> scan order
+  const uint4* lmpass;
+  const unsigned char* bcount;
+  const unsigned char* pflag;
+  const unsigned char* immutable;
+  int L, Lp, B;
+  int reset;
+  unsigned long long* gmax_key;
+  Noise<double> qt;
+};
+
+struct FastSlot {
+  int t;                    // blob (cell order) or -1
+  int b;                    // its scan index
+  int q;                    // entry of the probability queue holding this slot's value, or -1
+  unsigned long long bits;  // contested candidate: probability bits (0: not positive)
+  unsigned flags;           // bit 0 contested, bit 1 apply the update, bit 2 unmatched (single, probability 0)
+};
+
+// probability_of_match (:439-455) from the two Mahalanobis terms and determinants
+__device__ __forceinline__ double pr_from_parts(double det2, double det3, double maha2, double maha3) {
+  const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + log(det2) + maha2));  // :439
+  const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + log(det3) + maha3));  // :446
+  return bp * cp / 250000.0;                                                                      // :455
+}
+
+// The few (landmark, blob) pairs whose probability VALUE is needed -- contested blobs, and pairs
+// too close to the float64 underflow edge to call positive without evaluating -- are queued in
+// LDS and evaluated densely by the first lanes of the workgroup (two log + two exp each), instead
+// of dragging every wave through that code for a handful of its lanes.
+constexpr int kFastQueue = 512;
+struct FastQueue {
+  double* det2;   // [kFastQueue]
+  double* det3;
+  double* maha2;  // overwritten with the probability bits by the evaluation pass
+  double* maha3;
+  int* meta;      // blob t | contested << 16
+  int* n;         // entries pushed (may exceed kFastQueue: the excess is evaluated in place)
+};
+__host__ __device__ inline size_t fast_queue_bytes() { return (size_t)kFastQueue * (4 * 8 + 4) + 16; }
+
+__device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<double>& lm, double sx, double sy,
+                                             double pse, uint2 packed, const unsigned char* bc,
+                                             unsigned long long* best, const FastQueue& fq,
+                                             FastSlot (&sl)[kFastSlots]) {
+  const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+  double det3;
+  const Sym3<double> inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+  const bool dets_sane = det2 > 0.0 && det2 < 1e60 && det3 > 0.0 && det3 < 1e60;
+  const unsigned w[2] = {packed.x, packed.y};
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+    sl[k].t = t == 0xFFFF ? -1 : t;
+    sl[k].b = INT_MAX;
+    sl[k].q = -1;
+    sl[k].bits = 0ull;
+    sl[k].flags = 0u;
+    if (sl[k].t < 0) continue;
+    sl[k].b = a.order[t];
+    const double* rec = a.exact + 6 * (size_t)t;
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+    // prob_position_match :457-494, prob_color_match :524-544
+    const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
+    double nx, ny;
+    closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+    const double ex = nx - lm.mx, ey = ny - lm.my;
+    const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / det2;
+    const double maha3 = sym3_quad(inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+    const bool contested = bc[t] >= 2;
+    // pr = (500 exp(a1)) (500 exp(a2)) / 250000 is certainly > 0 when a1 + a2 is far from the
+    // float64 underflow edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 here
+    const bool surely_positive = angle_ok && dets_sane && maha2 >= 0.0 && maha3 >= 0.0 && maha2 + maha3 < 800.0;
+    if (contested) sl[k].flags = 1u;
+    if (!angle_ok) {  // bp = 0 (:475): probability 0
+      if (!contested) sl[k].flags = 4u;
+      continue;
+    }
+    if (!contested && surely_positive) {
+      sl[k].flags = 2u;
+      continue;
+    }
+    const int qi = atomicAdd(fq.n, 1);
+    if (qi < kFastQueue) {
+      fq.det2[qi] = det2;
+      fq.det3[qi] = det3;
+      fq.maha2[qi] = maha2;
+      fq.maha3[qi] = maha3;
+      fq.meta[qi] = t | (contested ? 0x10000 : 0);
+      sl[k].q = qi;
+    } else {  // queue full (dense clusters of look-alike landmarks): evaluate in place
+      // (opaque copies: keeps the compiler from hoisting the two log() out of this rare branch
+      // into the code every lane runs)
+      double d2 = det2, d3 = det3;
+      asm volatile("" : "+v"(d2), "+v"(d3));
+      const double pr = pr_from_parts(d2, d3, maha2, maha3);
+      if (contested) {
+        if (pr > 0.0) {
+          sl[k].bits = (unsigned long long)__double_as_longlong(pr);
+          atomicMax(&best[t], sl[k].bits);
+        }
+      } else {
+        sl[k].flags = pr > 0.0 ? 2u : 4u;
+      }
+    }
+  }
+}
+
+// Dense evaluation of the queued probabilities, lanes over queue entries.
+__device__ __forceinline__ void fast_evaluate_queue(const FastQueue& fq, unsigned long long* best, int tid,
+                                                    int nthreads) {
+  const int n = min(*fq.n, kFastQueue);
+  // entries dealt round-robin to the first four waves (one per SIMD): the pass is a serial
+  // section of the workgroup, so its latency counts, not its lane efficiency
+  if (tid >= 256) return;
+  for (int i = ((tid & 63) << 2) + (tid >> 6); i < n; i += 256) {
+    const double pr = pr_from_parts(fq.det2[i], fq.det3[i], fq.maha2[i], fq.maha3[i]);
+    const unsigned long long bits = pr > 0.0 ? (unsigned long long)__double_as_longlong(pr) : 0ull;
+    reinterpret_cast<unsigned long long*>(fq.maha2)[i] = bits;
+    const int m = fq.meta[i];
+    if ((m & 0x10000) && bits != 0ull) atomicMax(&best[m & 0xFFFF], bits);
+  }
+}
+
+// Read the queued results back into the owner's slots; contested candidates that attain the
+// blob's best probability bid for it with their landmark index (earliest wins, :377).
+__device__ __forceinline__ void fast_collect(const FastQueue& fq, const unsigned long long* best, int* win, int l,
+                                             FastSlot (&sl)[kFastSlots]) {
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].t < 0) continue;
+    if (sl[k].q >= 0) {
+      const unsigned long long bits = reinterpret_cast<const unsigned long long*>(fq.maha2)[sl[k].q];
+      if (sl[k].flags & 1u)
+        sl[k].bits = bits;
+      else
+        sl[k].flags = bits != 0ull ? 2u : 4u;
+    }
+    if ((sl[k].flags & 1u) && sl[k].bits != 0ull && sl[k].bits == best[sl[k].t]) atomicMin(&win[sl[k].t], l);
+  }
+}
+
+__device__ __forceinline__ double fast_apply(const FastArgs& a, Landmark<double>& lm, int l, double sx, double sy,
+                                             double pse, FastSlot (&sl)[kFastSlots], const int* win) {
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].t < 0) continue;
+    if ((sl[k].flags & 1u) && sl[k].bits != 0ull && win[sl[k].t] == l) sl[k].flags |= 2u;
+    if (sl[k].flags & 4u) acc += Consts<double>::log_no_match;  // single candidate, probability 0 (:94-95)
+    if (!(sl[k].flags & 2u)) sl[k].b = INT_MAX;                 // not applied: sorts to the back
+  }
+  // the blobs to apply first, in scan order (:88) -- so that nearly every lane of the wave
+  // applies its (usually only) update in the same iteration (5-comparator network)
+  auto cswap = [&](FastSlot& u, FastSlot& v) {
+    if (u.b > v.b) {
+      const FastSlot tmp = u;
+      u = v;
+      v = tmp;
+    }
+  };
+  cswap(sl[0], sl[1]);
+  cswap(sl[2], sl[3]);
+  cswap(sl[0], sl[2]);
+  cswap(sl[1], sl[3]);
+  cswap(sl[1], sl[2]);
+  const bool imm = a.immutable[l] != 0;
+  bool fresh = true;
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    if (sl[k].b == INT_MAX) continue;
+    const double* rec = a.exact + 6 * (size_t)sl[k].t;
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+    acc += ekf_update(lm, sx, sy, z, a.qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+    fresh = imm;
+  }
+  return acc;
+}
+
+constexpr int kFastThreads = 512;  // one landmark per lane: L <= 512 in one pass
+
+__global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kFastThreads / kWave];
+  const int64_t p = blockIdx.x;
+  if (a.pflag[p]) return;  // workgroup-uniform: the general kernel takes this particle
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp;
+  FastQueue fq;
+  fq.det2 = reinterpret_cast<double*>(smem);
+  fq.det3 = fq.det2 + kFastQueue;
+  fq.maha2 = fq.det3 + kFastQueue;
+  fq.maha3 = fq.maha2 + kFastQueue;
+  fq.meta = reinterpret_cast<int*>(fq.maha3 + kFastQueue);
+  fq.n = fq.meta + kFastQueue;
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + fast_queue_bytes());
+  int* win = reinterpret_cast<int*>(best + B);
+  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
+  const unsigned char* sslot = a.ss.at(a.src[p]);
+  unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p];
+  const int l = tid;
+  const bool active = l < Lp, has = l < a.L;
+  Landmark<double> A{};
+  uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+  if (active) {
+    lp = a.lmpass[(size_t)p * Lp + l];  // first: the blob records it points to are the next dependent loads
+    A = load_landmark(sf, sc, Lp, l);
+  }
+  for (int t = tid; t < B; t += kFastThreads) {
+    best[t] = 0ull;
+    win[t] = INT_MAX;
+    bc[t] = a.bcount[(size_t)p * B + t];
+  }
+  if (tid == 0) *fq.n = 0;
+  __syncthreads();
+  int nun = 0;  // blobs no landmark passes
+  for (int t = tid; t < B; t += kFastThreads) nun += bc[t] == 0;
+  FastSlot sa[kFastSlots];
+  // atan2(my - sy, mx - sx) of the untouched state, handed over by the association kernel
+  const double pseA = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
+  fast_prepare(a, A, sx, sy, pseA, has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, fq,
+               sa);
+  __syncthreads();
+  fast_evaluate_queue(fq, best, tid, kFastThreads);
+  __syncthreads();
+  fast_collect(fq, best, win, l, sa);
+  __syncthreads();
+  for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
+  double acc = (double)nun * Consts<double>::log_no_match;
+  if (has) acc += fast_apply(a, A, l, sx, sy, pseA, sa, win);
+  if (active) {
+    df[(size_t)F_MX * Lp + l] = A.mx;
+    df[(size_t)F_MY * Lp + l] = A.my;
+    df[(size_t)F_MR * Lp + l] = A.mr;
+    df[(size_t)F_MG * Lp + l] = A.mg;
+    df[(size_t)F_MB * Lp + l] = A.mb;
+    df[(size_t)F_PXX * Lp + l] = A.pxx;
+    df[(size_t)F_PXY * Lp + l] = A.pxy;
+    df[(size_t)F_PYY * Lp + l] = A.pyy;
+    df[(size_t)F_CRR * Lp + l] = A.crr;
+    df[(size_t)F_CRG * Lp + l] = A.crg;
+    df[(size_t)F_CRB * Lp + l] = A.crb;
+    df[(size_t)F_CGG * Lp + l] = A.cgg;
+    df[(size_t)F_CGB * Lp + l] = A.cgb;
+    df[(size_t)F_CBB * Lp + l] = A.cbb;
+    dc[l] = A.count;
+  }
+  const double tot = block_sum<kFastThreads / kWave>(acc, red);
+  if (tid == 0) {
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));  // sharded: same-address atomics serialise
+    a.src[p] = (int32_t)p;
+  }
+}
+
+void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
+                         const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                         const ObserveExtras& ex) {
+  if (d.P == 0) return;
+  FastArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = fh.lmpass;
+  a.bcount = fh.bcount;
+  a.pflag = fh.pflag;
+  a.immutable = d.immutable;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  const size_t lds = fast_queue_bytes() + (size_t)B * 13 + 16;
+  hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
+}
+
+// ------------------------------------------------------------------ K2 + K3 fused (ML, L <= 512, small scan tables)
+// One workgroup per particle, one landmark per lane, from the association gates to the coalesced
+// store of the updated map: what k_assoc_grid<hand-off> and k_observe_fast do in two launches,
+// without the hand-off through HBM (no lmpass / bcount arrays, the means are read once).
+//   1. the scan tables (cell starts, fp32 records, duplicated index list) are copied to LDS; the lane
+//      requests its landmark's 14 rows;
+//   2. gates: atan2, colour cell, 4-wide walk of the duplicated list with the conservative fp32
+//      screen, exact float64 gates (:433, :441) on the survivors; the (<= 4) passing blobs stay in
+//      registers, the per-blob counts are LDS atomics;
+//   3. a particle in which some landmark passes more than kFastSlots blobs is flagged for the general
+//      kernels and left untouched;
+//   4. everything is settled and applied exactly as in k_observe_fast (the covariance rows were
+//      requested together with the means and arrived during the gates).
+struct FusedArgs {
+  FastArgs f;                   // lmpass, bcount unused
+  BlobGrid g;
+  const unsigned char* tables;  // start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9]
+  const double* h;
+  unsigned char* pflag_out;     // [P] 1 = general route
+  unsigned* n_flagged;
+  int n9;
+};
+
+size_t fused_lds_bytes(int ncell, int B, int n9) {
+  const size_t tab = (grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + 15) & ~(size_t)15;
+  return tab + (((size_t)B * 4 + 15) & ~(size_t)15) + fast_queue_bytes() + (size_t)B * 13 + 16;
+}
+
+__global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kFastThreads / kWave];
+  __shared__ int wg_flag;
+  const FastArgs& a = fa.f;
+  const BlobGrid& g = fa.g;
+  const int64_t p = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp;
+  const size_t cs_bytes = grid_cs_bytes(g.ncell);
+  const size_t tab_bytes = (cs_bytes + (size_t)B * 16 + (size_t)fa.n9 * 2 + 15) & ~(size_t)15;
+  const unsigned short* start = reinterpret_cast<const unsigned short*>(smem);
+  const float4* rec32 = reinterpret_cast<const float4*>(smem + cs_bytes);
+  const unsigned short* idx9 = reinterpret_cast<const unsigned short*>(smem + cs_bytes + (size_t)B * 16);
+  int* ccount = reinterpret_cast<int*>(smem + tab_bytes);
+  unsigned char* qbase = smem + tab_bytes + (((size_t)B * 4 + 15) & ~(size_t)15);
+  FastQueue fq;
+  fq.det2 = reinterpret_cast<double*>(qbase);
+  fq.det3 = fq.det2 + kFastQueue;
+  fq.maha2 = fq.det3 + kFastQueue;
+  fq.maha3 = fq.maha2 + kFastQueue;
+  fq.meta = reinterpret_cast<int*>(fq.maha3 + kFastQueue);
+  fq.n = fq.meta + kFastQueue;
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(qbase + fast_queue_bytes());
+  int* win = reinterpret_cast<int*>(best + B);
+  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
+
+  const unsigned char* sslot = a.ss.at(a.src[p]);
+  unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+  const double* sf = reinterpret_cast<const double*>(sslot);
+  double* df = reinterpret_cast<double*>(dslot);
+  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+  const double sx = a.x[p], sy = a.y[p], sh = fa.h[p];
+  const int l = tid;
+  const bool active = l < Lp, has = l < a.L;
+  // ---- 1. tables -> LDS, own state ------------------------------------------------------------
+  // The table words are requested first and the whole state right behind them: vmcnt retires in
+  // order, so the LDS copy waits for the table words only, and every barrier of this kernel orders
+  // LDS alone -- the covariance rows arrive while the gates are worked out.
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(fa.tables);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (size_t i = tid; i < tab_bytes / 16; i += kFastThreads) dst[i] = src[i];
+  }
+  Landmark<double> A{};
+  if (active) A = load_landmark(sf, sc, Lp, l);
+  for (int t = tid; t < B; t += kFastThreads) {
+    ccount[t] = 0;
+    best[t] = 0ull;
+    win[t] = INT_MAX;
+  }
+  if (tid == 0) {
+    *fq.n = 0;
+    wg_flag = 0;
+  }
+  lds_barrier();
+  // ---- 2. gates ----------------------------------------------------------------------------------
+  unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;
+  double pseA = 0.0;
+  if (has) {
+    const double mx = A.mx, my = A.my, mr = A.mr, mg = A.mg, mb = A.mb;
+    pseA = atan2(my - sy, mx - sx);
+    const double eb = pseA - sh;  // :408
+    const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
+    int c[3];
+    const double m3[3] = {mr, mg, mb};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // same cell function as the host, see k_assoc_grid
+      double q = floor(__dmul_rn(__dsub_rn(m3[k], g.lo[k]), g.inv_h));
+      q = fmin(fmax(q, -1.0), (double)g.G[k]);
+      c[k] = (int)q;
+    }
+    const int k0 = max(c[2] - 1, 0), k1 = min(c[2] + 1, g.G[2] - 1);
+    const int r = min(max(c[0], 0), g.G[0] - 1), gg = min(max(c[1], 0), g.G[1] - 1);
+    const int base = (r * g.G[1] + gg) * g.G[2];
+    int i0 = 0, i1 = 0;
+    if (k0 <= k1) {
+      i0 = start[base + k0];
+      i1 = start[base + k1 + 1];
+    }
+    int npass = 0;
+    auto prefilter_q = [&](const float4& q) {
+      const float d0 = q.x - mr32, d1 = q.y - mg32, d2 = q.z - mb32;
+      const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
+      return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
+    };
+    auto exact_gates = [&](int tt) {
+      const double* rec = a.exact + 6 * (size_t)tt;
+      const double2 z01 = *reinterpret_cast<const double2*>(rec);
+      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+      if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
+        atomicAdd(&ccount[tt], 1);
+        if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
+        if (npass == 1) pass01 = (pass01 & 0x0000FFFFu) | ((unsigned)tt << 16);
+        if (npass == 2) pass23 = (pass23 & 0xFFFF0000u) | (unsigned)tt;
+        if (npass == 3) pass23 = (pass23 & 0x0000FFFFu) | ((unsigned)tt << 16);
+        ++npass;
+      }
+    };
+    for (int i = i0; i < i1; i += 4) {
+      int t4[4];
+      float4 q4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t4[j] = idx9[i + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q4[j] = rec32[t4[j]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j < i1 && prefilter_q(q4[j])) exact_gates(t4[j]);
+    }
+    if (npass > kFastSlots) wg_flag = 1;
+  }
+  lds_barrier();
+  // ---- 3. flagged particles go the general way ----------------------------------------------------
+  if (wg_flag) {  // workgroup-uniform
+    if (tid == 0) {
+      fa.pflag_out[p] = 1;
+      atomicAdd(fa.n_flagged, 1u);
+    }
+    return;
+  }
+  if (tid == 0) fa.pflag_out[p] = 0;
+  int nun = 0;  // blobs no landmark passes
+  for (int t = tid; t < B; t += kFastThreads) {
+    const int n = ccount[t];
+    bc[t] = (unsigned char)(n > 255 ? 255 : n);
+    nun += n == 0;
+  }
+  // ---- 4. exactly k_observe_fast from here ----------------------------------------------------------
+  lds_barrier();
+  FastSlot sa[kFastSlots];
+  fast_prepare(a, A, sx, sy, pseA, make_uint2(pass01, pass23), bc, best, fq, sa);
+  lds_barrier();
+  fast_evaluate_queue(fq, best, tid, kFastThreads);
+  lds_barrier();
+  fast_collect(fq, best, win, l, sa);
+  lds_barrier();
+  for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
+  double acc = (double)nun * Consts<double>::log_no_match;
+  if (has) acc += fast_apply(a, A, l, sx, sy, pseA, sa, win);
+  if (active) {
+    df[(size_t)F_MX * Lp + l] = A.mx;
+    df[(size_t)F_MY * Lp + l] = A.my;
+    df[(size_t)F_MR * Lp + l] = A.mr;
+    df[(size_t)F_MG * Lp + l] = A.mg;
+    df[(size_t)F_MB * Lp + l] = A.mb;
+    df[(size_t)F_PXX * Lp + l] = A.pxx;
+    df[(size_t)F_PXY * Lp + l] = A.pxy;
+    df[(size_t)F_PYY * Lp + l] = A.pyy;
+    df[(size_t)F_CRR * Lp + l] = A.crr;
+    df[(size_t)F_CRG * Lp + l] = A.crg;
+    df[(size_t)F_CRB * Lp + l] = A.crb;
+    df[(size_t)F_CGG * Lp + l] = A.cgg;
+    df[(size_t)F_CGB * Lp + l] = A.cgb;
+    df[(size_t)F_CBB * Lp + l] = A.cbb;
+    dc[l] = A.count;
+  }
+  const double tot = block_sum<kFastThreads / kWave>(acc, red);
+  if (tid == 0) {
+    const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+    a.logw[p] = v;
+    if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));
+    a.src[p] = (int32_t)p;
+  }
+}
+
+void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
+                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex) {
+  if (d.P == 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  FusedArgs fa;
+  FastArgs& a = fa.f;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = nullptr;
+  a.bcount = nullptr;
+  a.pflag = nullptr;
+  a.immutable = d.immutable;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  fa.g = grid;
+  fa.tables = tables_dev;
+  fa.h = d.h[d.cur];
+  fa.pflag_out = fh.pflag;
+  fa.n_flagged = fh.n_flagged;
+  fa.n9 = n9;
+  hipLaunchKernelGGL(k_step_fused, dim3((unsigned)d.P), dim3(kFastThreads), fused_lds_bytes(grid.ncell, B, n9), s, fa);
+}
+
+// ------------------------------------------------------------------ K3 (sweep ML variant, any L)
+// The same hand-off as k_observe_fast, for maps that do not fit one landmark per lane: persistent
+// workgroups, each particle's landmarks in chunks of kSweepThreads, two sweeps.
+//   sweep 1 (read only): landmarks that pass a CONTESTED blob (one that several landmarks pass)
+//     load their state and queue the pair's probability inputs in LDS; the queue is evaluated
+//     densely (two log + two exp per pair), atomicMax of the probability bits per blob in LDS,
+//     and every positive (blob, landmark, probability) goes to a result list (per-workgroup
+//     scratch in global memory, L2 resident).  After the last chunk the pairs that attain their
+//     blob's best probability bid with their landmark index: atomicMin -> the earliest wins (:377).
+//   sweep 2: every landmark again (the second read comes from L2 / Infinity Cache: one
+//     particle's map is <= a few hundred KB), uncontested blobs settled by the strict '>' from 0.0
+//     as in k_observe_fast, contested ones applied by their winner, updates in scan order (:88),
+//     coalesced store of all 14 rows into the other map buffer.
+// A particle the association kernel flagged (a landmark passing more than kFastSlots blobs) is
+// skipped here and taken by the general kernels.
+constexpr int kSweepThreads = 256;  // 3 workgroups per CU at <= 168 VGPRs
+
+struct SweepArgs {
+  SlotSource ss;
+  unsigned char* map_dst;
+  size_t count_off;
+  int32_t* src;
+  const double *x, *y;
+  double* logw;
+  const double* exact;          // [B][6] cell order: bearing, r, g, b, ux, uy
+  const unsigned short* order;  // [B] cell order -> scan order
+  const uint4* lmpass;
+  const unsigned char* bcount;
+  const unsigned char* pflag;
+  const unsigned char* immutable;
+  uint4* results;               // [gridDim.x][kSweepSlots * Lp]: probability bits (lo, hi), blob t, landmark l
+  int64_t P;
+  int L, Lp, B;
+  int qcap;                     // entries of the LDS probability queue
+  int reset;
+  unsigned long long* gmax_key;
+  Noise<double> qt;
+};
+
+__host__ __device__ inline size_t sweep_lds_bytes(int B, int qcap) {
+  return (size_t)qcap * 36 + 16 + (((size_t)B * 13 + 15) & ~(size_t)15);
+}
+
+SweepPlan observe_sweep_plan(const DeviceState& d, int B) {
+  SweepPlan pl{};
+  const size_t fixed = sweep_lds_bytes(B, 0);
+  // workgroups per CU: three (the register budget of the kernel) when the blob tables leave room
+  // for a queue of >= 256 entries each, else two, else one
+  int per_cu = 3;
+  size_t budget = (kMaxDynLds / 3) & ~(size_t)255;
+  if (fixed + 256 * 36 > budget) {
+    per_cu = 2;
+    budget = (kMaxDynLds / 2) & ~(size_t)255;
+  }
+  if (fixed + 256 * 36 > budget) {
+    per_cu = 1;
+    budget = kMaxDynLds;
+  }
+  if (fixed + 64 * 36 > budget) return pl;  // scan too large for the LDS tables: grid = 0
+  long q = (long)((budget - fixed) / 36);
+  q = q > 1024 ? 1024 : q;  // kSweepThreads lanes x kFastSlots
+  q &= ~63L;
+  pl.qcap = (int)q;
+  pl.lds = sweep_lds_bytes(B, pl.qcap);
+  int64_t g = 256 * (int64_t)per_cu;
+  pl.grid = (int)(g < d.P ? g : d.P);
+  pl.results_per_wg = kSweepSlots * (size_t)d.lay.Lp;
+  return pl;
+}
+
+// SLOTS = kFastSlots (hand-off entry 16 B: four blob fields + atan2) or kSweepSlots (32 B: eight + atan2)
+template <int SLOTS>
+__global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kSweepThreads / kWave];
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp, qcap = a.qcap;
+  double* q_det2 = reinterpret_cast<double*>(smem);
+  double* q_det3 = q_det2 + qcap;
+  double* q_maha2 = q_det3 + qcap;
+  double* q_maha3 = q_maha2 + qcap;
+  unsigned* q_meta = reinterpret_cast<unsigned*>(q_maha3 + qcap);  // blob t | landmark l << 16
+  int* q_n = reinterpret_cast<int*>(q_meta + qcap);                // [2] alternating per chunk, [2] = result count
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(smem + (size_t)qcap * 36 + 16);
+  int* win = reinterpret_cast<int*>(best + B);
+  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
+  uint4* results = a.results + (size_t)blockIdx.x * SLOTS * (size_t)Lp;
+
+  for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
+    if (a.pflag[p]) continue;  // workgroup-uniform: the general kernels take this particle
+    const unsigned char* sslot = a.ss.at(a.src[p]);
+    unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+    const double* sf = reinterpret_cast<const double*>(sslot);
+    double* df = reinterpret_cast<double*>(dslot);
+    const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+    int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+    const double sx = a.x[p], sy = a.y[p];
+    const uint4* lmp = a.lmpass + (SLOTS == 4 ? 1 : 2) * (size_t)p * Lp;  // entries as written by k_assoc_grid
+    // blob fields of landmark l (unused words all ones) and its atan2(my - sy, mx - sx)
+    auto entry_blobs = [&](int l) {
+      if (SLOTS == 4) {
+        const uint4 e = lmp[l];
+        return make_uint4(e.x, e.y, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      }
+      return lmp[2 * l];
+    };
+    auto entry_pse = [&](int l) {
+      const uint4 e = SLOTS == 4 ? lmp[l] : lmp[2 * l + 1];
+      const unsigned lo = SLOTS == 4 ? e.z : e.x, hi = SLOTS == 4 ? e.w : e.y;
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    for (int t = tid; t < B; t += kSweepThreads) {
+      best[t] = 0ull;
+      win[t] = INT_MAX;
+      bc[t] = a.bcount[(size_t)p * B + t];
+    }
+    if (tid < 3) q_n[tid] = 0;
+    __syncthreads();
+
+    // ---- sweep 1: probabilities of the contested pairs ------------------------------------
+    int par = 0;
+    for (int base = 0; base < a.L; base += kSweepThreads, par ^= 1) {
+      int l = base + tid;
+      asm volatile("" : "+v"(l));
+      uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      if (l < a.L) lp = entry_blobs(l);
+      // slot k of this landmark: blob (cell order) or 0xFFFF; the slots are filled from the front
+      auto slot_of = [&](int k) {
+        const unsigned w = k < 2 ? lp.x : (k < 4 ? lp.y : (k < 6 ? lp.z : lp.w));
+        return (int)((w >> (16 * (k & 1))) & 0xFFFFu);
+      };
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        const int t = slot_of(k);
+        any |= t != 0xFFFF && bc[t] >= 2;
+      }
+      if (any) {
+        const Landmark<double> lm = load_landmark_nocount(sf, Lp, l);
+        const double pse = entry_pse(l);
+        const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+        double det3;
+        const Sym3<double> inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+#pragma unroll 1
+        for (int k = 0; k < SLOTS; ++k) {  // rolled: one copy of the code, a lane leaves at its first empty slot
+          const int t = slot_of(k);
+          if (t == 0xFFFF) break;
+          if (bc[t] < 2) continue;
+          const double* rec = a.exact + 6 * (size_t)t;
+          const double2 z01 = *reinterpret_cast<const double2*>(rec);
+          const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+          const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+          if (fabs(pse - z01.x) > Consts<double>::half_pi) continue;  // :473-475 -> probability 0
+          double nx, ny;
+          closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+          const double ex = nx - lm.mx, ey = ny - lm.my;
+          const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / det2;
+          const double maha3 = sym3_quad(inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+          const int qi = atomicAdd(&q_n[par], 1);
+          if (qi < qcap) {
+            q_det2[qi] = det2;
+            q_det3[qi] = det3;
+            q_maha2[qi] = maha2;
+            q_maha3[qi] = maha3;
+            q_meta[qi] = (unsigned)t | ((unsigned)l << 16);
+          } else {  // queue full: evaluate in place (opaque copies keep the logs out of the common path)
+            double d2 = det2, d3 = det3;
+            asm volatile("" : "+v"(d2), "+v"(d3));
+            const double pr = pr_from_parts(d2, d3, maha2, maha3);
+            if (pr > 0.0) {
+              const unsigned long long bits = (unsigned long long)__double_as_longlong(pr);
+              atomicMax(&best[t], bits);
+              results[atomicAdd(&q_n[2], 1)] = make_uint4((unsigned)bits, (unsigned)(bits >> 32), (unsigned)t, (unsigned)l);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int n = min(q_n[par], qcap);
+      for (int i = tid; i < n; i += kSweepThreads) {
+        const double pr = pr_from_parts(q_det2[i], q_det3[i], q_maha2[i], q_maha3[i]);
+        if (pr > 0.0) {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(pr);
+          const unsigned m = q_meta[i];
+          atomicMax(&best[m & 0xFFFFu], bits);
+          results[atomicAdd(&q_n[2], 1)] = make_uint4((unsigned)bits, (unsigned)(bits >> 32), m & 0xFFFFu, m >> 16);
+        }
+      }
+      if (tid == 0) q_n[par ^ 1] = 0;  // the other counter: last read before the previous barrier
+      __syncthreads();
+    }
+    // the pairs that attain their blob's best probability bid with their landmark index
+    {
+      const int nres = q_n[2];
+      for (int i = tid; i < nres; i += kSweepThreads) {
+        const uint4 e = results[i];
+        const unsigned long long bits = ((unsigned long long)e.y << 32) | e.x;
+        if (bits == best[e.z]) atomicMin(&win[e.z], (int)e.w);
+      }
+    }
+    __syncthreads();
+    int nun = 0;  // blobs nobody passes, and contested blobs whose probabilities are all 0
+    for (int t = tid; t < B; t += kSweepThreads) nun += (bc[t] == 0) || (bc[t] >= 2 && best[t] == 0ull);
+    double acc = (double)nun * Consts<double>::log_no_match;
+
+    // ---- sweep 2: settle the uncontested blobs, apply, store ----------------------------------
+    for (int base = 0; base < Lp; base += kSweepThreads) {
+      int l = base + tid;
+      asm volatile("" : "+v"(l));  // opaque: no strength-reduced row pointers kept live across the chunk loop
+      if (l >= Lp) continue;
+      Landmark<double> A = load_landmark(sf, sc, Lp, l);
+      if (l < a.L) {
+        const uint4 lp = entry_blobs(l);
+        const double pse = entry_pse(l);
+        // per slot: scan index << 16 | blob when the update is applied, else 0xFFFFFFFF
+        unsigned key[SLOTS];
+        // Division-free sufficient test for "probability certainly > 0" (all an uncontested blob
+        // needs, :369-381).  With P, C positive definite (Sylvester's criterion),
+        //   maha2 = e' P^-1 e <= |e|^2 / lmin(P) <= |e|^2 tr(P) / det(P)
+        //   maha3 = d' C^-1 d <= |d|^2 / lmin(C) <= |d|^2 m2(C) / det(C),  m2 = sum of principal 2x2 minors
+        // so maha2 + maha3 < 800 follows from |e|^2 tr det3 + |d|^2 m2 det2 < 800 det2 det3, and then
+        // pr = (500 exp(a1)) (500 exp(a2)) / 250000 has a1 + a2 > -543 (log det <= 138.2 for det <= 1e60):
+        // no underflow.  Pairs that fail it are evaluated exactly as the reference does.
+        bool have_q = false, spd = false;
+        double det2 = 0.0, det3 = 0.0, tr2 = 0.0, m2 = 0.0, lim = 0.0;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) key[k] = 0xFFFFFFFFu;
+#pragma unroll 1
+        for (int k = 0; k < SLOTS; ++k) {  // rolled: one copy of the settling code
+          const unsigned wk = k < 2 ? lp.x : (k < 4 ? lp.y : (k < 6 ? lp.z : lp.w));
+          const int t = (int)((wk >> (16 * (k & 1))) & 0xFFFFu);
+          if (t == 0xFFFF) break;  // the slots are filled from the front
+          bool apply;
+          if (bc[t] >= 2) {
+            apply = win[t] == l;
+          } else {
+            const double* rec = a.exact + 6 * (size_t)t;
+            const double2 z01 = *reinterpret_cast<const double2*>(rec);
+            const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+            const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+            if (!have_q) {
+              det2 = A.pxx * A.pyy - A.pxy * A.pxy;
+              const double c00 = A.cgg * A.cbb - A.cgb * A.cgb;
+              const double c11 = A.crr * A.cbb - A.crb * A.crb;
+              const double c22 = A.crr * A.cgg - A.crg * A.crg;
+              det3 = A.crr * c00 + A.crg * (A.crb * A.cgb - A.crg * A.cbb) + A.crb * (A.crg * A.cgb - A.crb * A.cgg);
+              tr2 = A.pxx + A.pyy;
+              m2 = c00 + c11 + c22;
+              spd = A.pxx > 0.0 && det2 > 0.0 && det2 < 1e60 && A.crr > 0.0 && c22 > 0.0 && det3 > 0.0 && det3 < 1e60 &&
+                    tr2 < 1e100 && m2 < 1e100;
+              lim = 800.0 * det2 * det3;
+              have_q = true;
+            }
+            apply = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
+            if (apply) {
+              double nx, ny;
+              closest_point(A.mx, A.my, sx, sy, dir.x, dir.y, nx, ny);
+              const double ex = nx - A.mx, ey = ny - A.my;
+              const double d1 = z01.y - A.mr, d2c = z23.x - A.mg, d3c = z23.y - A.mb;
+              const bool sure = spd && (ex * ex + ey * ey) * tr2 * det3 + (d1 * d1 + d2c * d2c + d3c * d3c) * m2 * det2 < lim;
+              if (!sure) {  // rare: tiny or indefinite covariances, far-off closest points
+                double e2 = ex, e3 = ey;
+                asm volatile("" : "+v"(e2), "+v"(e3));  // opaque: keeps the divisions out of the code every lane runs
+                double det3b;
+                const Sym3<double> inv3 = sym3_inverse(Sym3<double>{A.crr, A.crg, A.crb, A.cgg, A.cgb, A.cbb}, det3b);
+                const double maha2 = (A.pyy * e2 * e2 - 2.0 * A.pxy * e2 * e3 + A.pxx * e3 * e3) / det2;
+                const double maha3 = sym3_quad(inv3, d1, d2c, d3c);
+                apply = pr_from_parts(det2, det3b, maha2, maha3) > 0.0;
+              }
+            }
+            if (!apply) acc += Consts<double>::log_no_match;  // probability 0: unseen feature (:94-95)
+          }
+          if (apply) {
+            const unsigned kv = ((unsigned)a.order[t] << 16) | (unsigned)t;
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j)
+              if (k == j) key[j] = kv;
+          }
+        }
+        // apply in scan order (:88): take the smallest remaining key each time (usually one or two)
+        const bool imm = a.immutable[l] != 0;
+        bool fresh = true;
+        for (;;) {
+          unsigned kk = key[0];
+#pragma unroll
+          for (int j = 1; j < SLOTS; ++j) kk = min(kk, key[j]);
+          if (kk == 0xFFFFFFFFu) break;
+#pragma unroll
+          for (int j = 0; j < SLOTS; ++j)
+            if (key[j] == kk) key[j] = 0xFFFFFFFFu;  // keys are distinct: one slot per blob
+          const double* rec = a.exact + 6 * (size_t)(kk & 0xFFFFu);
+          const double2 z01 = *reinterpret_cast<const double2*>(rec);
+          const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+          BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+          acc += ekf_update(A, sx, sy, z, a.qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+          fresh = imm;
+        }
+      }
+      df[(size_t)F_MX * Lp + l] = A.mx;
+      df[(size_t)F_MY * Lp + l] = A.my;
+      df[(size_t)F_MR * Lp + l] = A.mr;
+      df[(size_t)F_MG * Lp + l] = A.mg;
+      df[(size_t)F_MB * Lp + l] = A.mb;
+      df[(size_t)F_PXX * Lp + l] = A.pxx;
+      df[(size_t)F_PXY * Lp + l] = A.pxy;
+      df[(size_t)F_PYY * Lp + l] = A.pyy;
+      df[(size_t)F_CRR * Lp + l] = A.crr;
+      df[(size_t)F_CRG * Lp + l] = A.crg;
+      df[(size_t)F_CRB * Lp + l] = A.crb;
+      df[(size_t)F_CGG * Lp + l] = A.cgg;
+      df[(size_t)F_CGB * Lp + l] = A.cgb;
+      df[(size_t)F_CBB * Lp + l] = A.cbb;
+      dc[l] = A.count;
+    }
+    const double tot = block_sum<kSweepThreads / kWave>(acc, red);  // two barriers: LDS is free for the next particle
+    if (tid == 0) {
+      const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+      a.logw[p] = v;
+      if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));
+      a.src[p] = (int32_t)p;
+    }
+  }
+}
+
+void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
+                          const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                          const ObserveExtras& ex, const SweepPlan& plan, uint4* results_dev) {
+  if (d.P == 0 || plan.grid == 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (const void* fn : {reinterpret_cast<const void*>(k_observe_sweep<kFastSlots>),
+                           reinterpret_cast<const void*>(k_observe_sweep<kSweepSlots>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
+        (void)hipGetLastError();
+    attr_set = true;
+  }
+  SweepArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = fh.lmpass;
+  a.bcount = fh.bcount;
+  a.pflag = fh.pflag;
+  a.immutable = d.immutable;
+  a.results = results_dev;
+  a.P = d.P;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.qcap = plan.qcap;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  // never more workgroups than are resident at once (results_dev is sized for plan.grid)
+  static size_t asked_lds = ~(size_t)0;
+  static int asked_per_cu = 0;
+  if (asked_lds != plan.lds) {
+    asked_lds = plan.lds;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&asked_per_cu, reinterpret_cast<const void*>(k_observe_sweep<kSweepSlots>),
+                                                     kSweepThreads, plan.lds) != hipSuccess) {
+      (void)hipGetLastError();
+      asked_per_cu = 0;
+    }
+  }
+  int grid = plan.grid;
+  if (asked_per_cu > 0 && 256 * asked_per_cu < grid) grid = 256 * asked_per_cu;
+  if (fh.slots == kSweepSlots)
+    hipLaunchKernelGGL(k_observe_sweep<kSweepSlots>, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
+  else
+    hipLaunchKernelGGL(k_observe_sweep<kFastSlots>, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
+}
+
+}  // namespace pk
