@@ -306,31 +306,32 @@ def main():
     tm["assoc"] = filt.timings()["assoc"]
     filt.enable_timing(0)
 
-    # the same filter, its EKF kernel run with SUPPLIED ids (no association, no resample in between,
-    # so every particle streams its own map slot -- after a resample duplicates of one ancestor read
-    # the same slot from cache): the HBM-bound form of the kernel, reported beside the headline so
-    # both routes' rooflines come from one run
+    # the EKF stage on its own (SURVEY 8d defines the HBM roofline on it): the same filter, reset to
+    # the initial map and poses, stepped with SUPPLIED ids -- whole steps, resample included, exactly
+    # what `--assoc known` times -- so both routes' rooflines come from one run
     known = None
-    if args.assoc == "ml":
+    if args.assoc == "ml" and world == 1 and not args.force_sharded:
         kids = np.arange(1, L + 1, dtype=np.int32)
-        kn = 10
-        sk = W + K + 10
-        for _ in range(2):
-            filt.observe(scans[sk], ids=kids, fresh=True)
+        kn, kw = (20, 3) if K >= 20 else (K, 2)
+        filt.upload_map(means, covs.reshape(L, 25))
+        filt.upload_poses(np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (P, 1)))
+        for s in range(kw):
+            filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
         filt.enable_timing(0b0000100)
         filt.reset_timings()
         barrier()
         k0 = time.perf_counter()
-        for _ in range(kn):
-            filt.observe(scans[sk], ids=kids, fresh=True)
+        for s in range(kw, kw + kn):
+            filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=kids, domain=_lib.PK_WEIGHTS_LOG)
         barrier()
         k1 = time.perf_counter()
         kms, kcnt = filt.timings()["observe"]
         filt.enable_timing(0)
         kavg = (kms / max(kcnt, 1)) * 1e-3
         known = {
-            "what": "%d x observe(ids = 1..L) on the same filter, no motion / resample between them" % kn,
-            "ms_per_observe_call": (k1 - k0) / kn * 1e3,
+            "what": "the filter reset to its initial state, %d whole steps with ids = 1..L (no association)" % kn,
+            "ms_per_step": (k1 - k0) / kn * 1e3,
+            "value": float(P) * L * kn / (k1 - k0),
             "kernel": ROUTE_KERNEL["known_ids"],
             "avg_launch_ms": kavg * 1e3,
             "launches": kcnt,
@@ -421,8 +422,8 @@ def main():
             "summary": list(summary),
             "matched_fraction_last_timed_scan": matched,  # validity: the scans stayed matchable to the end
         }
-        if known is not None and world == 1:
-            out["supplied_ids_route"] = known
+        if known is not None:
+            out["ekf_stage_supplied_ids"] = known
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
