@@ -449,13 +449,14 @@ class FastSLAM(object):
     def cam_cb(self, ros_view):
         """One filter step (:59-137)."""
         with self._lock:
-            self._filter.reset_weights()  # :73
             self._motion_update(self.last_control)  # :75-77
             scan = ros_view.last_sensor_reading  # :82
             observes = list(scan.observes)
             blobs = np.array([_blob_row(b) for b in observes], dtype=np.float64).reshape(-1, 4)
             self._filter.set_measurement_noise(self.Qt)
-            self._filter.observe(blobs)  # :84-124 association + EKF + weights
+            # :73 weight = 1 (the reset is fused into the observe kernels: pk_observe_fresh; the motion
+            # update in between does not read the weights), :84-124 association + EKF + weights
+            self._filter.observe(blobs, fresh=True)
             self._touch()
             if self._publish:
                 self._publish_all(self.particle_track_pub, self._poses())  # :126-127

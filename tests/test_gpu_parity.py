@@ -278,3 +278,30 @@ def test_staged_observe_equals_observe(lib):
     with pytest.raises(Exception):
         f.observe_staged()
     f.close()
+
+
+def test_upload_kernel_and_copy_engine_give_the_same_step(lib):
+    """"upload_kernel" = 0 (hipMemcpyAsync) and 1 (k_upload reading the pinned staging block) feed the
+    kernels the same scan block; "timing_stride" only thins out the event probe."""
+    from oracle.fastslam_oracle import synthetic_scan, synthetic_world
+
+    L, P = 70, 300
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.02, 0.0, 0.01))
+    out = []
+    for uk, stride in ((1, 1), (0, 1), (1, 3)):
+        f = lib.DeviceFilter(P, L)
+        f.set_option("upload_kernel", uk)
+        f.set_option("timing_stride", stride)
+        f.enable_timing(True)
+        f.upload_map(means, covs.reshape(L, 25))
+        for s in range(6):
+            f.step(0.2, 0.1, 0.1, blobs, 0.1 + 0.1 * s, seed=3, draw=s, domain=lib.PK_WEIGHTS_LOG)
+        tm = f.timings()
+        out.append((f.download_poses(), f.download_landmarks(), tm["observe"][1]))
+        f.close()
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0])
+        for a, b in zip(out[0][1], other[1]):
+            assert np.array_equal(a, b)
+    assert out[0][2] == 6 and out[2][2] == 2  # launches bracketed: every step / every third
