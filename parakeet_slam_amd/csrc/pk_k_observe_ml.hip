@@ -435,10 +435,7 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
       const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
       return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
     };
-    auto exact_gates = [&](int tt) {
-      const double* rec = a.exact + 6 * (size_t)tt;
-      const double2 z01 = *reinterpret_cast<const double2*>(rec);
-      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
       if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
         atomicAdd(&ccount[tt], 1);
         if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
@@ -448,6 +445,8 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
         ++npass;
       }
     };
+    // phase 1 (LDS only): survivors of the fp32 screen, the first four kept in registers
+    int pc[4], npc = 0;
     for (int i = i0; i < i1; i += 4) {
       int t4[4];
       float4 q4[4];
@@ -457,7 +456,39 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
       for (int j = 0; j < 4; ++j) q4[j] = rec32[t4[j]];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (i + j < i1 && prefilter_q(q4[j])) exact_gates(t4[j]);
+        if (i + j < i1 && prefilter_q(q4[j])) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (npc == k) pc[k] = t4[j];
+          ++npc;
+        }
+    }
+    // phase 2 (global): the exact records of all survivors in one batch of loads, then the float64 gates
+    {
+      double2 z01[4], z23[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (npc > k) {
+          const double* rec = a.exact + 6 * (size_t)pc[k];
+          z01[k] = *reinterpret_cast<const double2*>(rec);
+          z23[k] = *reinterpret_cast<const double2*>(rec + 2);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (npc > k) exact_gates(pc[k], z01[k], z23[k]);
+    }
+    if (npc > 4) {  // dense colour clusters: walk again for the survivors beyond the first four
+      int seen = 0;
+      for (int i = i0; i < i1; ++i) {
+        const int t = idx9[i];
+        if (prefilter_q(rec32[t])) {
+          if (seen >= 4) {
+            const double* rec = a.exact + 6 * (size_t)t;
+            exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
+          }
+          ++seen;
+        }
+      }
     }
     if (npass > kFastSlots) wg_flag = 1;
   }
