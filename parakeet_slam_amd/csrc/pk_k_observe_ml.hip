@@ -68,7 +68,10 @@ struct FastQueue {
 };
 __host__ __device__ inline size_t fast_queue_bytes() { return (size_t)kFastQueue * (4 * 8 + 4) + 16; }
 
-__device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<double>& lm, double sx, double sy,
+// exact / order: the scan's exact records [B][6] and cell -> scan order table, in global memory
+// (a.exact, a.order) or staged in LDS by the caller
+__device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* exact, const unsigned short* order,
+                                             const Landmark<double>& lm, double sx, double sy,
                                              double pse, uint2 packed, const unsigned char* bc,
                                              unsigned long long* best, const FastQueue& fq,
                                              FastSlot (&sl)[kFastSlots]) {
@@ -86,8 +89,8 @@ __device__ __forceinline__ void fast_prepare(const FastArgs& a, const Landmark<d
     sl[k].bits = 0ull;
     sl[k].flags = 0u;
     if (sl[k].t < 0) continue;
-    sl[k].b = a.order[t];
-    const double* rec = a.exact + 6 * (size_t)t;
+    sl[k].b = order[t];
+    const double* rec = exact + 6 * (size_t)t;
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
     const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
@@ -171,8 +174,9 @@ __device__ __forceinline__ void fast_collect(const FastQueue& fq, const unsigned
   }
 }
 
-__device__ __forceinline__ double fast_apply(const FastArgs& a, Landmark<double>& lm, int l, double sx, double sy,
-                                             double pse, FastSlot (&sl)[kFastSlots], const int* win) {
+__device__ __forceinline__ double fast_apply(const FastArgs& a, const double* exact, Landmark<double>& lm, int l,
+                                             double sx, double sy, double pse, FastSlot (&sl)[kFastSlots],
+                                             const int* win) {
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
@@ -200,7 +204,7 @@ __device__ __forceinline__ double fast_apply(const FastArgs& a, Landmark<double>
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
     if (sl[k].b == INT_MAX) continue;
-    const double* rec = a.exact + 6 * (size_t)sl[k].t;
+    const double* rec = exact + 6 * (size_t)sl[k].t;
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
     BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
@@ -256,8 +260,8 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   FastSlot sa[kFastSlots];
   // atan2(my - sy, mx - sx) of the untouched state, handed over by the association kernel
   const double pseA = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
-  fast_prepare(a, A, sx, sy, pseA, has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, fq,
-               sa);
+  fast_prepare(a, a.exact, a.order, A, sx, sy, pseA,
+               has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, fq, sa);
   __syncthreads();
   fast_evaluate_queue(fq, best, tid, kFastThreads);
   __syncthreads();
@@ -265,7 +269,7 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   __syncthreads();
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
-  if (has) acc += fast_apply(a, A, l, sx, sy, pseA, sa, win);
+  if (has) acc += fast_apply(a, a.exact, A, l, sx, sy, pseA, sa, win);
   if (active) {
     df[(size_t)F_MX * Lp + l] = A.mx;
     df[(size_t)F_MY * Lp + l] = A.my;
@@ -343,11 +347,16 @@ struct FusedArgs {
   int n9;
 };
 
-size_t fused_lds_bytes(int ncell, int B, int n9) {
-  const size_t tab = (grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + 15) & ~(size_t)15;
+// exact_lds: the exact records [B][6] and the order table are staged in LDS too (one contiguous
+// image exact | start | rec32 | idx9 | order, as the host lays the scan block out)
+size_t fused_lds_bytes(int ncell, int B, int n9, bool exact_lds) {
+  size_t tab = grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2;
+  if (exact_lds) tab += (size_t)B * 48 + (size_t)B * 2;
+  tab = (tab + 15) & ~(size_t)15;
   return tab + (((size_t)B * 4 + 15) & ~(size_t)15) + fast_queue_bytes() + (size_t)B * 13 + 16;
 }
 
+template <bool EXACT_LDS>
 __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kFastThreads / kWave];
@@ -358,10 +367,17 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   const int tid = threadIdx.x;
   const int B = a.B, Lp = a.Lp;
   const size_t cs_bytes = grid_cs_bytes(g.ncell);
-  const size_t tab_bytes = (cs_bytes + (size_t)B * 16 + (size_t)fa.n9 * 2 + 15) & ~(size_t)15;
-  const unsigned short* start = reinterpret_cast<const unsigned short*>(smem);
-  const float4* rec32 = reinterpret_cast<const float4*>(smem + cs_bytes);
-  const unsigned short* idx9 = reinterpret_cast<const unsigned short*>(smem + cs_bytes + (size_t)B * 16);
+  // LDS image: [exact records] | start | rec32 | idx9 | [order]  (a contiguous piece of the scan block)
+  const size_t ex_bytes = EXACT_LDS ? (size_t)B * 48 : 0;
+  const size_t tab_bytes = (ex_bytes + cs_bytes + (size_t)B * 16 + (size_t)fa.n9 * 2 + (EXACT_LDS ? (size_t)B * 2 : 0) + 15) & ~(size_t)15;
+  const unsigned short* start = reinterpret_cast<const unsigned short*>(smem + ex_bytes);
+  const float4* rec32 = reinterpret_cast<const float4*>(smem + ex_bytes + cs_bytes);
+  const unsigned short* idx9 = reinterpret_cast<const unsigned short*>(smem + ex_bytes + cs_bytes + (size_t)B * 16);
+  // the exact records and the order table the settling / update code reads: LDS copy or global
+  const double* exact = EXACT_LDS ? reinterpret_cast<const double*>(smem) : a.exact;
+  const unsigned short* order =
+      EXACT_LDS ? reinterpret_cast<const unsigned short*>(smem + ex_bytes + cs_bytes + (size_t)B * 16 + (size_t)fa.n9 * 2)
+                : a.order;
   int* ccount = reinterpret_cast<int*>(smem + tab_bytes);
   unsigned char* qbase = smem + tab_bytes + (((size_t)B * 4 + 15) & ~(size_t)15);
   FastQueue fq;
@@ -389,7 +405,7 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   // order, so the LDS copy waits for the table words only, and every barrier of this kernel orders
   // LDS alone -- the covariance rows arrive while the gates are worked out.
   {
-    const uint4* src = reinterpret_cast<const uint4*>(fa.tables);
+    const uint4* src = reinterpret_cast<const uint4*>(EXACT_LDS ? reinterpret_cast<const unsigned char*>(a.exact) : fa.tables);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     for (size_t i = tid; i < tab_bytes / 16; i += kFastThreads) dst[i] = src[i];
   }
@@ -469,7 +485,7 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (npc > k) {
-          const double* rec = a.exact + 6 * (size_t)pc[k];
+          const double* rec = exact + 6 * (size_t)pc[k];
           z01[k] = *reinterpret_cast<const double2*>(rec);
           z23[k] = *reinterpret_cast<const double2*>(rec + 2);
         }
@@ -483,7 +499,7 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
         const int t = idx9[i];
         if (prefilter_q(rec32[t])) {
           if (seen >= 4) {
-            const double* rec = a.exact + 6 * (size_t)t;
+            const double* rec = exact + 6 * (size_t)t;
             exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
           }
           ++seen;
@@ -511,7 +527,7 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   // ---- 4. exactly k_observe_fast from here ----------------------------------------------------------
   lds_barrier();
   FastSlot sa[kFastSlots];
-  fast_prepare(a, A, sx, sy, pseA, make_uint2(pass01, pass23), bc, best, fq, sa);
+  fast_prepare(a, exact, order, A, sx, sy, pseA, make_uint2(pass01, pass23), bc, best, fq, sa);
   lds_barrier();
   fast_evaluate_queue(fq, best, tid, kFastThreads);
   lds_barrier();
@@ -519,7 +535,7 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   lds_barrier();
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
-  if (has) acc += fast_apply(a, A, l, sx, sy, pseA, sa, win);
+  if (has) acc += fast_apply(a, exact, A, l, sx, sy, pseA, sa, win);
   if (active) {
     df[(size_t)F_MX * Lp + l] = A.mx;
     df[(size_t)F_MY * Lp + l] = A.my;
@@ -552,9 +568,9 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   if (d.P == 0) return;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kMaxDynLds) != hipSuccess)
-      (void)hipGetLastError();
+    for (const void* fn : {reinterpret_cast<const void*>(k_step_fused<false>), reinterpret_cast<const void*>(k_step_fused<true>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
+        (void)hipGetLastError();
     attr_set = true;
   }
   FusedArgs fa;
@@ -584,7 +600,11 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   fa.pflag_out = fh.pflag;
   fa.n_flagged = fh.n_flagged;
   fa.n9 = n9;
-  hipLaunchKernelGGL(k_step_fused, dim3((unsigned)d.P), dim3(kFastThreads), fused_lds_bytes(grid.ncell, B, n9), s, fa);
+  // exact records + order table in LDS as well when two workgroups per CU still fit
+  if (fused_lds_bytes(grid.ncell, B, n9, true) <= kFusedMaxLds)
+    hipLaunchKernelGGL(k_step_fused<true>, dim3((unsigned)d.P), dim3(kFastThreads), fused_lds_bytes(grid.ncell, B, n9, true), s, fa);
+  else
+    hipLaunchKernelGGL(k_step_fused<false>, dim3((unsigned)d.P), dim3(kFastThreads), fused_lds_bytes(grid.ncell, B, n9, false), s, fa);
 }
 
 // ------------------------------------------------------------------ K3 (sweep ML variant, any L)

@@ -131,7 +131,7 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
 // K2 + K3 fused for L <= kFastMaxL and scan tables small enough for two workgroups per CU: gates,
 // settling and EKF update of a particle in one workgroup, no hand-off through HBM.  Writes fh.pflag /
 // fh.n_flagged (particles left to the general kernels).
-size_t fused_lds_bytes(int ncell, int B, int n9);
+size_t fused_lds_bytes(int ncell, int B, int n9, bool exact_lds = false);
 constexpr size_t kFusedMaxLds = 78 * 1024;
 void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
