@@ -144,15 +144,28 @@ __device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* ex
 __device__ __forceinline__ void fast_evaluate_queue(const FastQueue& fq, unsigned long long* best, int tid,
                                                     int nthreads) {
   const int n = min(*fq.n, kFastQueue);
-  // entries dealt round-robin to the first four waves (one per SIMD): the pass is a serial
-  // section of the workgroup, so its latency counts, not its lane efficiency
+  // The pass is a serial section of the workgroup, so its latency counts, not its lane efficiency:
+  // entries are dealt round-robin to the first four waves (one per SIMD), and each entry to a PAIR of
+  // lanes -- the even lane evaluates the position pdf (:439), the odd lane the colour pdf (:446), one
+  // log + one exp each instead of two in a row; the product (:455) is formed from the same two
+  // values, in the same order, as pr_from_parts does.
   if (tid >= 256) return;
-  for (int i = ((tid & 63) << 2) + (tid >> 6); i < n; i += 256) {
-    const double pr = pr_from_parts(fq.det2[i], fq.det3[i], fq.maha2[i], fq.maha3[i]);
-    const unsigned long long bits = pr > 0.0 ? (unsigned long long)__double_as_longlong(pr) : 0ull;
-    reinterpret_cast<unsigned long long*>(fq.maha2)[i] = bits;
-    const int m = fq.meta[i];
-    if ((m & 0x10000) && bits != 0ull) atomicMax(&best[m & 0xFFFF], bits);
+  const int lane = tid & 63, wave = tid >> 6, role = lane & 1;
+  for (int base = 0; base < n; base += 128) {  // wave-uniform trip count (the shuffle needs both lanes of a pair)
+    const int i = base + ((lane >> 1) << 2) + wave;
+    const bool on = i < n;
+    const double det = on ? (role ? fq.det3[i] : fq.det2[i]) : 1.0;
+    const double maha = on ? (role ? fq.maha3[i] : fq.maha2[i]) : 0.0;
+    const double k = role ? 3.0 : 2.0;
+    const double mine = 500.0 * exp(-0.5 * (k * Consts<double>::log_two_pi + log(det) + maha));
+    const double other = __shfl_xor(mine, 1, kWave);
+    if (on && role == 0) {
+      const double pr = mine * other / 250000.0;  // bp * cp / 250000
+      const unsigned long long bits = pr > 0.0 ? (unsigned long long)__double_as_longlong(pr) : 0ull;
+      reinterpret_cast<unsigned long long*>(fq.maha2)[i] = bits;
+      const int m = fq.meta[i];
+      if ((m & 0x10000) && bits != 0ull) atomicMax(&best[m & 0xFFFF], bits);
+    }
   }
 }
 
