@@ -124,6 +124,9 @@ int pk_upload_map(pk_filter* f, const double* means, const double* covs, const u
  * (FilterParticle.weight, :288), stored on the device as its natural log. */
 int pk_upload_poses(pk_filter* f, const double* xyhw);
 int pk_download_poses(pk_filter* f, double* xyhw);
+/* The natural logarithms of the particle weights (the quantity the filter keeps: with B >~ 1000
+ * blobs per scan the weights themselves underflow float64, prkt_core_v2.py:95,124). */
+int pk_download_log_weights(pk_filter* f, double* logw);
 
 /* Landmark state of particles [p0, p1): means (n*L*5), covs (n*L*25 dense 5x5),
  * counts (n*L) = Feature.update_count.  Any output/input pointer may be NULL. */

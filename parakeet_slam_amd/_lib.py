@@ -50,6 +50,7 @@ SIGNATURES = {
     "pk_upload_landmarks": (C.c_int, [_h, C.c_int64, C.c_int64, _dp, _dp, _ip]),
     "pk_reset_weights": (C.c_int, [_h]),
     "pk_motion": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, _dp, C.c_uint64, C.c_uint64]),
+    "pk_download_log_weights": (C.c_int, [_h, _dp]),
     "pk_observe": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
     "pk_observe_fresh": (C.c_int, [_h, _dp, C.c_int32, _ip, _ip]),
     "pk_stage_scan": (C.c_int, [_h, _dp, C.c_int32]),
@@ -227,6 +228,11 @@ class DeviceFilter(object):
     def motion(self, v, w, dt, z=None, seed=0, draw=0):
         zz = f64(z, (self.P, 3)) if z is not None else None
         check(self._lib.pk_motion(self._h, float(v), float(w), float(dt), dptr(zz), int(seed), int(draw)))
+
+    def download_log_weights(self):
+        out = np.empty(self.P, dtype=np.float64)
+        check(self._lib.pk_download_log_weights(self._h, dptr(out)))
+        return out
 
     def observe(self, blobs, ids=None, return_ids=False, fresh=False):
         """fresh: the weights restart from 1 first (prkt_core_v2.py:73), fused into the same kernels."""

@@ -839,6 +839,15 @@ int pk_download_poses(pk_filter* f, double* xyhw) {
   return PK_OK;
 }
 
+int pk_download_log_weights(pk_filter* f, double* logw) {
+  if (!f || !logw) return fail(PK_ERR_INVALID, "pk_download_log_weights: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipMemcpyAsync(logw, f->d.logw[f->d.cur], (size_t)f->d.P * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
 int pk_download_landmarks(pk_filter* f, int64_t p0, int64_t p1, double* means, double* covs, int32_t* counts) {
   if (!f) return fail(PK_ERR_INVALID, "pk_download_landmarks: NULL handle");
   if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "pk_download_landmarks: bad particle range");

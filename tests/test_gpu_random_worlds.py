@@ -1,0 +1,97 @@
+"""GPU: randomised worlds (fixed seeds) through every maximum-likelihood route against the oracle.
+
+Each case draws its own map size, scan (landmark sightings with noise, repeated sightings, stray
+blobs, shuffled scan order), block-diagonal SPD covariances of random scale and shape, immutable
+flags, measurement noise and particle poses, then compares weights, means, covariances and update
+counts of: k_step_fused (default, L <= 512), hand-off + k_observe_fast, hand-off + k_observe_sweep
+(four and eight slots), the general kernels, with the NumPy oracle."""
+import numpy as np
+import pytest
+
+from oracle.fastslam_oracle import OracleFilter
+
+pytestmark = pytest.mark.gpu
+
+
+def random_spd(rs, n, scale):
+    a = rs.normal(size=(n, n))
+    q, _ = np.linalg.qr(a)
+    ev = scale * rs.uniform(0.3, 3.0, n)
+    return (q * ev) @ q.T
+
+
+def random_case(seed):
+    rs = np.random.RandomState(seed)
+    L = int(rs.choice([1, 2, 3, 9, 33, 64, 130, 257, 400, 512, 513, 640]))
+    P = int(rs.choice([1, 5, 17, 40]))
+    means = np.empty((L, 5))
+    phi = rs.uniform(-np.pi, np.pi, L)
+    rho = rs.uniform(4.0, 30.0, L)
+    means[:, 0] = rho * np.cos(phi)
+    means[:, 1] = rho * np.sin(phi)
+    ncol = max(1, int(L * rs.choice([0.2, 0.6, 1.0])))  # fewer colours than landmarks: look-alikes
+    palette = rs.uniform(0, 255, (ncol, 3))
+    means[:, 2:] = palette[rs.randint(0, ncol, L)] + rs.normal(0, 1.5, (L, 3))
+    covs = np.zeros((L, 5, 5))
+    for l in range(L):
+        covs[l, :2, :2] = random_spd(rs, 2, 10.0 ** rs.uniform(-2, 0.5))
+        covs[l, 2:, 2:] = random_spd(rs, 3, 10.0 ** rs.uniform(-1.5, 1.0))
+    immutable = (rs.uniform(size=L) < 0.15).astype(np.uint8)
+    pose = np.array([rs.normal(0, 0.5), rs.normal(0, 0.5), rs.normal(0, 0.4)])
+    poses = np.zeros((P, 4))
+    poses[:, :3] = pose + rs.normal(0, [0.15, 0.15, 0.03], (P, 3))
+    poses[:, 3] = rs.uniform(0.2, 1.5, P)
+    seen = np.flatnonzero(rs.uniform(size=L) < rs.choice([0.5, 0.9, 1.0]))
+    again = seen[rs.uniform(size=len(seen)) < 0.1]  # sighted twice
+    src = np.concatenate([seen, again])
+    blobs = np.empty((len(src), 4))
+    blobs[:, 0] = np.arctan2(means[src, 1] - pose[1], means[src, 0] - pose[0]) - pose[2] + rs.normal(0, 0.01, len(src))
+    blobs[:, 1:] = means[src, 2:] + rs.normal(0, 1.0, (len(src), 3))
+    strays = np.column_stack([rs.uniform(-3, 3, 4), rs.uniform(0, 255, (4, 3))])
+    blobs = np.vstack([blobs, strays])
+    blobs = blobs[rs.permutation(len(blobs))]
+    qt = np.zeros((4, 4))
+    qt[0, 0] = 10.0 ** rs.uniform(-2, -0.5)
+    qt[1:, 1:] = random_spd(rs, 3, 10.0 ** rs.uniform(-1.5, 0))
+    return L, P, means, covs, immutable, poses, blobs, qt
+
+
+def device_state(lib, case, opts):
+    L, P, means, covs, immutable, poses, blobs, qt = case
+    f = lib.DeviceFilter(P, L)
+    for k, v in opts.items():
+        f.set_option(k, v)
+    f.set_measurement_noise(qt)
+    f.upload_map(means, covs.reshape(L, 25), immutable)
+    f.upload_poses(poses)
+    f.observe(blobs)
+    out = (f.download_log_weights(), f.download_landmarks(), f.observe_route())
+    f.close()
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_world_all_routes(lib, seed):
+    case = random_case(1000 + seed)
+    L, P, means, covs, immutable, poses, blobs, qt = case
+    o = OracleFilter(P, means, covs, immutable)
+    o.Qt = qt.copy()
+    o.x, o.y, o.h = poses[:, 0].copy(), poses[:, 1].copy(), poses[:, 2].copy()
+    o.logw = np.log(poses[:, 3])
+    o.observe(blobs)
+    routes = {
+        "default": {},
+        "two_kernel": {"fused_step": 0},
+        "sweep4": {"fast_observe": 2},
+        "sweep8": {"fast_observe": 3},
+        "general": {"fast_observe": 0},
+        "general_brute": {"fast_observe": 0, "assoc_kernel": 1},
+    }
+    got = {name: device_state(lib, case, opts) for name, opts in routes.items()}
+    assert got["default"][2] == ("ml_fused" if L <= 512 else "ml_sweep")
+    assert got["general"][2] == "ml_general"
+    for name, (logw, (m, c, k), _) in got.items():
+        assert np.allclose(logw, o.logw, rtol=1e-10, atol=1e-9), name  # log domain: the weights themselves underflow
+        assert np.allclose(m, o.mean, rtol=1e-9, atol=1e-11), name
+        assert np.allclose(c, o.cov, rtol=1e-8, atol=1e-13), name
+        assert np.array_equal(k, o.count), name
