@@ -95,3 +95,55 @@ def test_random_world_all_routes(lib, seed):
         assert np.allclose(m, o.mean, rtol=1e-9, atol=1e-11), name
         assert np.allclose(c, o.cov, rtol=1e-8, atol=1e-13), name
         assert np.array_equal(k, o.count), name
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_world_several_steps(lib, seed):
+    """Whole steps (motion with host-supplied normals, ML association, EKF, log-domain resample) on a
+    random world: ancestors exact, log-weights / poses / maps within tolerance of the oracle after
+    every step, for the default route and the general kernels."""
+    rs = np.random.RandomState(5000 + seed)
+    L, _, means, covs, immutable, _, _, qt = random_case(5000 + seed)
+    P = 1030 if L <= 64 else (200 if L <= 257 else 48)  # more than one scan block where the oracle can afford it
+    o = OracleFilter(P, means, covs, immutable)
+    o.Qt = qt.copy()
+    filters = []
+    for opts in ({}, {"fast_observe": 0}):
+        f = lib.DeviceFilter(P, L)
+        for k, v in opts.items():
+            f.set_option(k, v)
+        f.set_measurement_noise(qt)
+        f.upload_map(means, covs.reshape(L, 25), immutable)
+        filters.append(f)
+    pose = np.zeros(3)
+    for s in range(4):
+        v, w, dt = 0.2 + 0.1 * rs.uniform(), 0.1 * rs.normal(), 0.1
+        h1 = pose[2] + w * dt / 2
+        pose = np.array([pose[0] + v * dt * np.cos(h1), pose[1] + v * dt * np.sin(h1), h1 + w * dt / 2])
+        seen = np.flatnonzero(rs.uniform(size=L) < 0.9)
+        blobs = np.empty((len(seen), 4))
+        blobs[:, 0] = np.arctan2(means[seen, 1] - pose[1], means[seen, 0] - pose[0]) - pose[2] + rs.normal(0, 0.01, len(seen))
+        blobs[:, 1:] = means[seen, 2:] + rs.normal(0, 1.0, (len(seen), 3))
+        blobs = blobs[rs.permutation(len(blobs))]
+        z = rs.standard_normal((P, 3))
+        u = rs.uniform()
+        o.reset_weights()
+        o.motion(v, w, dt, z)
+        o.observe(blobs)
+        logw = o.logw.copy()
+        anc = o.resample(u, domain="log")  # gathers the oracle's particles as well
+        for f in filters:
+            f.motion(v, w, dt, z=z)
+            f.observe(blobs, fresh=True)
+            assert np.allclose(f.download_log_weights(), logw, rtol=1e-10, atol=1e-9)
+            got = f.resample(u, domain=lib.PK_WEIGHTS_LOG, return_ancestors=True)
+            assert np.array_equal(got, anc), "ancestors differ from the oracle at step %d" % s
+            ps = f.download_poses()
+            assert np.allclose(ps[:, 0], o.x, rtol=1e-10, atol=1e-13) and np.allclose(ps[:, 1], o.y, rtol=1e-10, atol=1e-13)
+            assert np.allclose(ps[:, 2], o.h, rtol=1e-10, atol=1e-13)
+    m, c, k = filters[0].download_landmarks()
+    assert np.allclose(m, o.mean, rtol=1e-9, atol=1e-11)
+    assert np.allclose(c, o.cov, rtol=1e-8, atol=1e-13)
+    assert np.array_equal(k, o.count)
+    for f in filters:
+        f.close()
