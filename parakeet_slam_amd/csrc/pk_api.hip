@@ -251,7 +251,10 @@ int take_stage(pk_filter* f, size_t bytes, unsigned char** out, int* slot) {
   }
   int i = f->stage_next;
   f->stage_next = (i + 1) % pk_filter::kRing;
-  PK_HIP(hipEventSynchronize(f->stage_done[i]));
+  // An event is recorded only behind every 4th upload (an event record costs the stream a few
+  // microseconds): slot i was last read by an upload that precedes, in stream order, the record
+  // behind slot (i | 3) of the previous trip round the ring.
+  PK_HIP(hipEventSynchronize(f->stage_done[i | 3]));
   *out = f->stage[i];
   *slot = i;
   return PK_OK;
@@ -526,7 +529,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   const bool use_grid = sg.use_grid;
   const size_t tab_bytes = sg.tab_bytes;
   if ((rc = upload_scan(f, st, use_grid ? o_tab + tab_bytes : o_exact))) return rc;
-  PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+  if ((slot & 3) == 3) PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
   f->gmax_fused = false;
   const double* blobs_dev = reinterpret_cast<const double*>(f->scan_dev + o_blobs);
   const double* dir_dev = reinterpret_cast<const double*>(f->scan_dev + o_dir);
@@ -994,7 +997,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
       last[id - 1] = b;
     }
     if ((rc = upload_scan(f, st, total))) return rc;
-    PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+    if ((slot & 3) == 3) PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
     ex.gmax_key = ctl_gmax_key(f);
     {
       Span t(f, PK_T_OBSERVE);
