@@ -8,6 +8,13 @@
 
 namespace pk {
 
+// The updated map rows are written with non-temporal stores: nothing reads them before the next
+// step, and keeping them out of L2 / Infinity Cache leaves the caches to the read stream (the
+// duplicates a resample leaves read shared source slots): the supplied-ids kernel went from 0.190
+// to 0.171 ms at 10 000 x 500 with nothing else changed.
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------ K3 observe (EKF + weight)
 struct ObserveArgs {
   SlotSource ss;
@@ -177,42 +184,42 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
                           v[8].y, v[9].y, v[10].y, v[11].y, v[12].y, v[13].y, c.y};
       if (l0 < a.L) acc += apply_blobs<KNOWN>(A, l0, sx, sy, a, first, next, s_ids_mut, gid_mut);
       if (l0 + 1 < a.L) acc += apply_blobs<KNOWN>(Bq, l0 + 1, sx, sy, a, first, next, s_ids_mut, gid_mut);
-      *reinterpret_cast<double2*>(df + (size_t)F_MX * Lp + l0) = make_double2(A.mx, Bq.mx);
-      *reinterpret_cast<double2*>(df + (size_t)F_MY * Lp + l0) = make_double2(A.my, Bq.my);
-      *reinterpret_cast<double2*>(df + (size_t)F_MR * Lp + l0) = make_double2(A.mr, Bq.mr);
-      *reinterpret_cast<double2*>(df + (size_t)F_MG * Lp + l0) = make_double2(A.mg, Bq.mg);
-      *reinterpret_cast<double2*>(df + (size_t)F_MB * Lp + l0) = make_double2(A.mb, Bq.mb);
-      *reinterpret_cast<double2*>(df + (size_t)F_PXX * Lp + l0) = make_double2(A.pxx, Bq.pxx);
-      *reinterpret_cast<double2*>(df + (size_t)F_PXY * Lp + l0) = make_double2(A.pxy, Bq.pxy);
-      *reinterpret_cast<double2*>(df + (size_t)F_PYY * Lp + l0) = make_double2(A.pyy, Bq.pyy);
-      *reinterpret_cast<double2*>(df + (size_t)F_CRR * Lp + l0) = make_double2(A.crr, Bq.crr);
-      *reinterpret_cast<double2*>(df + (size_t)F_CRG * Lp + l0) = make_double2(A.crg, Bq.crg);
-      *reinterpret_cast<double2*>(df + (size_t)F_CRB * Lp + l0) = make_double2(A.crb, Bq.crb);
-      *reinterpret_cast<double2*>(df + (size_t)F_CGG * Lp + l0) = make_double2(A.cgg, Bq.cgg);
-      *reinterpret_cast<double2*>(df + (size_t)F_CGB * Lp + l0) = make_double2(A.cgb, Bq.cgb);
-      *reinterpret_cast<double2*>(df + (size_t)F_CBB * Lp + l0) = make_double2(A.cbb, Bq.cbb);
-      *reinterpret_cast<int2*>(dc + l0) = make_int2(A.count, Bq.count);
+      __builtin_nontemporal_store(d2v{A.mx, Bq.mx}, reinterpret_cast<d2v*>(df + (size_t)F_MX * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.my, Bq.my}, reinterpret_cast<d2v*>(df + (size_t)F_MY * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.mr, Bq.mr}, reinterpret_cast<d2v*>(df + (size_t)F_MR * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.mg, Bq.mg}, reinterpret_cast<d2v*>(df + (size_t)F_MG * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.mb, Bq.mb}, reinterpret_cast<d2v*>(df + (size_t)F_MB * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.pxx, Bq.pxx}, reinterpret_cast<d2v*>(df + (size_t)F_PXX * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.pxy, Bq.pxy}, reinterpret_cast<d2v*>(df + (size_t)F_PXY * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.pyy, Bq.pyy}, reinterpret_cast<d2v*>(df + (size_t)F_PYY * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.crr, Bq.crr}, reinterpret_cast<d2v*>(df + (size_t)F_CRR * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.crg, Bq.crg}, reinterpret_cast<d2v*>(df + (size_t)F_CRG * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.crb, Bq.crb}, reinterpret_cast<d2v*>(df + (size_t)F_CRB * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.cgg, Bq.cgg}, reinterpret_cast<d2v*>(df + (size_t)F_CGG * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.cgb, Bq.cgb}, reinterpret_cast<d2v*>(df + (size_t)F_CGB * Lp + l0));
+      __builtin_nontemporal_store(d2v{A.cbb, Bq.cbb}, reinterpret_cast<d2v*>(df + (size_t)F_CBB * Lp + l0));
+      __builtin_nontemporal_store(i2v{A.count, Bq.count}, reinterpret_cast<i2v*>(dc + l0));
     }
   } else {
     // one landmark per lane: half the registers, twice the waves in flight
     for (int l = tid; l < Lp; l += kObsThreads) {
       Landmark<double> A = load_landmark(sf, sc, Lp, l);
       if (l < a.L) acc += apply_blobs<KNOWN>(A, l, sx, sy, a, first, next, s_ids_mut, gid_mut);
-      df[(size_t)F_MX * Lp + l] = A.mx;
-      df[(size_t)F_MY * Lp + l] = A.my;
-      df[(size_t)F_MR * Lp + l] = A.mr;
-      df[(size_t)F_MG * Lp + l] = A.mg;
-      df[(size_t)F_MB * Lp + l] = A.mb;
-      df[(size_t)F_PXX * Lp + l] = A.pxx;
-      df[(size_t)F_PXY * Lp + l] = A.pxy;
-      df[(size_t)F_PYY * Lp + l] = A.pyy;
-      df[(size_t)F_CRR * Lp + l] = A.crr;
-      df[(size_t)F_CRG * Lp + l] = A.crg;
-      df[(size_t)F_CRB * Lp + l] = A.crb;
-      df[(size_t)F_CGG * Lp + l] = A.cgg;
-      df[(size_t)F_CGB * Lp + l] = A.cgb;
-      df[(size_t)F_CBB * Lp + l] = A.cbb;
-      dc[l] = A.count;
+      __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
+      __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
+      __builtin_nontemporal_store(A.mr, &df[(size_t)F_MR * Lp + l]);
+      __builtin_nontemporal_store(A.mg, &df[(size_t)F_MG * Lp + l]);
+      __builtin_nontemporal_store(A.mb, &df[(size_t)F_MB * Lp + l]);
+      __builtin_nontemporal_store(A.pxx, &df[(size_t)F_PXX * Lp + l]);
+      __builtin_nontemporal_store(A.pxy, &df[(size_t)F_PXY * Lp + l]);
+      __builtin_nontemporal_store(A.pyy, &df[(size_t)F_PYY * Lp + l]);
+      __builtin_nontemporal_store(A.crr, &df[(size_t)F_CRR * Lp + l]);
+      __builtin_nontemporal_store(A.crg, &df[(size_t)F_CRG * Lp + l]);
+      __builtin_nontemporal_store(A.crb, &df[(size_t)F_CRB * Lp + l]);
+      __builtin_nontemporal_store(A.cgg, &df[(size_t)F_CGG * Lp + l]);
+      __builtin_nontemporal_store(A.cgb, &df[(size_t)F_CGB * Lp + l]);
+      __builtin_nontemporal_store(A.cbb, &df[(size_t)F_CBB * Lp + l]);
+      __builtin_nontemporal_store(A.count, &dc[l]);
     }
   }
   double tot = block_sum<kObsThreads / kWave>(acc, red);
@@ -253,21 +260,21 @@ __global__ void __launch_bounds__(THREADS) k_observe_single(ObserveArgs a) {
         acc = ekf_update(A, sx, sy, z, a.qt, a.immutable[l] != 0);
       }
     }
-    df[(size_t)F_MX * Lp + l] = A.mx;
-    df[(size_t)F_MY * Lp + l] = A.my;
-    df[(size_t)F_MR * Lp + l] = A.mr;
-    df[(size_t)F_MG * Lp + l] = A.mg;
-    df[(size_t)F_MB * Lp + l] = A.mb;
-    df[(size_t)F_PXX * Lp + l] = A.pxx;
-    df[(size_t)F_PXY * Lp + l] = A.pxy;
-    df[(size_t)F_PYY * Lp + l] = A.pyy;
-    df[(size_t)F_CRR * Lp + l] = A.crr;
-    df[(size_t)F_CRG * Lp + l] = A.crg;
-    df[(size_t)F_CRB * Lp + l] = A.crb;
-    df[(size_t)F_CGG * Lp + l] = A.cgg;
-    df[(size_t)F_CGB * Lp + l] = A.cgb;
-    df[(size_t)F_CBB * Lp + l] = A.cbb;
-    dc[l] = A.count;
+    __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
+    __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
+    __builtin_nontemporal_store(A.mr, &df[(size_t)F_MR * Lp + l]);
+    __builtin_nontemporal_store(A.mg, &df[(size_t)F_MG * Lp + l]);
+    __builtin_nontemporal_store(A.mb, &df[(size_t)F_MB * Lp + l]);
+    __builtin_nontemporal_store(A.pxx, &df[(size_t)F_PXX * Lp + l]);
+    __builtin_nontemporal_store(A.pxy, &df[(size_t)F_PXY * Lp + l]);
+    __builtin_nontemporal_store(A.pyy, &df[(size_t)F_PYY * Lp + l]);
+    __builtin_nontemporal_store(A.crr, &df[(size_t)F_CRR * Lp + l]);
+    __builtin_nontemporal_store(A.crg, &df[(size_t)F_CRG * Lp + l]);
+    __builtin_nontemporal_store(A.crb, &df[(size_t)F_CRB * Lp + l]);
+    __builtin_nontemporal_store(A.cgg, &df[(size_t)F_CGG * Lp + l]);
+    __builtin_nontemporal_store(A.cgb, &df[(size_t)F_CGB * Lp + l]);
+    __builtin_nontemporal_store(A.cbb, &df[(size_t)F_CBB * Lp + l]);
+    __builtin_nontemporal_store(A.count, &dc[l]);
   }
   const double tot = block_sum<THREADS / kWave>(acc, red);
   if (l == 0) {

@@ -284,21 +284,21 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   double acc = (double)nun * Consts<double>::log_no_match;
   if (has) acc += fast_apply(a, a.exact, A, l, sx, sy, pseA, sa, win);
   if (active) {
-    df[(size_t)F_MX * Lp + l] = A.mx;
-    df[(size_t)F_MY * Lp + l] = A.my;
-    df[(size_t)F_MR * Lp + l] = A.mr;
-    df[(size_t)F_MG * Lp + l] = A.mg;
-    df[(size_t)F_MB * Lp + l] = A.mb;
-    df[(size_t)F_PXX * Lp + l] = A.pxx;
-    df[(size_t)F_PXY * Lp + l] = A.pxy;
-    df[(size_t)F_PYY * Lp + l] = A.pyy;
-    df[(size_t)F_CRR * Lp + l] = A.crr;
-    df[(size_t)F_CRG * Lp + l] = A.crg;
-    df[(size_t)F_CRB * Lp + l] = A.crb;
-    df[(size_t)F_CGG * Lp + l] = A.cgg;
-    df[(size_t)F_CGB * Lp + l] = A.cgb;
-    df[(size_t)F_CBB * Lp + l] = A.cbb;
-    dc[l] = A.count;
+    __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
+    __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
+    __builtin_nontemporal_store(A.mr, &df[(size_t)F_MR * Lp + l]);
+    __builtin_nontemporal_store(A.mg, &df[(size_t)F_MG * Lp + l]);
+    __builtin_nontemporal_store(A.mb, &df[(size_t)F_MB * Lp + l]);
+    __builtin_nontemporal_store(A.pxx, &df[(size_t)F_PXX * Lp + l]);
+    __builtin_nontemporal_store(A.pxy, &df[(size_t)F_PXY * Lp + l]);
+    __builtin_nontemporal_store(A.pyy, &df[(size_t)F_PYY * Lp + l]);
+    __builtin_nontemporal_store(A.crr, &df[(size_t)F_CRR * Lp + l]);
+    __builtin_nontemporal_store(A.crg, &df[(size_t)F_CRG * Lp + l]);
+    __builtin_nontemporal_store(A.crb, &df[(size_t)F_CRB * Lp + l]);
+    __builtin_nontemporal_store(A.cgg, &df[(size_t)F_CGG * Lp + l]);
+    __builtin_nontemporal_store(A.cgb, &df[(size_t)F_CGB * Lp + l]);
+    __builtin_nontemporal_store(A.cbb, &df[(size_t)F_CBB * Lp + l]);
+    __builtin_nontemporal_store(A.count, &dc[l]);
   }
   const double tot = block_sum<kFastThreads / kWave>(acc, red);
   if (tid == 0) {
@@ -550,21 +550,21 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   double acc = (double)nun * Consts<double>::log_no_match;
   if (has) acc += fast_apply(a, exact, A, l, sx, sy, pseA, sa, win);
   if (active) {
-    df[(size_t)F_MX * Lp + l] = A.mx;
-    df[(size_t)F_MY * Lp + l] = A.my;
-    df[(size_t)F_MR * Lp + l] = A.mr;
-    df[(size_t)F_MG * Lp + l] = A.mg;
-    df[(size_t)F_MB * Lp + l] = A.mb;
-    df[(size_t)F_PXX * Lp + l] = A.pxx;
-    df[(size_t)F_PXY * Lp + l] = A.pxy;
-    df[(size_t)F_PYY * Lp + l] = A.pyy;
-    df[(size_t)F_CRR * Lp + l] = A.crr;
-    df[(size_t)F_CRG * Lp + l] = A.crg;
-    df[(size_t)F_CRB * Lp + l] = A.crb;
-    df[(size_t)F_CGG * Lp + l] = A.cgg;
-    df[(size_t)F_CGB * Lp + l] = A.cgb;
-    df[(size_t)F_CBB * Lp + l] = A.cbb;
-    dc[l] = A.count;
+    __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
+    __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
+    __builtin_nontemporal_store(A.mr, &df[(size_t)F_MR * Lp + l]);
+    __builtin_nontemporal_store(A.mg, &df[(size_t)F_MG * Lp + l]);
+    __builtin_nontemporal_store(A.mb, &df[(size_t)F_MB * Lp + l]);
+    __builtin_nontemporal_store(A.pxx, &df[(size_t)F_PXX * Lp + l]);
+    __builtin_nontemporal_store(A.pxy, &df[(size_t)F_PXY * Lp + l]);
+    __builtin_nontemporal_store(A.pyy, &df[(size_t)F_PYY * Lp + l]);
+    __builtin_nontemporal_store(A.crr, &df[(size_t)F_CRR * Lp + l]);
+    __builtin_nontemporal_store(A.crg, &df[(size_t)F_CRG * Lp + l]);
+    __builtin_nontemporal_store(A.crb, &df[(size_t)F_CRB * Lp + l]);
+    __builtin_nontemporal_store(A.cgg, &df[(size_t)F_CGG * Lp + l]);
+    __builtin_nontemporal_store(A.cgb, &df[(size_t)F_CGB * Lp + l]);
+    __builtin_nontemporal_store(A.cbb, &df[(size_t)F_CBB * Lp + l]);
+    __builtin_nontemporal_store(A.count, &dc[l]);
   }
   const double tot = block_sum<kFastThreads / kWave>(acc, red);
   if (tid == 0) {
@@ -918,21 +918,21 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
           fresh = imm;
         }
       }
-      df[(size_t)F_MX * Lp + l] = A.mx;
-      df[(size_t)F_MY * Lp + l] = A.my;
-      df[(size_t)F_MR * Lp + l] = A.mr;
-      df[(size_t)F_MG * Lp + l] = A.mg;
-      df[(size_t)F_MB * Lp + l] = A.mb;
-      df[(size_t)F_PXX * Lp + l] = A.pxx;
-      df[(size_t)F_PXY * Lp + l] = A.pxy;
-      df[(size_t)F_PYY * Lp + l] = A.pyy;
-      df[(size_t)F_CRR * Lp + l] = A.crr;
-      df[(size_t)F_CRG * Lp + l] = A.crg;
-      df[(size_t)F_CRB * Lp + l] = A.crb;
-      df[(size_t)F_CGG * Lp + l] = A.cgg;
-      df[(size_t)F_CGB * Lp + l] = A.cgb;
-      df[(size_t)F_CBB * Lp + l] = A.cbb;
-      dc[l] = A.count;
+      __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
+      __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
+      __builtin_nontemporal_store(A.mr, &df[(size_t)F_MR * Lp + l]);
+      __builtin_nontemporal_store(A.mg, &df[(size_t)F_MG * Lp + l]);
+      __builtin_nontemporal_store(A.mb, &df[(size_t)F_MB * Lp + l]);
+      __builtin_nontemporal_store(A.pxx, &df[(size_t)F_PXX * Lp + l]);
+      __builtin_nontemporal_store(A.pxy, &df[(size_t)F_PXY * Lp + l]);
+      __builtin_nontemporal_store(A.pyy, &df[(size_t)F_PYY * Lp + l]);
+      __builtin_nontemporal_store(A.crr, &df[(size_t)F_CRR * Lp + l]);
+      __builtin_nontemporal_store(A.crg, &df[(size_t)F_CRG * Lp + l]);
+      __builtin_nontemporal_store(A.crb, &df[(size_t)F_CRB * Lp + l]);
+      __builtin_nontemporal_store(A.cgg, &df[(size_t)F_CGG * Lp + l]);
+      __builtin_nontemporal_store(A.cgb, &df[(size_t)F_CGB * Lp + l]);
+      __builtin_nontemporal_store(A.cbb, &df[(size_t)F_CBB * Lp + l]);
+      __builtin_nontemporal_store(A.count, &dc[l]);
     }
     const double tot = block_sum<kSweepThreads / kWave>(acc, red);  // two barriers: LDS is free for the next particle
     if (tid == 0) {
