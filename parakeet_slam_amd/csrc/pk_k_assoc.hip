@@ -528,12 +528,11 @@ size_t assoc_grid_lds_bytes(int ncell, int B, int n9) {
 
 template <int THREADS, bool DUP, bool GENERAL, int SLOTS>
 static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t lds, int64_t P) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_grid<THREADS, DUP, GENERAL, SLOTS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
       (void)hipGetLastError();  // leave no sticky error behind for other users of the runtime
-    attr_set = true;
   }
   // persistent grid = the workgroups that are resident at once (registers, LDS and the wave limit all
   // count: a workgroup that has to wait for a slot would run its particles after the others finished)

@@ -579,12 +579,11 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
                        const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
                        const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex) {
   if (d.P == 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
     for (const void* fn : {reinterpret_cast<const void*>(k_step_fused<false>), reinterpret_cast<const void*>(k_step_fused<true>)})
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
         (void)hipGetLastError();
-    attr_set = true;
   }
   FusedArgs fa;
   FastArgs& a = fa.f;
@@ -948,13 +947,12 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
                           const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
                           const ObserveExtras& ex, const SweepPlan& plan, uint4* results_dev) {
   if (d.P == 0 || plan.grid == 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
     for (const void* fn : {reinterpret_cast<const void*>(k_observe_sweep<kFastSlots>),
                            reinterpret_cast<const void*>(k_observe_sweep<kSweepSlots>)})
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
         (void)hipGetLastError();
-    attr_set = true;
   }
   SweepArgs a;
   a.ss = slot_source(d);

@@ -78,7 +78,18 @@ constexpr int kGridMax = 16;
 __host__ __device__ inline size_t grid_cs_bytes(int ncell) { return ((size_t)(ncell + 1) * 2 + 15) & ~(size_t)15; }
 size_t blob_grid_table_bytes(int ncell, int B, int n9);
 size_t assoc_grid_lds_bytes(int ncell, int B, int n9);
-constexpr size_t kMaxDynLds = 156 * 1024;  // 160 KiB per workgroup minus the kernels' static __shared__
+constexpr size_t kMaxDynLds = 156 * 1024;
+// Per-device "already done" flag for one-time function attributes (hipFuncSetAttribute is per
+// device; one process may hold filters on several GPUs).  Returns true the first time it is asked
+// for the CURRENT device.
+constexpr int kMaxDevices = 64;
+inline bool first_time_on_this_device(bool (&done)[kMaxDevices]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return true;
+  if (done[dev]) return false;
+  done[dev] = true;
+  return true;
+}  // 160 KiB per workgroup minus the kernels' static __shared__
 // Hand-off from the association kernel to k_observe_fast (all three NULL = not used).
 struct FastHandoff {
   uint4* lmpass = nullptr;          // [P][Lp] (slots = 4) or [P][Lp][2] (slots = 8): see k_assoc_grid
