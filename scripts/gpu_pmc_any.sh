@@ -22,7 +22,7 @@ for f in sorted(glob.glob('gpurun_out/pmcany_*/**/*counter_collection.csv', recu
         k = r['Kernel_Name'][:48]
         acc[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
     for k, v in acc.items():
-        if 'assoc' in k or 'observe' in k or 'settle' in k:
+        if 'assoc' in k or 'observe' in k or 'settle' in k or 'fused' in k:
             out.setdefault(k, {}).update({a: b / n[(k, a)] for a, b in v.items()})
 for k, v in out.items():
     print(k, {a: '%.4g' % b for a, b in v.items()})
