@@ -91,6 +91,7 @@ struct pk_filter {
     int n9 = 0;
     bool use_grid = false;
     size_t tab_bytes = 0;
+    bool uploaded = false;  // pk_step sent the block to the device together with the motion kernel
   } staged;
   int route = PK_ROUTE_NONE;  // kernels used by the last observe
   int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
@@ -477,6 +478,7 @@ int stage_ml_scan(pk_filter* f, const double* blobs, int B) {
   if ((rc = ensure_ids_capacity(f, B))) return rc;
   pk_filter::Staged& sg = f->staged;
   sg.valid = false;
+  sg.uploaded = false;
   const int ncell_max = kGridMax * kGridMax * kGridMax;
   const size_t tab_max = (blob_grid_table_bytes(ncell_max, B, 9 * B + 16) + 15) & ~(size_t)15;
   const size_t o_blobs = kCtlBytes;
@@ -528,7 +530,8 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   const int n9 = sg.n9;
   const bool use_grid = sg.use_grid;
   const size_t tab_bytes = sg.tab_bytes;
-  if ((rc = upload_scan(f, st, use_grid ? o_tab + tab_bytes : o_exact))) return rc;
+  if (!sg.uploaded && (rc = upload_scan(f, st, use_grid ? o_tab + tab_bytes : o_exact))) return rc;
+  sg.uploaded = false;
   if ((slot & 3) == 3) PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
   f->gmax_fused = false;
   const double* blobs_dev = reinterpret_cast<const double*>(f->scan_dev + o_blobs);
@@ -1223,6 +1226,33 @@ int pk_pose_sums(pk_filter* f, double out[4]) {
 int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed, uint64_t draw,
             const double* blobs, int32_t B, const int32_t* ids, double u, int32_t weight_domain) {
   int rc;
+  // Throughput mode with ML association: the host half of the scan upload first, then ONE launch
+  // for the motion update and the upload of the scan block, then the observe kernels.
+  if (f && !z && !ids && B > 0 && blobs && f->map_loaded && f->upload_kernel && std::isfinite(v) && std::isfinite(w) &&
+      std::isfinite(dt)) {
+    bool finite = true;
+    for (int i = 0; i < 4 * B && finite; ++i) finite = std::isfinite(blobs[i]);
+    if (finite && B <= 65535) {
+      if ((rc = use_device(f))) return rc;
+      if ((rc = stage_ml_scan(f, blobs, B))) return rc;
+      pk_filter::Staged& sg = f->staged;
+      void* dev_view = nullptr;
+      if (hipHostGetDevicePointer(&dev_view, sg.st, 0) == hipSuccess && dev_view) {
+        const size_t o_exact = kCtlBytes + (size_t)B * 6 * sizeof(double);
+        const size_t o_tab = o_exact + (size_t)B * 6 * sizeof(double);
+        {
+          Span t(f, PK_T_MOTION);
+          launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view,
+                        sg.use_grid ? o_tab + sg.tab_bytes : o_exact);
+        }
+        sg.uploaded = true;
+        const double* staged_blobs = reinterpret_cast<const double*>(sg.st + kCtlBytes);
+        if ((rc = observe_impl(f, staged_blobs, B, nullptr, nullptr, true))) return rc;  // :73 (reset fused) + :82-124
+        return pk_resample(f, u, weight_domain, nullptr);                                // :137
+      }
+      (void)hipGetLastError();
+    }
+  }
   if ((rc = pk_motion(f, v, w, dt, z, seed, draw))) return rc;              // :75-77
   if ((rc = observe_impl(f, blobs, B, ids, nullptr, true))) return rc;    // :73 (reset fused) + :82-124
   return pk_resample(f, u, weight_domain, nullptr);                         // :137

@@ -12,7 +12,16 @@ __global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* 
                                                 double* __restrict__ h, int64_t P, double v, double w,
                                                 double dt, double sd, double sh,
                                                 const double* __restrict__ z, uint64_t seed,
-                                                uint64_t draw, int64_t goff) {
+                                                uint64_t draw, int64_t goff, int motion_blocks,
+                                                uint4* __restrict__ up_dst, const uint4* __restrict__ up_src,
+                                                int64_t up_n16) {
+  if ((int)blockIdx.x >= motion_blocks) {
+    // the extra workgroups of a combined launch: the per-scan upload (see k_upload)
+    const int64_t nb = (int64_t)gridDim.x - motion_blocks;
+    for (int64_t i = (int64_t)(blockIdx.x - motion_blocks) * blockDim.x + threadIdx.x; i < up_n16; i += nb * blockDim.x)
+      up_dst[i] = up_src[i];
+    return;
+  }
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   double z0, z1, z2;
@@ -47,13 +56,18 @@ __global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* 
 }
 
 void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt, const double* z_dev,
-                   uint64_t seed, uint64_t draw, int64_t global_offset) {
-  if (d.P == 0) return;
+                   uint64_t seed, uint64_t draw, int64_t global_offset, void* up_dst_dev,
+                   const void* up_src_host_mapped, size_t up_bytes) {
+  const int64_t n16 = up_dst_dev ? (int64_t)((up_bytes + 15) / 16) : 0;
+  if (d.P == 0 && n16 == 0) return;
   double sd = fabs(.05 * v) + fabs(.005 * w) + .0005;  // :185
   double sh = fabs(.025 * w) + fabs(.005 * v) + .0005;  // :190,:193
   int blocks = (int)((d.P + 255) / 256);
-  hipLaunchKernelGGL(k_motion, dim3(blocks), dim3(256), 0, s, d.x[d.cur], d.y[d.cur], d.h[d.cur], d.P, v, w,
-                     dt, sd, sh, z_dev, seed, draw, global_offset + d.global_offset);
+  int64_t ub = (n16 + 255) / 256;
+  if (ub > 256) ub = 256;
+  hipLaunchKernelGGL(k_motion, dim3((unsigned)(blocks + ub)), dim3(256), 0, s, d.x[d.cur], d.y[d.cur], d.h[d.cur], d.P,
+                     v, w, dt, sd, sh, z_dev, seed, draw, global_offset + d.global_offset, blocks,
+                     static_cast<uint4*>(up_dst_dev), static_cast<const uint4*>(up_src_host_mapped), n16);
 }
 
 __global__ void k_fill(double* p, int64_t n, double v) {

@@ -51,8 +51,11 @@ inline SlotSource slot_source(const DeviceState& d) {
 constexpr int kScanBlock = 1024;  // particles per weight-scan block (256 threads x 4)
 
 // K1
+// up_dst_dev != NULL: the same launch also pulls the per-scan block (up_bytes from the pinned,
+// device-mapped staging slot) into HBM with a few extra workgroups -- one launch less per step
 void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt, const double* z_dev,
-                   uint64_t seed, uint64_t draw, int64_t global_offset);
+                   uint64_t seed, uint64_t draw, int64_t global_offset, void* up_dst_dev = nullptr,
+                   const void* up_src_host_mapped = nullptr, size_t up_bytes = 0);
 void launch_reset_weights(hipStream_t s, DeviceState& d);
 // K2: maximum-likelihood association -> ids[P*B]
 // (a) reference kernel: every (landmark, blob) pair is gate-tested
