@@ -234,6 +234,8 @@ def main():
 
     from parakeet_slam_amd import _lib
 
+    if os.environ.get("PK_BENCH_LIB"):  # tuning experiments only: A/B of two builds on one box
+        _lib.LIB_PATH = os.path.join(ROOT, "parakeet_slam_amd", os.environ["PK_BENCH_LIB"])
     P, L = args.particles, args.landmarks
     K, W = args.steps, args.warmup
     EXTRA = 32  # untimed steps after the timed region (association share, supplied-ids route)

@@ -28,6 +28,10 @@ HEADERS = [
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-Wall", "-Wno-unused-function",
+    # a * b + c is fused only inside one expression (by the front end), not wherever the back end finds a
+    # multiply feeding an add: the same inlined device function then rounds the same way in every kernel
+    # (fused and two-kernel routes are required to agree bit for bit), whatever the surrounding control flow
+    "-ffp-contract=on",
 ]
 
 

@@ -21,6 +21,15 @@ constexpr int kRedBlocks = 1024;
 // phases that exchange data through LDS alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Diagnostic build only (-DPK_STAMPS, never shipped): shader-clock stamps for per-phase cycle sums.
+#ifdef PK_STAMPS
+#define PK_STAMP(var) \
+  unsigned long long var; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
+#else
+#define PK_STAMP(var)
+#endif
+
 // ------------------------------------------------------------------ reductions
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -41,6 +50,19 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= NW doubl
   __syncthreads();
   if (lane == 0) lds[wave] = v;
   __syncthreads();
+  double t = lds[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t += lds[i];
+  return t;
+}
+// The same sum with barriers that order LDS only: the workgroup's stores stay in flight (a
+// __syncthreads() waits for vmcnt(0), i.e. until every store of the wave has been acknowledged).
+template <int NW>
+__device__ __forceinline__ double block_sum_lds_only(double v, double* lds /* >= NW doubles, not in use */) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  if (lane == 0) lds[wave] = v;
+  lds_barrier();
   double t = lds[0];
 #pragma unroll
   for (int i = 1; i < NW; ++i) t += lds[i];

@@ -179,13 +179,9 @@ constexpr int kCand = 4;
 // Diagnostic build only (-DPK_STAMPS, never shipped): per-phase cycle sums of k_assoc_grid.
 #ifdef PK_STAMPS
 __device__ unsigned long long pk_stamp_acc[16];
-#define PK_STAMP(var) \
-  unsigned long long var; \
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");
 #define PK_STAMP_ADD(slot, a, b) \
   if ((threadIdx.x & 63) == 0) atomicAdd(&pk_stamp_acc[slot], (b) - (a));
 #else
-#define PK_STAMP(var)
 #define PK_STAMP_ADD(slot, a, b)
 #endif
 

@@ -194,7 +194,7 @@ __global__ void k_probe(const double* __restrict__ in, double* __restrict__ out)
   Landmark<double> f{mean[0], mean[1], mean[2], mean[3], mean[4], cov[0], cov[1], cov[6],
                      cov[12], cov[13], cov[14], cov[18], cov[19], cov[24], 0};
   BlobT<double> z{blob[0], blob[1], blob[2], blob[3]};
-  Noise<double> qt{Qt[0], Qt[5], Qt[6], Qt[7], Qt[10], Qt[11], Qt[15]};
+  const Noise<double> qt = make_noise(Qt[0], Qt[5], Qt[6], Qt[7], Qt[10], Qt[11], Qt[15]);
   const double ux = in[53], uy = in[54];  // unit((cos b, sin b, 0)), host side like the kernels' input
   for (int i = 0; i < 79; ++i) out[i] = 0.0;
   out[0] = probability_of_match(f, sx, sy, sh, z, ux, uy);

@@ -314,7 +314,7 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
-  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
   if (ids_dev == nullptr && ex.single_sightings && !ex.only_flagged && d.lay.Lp <= 1024 && g_observe_nv == 0) {
     if (d.lay.Lp <= 256)
       hipLaunchKernelGGL((k_observe_single<256>), dim3((unsigned)d.P), dim3(256), 0, s, a);

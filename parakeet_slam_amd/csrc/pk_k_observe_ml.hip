@@ -38,19 +38,24 @@ struct FastArgs {
   Noise<double> qt;
 };
 
+typedef float Float2 __attribute__((ext_vector_type(2)));
+
+// What a lane keeps about one gate-passing blob of its landmark between the phases of the settling.
 struct FastSlot {
   int t;                    // blob (cell order) or -1
-  int b;                    // its scan index
-  int q;                    // entry of the probability queue holding this slot's value, or -1
-  unsigned long long bits;  // contested candidate: probability bits (0: not positive)
-  unsigned flags;           // bit 0 contested, bit 1 apply the update, bit 2 unmatched (single, probability 0)
+  unsigned qf;              // bits 0-3 flags: 1 contested, 2 apply the update, 4 unmatched (single, probability 0),
+                            // 8 this lane bids for the contested blob; bits 4..: 1 + entry of the probability queue (0: none)
+  unsigned long long bits;  // in-place evaluation only (queue full): probability bits of a contested candidate
 };
 
-// probability_of_match (:439-455) from the two Mahalanobis terms and determinants
-__device__ __forceinline__ double pr_from_parts(double det2, double det3, double maha2, double maha3) {
-  const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + log(det2) + maha2));  // :439
-  const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + log(det3) + maha3));  // :446
-  return bp * cp / 250000.0;                                                                      // :455
+// probability_of_match (:439-455) from the determinants and the Mahalanobis terms' numerators
+// (maha = num / det: e' adj(P) e and d' adj(C) d -- the divisions are made here, for the few pairs
+// whose probability VALUE is needed, not in the code every lane runs)
+__device__ __forceinline__ double pr_from_parts(double det2, double det3, double num2, double num3) {
+  const double maha2 = num2 / det2, maha3 = num3 / det3;
+  const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + log_few_ulp(det2) + maha2));  // :439
+  const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + log_few_ulp(det3) + maha3));  // :446
+  return bp * cp / 250000.0;                                                                              // :455
 }
 
 // The few (landmark, blob) pairs whose probability VALUE is needed -- contested blobs, and pairs
@@ -61,35 +66,34 @@ constexpr int kFastQueue = 512;
 struct FastQueue {
   double* det2;   // [kFastQueue]
   double* det3;
-  double* maha2;  // overwritten with the probability bits by the evaluation pass
-  double* maha3;
+  double* maha2;  // numerator of the position Mahalanobis term (x 1 / det2); overwritten with the probability bits by the evaluation pass
+  double* maha3;  // numerator of the colour term (x 1 / det3)
   int* meta;      // blob t | contested << 16
   int* n;         // entries pushed (may exceed kFastQueue: the excess is evaluated in place)
 };
 __host__ __device__ inline size_t fast_queue_bytes() { return (size_t)kFastQueue * (4 * 8 + 4) + 16; }
 
-// exact / order: the scan's exact records [B][6] and cell -> scan order table, in global memory
-// (a.exact, a.order) or staged in LDS by the caller
-__device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* exact, const unsigned short* order,
+// exact: the scan's exact records [B][6], in global memory (a.exact) or staged in LDS by the caller.
+// INPLACE: entries that do not fit the queue are evaluated on the spot (k_observe_fast); without it
+// the caller checks *fq.n > kFastQueue afterwards and hands the particle to the general kernels.
+template <bool INPLACE>
+__device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* exact,
                                              const Landmark<double>& lm, double sx, double sy,
                                              double pse, uint2 packed, const unsigned char* bc,
                                              unsigned long long* best, const FastQueue& fq,
                                              FastSlot (&sl)[kFastSlots]) {
   const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
   double det3;
-  const Sym3<double> inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+  const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
   const bool dets_sane = det2 > 0.0 && det2 < 1e60 && det3 > 0.0 && det3 < 1e60;
   const unsigned w[2] = {packed.x, packed.y};
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
     const int t = (int)((w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
     sl[k].t = t == 0xFFFF ? -1 : t;
-    sl[k].b = INT_MAX;
-    sl[k].q = -1;
+    sl[k].qf = 0u;
     sl[k].bits = 0ull;
-    sl[k].flags = 0u;
     if (sl[k].t < 0) continue;
-    sl[k].b = order[t];
     const double* rec = exact + 6 * (size_t)t;
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
@@ -99,42 +103,45 @@ __device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* ex
     double nx, ny;
     closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
     const double ex = nx - lm.mx, ey = ny - lm.my;
-    const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / det2;
-    const double maha3 = sym3_quad(inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+    const double num2 = lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey;  // maha2 = num2 / det2
+    const double num3 = sym3_quad(adj3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);   // maha3 = num3 / det3
     const bool contested = bc[t] >= 2;
     // pr = (500 exp(a1)) (500 exp(a2)) / 250000 is certainly > 0 when a1 + a2 is far from the
-    // float64 underflow edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 here
-    const bool surely_positive = angle_ok && dets_sane && maha2 >= 0.0 && maha3 >= 0.0 && maha2 + maha3 < 800.0;
-    if (contested) sl[k].flags = 1u;
+    // float64 underflow edge: log det <= 138.2 for det <= 1e60, so a1 + a2 > -543 when
+    // maha2 + maha3 < 800 -- tested without a division: num2 det3 + num3 det2 < 800 det2 det3
+    // (both determinants positive; an overflow or NaN fails the test and the pair is evaluated)
+    const bool surely_positive = angle_ok && dets_sane && num2 >= 0.0 && num3 >= 0.0 &&
+                                 num2 * det3 + num3 * det2 < 800.0 * det2 * det3;
+    if (contested) sl[k].qf = 1u;
     if (!angle_ok) {  // bp = 0 (:475): probability 0
-      if (!contested) sl[k].flags = 4u;
+      if (!contested) sl[k].qf = 4u;
       continue;
     }
     if (!contested && surely_positive) {
-      sl[k].flags = 2u;
+      sl[k].qf = 2u;
       continue;
     }
     const int qi = atomicAdd(fq.n, 1);
     if (qi < kFastQueue) {
       fq.det2[qi] = det2;
       fq.det3[qi] = det3;
-      fq.maha2[qi] = maha2;
-      fq.maha3[qi] = maha3;
+      fq.maha2[qi] = num2;
+      fq.maha3[qi] = num3;
       fq.meta[qi] = t | (contested ? 0x10000 : 0);
-      sl[k].q = qi;
-    } else {  // queue full (dense clusters of look-alike landmarks): evaluate in place
-      // (opaque copies: keeps the compiler from hoisting the two log() out of this rare branch
-      // into the code every lane runs)
+      sl[k].qf |= (unsigned)(qi + 1) << 4;
+    } else if (INPLACE) {  // queue full (dense clusters of look-alike landmarks): evaluate in place
+      // (opaque copies: keeps the compiler from hoisting the logs out of this rare branch into the
+      // code every lane runs)
       double d2 = det2, d3 = det3;
       asm volatile("" : "+v"(d2), "+v"(d3));
-      const double pr = pr_from_parts(d2, d3, maha2, maha3);
+      const double pr = pr_from_parts(d2, d3, num2, num3);
       if (contested) {
         if (pr > 0.0) {
           sl[k].bits = (unsigned long long)__double_as_longlong(pr);
           atomicMax(&best[t], sl[k].bits);
         }
       } else {
-        sl[k].flags = pr > 0.0 ? 2u : 4u;
+        sl[k].qf = pr > 0.0 ? 2u : 4u;
       }
     }
   }
@@ -155,9 +162,9 @@ __device__ __forceinline__ void fast_evaluate_queue(const FastQueue& fq, unsigne
     const int i = base + ((lane >> 1) << 2) + wave;
     const bool on = i < n;
     const double det = on ? (role ? fq.det3[i] : fq.det2[i]) : 1.0;
-    const double maha = on ? (role ? fq.maha3[i] : fq.maha2[i]) : 0.0;
+    const double maha = (on ? (role ? fq.maha3[i] : fq.maha2[i]) : 0.0) / det;
     const double k = role ? 3.0 : 2.0;
-    const double mine = 500.0 * exp(-0.5 * (k * Consts<double>::log_two_pi + log(det) + maha));
+    const double mine = 500.0 * exp(-0.5 * (k * Consts<double>::log_two_pi + log_few_ulp(det) + maha));
     const double other = __shfl_xor(mine, 1, kWave);
     if (on && role == 0) {
       const double pr = mine * other / 250000.0;  // bp * cp / 250000
@@ -176,48 +183,51 @@ __device__ __forceinline__ void fast_collect(const FastQueue& fq, const unsigned
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
     if (sl[k].t < 0) continue;
-    if (sl[k].q >= 0) {
-      const unsigned long long bits = reinterpret_cast<const unsigned long long*>(fq.maha2)[sl[k].q];
-      if (sl[k].flags & 1u)
-        sl[k].bits = bits;
-      else
-        sl[k].flags = bits != 0ull ? 2u : 4u;
+    unsigned long long bits = sl[k].bits;
+    if (sl[k].qf >> 4) {
+      bits = reinterpret_cast<const unsigned long long*>(fq.maha2)[(sl[k].qf >> 4) - 1];
+      if (!(sl[k].qf & 1u)) sl[k].qf = bits != 0ull ? 2u : 4u;
     }
-    if ((sl[k].flags & 1u) && sl[k].bits != 0ull && sl[k].bits == best[sl[k].t]) atomicMin(&win[sl[k].t], l);
+    if ((sl[k].qf & 1u) && bits != 0ull && bits == best[sl[k].t]) {
+      atomicMin(&win[sl[k].t], l);
+      sl[k].qf |= 8u;
+    }
   }
 }
 
-__device__ __forceinline__ double fast_apply(const FastArgs& a, const double* exact, Landmark<double>& lm, int l,
-                                             double sx, double sy, double pse, FastSlot (&sl)[kFastSlots],
-                                             const int* win) {
+__device__ __forceinline__ double fast_apply(const FastArgs& a, const double* exact, const unsigned short* order,
+                                             Landmark<double>& lm, int l, double sx, double sy, double pse,
+                                             FastSlot (&sl)[kFastSlots], const int* win) {
   double acc = 0.0;
+  // per slot: scan index << 16 | blob when the update is applied, else all ones (sorts to the back)
+  unsigned key[kFastSlots];
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
+    key[k] = 0xFFFFFFFFu;
     if (sl[k].t < 0) continue;
-    if ((sl[k].flags & 1u) && sl[k].bits != 0ull && win[sl[k].t] == l) sl[k].flags |= 2u;
-    if (sl[k].flags & 4u) acc += Consts<double>::log_no_match;  // single candidate, probability 0 (:94-95)
-    if (!(sl[k].flags & 2u)) sl[k].b = INT_MAX;                 // not applied: sorts to the back
+    bool apply = (sl[k].qf & 2u) != 0u;
+    if ((sl[k].qf & 8u) && win[sl[k].t] == l) apply = true;          // the earliest of the best bidders
+    if (sl[k].qf & 4u) acc += Consts<double>::log_no_match;          // single candidate, probability 0 (:94-95)
+    if (apply) key[k] = ((unsigned)order[sl[k].t] << 16) | (unsigned)sl[k].t;
   }
   // the blobs to apply first, in scan order (:88) -- so that nearly every lane of the wave
-  // applies its (usually only) update in the same iteration (5-comparator network)
-  auto cswap = [&](FastSlot& u, FastSlot& v) {
-    if (u.b > v.b) {
-      const FastSlot tmp = u;
-      u = v;
-      v = tmp;
-    }
+  // applies its (usually only) update in the same iteration (5-comparator network on the keys)
+  auto cswap = [&](unsigned& u, unsigned& v) {
+    const unsigned lo = min(u, v), hi = max(u, v);
+    u = lo;
+    v = hi;
   };
-  cswap(sl[0], sl[1]);
-  cswap(sl[2], sl[3]);
-  cswap(sl[0], sl[2]);
-  cswap(sl[1], sl[3]);
-  cswap(sl[1], sl[2]);
+  cswap(key[0], key[1]);
+  cswap(key[2], key[3]);
+  cswap(key[0], key[2]);
+  cswap(key[1], key[3]);
+  cswap(key[1], key[2]);
   const bool imm = a.immutable[l] != 0;
   bool fresh = true;
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
-    if (sl[k].b == INT_MAX) continue;
-    const double* rec = exact + 6 * (size_t)sl[k].t;
+    if (key[k] == 0xFFFFFFFFu) continue;
+    const double* rec = exact + 6 * (size_t)(key[k] & 0xFFFFu);
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
     BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
@@ -273,8 +283,8 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   FastSlot sa[kFastSlots];
   // atan2(my - sy, mx - sx) of the untouched state, handed over by the association kernel
   const double pseA = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
-  fast_prepare(a, a.exact, a.order, A, sx, sy, pseA,
-               has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, fq, sa);
+  fast_prepare<true>(a, a.exact, A, sx, sy, pseA,
+                     has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, fq, sa);
   __syncthreads();
   fast_evaluate_queue(fq, best, tid, kFastThreads);
   __syncthreads();
@@ -282,7 +292,7 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   __syncthreads();
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
-  if (has) acc += fast_apply(a, a.exact, A, l, sx, sy, pseA, sa, win);
+  if (has) acc += fast_apply(a, a.exact, a.order, A, l, sx, sy, pseA, sa, win);
   if (active) {
     __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
     __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
@@ -332,7 +342,7 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
   a.B = B;
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
-  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
   const size_t lds = fast_queue_bytes() + (size_t)B * 13 + 16;
   hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
 }
@@ -369,8 +379,26 @@ size_t fused_lds_bytes(int ncell, int B, int n9, bool exact_lds) {
   return tab + (((size_t)B * 4 + 15) & ~(size_t)15) + fast_queue_bytes() + (size_t)B * 13 + 16;
 }
 
+// Diagnostic build only (-DPK_STAMPS): per-phase cycle sums of k_step_fused (slots 16.. of pk_debug_stamps).
+#ifdef PK_STAMPS
+__device__ unsigned long long pk_fstamp_acc[16];
+#define PK_FSTAMP_ADD(slot, a, b) \
+  if ((threadIdx.x & 63) == 0) atomicAdd(&pk_fstamp_acc[slot], (b) - (a));
+void debug_read_fused_stamps(unsigned long long* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_fstamp_acc), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pk_fstamp_acc), z, sizeof(z));
+  }
+}
+#else
+#define PK_FSTAMP_ADD(slot, a, b)
+#endif
+
 template <bool EXACT_LDS>
 __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
+  PK_STAMP(f0)
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kFastThreads / kWave];
   __shared__ int wg_flag;
@@ -414,16 +442,43 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   const int l = tid;
   const bool active = l < Lp, has = l < a.L;
   // ---- 1. tables -> LDS, own state ------------------------------------------------------------
-  // The table words are requested first and the whole state right behind them: vmcnt retires in
-  // order, so the LDS copy waits for the table words only, and every barrier of this kernel orders
-  // LDS alone -- the covariance rows arrive while the gates are worked out.
+  // All table words of the lane are requested in one batch (a copy loop of load / wait / LDS write
+  // costs one L2 round trip per 8 KB: six in a row at B = 500, 44 % of the workgroup's lifetime
+  // when measured with the -DPK_STAMPS build), the whole state right behind them: vmcnt retires
+  // in order, so the LDS writes wait for the table words only, and every barrier of this kernel
+  // orders LDS alone -- the covariance rows arrive while the gates are worked out.
+  constexpr int kTabBatch = 8;  // x 512 lanes x 16 B = 64 KB in one batch; larger tables: a loop for the rest
+  Landmark<double> A{};
   {
     const uint4* src = reinterpret_cast<const uint4*>(EXACT_LDS ? reinterpret_cast<const unsigned char*>(a.exact) : fa.tables);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (size_t i = tid; i < tab_bytes / 16; i += kFastThreads) dst[i] = src[i];
+    const unsigned n16 = (unsigned)(tab_bytes / 16);
+    uint4 tw[kTabBatch];
+    PK_STAMP(h0)
+    PK_FSTAMP_ADD(14, f0, h0)  // scalar prologue
+#pragma unroll
+    for (int j = 0; j < kTabBatch; ++j) {
+      // unconditional (clamped index): a predicated load gets a branch and a wait of its own
+      const unsigned i = (unsigned)tid + (unsigned)j * kFastThreads;
+      tw[j] = src[min(i, n16 - 1u)];
+    }
+    asm volatile("" ::: "memory");  // the table requests first: they come back first
+    // unconditional too (lanes beyond the map read its last landmark and never use or store it):
+    // straight-line code, so that the wait below is vmcnt(15) -- table words only
+    A = load_landmark(sf, sc, Lp, min(l, Lp - 1));
+    // the table words are needed HERE (keeps the compiler from sinking each load into its
+    // predicated LDS write, one round trip at a time); nothing moves across
+#pragma unroll
+    for (int j = 0; j < kTabBatch; ++j) asm volatile("" : "+v"(tw[j].x), "+v"(tw[j].y), "+v"(tw[j].z), "+v"(tw[j].w)::"memory");
+    PK_STAMP(h1)
+    PK_FSTAMP_ADD(15, h0, h1)  // table words arrived
+#pragma unroll
+    for (int j = 0; j < kTabBatch; ++j) {
+      const unsigned i = (unsigned)tid + (unsigned)j * kFastThreads;
+      if (i < n16) dst[i] = tw[j];
+    }
+    for (unsigned i = (unsigned)tid + kTabBatch * kFastThreads; i < n16; i += kFastThreads) dst[i] = src[i];
   }
-  Landmark<double> A{};
-  if (active) A = load_landmark(sf, sc, Lp, l);
   for (int t = tid; t < B; t += kFastThreads) {
     ccount[t] = 0;
     best[t] = 0ull;
@@ -434,11 +489,15 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
     wg_flag = 0;
   }
   lds_barrier();
+  PK_STAMP(f1)
+  PK_FSTAMP_ADD(0, f0, f1)
   // ---- 2. gates ----------------------------------------------------------------------------------
   unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;
   double pseA = 0.0;
   if (has) {
     const double mx = A.mx, my = A.my, mr = A.mr, mg = A.mg, mb = A.mb;
+    PK_STAMP(g0)
+    PK_FSTAMP_ADD(1, f1, g0)  // wait for the means
     pseA = atan2(my - sy, mx - sx);
     const double eb = pseA - sh;  // :408
     const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
@@ -459,10 +518,14 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
       i1 = start[base + k1 + 1];
     }
     int npass = 0;
+    // fp32 screen on packed pairs (v_pk_add_f32 / v_pk_mul_f32): (r, g) and (b, bearing)
+    const Float2 m01 = {mr32, mg32}, m23 = {mb32, eb32};
     auto prefilter_q = [&](const float4& q) {
-      const float d0 = q.x - mr32, d1 = q.y - mg32, d2 = q.z - mb32;
-      const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
-      return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
+      const Float2 q01 = {q.x, q.y}, q23 = {q.z, q.w};
+      const Float2 d01 = q01 - m01, d23 = q23 - m23;
+      const Float2 s01 = d01 * d01;
+      const float cd32 = fmaf(d23.x, d23.x, s01.x + s01.y);
+      return !(cd32 > g.thr32) && !(fabsf(d23.y) > g.thrb32);
     };
     auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
       if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
@@ -474,8 +537,10 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
         ++npass;
       }
     };
-    // phase 1 (LDS only): survivors of the fp32 screen, the first four kept in registers
-    int pc[4], npc = 0;
+    // phase 1 (LDS only): survivors of the fp32 screen, the LAST four kept in registers -- a 64-bit
+    // shift register of 16-bit blob indices (two instructions per survivor)
+    unsigned slo = 0u, shi = 0u;
+    int npc = 0;
     for (int i = i0; i < i1; i += 4) {
       int t4[4];
       float4 q4[4];
@@ -486,14 +551,16 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (i + j < i1 && prefilter_q(q4[j])) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (npc == k) pc[k] = t4[j];
+          shi = __builtin_amdgcn_alignbit(shi, slo, 16);
+          slo = (slo << 16) | (unsigned)t4[j];
           ++npc;
         }
     }
-    // phase 2 (global): the exact records of all survivors in one batch of loads, then the float64 gates
+    PK_STAMP(g1)
+    PK_FSTAMP_ADD(2, g0, g1)  // atan2, cell, walk
+    // phase 2: the exact records of the (last four) survivors in one batch of loads, then the float64 gates
     {
+      const int pc[4] = {(int)(slo & 0xFFFFu), (int)(slo >> 16), (int)(shi & 0xFFFFu), (int)(shi >> 16)};
       double2 z01[4], z23[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -506,22 +573,25 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
       for (int k = 0; k < 4; ++k)
         if (npc > k) exact_gates(pc[k], z01[k], z23[k]);
     }
-    if (npc > 4) {  // dense colour clusters: walk again for the survivors beyond the first four
+    if (npc > 4) {  // dense colour clusters: walk again for the survivors before the last four
       int seen = 0;
-      for (int i = i0; i < i1; ++i) {
+      for (int i = i0; i < i1 && seen < npc - 4; ++i) {
         const int t = idx9[i];
         if (prefilter_q(rec32[t])) {
-          if (seen >= 4) {
-            const double* rec = exact + 6 * (size_t)t;
-            exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
-          }
+          const double* rec = exact + 6 * (size_t)t;
+          exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
           ++seen;
         }
       }
     }
     if (npass > kFastSlots) wg_flag = 1;
+    PK_STAMP(g2)
+    PK_FSTAMP_ADD(3, g1, g2)  // exact gates
   }
+  PK_STAMP(f2)
   lds_barrier();
+  PK_STAMP(f3)
+  PK_FSTAMP_ADD(4, f2, f3)  // barrier wait after the gates
   // ---- 3. flagged particles go the general way ----------------------------------------------------
   if (wg_flag) {  // workgroup-uniform
     if (tid == 0) {
@@ -530,25 +600,44 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
     }
     return;
   }
-  if (tid == 0) fa.pflag_out[p] = 0;
   int nun = 0;  // blobs no landmark passes
   for (int t = tid; t < B; t += kFastThreads) {
     const int n = ccount[t];
     bc[t] = (unsigned char)(n > 255 ? 255 : n);
     nun += n == 0;
   }
-  // ---- 4. exactly k_observe_fast from here ----------------------------------------------------------
+  // ---- 4. k_observe_fast from here (same device functions, same bits) ---------------------------------
   lds_barrier();
   FastSlot sa[kFastSlots];
-  fast_prepare(a, exact, order, A, sx, sy, pseA, make_uint2(pass01, pass23), bc, best, fq, sa);
+  PK_STAMP(f4)
+  PK_FSTAMP_ADD(5, f3, f4)  // counts + barrier
+  fast_prepare<false>(a, exact, A, sx, sy, pseA, make_uint2(pass01, pass23), bc, best, fq, sa);
+  PK_STAMP(f5)
+  PK_FSTAMP_ADD(6, f4, f5)  // prepare (first use of the covariance rows)
   lds_barrier();
+  PK_STAMP(f6)
+  PK_FSTAMP_ADD(7, f5, f6)  // barrier wait after prepare
+  // more probabilities wanted than the queue holds (dense clusters of look-alike landmarks): nothing
+  // has been written yet, the general kernels take the particle
+  const bool overflow = *fq.n > kFastQueue;  // workgroup-uniform
+  if (tid == 0) {
+    fa.pflag_out[p] = overflow ? 1 : 0;
+    if (overflow) atomicAdd(fa.n_flagged, 1u);
+  }
+  if (overflow) return;
   fast_evaluate_queue(fq, best, tid, kFastThreads);
   lds_barrier();
+  PK_STAMP(f7)
+  PK_FSTAMP_ADD(8, f6, f7)  // queue evaluation + barrier
   fast_collect(fq, best, win, l, sa);
   lds_barrier();
+  PK_STAMP(f8)
+  PK_FSTAMP_ADD(9, f7, f8)  // collect + barrier
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
-  if (has) acc += fast_apply(a, exact, A, l, sx, sy, pseA, sa, win);
+  if (has) acc += fast_apply(a, exact, order, A, l, sx, sy, pseA, sa, win);
+  PK_STAMP(f9)
+  PK_FSTAMP_ADD(10, f8, f9)  // apply
   if (active) {
     __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
     __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
@@ -566,13 +655,18 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
     __builtin_nontemporal_store(A.cbb, &df[(size_t)F_CBB * Lp + l]);
     __builtin_nontemporal_store(A.count, &dc[l]);
   }
-  const double tot = block_sum<kFastThreads / kWave>(acc, red);
+  PK_STAMP(f10)
+  PK_FSTAMP_ADD(11, f9, f10)  // stores issued
+  const double tot = block_sum_lds_only<kFastThreads / kWave>(acc, red);  // the stores stay in flight
   if (tid == 0) {
     const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
     a.logw[p] = v;
     if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));
     a.src[p] = (int32_t)p;
   }
+  PK_STAMP(f11)
+  PK_FSTAMP_ADD(12, f10, f11)  // block sum
+  PK_FSTAMP_ADD(13, f0, f11)   // lifetime
 }
 
 void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
@@ -605,7 +699,7 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   a.B = B;
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
-  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
   fa.g = grid;
   fa.tables = tables_dev;
   fa.h = d.h[d.cur];
@@ -761,7 +855,7 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
         const double pse = entry_pse(l);
         const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
         double det3;
-        const Sym3<double> inv3 = sym3_inverse(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+        const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
 #pragma unroll 1
         for (int k = 0; k < SLOTS; ++k) {  // rolled: one copy of the code, a lane leaves at its first empty slot
           const int t = slot_of(k);
@@ -775,8 +869,9 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
           double nx, ny;
           closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
           const double ex = nx - lm.mx, ey = ny - lm.my;
-          const double maha2 = (lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey) / det2;
-          const double maha3 = sym3_quad(inv3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
+          // numerators of the two Mahalanobis terms (maha = num / det, divided in pr_from_parts)
+          const double maha2 = lm.pyy * ex * ex - 2.0 * lm.pxy * ex * ey + lm.pxx * ey * ey;
+          const double maha3 = sym3_quad(adj3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);
           const int qi = atomicAdd(&q_n[par], 1);
           if (qi < qcap) {
             q_det2[qi] = det2;
@@ -883,9 +978,9 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
                 double e2 = ex, e3 = ey;
                 asm volatile("" : "+v"(e2), "+v"(e3));  // opaque: keeps the divisions out of the code every lane runs
                 double det3b;
-                const Sym3<double> inv3 = sym3_inverse(Sym3<double>{A.crr, A.crg, A.crb, A.cgg, A.cgb, A.cbb}, det3b);
-                const double maha2 = (A.pyy * e2 * e2 - 2.0 * A.pxy * e2 * e3 + A.pxx * e3 * e3) / det2;
-                const double maha3 = sym3_quad(inv3, d1, d2c, d3c);
+                const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{A.crr, A.crg, A.crb, A.cgg, A.cgb, A.cbb}, det3b);
+                const double maha2 = A.pyy * e2 * e2 - 2.0 * A.pxy * e2 * e3 + A.pxx * e3 * e3;  // numerators
+                const double maha3 = sym3_quad(adj3, d1, d2c, d3c);
                 apply = pr_from_parts(det2, det3b, maha2, maha3) > 0.0;
               }
             }
@@ -976,7 +1071,7 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   a.qcap = plan.qcap;
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
-  a.qt = Noise<double>{qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb};
+  a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
   // never more workgroups than are resident at once (results_dev is sized for plan.grid)
   static size_t asked_lds = ~(size_t)0;
   static int asked_per_cu = 0;

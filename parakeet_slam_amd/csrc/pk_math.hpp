@@ -36,7 +36,12 @@ template <typename T>
 struct Noise {
   T q00;
   T rr, rg, rb, gg, gb, bb;
+  int diag;  // colour block diagonal (rg = rb = gb = 0, the reference's Qt = 0.1 I, :50-53): short forms below
 };
+template <typename T>
+__host__ __device__ inline Noise<T> make_noise(T q00, T rr, T rg, T rb, T gg, T gb, T bb) {
+  return Noise<T>{q00, rr, rg, rb, gg, gb, bb, (rg == T(0) && rb == T(0) && gb == T(0)) ? 1 : 0};
+}
 
 // One observed blob (matrix.blob_to_matrix, matrix.py:35-39).
 template <typename T>
@@ -50,8 +55,9 @@ struct Sym3 {
   T a, b, c, d, e, f;  // [[a,b,c],[b,d,e],[c,e,f]]
 };
 
+// Adjugate (the symmetric cofactor matrix) and determinant of a symmetric 3x3: inverse = adj / det.
 template <typename T>
-__device__ __forceinline__ Sym3<T> sym3_inverse(const Sym3<T>& m, T& det) {
+__device__ __forceinline__ Sym3<T> sym3_adjugate(const Sym3<T>& m, T& det) {
   T c00 = m.d * m.f - m.e * m.e;
   T c01 = m.c * m.e - m.b * m.f;
   T c02 = m.b * m.e - m.c * m.d;
@@ -59,8 +65,14 @@ __device__ __forceinline__ Sym3<T> sym3_inverse(const Sym3<T>& m, T& det) {
   T c12 = m.b * m.c - m.a * m.e;
   T c22 = m.a * m.d - m.b * m.b;
   det = m.a * c00 + m.b * c01 + m.c * c02;
+  return Sym3<T>{c00, c01, c02, c11, c12, c22};
+}
+
+template <typename T>
+__device__ __forceinline__ Sym3<T> sym3_inverse(const Sym3<T>& m, T& det) {
+  const Sym3<T> c = sym3_adjugate(m, det);
   T inv = T(1) / det;
-  return Sym3<T>{c00 * inv, c01 * inv, c02 * inv, c11 * inv, c12 * inv, c22 * inv};
+  return Sym3<T>{c.a * inv, c.b * inv, c.c * inv, c.d * inv, c.e * inv, c.f * inv};
 }
 
 template <typename T>
@@ -140,6 +152,39 @@ __device__ __forceinline__ T probability_of_match(const Landmark<T>& f, T sx, T 
   return bp * cp / T(250000);                                            // :455
 }
 
+// Natural logarithm accurate to 2 ulp (checked on the host against logl over 2e7 arguments from
+// 1e-304 to 1e304 and around 1): log(x) = e ln 2 + 2 atanh(s), s = (m - 1) / (m + 1), with x = m 2^e
+// and m in [sqrt(1/2), sqrt(2)) so that s^2 <= 0.0295 and eleven terms of the atanh series leave
+// < 1e-18.  About 45 float64 instructions against ~95 for the library log.  Used for the importance
+// factor (:844-849) and for the probabilities of contested pairs (:439, :446) -- quantities whose
+// tolerance is 1e-5 relative (north star) and which the parity tests hold to 1e-9; a tie between
+// identical landmarks stays a tie (same function, same inputs).  Anything that is not a positive
+// normal number takes the library path.
+__device__ __forceinline__ double log_few_ulp(double x) {
+  if (!(x > 2.3e-308 && x < 1.7e308)) return log(x);
+  int e = 0;
+  double m = frexp(x, &e);  // m in [0.5, 1)
+  if (m < 0.70710678118654752440) {
+    m *= 2.0;
+    e -= 1;
+  }
+  const double s = (m - 1.0) / (m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 21.0;
+  p = p * z + 1.0 / 19.0;
+  p = p * z + 1.0 / 17.0;
+  p = p * z + 1.0 / 15.0;
+  p = p * z + 1.0 / 13.0;
+  p = p * z + 1.0 / 11.0;
+  p = p * z + 1.0 / 9.0;
+  p = p * z + 1.0 / 7.0;
+  p = p * z + 1.0 / 5.0;
+  p = p * z + 1.0 / 3.0;
+  const double lm = 2.0 * s + 2.0 * s * (z * p);  // 2 atanh(s)
+  const double ed = (double)e;
+  return ed * 0.69314718055994528623 + (ed * 2.3190468138462995584e-17 + lm);  // ln 2 = hi + lo
+}
+
 // Intermediate quantities of one EKF update, for the probe entry point.
 template <typename T>
 struct EkfAux {
@@ -161,6 +206,9 @@ struct EkfAux {
 //   Q   = [h' Pxy h + q00] (+) [C + Qc]
 //   K   = [Pxy h / Q00]    (+) [C (C + Qc)^-1]
 //   Sigma' = [Pxy - (Pxy h)(Pxy h)'/Q00] (+) [C - C (C + Qc)^-1 C]
+// With a diagonal Qc the colour block is written C' = Qc (C + Qc)^-1 C (the same matrix:
+// I - C (C + Qc)^-1 = Qc (C + Qc)^-1), six products instead of eighteen and without the
+// subtraction; the Mahalanobis term is d'v with v = (C + Qc)^-1 d in both forms.
 template <typename T>
 __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<T>& z,
                                         const Noise<T>& qt, bool immutable,
@@ -194,13 +242,12 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
   // Frobenius norm of Q (matrix.py:31-33), not its determinant.
   T fro2 = q00 * q00 + qc.a * qc.a + qc.d * qc.d + qc.f * qc.f +
            T(2) * (qc.b * qc.b + qc.c * qc.c + qc.e * qc.e);
-  T maha = d0 * d0 * iq00 + sym3_quad(qci, d1, d2, d3);
-  T logw = T(-0.5) * (Consts<T>::log_two_pi + T(0.5) * log(fro2)) - T(0.5) * maha;
-
   // v = (C + Qc)^-1 d_c ;  M = (C + Qc)^-1 C  (3x3, rows r,g,b)
   T v0 = qci.a * d1 + qci.b * d2 + qci.c * d3;
   T v1 = qci.b * d1 + qci.d * d2 + qci.e * d3;
   T v2 = qci.c * d1 + qci.e * d2 + qci.f * d3;
+  T maha = d0 * d0 * iq00 + (d1 * v0 + d2 * v1 + d3 * v2);
+  T logw = T(-0.5) * (Consts<T>::log_two_pi + T(0.5) * log_few_ulp(fro2)) - T(0.5) * maha;
   T k0 = a0 * iq00, k1 = a1 * iq00;
 
   if (aux) {
@@ -239,13 +286,22 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
     T m20 = qci.c * f.crr + qci.e * f.crg + qci.f * f.crb;
     T m21 = qci.c * f.crg + qci.e * f.cgg + qci.f * f.cgb;
     T m22 = qci.c * f.crb + qci.e * f.cgb + qci.f * f.cbb;
-    // C' = C - C M (symmetric)
-    T nrr = f.crr - (f.crr * m00 + f.crg * m10 + f.crb * m20);
-    T nrg = f.crg - (f.crr * m01 + f.crg * m11 + f.crb * m21);
-    T nrb = f.crb - (f.crr * m02 + f.crg * m12 + f.crb * m22);
-    T ngg = f.cgg - (f.crg * m01 + f.cgg * m11 + f.cgb * m21);
-    T ngb = f.cgb - (f.crg * m02 + f.cgg * m12 + f.cgb * m22);
-    T nbb = f.cbb - (f.crb * m02 + f.cgb * m12 + f.cbb * m22);
+    T nrr, nrg, nrb, ngg, ngb, nbb;
+    if (qt.diag) {  // uniform.  C' = Qc M
+      nrr = qt.rr * m00;
+      nrg = qt.rr * m01;
+      nrb = qt.rr * m02;
+      ngg = qt.gg * m11;
+      ngb = qt.gg * m12;
+      nbb = qt.bb * m22;
+    } else {  // C' = C - C M (symmetric)
+      nrr = f.crr - (f.crr * m00 + f.crg * m10 + f.crb * m20);
+      nrg = f.crg - (f.crr * m01 + f.crg * m11 + f.crb * m21);
+      nrb = f.crb - (f.crr * m02 + f.crg * m12 + f.crb * m22);
+      ngg = f.cgg - (f.crg * m01 + f.cgg * m11 + f.cgb * m21);
+      ngb = f.cgb - (f.crg * m02 + f.cgg * m12 + f.cgb * m22);
+      nbb = f.cbb - (f.crb * m02 + f.cgb * m12 + f.cbb * m22);
+    }
     f.mr = nr;
     f.mg = ng;
     f.mb = nb;

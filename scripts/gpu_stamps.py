@@ -1,4 +1,5 @@
-"""Diagnostic: per-phase cycle shares of k_assoc_grid from the -DPK_STAMPS build."""
+"""Diagnostic: per-phase cycle shares of k_assoc_grid / k_step_fused from the -DPK_STAMPS build
+(python -m parakeet_slam_amd.build --stamps)."""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +14,7 @@ f = _lib.DeviceFilter(P, L)
 f.upload_map(means, covs.reshape(L, 25))
 so = _lib.load()
 so.pk_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 32)()
 for s in range(3):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
@@ -21,6 +22,15 @@ for s in range(3, 6):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
+if v[16 + 13] > 0:  # k_step_fused ran (L <= 512)
+    fn = ["tables->LDS + barrier", "wait for the means", "atan2, cell, walk", "exact gates", "barrier after gates",
+          "counts + barrier", "prepare (settling)", "barrier after prepare", "queue evaluation + barrier",
+          "collect + barrier", "apply (EKF)", "stores issued", "block sum", "lifetime",
+          "  (of the first:) scalar prologue", "  (of the first:) table words arrived"]
+    life = v[16 + 13]
+    for i, n in enumerate(fn):
+        print("fused %-28s %12.4g  %5.1f%%" % (n, v[16 + i], 100 * v[16 + i] / life))
+    sys.exit(0)
 names = ["init+sync", "S1 atan2+cell", "S1 phase1 walk", "S1 phase2 exact", "S1 total", "S1 barrier wait", "S2", "S3", "S4", "writeout"]
 tot = v[0] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9]
 for i, n in enumerate(names):
