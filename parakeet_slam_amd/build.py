@@ -13,6 +13,11 @@ import shutil
 import subprocess
 import sys
 
+# Per-file extra flags.  The ML observe kernels are register-bound: with MachineLICM on, the back end hoists
+# constant materialisations and address arithmetic out of every loop and keeps them live around it
+# (k_observe_sweep: 168 VGPRs + 96 B of scratch against 129 / none; k_step_fused: 121 against 99).
+EXTRA_FLAGS = {"pk_k_observe_ml.hip": ["-mllvm", "-disable-machine-licm"]}
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libparakeet_slam.so")
@@ -55,7 +60,7 @@ def build_stamps(verbose=True):
     hipcc = _hipcc()
     out = os.path.join(HERE, "libparakeet_slam_stamps.so")
     srcs = [os.path.join(CSRC, x) for x in HIP_SOURCES + CXX_SOURCES]
-    cmd = [hipcc] + HIPCC_FLAGS + ["-DPK_STAMPS", "-shared", "-o", out] + srcs
+    cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS["pk_k_observe_ml.hip"] + ["-DPK_STAMPS", "-shared", "-o", out] + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -73,7 +78,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or _stale(obj, [path] + headers + [os.path.abspath(__file__)]):
             if src.endswith(".hip"):
-                cmd = [hipcc] + HIPCC_FLAGS + ["-c", path, "-o", obj]
+                cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
             else:
                 cmd = [hipcc, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden",
                        "-ffp-contract=off", "-Wall", "-c", path, "-o", obj]

@@ -58,9 +58,9 @@ __device__ __forceinline__ double block_sum(double v, double* lds /* >= NW doubl
 // The same sum with barriers that order LDS only: the workgroup's stores stay in flight (a
 // __syncthreads() waits for vmcnt(0), i.e. until every store of the wave has been acknowledged).
 template <int NW>
-__device__ __forceinline__ double block_sum_lds_only(double v, double* lds /* >= NW doubles, not in use */) {
+__device__ __forceinline__ double block_sum_lds_only(double v, double* lds /* >= NW doubles, not in use */, int tid) {
   v = wave_sum(v);
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int wave = tid / kWave, lane = tid % kWave;
   if (lane == 0) lds[wave] = v;
   lds_barrier();
   double t = lds[0];
@@ -103,6 +103,29 @@ __device__ __forceinline__ Landmark<double> load_landmark(const double* f, const
   m.mr = f[F_MR * Lp + l];
   m.mg = f[F_MG * Lp + l];
   m.mb = f[F_MB * Lp + l];
+  m.pxx = f[F_PXX * Lp + l];
+  m.pxy = f[F_PXY * Lp + l];
+  m.pyy = f[F_PYY * Lp + l];
+  m.crr = f[F_CRR * Lp + l];
+  m.crg = f[F_CRG * Lp + l];
+  m.crb = f[F_CRB * Lp + l];
+  m.cgg = f[F_CGG * Lp + l];
+  m.cgb = f[F_CGB * Lp + l];
+  m.cbb = f[F_CBB * Lp + l];
+  m.count = cnt[l];
+  return m;
+}
+
+// The same with the five mean rows requested FIRST (vmcnt retires in order: a kernel whose first phase
+// needs only the means then waits for five loads, not for wherever the scheduler put them).
+__device__ __forceinline__ Landmark<double> load_landmark_means_first(const double* f, const int* cnt, int Lp, int l) {
+  Landmark<double> m;
+  m.mx = f[F_MX * Lp + l];
+  m.my = f[F_MY * Lp + l];
+  m.mr = f[F_MR * Lp + l];
+  m.mg = f[F_MG * Lp + l];
+  m.mb = f[F_MB * Lp + l];
+  asm volatile("" ::: "memory");
   m.pxx = f[F_PXX * Lp + l];
   m.pxy = f[F_PXY * Lp + l];
   m.pyy = f[F_PYY * Lp + l];

@@ -195,8 +195,9 @@ __device__ __forceinline__ void fast_collect(const FastQueue& fq, const unsigned
   }
 }
 
+// imm: Feature.__immutable__ of this landmark (:909, :926), read by the caller together with the state
 __device__ __forceinline__ double fast_apply(const FastArgs& a, const double* exact, const unsigned short* order,
-                                             Landmark<double>& lm, int l, double sx, double sy, double pse,
+                                             Landmark<double>& lm, int l, bool imm, double sx, double sy, double pse,
                                              FastSlot (&sl)[kFastSlots], const int* win) {
   double acc = 0.0;
   // per slot: scan index << 16 | blob when the update is applied, else all ones (sorts to the back)
@@ -222,7 +223,6 @@ __device__ __forceinline__ double fast_apply(const FastArgs& a, const double* ex
   cswap(key[0], key[2]);
   cswap(key[1], key[3]);
   cswap(key[1], key[2]);
-  const bool imm = a.immutable[l] != 0;
   bool fresh = true;
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
@@ -267,9 +267,11 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   const bool active = l < Lp, has = l < a.L;
   Landmark<double> A{};
   uint4 lp = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+  unsigned char immA = 0;
   if (active) {
     lp = a.lmpass[(size_t)p * Lp + l];  // first: the blob records it points to are the next dependent loads
     A = load_landmark(sf, sc, Lp, l);
+    immA = a.immutable[min(l, a.L - 1)];
   }
   for (int t = tid; t < B; t += kFastThreads) {
     best[t] = 0ull;
@@ -292,7 +294,8 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   __syncthreads();
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
-  if (has) acc += fast_apply(a, a.exact, a.order, A, l, sx, sy, pseA, sa, win);
+  if (has) acc += fast_apply(a, a.exact, a.order, A, l, immA != 0, sx, sy, pseA, sa, win);
+  asm volatile("" ::"v"(A.count));  // consumed on every path: no load left pending at the join below (it would cost a vmcnt(0) after the stores)
   if (active) {
     __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
     __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
@@ -397,14 +400,24 @@ void debug_read_fused_stamps(unsigned long long* out, bool reset) {
 #endif
 
 template <bool EXACT_LDS>
-__global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
+__global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) k_step_fused(FusedArgs fa) {
   PK_STAMP(f0)
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kFastThreads / kWave];
   __shared__ int wg_flag;
   const FastArgs& a = fa.f;
   const BlobGrid& g = fa.g;
-  const int64_t p = blockIdx.x;
+  // Every argument the first loads depend on is wanted at once: one batch of kernarg loads and one
+  // wait, not seven dependent round trips through the scalar cache before the first request leaves.
+  // A pure asm (no side effects: a volatile one in front of them would turn the scalar loads of
+  // src[p], x[p], ... into vector loads) whose result, an opaque zero, is added to the particle index.
+  int zero;
+  asm("s_mov_b32 %0, 0"
+      : "=s"(zero)
+      : "s"(fa.f.src), "s"(fa.f.x), "s"(fa.f.y), "s"(fa.h), "s"(fa.f.exact), "s"(fa.tables), "s"(fa.f.B), "s"(fa.n9),
+        "s"(fa.g.ncell), "s"(fa.f.Lp), "s"(fa.f.L), "s"(fa.f.ss.map), "s"(fa.f.ss.slot_bytes), "s"(fa.f.map_dst),
+        "s"(fa.f.count_off), "s"(fa.f.immutable), "s"(fa.f.ss.alt), "s"(fa.f.ss.alt_stride), "s"(fa.f.ss.alt_off));
+  const int64_t p = (int64_t)blockIdx.x + zero;
   const int tid = threadIdx.x;
   const int B = a.B, Lp = a.Lp;
   const size_t cs_bytes = grid_cs_bytes(g.ncell);
@@ -440,7 +453,6 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   int* dc = reinterpret_cast<int*>(dslot + a.count_off);
   const double sx = a.x[p], sy = a.y[p], sh = fa.h[p];
   const int l = tid;
-  const bool active = l < Lp, has = l < a.L;
   // ---- 1. tables -> LDS, own state ------------------------------------------------------------
   // All table words of the lane are requested in one batch (a copy loop of load / wait / LDS write
   // costs one L2 round trip per 8 KB: six in a row at B = 500, 44 % of the workgroup's lifetime
@@ -449,6 +461,9 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   // orders LDS alone -- the covariance rows arrive while the gates are worked out.
   constexpr int kTabBatch = 8;  // x 512 lanes x 16 B = 64 KB in one batch; larger tables: a loop for the rest
   Landmark<double> A{};
+  double lw0 = 0.0;    // the particle's log-weight so far (0 = log 1 after the fused reset, :73)
+  unsigned char immA;  // Feature.__immutable__ of the lane's landmark: one more load of this batch, not a
+                       // dependent L2 round trip in front of the update
   {
     const uint4* src = reinterpret_cast<const uint4*>(EXACT_LDS ? reinterpret_cast<const unsigned char*>(a.exact) : fa.tables);
     uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -465,7 +480,9 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
     asm volatile("" ::: "memory");  // the table requests first: they come back first
     // unconditional too (lanes beyond the map read its last landmark and never use or store it):
     // straight-line code, so that the wait below is vmcnt(15) -- table words only
-    A = load_landmark(sf, sc, Lp, min(l, Lp - 1));
+    A = load_landmark_means_first(sf, sc, Lp, min(l, Lp - 1));
+    immA = a.immutable[min(l, a.L - 1)];
+    if (!a.reset) lw0 = a.logw[p];  // requested with the state: read at the very end it would wait for every store of the wave
     // the table words are needed HERE (keeps the compiler from sinking each load into its
     // predicated LDS write, one round trip at a time); nothing moves across
 #pragma unroll
@@ -488,6 +505,7 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
     *fq.n = 0;
     wg_flag = 0;
   }
+  const bool active = l < Lp, has = l < a.L;
   lds_barrier();
   PK_STAMP(f1)
   PK_FSTAMP_ADD(0, f0, f1)
@@ -635,9 +653,12 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   PK_FSTAMP_ADD(9, f7, f8)  // collect + barrier
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
-  if (has) acc += fast_apply(a, exact, order, A, l, sx, sy, pseA, sa, win);
+  if (has) acc += fast_apply(a, exact, order, A, l, immA != 0, sx, sy, pseA, sa, win);
   PK_STAMP(f9)
   PK_FSTAMP_ADD(10, f8, f9)  // apply
+  // consumed on every path: no load is left pending at the join below -- it cost a vmcnt(0), i.e. every
+  // wave sat out the acknowledgement of all its stores before the block sum
+  asm volatile("" ::"v"(A.count));
   if (active) {
     __builtin_nontemporal_store(A.mx, &df[(size_t)F_MX * Lp + l]);
     __builtin_nontemporal_store(A.my, &df[(size_t)F_MY * Lp + l]);
@@ -657,9 +678,9 @@ __global__ void __launch_bounds__(kFastThreads) k_step_fused(FusedArgs fa) {
   }
   PK_STAMP(f10)
   PK_FSTAMP_ADD(11, f9, f10)  // stores issued
-  const double tot = block_sum_lds_only<kFastThreads / kWave>(acc, red);  // the stores stay in flight
+  const double tot = block_sum_lds_only<kFastThreads / kWave>(acc, red, tid);  // the stores stay in flight
   if (tid == 0) {
-    const double v = (a.reset ? 0.0 : a.logw[p]) + tot;
+    const double v = lw0 + tot;
     a.logw[p] = v;
     if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));
     a.src[p] = (int32_t)p;
@@ -707,10 +728,12 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   fa.n_flagged = fh.n_flagged;
   fa.n9 = n9;
   // exact records + order table in LDS as well when two workgroups per CU still fit
-  if (fused_lds_bytes(grid.ncell, B, n9, true) <= kFusedMaxLds)
-    hipLaunchKernelGGL(k_step_fused<true>, dim3((unsigned)d.P), dim3(kFastThreads), fused_lds_bytes(grid.ncell, B, n9, true), s, fa);
+  const bool exact_lds = fused_lds_bytes(grid.ncell, B, n9, true) <= kFusedMaxLds;
+  const size_t lds = fused_lds_bytes(grid.ncell, B, n9, exact_lds);
+  if (exact_lds)
+    hipLaunchKernelGGL((k_step_fused<true>), dim3((unsigned)d.P), dim3(kFastThreads), lds, s, fa);
   else
-    hipLaunchKernelGGL(k_step_fused<false>, dim3((unsigned)d.P), dim3(kFastThreads), fused_lds_bytes(grid.ncell, B, n9, false), s, fa);
+    hipLaunchKernelGGL((k_step_fused<false>), dim3((unsigned)d.P), dim3(kFastThreads), lds, s, fa);
 }
 
 // ------------------------------------------------------------------ K3 (sweep ML variant, any L)
