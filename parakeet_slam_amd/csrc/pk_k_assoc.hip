@@ -265,15 +265,27 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         c[k] = (int)q;
       }
       const int k0 = max(c[2] - 1, 0), k1 = min(c[2] + 1, g.G[2] - 1);
-      int pc[kCand];
+      // survivors of the fp32 screen: the LAST kCand = 4 kept in a 64-bit shift register of 16-bit
+      // blob indices (two instructions per survivor instead of a compare-and-select chain)
+      unsigned slo = 0u, shi = 0u;
       int npc = 0;
+      auto push = [&](int t) {
+        shi = __builtin_amdgcn_alignbit(shi, slo, 16);
+        slo = (slo << 16) | (unsigned)t;
+        ++npc;
+      };
       PK_STAMP(ta1)
       PK_STAMP_ADD(1, ta0, ta1)
+      // fp32 screen on packed pairs (v_pk_add_f32 / v_pk_mul_f32): (r, g) and (b, bearing)
+      typedef float Float2 __attribute__((ext_vector_type(2)));
+      const Float2 m01 = {mr32, mg32}, m23 = {mb32, eb32};
       auto prefilter_q = [&](const float4& q) {
-        const float d0 = q.x - mr32, d1 = q.y - mg32, d2 = q.z - mb32;
-        const float cd32 = d0 * d0 + d1 * d1 + d2 * d2;
+        const Float2 q01 = {q.x, q.y}, q23 = {q.z, q.w};
+        const Float2 d01 = q01 - m01, d23 = q23 - m23;
+        const Float2 s01 = d01 * d01;
+        const float cd32 = fmaf(d23.x, d23.x, s01.x + s01.y);
         // conservative fp32 gates; NaN/inf fall through to the exact float64 tests
-        return !(cd32 > g.thr32) && !(fabsf(q.w - eb32) > g.thrb32);
+        return !(cd32 > g.thr32) && !(fabsf(d23.y) > g.thrb32);
       };
       auto prefilter = [&](int t) { return prefilter_q(rec32[t]); };
       unsigned pass[SLOTS / 2];  // the blobs that pass this landmark's gates (first SLOTS), two per word
@@ -315,12 +327,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
           for (int j = 0; j < 4; ++j) q4[j] = rec32[t4[j]];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            if (i + j < i1 && prefilter_q(q4[j])) {
-#pragma unroll
-              for (int k = 0; k < kCand; ++k)
-                if (npc == k) pc[k] = t4[j];
-              ++npc;
-            }
+            if (i + j < i1 && prefilter_q(q4[j])) push(t4[j]);
           }
         }
       } else {
@@ -339,12 +346,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
               for (int i = 0; i < 4; ++i) q4[i] = rec32[min(t + i, B - 1)];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                if (t + i < t1 && prefilter_q(q4[i])) {
-#pragma unroll
-                  for (int k = 0; k < kCand; ++k)
-                    if (npc == k) pc[k] = t + i;
-                  ++npc;
-                }
+                if (t + i < t1 && prefilter_q(q4[i])) push(t + i);
               }
             }
           }
@@ -354,6 +356,8 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
       PK_STAMP_ADD(2, ta1, ta2)
       // ---- phase 2 (global, convergent): all survivors' exact records in one batch -----
       if (__any(npc > 0)) {
+        static_assert(kCand == 4, "the shift register holds four 16-bit indices");
+        const int pc[kCand] = {(int)(slo & 0xFFFFu), (int)(slo >> 16), (int)(shi & 0xFFFFu), (int)(shi >> 16)};
         double2 z01[kCand], z23[kCand];
 #pragma unroll
         for (int k = 0; k < kCand; ++k)
@@ -370,12 +374,12 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
       PK_STAMP_ADD(3, ta2, ta3)
       if (npc > kCand) {
         // more fp32 survivors than register slots (dense colour clusters): walk again and take
-        // the ones beyond the first kCand as they come (nine-range walk works for both layouts
+        // the ones before the last kCand as they come (nine-range walk works for both layouts
         // only without DUP; with DUP repeat the single range)
         int seen = 0;
         auto late = [&](int t) {
           if (prefilter(t)) {
-            if (seen >= kCand) {
+            if (seen < npc - kCand) {
               const double* rec = ga.exact + 6 * (size_t)t;
               exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
             }

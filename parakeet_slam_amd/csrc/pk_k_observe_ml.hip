@@ -576,20 +576,33 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
     }
     PK_STAMP(g1)
     PK_FSTAMP_ADD(2, g0, g1)  // atan2, cell, walk
-    // phase 2: the exact records of the (last four) survivors in one batch of loads, then the float64 gates
+    // phase 2: the float64 gates of the (last four) survivors.  Records in global memory: all loads in
+    // one batch (one L2 round trip instead of four); records in LDS: one at a time (16 instead of 32
+    // VGPRs at the kernel's register peak)
     {
       const int pc[4] = {(int)(slo & 0xFFFFu), (int)(slo >> 16), (int)(shi & 0xFFFFu), (int)(shi >> 16)};
-      double2 z01[4], z23[4];
+      if (EXACT_LDS) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (npc > k) {
-          const double* rec = exact + 6 * (size_t)pc[k];
-          z01[k] = *reinterpret_cast<const double2*>(rec);
-          z23[k] = *reinterpret_cast<const double2*>(rec + 2);
-        }
+        for (int k = 0; k < 4; ++k)
+          if (npc > k) {
+            const double* rec = exact + 6 * (size_t)pc[k];
+            const double2 z01 = *reinterpret_cast<const double2*>(rec);
+            const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+            exact_gates(pc[k], z01, z23);
+          }
+      } else {
+        double2 z01[4], z23[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (npc > k) exact_gates(pc[k], z01[k], z23[k]);
+        for (int k = 0; k < 4; ++k)
+          if (npc > k) {
+            const double* rec = exact + 6 * (size_t)pc[k];
+            z01[k] = *reinterpret_cast<const double2*>(rec);
+            z23[k] = *reinterpret_cast<const double2*>(rec + 2);
+          }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (npc > k) exact_gates(pc[k], z01[k], z23[k]);
+      }
     }
     if (npc > 4) {  // dense colour clusters: walk again for the survivors before the last four
       int seen = 0;
