@@ -276,18 +276,15 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
     T nxx = f.pxx - k0 * a0;
     T nxy = f.pxy - T(0.5) * (k0 * a1 + k1 * a0);
     T nyy = f.pyy - k1 * a1;
-    // M = Qci C
+    T nrr, nrg, nrb, ngg, ngb, nbb;
+    // M = Qci C (rows r, g, b)
     T m00 = qci.a * f.crr + qci.b * f.crg + qci.c * f.crb;
     T m01 = qci.a * f.crg + qci.b * f.cgg + qci.c * f.cgb;
     T m02 = qci.a * f.crb + qci.b * f.cgb + qci.c * f.cbb;
-    T m10 = qci.b * f.crr + qci.d * f.crg + qci.e * f.crb;
     T m11 = qci.b * f.crg + qci.d * f.cgg + qci.e * f.cgb;
     T m12 = qci.b * f.crb + qci.d * f.cgb + qci.e * f.cbb;
-    T m20 = qci.c * f.crr + qci.e * f.crg + qci.f * f.crb;
-    T m21 = qci.c * f.crg + qci.e * f.cgg + qci.f * f.cgb;
     T m22 = qci.c * f.crb + qci.e * f.cgb + qci.f * f.cbb;
-    T nrr, nrg, nrb, ngg, ngb, nbb;
-    if (qt.diag) {  // uniform.  C' = Qc M
+    if (qt.diag) {  // uniform.  C' = Qc M: the upper triangle of M is all it takes
       nrr = qt.rr * m00;
       nrg = qt.rr * m01;
       nrb = qt.rr * m02;
@@ -295,6 +292,9 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
       ngb = qt.gg * m12;
       nbb = qt.bb * m22;
     } else {  // C' = C - C M (symmetric)
+      T m10 = qci.b * f.crr + qci.d * f.crg + qci.e * f.crb;
+      T m20 = qci.c * f.crr + qci.e * f.crg + qci.f * f.crb;
+      T m21 = qci.c * f.crg + qci.e * f.cgg + qci.f * f.cgb;
       nrr = f.crr - (f.crr * m00 + f.crg * m10 + f.crb * m20);
       nrg = f.crg - (f.crr * m01 + f.crg * m11 + f.crb * m21);
       nrb = f.crb - (f.crr * m02 + f.crg * m12 + f.crb * m22);
