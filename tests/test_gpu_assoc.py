@@ -299,6 +299,39 @@ def test_sweep_observe_everything_contested_across_chunks(lib):
     check_fast(lib, 6, means, covs, poses, blobs)
 
 
+def test_fused_queue_overflow_goes_the_general_way(lib):
+    # L = 512 in groups of four look-alike bearing neighbours: every blob is contested by four
+    # landmarks, 2048 probabilities are wanted and the LDS queue of k_step_fused holds 512 -> the
+    # particle is handed to the general kernels (nothing was written yet); the two-kernel route
+    # evaluates the excess in place.  All against the oracle; the fused route must then be the
+    # general route bit for bit.
+    rs = np.random.RandomState(17)
+    L, P = 512, 6
+    means, covs = synthetic_world(L)
+    g = np.arange(L // 4)
+    lattice = np.stack([g % 8, (g // 8) % 4, g // 32], axis=1) * 36.0 + 10.0  # groups two gates apart
+    means[:, 2:] = np.repeat(lattice, 4, axis=0) + rs.uniform(-2, 2, (L, 3))
+    covs = covs * rs.uniform(0.5, 2.0, (L, 1, 1))
+    perm = rs.permutation(L)
+    means, covs = means[perm], covs[perm]
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    poses = rand_poses(rs, P, 0.1)
+    assert max_passers(means, blobs, poses) == 4
+    fused = observe_state(lib, P, means, covs, poses, blobs, 1)
+    two = observe_state(lib, P, means, covs, poses, blobs, 1, fused=0)
+    gen = observe_state(lib, P, means, covs, poses, blobs, 0)
+    o = oracle_state(P, means, covs, poses, blobs)
+    for got in (fused, two, gen):
+        assert np.allclose(got[0][:, 3], o.weights(), rtol=1e-9, atol=0)
+        m, c, k = got[1]
+        assert np.allclose(m, o.mean, rtol=1e-10, atol=1e-12)
+        assert np.allclose(c, o.cov, rtol=1e-9, atol=1e-13)
+        assert np.array_equal(k, o.count)
+    assert np.array_equal(fused[0], gen[0])
+    for x, y in zip(fused[1], gen[1]):
+        assert np.array_equal(x, y)
+
+
 def test_sweep_observe_ties_across_chunks_keep_the_earliest(lib):
     # exact duplicates 600 landmarks apart: equal probabilities from different chunks, earliest wins (:377)
     rs = np.random.RandomState(12)
