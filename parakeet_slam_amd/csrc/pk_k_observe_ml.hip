@@ -76,10 +76,11 @@ __host__ __device__ inline size_t fast_queue_bytes() { return (size_t)kFastQueue
 // exact: the scan's exact records [B][6], in global memory (a.exact) or staged in LDS by the caller.
 // INPLACE: entries that do not fit the queue are evaluated on the spot (k_observe_fast); without it
 // the caller checks *fq.n > kFastQueue afterwards and hands the particle to the general kernels.
-template <bool INPLACE>
+// bc: landmarks passing each blob's gates (unsigned char from the hand-off, or the int LDS counters of k_step_fused)
+template <bool INPLACE, typename CountT>
 __device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* exact,
                                              const Landmark<double>& lm, double sx, double sy,
-                                             double pse, uint2 packed, const unsigned char* bc,
+                                             double pse, uint2 packed, const CountT* bc,
                                              unsigned long long* best, const FastQueue& fq,
                                              FastSlot (&sl)[kFastSlots]) {
   const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   FastSlot sa[kFastSlots];
   // atan2(my - sy, mx - sx) of the untouched state, handed over by the association kernel
   const double pseA = __longlong_as_double((long long)(((unsigned long long)lp.w << 32) | lp.z));
-  fast_prepare<true>(a, a.exact, A, sx, sy, pseA,
+  fast_prepare<true, unsigned char>(a, a.exact, A, sx, sy, pseA,
                      has ? make_uint2(lp.x, lp.y) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), bc, best, fq, sa);
   __syncthreads();
   fast_evaluate_queue(fq, best, tid, kFastThreads);
@@ -443,7 +444,6 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
   fq.n = fq.meta + kFastQueue;
   unsigned long long* best = reinterpret_cast<unsigned long long*>(qbase + fast_queue_bytes());
   int* win = reinterpret_cast<int*>(best + B);
-  unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
 
   const unsigned char* sslot = a.ss.at(a.src[p]);
   unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
@@ -631,18 +631,14 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
     }
     return;
   }
+  // ---- 4. k_observe_fast from here (same device functions, same bits); the per-blob counts are read
+  // straight from the LDS counters (no conversion pass, one barrier less)
   int nun = 0;  // blobs no landmark passes
-  for (int t = tid; t < B; t += kFastThreads) {
-    const int n = ccount[t];
-    bc[t] = (unsigned char)(n > 255 ? 255 : n);
-    nun += n == 0;
-  }
-  // ---- 4. k_observe_fast from here (same device functions, same bits) ---------------------------------
-  lds_barrier();
+  for (int t = tid; t < B; t += kFastThreads) nun += ccount[t] == 0;
   FastSlot sa[kFastSlots];
   PK_STAMP(f4)
-  PK_FSTAMP_ADD(5, f3, f4)  // counts + barrier
-  fast_prepare<false>(a, exact, A, sx, sy, pseA, make_uint2(pass01, pass23), bc, best, fq, sa);
+  PK_FSTAMP_ADD(5, f3, f4)  // counts
+  fast_prepare<false, int>(a, exact, A, sx, sy, pseA, make_uint2(pass01, pass23), ccount, best, fq, sa);
   PK_STAMP(f5)
   PK_FSTAMP_ADD(6, f4, f5)  // prepare (first use of the covariance rows)
   lds_barrier();
@@ -664,7 +660,7 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
   lds_barrier();
   PK_STAMP(f8)
   PK_FSTAMP_ADD(9, f7, f8)  // collect + barrier
-  for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
+  for (int t = tid; t < B; t += kFastThreads) nun += (ccount[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
   if (has) acc += fast_apply(a, exact, order, A, l, immA != 0, sx, sy, pseA, sa, win);
   PK_STAMP(f9)
