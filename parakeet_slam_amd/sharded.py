@@ -188,6 +188,7 @@ class HipShard(_lib.DeviceFilter):
         self.tdev = torch.device("cuda", device)
         self.stream = torch.cuda.Stream(device=self.tdev)
         self.set_stream(self.stream.cuda_stream)
+        self._host_reads = {}
 
     def on_stream(self):
         return self.torch.cuda.stream(self.stream)
@@ -221,9 +222,15 @@ class HipShard(_lib.DeviceFilter):
         """Begin copying a small device tensor to pinned host memory on the shard's stream; returns a
         handle for finish_host_read.  Lets the caller do host work before it has to wait."""
         torch = self.torch
-        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        # the pinned landing buffer and the event are kept (a pinned allocation per step costs tens of
+        # microseconds of host time in front of the next step's launches); one read is pending at a time
+        key = (tuple(t.shape), t.dtype)
+        slot = self._host_reads.get(key)
+        if slot is None:
+            slot = (torch.empty(t.shape, dtype=t.dtype, pin_memory=True), torch.cuda.Event())
+            self._host_reads[key] = slot
+        host, ev = slot
         host.copy_(t, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.tdev))
         return host, ev
 
@@ -231,7 +238,7 @@ class HipShard(_lib.DeviceFilter):
     def finish_host_read(handle):
         host, ev = handle
         ev.synchronize()
-        return host.numpy()
+        return host.numpy().copy()  # the buffer is reused by the next read
 
 
 class ShardedFilter(object):
