@@ -75,6 +75,7 @@ struct pk_filter {
   double* g_offsets = nullptr;
   int64_t gblocks_cap = 0;
   int64_t* hi_dev = nullptr;    // P + 1
+  unsigned* plan_ticket = nullptr;  // workgroup counter of the one-launch shard plan
   int64_t* idx_dev = nullptr;   // P
   int64_t* srcs_dev = nullptr;  // P
   int64_t* rlohi_dev = nullptr; // (lo, hi) of the received records
@@ -718,7 +719,7 @@ int pk_destroy(pk_filter* f) {
   if (f->scan_dev) (void)hipFree(f->scan_dev);
   for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results})
     if (q) (void)hipFree(q);
-  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
+  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
   void* rest[] = {d.immutable, f->z_dev,  f->ids_dev,
                   f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
@@ -929,6 +930,13 @@ int pk_reset_weights(pk_filter* f) {
   return PK_OK;
 }
 
+// bytes of a staged ML scan block that the device needs: ctl | blobs + directions | exact records | [tables]
+static size_t staged_upload_bytes(const pk_filter::Staged& sg) {
+  const size_t o_exact = kCtlBytes + (size_t)sg.B * 6 * sizeof(double);
+  const size_t o_tab = o_exact + (size_t)sg.B * 6 * sizeof(double);
+  return sg.use_grid ? o_tab + sg.tab_bytes : o_exact;
+}
+
 int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint64_t seed, uint64_t draw) {
   if (!f) return fail(PK_ERR_INVALID, "pk_motion: NULL handle");
   if (!std::isfinite(v) || !std::isfinite(w) || !std::isfinite(dt)) return fail(PK_ERR_INVALID, "pk_motion: non-finite control");
@@ -942,6 +950,19 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
     zd = f->z_dev;
   }
   Span t(f, PK_T_MOTION);
+  // a scan staged by pk_stage_scan and not uploaded yet rides in extra workgroups of this launch
+  // (what pk_step does; the sharded step stages the next scan before it calls pk_motion)
+  pk_filter::Staged& sg = f->staged;
+  if (!z && sg.valid && !sg.uploaded && f->upload_kernel) {
+    void* dev_view = nullptr;
+    if (hipHostGetDevicePointer(&dev_view, sg.st, 0) == hipSuccess && dev_view) {
+      launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg));
+      sg.uploaded = true;
+      f->gmax_fused = false;  // the block's control words (running weight maximum) were just overwritten
+      return PK_OK;
+    }
+    (void)hipGetLastError();
+  }
   launch_motion(f->stream, f->d, v, w, dt, zd, seed, draw, 0);
   return PK_OK;
 }
@@ -1238,12 +1259,9 @@ int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64
       pk_filter::Staged& sg = f->staged;
       void* dev_view = nullptr;
       if (hipHostGetDevicePointer(&dev_view, sg.st, 0) == hipSuccess && dev_view) {
-        const size_t o_exact = kCtlBytes + (size_t)B * 6 * sizeof(double);
-        const size_t o_tab = o_exact + (size_t)B * 6 * sizeof(double);
         {
           Span t(f, PK_T_MOTION);
-          launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view,
-                        sg.use_grid ? o_tab + sg.tab_bytes : o_exact);
+          launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg));
         }
         sg.uploaded = true;
         const double* staged_blobs = reinterpret_cast<const double*>(sg.st + kCtlBytes);
@@ -1409,7 +1427,18 @@ int pk_shard_plan_dev(pk_filter* f, const double* dev_global_totals, int64_t n_g
     f->gblocks_cap = n_global_blocks;
   }
   if (!f->hi_dev && (rc = dev_alloc(f, &f->hi_dev, (size_t)f->d.P + 1))) return rc;
+  if (!f->plan_ticket) {
+    if ((rc = dev_alloc(f, &f->plan_ticket, (size_t)1))) return rc;
+    PK_HIP(hipMemsetAsync(f->plan_ticket, 0, sizeof(unsigned), f->stream));
+  }
   Span t(f, PK_T_WEIGHTS);
+  if (n_global_blocks <= kAncestorsScanMaxBlocks) {
+    // one launch: every workgroup scans the few global block totals itself, the last one to finish
+    // writes the per-destination ranges
+    launch_offspring_plan(f->stream, f->clocal, dev_global_totals, n_global_blocks, first_block, f->d.P, global_particles, u,
+                          last_shard ? 1 : 0, f->hi_dev, world, dev_ranges, f->plan_ticket);
+    return PK_OK;
+  }
   launch_scan_blocks(f->stream, dev_global_totals, n_global_blocks, f->g_offsets, f->sum);
   launch_offspring(f->stream, f->clocal, f->g_offsets, f->sum, first_block, f->d.P, global_particles, u,
                    last_shard ? 1 : 0, f->hi_dev);

@@ -218,46 +218,140 @@ void launch_ancestors(hipStream_t s, const double* clocal_dev, const double* tot
 // the output slots [hi_{j-1}, hi_j), hi_j = #{k : t_k <= C_j}.  hi[0] is the count at the
 // shard's lower boundary, hi[1 + j] that of particle j.  Every shard evaluates the same
 // formula on the same block offsets, so the slot ranges tile [0, P) without communication.
+//
+// Two launches are folded in when the caller asks for them: with offsets == NULL (<= kAncMaxBlocks global
+// scan blocks) every workgroup scans the global block totals itself, sequentially in block order -- the
+// same additions in the same order as k_scan_blocks, as k_ancestors does; and with ranges != NULL the
+// LAST workgroup to finish (ticket counter, reset for the next call) derives the per-destination
+// particle ranges that k_shard_ranges would: 2 x world binary searches over the finished hi[].
 __global__ void __launch_bounds__(256) k_offspring(const double* __restrict__ clocal,
-                                                   const double* __restrict__ offsets,
-                                                   const double* __restrict__ sum, int64_t first_block,
+                                                   const double* __restrict__ totals, const double* offsets,
+                                                   const double* sum, int64_t nb_global, int64_t first_block,
                                                    int64_t Pl, int64_t Pg, double u, int last_shard,
-                                                   int64_t* __restrict__ hi) {
+                                                   int64_t* __restrict__ hi, int world, int64_t* __restrict__ ranges,
+                                                   unsigned* __restrict__ ticket) {
+  __shared__ double s_off[kAncMaxBlocks + 1];
+  __shared__ int s_last;
+  if (offsets == nullptr) {
+    // the totals are fetched by all lanes at once (one L2 round trip), then scanned by one thread
+    for (int b = threadIdx.x; b < nb_global; b += blockDim.x) s_off[b] = totals[b];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double run = 0.0;
+      for (int64_t b = 0; b < nb_global; ++b) {
+        const double v = s_off[b];
+        s_off[b] = run;
+        run += v;
+      }
+      s_off[nb_global] = run;
+    }
+    __syncthreads();
+    offsets = s_off;
+    sum = s_off + nb_global;
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 0 .. Pl
-  if (i > Pl) return;
-  const double r = __ddiv_rn(sum[0], (double)Pg);
-  const double ur = __dmul_rn(u, r);
-  double C;
-  if (i == 0) {
-    if (first_block == 0) {
-      hi[0] = 0;
-      return;
+  if (i <= Pl) {
+    const double r = __ddiv_rn(sum[0], (double)Pg);
+    const double ur = __dmul_rn(u, r);
+    double C = 0.0;
+    bool search = true;
+    int64_t val = 0;
+    if (i == 0) {
+      if (first_block == 0) {
+        val = 0;
+        search = false;
+      } else {
+        C = offsets[first_block];
+      }
+    } else {
+      const int64_t j = i - 1;
+      if (last_shard && j == Pl - 1) {  // the tail is clamped to the last particle, as k_ancestors does
+        val = Pg;
+        search = false;
+      } else {
+        C = __dadd_rn(offsets[first_block + j / kScanBlock], clocal[j]);
+      }
     }
-    C = offsets[first_block];
-  } else {
-    const int64_t j = i - 1;
-    if (last_shard && j == Pl - 1) {  // the tail is clamped to the last particle, as k_ancestors does
-      hi[i] = Pg;
-      return;
+    if (search) {
+      int64_t lo = 0, up = Pg;  // first k with t_k > C
+      while (lo < up) {
+        const int64_t mid = (lo + up) >> 1;
+        const double t = __dadd_rn(ur, __dmul_rn((double)mid, r));
+        if (t > C)
+          up = mid;
+        else
+          lo = mid + 1;
+      }
+      val = lo;
     }
-    C = __dadd_rn(offsets[first_block + j / kScanBlock], clocal[j]);
+    hi[i] = val;
   }
-  int64_t lo = 0, up = Pg;  // first k with t_k > C
-  while (lo < up) {
-    const int64_t mid = (lo + up) >> 1;
-    const double t = __dadd_rn(ur, __dmul_rn((double)mid, r));
-    if (t > C)
-      up = mid;
-    else
-      lo = mid + 1;
+  if (ranges == nullptr) return;
+  // ---- the last workgroup to get here writes the ranges (what k_shard_ranges does) --------------
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) *ticket = 0u;  // ready for the next call (stream-ordered)
+  __threadfence();
+  // Two predicates per destination d, both monotone in j: A_d(j) = hi[j + 1] > d Pl and
+  // B_d(j) = hi[j] >= (d + 1) Pl; wanted: the first j in [0, Pl) where each holds (Pl if none).
+  // A 256-ary search by the whole workgroup -- two L2 round trips (coarse probes, then the one
+  // segment), where a binary search per destination costs fourteen dependent ones.
+  const volatile int64_t* vhi = hi;  // written by other workgroups: not through this CU's L1
+  __shared__ int s_first[2];
+  const int64_t step = (Pl + blockDim.x - 1) / blockDim.x;  // coarse probe j_t = min(t step, Pl - 1)
+  for (int d = 0; d < world; ++d) {
+    const int64_t start = (int64_t)d * Pl, end = start + Pl;
+    if (threadIdx.x < 2) s_first[threadIdx.x] = INT_MAX;
+    __syncthreads();
+    {
+      int64_t j = (int64_t)threadIdx.x * step;
+      if (j > Pl - 1) j = Pl - 1;
+      const int64_t h0 = vhi[j], h1 = vhi[j + 1];
+      if (h1 > start) atomicMin(&s_first[0], (int)threadIdx.x);
+      if (h0 >= end) atomicMin(&s_first[1], (int)threadIdx.x);
+    }
+    __syncthreads();
+    const int ta = s_first[0], tb = s_first[1];
+    __syncthreads();
+    if (threadIdx.x < 2) s_first[threadIdx.x] = INT_MAX;
+    __syncthreads();
+    // fine: the segment before the first coarse hit (or the tail when no coarse probe holds)
+    {
+      const int64_t baseA = ta == INT_MAX ? (int64_t)(blockDim.x - 1) * step : (ta == 0 ? 0 : (int64_t)(ta - 1) * step);
+      const int64_t baseB = tb == INT_MAX ? (int64_t)(blockDim.x - 1) * step : (tb == 0 ? 0 : (int64_t)(tb - 1) * step);
+      for (int64_t o = threadIdx.x; o <= step; o += blockDim.x) {  // one pass unless Pl > 65 280
+        const int64_t ja = baseA + o, jb = baseB + o;
+        if (ja < Pl && vhi[ja + 1] > start) atomicMin(&s_first[0], (int)o);
+        if (jb < Pl && vhi[jb] >= end) atomicMin(&s_first[1], (int)o);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int64_t j0 = s_first[0] == INT_MAX ? Pl : baseA + s_first[0];
+        const int64_t j1 = s_first[1] == INT_MAX ? Pl : baseB + s_first[1];
+        ranges[2 * d] = j0;
+        ranges[2 * d + 1] = j1 < j0 ? j0 : j1;
+      }
+    }
+    __syncthreads();
   }
-  hi[i] = lo;
 }
 void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,
                       int64_t first_block, int64_t P_local, int64_t P_global, double u, int last_shard,
                       int64_t* hi_dev) {
   hipLaunchKernelGGL(k_offspring, dim3((unsigned)((P_local + 1 + 255) / 256)), dim3(256), 0, s, clocal_dev,
-                     offsets_dev, sum_dev, first_block, P_local, P_global, u, last_shard, hi_dev);
+                     (const double*)nullptr, offsets_dev, sum_dev, (int64_t)0, first_block, P_local, P_global, u, last_shard,
+                     hi_dev, 0, (int64_t*)nullptr, (unsigned*)nullptr);
+}
+// offspring + block-total scan + per-destination ranges in ONE launch (n_global_blocks <= kAncestorsScanMaxBlocks)
+void launch_offspring_plan(hipStream_t s, const double* clocal_dev, const double* global_totals_dev,
+                           int64_t n_global_blocks, int64_t first_block, int64_t P_local, int64_t P_global, double u,
+                           int last_shard, int64_t* hi_dev, int world, int64_t* ranges_dev, unsigned* ticket_dev) {
+  hipLaunchKernelGGL(k_offspring, dim3((unsigned)((P_local + 1 + 255) / 256)), dim3(256), 0, s, clocal_dev,
+                     global_totals_dev, (const double*)nullptr, (const double*)nullptr, n_global_blocks, first_block,
+                     P_local, P_global, u, last_shard, hi_dev, world, ranges_dev, ticket_dev);
 }
 
 // record = (x, y, h, logw) + map slot

@@ -143,3 +143,54 @@ def test_rccl_code_path_with_one_rank():
     p.join(timeout=60)
     assert status == "ok", payload
     assert np.isfinite(payload).all()
+
+
+def _expected_ranges(hi, P, world):
+    """What k_shard_ranges computes from the offspring bounds hi[0..P]: per destination d the local
+    particles [j0, j1) whose offspring overlap its output slots [d P, (d + 1) P)."""
+    out = np.empty(2 * world, dtype=np.int64)
+    for d in range(world):
+        start, end = d * P, (d + 1) * P
+        a = np.nonzero(hi[1:P + 1] > start)[0]
+        j0 = int(a[0]) if a.size else P
+        b = np.nonzero(hi[:P] >= end)[0]
+        j1 = int(b[0]) if b.size else P
+        out[2 * d], out[2 * d + 1] = j0, max(j0, j1)
+    return out
+
+
+@pytest.mark.parametrize("P,world,rank,others", [(2048, 2, 0, 1.0), (2048, 2, 1, 1.0), (10000, 8, 3, 1.0),
+                                                 (10000, 8, 3, 1e-3), (10000, 8, 0, 1e-3), (10000, 8, 7, 30.0),
+                                                 (70000, 4, 2, 1e-2), (70000, 4, 3, 1.0)])
+def test_one_launch_shard_plan_matches_the_host_variant(lib, P, world, rank, others):
+    # pk_shard_plan_dev (block-total scan + offspring + per-destination ranges in ONE launch: every
+    # workgroup scans the few global totals itself, the last one to finish searches the ranges with
+    # the whole workgroup) against pk_shard_offspring + NumPy; `others` scales the weight of the
+    # other shards (tiny: this shard fills nearly every slot of every rank; 70 000: the search needs
+    # more than one pass per segment)
+    import torch
+
+    rs = np.random.RandomState(P + 13 * world + rank)
+    L = 2
+    f = lib.DeviceFilter(P, L)
+    means = np.array([[5.0, 0.0, 10, 20, 30], [0.0, 5.0, 200, 100, 50]])
+    f.upload_map(means, np.tile(0.25 * np.identity(5), (L, 1, 1)).reshape(L, 25))
+    poses = np.zeros((P, 4))
+    poses[:, 3] = rs.uniform(0.1, 1.0, P) * np.where(rs.uniform(size=P) < 0.05, 40.0, 1.0)  # a few heavy particles
+    f.upload_poses(poses)
+    f.set_shard(rank * P)
+    gmax = f.shard_max_logw()
+    mine = f.shard_block_totals(gmax, 1)
+    nb = mine.size
+    gt = np.concatenate([mine if r == rank else others * mine.mean() * rs.uniform(0.5, 1.5, nb) for r in range(world)])
+    u = 0.4321
+    hi = f.shard_offspring(gt, rank * nb, P * world, u, rank == world - 1)
+    want = _expected_ranges(np.maximum.accumulate(hi), P, world)
+    gt_dev = torch.from_numpy(gt).cuda()
+    ranges = torch.full((2 * world,), -7, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):  # twice: the ticket counter must be back at zero for the next call
+        f.shard_plan_dev(gt_dev.data_ptr(), gt.size, rank * nb, P * world, u, rank == world - 1, world, ranges.data_ptr())
+        f.synchronize()
+        assert np.array_equal(ranges.cpu().numpy(), want), (ranges.cpu().numpy(), want)
+    f.close()
