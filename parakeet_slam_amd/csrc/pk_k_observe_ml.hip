@@ -355,13 +355,15 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
 // One workgroup per particle, one landmark per lane, from the association gates to the coalesced
 // store of the updated map: what k_assoc_grid<hand-off> and k_observe_fast do in two launches,
 // without the hand-off through HBM (no lmpass / bcount arrays, the means are read once).
-//   1. the scan tables (cell starts, fp32 records, duplicated index list) are copied to LDS; the lane
-//      requests its landmark's 14 rows;
+//   1. the scan tables (exact records when they fit, cell starts, fp32 records, duplicated index list,
+//      order table) are copied to LDS -- all table words of a lane requested in one batch; the lane
+//      requests its landmark's 14 rows (means first), count and immutable flag right behind them;
 //   2. gates: atan2, colour cell, 4-wide walk of the duplicated list with the conservative fp32
 //      screen, exact float64 gates (:433, :441) on the survivors; the (<= 4) passing blobs stay in
 //      registers, the per-blob counts are LDS atomics;
-//   3. a particle in which some landmark passes more than kFastSlots blobs is flagged for the general
-//      kernels and left untouched;
+//   3. a particle in which some landmark passes more than kFastSlots blobs -- or, after step 4's
+//      preparation, one that wants more probabilities than the LDS queue holds -- is flagged for the
+//      general kernels and left untouched (nothing has been written by then);
 //   4. everything is settled and applied exactly as in k_observe_fast (the covariance rows were
 //      requested together with the means and arrived during the gates).
 struct FusedArgs {
