@@ -9,7 +9,7 @@
 namespace pk {
 
 // ------------------------------------------------------------------ K3 (fast ML variant, L <= 512)
-// One workgroup per particle, two adjacent landmarks per lane, the particle's whole map in
+// One workgroup per particle, one landmark per lane, the particle's whole map in
 // registers from the single coalesced load to the single coalesced store.  Input is the
 // association kernel's hand-off: per landmark the (<= 4) blobs that pass its gates, per blob
 // the number of landmarks that pass.  A blob passed by one landmark is matched iff its

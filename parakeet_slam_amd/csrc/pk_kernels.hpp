@@ -114,7 +114,7 @@ struct ObserveExtras {
 };
 constexpr int kFastSlots = 4;   // gate-passing blobs a landmark can hand over to k_observe_fast; more -> general path
 constexpr int kSweepSlots = 8;  // ... to k_observe_sweep (large maps: a landmark's colour neighbourhood is busier)
-constexpr int kFastMaxL = 512;  // k_observe_fast keeps a particle's whole map in registers (2 landmarks/lane)
+constexpr int kFastMaxL = 512;  // k_observe_fast / k_step_fused keep a particle's whole map in registers (one landmark per lane, 512 lanes)
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev,
                        bool finalize, const FastHandoff& fh);
