@@ -230,6 +230,8 @@ def main():
         cpu = cpu_baseline(args.landmarks, args.cpu_budget)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the particle update has no CPU fallback")
+    if os.environ.get("PK_BENCH_SAME_GPU"):  # rehearsal of the N > 1 control flow on a one-GPU box (with PK_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from parakeet_slam_amd import _lib
@@ -442,6 +444,6 @@ if __name__ == "__main__":
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(0 if os.environ.get("PK_BENCH_SAME_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(os.environ.get("PK_BENCH_BACKEND", "nccl"))  # "nccl" = RCCL over xGMI
     main()
