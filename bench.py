@@ -2,19 +2,25 @@
 """Headline benchmark: FastSLAM filter steps on synthetic 360-degree bearing+colour scans.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P] [--landmarks L]
-                    [--assoc ml|known] [--no-cpu-baseline]
+                    [--assoc ml|known] [--no-cpu-baseline] [--no-secondary]
 
 One "step" = one whole cam_cb (prkt_core_v2.py:59-137): weight reset, motion sample,
 maximum-likelihood data association, per particle x landmark EKF update + weight,
 systematic resample -- all on the GPU through the C ABI (include/parakeet_slam.h).
-The default workload is BASELINE.json configs[1]: 10 000 particles x 500 landmarks per
-GPU, B = L blobs per scan, float64 like the reference.  N > 1: one process per GPU
-(launched by torch.distributed.run), particles sharded, weak scaling.
+The default workload is BASELINE.json configs[2], the largest single-GPU configuration:
+100 000 particles x 2 000 landmarks per GPU, B = L blobs per scan, float64 like the
+reference; configs[1] (10 000 x 500) rides along as a secondary object at N = 1.
+
+N > 1: one process per GPU, particles sharded, weak scaling.  Started as the driver does
+(`python -m torch.distributed.run ... bench.py --gpus N`) the ranks find RANK / WORLD_SIZE in
+the environment; started bare (`python bench.py --gpus N`) the script launches those N ranks
+itself as child processes BEFORE it touches the GPU and relays rank 0's line.  `n_gpus` is
+the world size RCCL actually formed, and it must equal --gpus.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with two extra
-objects: "roofline" for the dominant HBM kernel (the fused EKF+weight kernel k_observe,
-timed with hipEvents on its own stream inside the timed region) and "cpu_baseline"
-(the NumPy oracle of the same step on a bounded sample of the same workload).
+objects: "roofline" for the dominant kernel of the timed route (timed with hipEvents on
+the library's own stream inside the timed region) and "cpu_baseline" (the NumPy oracle of
+the same step on a bounded sample of the same workload).
 """
 from __future__ import annotations
 
@@ -23,6 +29,8 @@ import json
 import math
 import os
 import random
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,14 +39,32 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CONFIGS = {  # BASELINE.json configs by (particles per GPU, landmarks)
+    (10000, 500): "configs[1]",
+    (100000, 2000): "configs[2]",
+    (125000, 5000): "configs[4] (one of its eight shards)",
+}
+DEFAULT_P, DEFAULT_L = 100000, 2000  # configs[2]: the largest single-GPU configuration
+SECOND_P, SECOND_L = 10000, 500      # configs[1]
+
+
 def measured_traffic(P, L, variant):
-    """HBM bytes per k_observe launch from the committed rocprofv3 PMC run (profiles/*/pmc_traffic.json,
-    made by scripts/gpu_pmc_traffic.sh) when it was taken on this very configuration, else None."""
+    """HBM bytes per launch of the route's dominant kernel from the committed rocprofv3 PMC run
+    (profiles/*/pmc_traffic*.json, made by scripts/gpu_pmc_traffic.sh) when it was taken on this very
+    configuration, else None.  The newest round wins."""
     best = None
-    for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
-        if os.path.exists(path):
-            d = json.load(open(path))
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        rdir = os.path.join(pdir, rnd)
+        if not os.path.isdir(rdir):
+            continue
+        for name in sorted(os.listdir(rdir)):
+            if not (name.startswith("pmc_traffic") and name.endswith(".json")):
+                continue
+            try:
+                d = json.load(open(os.path.join(rdir, name)))
+            except ValueError:
+                continue
             if d["config"]["particles"] == P and d["config"]["landmarks"] == L and variant in d["bytes_per_launch"]:
                 best = d["bytes_per_launch"][variant]
     return best
@@ -47,12 +73,16 @@ def measured_traffic(P, L, variant):
 ROUTE_KERNEL = {
     "known_ids": "k_observe<known ids> (fused EKF update + log-weight)",
     "ml_fused": "k_step_fused (association gates + settling of contested blobs + EKF update + log-weight in ONE kernel)",
+    "ml_regs": "k_step_regs (L <= 2048: a particle's whole map in registers, two landmarks per lane; association "
+               "gates + settling of contested blobs + EKF update + log-weight in ONE pass over the map)",
     "ml_handoff": "k_observe_fast (EKF update + log-weight + settling of contested associations; includes the "
                   "near-empty general k_observe launch for flagged particles; the association kernel is separate)",
     "ml_sweep": "k_observe_sweep (two sweeps over landmark chunks: settling of contested associations, EKF update + "
                 "log-weight; the association kernel is separate)",
     "ml_general": "k_observe<ML general> (fused EKF update + log-weight)",
 }
+ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_regs": "step_regs",
+                     "ml_handoff": "observe_ml", "ml_sweep": "observe_sweep"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_UPDATE = 224  # 14 fp64 read + 14 written per particle.landmark
 
@@ -156,7 +186,7 @@ def cpu_baseline(L, budget_s=20.0):
     cores = min(usable_cores(), 64)
     nsteps = 2
     half = budget_s / 2.0
-    Ps = 4
+    Ps = 2 if L >= 1500 else 4
     t1 = _cpu_run((L, Ps, nsteps, 7))
     while t1 < half / 1.5 and Ps < 4096:  # the oracle vectorises over particles: grow until the sample fills the budget
         Ps = int(min(4096, max(Ps + 1, Ps * min(8.0, 0.8 * half / t1))))
@@ -177,7 +207,7 @@ def cpu_baseline(L, budget_s=20.0):
             with mp.get_context("fork").Pool(cores) as pool:
                 # page the workers in; a pool that is much slower than one thread alone (cores
                 # fewer than reported) times out and leaves the 1-thread figure
-                pool.map_async(_cpu_run, [(L, 2, 1, 7)] * cores).get(timeout=60)
+                pool.map_async(_cpu_run, [(L, 2, 1, 7)] * cores).get(timeout=90)
                 t0 = time.perf_counter()
                 pool.map_async(_cpu_run, [(L, Ps, nsteps, 7 + i) for i in range(cores)],
                                chunksize=1).get(timeout=max(30.0, 6.0 * t1))
@@ -195,34 +225,143 @@ def cpu_baseline(L, budget_s=20.0):
     return out
 
 
+def workload_name(P, L, assoc):
+    tag = CONFIGS.get((P, L))
+    head = "BASELINE.json %s" % tag if tag else "custom size (not a BASELINE.json config)"
+    return "%s: %d particles/GPU x %d landmarks, B=%d blobs/scan, synthetic 360deg bearing+colour obs, assoc=%s, " \
+           "resample every step" % (head, P, L, L, assoc)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run,
+    one process per GPU) BEFORE anything touches the GPU in this process, relay rank 0's JSON line and
+    exit with the launcher's code.  This process never initialises the GPU and never exec()s."""
+    import torch
+
+    same_gpu = bool(os.environ.get("PK_BENCH_SAME_GPU"))  # rehearsal on a one-GPU box (gloo): ranks share cuda:0
+    ndev = torch.cuda.device_count()  # does not initialise the GPU on this image
+    if ndev < args.gpus and not same_gpu:
+        sys.stderr.write("bench.py --gpus %d: only %d HIP device(s) visible; not running on fewer GPUs than asked\n"
+                         % (args.gpus, ndev))
+        raise SystemExit(3)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env["PK_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in proc.stdout.decode("utf-8", "replace").splitlines():
+        raw = raw.strip()
+        if raw.startswith("{") and '"metric"' in raw:
+            line = raw
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write("bench.py --gpus %d: the %d-rank launch failed (exit code %d, %s)\n"
+                         % (args.gpus, args.gpus, proc.returncode, "no result line" if line is None else "result line seen"))
+        raise SystemExit(proc.returncode or 4)
+    if json.loads(line).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py --gpus %d: the ranks report n_gpus = %r\n" % (args.gpus, json.loads(line).get("n_gpus")))
+        raise SystemExit(5)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
+def timed_steps(filt, lib, P, L, K, W, scans, ws, us, ids, barrier, stride):
+    """W warm-up steps, then exactly K steps between barriers; hipEvents around the observe launch(es)
+    of every stride-th step on the library's stream.  Returns (seconds, timings dict, route)."""
+    def one_step(s):
+        filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=ids, domain=lib.PK_WEIGHTS_LOG)
+
+    for s in range(W):
+        one_step(s)
+    barrier()
+    filt.set_option("timing_stride", stride)
+    filt.enable_timing(0b0000100)
+    filt.reset_timings()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        one_step(s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    route = filt.observe_route() if hasattr(filt, "observe_route") else ("known_ids" if ids is not None else "ml")
+    tm = filt.timings()
+    filt.enable_timing(0)
+    filt.set_option("timing_stride", 1)
+    return elapsed, tm, route, one_step
+
+
+def roofline_object(P, L, route, obs_ms, obs_n, stride, K, copy_gbs):
+    obs_avg_s = (obs_ms / max(obs_n, 1)) * 1e-3
+    alg_bytes = float(P) * L * BYTES_PER_UPDATE
+    achieved = alg_bytes / obs_avg_s / 1e9 if obs_avg_s > 0 else 0.0
+    return {
+        "kernel": ROUTE_KERNEL.get(route, route),
+        "route": route,
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": measured_traffic(P, L, ROUTE_TRAFFIC_KEY.get(route, "none")),
+        "traffic_source": "builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this configuration (separate "
+        "passes, bytes = (2*FETCH + WRITE)*1024; FETCH counts Infinity-Cache hits too), replayed from "
+        "profiles/*/pmc_traffic*.json -- not collected by this run; null when no pass exists for this size",
+        "copy_measured": copy_gbs,
+        "frac_of_copy": achieved / copy_gbs if copy_gbs else None,
+        "avg_launch_ms": obs_avg_s * 1e3,
+        "launches": obs_n,
+        "launches_note": "hipEvent-bracketed launches inside the timed region (every %d-th step of %d)" % (stride, K),
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "achieved_note": "algorithmic bytes (224 B per particle.landmark) / launch time: after a resample duplicate "
+        "particles read a shared source slot, part of which is served by L2 / Infinity Cache, so this is "
+        "NOT all HBM traffic -- see achieved_unique and frac_no_duplicates",
+    }
+
+
 def main():
-    # Exactly ONE line may reach stdout (the JSON).  RCCL and friends print banners to fd 1,
-    # so park the real stdout and point fd 1 at stderr until the result is ready.
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--particles", type=int, default=10000, help="particles per GPU")
-    ap.add_argument("--landmarks", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=DEFAULT_P, help="particles per GPU")
+    ap.add_argument("--landmarks", type=int, default=DEFAULT_L)
     ap.add_argument("--assoc", choices=["ml", "known"], default="ml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] object")
+    ap.add_argument("--no-probes", action="store_true", help="skip the untimed probes behind the timed region")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (collectives included) even with one rank")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])  # never returns
+
+    # Exactly ONE line may reach stdout (the JSON).  RCCL and friends print banners to fd 1,
+    # so park the real stdout and point fd 1 at stderr until the result is ready.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU, no more, no fewer" % (args.gpus, world))
 
     import torch
 
-    if torch.cuda.device_count() == 0:  # does not initialise the GPU
+    same_gpu = bool(os.environ.get("PK_BENCH_SAME_GPU"))
+    ndev = torch.cuda.device_count()  # does not initialise the GPU
+    if ndev == 0:
         raise SystemExit("bench.py needs a GPU: the particle update has no CPU fallback")
+    if ndev < world and not same_gpu:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (world, ndev))
     # CPU baseline first: it fork()s a process pool, which must happen before any HIP call.
     # Rank 0 at N=1 only (the other ranks would just wait on it).
     cpu = None
@@ -230,9 +369,16 @@ def main():
         cpu = cpu_baseline(args.landmarks, args.cpu_budget)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the particle update has no CPU fallback")
-    if os.environ.get("PK_BENCH_SAME_GPU"):  # rehearsal of the N > 1 control flow on a one-GPU box (with PK_BENCH_BACKEND=gloo)
+    if same_gpu:  # rehearsal of the N > 1 control flow on a one-GPU box (with PK_BENCH_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(os.environ.get("PK_BENCH_BACKEND", "nccl"))  # "nccl" = RCCL over xGMI
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
+        world = dist.get_world_size()
 
     from parakeet_slam_amd import _lib
 
@@ -240,12 +386,13 @@ def main():
         _lib.LIB_PATH = os.path.join(ROOT, "parakeet_slam_amd", os.environ["PK_BENCH_LIB"])
     P, L = args.particles, args.landmarks
     K, W = args.steps, args.warmup
-    EXTRA = 32  # untimed steps after the timed region (association share, supplied-ids route)
+    EXTRA = 32  # untimed steps after the timed region (association share, unique sources, supplied-ids route)
     means, covs, scans = synthetic_inputs(L, K + W + EXTRA)
     ws = synthetic_controls(K + W + EXTRA)
     ids = np.arange(1, L + 1, dtype=np.int32) if args.assoc == "known" else None
+    sharded = world > 1 or args.force_sharded
 
-    if world > 1 or args.force_sharded:
+    if sharded:
         import torch.distributed as dist
 
         if not dist.is_initialized():  # --force-sharded with a single rank
@@ -258,6 +405,9 @@ def main():
     else:
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
+    for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM"):  # tuning experiments only
+        if os.environ.get(name):
+            filt.set_option(name[7:].lower(), int(os.environ[name]))
     if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only
         filt.set_option("observe_landmarks_per_lane", int(os.environ["PK_OBSERVE_NV"]))
     rnd = random.Random(7)
@@ -271,50 +421,66 @@ def main():
         torch.cuda.synchronize()
         filt.synchronize()
 
-    def one_step(s):
-        filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=ids, domain=_lib.PK_WEIGHTS_LOG)
-
-    for s in range(W):
-        one_step(s)
-    barrier()
-    # hipEvents around the dominant kernel only (the observe launch), on the library's own stream,
-    # inside the timed region; every bracketed launch costs two event records
-    # (two event records per bracketed launch cost the stream ~8 us: every 4th step is sampled)
-    stride = 4 if K >= 16 else 1
-    filt.set_option("timing_stride", stride)
-    filt.enable_timing(0b0000100)
-    filt.reset_timings()
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(W, W + K):
-        one_step(s)
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    route = filt.observe_route() if hasattr(filt, "observe_route") else ("known_ids" if args.assoc == "known" else "ml")
-    tm = filt.timings()
-    filt.enable_timing(0)
-    filt.set_option("timing_stride", 1)
+    # hipEvents around the dominant kernel only (the observe launch), on the library's own stream, inside
+    # the timed region.  Two event records cost the stream ~8 us: every launch is bracketed when a step
+    # takes milliseconds, every 4th when it takes a fraction of one.
+    stride = 1 if float(P) * L >= 5e7 or K < 16 else 4
+    elapsed, tm, route, one_step = timed_steps(filt, _lib, P, L, K, W, scans, ws, us, ids, barrier, stride)
     summary = filt.summary()
     # validity probe (untimed): share of the blobs of the last timed scan that the particles, as they
     # stand now, still associate with some landmark (the workload degenerates when this collapses)
     matched = None
-    if world == 1 and not args.force_sharded and float(P) * L <= 2e7 and hasattr(filt, "associate"):
-        matched = float((filt.associate(scans[W + K - 1]) > 0).mean())
-    # the association kernel's share, from a few extra (untimed) steps
+    if not sharded and hasattr(filt, "associate") and not args.no_probes:
+        if float(P) * L <= 2e7:
+            matched = float((filt.associate(scans[W + K - 1]) > 0).mean())
+        else:  # P x B ids would be gigabytes: a 512-particle filter stepped through the same scans instead
+            side = _lib.DeviceFilter(512, L, device=local_rank)
+            side.upload_map(means, covs.reshape(L, 25))
+            for s in range(W + K):
+                side.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=ids, domain=_lib.PK_WEIGHTS_LOG)
+            matched = float((side.associate(scans[W + K - 1]) > 0).mean())
+            side.close()
+    # the association kernel's share and the number of DISTINCT source slots the observe kernel reads
+    # (after a resample several particles descend from one ancestor and read the same slot, so part of
+    # the 224 B/update stream is served by L2 / Infinity Cache, not HBM), from a few extra untimed steps
+    uniq = []
     filt.enable_timing(0b0000010)
     filt.reset_timings()
-    for s in range(W + K, W + K + 10):
+    for s in range(W + K, W + K + (0 if args.no_probes else 8)):
         one_step(s)
+        if not sharded and hasattr(filt, "download_sources"):
+            uniq.append(int(np.unique(filt.download_sources()).size))
     barrier()
     tm["assoc"] = filt.timings()["assoc"]
     filt.enable_timing(0)
+
+    # the streaming figure without duplicates: the same observe launches back to back WITHOUT resamples,
+    # every particle reading its own slot (all particles then sit at one pose: the bytes are the same)
+    no_dup = None
+    if not sharded and not args.no_probes:
+        no_dup = {}
+        for tag, pids in (("ml", None), ("supplied_ids", np.arange(1, L + 1, dtype=np.int32))):
+            if tag == "ml" and args.assoc != "ml":
+                continue
+            filt.upload_map(means, covs.reshape(L, 25))
+            filt.upload_poses(np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (P, 1)))
+            filt.observe(scans[0], ids=pids, fresh=True)
+            filt.enable_timing(0b0000100)
+            filt.reset_timings()
+            for _ in range(6):
+                filt.observe(scans[0], ids=pids, fresh=True)
+            ms, cnt = filt.timings()["observe"]
+            filt.enable_timing(0)
+            avg = ms / max(cnt, 1) * 1e-3
+            no_dup[tag] = {"avg_launch_ms": avg * 1e3, "launches": cnt,
+                           "achieved": float(P) * L * BYTES_PER_UPDATE / avg / 1e9 if avg > 0 else 0.0,
+                           "frac": float(P) * L * BYTES_PER_UPDATE / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0}
 
     # the EKF stage on its own (SURVEY 8d defines the HBM roofline on it): the same filter, reset to
     # the initial map and poses, stepped with SUPPLIED ids -- whole steps, resample included, exactly
     # what `--assoc known` times -- so both routes' rooflines come from one run
     known = None
-    if args.assoc == "ml" and world == 1 and not args.force_sharded:
+    if args.assoc == "ml" and not sharded and not args.no_probes:
         kids = np.arange(1, L + 1, dtype=np.int32)
         kn, kw = (20, 3) if K >= 20 else (K, 2)
         filt.upload_map(means, covs.reshape(L, 25))
@@ -341,9 +507,36 @@ def main():
             "launches": kcnt,
             "achieved": float(P) * L * BYTES_PER_UPDATE / kavg / 1e9 if kavg > 0 else 0.0,
             "frac": float(P) * L * BYTES_PER_UPDATE / kavg / 1e9 / HBM_PEAK_GBS if kavg > 0 else 0.0,
+            "frac_no_duplicates": no_dup["supplied_ids"]["frac"] if no_dup else None,
             "unit": "GB/s",
             "traffic": measured_traffic(P, L, "observe_known"),
         }
+    filt.close()
+    del filt
+
+    # BASELINE.json configs[1] beside the headline (N = 1, default workload only): same code, the
+    # L <= 512 route (k_step_fused)
+    second = None
+    if world == 1 and not args.force_sharded and not args.no_secondary and (P, L) == (DEFAULT_P, DEFAULT_L) \
+            and args.assoc == "ml":
+        P2, L2, K2, W2 = SECOND_P, SECOND_L, 120, 10
+        m2, c2, s2 = synthetic_inputs(L2, K2 + W2)
+        f2 = _lib.DeviceFilter(P2, L2, device=local_rank)
+        f2.upload_map(m2, c2.reshape(L2, 25))
+        e2, tm2, route2, _ = timed_steps(f2, _lib, P2, L2, K2, W2, s2, synthetic_controls(K2 + W2),
+                                          [rnd.random() for _ in range(K2 + W2)], None, barrier2(torch, f2), 4)
+        second = {
+            "workload": workload_name(P2, L2, "ml"),
+            "value": float(P2) * L2 * K2 / e2,
+            "unit": "updates/s",
+            "steps": K2,
+            "warmup": W2,
+            "ms_per_step": e2 / K2 * 1e3,
+            "filter_steps_per_sec": K2 / e2,
+            "roofline": roofline_object(P2, L2, route2, tm2["observe"][0], tm2["observe"][1], 4, K2, None),
+        }
+        f2.close()
+        del f2
 
     # what a plain device-to-device copy reaches on THIS box (read + write bytes / time), outside the
     # timed region: the practical ceiling next to the 8 TB/s vendor figure
@@ -374,9 +567,28 @@ def main():
         total_updates = float(P) * world * L * K
         obs_ms, obs_n = tm["observe"]
         assoc_ms, assoc_n = tm["assoc"]
+        roof = roofline_object(P, L, route, obs_ms, obs_n, stride, K, copy_gbs)
         obs_avg_s = (obs_ms / max(obs_n, 1)) * 1e-3
-        alg_bytes = float(P) * L * BYTES_PER_UPDATE
-        achieved = alg_bytes / obs_avg_s / 1e9 if obs_avg_s > 0 else 0.0
+        if uniq and obs_avg_s > 0:
+            mean_unique = float(np.mean(uniq))
+            half = float(L) * BYTES_PER_UPDATE / 2.0
+            roof["unique_source_slots"] = mean_unique
+            roof["unique_source_slots_note"] = "distinct map slots read by one observe launch (of %d particles), mean of %d " \
+                "untimed steps behind the timed region" % (P, len(uniq))
+            roof["achieved_unique"] = (mean_unique * half + float(P) * half) / obs_avg_s / 1e9
+            roof["frac_unique"] = roof["achieved_unique"] / HBM_PEAK_GBS
+        if no_dup and args.assoc in no_dup:
+            roof["frac_no_duplicates"] = no_dup[args.assoc]["frac"]
+        elif no_dup and args.assoc == "known":
+            roof["frac_no_duplicates"] = no_dup["supplied_ids"]["frac"]
+        if no_dup:
+            roof["no_resample_probe"] = no_dup
+        if known is not None:
+            roof["ekf_stage"] = known
+        roof["assoc_kernel_ms"] = assoc_ms / max(assoc_n, 1)
+        if second is not None and copy_gbs:
+            second["roofline"]["copy_measured"] = copy_gbs
+            second["roofline"]["frac_of_copy"] = second["roofline"]["achieved"] / copy_gbs
         out = {
             "metric": "particle*landmark EKF updates/sec (whole filter step)",
             "value": total_updates / elapsed,
@@ -392,42 +604,23 @@ def main():
             "data": "synthetic",
             "filter_steps_per_sec": K / elapsed,
             "config": {
-                "workload": "BASELINE.json configs[1]: %d particles/GPU x %d landmarks, B=%d blobs/scan, "
-                "synthetic 360deg bearing+colour obs, assoc=%s, resample every step" % (P, L, L, args.assoc),
+                "workload": workload_name(P, L, args.assoc),
                 "particles_per_gpu": P,
                 "landmarks": L,
                 "blobs": L,
                 "assoc": args.assoc,
                 "global_particles": P * world,
-                "parallelism": "particles sharded over %d GPU(s); RCCL all-reduce(max) + all-gather(block weight "
-                "totals) + all-to-all(migrating particles) per resample" % world if (world > 1 or args.force_sharded)
+                "parallelism": "particles sharded over %d GPU(s), one process per GPU; RCCL all-reduce(max) + "
+                "all-gather(block weight totals) + all-to-all(migrating particles) per resample" % world if sharded
                 else "single GPU",
             },
-            "roofline": {
-                "kernel": ROUTE_KERNEL.get(route, route),
-                "route": route,
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(P, L, {"known_ids": "observe_known", "ml_fused": "step_fused",
-                                                   "ml_handoff": "observe_ml"}.get(route, "none")),
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = (2*FETCH + WRITE)*1024, "
-                "see profiles/*/pmc_traffic.json",
-                "copy_measured": copy_gbs,
-                "frac_of_copy": achieved / copy_gbs if copy_gbs else None,
-                "avg_launch_ms": obs_avg_s * 1e3,
-                "launches": obs_n,
-                "launches_note": "hipEvent-bracketed launches inside the timed region (every %d-th step of %d)" % (stride, K),
-                "algorithmic_bytes_per_launch": alg_bytes,
-            },
+            "roofline": roof,
             "kernel_ms_per_step": {"observe": obs_ms / max(obs_n, 1), "assoc": assoc_ms / max(assoc_n, 1)},
             "summary": list(summary),
             "matched_fraction_last_timed_scan": matched,  # validity: the scans stayed matchable to the end
         }
-        if known is not None:
-            out["ekf_stage_supplied_ids"] = known
+        if second is not None:
+            out["configs1"] = second
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
@@ -439,11 +632,12 @@ def main():
         dist.destroy_process_group()
 
 
-if __name__ == "__main__":
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch
-        import torch.distributed as dist
+def barrier2(torch, filt):
+    def b():
+        torch.cuda.synchronize()
+        filt.synchronize()
+    return b
 
-        torch.cuda.set_device(0 if os.environ.get("PK_BENCH_SAME_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(os.environ.get("PK_BENCH_BACKEND", "nccl"))  # "nccl" = RCCL over xGMI
+
+if __name__ == "__main__":
     main()

@@ -105,6 +105,11 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "fused_step"   = 1 (default: with "fast_observe" = 1, L <= 512 and scan tables that fit LDS twice
  *                    per CU, gates + settling + EKF update of a particle run in ONE kernel,
  *                    k_step_fused, without the hand-off through HBM) or 0;
+ *   "regs_step"    = 1 (default: with "fast_observe" = 1, 512 < L <= 2048 and scan tables that fit LDS,
+ *                    gates + settling + EKF update of a particle run in ONE pass, k_step_regs, with the
+ *                    particle's whole map in registers) or 0 (k_assoc_grid hand-off + k_observe_sweep);
+ *   "regs_warm"    = 0..2: how much of the NEXT particle's map slot k_step_regs touches ahead of time
+ *                    (0 nothing, 1 the mean rows, 2 the whole slot; default 2) so that it waits in L2;
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
 int pk_set_option(pk_filter* f, const char* name, int64_t value);
 
@@ -277,9 +282,16 @@ enum {
   PK_ROUTE_ML_GENERAL = 2,   /* association kernel writes ids, k_observe builds chains from them */
   PK_ROUTE_ML_HANDOFF = 3,   /* k_assoc_grid hand-off + k_observe_fast (L <= 512) */
   PK_ROUTE_ML_SWEEP = 4,     /* k_assoc_grid hand-off + k_observe_sweep (L > 512) */
-  PK_ROUTE_ML_FUSED = 5      /* k_step_fused: gates + settling + EKF update in one kernel */
+  PK_ROUTE_ML_FUSED = 5,     /* k_step_fused: gates + settling + EKF update in one kernel (L <= 512) */
+  PK_ROUTE_ML_REGS = 6       /* k_step_regs: the same in one pass for 512 < L <= 2048, two landmarks per lane */
 };
 int pk_observe_route(const pk_filter* f);
+/* The map indirection of the live generation (instrumentation): src[P], the map slot each particle's
+ * landmarks currently live in.  After pk_resample slot k holds src[ancestor(k)] (the lazy copy of
+ * prkt_core_v2.py:236,:246: maps are not moved until the next observe rewrites them); the number of
+ * DISTINCT values is the number of slots the next observe launch really has to fetch.  Negative
+ * values name records of a sharded adoption buffer. */
+int pk_download_sources(pk_filter* f, int32_t* src);
 
 /* ---- host-side reproductions of the reference's RNG streams (no GPU needed) ------
  * numpy.random.seed(s); numpy.random.normal(0,1,n)  (legacy MT19937 + polar method), the

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pk_timings": (C.c_int, [_h, _dp, _lp]),
     "pk_observe_bytes": (C.c_int, [_h, C.c_int32, _lp, _lp]),
     "pk_observe_route": (C.c_int, [_h]),
+    "pk_download_sources": (C.c_int, [_h, _ip]),
     "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_create_python": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_destroy": (C.c_int, [_h]),
@@ -324,11 +325,17 @@ class DeviceFilter(object):
     def shard_adopt_dev(self, rank, recv_ptr, n_received):
         check(self._lib.pk_shard_adopt_dev(self._h, int(rank), C.c_void_p(recv_ptr), int(n_received)))
 
-    ROUTES = {0: "none", 1: "known_ids", 2: "ml_general", 3: "ml_handoff", 4: "ml_sweep", 5: "ml_fused"}
+    ROUTES = {0: "none", 1: "known_ids", 2: "ml_general", 3: "ml_handoff", 4: "ml_sweep", 5: "ml_fused", 6: "ml_regs"}
 
     def observe_route(self):
         """Kernels the last observe / step used for association + EKF update (pk_observe_route)."""
         return self.ROUTES[int(self._lib.pk_observe_route(self._h))]
+
+    def download_sources(self):
+        """Map slot each particle's landmarks currently live in (pk_download_sources)."""
+        out = np.empty(self.P, dtype=np.int32)
+        check(self._lib.pk_download_sources(self._h, iptr(out)))
+        return out
 
     def particle_bytes(self):
         return int(self._lib.pk_particle_bytes(self._h))

@@ -47,6 +47,16 @@ int fail(int code, const char* fmt, ...) {
     }                                                                                        \
   } while (0)
 
+// Kernel launches report configuration errors (too much dynamic LDS, bad grid) through the
+// runtime's last-error slot, not through a return value: every entry point that enqueued kernels
+// asks for it before it reports success.
+#define PK_LAUNCH_CHECK(what)                                                                \
+  do {                                                                                       \
+    hipError_t e_ = hipGetLastError();                                                       \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(PK_ERR_HIP, "%s: a kernel launch failed: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
 struct TimedSpan {
   int slot;
   hipEvent_t a, b;
@@ -107,6 +117,12 @@ struct pk_filter {
   static constexpr int kRing = 8;
   unsigned char* stage[kRing] = {nullptr};
   hipEvent_t stage_done[kRing] = {nullptr};
+  // which enqueued upload last read each slot, and up to which upload each slot's event covers
+  // (an event is recorded behind every 4th upload only; a slot whose covering record never came --
+  // its scan was staged and then discarded -- gets one when the slot is next handed out)
+  uint64_t upload_seq = 0;
+  uint64_t slot_seq[kRing] = {0};
+  uint64_t event_seq[kRing] = {0};
   size_t stage_cap = 0;
   int stage_next = 0;
   double* partial = nullptr;  // 4 * 1024
@@ -208,6 +224,7 @@ int ensure_scan_capacity(pk_filter* f, size_t bytes) {
   int rc;
   if ((rc = dev_alloc(f, &f->scan_dev, cap))) return rc;
   f->scan_cap = cap;
+  f->gmax_fused = false;  // the running-max keys lived in the block that was just freed
   return PK_OK;
 }
 
@@ -238,7 +255,17 @@ int upload_scan(pk_filter* f, const unsigned char* st, size_t bytes) {
   return PK_OK;
 }
 
-// Next pinned staging block of at least `bytes`; waits for the upload that last used it.
+// An upload that reads staging slot `slot` has just been enqueued on the stream.
+int note_upload(pk_filter* f, int slot) {
+  f->slot_seq[slot] = ++f->upload_seq;
+  if ((slot & 3) == 3) {  // an event record costs the stream a few microseconds: one per four uploads
+    PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+    f->event_seq[slot] = f->upload_seq;
+  }
+  return PK_OK;
+}
+
+// Next pinned staging block of at least `bytes`; waits for the upload that last read it.
 int take_stage(pk_filter* f, size_t bytes, unsigned char** out, int* slot) {
   if (bytes > f->stage_cap) {
     PK_HIP(hipStreamSynchronize(f->stream));
@@ -248,15 +275,29 @@ int take_stage(pk_filter* f, size_t bytes, unsigned char** out, int* slot) {
       f->stage[i] = nullptr;
       PK_HIP(hipHostMalloc((void**)&f->stage[i], cap, hipHostMallocMapped));
       if (!f->stage_done[i]) PK_HIP(hipEventCreateWithFlags(&f->stage_done[i], hipEventDisableTiming));
+      f->slot_seq[i] = 0;  // the stream is idle: nothing reads the old blocks any more
     }
     f->stage_cap = cap;
   }
   int i = f->stage_next;
   f->stage_next = (i + 1) % pk_filter::kRing;
-  // An event is recorded only behind every 4th upload (an event record costs the stream a few
-  // microseconds): slot i was last read by an upload that precedes, in stream order, the record
-  // behind slot (i | 3) of the previous trip round the ring.
-  PK_HIP(hipEventSynchronize(f->stage_done[i | 3]));
+  // Slot i may still be read by upload number slot_seq[i]; any event recorded at or after that upload
+  // covers it.  Normally that is the record behind slot (i | 3) of the previous trip round the ring;
+  // when that slot's scan was discarded before its upload (pk_stage_scan followed by a supplied-ids
+  // observe, an error between take_stage and the upload) no such record exists and one is made now.
+  const uint64_t need = f->slot_seq[i];
+  if (need != 0) {
+    int ev = -1;
+    for (int j = 0; j < pk_filter::kRing; ++j)
+      if (f->event_seq[j] >= need && (ev < 0 || f->event_seq[j] < f->event_seq[ev])) ev = j;
+    if (ev < 0) {
+      PK_HIP(hipEventRecord(f->stage_done[i], f->stream));
+      f->event_seq[i] = f->upload_seq;
+      ev = i;
+    }
+    PK_HIP(hipEventSynchronize(f->stage_done[ev]));
+    f->slot_seq[i] = 0;
+  }
   *out = f->stage[i];
   *slot = i;
   return PK_OK;
@@ -476,6 +517,11 @@ inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*
 int stage_ml_scan(pk_filter* f, const double* blobs, int B) {
   int rc;
   if (B > 65535) return fail(PK_ERR_UNSUPPORTED, "maximum-likelihood association handles at most 65535 blobs per scan (got %d)", B);
+  // the general EKF kernel (every ML route's last resort) builds per-particle chains in LDS
+  if (observe_general_lds_bytes(f->d.lay.Lp, B) > kMaxDynLds)
+    return fail(PK_ERR_UNSUPPORTED,
+                "maximum-likelihood association: %d landmarks + 2 x %d blobs need %zu bytes of LDS chains per particle, the "
+                "workgroup has %zu", f->d.lay.Lp, B, observe_general_lds_bytes(f->d.lay.Lp, B), (size_t)kMaxDynLds);
   if ((rc = ensure_ids_capacity(f, B))) return rc;
   pk_filter::Staged& sg = f->staged;
   sg.valid = false;
@@ -531,9 +577,11 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   const int n9 = sg.n9;
   const bool use_grid = sg.use_grid;
   const size_t tab_bytes = sg.tab_bytes;
-  if (!sg.uploaded && (rc = upload_scan(f, st, use_grid ? o_tab + tab_bytes : o_exact))) return rc;
+  if (!sg.uploaded) {
+    if ((rc = upload_scan(f, st, use_grid ? o_tab + tab_bytes : o_exact))) return rc;
+    if ((rc = note_upload(f, slot))) return rc;
+  }
   sg.uploaded = false;
-  if ((slot & 3) == 3) PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
   f->gmax_fused = false;
   const double* blobs_dev = reinterpret_cast<const double*>(f->scan_dev + o_blobs);
   const double* dir_dev = reinterpret_cast<const double*>(f->scan_dev + o_dir);
@@ -556,7 +604,8 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
       return PK_OK;
     }
-    if (want_fast && !finalize && f->fast_observe && B > 0 && (!sweep || observe_sweep_plan(f->d, B).grid > 0)) {
+    if (want_fast && !finalize && f->fast_observe && B > 0 &&
+        (sweep ? observe_sweep_plan(f->d, B).grid > 0 : observe_fast_lds_bytes(B) <= kMaxDynLds)) {
       // eight hand-off slots per landmark for the large scans (a landmark's colour neighbourhood gets
       // busier with B: at B = 5 000 random colours some landmark of every particle passes 5-7 blobs),
       // four (16-byte entries) otherwise; "fast_observe" = 3 forces eight
@@ -577,6 +626,10 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
     }
     return PK_OK;
   }
+  if (assoc_brute_lds_bytes(B) > kMaxDynLds)
+    return fail(PK_ERR_UNSUPPORTED,
+                "maximum-likelihood association of %d blobs: neither the colour-grid tables nor the brute-force kernel's "
+                "%zu bytes of per-blob state fit the workgroup's %zu bytes of LDS", B, assoc_brute_lds_bytes(B), (size_t)kMaxDynLds);
   Span t(f, PK_T_ASSOC);
   launch_assoc_brute(f->stream, f->d, blobs_dev, dir_dev, B, f->ids_dev);
   return PK_OK;
@@ -927,6 +980,7 @@ int pk_reset_weights(pk_filter* f) {
   if ((rc = use_device(f))) return rc;
   launch_reset_weights(f->stream, f->d);
   f->gmax_fused = false;
+  PK_LAUNCH_CHECK("pk_reset_weights");
   return PK_OK;
 }
 
@@ -959,11 +1013,14 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
       launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg));
       sg.uploaded = true;
       f->gmax_fused = false;  // the block's control words (running weight maximum) were just overwritten
+      if ((rc = note_upload(f, sg.slot))) return rc;
+      PK_LAUNCH_CHECK("pk_motion");
       return PK_OK;
     }
     (void)hipGetLastError();
   }
   launch_motion(f->stream, f->d, v, w, dt, zd, seed, draw, 0);
+  PK_LAUNCH_CHECK("pk_motion");
   return PK_OK;
 }
 
@@ -1021,7 +1078,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
       last[id - 1] = b;
     }
     if ((rc = upload_scan(f, st, total))) return rc;
-    if ((slot & 3) == 3) PK_HIP(hipEventRecord(f->stage_done[slot], f->stream));
+    if ((rc = note_upload(f, slot))) return rc;
     ex.gmax_key = ctl_gmax_key(f);
     {
       Span t(f, PK_T_OBSERVE);
@@ -1029,6 +1086,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
                      reinterpret_cast<const int32_t*>(f->scan_dev + o_first),
                      reinterpret_cast<const int32_t*>(f->scan_dev + o_next), n0, nullptr, f->qt, ex);
     }
+    PK_LAUNCH_CHECK("pk_observe");
     f->src_identity = true;
     f->gmax_fused = true;
     f->route = PK_ROUTE_KNOWN_IDS;
@@ -1089,6 +1147,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
       launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, ex);
     }
   }
+  PK_LAUNCH_CHECK("pk_observe");
   f->src_identity = true;
   f->gmax_fused = true;
   if (ids_out && B > 0) {
@@ -1134,6 +1193,7 @@ int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out)
   for (int i = 0; i < 4 * B; ++i)
     if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_associate: blob %d is not finite", i / 4);
   if ((rc = enqueue_association(f, blobs, B, true, false, nullptr))) return rc;
+  PK_LAUNCH_CHECK("pk_associate");
   PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
   PK_HIP(hipStreamSynchronize(f->stream));
   return PK_OK;
@@ -1202,6 +1262,7 @@ int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestor
       launch_ancestors(f->stream, f->clocal, f->totals, f->offsets, f->sum, f->nblocks, d.P, d.P, u, 0, d.P, f->anc, &d);
     }
   }
+  PK_LAUNCH_CHECK("pk_resample");
   f->src_identity = false;
   f->gmax_fused = false;
   if (ancestors_out) {
@@ -1264,6 +1325,8 @@ int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64
           launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg));
         }
         sg.uploaded = true;
+        f->gmax_fused = false;
+        if ((rc = note_upload(f, sg.slot))) return rc;
         const double* staged_blobs = reinterpret_cast<const double*>(sg.st + kCtlBytes);
         if ((rc = observe_impl(f, staged_blobs, B, nullptr, nullptr, true))) return rc;  // :73 (reset fused) + :82-124
         return pk_resample(f, u, weight_domain, nullptr);                                // :137
@@ -1562,6 +1625,14 @@ int pk_timings(pk_filter* f, double ms[PK_T_COUNT], int64_t launches[PK_T_COUNT]
   return PK_OK;
 }
 int pk_observe_route(const pk_filter* f) { return f ? f->route : PK_ROUTE_NONE; }
+int pk_download_sources(pk_filter* f, int32_t* src) {
+  if (!f || !src) return fail(PK_ERR_INVALID, "pk_download_sources: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipMemcpyAsync(src, f->d.src[f->d.cur], (size_t)f->d.P * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
 int pk_observe_bytes(const pk_filter* f, int32_t B, int64_t* algorithmic, int64_t* moved) {
   if (!f) return fail(PK_ERR_INVALID, "pk_observe_bytes: NULL handle");
   const int64_t P = f->d.P, L = f->d.lay.L;

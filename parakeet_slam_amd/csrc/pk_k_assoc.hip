@@ -111,7 +111,13 @@ void launch_assoc_brute(hipStream_t s, DeviceState& d, const double* blobs_dev, 
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
-  size_t lds = (size_t)B * 12;
+  const size_t lds = assoc_brute_lds_bytes(B);  // <= kMaxDynLds: checked by the caller
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_assoc_brute), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();
+  }
   hipLaunchKernelGGL(k_assoc_brute, dim3((unsigned)d.P), dim3(256), lds, s, a);
 }
 

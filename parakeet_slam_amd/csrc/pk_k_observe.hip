@@ -328,7 +328,13 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
     else
       hipLaunchKernelGGL((k_observe<true, 2>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
   } else {
-    size_t lds = sizeof(int32_t) * ((size_t)d.lay.Lp + 2 * (size_t)B);
+    const size_t lds = observe_general_lds_bytes(d.lay.Lp, B);  // <= kMaxDynLds: checked by the caller
+    static bool attr_set[kMaxDevices] = {false};
+    if (first_time_on_this_device(attr_set)) {
+      for (const void* fn : {reinterpret_cast<const void*>(k_observe<false, 1>), reinterpret_cast<const void*>(k_observe<false, 2>)})
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess)
+          (void)hipGetLastError();
+    }
     if (g_observe_nv == 2)
       hipLaunchKernelGGL((k_observe<false, 2>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
     else

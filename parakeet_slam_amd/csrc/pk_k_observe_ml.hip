@@ -72,6 +72,7 @@ struct FastQueue {
   int* n;         // entries pushed (may exceed kFastQueue: the excess is evaluated in place)
 };
 __host__ __device__ inline size_t fast_queue_bytes() { return (size_t)kFastQueue * (4 * 8 + 4) + 16; }
+size_t observe_fast_lds_bytes(int B) { return fast_queue_bytes() + (size_t)B * 13 + 16; }
 
 // exact: the scan's exact records [B][6], in global memory (a.exact) or staged in LDS by the caller.
 // INPLACE: entries that do not fit the queue are evaluated on the spot (k_observe_fast); without it
@@ -347,7 +348,13 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
   a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
-  const size_t lds = fast_queue_bytes() + (size_t)B * 13 + 16;
+  const size_t lds = observe_fast_lds_bytes(B);  // <= kMaxDynLds: checked by the caller
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_observe_fast), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();
+  }
   hipLaunchKernelGGL(k_observe_fast, dim3((unsigned)d.P), dim3(kFastThreads), lds, s, a);
 }
 

@@ -121,6 +121,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 // ML observe for L <= kFastMaxL straight from the hand-off: contested blobs are settled here,
 // with the landmark state in registers.  Particles flagged in fh.pflag are skipped (the general
 // k_observe, launched with only_flagged, takes them).
+size_t observe_fast_lds_bytes(int B);  // dynamic LDS of k_observe_fast: must fit kMaxDynLds
 void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exact_dev,
                          const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
                          const ObserveExtras& ex = ObserveExtras());
@@ -151,6 +152,10 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
                        const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
                        const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex);
 extern int g_observe_nv;
+// dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
+// k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued
+inline size_t observe_general_lds_bytes(int Lp, int B) { return sizeof(int32_t) * ((size_t)Lp + 2 * (size_t)B); }
+inline size_t assoc_brute_lds_bytes(int B) { return (size_t)B * 12; }
 // K4: weights -> block totals / local scans
 void launch_block_max(hipStream_t s, DeviceState& d, double* partial_dev, double* gmax_dev);
 void launch_keys_max(hipStream_t s, const unsigned long long* keys_dev, double* gmax_dev);

@@ -1,0 +1,197 @@
+"""GPU, BASELINE.json configs[2] at FULL size (100 000 particles x 2 000 landmarks, the bench's headline
+workload, 46 GB of HBM) and one whole shard of configs[4] (125 000 x 5 000, 145 GB).
+
+The oracle cannot run these sizes, so parity is held through
+  * route agreement: the production ML route, the two-sweep route, the general route leave the same
+    weights / ancestors / maps (the small-size tests hold each of them to the oracle and the goldens);
+  * ancestors recomputed on the host from the DOWNLOADED log-weights with the oracle's resampler
+    (prkt_core_v2.py:216-250) -- exact, at P = 10 000 and 100 000, both weight domains;
+  * the size-independent properties of tests/test_gpu_fullsize.py (systematic-resampling bounds,
+    replay bit-identity, tracking of the true trajectory).
+"""
+import json
+import math
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.fastslam_oracle import low_variance_ancestors, synthetic_scan, synthetic_world, truth_step
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P2, L2 = 100000, 2000
+
+
+def ancestors_match_oracle(anc, w, u):
+    """Device ancestors == the oracle's on the same weights.  Ancestors are discrete: the device sums
+    the weights in 1024-blocks (Kogge-Stone inside a wave), the reference sequentially, so a comb point
+    u r + k r that lies within a few ulp of a cumulative sum may legitimately fall on either side of it
+    (expected rate ~ P^2 eps per resample: 1e-6 at P = 1e5).  Anything else is an error."""
+    ref = low_variance_ancestors(w, u)
+    bad = np.flatnonzero(anc != ref)
+    if bad.size == 0:
+        return True
+    c = np.cumsum(w)
+    r = c[-1] / float(len(w))
+    for k in bad:
+        t = u * r + k * r
+        j = min(anc[k], ref[k])
+        assert abs(anc[k] - ref[k]) == 1 and abs(t - c[j]) <= 8 * np.finfo(float).eps * c[j], \
+            "slot %d: device ancestor %d, oracle %d, comb point %.17g vs cumulative sum %.17g" % (k, anc[k], ref[k], t, c[j])
+    assert bad.size <= 2
+    return True
+
+
+@pytest.mark.parametrize("P", [10000, 100000])
+def test_ancestors_exact_at_scale_on_random_weights(lib, P):
+    L = 4
+    means, covs = synthetic_world(L)
+    f = lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    rs = np.random.RandomState(P)
+    for trial, (decades, u) in enumerate([(0.0, 0.5), (3.0, 0.123456789), (12.0, 0.999), (200.0, 1e-9), (40.0, 0.31)]):
+        poses = np.zeros((P, 4))
+        poses[:, 3] = 10.0 ** (-decades * rs.uniform(0, 1, P))
+        if trial == 4:
+            poses[rs.uniform(0, 1, P) < 0.7, 3] = 0.0  # most particles dead
+        f.upload_poses(poses)
+        logw = f.download_log_weights()
+        for domain, w in ((lib.PK_WEIGHTS_LINEAR, np.exp(logw)), (lib.PK_WEIGHTS_LOG, np.exp(logw - logw.max()))):
+            f.upload_poses(poses)  # the resample gathered the poses: restore the generation
+            anc = f.resample(u, domain=domain, return_ancestors=True)
+            assert ancestors_match_oracle(anc, w, u)
+    f.close()
+
+
+def run_config2(lib, steps, opts, seed=7):
+    means, covs = synthetic_world(L2)
+    f = lib.DeviceFilter(P2, L2)
+    for k, v in opts.items():
+        f.set_option(k, v)
+    f.upload_map(means, covs.reshape(L2, 25))
+    rnd = random.Random(seed)
+    pose = (0.0, 0.0, 0.0)
+    hist = []
+    route = None
+    for s in range(steps):
+        pose = truth_step(pose, 0.2, 0.1, 0.1)
+        blobs = synthetic_scan(means, pose)
+        f.reset_weights()
+        f.motion(0.2, 0.1, 0.1, seed=seed, draw=s)
+        f.observe(blobs)
+        route = f.observe_route()
+        logw = f.download_log_weights()
+        u = rnd.random()
+        anc = f.resample(u, domain=lib.PK_WEIGHTS_LOG, return_ancestors=True)
+        hist.append((logw, anc, f.summary(), pose, u))
+    sel = np.r_[0:16, 50000:50016, P2 - 16:P2]
+    maps = [f.download_landmarks(int(a), int(a) + 16) for a in (0, 50000, P2 - 16)]
+    out = dict(poses=f.download_poses(), maps=maps, hist=hist, route=route, sel=sel)
+    f.close()
+    return out
+
+
+@pytest.fixture(scope="module")
+def config2_default(lib):
+    return run_config2(lib, 3, {})
+
+
+def test_config2_resample_properties_tracking_and_oracle_ancestors(lib, config2_default):
+    out = config2_default
+    assert out["route"] in ("ml_regs", "ml_sweep")
+    for logw, anc, sm, pose, u in out["hist"]:
+        assert np.isfinite(logw).all()
+        w = np.exp(logw - logw.max())
+        assert np.all(np.diff(anc) >= 0) and anc[0] >= 0 and anc[-1] < P2
+        counts = np.bincount(anc, minlength=P2)
+        assert np.all(np.abs(counts - P2 * w / w.sum()) < 1.0 + 1e-6)
+        assert ancestors_match_oracle(anc, w, u)  # the weights of a real step, P = 100 000
+        assert abs(sm[0] - pose[0]) < 0.05 and abs(sm[1] - pose[1]) < 0.05
+    assert np.isfinite(out["poses"]).all()
+
+
+@pytest.mark.parametrize("name,opts", [("sweep", {"regs_step": 0}), ("general", {"fast_observe": 0})])
+def test_config2_routes_agree_at_full_size(lib, config2_default, name, opts):
+    a, b = config2_default, run_config2(lib, 3, opts)
+    assert b["route"] == {"sweep": "ml_sweep", "general": "ml_general"}[name]
+    for s in range(3):
+        assert np.array_equal(a["hist"][s][1], b["hist"][s][1]), "ancestors differ between ML routes (step %d)" % s
+        assert np.allclose(a["hist"][s][0], b["hist"][s][0], rtol=1e-10, atol=1e-9)  # log-weights
+    assert np.allclose(a["poses"][:, :3], b["poses"][:, :3], rtol=1e-10, atol=1e-13)
+    for (ma, ca, ka), (mb, cb, kb) in zip(a["maps"], b["maps"]):
+        assert np.allclose(ma, mb, rtol=1e-11, atol=1e-12)
+        assert np.allclose(ca, cb, rtol=1e-10, atol=1e-14)
+        assert np.array_equal(ka, kb)
+
+
+def test_config2_replay_is_bit_identical(lib, config2_default):
+    a, b = config2_default, run_config2(lib, 3, {})
+    assert np.array_equal(a["poses"], b["poses"])
+    for s in range(3):
+        assert np.array_equal(a["hist"][s][0], b["hist"][s][0]) and np.array_equal(a["hist"][s][1], b["hist"][s][1])
+    for x, y in zip(a["maps"], b["maps"]):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))
+
+
+def test_config4_single_shard_smoke(lib):
+    """One whole shard of BASELINE.json configs[4]: 125 000 particles x 5 000 landmarks (145 GB of the
+    288 GB).  Two ML steps and one supplied-ids step run, stay finite, resample within the systematic
+    bounds and keep tracking the true pose."""
+    P, L = 125000, 5000
+    means, covs = synthetic_world(L)
+    f = lib.DeviceFilter(P, L)
+    assert f.device_bytes() > 140e9
+    f.upload_map(means, covs.reshape(L, 25))
+    pose = (0.0, 0.0, 0.0)
+    rnd = random.Random(5)
+    for s, ids in enumerate((None, None, np.arange(1, L + 1))):
+        pose = truth_step(pose, 0.2, 0.1, 0.1)
+        blobs = synthetic_scan(means, pose)
+        f.reset_weights()
+        f.motion(0.2, 0.1, 0.1, seed=5, draw=s)
+        f.observe(blobs, ids=ids)
+        logw = f.download_log_weights()
+        assert np.isfinite(logw).all()
+        u = rnd.random()
+        anc = f.resample(u, domain=lib.PK_WEIGHTS_LOG, return_ancestors=True)
+        w = np.exp(logw - logw.max())
+        assert np.all(np.diff(anc) >= 0) and anc[-1] < P
+        assert np.all(np.abs(np.bincount(anc, minlength=P) - P * w / w.sum()) < 1.0 + 1e-6)
+        assert ancestors_match_oracle(anc, w, u)
+        sm = f.summary()
+        assert abs(sm[0] - pose[0]) < 0.05 and abs(sm[1] - pose[1]) < 0.05
+    m, c, k = f.download_landmarks(P - 4, P)
+    assert np.isfinite(m).all() and np.isfinite(c).all() and k.max() >= 2
+    f.close()
+
+
+def _bench(args, timeout=900):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_bench_gpus_2_launches_its_own_ranks_or_refuses(lib):
+    """`python bench.py --gpus 2` with no launcher around it: on a box with >= 2 devices it forms a
+    2-rank RCCL world itself and says n_gpus = 2; on a 1-GPU box it exits non-zero instead of quietly
+    timing one GPU."""
+    import torch
+
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--particles", "4096", "--landmarks", "64",
+            "--no-cpu-baseline", "--no-probes"]
+    r = _bench(args)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert d["n_gpus"] == 2 and d["config"]["global_particles"] == 8192
+        assert "RCCL" in d["config"]["parallelism"]
+        assert all(math.isfinite(v) for v in d["summary"])
+    else:
+        assert r.returncode != 0
+        assert b'"n_gpus"' not in r.stdout

@@ -87,3 +87,86 @@ def test_many_blobs_few_landmarks_and_odd_counts(lib):
     assert np.array_equal(ids, o.observe(blobs))
     assert np.allclose(f.download_poses()[:, 3], o.weights(), rtol=1e-9, atol=0)
     f.close()
+
+
+def _few_landmarks_many_blobs(L, B, seed):
+    rs = np.random.RandomState(seed)
+    means = np.column_stack([rs.uniform(-10, 10, (L, 2)), rs.uniform(0, 255, (L, 3))])
+    covs = np.broadcast_to(0.25 * np.identity(5), (L, 5, 5)).copy()
+    blobs = np.column_stack([rs.uniform(-3, 3, B), rs.uniform(0, 255, (B, 3))])
+    own = np.column_stack([np.arctan2(means[:, 1], means[:, 0]), means[:, 2:]])
+    where = rs.choice(B, size=3 * L, replace=False)
+    blobs[where] = np.tile(own, (3, 1)) + rs.normal(0, 0.01, (3 * L, 4))  # every landmark is sighted three times
+    return means, covs, blobs
+
+
+def test_scans_beyond_the_default_64k_of_lds(lib):
+    """B = 9 000 blobs: the brute-force association kernel needs 12 B of LDS per blob (108 KB), the general
+    EKF kernel 4 (Lp + 2 B) = 72 KB for its per-particle chains -- both above the 64 KB a kernel gets
+    without the max-dynamic-LDS attribute.  Every route must still agree with the oracle."""
+    from oracle.fastslam_oracle import OracleFilter
+
+    L, B, P = 24, 9000, 6
+    means, covs, blobs = _few_landmarks_many_blobs(L, B, 11)
+    o = OracleFilter(P, means, covs)
+    ids_o = o.observe(blobs)
+    assert (ids_o > 0).sum() >= 3 * L * P // 2
+    for opts in ({"fast_observe": 0, "assoc_kernel": 1}, {"fast_observe": 0}, {}):
+        f = lib.DeviceFilter(P, L)
+        for k, v in opts.items():
+            f.set_option(k, v)
+        f.upload_map(means, covs.reshape(L, 25))
+        ids = f.observe(blobs, return_ids=True)
+        assert np.array_equal(ids, ids_o), opts
+        assert np.allclose(f.download_log_weights(), o.logw, rtol=1e-9, atol=1e-9)
+        m, c, k = f.download_landmarks()
+        assert np.allclose(m, o.mean, rtol=1e-9, atol=1e-11) and np.array_equal(k, o.count)
+        f.close()
+
+
+def test_scan_too_large_for_the_lds_chains_is_refused_loudly(lib):
+    """B = 20 000: the per-particle chains of the general EKF kernel (the last resort of every ML route)
+    would need 160 KB of LDS.  ML association is refused with PK_ERR_UNSUPPORTED -- not launched to fail
+    silently -- while supplied ids (chains shared by all particles, in HBM) still work."""
+    L, B, P = 24, 20000, 4
+    means, covs, blobs = _few_landmarks_many_blobs(L, B, 12)
+    f = lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    before = f.download_landmarks()
+    with pytest.raises(lib.PkError) as e:
+        f.observe(blobs)
+    assert e.value.status == lib.PK_ERR_UNSUPPORTED and "LDS" in str(e.value)
+    with pytest.raises(lib.PkError) as e:
+        f.associate(blobs)
+    assert e.value.status == lib.PK_ERR_UNSUPPORTED
+    after = f.download_landmarks()
+    assert all(np.array_equal(a, b) for a, b in zip(before, after)), "a refused observe must not touch the state"
+    f.observe(blobs, ids=np.zeros(B, dtype=np.int32))
+    assert np.allclose(f.download_log_weights(), B * np.log(0.1), rtol=1e-12)
+    f.close()
+
+
+def test_staged_scan_discarded_by_a_supplied_ids_observe(lib):
+    """pk_stage_scan followed by a supplied-ids observe discards the staged scan; the staging ring must keep
+    turning (every slot's reuse waits for the upload that last read it, recorded or not)."""
+    L, P = 40, 64
+    rs = np.random.RandomState(2)
+    means = np.column_stack([rs.uniform(-10, 10, (L, 2)), rs.uniform(0, 255, (L, 3))])
+    covs = np.broadcast_to(0.25 * np.identity(5), (L, 5, 5)).copy()
+    blobs = np.column_stack([np.arctan2(means[:, 1], means[:, 0]), means[:, 2:]])
+    ids = np.arange(1, L + 1, dtype=np.int32)
+    f, g = lib.DeviceFilter(P, L), lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    g.upload_map(means, covs.reshape(L, 25))
+    for i in range(40):  # five trips round the ring of eight
+        f.stage_scan(blobs)
+        if i % 3 == 0:
+            f.observe(blobs, ids=ids)       # discards the staged scan
+            g.observe(blobs, ids=ids)
+        else:
+            f.observe_staged()
+            g.observe(blobs)
+    assert np.array_equal(f.download_log_weights(), g.download_log_weights())
+    assert all(np.array_equal(a, b) for a, b in zip(f.download_landmarks(), g.download_landmarks()))
+    f.close()
+    g.close()
