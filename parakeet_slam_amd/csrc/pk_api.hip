@@ -107,6 +107,8 @@ struct pk_filter {
   int route = PK_ROUTE_NONE;  // kernels used by the last observe
   int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
   int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
+  int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
+  int regs_warm = 2;     // k_step_regs: 0 no L2 warming of the next particle's slot, 1 mean rows, 2 whole slot
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
   uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
   size_t sweep_cap = 0;
@@ -1223,6 +1225,15 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "fused_step")) {
     f->fused_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "regs_step")) {
+    f->regs_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "regs_warm")) {
+    if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "regs_warm: 0 (off), 1 (mean rows) or 2 (whole slot)");
+    f->regs_warm = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "assoc_dup")) {
