@@ -476,6 +476,7 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
 // Upload one scan for maximum-likelihood association and enqueue the association kernel.
 struct AssocLaunch {
   bool fused = false;  // nothing launched yet: k_step_fused does gates + EKF in one kernel
+  bool regs = false;   // nothing launched yet: k_step_regs does the same for 512 < L <= 2048
   BlobGrid grid{};
   int n9 = 0;
   const unsigned char* tables = nullptr;
@@ -598,6 +599,18 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
         fused_lds_bytes(g.ncell, B, n9) <= kFusedMaxLds) {
       if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
       out->fused = true;
+      out->grid = g;
+      out->n9 = n9;
+      out->tables = f->scan_dev + o_tab;
+      out->exact = reinterpret_cast<const double*>(f->scan_dev + o_exact);
+      const size_t cs_b = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
+      out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
+      return PK_OK;
+    }
+    if (out && want_fast && !finalize && f->fast_observe == 1 && f->regs_step && f->d.lay.L > kFastMaxL &&
+        f->d.lay.L <= kRegsMaxL && B > 0 && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds) {
+      if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
+      out->regs = true;
       out->grid = g;
       out->n9 = n9;
       out->tables = f->scan_dev + o_tab;
@@ -1101,9 +1114,10 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
   ex.gmax_key = ctl_gmax_key(f);
   f->route = al.fused ? PK_ROUTE_ML_FUSED
+             : al.regs ? PK_ROUTE_ML_REGS
              : !al.fast ? PK_ROUTE_ML_GENERAL
              : (f->d.lay.L > kFastMaxL || f->fast_observe >= 2) ? PK_ROUTE_ML_SWEEP : PK_ROUTE_ML_HANDOFF;
-  if (al.fused) {
+  if (al.fused || al.regs) {
     FastHandoff fh = f->fh;
     fh.n_flagged = ctl_n_flagged(f);
     fh.flags_only = true;
@@ -1111,7 +1125,10 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
       Span t(f, PK_T_OBSERVE);
       ObserveExtras e1 = ex;
       e1.flip = false;
-      launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
+      if (al.regs)
+        launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm);
+      else
+        launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
     }
     // the particles it flagged (a landmark passing more than kFastSlots blobs): general kernels,
     // both timed in the association slot

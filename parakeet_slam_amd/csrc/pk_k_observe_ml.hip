@@ -78,7 +78,7 @@ size_t observe_fast_lds_bytes(int B) { return fast_queue_bytes() + (size_t)B * 1
 // INPLACE: entries that do not fit the queue are evaluated on the spot (k_observe_fast); without it
 // the caller checks *fq.n > kFastQueue afterwards and hands the particle to the general kernels.
 // bc: landmarks passing each blob's gates (unsigned char from the hand-off, or the int LDS counters of k_step_fused)
-template <bool INPLACE, typename CountT>
+template <bool INPLACE, typename CountT, int QCAP = kFastQueue>
 __device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* exact,
                                              const Landmark<double>& lm, double sx, double sy,
                                              double pse, uint2 packed, const CountT* bc,
@@ -124,7 +124,7 @@ __device__ __forceinline__ void fast_prepare(const FastArgs& a, const double* ex
       continue;
     }
     const int qi = atomicAdd(fq.n, 1);
-    if (qi < kFastQueue) {
+    if (qi < QCAP) {
       fq.det2[qi] = det2;
       fq.det3[qi] = det3;
       fq.maha2[qi] = num2;
@@ -180,14 +180,15 @@ __device__ __forceinline__ void fast_evaluate_queue(const FastQueue& fq, unsigne
 
 // Read the queued results back into the owner's slots; contested candidates that attain the
 // blob's best probability bid for it with their landmark index (earliest wins, :377).
-__device__ __forceinline__ void fast_collect(const FastQueue& fq, const unsigned long long* best, int* win, int l,
+// results: probability bits of the queue entries (the evaluation pass wrote them over fq.maha2, or into an array of its own)
+__device__ __forceinline__ void fast_collect(const unsigned long long* results, const unsigned long long* best, int* win, int l,
                                              FastSlot (&sl)[kFastSlots]) {
 #pragma unroll
   for (int k = 0; k < kFastSlots; ++k) {
     if (sl[k].t < 0) continue;
     unsigned long long bits = sl[k].bits;
     if (sl[k].qf >> 4) {
-      bits = reinterpret_cast<const unsigned long long*>(fq.maha2)[(sl[k].qf >> 4) - 1];
+      bits = results[(sl[k].qf >> 4) - 1];
       if (!(sl[k].qf & 1u)) sl[k].qf = bits != 0ull ? 2u : 4u;
     }
     if ((sl[k].qf & 1u) && bits != 0ull && bits == best[sl[k].t]) {
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(kFastThreads) k_observe_fast(FastArgs a) {
   __syncthreads();
   fast_evaluate_queue(fq, best, tid, kFastThreads);
   __syncthreads();
-  fast_collect(fq, best, win, l, sa);
+  fast_collect(reinterpret_cast<const unsigned long long*>(fq.maha2), best, win, l, sa);
   __syncthreads();
   for (int t = tid; t < B; t += kFastThreads) nun += (bc[t] >= 2 && best[t] == 0ull);  // contested, all 0
   double acc = (double)nun * Consts<double>::log_no_match;
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
   lds_barrier();
   PK_STAMP(f7)
   PK_FSTAMP_ADD(8, f6, f7)  // queue evaluation + barrier
-  fast_collect(fq, best, win, l, sa);
+  fast_collect(reinterpret_cast<const unsigned long long*>(fq.maha2), best, win, l, sa);
   lds_barrier();
   PK_STAMP(f8)
   PK_FSTAMP_ADD(9, f7, f8)  // collect + barrier
@@ -1130,6 +1131,674 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
     hipLaunchKernelGGL(k_observe_sweep<kSweepSlots>, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
   else
     hipLaunchKernelGGL(k_observe_sweep<kFastSlots>, dim3((unsigned)grid), dim3(kSweepThreads), plan.lds, s, a);
+}
+
+// ------------------------------------------------------------------ K2 + K3 in ONE pass, 512 < L <= 2048
+// k_step_fused's shape for maps that do not fit one landmark per lane: a workgroup of 1024 lanes owns
+// one particle at a time and keeps the particle's WHOLE map in registers, two landmarks per lane
+// (l and l + 1024: every row access of a wave is one contiguous 512-byte run), from the single coalesced
+// load to the single coalesced store -- the state is read once (k_assoc_grid + k_observe_sweep read the
+// means twice and most covariance rows twice, and hand 32 B per landmark over through HBM).
+// 16 waves x 128 VGPRs are the CU's whole register file, so exactly one particle is in flight per CU:
+// the grid is persistent (one workgroup per CU), the scan tables are staged in LDS once per workgroup,
+// and the NEXT particle's map slot is touched (one dword per 128-byte line, LDS-DMA into a dump word: no
+// register is tied up) while this one is worked on, so that it waits in L2 when its turn comes -- the
+// only way one resident workgroup overlaps its memory time with its arithmetic.
+//   per particle: state requested (means first) -> gates of both landmarks of the lane (as in
+//   k_step_fused) -> settling in two rounds, one per landmark of the lane, through ONE probability queue
+//   in LDS (results of both rounds kept) -> bids -> EKF updates in scan order -> stores -> log-weight.
+// Registers are the scarce resource (58 of the 128 hold the two landmarks): what a lane knows about its
+// gate-passing blobs is packed into 16-bit fields between the phases, and while the first landmark is
+// updated the six colour-covariance rows of the second wait in the (by then dead) queue area of LDS.
+// A particle in which a landmark passes more than kFastSlots blobs, or whose queue overflows in a round,
+// is flagged for the general kernels before anything of it has been written.
+constexpr int kRegsThreads = 1024;
+constexpr int kRegsQueue = 1024;  // probability queue entries per settling round
+
+struct RegsArgs {
+  FastArgs f;                   // lmpass, bcount, pflag unused
+  BlobGrid g;
+  const unsigned char* tables;  // start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9]
+  const double* h;
+  unsigned char* pflag_out;     // [P] 1 = general route
+  unsigned* n_flagged;
+  int n9;
+  int warm;                     // 0: no L2 warming of the next particle's slot, 1: mean rows, 2: whole slot
+  int64_t P;
+};
+
+// LDS: tables | ccount int[B] (later: win) | best u64[B] | queue inputs 36 B x kRegsQueue | results u64[2 kRegsQueue] | counters
+// (queue inputs + results = 52 KB: the parking area of the second landmark's colour block, 48 KB, during the updates)
+size_t regs_lds_bytes(int ncell, int B, int n9) {
+  size_t tab = (grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + 15) & ~(size_t)15;
+  return tab + (((size_t)B * 4 + 15) & ~(size_t)15) + (size_t)B * 8 + (size_t)kRegsQueue * 36 + (size_t)kRegsQueue * 16 + 32;
+}
+
+// Gates of one landmark (prkt_core_v2.py:433, :441) against the scan tables in LDS: the same walk as in
+// k_step_fused (4-wide over the duplicated list, fp32 screen on packed pairs, exact float64 gates on the
+// survivors, their records from L2 two at a time).  pass01 / pass23: the (first four) passing blobs, 16 bits each.
+struct RegsGated {
+  unsigned pass01, pass23;
+  double pse;
+};
+__device__ __forceinline__ RegsGated regs_gates(const BlobGrid& g, const unsigned short* start, const float4* rec32,
+                                                const unsigned short* idx9, const double* exact, int* ccount, int* wg_flag,
+                                                double mx, double my, double mr, double mg, double mb, double sx, double sy,
+                                                double sh) {
+  unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;
+  const double pse = atan2(my - sy, mx - sx);
+  const double eb = pse - sh;  // :408
+  const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
+  int c[3];
+  const double m3[3] = {mr, mg, mb};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // same cell function as the host, see k_assoc_grid
+    double q = floor(__dmul_rn(__dsub_rn(m3[k], g.lo[k]), g.inv_h));
+    q = fmin(fmax(q, -1.0), (double)g.G[k]);
+    c[k] = (int)q;
+  }
+  const int k0 = max(c[2] - 1, 0), k1 = min(c[2] + 1, g.G[2] - 1);
+  const int r = min(max(c[0], 0), g.G[0] - 1), gg = min(max(c[1], 0), g.G[1] - 1);
+  const int base = (r * g.G[1] + gg) * g.G[2];
+  int i0 = 0, i1 = 0;
+  if (k0 <= k1) {
+    i0 = start[base + k0];
+    i1 = start[base + k1 + 1];
+  }
+  int npass = 0;
+  const Float2 m01 = {mr32, mg32}, m23 = {mb32, eb32};
+  auto prefilter_q = [&](const float4& q) {
+    const Float2 q01 = {q.x, q.y}, q23 = {q.z, q.w};
+    const Float2 d01 = q01 - m01, d23 = q23 - m23;
+    const Float2 s01 = d01 * d01;
+    const float cd32 = fmaf(d23.x, d23.x, s01.x + s01.y);
+    return !(cd32 > g.thr32) && !(fabsf(d23.y) > g.thrb32);
+  };
+  auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
+    if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
+      atomicAdd(&ccount[tt], 1);
+      if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
+      if (npass == 1) pass01 = (pass01 & 0x0000FFFFu) | ((unsigned)tt << 16);
+      if (npass == 2) pass23 = (pass23 & 0xFFFF0000u) | (unsigned)tt;
+      if (npass == 3) pass23 = (pass23 & 0x0000FFFFu) | ((unsigned)tt << 16);
+      ++npass;
+    }
+  };
+  unsigned slo = 0u, shi = 0u;  // the LAST four survivors of the fp32 screen, 16 bits each
+  int npc = 0;
+  for (int i = i0; i < i1; i += 4) {
+    int t4[4];
+    float4 q4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t4[j] = idx9[i + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q4[j] = rec32[t4[j]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + j < i1 && prefilter_q(q4[j])) {
+        shi = __builtin_amdgcn_alignbit(shi, slo, 16);
+        slo = (slo << 16) | (unsigned)t4[j];
+        ++npc;
+      }
+  }
+  {
+    const int pc[4] = {(int)(slo & 0xFFFFu), (int)(slo >> 16), (int)(shi & 0xFFFFu), (int)(shi >> 16)};
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2 += 2) {  // two records per L2 round trip (16 VGPRs; all four at once: 32)
+      double2 z01[2], z23[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (npc > k2 + k) {
+          const double* rec = exact + 6 * (size_t)pc[k2 + k];
+          z01[k] = *reinterpret_cast<const double2*>(rec);
+          z23[k] = *reinterpret_cast<const double2*>(rec + 2);
+        }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (npc > k2 + k) exact_gates(pc[k2 + k], z01[k], z23[k]);
+    }
+  }
+  if (npc > 4) {  // dense colour clusters: walk again for the survivors before the last four
+    int seen = 0;
+    for (int i = i0; i < i1 && seen < npc - 4; ++i) {
+      const int t = idx9[i];
+      if (prefilter_q(rec32[t])) {
+        const double* rec = exact + 6 * (size_t)t;
+        exact_gates(t, *reinterpret_cast<const double2*>(rec), *reinterpret_cast<const double2*>(rec + 2));
+        ++seen;
+      }
+    }
+  }
+  if (npass > kFastSlots) *wg_flag = 1;
+  return RegsGated{pass01, pass23, pse};
+}
+
+// What a lane keeps about one landmark's (<= 4) gate-passing blobs between the phases: the blobs in `pass`
+// (2 registers) and the four FastSlot::qf words (4 flag bits + 12 bits of queue entry) in 2 more.
+__device__ __forceinline__ void regs_pack(const FastSlot (&sl)[kFastSlots], unsigned& q01, unsigned& q23) {
+  q01 = (sl[0].qf & 0xFFFFu) | (sl[1].qf << 16);
+  q23 = (sl[2].qf & 0xFFFFu) | (sl[3].qf << 16);
+  asm volatile("" : "+v"(q01), "+v"(q23));  // these two are what stays live, not the slots they came from
+}
+__device__ __forceinline__ void regs_unpack(unsigned p01, unsigned p23, unsigned q01, unsigned q23, FastSlot (&sl)[kFastSlots]) {
+  const unsigned pw[2] = {p01, p23}, qw[2] = {q01, q23};
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    const int t = (int)((pw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+    sl[k].t = t == 0xFFFF ? -1 : t;
+    sl[k].qf = (qw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+    sl[k].bits = 0ull;
+  }
+}
+
+// fast_apply with ONE copy of the update code (the slots to apply are sorted to the front; a lane leaves at its
+// first empty one): same arithmetic, same order, a quarter of the instructions in the cache.
+__device__ __forceinline__ double regs_apply(const double* exact, const unsigned short* order, const Noise<double>& qt,
+                                             Landmark<double>& lm, int l, bool imm, double sx, double sy, double pse,
+                                             FastSlot (&sl)[kFastSlots], const int* win) {
+  double acc = 0.0;
+  unsigned key[kFastSlots];
+#pragma unroll
+  for (int k = 0; k < kFastSlots; ++k) {
+    key[k] = 0xFFFFFFFFu;
+    if (sl[k].t < 0) continue;
+    bool apply = (sl[k].qf & 2u) != 0u;
+    if ((sl[k].qf & 8u) && win[sl[k].t] == l) apply = true;          // the earliest of the best bidders
+    if (sl[k].qf & 4u) acc += Consts<double>::log_no_match;          // single candidate, probability 0 (:94-95)
+    if (apply) key[k] = ((unsigned)order[sl[k].t] << 16) | (unsigned)sl[k].t;
+  }
+  auto cswap = [&](unsigned& u, unsigned& v) {
+    const unsigned lo = min(u, v), hi = max(u, v);
+    u = lo;
+    v = hi;
+  };
+  cswap(key[0], key[1]);
+  cswap(key[2], key[3]);
+  cswap(key[0], key[2]);
+  cswap(key[1], key[3]);
+  cswap(key[1], key[2]);
+  bool fresh = true;
+#pragma unroll 1
+  for (int it = 0; it < kFastSlots; ++it) {
+    const unsigned kk = key[0];
+    if (kk == 0xFFFFFFFFu) break;
+    key[0] = key[1];
+    key[1] = key[2];
+    key[2] = key[3];
+    key[3] = 0xFFFFFFFFu;
+    const double* rec = exact + 6 * (size_t)(kk & 0xFFFFu);
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+    acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+    fresh = imm;
+  }
+  return acc;
+}
+
+// Dense evaluation of one round's queue by ALL the waves of the workgroup (an entry per pair of lanes, as
+// in fast_evaluate_queue); the probability bits go to results[] (kept for both rounds), contested ones bid
+// for their blob's best probability.
+template <int NWAVES>
+__device__ __forceinline__ void regs_evaluate_queue(const FastQueue& fq, int n, unsigned long long* results,
+                                                    unsigned long long* best, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, role = lane & 1;
+  for (int base = 0; base < n; base += 32 * NWAVES) {  // workgroup-uniform trip count
+    const int i = base + (lane >> 1) * NWAVES + wave;
+    const bool on = i < n;
+    const double det = on ? (role ? fq.det3[i] : fq.det2[i]) : 1.0;
+    const double maha = (on ? (role ? fq.maha3[i] : fq.maha2[i]) : 0.0) / det;
+    const double k = role ? 3.0 : 2.0;
+    const double mine = 500.0 * exp(-0.5 * (k * Consts<double>::log_two_pi + log_few_ulp(det) + maha));
+    const double other = __shfl_xor(mine, 1, kWave);
+    if (on && role == 0) {
+      const double pr = mine * other / 250000.0;  // bp * cp / 250000
+      const unsigned long long bits = pr > 0.0 ? (unsigned long long)__double_as_longlong(pr) : 0ull;
+      results[i] = bits;
+      const int m = fq.meta[i];
+      if ((m & 0x10000) && bits != 0ull) atomicMax(&best[m & 0xFFFF], bits);
+    }
+  }
+}
+
+// off: byte offset of the landmark inside a row (uniform row base + 32-bit lane offset addressing)
+__device__ __forceinline__ void regs_store_landmark(double* df, int* dc, int Lp, unsigned off, const Landmark<double>& A) {
+  auto at = [&](int f) { return reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(df + (size_t)f * Lp) + off); };
+  __builtin_nontemporal_store(A.mx, at(F_MX));
+  __builtin_nontemporal_store(A.my, at(F_MY));
+  __builtin_nontemporal_store(A.mr, at(F_MR));
+  __builtin_nontemporal_store(A.mg, at(F_MG));
+  __builtin_nontemporal_store(A.mb, at(F_MB));
+  __builtin_nontemporal_store(A.pxx, at(F_PXX));
+  __builtin_nontemporal_store(A.pxy, at(F_PXY));
+  __builtin_nontemporal_store(A.pyy, at(F_PYY));
+  __builtin_nontemporal_store(A.crr, at(F_CRR));
+  __builtin_nontemporal_store(A.crg, at(F_CRG));
+  __builtin_nontemporal_store(A.crb, at(F_CRB));
+  __builtin_nontemporal_store(A.cgg, at(F_CGG));
+  __builtin_nontemporal_store(A.cgb, at(F_CGB));
+  __builtin_nontemporal_store(A.cbb, at(F_CBB));
+  __builtin_nontemporal_store(A.count, reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(dc) + (off >> 1)));
+}
+
+// The kernel's arguments are read from the kernarg segment where they are needed, phase by phase, instead
+// of sitting in ~100 SGPRs for the whole particle loop (the register allocator spilled 87 of them into VGPR
+// lanes, 340 v_readlane / v_writelane per particle): an empty asm makes the pointer opaque, so that nothing
+// loaded through it before is kept alive across it.
+typedef const __attribute__((address_space(4))) RegsArgs* RegsArgsPtr;
+__device__ __forceinline__ RegsArgsPtr regs_args_now(RegsArgsPtr rp) {
+  asm volatile("" : "+s"(rp));
+  return rp;
+}
+// member-wise copies out of the kernarg segment (a struct copy cannot bind across address spaces)
+__device__ __forceinline__ SlotSource regs_slot_source(RegsArgsPtr R) {
+  return SlotSource{R->f.ss.map, R->f.ss.slot_bytes, R->f.ss.alt, R->f.ss.alt_stride, R->f.ss.alt_off};
+}
+__device__ __forceinline__ BlobGrid regs_blob_grid(RegsArgsPtr R) {
+  BlobGrid g;
+  g.lo[0] = R->g.lo[0];
+  g.lo[1] = R->g.lo[1];
+  g.lo[2] = R->g.lo[2];
+  g.inv_h = R->g.inv_h;
+  g.G[0] = R->g.G[0];
+  g.G[1] = R->g.G[1];
+  g.G[2] = R->g.G[2];
+  g.ncell = R->g.ncell;
+  g.thr32 = R->g.thr32;
+  g.thrb32 = R->g.thrb32;
+  return g;
+}
+__device__ __forceinline__ Noise<double> regs_noise(RegsArgsPtr R) {
+  return Noise<double>{R->f.qt.q00, R->f.qt.rr, R->f.qt.rg, R->f.qt.rb, R->f.qt.gg, R->f.qt.gb, R->f.qt.bb, R->f.qt.diag};
+}
+
+// LDS offsets of the workgroup's arrays (see regs_lds_bytes), all derived from three numbers
+struct RegsLds {
+  unsigned cs_bytes, tab_bytes, best_off;  // start at 0, rec32 at cs_bytes, idx9 behind it; ccount at tab_bytes
+  int B;
+  __device__ __forceinline__ const unsigned short* start(unsigned char* m) const { return reinterpret_cast<const unsigned short*>(m); }
+  __device__ __forceinline__ const float4* rec32(unsigned char* m) const { return reinterpret_cast<const float4*>(m + cs_bytes); }
+  __device__ __forceinline__ const unsigned short* idx9(unsigned char* m) const { return reinterpret_cast<const unsigned short*>(m + cs_bytes + (size_t)B * 16); }
+  __device__ __forceinline__ int* ccount(unsigned char* m) const { return reinterpret_cast<int*>(m + tab_bytes); }
+  __device__ __forceinline__ unsigned long long* best(unsigned char* m) const { return reinterpret_cast<unsigned long long*>(m + best_off); }
+  __device__ __forceinline__ FastQueue queue(unsigned char* m, int* n) const {
+    FastQueue fq;
+    fq.det2 = reinterpret_cast<double*>(m + best_off + (size_t)B * 8);
+    fq.det3 = fq.det2 + kRegsQueue;
+    fq.maha2 = fq.det3 + kRegsQueue;
+    fq.maha3 = fq.maha2 + kRegsQueue;
+    fq.meta = reinterpret_cast<int*>(fq.maha3 + kRegsQueue);
+    fq.n = n;
+    return fq;
+  }
+  __device__ __forceinline__ unsigned long long* results(unsigned char* m) const {
+    return reinterpret_cast<unsigned long long*>(m + best_off + (size_t)B * 8 + (size_t)kRegsQueue * 36);
+  }
+  __device__ __forceinline__ int* qn(unsigned char* m) const { return reinterpret_cast<int*>(results(m) + 2 * kRegsQueue); }
+  __device__ __forceinline__ double* park(unsigned char* m) const { return reinterpret_cast<double*>(m + best_off + (size_t)B * 8); }
+};
+
+__global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[kRegsThreads / kWave];
+  __shared__ unsigned warm_dump[kWave];  // where the L2-warming loads of every wave land (never read)
+  __shared__ int wg_flag;
+  RegsArgsPtr rp = (RegsArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  const int tid0 = threadIdx.x;
+  RegsLds lds;
+  int Lp, L;
+  bool immA, immB;
+  {
+    const int tid = tid0;
+    RegsArgsPtr R = regs_args_now(rp);
+    lds.B = R->f.B;
+    lds.cs_bytes = (unsigned)grid_cs_bytes(R->g.ncell);
+    lds.tab_bytes = (unsigned)((lds.cs_bytes + (size_t)lds.B * 16 + (size_t)R->n9 * 2 + 15) & ~(size_t)15);
+    lds.best_off = lds.tab_bytes + (unsigned)(((size_t)lds.B * 4 + 15) & ~(size_t)15);
+    Lp = R->f.Lp;
+    L = R->f.L;
+    // the scan tables: once per workgroup
+    const uint4* src = reinterpret_cast<const uint4*>(R->tables);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (unsigned i = (unsigned)tid; i < lds.tab_bytes / 16; i += kRegsThreads) dst[i] = src[i];
+    const unsigned char* imm = R->f.immutable;
+    immA = imm[min(tid, L - 1)] != 0;
+    immB = imm[min(tid + kRegsThreads, L - 1)] != 0;
+  }
+  const int B = lds.B;
+  // the lane's two landmarks: lA = tid and lB = tid + 1024 (lanes beyond the map re-read its last landmark and
+  // never use or store it)
+
+  for (int64_t p = blockIdx.x;; p += gridDim.x) {
+    double sx, sy;
+    Landmark<double> A, Bq;
+    // everything derived from the lane index is derived afresh for every particle: hoisted out of this loop
+    // (LDS addresses, row offsets, queue-entry indices ...) those values filled the register file and spilled
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lA = tid, lB = tid + kRegsThreads;
+    const bool hasA = lA < L, hasB = lB < L;
+    // byte offsets of the lane's two landmarks inside a row: the only per-lane part of the 30 addresses (row
+    // bases are uniform: SGPR pair + 32-bit VGPR offset addressing)
+    const unsigned oA = (unsigned)min(lA, Lp - 1) * 8u, oB = (unsigned)min(lB, Lp - 1) * 8u;
+    const double* sf;
+    const int* sc;
+    auto row = [&](int f, unsigned off) {
+      return *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(sf + (size_t)f * Lp) + off);
+    };
+    {
+      RegsArgsPtr R = regs_args_now(rp);
+      if (p >= R->P) break;
+      const SlotSource ss = regs_slot_source(R);
+      const unsigned char* sslot = ss.at(R->f.src[p]);
+      sf = reinterpret_cast<const double*>(sslot);
+      sc = reinterpret_cast<const int*>(sslot + R->f.count_off);
+      sx = R->f.x[p];
+      sy = R->f.y[p];
+      // ---- 1. the state is requested in three instalments, each one phase before it is needed (a row that is
+      // requested now but used three phases later holds its registers all the way): the means of both landmarks
+      // now, the first landmark's covariance rows behind its gates, the second one's behind the second gates
+      A.mx = row(F_MX, oA);
+      A.my = row(F_MY, oA);
+      A.mr = row(F_MR, oA);
+      A.mg = row(F_MG, oA);
+      A.mb = row(F_MB, oA);
+      Bq.mx = row(F_MX, oB);
+      Bq.my = row(F_MY, oB);
+      Bq.mr = row(F_MR, oB);
+      Bq.mg = row(F_MG, oB);
+      Bq.mb = row(F_MB, oB);
+    }
+    {
+      int* ccount = lds.ccount(smem);
+      unsigned long long* best = lds.best(smem);
+      for (int t = tid; t < B; t += kRegsThreads) {
+        ccount[t] = 0;
+        best[t] = 0ull;
+      }
+      if (tid == 0) {
+        int* qn = lds.qn(smem);
+        qn[0] = 0;
+        qn[1] = 0;
+        wg_flag = 0;
+      }
+    }
+    lds_barrier();
+    // ---- 2. gates -------------------------------------------------------------------------------------
+    unsigned pA01 = 0xFFFFFFFFu, pA23 = 0xFFFFFFFFu, pB01 = 0xFFFFFFFFu, pB23 = 0xFFFFFFFFu;
+    double pseA = 0.0, pseB = 0.0;
+    {
+      RegsArgsPtr R = regs_args_now(rp);
+      const BlobGrid g = regs_blob_grid(R);
+      const double* exact = R->f.exact;
+      const double sh = R->h[p];
+      if (hasA) {
+        const RegsGated r = regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh);
+        pA01 = r.pass01;
+        pA23 = r.pass23;
+        pseA = r.pse;
+      }
+      // the first landmark's covariance rows: requested here, behind its gates (the offset is made to depend on
+      // their result: the requests cannot be moved up), they arrive while the second landmark's gates are worked out
+      unsigned oA2 = oA;
+      asm volatile("" : "+v"(oA2) : "v"(pA01));
+      A.pxx = row(F_PXX, oA2);
+      A.pxy = row(F_PXY, oA2);
+      A.pyy = row(F_PYY, oA2);
+      A.crr = row(F_CRR, oA2);
+      A.crg = row(F_CRG, oA2);
+      A.crb = row(F_CRB, oA2);
+      A.cgg = row(F_CGG, oA2);
+      A.cgb = row(F_CGB, oA2);
+      A.cbb = row(F_CBB, oA2);
+      A.count = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sc) + (oA2 >> 1));
+      if (hasB) {
+        const RegsGated r = regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh);
+        pB01 = r.pass01;
+        pB23 = r.pass23;
+        pseB = r.pse;
+      }
+    }
+    lds_barrier();
+    // ---- 3. flagged particles go the general way (nothing has been written) ------------------------------
+    if (wg_flag) {  // workgroup-uniform
+      if (tid == 0) {
+        RegsArgsPtr R = regs_args_now(rp);
+        R->pflag_out[p] = 1;
+        atomicAdd(R->n_flagged, 1u);
+      }
+      lds_barrier();  // everybody has read the flag before the next particle clears it
+      continue;
+    }
+    {  // the next particle's map slot: one dword per 128-byte line, so that the lines wait in L2
+      RegsArgsPtr R = regs_args_now(rp);
+      const int warm = R->warm;
+      if (warm != 0 && p + gridDim.x < R->P) {
+        const SlotSource ss = regs_slot_source(R);
+        const size_t warm_lines = warm >= 2 ? ss.slot_bytes >> 7 : ((size_t)5 * Lp * 8 + 127) >> 7;  // slot_bytes: a multiple of 256
+        const unsigned char* nslot = ss.at(R->f.src[p + gridDim.x]);
+        for (size_t i = (size_t)tid; i < warm_lines; i += kRegsThreads)
+          // (address spaces spelled out: through generic pointers the builtin is accepted but M0, the LDS base of
+          // the transfer, is never set)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned*)(nslot + (i << 7)),
+                                           (__attribute__((address_space(3))) unsigned*)warm_dump, 4, 0, 0);
+      }
+    }
+    // ---- 4. settling: one round per landmark of the lane -----------------------------------------------------
+    int nun = 0;  // blobs no landmark passes
+    {
+      const int* ccount = lds.ccount(smem);
+      for (int t = tid; t < B; t += kRegsThreads) nun += ccount[t] == 0;
+    }
+    unsigned qA01, qA23, qB01, qB23;
+    {
+      RegsArgsPtr R = regs_args_now(rp);
+      FastSlot sl[kFastSlots];
+      const FastQueue fq = lds.queue(smem, lds.qn(smem));
+      fast_prepare<false, int, kRegsQueue>(ra_unused.f, R->f.exact, A, sx, sy, pseA, hasA ? make_uint2(pA01, pA23) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), lds.ccount(smem), lds.best(smem), fq, sl);
+      regs_pack(sl, qA01, qA23);
+      // the second landmark's covariance rows: requested here (the offset depends on the first round's result:
+      // the requests cannot be moved up), they arrive while the first round's queue is evaluated
+      unsigned oB2 = oB;
+      asm volatile("" : "+v"(oB2) : "v"(qA01));
+      Bq.pxx = row(F_PXX, oB2);
+      Bq.pxy = row(F_PXY, oB2);
+      Bq.pyy = row(F_PYY, oB2);
+      Bq.crr = row(F_CRR, oB2);
+      Bq.crg = row(F_CRG, oB2);
+      Bq.crb = row(F_CRB, oB2);
+      Bq.cgg = row(F_CGG, oB2);
+      Bq.cgb = row(F_CGB, oB2);
+      Bq.cbb = row(F_CBB, oB2);
+      Bq.count = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sc) + (oB2 >> 1));
+    }
+    lds_barrier();
+    const int nA = lds.qn(smem)[0];
+    regs_evaluate_queue<kRegsThreads / kWave>(lds.queue(smem, nullptr), min(nA, kRegsQueue), lds.results(smem), lds.best(smem), tid);
+    lds_barrier();
+    {
+      RegsArgsPtr R = regs_args_now(rp);
+      FastSlot sl[kFastSlots];
+      const FastQueue fq = lds.queue(smem, lds.qn(smem) + 1);
+      fast_prepare<false, int, kRegsQueue>(ra_unused.f, R->f.exact, Bq, sx, sy, pseB, hasB ? make_uint2(pB01, pB23) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), lds.ccount(smem), lds.best(smem), fq, sl);
+#pragma unroll
+      for (int k = 0; k < kFastSlots; ++k)
+        if (sl[k].qf >> 4) sl[k].qf += (unsigned)kRegsQueue << 4;  // the second round's results live behind the first's
+      regs_pack(sl, qB01, qB23);
+    }
+    lds_barrier();
+    const int nB = lds.qn(smem)[1];
+    // more probabilities wanted in a round than the queue holds (dense clusters of look-alike landmarks):
+    // nothing has been written yet, the general kernels take the particle
+    if (nA > kRegsQueue || nB > kRegsQueue) {  // workgroup-uniform
+      if (tid == 0) {
+        RegsArgsPtr R = regs_args_now(rp);
+        R->pflag_out[p] = 1;
+        atomicAdd(R->n_flagged, 1u);
+      }
+      lds_barrier();
+      continue;
+    }
+    // which of the lane's blobs are contested (the counts then make room for the bids: win aliases ccount)
+    unsigned cont = 0u;
+    {
+      const int* ccount = lds.ccount(smem);
+      int j = 0;
+      for (int t = tid; t < B; t += kRegsThreads, ++j) cont |= (ccount[t] >= 2 ? 1u : 0u) << j;
+    }
+    regs_evaluate_queue<kRegsThreads / kWave>(lds.queue(smem, nullptr), nB, lds.results(smem) + kRegsQueue, lds.best(smem), tid);
+    lds_barrier();  // every count has been read (fast_prepare, cont), every probability is in
+    int* win = lds.ccount(smem);
+    for (int t = tid; t < B; t += kRegsThreads) win[t] = INT_MAX;
+    if (tid == 0) regs_args_now(rp)->pflag_out[p] = 0;
+    lds_barrier();
+    {
+      FastSlot sl[kFastSlots];
+      regs_unpack(pA01, pA23, qA01, qA23, sl);
+      fast_collect(lds.results(smem), lds.best(smem), win, lA, sl);
+      regs_pack(sl, qA01, qA23);
+      regs_unpack(pB01, pB23, qB01, qB23, sl);
+      fast_collect(lds.results(smem), lds.best(smem), win, lB, sl);
+      regs_pack(sl, qB01, qB23);
+    }
+    lds_barrier();
+    {
+      const unsigned long long* best = lds.best(smem);
+      int j = 0;
+      for (int t = tid; t < B; t += kRegsThreads, ++j) nun += (((cont >> j) & 1u) && best[t] == 0ull);  // contested, all 0
+    }
+    double acc = (double)nun * Consts<double>::log_no_match;
+    // ---- 5. updates in scan order, stores: the first landmark, then the second ---------------------------------
+    // (the second one's colour block waits in LDS meanwhile: the queue and its results are dead)
+    double* park = lds.park(smem);
+    park[0 * kRegsThreads + tid] = Bq.crr;
+    park[1 * kRegsThreads + tid] = Bq.crg;
+    park[2 * kRegsThreads + tid] = Bq.crb;
+    park[3 * kRegsThreads + tid] = Bq.cgg;
+    park[4 * kRegsThreads + tid] = Bq.cgb;
+    park[5 * kRegsThreads + tid] = Bq.cbb;
+    {
+      RegsArgsPtr R = regs_args_now(rp);
+      const double* exact = R->f.exact;
+      const unsigned short* order = R->f.order;
+      const Noise<double> qt = regs_noise(R);
+      unsigned char* dslot = R->f.map_dst + (size_t)p * R->f.ss.slot_bytes;
+      double* df = reinterpret_cast<double*>(dslot);
+      int* dc = reinterpret_cast<int*>(dslot + R->f.count_off);
+      Landmark<double> cur = A;
+      double pseC = pseA;
+      unsigned pc01 = pA01, pc23 = pA23, qc01 = qA01, qc23 = qA23;
+      bool immC = immA, hasC = hasA;
+      int lC = lA;
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        if (hasC) {
+          FastSlot sl[kFastSlots];
+          regs_unpack(pc01, pc23, qc01, qc23, sl);
+          acc += regs_apply(exact, order, qt, cur, lC, immC, sx, sy, pseC, sl, win);
+        }
+        if (lC < Lp) {
+          unsigned off = (unsigned)lC * 8u;
+          asm volatile("" : "+v"(off));
+          regs_store_landmark(df, dc, Lp, off, cur);
+        }
+        cur.mx = Bq.mx;
+        cur.my = Bq.my;
+        cur.mr = Bq.mr;
+        cur.mg = Bq.mg;
+        cur.mb = Bq.mb;
+        cur.pxx = Bq.pxx;
+        cur.pxy = Bq.pxy;
+        cur.pyy = Bq.pyy;
+        cur.count = Bq.count;
+        cur.crr = park[0 * kRegsThreads + tid];
+        cur.crg = park[1 * kRegsThreads + tid];
+        cur.crb = park[2 * kRegsThreads + tid];
+        cur.cgg = park[3 * kRegsThreads + tid];
+        cur.cgb = park[4 * kRegsThreads + tid];
+        cur.cbb = park[5 * kRegsThreads + tid];
+        pseC = pseB;
+        pc01 = pB01;
+        pc23 = pB23;
+        qc01 = qB01;
+        qc23 = qB23;
+        immC = immB;
+        hasC = hasB;
+        lC = lB;
+      }
+    }
+    const double tot = block_sum_lds_only<kRegsThreads / kWave>(acc, red, tid);  // the stores stay in flight
+    if (tid == 0) {
+      RegsArgsPtr R = regs_args_now(rp);
+      double* logw = R->f.logw;
+      const double w = (R->f.reset ? 0.0 : logw[p]) + tot;
+      logw[p] = w;
+      unsigned long long* gk = R->f.gmax_key;
+      if (gk) atomicMax(gk + (p & (kGmaxKeys - 1)), double_to_key(w));
+      R->f.src[p] = (int32_t)p;
+    }
+  }
+}
+
+void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
+                      const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                      const ObserveExtras& ex, int warm) {
+  if (d.P == 0) return;
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_regs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kMaxDynLds) != hipSuccess)
+      (void)hipGetLastError();
+  }
+  RegsArgs ra;
+  FastArgs& a = ra.f;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.lmpass = nullptr;
+  a.bcount = nullptr;
+  a.pflag = nullptr;
+  a.immutable = d.immutable;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
+  ra.g = grid;
+  ra.tables = tables_dev;
+  ra.h = d.h[d.cur];
+  ra.pflag_out = fh.pflag;
+  ra.n_flagged = fh.n_flagged;
+  ra.n9 = n9;
+  ra.warm = warm;
+  ra.P = d.P;
+  const size_t lds = regs_lds_bytes(grid.ncell, B, n9);
+  // persistent grid: the workgroups that are resident at once (one per CU: 1024 lanes x 128 VGPRs)
+  static int per_cu = 0, n_cu = 0;
+  if (per_cu == 0) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_step_regs), kRegsThreads, lds) != hipSuccess ||
+        per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 1;
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    else
+      n_cu = 256;
+    (void)hipGetLastError();
+  }
+  int64_t grid_n = (int64_t)n_cu * per_cu;
+  if (grid_n > d.P) grid_n = d.P;
+  hipLaunchKernelGGL(k_step_regs, dim3((unsigned)grid_n), dim3(kRegsThreads), lds, s, ra);
 }
 
 }  // namespace pk

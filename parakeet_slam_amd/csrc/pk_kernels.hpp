@@ -151,6 +151,13 @@ constexpr size_t kFusedMaxLds = 78 * 1024;
 void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
                        const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex);
+// The same for 512 < L <= kRegsMaxL: persistent 1024-lane workgroups, a particle's whole map in registers (two
+// landmarks per lane), state read once; warm: how much of the next particle's slot is pulled into L2 ahead of time.
+constexpr int kRegsMaxL = 2048;
+size_t regs_lds_bytes(int ncell, int B, int n9);
+void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
+                      const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
+                      const ObserveExtras& ex, int warm);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued

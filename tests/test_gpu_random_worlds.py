@@ -20,10 +20,12 @@ def random_spd(rs, n, scale):
     return (q * ev) @ q.T
 
 
-def random_case(seed):
+def random_case(seed, L=None, P=None):
     rs = np.random.RandomState(seed)
-    L = int(rs.choice([1, 2, 3, 9, 33, 64, 130, 257, 400, 512, 513, 640]))
-    P = int(rs.choice([1, 5, 17, 40]))
+    L0 = int(rs.choice([1, 2, 3, 9, 33, 64, 130, 257, 400, 512, 513, 640]))
+    P0 = int(rs.choice([1, 5, 17, 40]))
+    L = L0 if L is None else L
+    P = P0 if P is None else P
     means = np.empty((L, 5))
     phi = rs.uniform(-np.pi, np.pi, L)
     rho = rs.uniform(4.0, 30.0, L)
@@ -81,20 +83,48 @@ def test_random_world_all_routes(lib, seed):
     o.observe(blobs)
     routes = {
         "default": {},
-        "two_kernel": {"fused_step": 0},
+        "two_kernel": {"fused_step": 0, "regs_step": 0},
         "sweep4": {"fast_observe": 2},
         "sweep8": {"fast_observe": 3},
         "general": {"fast_observe": 0},
         "general_brute": {"fast_observe": 0, "assoc_kernel": 1},
     }
     got = {name: device_state(lib, case, opts) for name, opts in routes.items()}
-    assert got["default"][2] == ("ml_fused" if L <= 512 else "ml_sweep")
+    assert got["default"][2] == ("ml_fused" if L <= 512 else "ml_regs")
+    assert got["two_kernel"][2] == ("ml_handoff" if L <= 512 else "ml_sweep")
     assert got["general"][2] == "ml_general"
     for name, (logw, (m, c, k), _) in got.items():
         assert np.allclose(logw, o.logw, rtol=1e-10, atol=1e-9), name  # log domain: the weights themselves underflow
         assert np.allclose(m, o.mean, rtol=1e-9, atol=1e-11), name
         assert np.allclose(c, o.cov, rtol=1e-8, atol=1e-13), name
         assert np.array_equal(k, o.count), name
+
+
+@pytest.mark.parametrize("seed,L,P", [(0, 700, 5), (1, 1024, 3), (2, 1025, 3), (3, 1500, 3), (4, 2048, 2), (5, 2000, 2)])
+def test_random_world_large_maps_one_pass_route(lib, seed, L, P):
+    """The same random worlds at map sizes of the one-pass register-resident route (k_step_regs, 512 < L <= 2048):
+    one pass, two sweeps, general kernels -- all against the oracle, and the maps of the one-pass and the
+    two-sweep routes bit for bit (same device functions)."""
+    case = random_case(7000 + seed, L=L, P=P)
+    L, P, means, covs, immutable, poses, blobs, qt = case
+    o = OracleFilter(P, means, covs, immutable)
+    o.Qt = qt.copy()
+    o.x, o.y, o.h = poses[:, 0].copy(), poses[:, 1].copy(), poses[:, 2].copy()
+    o.logw = np.log(poses[:, 3])
+    o.observe(blobs)
+    routes = {"default": {}, "sweep": {"regs_step": 0}, "general": {"fast_observe": 0}}
+    got = {name: device_state(lib, case, opts) for name, opts in routes.items()}
+    # the one-pass route needs the scan tables AND its probability queue in LDS (about 2 000 blobs, depending on
+    # how the colours fill the grid); larger scans take the two-sweep route
+    assert got["default"][2] in ("ml_regs", "ml_sweep") and (len(blobs) > 1800 or got["default"][2] == "ml_regs")
+    assert got["sweep"][2] == "ml_sweep"
+    for name, (logw, (m, c, k), _) in got.items():
+        assert np.allclose(logw, o.logw, rtol=1e-10, atol=1e-9), name
+        assert np.allclose(m, o.mean, rtol=1e-9, atol=1e-11), name
+        assert np.allclose(c, o.cov, rtol=1e-8, atol=1e-13), name
+        assert np.array_equal(k, o.count), name
+    for x, y in zip(got["default"][1], got["sweep"][1]):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("seed", range(8))
