@@ -20,7 +20,7 @@
 using namespace pk;
 
 #ifdef PK_STAMPS
-namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); void debug_read_fused_stamps(unsigned long long* out, bool reset); }
+namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); void debug_read_fused_stamps(unsigned long long* out, bool reset); void debug_read_regs_stamps(unsigned long long* out, bool reset); }
 #endif
 
 namespace {
@@ -1616,6 +1616,7 @@ int pk_probe(int32_t device, const double pose[3], const double mean[5], const d
 __attribute__((visibility("default"))) int pk_debug_stamps(unsigned long long* out, int reset) {
   pk::debug_read_stamps(out, reset != 0);            // out[0..15]: k_assoc_grid
   pk::debug_read_fused_stamps(out + 16, reset != 0);  // out[16..31]: k_step_fused
+  pk::debug_read_regs_stamps(out + 32, reset != 0);   // out[32..47]: k_step_regs
   return PK_OK;
 }
 #endif

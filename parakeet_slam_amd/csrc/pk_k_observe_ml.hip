@@ -1438,6 +1438,23 @@ struct RegsLds {
   __device__ __forceinline__ double* park(unsigned char* m) const { return reinterpret_cast<double*>(m + best_off + (size_t)B * 8); }
 };
 
+// Diagnostic build only (-DPK_STAMPS): per-phase cycle sums of k_step_regs (slots 32.. of pk_debug_stamps).
+#ifdef PK_STAMPS
+__device__ unsigned long long pk_rstamp_acc[16];
+#define PK_RSTAMP(slot, a, b) \
+  if ((threadIdx.x & 63) == 0) atomicAdd(&pk_rstamp_acc[slot], (b) - (a));
+void debug_read_regs_stamps(unsigned long long* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_rstamp_acc), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pk_rstamp_acc), z, sizeof(z));
+  }
+}
+#else
+#define PK_RSTAMP(slot, a, b)
+#endif
+
 __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kRegsThreads / kWave];
@@ -1476,6 +1493,7 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
     // (LDS addresses, row offsets, queue-entry indices ...) those values filled the register file and spilled
     int tid = tid0;
     asm volatile("" : "+v"(tid));
+    PK_STAMP(r0)
     const int lA = tid, lB = tid + kRegsThreads;
     const bool hasA = lA < L, hasB = lB < L;
     // byte offsets of the lane's two landmarks inside a row: the only per-lane part of the 30 addresses (row
@@ -1523,8 +1541,12 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
         wg_flag = 0;
       }
     }
+    PK_STAMP(r1)
+    PK_RSTAMP(0, r0, r1)  // scalars, requests, zeroing
     lds_barrier();
     // ---- 2. gates -------------------------------------------------------------------------------------
+    PK_STAMP(r2)
+    PK_RSTAMP(1, r1, r2)  // barrier
     unsigned pA01 = 0xFFFFFFFFu, pA23 = 0xFFFFFFFFu, pB01 = 0xFFFFFFFFu, pB23 = 0xFFFFFFFFu;
     double pseA = 0.0, pseB = 0.0;
     {
@@ -1532,6 +1554,8 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       const BlobGrid g = regs_blob_grid(R);
       const double* exact = R->f.exact;
       const double sh = R->h[p];
+      PK_STAMP(r3)
+      PK_RSTAMP(2, r2, r3)  // gate arguments (scalar loads)
       if (hasA) {
         const RegsGated r = regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh);
         pA01 = r.pass01;
@@ -1552,14 +1576,21 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       A.cgb = row(F_CGB, oA2);
       A.cbb = row(F_CBB, oA2);
       A.count = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sc) + (oA2 >> 1));
+      PK_STAMP(r4)
+      PK_RSTAMP(3, r3, r4)  // gates of the first landmark (waits for its means)
       if (hasB) {
         const RegsGated r = regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh);
         pB01 = r.pass01;
         pB23 = r.pass23;
         pseB = r.pse;
       }
+      PK_STAMP(r5)
+      PK_RSTAMP(4, r4, r5)  // gates of the second landmark
     }
+    PK_STAMP(r6)
     lds_barrier();
+    PK_STAMP(r7)
+    PK_RSTAMP(5, r6, r7)  // barrier behind the gates
     // ---- 3. flagged particles go the general way (nothing has been written) ------------------------------
     if (wg_flag) {  // workgroup-uniform
       if (tid == 0) {
@@ -1591,6 +1622,8 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       for (int t = tid; t < B; t += kRegsThreads) nun += ccount[t] == 0;
     }
     unsigned qA01, qA23, qB01, qB23;
+    PK_STAMP(r8)
+    PK_RSTAMP(6, r7, r8)  // warming requests, count of unseen blobs
     {
       RegsArgsPtr R = regs_args_now(rp);
       FastSlot sl[kFastSlots];
@@ -1612,10 +1645,16 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       Bq.cbb = row(F_CBB, oB2);
       Bq.count = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sc) + (oB2 >> 1));
     }
+    PK_STAMP(r9)
+    PK_RSTAMP(7, r8, r9)  // first settling round: prepare (waits for the covariance rows)
     lds_barrier();
     const int nA = lds.qn(smem)[0];
+    PK_STAMP(r10)
     regs_evaluate_queue<kRegsThreads / kWave>(lds.queue(smem, nullptr), min(nA, kRegsQueue), lds.results(smem), lds.best(smem), tid);
+    PK_STAMP(r11)
+    PK_RSTAMP(8, r10, r11)  // first round: queue evaluation
     lds_barrier();
+    PK_STAMP(r12)
     {
       RegsArgsPtr R = regs_args_now(rp);
       FastSlot sl[kFastSlots];
@@ -1626,6 +1665,8 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
         if (sl[k].qf >> 4) sl[k].qf += (unsigned)kRegsQueue << 4;  // the second round's results live behind the first's
       regs_pack(sl, qB01, qB23);
     }
+    PK_STAMP(r13)
+    PK_RSTAMP(9, r12, r13)  // second round: prepare
     lds_barrier();
     const int nB = lds.qn(smem)[1];
     // more probabilities wanted in a round than the queue holds (dense clusters of look-alike landmarks):
@@ -1646,7 +1687,10 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       int j = 0;
       for (int t = tid; t < B; t += kRegsThreads, ++j) cont |= (ccount[t] >= 2 ? 1u : 0u) << j;
     }
+    PK_STAMP(r14)
     regs_evaluate_queue<kRegsThreads / kWave>(lds.queue(smem, nullptr), nB, lds.results(smem) + kRegsQueue, lds.best(smem), tid);
+    PK_STAMP(r15)
+    PK_RSTAMP(10, r14, r15)  // second round: queue evaluation
     lds_barrier();  // every count has been read (fast_prepare, cont), every probability is in
     int* win = lds.ccount(smem);
     for (int t = tid; t < B; t += kRegsThreads) win[t] = INT_MAX;
@@ -1668,6 +1712,8 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       for (int t = tid; t < B; t += kRegsThreads, ++j) nun += (((cont >> j) & 1u) && best[t] == 0ull);  // contested, all 0
     }
     double acc = (double)nun * Consts<double>::log_no_match;
+    PK_STAMP(r16)
+    PK_RSTAMP(11, r15, r16)  // bids: barriers, win, collect
     // ---- 5. updates in scan order, stores: the first landmark, then the second ---------------------------------
     // (the second one's colour block waits in LDS meanwhile: the queue and its results are dead)
     double* park = lds.park(smem);
@@ -1727,6 +1773,8 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
         lC = lB;
       }
     }
+    PK_STAMP(r17)
+    PK_RSTAMP(12, r16, r17)  // updates + stores issued
     const double tot = block_sum_lds_only<kRegsThreads / kWave>(acc, red, tid);  // the stores stay in flight
     if (tid == 0) {
       RegsArgsPtr R = regs_args_now(rp);
@@ -1737,6 +1785,12 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       if (gk) atomicMax(gk + (p & (kGmaxKeys - 1)), double_to_key(w));
       R->f.src[p] = (int32_t)p;
     }
+    PK_STAMP(r18)
+    PK_RSTAMP(13, r17, r18)  // block sum + tail
+    PK_RSTAMP(14, r0, r18)   // particle
+#ifdef PK_STAMPS
+    if (tid == 0) atomicAdd(&pk_rstamp_acc[15], (unsigned long long)(nA + nB));  // queued probabilities
+#endif
   }
 }
 

@@ -12,9 +12,12 @@ P = int(os.environ.get("ST_P", 10000)); L = int(os.environ.get("ST_L", 500))
 means, covs, scans = bench.synthetic_inputs(L, 6)
 f = _lib.DeviceFilter(P, L)
 f.upload_map(means, covs.reshape(L, 25))
+for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM"):
+    if os.environ.get(name):
+        f.set_option(name[7:].lower(), int(os.environ[name]))
 so = _lib.load()
 so.pk_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-buf = (ctypes.c_ulonglong * 32)()
+buf = (ctypes.c_ulonglong * 48)()
 for s in range(3):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
@@ -22,6 +25,16 @@ for s in range(3, 6):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
+if v[32 + 14] > 0:  # k_step_regs ran (512 < L <= 2048)
+    rn = ["scalars, requests, zeroing", "barrier", "gate arguments (scalar loads)", "gates 1st landmark (waits for means)",
+          "gates 2nd landmark", "barrier behind the gates", "warming, unseen blobs", "round 1: prepare (waits for cov rows)",
+          "round 1: queue evaluation", "round 2: prepare", "round 2: queue evaluation", "bids: barriers, win, collect",
+          "updates + stores issued", "block sum + tail", "particle", "-"]
+    life = v[32 + 14]
+    for i, n in enumerate(rn[:15]):
+        print("regs %-40s %12.4g  %5.1f%%" % (n, v[32 + i], 100 * v[32 + i] / life))
+    print("regs queued probabilities per particle: %.1f" % (v[32 + 15] / (3.0 * P)))
+    sys.exit(0)
 if v[16 + 13] > 0:  # k_step_fused ran (L <= 512)
     fn = ["tables->LDS + barrier", "wait for the means", "atan2, cell, walk", "exact gates", "barrier after gates",
           "counts + barrier", "prepare (settling)", "barrier after prepare", "queue evaluation + barrier",
