@@ -108,7 +108,7 @@ struct pk_filter {
   int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
   int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
-  int regs_warm = 2;     // k_step_regs: 0 no L2 warming of the next particle's slot, 1 mean rows, 2 whole slot
+  int regs_warm = 0;     // k_step_regs: 0 no L2 warming of the next particle's slot (default: measured slower), 1 mean rows, 2 whole slot
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
   uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
   size_t sweep_cap = 0;
