@@ -405,7 +405,7 @@ def main():
     else:
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
-    for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM"):  # tuning experiments only
+    for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_CAND_LISTS"):  # tuning experiments only
         if os.environ.get(name):
             filt.set_option(name[7:].lower(), int(os.environ[name]))
     if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only
@@ -427,6 +427,7 @@ def main():
     stride = 1 if float(P) * L >= 5e7 or K < 16 else 4
     elapsed, tm, route, one_step = timed_steps(filt, _lib, P, L, K, W, scans, ws, us, ids, barrier, stride)
     summary = filt.summary()
+    flagged = filt.observe_flagged() if hasattr(filt, "observe_flagged") else None
     # validity probe (untimed): share of the blobs of the last timed scan that the particles, as they
     # stand now, still associate with some landmark (the workload degenerates when this collapses)
     matched = None
@@ -586,6 +587,9 @@ def main():
         if known is not None:
             roof["ekf_stage"] = known
         roof["assoc_kernel_ms"] = assoc_ms / max(assoc_n, 1)
+        if flagged is not None:
+            roof["particles_sent_to_general_kernels_last_step"] = flagged[0]
+            roof["candidate_list_overflows_last_step"] = flagged[1]
         if second is not None and copy_gbs:
             second["roofline"]["copy_measured"] = copy_gbs
             second["roofline"]["frac_of_copy"] = second["roofline"]["achieved"] / copy_gbs

@@ -108,6 +108,9 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "regs_step"    = 1 (default: with "fast_observe" = 1, 512 < L <= 2048 and scan tables that fit LDS,
  *                    gates + settling + EKF update of a particle run in ONE pass, k_step_regs, with the
  *                    particle's whole map in registers) or 0 (k_assoc_grid hand-off + k_observe_sweep);
+ *   "cand_lists"   = 1 (default: k_step_regs tests each landmark against the candidate list of a reference particle
+ *                    -- k_candidates, once per scan -- instead of walking the colour grid; particles outside the
+ *                    list's margins go the general way) or 0 (grid walk);
  *   "regs_warm"    = 0..2: how much of the NEXT particle's map slot k_step_regs touches ahead of time
  *                    (0 nothing -- the default: measured slower, DESIGN.md --, 1 the mean rows, 2 the whole slot) so that it waits in L2;
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
@@ -292,6 +295,12 @@ int pk_observe_route(const pk_filter* f);
  * DISTINCT values is the number of slots the next observe launch really has to fetch.  Negative
  * values name records of a sharded adoption buffer. */
 int pk_download_sources(pk_filter* f, int32_t* src);
+/* How the last maximum-likelihood observe went (instrumentation): flagged = particles the one-pass kernels
+ * (k_step_fused / k_step_regs) handed to the general kernels (a landmark passing more blobs than it has slots, a
+ * full probability queue, a particle outside the margins of the reference particle's candidate lists);
+ * cand_overflow = landmarks of the reference particle with more candidate blobs than list slots (non-zero: the
+ * scan took the grid walk instead of the lists).  Synchronises the stream. */
+int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow);
 
 /* ---- host-side reproductions of the reference's RNG streams (no GPU needed) ------
  * numpy.random.seed(s); numpy.random.normal(0,1,n)  (legacy MT19937 + polar method), the

@@ -82,6 +82,7 @@ SIGNATURES = {
     "pk_observe_bytes": (C.c_int, [_h, C.c_int32, _lp, _lp]),
     "pk_observe_route": (C.c_int, [_h]),
     "pk_download_sources": (C.c_int, [_h, _ip]),
+    "pk_observe_flagged": (C.c_int, [_h, _lp, _lp]),
     "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_create_python": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_destroy": (C.c_int, [_h]),
@@ -330,6 +331,12 @@ class DeviceFilter(object):
     def observe_route(self):
         """Kernels the last observe / step used for association + EKF update (pk_observe_route)."""
         return self.ROUTES[int(self._lib.pk_observe_route(self._h))]
+
+    def observe_flagged(self):
+        """(particles the last ML observe handed to the general kernels, candidate-list overflows) -- pk_observe_flagged."""
+        a, b = C.c_int64(), C.c_int64()
+        check(self._lib.pk_observe_flagged(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def download_sources(self):
         """Map slot each particle's landmarks currently live in (pk_download_sources)."""

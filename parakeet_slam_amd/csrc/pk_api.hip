@@ -107,6 +107,8 @@ struct pk_filter {
   int route = PK_ROUTE_NONE;  // kernels used by the last observe
   int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
   int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
+  int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
+  uint4* cand_dev = nullptr;  // [Lp][2] candidate records
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int regs_warm = 0;     // k_step_regs: 0 no L2 warming of the next particle's slot (default: measured slower), 1 mean rows, 2 whole slot
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
@@ -513,6 +515,7 @@ int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true) {
 
 inline unsigned long long* ctl_gmax_key(pk_filter* f) { return reinterpret_cast<unsigned long long*>(f->scan_dev); }
 inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys); }
+inline unsigned* ctl_cand_over(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 4); }
 
 // Host half of the ML scan upload: blobs, ray directions, exact records and the association tables
 // are laid out in a pinned staging slot (no device work; may synchronise only to grow buffers).
@@ -785,7 +788,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1121,12 +1124,21 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     FastHandoff fh = f->fh;
     fh.n_flagged = ctl_n_flagged(f);
     fh.flags_only = true;
+    CandTable cand;
+    if (al.regs && f->cand_lists) {
+      // the reference particle's candidate lists (particle 0 of the live generation), timed with the association
+      if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 2))) return rc;
+      Span t(f, PK_T_ASSOC);
+      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f));
+      cand.rec = f->cand_dev;
+      cand.over = ctl_cand_over(f);
+    }
     {
       Span t(f, PK_T_OBSERVE);
       ObserveExtras e1 = ex;
       e1.flip = false;
       if (al.regs)
-        launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm);
+        launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand);
       else
         launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
     }
@@ -1242,6 +1254,10 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "fused_step")) {
     f->fused_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "cand_lists")) {
+    f->cand_lists = value != 0;
     return PK_OK;
   }
   if (!strcmp(name, "regs_step")) {
@@ -1654,6 +1670,19 @@ int pk_timings(pk_filter* f, double ms[PK_T_COUNT], int64_t launches[PK_T_COUNT]
   return PK_OK;
 }
 int pk_observe_route(const pk_filter* f) { return f ? f->route : PK_ROUTE_NONE; }
+int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_observe_flagged: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  unsigned w[2] = {0u, 0u};
+  if (f->scan_dev && f->route != PK_ROUTE_NONE && f->route != PK_ROUTE_KNOWN_IDS) {
+    PK_HIP(hipMemcpyAsync(w, ctl_n_flagged(f), sizeof(w), hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+  }
+  if (flagged) *flagged = w[0];
+  if (cand_overflow) *cand_overflow = w[1];
+  return PK_OK;
+}
 int pk_download_sources(pk_filter* f, int32_t* src) {
   if (!f || !src) return fail(PK_ERR_INVALID, "pk_download_sources: NULL argument");
   int rc;

@@ -634,4 +634,92 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   }
 }
 
+// ------------------------------------------------------------------ K2' candidate lists from a reference particle
+// See pk_kernels.hpp (CandTable).  A workgroup takes 64 landmarks of the reference particle; its four waves share the
+// scan's blobs (uniform reads of the exact records), candidates are appended per landmark through LDS atomics.
+struct CandArgs {
+  SlotSource ss;
+  const int32_t* src;
+  const double *x, *y, *h;
+  const double* exact;  // [B][6] in cell order: bearing, r, g, b, ux, uy
+  uint4* rec;           // [Lp][2]
+  unsigned* over;
+  int64_t ref;
+  int L, Lp, B;
+};
+
+__global__ void __launch_bounds__(256) k_candidates(CandArgs a) {
+  __shared__ unsigned short s_c[64][kCandSlots];
+  __shared__ int s_n[64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int l = blockIdx.x * 64 + lane;
+  const unsigned char* slot = a.ss.at(a.src[a.ref]);
+  const double* f = reinterpret_cast<const double*>(slot);
+  const double sx = a.x[a.ref], sy = a.y[a.ref], sh = a.h[a.ref];
+  float ebf = 0.f, rf = 0.f, gf = 0.f, bf = 0.f;
+  const bool has = l < a.L;
+  if (has) {
+    const double mx = f[(size_t)F_MX * a.Lp + l], my = f[(size_t)F_MY * a.Lp + l];
+    ebf = (float)(atan2(my - sy, mx - sx) - sh);  // :408 for the reference particle
+    rf = (float)f[(size_t)F_MR * a.Lp + l];
+    gf = (float)f[(size_t)F_MG * a.Lp + l];
+    bf = (float)f[(size_t)F_MB * a.Lp + l];
+  }
+  // the centres are the ROUNDED values the particles will compare themselves with
+  const double cb = (double)ebf, cr = (double)rf, cg = (double)gf, cc = (double)bf;
+  const double tb = 0.5 + kCandBearing + 1e-9;
+  const double rad = 17.320508075688775 + 1.7320508075688773 * kCandColour + 1e-6;  // sqrt(300) + sqrt(3) margin
+  const double tc = rad * rad;
+  if (w == 0) s_n[lane] = 0;
+  __syncthreads();
+  const int chunk = (a.B + 3) / 4;
+  const int t1 = min(a.B, (w + 1) * chunk);
+  for (int t = w * chunk; t < t1; ++t) {  // wave-uniform: the records come through the scalar cache
+    const double* rec = a.exact + 6 * (size_t)t;
+    const double zb = rec[0], zr = rec[1], zg = rec[2], zc = rec[3];
+    const double dr = zr - cr, dg = zg - cg, dc = zc - cc;
+    // NaN / inf in the reference's state fail both tests: no candidates, and every particle near such a state
+    // breaks the margin test (comparisons with NaN are false) and goes the general way
+    // the expected bearing is not wrapped (:416-423 are commented out in the reference): particles on the other side
+    // of atan2's branch cut for this landmark, or of the heading wrap, sit 2 pi away from the reference -- their
+    // blobs are listed as well
+    const double db = zb - cb;
+    const bool near = fabs(db) <= tb || fabs(db - Consts<double>::two_pi) <= tb || fabs(db + Consts<double>::two_pi) <= tb;
+    if (has && near && dr * dr + dg * dg + dc * dc <= tc) {
+      const int n = atomicAdd(&s_n[lane], 1);
+      if (n < kCandSlots) s_c[lane][n] = (unsigned short)t;
+    }
+  }
+  __syncthreads();
+  if (w == 0 && l < a.Lp) {
+    const int n = has ? s_n[lane] : 0;
+    unsigned short c[kCandSlots];
+#pragma unroll
+    for (int k = 0; k < kCandSlots; ++k) c[k] = k < n ? s_c[lane][k] : (unsigned short)0xFFFF;
+    a.rec[2 * (size_t)l] = make_uint4(__float_as_uint(ebf), __float_as_uint(rf), __float_as_uint(gf), __float_as_uint(bf));
+    a.rec[2 * (size_t)l + 1] = make_uint4((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16),
+                                          (unsigned)c[4] | ((unsigned)c[5] << 16), (unsigned)c[6] | ((unsigned)c[7] << 16));
+    if (n > kCandSlots) atomicAdd(a.over, 1u);
+  }
+}
+
+void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
+                       unsigned* over_dev) {
+  if (d.P == 0 || d.lay.Lp == 0) return;
+  CandArgs a;
+  a.ss = slot_source(d);
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.h = d.h[d.cur];
+  a.exact = exact_dev;
+  a.rec = rec_dev;
+  a.over = over_dev;
+  a.ref = ref_particle;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  hipLaunchKernelGGL(k_candidates, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(256), 0, s, a);
+}
+
 }  // namespace pk

@@ -1165,6 +1165,8 @@ struct RegsArgs {
   int n9;
   int warm;                     // 0: no L2 warming of the next particle's slot, 1: mean rows, 2: whole slot
   int64_t P;
+  const uint4* cand;            // candidate lists of the reference particle (CandTable), or NULL
+  const unsigned* cand_over;    // != 0: the lists overflowed, this scan takes the grid walk
 };
 
 // LDS: tables | ccount int[B] (later: win) | best u64[B] | queue inputs 36 B x kRegsQueue | results u64[2 kRegsQueue] | counters
@@ -1172,6 +1174,11 @@ struct RegsArgs {
 size_t regs_lds_bytes(int ncell, int B, int n9) {
   size_t tab = (grid_cs_bytes(ncell) + (size_t)B * 16 + (size_t)n9 * 2 + 15) & ~(size_t)15;
   return tab + (((size_t)B * 4 + 15) & ~(size_t)15) + (size_t)B * 8 + (size_t)kRegsQueue * 36 + (size_t)kRegsQueue * 16 + 32;
+}
+
+// LDS of the candidate-list instance: the candidate records (32 B per landmark) stand where the grid tables stood
+size_t regs_cand_lds_bytes(int Lp, int B) {
+  return (size_t)Lp * 32 + (((size_t)B * 4 + 15) & ~(size_t)15) + (size_t)B * 8 + (size_t)kRegsQueue * 36 + (size_t)kRegsQueue * 16 + 32;
 }
 
 // Gates of one landmark (prkt_core_v2.py:433, :441) against the scan tables in LDS: the same walk as in
@@ -1270,6 +1277,54 @@ __device__ __forceinline__ RegsGated regs_gates(const BlobGrid& g, const unsigne
     }
   }
   if (npass > kFastSlots) *wg_flag = 1;
+  return RegsGated{pass01, pass23, pse};
+}
+
+// Gates of one landmark against the reference particle's candidate list (pk_kernels.hpp, CandTable): the landmark's
+// expected bearing and colour must lie within the margins of the reference's -- else the particle is flagged for the
+// general kernels -- and then only the listed blobs can pass: exact float64 gates on those, two records per L2 round trip.
+__device__ __forceinline__ RegsGated regs_gates_cand(uint4 ref, uint4 cands, const double* exact, int* ccount, int* wg_flag,
+                                                     double mx, double my, double mr, double mg, double mb, double sx,
+                                                     double sy, double sh) {
+  unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;
+  const double pse = atan2(my - sy, mx - sx);
+  const double eb = pse - sh;  // :408
+  // (written so that a NaN anywhere breaks the margin)
+  const double deb = eb - (double)__uint_as_float(ref.x);  // 2 pi off: the other side of a branch cut, listed too (k_candidates)
+  const bool inside = (fabs(deb) <= kCandBearing || fabs(deb - Consts<double>::two_pi) <= kCandBearing ||
+                       fabs(deb + Consts<double>::two_pi) <= kCandBearing) &&
+                      fabs(mr - (double)__uint_as_float(ref.y)) <= kCandColour &&
+                      fabs(mg - (double)__uint_as_float(ref.z)) <= kCandColour && fabs(mb - (double)__uint_as_float(ref.w)) <= kCandColour;
+  int npass = 0;
+  auto exact_gates = [&](int tt, const double2& z01, const double2& z23) {
+    if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
+      atomicAdd(&ccount[tt], 1);
+      if (npass == 0) pass01 = (pass01 & 0xFFFF0000u) | (unsigned)tt;
+      if (npass == 1) pass01 = (pass01 & 0x0000FFFFu) | ((unsigned)tt << 16);
+      if (npass == 2) pass23 = (pass23 & 0xFFFF0000u) | (unsigned)tt;
+      if (npass == 3) pass23 = (pass23 & 0x0000FFFFu) | ((unsigned)tt << 16);
+      ++npass;
+    }
+  };
+  unsigned c0 = cands.x, c1 = cands.y, c2 = cands.z, c3 = cands.w;  // the list is filled from the front
+#pragma unroll 1
+  for (int k = 0; k < kCandSlots; k += 2) {
+    const int ta = (int)(c0 & 0xFFFFu), tb = (int)(c0 >> 16);
+    if (ta == 0xFFFF) break;
+    c0 = c1;
+    c1 = c2;
+    c2 = c3;
+    c3 = 0xFFFFFFFFu;
+    const double* ra = exact + 6 * (size_t)ta;
+    const double* rb = exact + 6 * (size_t)(tb == 0xFFFF ? ta : tb);
+    const double2 a01 = *reinterpret_cast<const double2*>(ra);
+    const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
+    const double2 b01 = *reinterpret_cast<const double2*>(rb);
+    const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
+    exact_gates(ta, a01, a23);
+    if (tb != 0xFFFF) exact_gates(tb, b01, b23);
+  }
+  if (!inside || npass > kFastSlots) *wg_flag = 1;
   return RegsGated{pass01, pass23, pse};
 }
 
@@ -1455,6 +1510,7 @@ void debug_read_regs_stamps(unsigned long long* out, bool reset) {
 #define PK_RSTAMP(slot, a, b)
 #endif
 
+template <bool CAND>
 __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kRegsThreads / kWave];
@@ -1468,14 +1524,19 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
   {
     const int tid = tid0;
     RegsArgsPtr R = regs_args_now(rp);
+    // which instance works on this scan: candidate lists, unless some landmark's list overflowed (workgroup-uniform)
+    {
+      const unsigned* over = R->cand_over;
+      if (CAND ? *over != 0u : (over != nullptr && *over == 0u)) return;
+    }
     lds.B = R->f.B;
-    lds.cs_bytes = (unsigned)grid_cs_bytes(R->g.ncell);
-    lds.tab_bytes = (unsigned)((lds.cs_bytes + (size_t)lds.B * 16 + (size_t)R->n9 * 2 + 15) & ~(size_t)15);
-    lds.best_off = lds.tab_bytes + (unsigned)(((size_t)lds.B * 4 + 15) & ~(size_t)15);
     Lp = R->f.Lp;
     L = R->f.L;
-    // the scan tables: once per workgroup
-    const uint4* src = reinterpret_cast<const uint4*>(R->tables);
+    lds.cs_bytes = CAND ? 0u : (unsigned)grid_cs_bytes(R->g.ncell);
+    lds.tab_bytes = CAND ? (unsigned)Lp * 32u : (unsigned)((lds.cs_bytes + (size_t)lds.B * 16 + (size_t)R->n9 * 2 + 15) & ~(size_t)15);
+    lds.best_off = lds.tab_bytes + (unsigned)(((size_t)lds.B * 4 + 15) & ~(size_t)15);
+    // the scan tables (grid walk) or the reference particle's candidate records: once per workgroup
+    const uint4* src = reinterpret_cast<const uint4*>(CAND ? reinterpret_cast<const unsigned char*>(R->cand) : R->tables);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     for (unsigned i = (unsigned)tid; i < lds.tab_bytes / 16; i += kRegsThreads) dst[i] = src[i];
     const unsigned char* imm = R->f.immutable;
@@ -1557,7 +1618,9 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       PK_STAMP(r3)
       PK_RSTAMP(2, r2, r3)  // gate arguments (scalar loads)
       if (hasA) {
-        const RegsGated r = regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh);
+        const uint4* crec = reinterpret_cast<const uint4*>(smem);
+        const RegsGated r = CAND ? regs_gates_cand(crec[2 * lA], crec[2 * lA + 1], exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh)
+                                 : regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh);
         pA01 = r.pass01;
         pA23 = r.pass23;
         pseA = r.pse;
@@ -1579,7 +1642,9 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       PK_STAMP(r4)
       PK_RSTAMP(3, r3, r4)  // gates of the first landmark (waits for its means)
       if (hasB) {
-        const RegsGated r = regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh);
+        const uint4* crec = reinterpret_cast<const uint4*>(smem);
+        const RegsGated r = CAND ? regs_gates_cand(crec[2 * lB], crec[2 * lB + 1], exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh)
+                                 : regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh);
         pB01 = r.pass01;
         pB23 = r.pass23;
         pseB = r.pse;
@@ -1796,13 +1861,12 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
 
 void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
-                      const ObserveExtras& ex, int warm) {
+                      const ObserveExtras& ex, int warm, const CandTable& cand) {
   if (d.P == 0) return;
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_regs), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kMaxDynLds) != hipSuccess)
-      (void)hipGetLastError();
+    for (const void* fn : {reinterpret_cast<const void*>(k_step_regs<false>), reinterpret_cast<const void*>(k_step_regs<true>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess) (void)hipGetLastError();
   }
   RegsArgs ra;
   FastArgs& a = ra.f;
@@ -1833,15 +1897,11 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
   ra.n9 = n9;
   ra.warm = warm;
   ra.P = d.P;
-  const size_t lds = regs_lds_bytes(grid.ncell, B, n9);
+  ra.cand = cand.rec;
+  ra.cand_over = cand.rec ? cand.over : nullptr;
   // persistent grid: the workgroups that are resident at once (one per CU: 1024 lanes x 128 VGPRs)
-  static int per_cu = 0, n_cu = 0;
-  if (per_cu == 0) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_step_regs), kRegsThreads, lds) != hipSuccess ||
-        per_cu < 1) {
-      (void)hipGetLastError();
-      per_cu = 1;
-    }
+  static int n_cu = 0;
+  if (n_cu == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1850,9 +1910,11 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
       n_cu = 256;
     (void)hipGetLastError();
   }
-  int64_t grid_n = (int64_t)n_cu * per_cu;
+  int64_t grid_n = n_cu;
   if (grid_n > d.P) grid_n = d.P;
-  hipLaunchKernelGGL(k_step_regs, dim3((unsigned)grid_n), dim3(kRegsThreads), lds, s, ra);
+  if (cand.rec)
+    hipLaunchKernelGGL(k_step_regs<true>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_cand_lds_bytes(d.lay.Lp, B), s, ra);
+  hipLaunchKernelGGL(k_step_regs<false>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_lds_bytes(grid.ncell, B, n9), s, ra);
 }
 
 }  // namespace pk

@@ -151,13 +151,36 @@ constexpr size_t kFusedMaxLds = 78 * 1024;
 void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
                        const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex);
+// Candidate lists from a reference particle (k_candidates).  All particles of a filter see the same scan and hold
+// nearly the same map (same initial map, same blobs matched), so the blobs that can pass a landmark's two gates
+// (prkt_core_v2.py:433, :441) are nearly the same for every particle.  Once per scan, for every landmark of ONE
+// reference particle, the blobs within the gates WIDENED by (kCandBearing, kCandColour) are listed; a particle whose
+// own expected bearing and colour of that landmark lie within those margins of the reference's can only match blobs of
+// that list (triangle inequality), and tests them with the exact float64 gates -- no walk through the colour grid.
+// The expected bearing is unwrapped in the reference (:408-423), so "within the margin" is taken modulo one turn of
+// 2 pi either way, and the list holds the blobs of all three centres.
+// A particle that breaks a margin anywhere is flagged and goes the general way; a landmark with more than kCandSlots
+// candidates switches the whole scan back to the grid walk (cand_over).  Record per landmark, 32 B:
+//   float ebref, r, g, b  |  kCandSlots x u16 blob (cell order) or 0xFFFF
+constexpr int kCandSlots = 8;
+constexpr double kCandBearing = 0.2;   // rad: |expected bearing - reference's| of every particle, else flagged (the particles' HEADING spread goes here: sigma 0.02 rad after 25 steps of the bench)
+constexpr double kCandColour = 1.5;    // per channel: |colour mean - reference's|
+struct CandTable {
+  const uint4* rec = nullptr;   // [Lp][2]
+  const unsigned* over = nullptr;  // != 0: some landmark has more candidates than slots -> grid walk for this scan
+};
+void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
+                       unsigned* over_dev);
 // The same for 512 < L <= kRegsMaxL: persistent 1024-lane workgroups, a particle's whole map in registers (two
 // landmarks per lane), state read once; warm: how much of the next particle's slot is pulled into L2 ahead of time.
 constexpr int kRegsMaxL = 2048;
 size_t regs_lds_bytes(int ncell, int B, int n9);
+size_t regs_cand_lds_bytes(int Lp, int B);
+// cand.rec != NULL: two launches -- the candidate-list instance (returns at once when *cand.over != 0) and the
+// grid-walk instance (returns at once when *cand.over == 0)
 void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
-                      const ObserveExtras& ex, int warm);
+                      const ObserveExtras& ex, int warm, const CandTable& cand = CandTable());
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued

@@ -78,6 +78,7 @@ def run_config2(lib, steps, opts, seed=7):
     pose = (0.0, 0.0, 0.0)
     hist = []
     route = None
+    flagged = []
     for s in range(steps):
         pose = truth_step(pose, 0.2, 0.1, 0.1)
         blobs = synthetic_scan(means, pose)
@@ -85,13 +86,14 @@ def run_config2(lib, steps, opts, seed=7):
         f.motion(0.2, 0.1, 0.1, seed=seed, draw=s)
         f.observe(blobs)
         route = f.observe_route()
+        flagged.append(f.observe_flagged())
         logw = f.download_log_weights()
         u = rnd.random()
         anc = f.resample(u, domain=lib.PK_WEIGHTS_LOG, return_ancestors=True)
         hist.append((logw, anc, f.summary(), pose, u))
     sel = np.r_[0:16, 50000:50016, P2 - 16:P2]
     maps = [f.download_landmarks(int(a), int(a) + 16) for a in (0, 50000, P2 - 16)]
-    out = dict(poses=f.download_poses(), maps=maps, hist=hist, route=route, sel=sel)
+    out = dict(poses=f.download_poses(), maps=maps, hist=hist, route=route, sel=sel, flagged=flagged)
     f.close()
     return out
 
@@ -104,6 +106,10 @@ def config2_default(lib):
 def test_config2_resample_properties_tracking_and_oracle_ancestors(lib, config2_default):
     out = config2_default
     assert out["route"] in ("ml_regs", "ml_sweep")
+    # the one-pass route really is the route: (nearly) no particle left to the general kernels, the reference
+    # particle's candidate lists fit their slots
+    for n_flagged, cand_over in out["flagged"]:
+        assert cand_over == 0 and n_flagged <= P2 // 100
     for logw, anc, sm, pose, u in out["hist"]:
         assert np.isfinite(logw).all()
         w = np.exp(logw - logw.max())
