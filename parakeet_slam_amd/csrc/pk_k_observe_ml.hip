@@ -1625,20 +1625,25 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
         pA23 = r.pass23;
         pseA = r.pse;
       }
-      // the first landmark's covariance rows: requested here, behind its gates (the offset is made to depend on
-      // their result: the requests cannot be moved up), they arrive while the second landmark's gates are worked out
-      unsigned oA2 = oA;
-      asm volatile("" : "+v"(oA2) : "v"(pA01));
-      A.pxx = row(F_PXX, oA2);
-      A.pxy = row(F_PXY, oA2);
-      A.pyy = row(F_PYY, oA2);
-      A.crr = row(F_CRR, oA2);
-      A.crg = row(F_CRG, oA2);
-      A.crb = row(F_CRB, oA2);
-      A.cgg = row(F_CGG, oA2);
-      A.cgb = row(F_CGB, oA2);
-      A.cbb = row(F_CBB, oA2);
-      A.count = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sc) + (oA2 >> 1));
+      // the first landmark's covariance rows.  Grid walk: requested here, behind its gates (the offset is made to depend on
+      // their result: the requests cannot be moved up), they arrive while the second landmark's gates are worked out.
+      // Candidate lists: requested behind BOTH gates -- the second landmark's gates read blob records from L2, and the
+      // vector memory counter retires in order: behind rows that come from HBM those reads would wait for the rows.
+      auto request_cov_a = [&](unsigned dep) {
+        unsigned oA2 = oA;
+        asm volatile("" : "+v"(oA2) : "v"(dep));
+        A.pxx = row(F_PXX, oA2);
+        A.pxy = row(F_PXY, oA2);
+        A.pyy = row(F_PYY, oA2);
+        A.crr = row(F_CRR, oA2);
+        A.crg = row(F_CRG, oA2);
+        A.crb = row(F_CRB, oA2);
+        A.cgg = row(F_CGG, oA2);
+        A.cgb = row(F_CGB, oA2);
+        A.cbb = row(F_CBB, oA2);
+        A.count = *reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(sc) + (oA2 >> 1));
+      };
+      if (!CAND) request_cov_a(pA01);
       PK_STAMP(r4)
       PK_RSTAMP(3, r3, r4)  // gates of the first landmark (waits for its means)
       if (hasB) {
@@ -1649,6 +1654,7 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
         pB23 = r.pass23;
         pseB = r.pse;
       }
+      if (CAND) request_cov_a(pB01);
       PK_STAMP(r5)
       PK_RSTAMP(4, r4, r5)  // gates of the second landmark
     }

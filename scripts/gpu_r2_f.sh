@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_assoc.py tests/test_gpu_random_worlds.py tests/test_gpu_fullsize.py -x -q -m gpu > gpurun_out/pytest_f.log 2>&1; rc=$?; echo "pytest rc $rc"; tail -3 gpurun_out/pytest_f.log
+if [ $rc -ne 0 ]; then tail -40 gpurun_out/pytest_f.log; exit 1; fi
+for c in 1 0 1; do
+PK_OPT_CAND_LISTS=$c timeout 300 python bench.py --no-cpu-baseline --no-secondary --no-probes --steps ${ST:-20} --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('cand=$c ms/step %.3f route %s observe %.3f assoc %.3f frac %.3f flagged %s over %s summary %r' % (d['ms_per_step'], r['route'], d['kernel_ms_per_step']['observe'], d['kernel_ms_per_step']['assoc'], r['frac'], r.get('particles_sent_to_general_kernels_last_step'), r.get('candidate_list_overflows_last_step'), d['summary']))"
+done
+ST_P=51200 ST_L=2000 timeout 300 python scripts/gpu_stamps.py
