@@ -108,6 +108,9 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "regs_step"    = 1 (default: with "fast_observe" = 1, 512 < L <= 2048 and scan tables that fit LDS,
  *                    gates + settling + EKF update of a particle run in ONE pass, k_step_regs, with the
  *                    particle's whole map in registers) or 0 (k_assoc_grid hand-off + k_observe_sweep);
+ *   "owner_step"   = 0, 1 (maps of more than 512 landmarks) or 2 (every map): k_step_owner -- candidate lists of a
+ *                    reference particle in both directions, every landmark settles its own blobs against its rivals,
+ *                    no synchronisation between the landmarks of a particle;
  *   "cand_lists"   = 1 (default: k_step_regs tests each landmark against the candidate list of a reference particle
  *                    -- k_candidates, once per scan -- instead of walking the colour grid; particles outside the
  *                    list's margins go the general way) or 0 (grid walk);
@@ -286,7 +289,9 @@ enum {
   PK_ROUTE_ML_HANDOFF = 3,   /* k_assoc_grid hand-off + k_observe_fast (L <= 512) */
   PK_ROUTE_ML_SWEEP = 4,     /* k_assoc_grid hand-off + k_observe_sweep (L > 512) */
   PK_ROUTE_ML_FUSED = 5,     /* k_step_fused: gates + settling + EKF update in one kernel (L <= 512) */
-  PK_ROUTE_ML_REGS = 6       /* k_step_regs: the same in one pass for 512 < L <= 2048, two landmarks per lane */
+  PK_ROUTE_ML_REGS = 6,      /* k_step_regs: the same in one pass for 512 < L <= 2048, two landmarks per lane */
+  PK_ROUTE_ML_OWNER = 7      /* k_step_owner: every landmark settles its own blobs against the rivals named by the
+                                reference particle's candidate lists; no synchronisation inside a particle, any L */
 };
 int pk_observe_route(const pk_filter* f);
 /* The map indirection of the live generation (instrumentation): src[P], the map slot each particle's

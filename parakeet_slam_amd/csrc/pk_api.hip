@@ -107,6 +107,10 @@ struct pk_filter {
   int route = PK_ROUTE_NONE;  // kernels used by the last observe
   int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
   int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
+  int owner_step = 0;    // k_step_owner (no synchronisation between a particle's landmarks): 0 off, 1 for L > 512, 2 for every L
+  unsigned* bcnt_dev = nullptr;  // [bcand_cap] entries of the blobs' inverse candidate lists
+  uint4* brec_dev = nullptr;     // [bcand_cap] the lists
+  int64_t bcand_cap = 0;
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
   uint4* cand_dev = nullptr;  // [Lp][2] candidate records
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
@@ -479,6 +483,7 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
 struct AssocLaunch {
   bool fused = false;  // nothing launched yet: k_step_fused does gates + EKF in one kernel
   bool regs = false;   // nothing launched yet: k_step_regs does the same for 512 < L <= 2048
+  bool owner = false;  // nothing launched yet: k_step_owner (candidate lists both ways, no barriers), any L
   BlobGrid grid{};
   int n9 = 0;
   const unsigned char* tables = nullptr;
@@ -516,6 +521,7 @@ int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true) {
 inline unsigned long long* ctl_gmax_key(pk_filter* f) { return reinterpret_cast<unsigned long long*>(f->scan_dev); }
 inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys); }
 inline unsigned* ctl_cand_over(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 4); }
+inline unsigned* ctl_n_stray(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 8); }
 
 // Host half of the ML scan upload: blobs, ray directions, exact records and the association tables
 // are laid out in a pinned staging slot (no device work; may synchronise only to grow buffers).
@@ -598,6 +604,18 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   if (use_grid) {
     FastHandoff fh{};
     const bool sweep = f->d.lay.L > kFastMaxL || f->fast_observe >= 2;
+    if (out && want_fast && !finalize && f->fast_observe == 1 && B > 0 && f->d.lay.L < 65535 &&
+        (f->owner_step == 2 || (f->owner_step == 1 && f->d.lay.L > kFastMaxL))) {
+      if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
+      out->owner = true;
+      out->grid = g;
+      out->n9 = n9;
+      out->tables = f->scan_dev + o_tab;
+      out->exact = reinterpret_cast<const double*>(f->scan_dev + o_exact);
+      const size_t cs_b = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
+      out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
+      return PK_OK;
+    }
     if (out && want_fast && !finalize && f->fast_observe == 1 && f->fused_step && !sweep && B > 0 && n9 > 0 &&
         fused_lds_bytes(g.ncell, B, n9) <= kFusedMaxLds) {
       if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
@@ -788,7 +806,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1116,11 +1134,51 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   AssocLaunch al;
   if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
   ex.gmax_key = ctl_gmax_key(f);
-  f->route = al.fused ? PK_ROUTE_ML_FUSED
+  f->route = al.owner ? PK_ROUTE_ML_OWNER
+             : al.fused ? PK_ROUTE_ML_FUSED
              : al.regs ? PK_ROUTE_ML_REGS
              : !al.fast ? PK_ROUTE_ML_GENERAL
              : (f->d.lay.L > kFastMaxL || f->fast_observe >= 2) ? PK_ROUTE_ML_SWEEP : PK_ROUTE_ML_HANDOFF;
-  if (al.fused || al.regs) {
+  if (al.owner) {
+    FastHandoff fh = f->fh;
+    fh.n_flagged = ctl_n_flagged(f);
+    fh.flags_only = true;
+    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 2))) return rc;
+    if (B > f->bcand_cap) {
+      PK_HIP(hipStreamSynchronize(f->stream));
+      if (f->bcnt_dev) (void)hipFree(f->bcnt_dev);
+      if (f->brec_dev) (void)hipFree(f->brec_dev);
+      f->bcnt_dev = nullptr;
+      f->brec_dev = nullptr;
+      f->bcand_cap = 0;
+      const int64_t cap = (int64_t)B + B / 4 + 64;
+      if ((rc = dev_alloc(f, &f->bcnt_dev, (size_t)cap))) return rc;
+      if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
+      f->bcand_cap = cap;
+    }
+    CandTable cand;
+    {
+      Span t(f, PK_T_ASSOC);  // the reference particle's candidate lists, both ways
+      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f));
+    }
+    cand.rec = f->cand_dev;
+    cand.brec = f->brec_dev;
+    cand.over = ctl_cand_over(f);
+    cand.n_stray = ctl_n_stray(f);
+    {
+      Span t(f, PK_T_OBSERVE);
+      ObserveExtras e1 = ex;
+      e1.flip = false;
+      launch_step_owner(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand);
+    }
+    // flagged particles (outside the lists' margins; every particle when a list overflowed): general kernels
+    Span t(f, PK_T_ASSOC);
+    launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fh);
+    ObserveExtras e2 = ex;
+    e2.only_flagged = f->fh.pflag;
+    e2.n_flagged = ctl_n_flagged(f);
+    launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
+  } else if (al.fused || al.regs) {
     FastHandoff fh = f->fh;
     fh.n_flagged = ctl_n_flagged(f);
     fh.flags_only = true;
@@ -1254,6 +1312,11 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "fused_step")) {
     f->fused_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "owner_step")) {
+    if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "owner_step: 0 (off), 1 (maps of more than 512 landmarks) or 2 (every map)");
+    f->owner_step = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "cand_lists")) {

@@ -644,6 +644,8 @@ struct CandArgs {
   const double* exact;  // [B][6] in cell order: bearing, r, g, b, ux, uy
   uint4* rec;           // [Lp][2]
   unsigned* over;
+  unsigned* bcnt;            // [B] entries of each blob's inverse list (cleared by the launcher), or NULL
+  unsigned short* blist;     // [B][kCandSlots] landmarks listing each blob (0xFFFF-filled by the launcher)
   int64_t ref;
   int L, Lp, B;
 };
@@ -700,13 +702,37 @@ __global__ void __launch_bounds__(256) k_candidates(CandArgs a) {
     a.rec[2 * (size_t)l + 1] = make_uint4((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16),
                                           (unsigned)c[4] | ((unsigned)c[5] << 16), (unsigned)c[6] | ((unsigned)c[7] << 16));
     if (n > kCandSlots) atomicAdd(a.over, 1u);
+    if (a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
+      for (int k = 0; k < min(n, kCandSlots); ++k) {
+        const unsigned t = s_c[lane][k];
+        const unsigned m = atomicAdd(&a.bcnt[t], 1u);
+        if (m < (unsigned)kCandSlots)
+          a.blist[(size_t)t * kCandSlots + m] = (unsigned short)l;
+        else
+          atomicAdd(a.over, 1u);
+      }
+    }
   }
 }
 
+// blobs on nobody's list: unmatched for every particle inside the margins (weight *= 0.1 each, :94-95)
+__global__ void __launch_bounds__(256) k_cand_strays(const unsigned* bcnt, int B, unsigned* n_stray) {
+  int n = 0;
+  for (int t = threadIdx.x; t < B; t += 256) n += bcnt[t] == 0u;
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, kWave);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(n_stray, (unsigned)n);
+}
+
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
-                       unsigned* over_dev) {
+                       unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev) {
   if (d.P == 0 || d.lay.Lp == 0) return;
+  if (bcnt_dev && brec_dev) {
+    (void)hipMemsetAsync(bcnt_dev, 0, (size_t)B * sizeof(unsigned), s);
+    (void)hipMemsetAsync(brec_dev, 0xFF, (size_t)B * sizeof(uint4), s);
+  }
   CandArgs a;
+  a.bcnt = brec_dev ? bcnt_dev : nullptr;
+  a.blist = reinterpret_cast<unsigned short*>(brec_dev);
   a.ss = slot_source(d);
   a.src = d.src[d.cur];
   a.x = d.x[d.cur];
@@ -720,6 +746,7 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.Lp = d.lay.Lp;
   a.B = B;
   hipLaunchKernelGGL(k_candidates, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(256), 0, s, a);
+  if (a.bcnt && stray_dev) hipLaunchKernelGGL(k_cand_strays, dim3(1), dim3(256), 0, s, a.bcnt, B, stray_dev);
 }
 
 }  // namespace pk

@@ -48,16 +48,6 @@ struct FastSlot {
   unsigned long long bits;  // in-place evaluation only (queue full): probability bits of a contested candidate
 };
 
-// probability_of_match (:439-455) from the determinants and the Mahalanobis terms' numerators
-// (maha = num / det: e' adj(P) e and d' adj(C) d -- the divisions are made here, for the few pairs
-// whose probability VALUE is needed, not in the code every lane runs)
-__device__ __forceinline__ double pr_from_parts(double det2, double det3, double num2, double num3) {
-  const double maha2 = num2 / det2, maha3 = num3 / det3;
-  const double bp = 500.0 * exp(-0.5 * (2.0 * Consts<double>::log_two_pi + log_few_ulp(det2) + maha2));  // :439
-  const double cp = 500.0 * exp(-0.5 * (3.0 * Consts<double>::log_two_pi + log_few_ulp(det3) + maha3));  // :446
-  return bp * cp / 250000.0;                                                                              // :455
-}
-
 // The few (landmark, blob) pairs whose probability VALUE is needed -- contested blobs, and pairs
 // too close to the float64 underflow edge to call positive without evaluating -- are queued in
 // LDS and evaluated densely by the first lanes of the workgroup (two log + two exp each), instead

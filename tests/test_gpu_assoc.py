@@ -170,10 +170,11 @@ def test_observe_with_both_kernels_gives_identical_state(lib):
 
 
 # ---------------------------------------------------------------- fast hand-off path (L <= 512)
-def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1, fused=1):
+def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1, fused=1, owner=0, want_flagged=False):
     L = means.shape[0]
     f = lib.DeviceFilter(P, L)
     f.set_option("fast_observe", fast)
+    f.set_option("owner_step", owner)  # 2: k_step_owner for every map size
     f.set_option("assoc_dup", dup)
     f.set_option("fused_step", fused)
     f.set_option("regs_step", fused)  # "one kernel": k_step_fused (L <= 512) / k_step_regs (L <= 2048); 0: hand-off + second kernel
@@ -181,6 +182,8 @@ def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1
     f.upload_poses(poses)
     f.observe(blobs)  # no ids requested: the production route
     out = (f.download_poses(), f.download_landmarks())
+    if want_flagged:
+        out = out + (f.observe_flagged(), f.observe_route())
     f.close()
     return out
 
@@ -207,7 +210,11 @@ def check_fast(lib, P, means, covs, poses, blobs, immutable=None):
     gen = observe_state(lib, P, means, covs, poses, blobs, 0, immutable)
     sweep = observe_state(lib, P, means, covs, poses, blobs, 2, immutable)
     sweep8 = observe_state(lib, P, means, covs, poses, blobs, 3, immutable)
+    own = observe_state(lib, P, means, covs, poses, blobs, 1, immutable, owner=2)  # k_step_owner (+ general kernels for flagged particles)
     o = oracle_state(P, means, covs, poses, blobs, immutable)
+    assert np.array_equal(own[0][:, :3], gen[0][:, :3]) and np.allclose(own[0][:, 3], gen[0][:, 3], rtol=1e-11, atol=0)
+    for x, y in zip(own[1], gen[1]):
+        assert np.array_equal(x, y)  # same device functions on the same inputs: the maps agree bit for bit
     for sw in (sweep, sweep8):
         assert np.allclose(sw[0], gen[0], rtol=1e-11, atol=0)
         assert np.allclose(sw[1][0], gen[1][0], rtol=1e-12, atol=1e-14)
@@ -344,6 +351,38 @@ def test_sweep_observe_ties_across_chunks_keep_the_earliest(lib):
     covs = np.vstack([bcov, bcov[:50]])
     blobs = synthetic_scan(base, (0.01, 0.0, 0.0))
     check_fast(lib, 6, means, covs, rand_poses(rs, 6, 0.1), blobs)
+
+
+@pytest.mark.parametrize("L,P", [(40, 64), (500, 32), (1400, 8), (2000, 6), (3000, 4)])
+def test_owner_route_tight_cloud_settles_contested_blobs_itself(lib, L, P):
+    """Particles as close together as a filter's are after a resample (centimetres, hundredths of a radian): everyone sits
+    inside the margins of the reference particle's candidate lists, k_step_owner flags nobody, and what it decides --
+    look-alike landmarks a few bearings apart contest every seventh blob -- is what the oracle and the general kernels decide."""
+    rs = np.random.RandomState(900 + L)
+    means, covs = synthetic_world(L)
+    n = len(means[3::7])
+    means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))  # look-alikes three bearings apart: contested blobs
+    covs = covs * rs.uniform(0.5, 2.0, (L, 1, 1))
+    imm = (rs.uniform(size=L) < 0.1).astype(np.uint8)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    blobs = np.vstack([blobs, blobs[5:8] + [0.01, 1.0, -1.0, 0.5],  # second sightings
+                       np.column_stack([rs.uniform(-3, 3, 5), rs.uniform(0, 255, (5, 3))])])  # strays
+    blobs = blobs[rs.permutation(len(blobs))]
+    poses = np.zeros((P, 4))
+    poses[:, :3] = np.array([0.02, -0.01, 0.01]) + rs.normal(0, [0.02, 0.02, 0.01], (P, 3))
+    poses[:, 3] = 1.0
+    own = observe_state(lib, P, means, covs, poses, blobs, 1, imm, owner=2, want_flagged=True)
+    assert own[3] == "ml_owner"
+    if L <= 2000:  # (at 3 000 landmarks this world's look-alike groups overflow a candidate list: everybody goes the general way)
+        assert own[2] == (0, 0), "nobody flagged, no list overflow"
+    gen = observe_state(lib, P, means, covs, poses, blobs, 0, imm)
+    o = oracle_state(P, means, covs, poses, blobs, imm)
+    assert np.allclose(own[0][:, 3], o.weights(), rtol=1e-9, atol=0)
+    m, c, k = own[1]
+    assert np.allclose(m, o.mean, rtol=1e-10, atol=1e-12) and np.allclose(c, o.cov, rtol=1e-9, atol=1e-13) and np.array_equal(k, o.count)
+    assert np.allclose(own[0][:, 3], gen[0][:, 3], rtol=1e-11, atol=0)
+    for x, y in zip(own[1], gen[1]):
+        assert np.array_equal(x, y)
 
 
 def test_regs_ties_across_the_two_rounds_keep_the_earliest(lib):
