@@ -60,6 +60,9 @@ for line in open('gpurun_out/pmc_WRITE_SIZE.log'):
     if line.startswith('slot_bytes'): slot = int(line.split()[1])
 raw, out = {}, {}
 for k, v in res.items():
+    # launches that return at once (the stand-by instance of a kernel pair, the general kernels with nothing flagged) move
+    # next to nothing: they are not averaged in
+    v = {c: [y for y in x if y > 0.01 * max(x)] or x for c, x in v.items()}
     raw[k] = {c: (sum(x) / len(x), len(x)) for c, x in v.items()}
     if 'FETCH_SIZE' in raw[k] and 'WRITE_SIZE' in raw[k]:
         out[k] = (2.0 * raw[k]['FETCH_SIZE'][0] + raw[k]['WRITE_SIZE'][0]) * 1024.0
