@@ -120,15 +120,18 @@ int64_t pk_device_bytes(const pk_filter* f);
 int pk_set_option(pk_filter* f, const char* name, int64_t value);
 
 /* ---- configuration ----------------------------------------------------------
- * FastSLAM.Qt (prkt_core_v2.py:50-53), row-major 4x4.  The compact device layout
- * needs Qt = [q00] (+) [3x3 symmetric]; anything else is PK_ERR_UNSUPPORTED. */
+ * FastSLAM.Qt (prkt_core_v2.py:50-53), row-major 4x4.  Qt = [q00] (+) [3x3 symmetric] runs on the compact layout and
+ * the fast kernels; any other finite Qt (bearing-colour coupling, asymmetry) switches the filter to the dense layout and
+ * the general dense kernel (PK_ROUTE_DENSE), converting maps that are already loaded. */
 int pk_set_measurement_noise(pk_filter* f, const double Qt[16]);
 
 /* FilterParticle.load_feature_list (prkt_core_v2.py:294-299) for every particle:
  * means[L*5] (x,y,r,g,b), covs[L*25] row-major 5x5, immutable[L] = Feature.__immutable__
- * (:883; NULL = all mutable).  update_count starts at 0.  Covariances must be
- * symmetric and block-diagonal (xy 2x2 (+) rgb 3x3) -- the structure the reference's
- * update preserves -- else PK_ERR_UNSUPPORTED. */
+ * (:883; NULL = all mutable).  update_count starts at 0.  Symmetric, block-diagonal covariances
+ * (xy 2x2 (+) rgb 3x3 -- the structure the reference's update preserves) take the compact
+ * 14-row layout and the fast kernels; a map in which ANY covariance couples position and colour or is not
+ * symmetric takes the dense 30-row layout (the reference's full 5 + 25 state) and the general dense kernel
+ * (PK_ROUTE_DENSE: the reference's 4x4 / 5x4 / 5x5 algebra entry by entry, :804-833, :897-930) -- correct, slow. */
 int pk_upload_map(pk_filter* f, const double* means, const double* covs, const uint8_t* immutable);
 
 /* Poses as rows (x, y, heading, weight); weight is the linear particle weight
@@ -290,6 +293,8 @@ enum {
   PK_ROUTE_ML_SWEEP = 4,     /* k_assoc_grid hand-off + k_observe_sweep (L > 512) */
   PK_ROUTE_ML_FUSED = 5,     /* k_step_fused: gates + settling + EKF update in one kernel (L <= 512) */
   PK_ROUTE_ML_REGS = 6,      /* k_step_regs: the same in one pass for 512 < L <= 2048, two landmarks per lane */
+  PK_ROUTE_DENSE = 8,        /* k_observe_dense: the general dense path (covariances that couple position and colour, or a
+                                coupled Qt): association, 4x4 / 5x5 update and weight in one slow, general kernel */
   PK_ROUTE_ML_OWNER = 7      /* k_step_owner: every landmark settles its own blobs against the rivals named by the
                                 reference particle's candidate lists; no synchronisation inside a particle, any L */
 };

@@ -326,7 +326,7 @@ class DeviceFilter(object):
     def shard_adopt_dev(self, rank, recv_ptr, n_received):
         check(self._lib.pk_shard_adopt_dev(self._h, int(rank), C.c_void_p(recv_ptr), int(n_received)))
 
-    ROUTES = {0: "none", 1: "known_ids", 2: "ml_general", 3: "ml_handoff", 4: "ml_sweep", 5: "ml_fused", 6: "ml_regs", 7: "ml_owner"}
+    ROUTES = {0: "none", 1: "known_ids", 2: "ml_general", 3: "ml_handoff", 4: "ml_sweep", 5: "ml_fused", 6: "ml_regs", 7: "ml_owner", 8: "dense"}
 
     def observe_route(self):
         """Kernels the last observe / step used for association + EKF update (pk_observe_route)."""

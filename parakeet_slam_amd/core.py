@@ -273,9 +273,6 @@ class FilterParticle(object):
         """K = Sigma H' Q^-1 (:821-833); Qt is recovered from the caller's Q^-1."""
         Q0 = self._probe_feature(feature_id, Qt=np.zeros((4, 4)))["Q"]
         Qt = np.linalg.inv(np.asarray(Qinv, dtype=np.float64)) - Q0
-        Qt = 0.5 * (Qt + Qt.T)
-        Qt[0, 1:] = 0.0
-        Qt[1:, 0] = 0.0
         return self._probe_feature(feature_id, Qt=Qt)["K"]
 
     def importance_factor(self, bigQ, blob, pseudoblob):

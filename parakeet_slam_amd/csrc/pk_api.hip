@@ -19,6 +19,11 @@
 
 using namespace pk;
 
+extern "C" {
+int pk_download_landmarks(pk_filter* f, int64_t p0, int64_t p1, double* means, double* covs, int32_t* counts);
+int pk_upload_landmarks(pk_filter* f, int64_t p0, int64_t p1, const double* means, const double* covs, const int32_t* counts);
+}
+
 #ifdef PK_STAMPS
 namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); void debug_read_fused_stamps(unsigned long long* out, bool reset); void debug_read_regs_stamps(unsigned long long* out, bool reset); }
 #endif
@@ -70,6 +75,10 @@ struct pk_filter {
   hipStream_t stream = nullptr;
   DeviceState d{};
   NoiseD qt{0.1, 0.1, 0.0, 0.0, 0.1, 0.0, 0.1};
+  double qt16[16] = {0.1, 0, 0, 0, 0, 0.1, 0, 0, 0, 0, 0.1, 0, 0, 0, 0, 0.1};  // the same, dense (prkt_core_v2.py:50-53)
+  bool qt_dense = false;   // Qt couples bearing and colour or is not symmetric: only the dense kernels take it
+  bool dense = false;      // maps in the dense 30-row layout (pk_layout.hpp): the general dense kernels run the observes
+  std::vector<double> dense_staged;  // pk_stage_scan in dense mode: the blobs, kept on the host
   bool map_loaded = false;
   bool src_identity = true;
   int64_t nblocks = 0;  // weight-scan blocks
@@ -326,6 +335,10 @@ void pack_landmark(const MapLayout& lay, unsigned char* slot, int l, const doubl
   double* fl = reinterpret_cast<double*>(slot);
   const int Lp = lay.Lp;
   for (int i = 0; i < 5; ++i) fl[(size_t)i * Lp + l] = mean[i];
+  if (lay.fields == kDenseFields) {  // the reference's full state, entry by entry
+    for (int i = 0; i < 25; ++i) fl[(size_t)(5 + i) * Lp + l] = cov[i];
+    return;
+  }
   fl[(size_t)F_PXX * Lp + l] = cov[0];
   fl[(size_t)F_PXY * Lp + l] = 0.5 * (cov[1] + cov[5]);
   fl[(size_t)F_PYY * Lp + l] = cov[6];
@@ -342,7 +355,9 @@ void unpack_landmark(const MapLayout& lay, const unsigned char* slot, int l, dou
   const int Lp = lay.Lp;
   if (mean)
     for (int i = 0; i < 5; ++i) mean[i] = fl[(size_t)i * Lp + l];
-  if (cov) {
+  if (cov && lay.fields == kDenseFields) {
+    for (int i = 0; i < 25; ++i) cov[i] = fl[(size_t)(5 + i) * Lp + l];
+  } else if (cov) {
     for (int i = 0; i < 25; ++i) cov[i] = 0.0;
     cov[0] = fl[(size_t)F_PXX * Lp + l];
     cov[1] = cov[5] = fl[(size_t)F_PXY * Lp + l];
@@ -671,6 +686,24 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   return PK_OK;
 }
 
+// 0: fits the compact layout (block diagonal xy (+) rgb, symmetric); 1: finite but needs the dense layout
+// (xy-rgb coupling, or not symmetric); PK_ERR_INVALID: not finite.
+int classify_covariance(const double* cov, int l) {
+  double scale = 0.0;
+  for (int i = 0; i < 25; ++i) {
+    if (!std::isfinite(cov[i])) return fail(PK_ERR_INVALID, "landmark %d: covariance not finite", l + 1);
+    if (i % 6 == 0) scale = fmax(scale, fabs(cov[i]));
+  }
+  const double tol = 1e-9 * (scale > 0 ? scale : 1.0);
+  for (int i = 0; i < 2; ++i)
+    for (int j = 2; j < 5; ++j)
+      if (fabs(cov[i * 5 + j]) > 1e-14 * scale || fabs(cov[j * 5 + i]) > 1e-14 * scale) return 1;
+  for (int i = 0; i < 5; ++i)
+    for (int j = i + 1; j < 5; ++j)
+      if (fabs(cov[i * 5 + j] - cov[j * 5 + i]) > tol) return 1;
+  return 0;
+}
+
 // The compact layout stores Sigma = Pxy (+) C: reject anything else loudly.
 int check_block_diagonal(const double* cov, int l) {
   double scale = 0.0;
@@ -691,6 +724,60 @@ int check_block_diagonal(const double* cov, int l) {
       if (fabs(cov[i * 5 + j] - cov[j * 5 + i]) > tol)
         return fail(PK_ERR_UNSUPPORTED, "landmark %d: covariance is not symmetric", l + 1);
     }
+  return PK_OK;
+}
+
+// Switch the filter's maps between the compact (14-row) and the dense (30-row) layout.  keep: the particles' landmark
+// states survive (through the host, in chunks: a rare, slow path -- a coupled Qt set after the map, coupled covariances
+// uploaded into a compact filter); otherwise the maps are simply reallocated (pk_upload_map refills them).
+int relayout(pk_filter* f, bool dense, bool keep) {
+  if (f->dense == dense) return PK_OK;
+  int rc;
+  DeviceState& d = f->d;
+  const MapLayout old = d.lay;
+  const MapLayout neu = MapLayout::make(old.L, sizeof(double), dense ? kDenseFields : (int)F_COUNT_FIELDS);
+  const int64_t P = d.P;
+  const int L = old.L;
+  std::vector<double> means, covs;
+  std::vector<int32_t> counts;
+  if (keep && L > 0) {
+    if ((rc = materialise(f))) return rc;
+    if (!dense)  // dense -> compact drops what the compact layout cannot hold: only when nothing is coupled
+      return fail(PK_ERR_STATE, "relayout: a dense map cannot be folded back into the compact layout");
+    means.resize((size_t)P * L * 5);
+    covs.resize((size_t)P * L * 25);
+    counts.resize((size_t)P * L);
+    if ((rc = pk_download_landmarks(f, 0, P, means.data(), covs.data(), counts.data()))) return rc;
+  }
+  PK_HIP(hipStreamSynchronize(f->stream));
+  for (int i = 0; i < 2; ++i) {
+    if (d.map[i]) (void)hipFree(d.map[i]);
+    d.map[i] = nullptr;
+    f->device_bytes -= (int64_t)((size_t)P * old.slot_bytes);
+  }
+  if (f->slot_tmp) (void)hipFree(f->slot_tmp);
+  f->slot_tmp = nullptr;
+  f->device_bytes -= (int64_t)old.slot_bytes;
+  d.lay = neu;
+  f->dense = dense;
+  d.alt = nullptr;
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = dev_alloc(f, &d.map[i], (size_t)P * neu.slot_bytes))) return rc;
+    PK_HIP(hipMemsetAsync(d.map[i], 0, (size_t)P * neu.slot_bytes, f->stream));
+  }
+  if ((rc = dev_alloc(f, &f->slot_tmp, neu.slot_bytes))) return rc;
+  launch_iota(f->stream, d.src[0], P);
+  launch_iota(f->stream, d.src[1], P);
+  f->src_identity = true;
+  d.mcur = 0;
+  if (keep && L > 0) {
+    const bool was_loaded = f->map_loaded;
+    f->map_loaded = true;
+    rc = pk_upload_landmarks(f, 0, P, means.data(), covs.data(), counts.data());
+    f->map_loaded = was_loaded;
+    if (rc) return rc;
+  }
+  PK_HIP(hipStreamSynchronize(f->stream));
   return PK_OK;
 }
 
@@ -852,13 +939,19 @@ int pk_set_measurement_noise(pk_filter* f, const double Qt[16]) {
     if (!std::isfinite(Qt[i])) return fail(PK_ERR_INVALID, "Qt is not finite");
   double scale = 0;
   for (int i = 0; i < 4; ++i) scale = fmax(scale, fabs(Qt[i * 5]));
+  // Qt = [q00] (+) symmetric 3x3 is what the compact layout and the fast kernels take; anything else (bearing-colour
+  // coupling, asymmetry -- the reference accepts any 4x4, prkt_core_v2.py:50-53, :817-818) needs the dense kernels
+  bool coupled = false;
   for (int j = 1; j < 4; ++j)
-    if (fabs(Qt[j]) > 1e-14 * scale || fabs(Qt[j * 4]) > 1e-14 * scale)
-      return fail(PK_ERR_UNSUPPORTED, "Qt couples bearing and colour; the compact device layout needs Qt = [q00] (+) 3x3");
+    if (fabs(Qt[j]) > 1e-14 * scale || fabs(Qt[j * 4]) > 1e-14 * scale) coupled = true;
   for (int i = 1; i < 4; ++i)
     for (int j = i + 1; j < 4; ++j)
-      if (fabs(Qt[i * 4 + j] - Qt[j * 4 + i]) > 1e-9 * (scale > 0 ? scale : 1.0))
-        return fail(PK_ERR_UNSUPPORTED, "Qt is not symmetric");
+      if (fabs(Qt[i * 4 + j] - Qt[j * 4 + i]) > 1e-9 * (scale > 0 ? scale : 1.0)) coupled = true;
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (coupled && !f->dense && (rc = relayout(f, true, f->map_loaded))) return rc;
+  for (int i = 0; i < 16; ++i) f->qt16[i] = Qt[i];
+  f->qt_dense = coupled;
   f->qt = NoiseD{Qt[0], Qt[5], 0.5 * (Qt[6] + Qt[9]), 0.5 * (Qt[7] + Qt[13]), Qt[10], 0.5 * (Qt[11] + Qt[14]), Qt[15]};
   return PK_OK;
 }
@@ -870,11 +963,15 @@ int pk_upload_map(pk_filter* f, const double* means, const double* covs, const u
   if (L > 0 && (!means || !covs)) return fail(PK_ERR_INVALID, "pk_upload_map: NULL means/covs");
   int rc;
   if ((rc = use_device(f))) return rc;
+  bool need_dense = f->qt_dense;
   for (int l = 0; l < L; ++l) {
     for (int i = 0; i < 5; ++i)
       if (!std::isfinite(means[l * 5 + i])) return fail(PK_ERR_INVALID, "landmark %d: mean is not finite", l + 1);
-    if ((rc = check_block_diagonal(covs + (size_t)l * 25, l))) return rc;
+    const int c = classify_covariance(covs + (size_t)l * 25, l);
+    if (c < 0) return c;
+    need_dense |= c == 1;  // xy-rgb coupling or asymmetry: the whole filter takes the dense layout and kernels
   }
+  if ((rc = relayout(f, need_dense, false))) return rc;  // (lay refers to f->d.lay: the new layout from here on)
   std::vector<unsigned char> slot(lay.slot_bytes, 0);
   std::vector<unsigned char> imm((size_t)lay.Lp, 0);
   for (int l = 0; l < L; ++l) {
@@ -983,9 +1080,15 @@ int pk_upload_landmarks(pk_filter* f, int64_t p0, int64_t p1, const double* mean
   if ((rc = materialise(f))) return rc;
   const MapLayout& lay = f->d.lay;
   const int L = lay.L;
-  if (covs)
-    for (int64_t o = 0; o < (p1 - p0) * L; ++o)
-      if ((rc = check_block_diagonal(covs + (size_t)o * 25, (int)(o % L)))) return rc;
+  if (covs && !f->dense) {
+    bool need_dense = false;
+    for (int64_t o = 0; o < (p1 - p0) * L; ++o) {
+      const int c = classify_covariance(covs + (size_t)o * 25, (int)(o % L));
+      if (c < 0) return c;
+      need_dense |= c == 1;
+    }
+    if (need_dense && (rc = relayout(f, true, true))) return rc;
+  }
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)lay.slot_bytes);
   std::vector<unsigned char> host((size_t)std::min<int64_t>(chunk, p1 - p0) * lay.slot_bytes);
   for (int64_t q0 = p0; q0 < p1; q0 += chunk) {
@@ -1060,6 +1163,63 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
   return PK_OK;
 }
 
+// The dense path (maps with xy-rgb coupling or a coupled Qt): one general kernel does association (or takes the ids),
+// EKF updates and weights.  update = false: association only.
+static int dense_observe(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out, bool reset,
+                         bool update) {
+  int rc;
+  const MapLayout& lay = f->d.lay;
+  f->staged.valid = false;
+  if (dense_lds_bytes(lay.Lp, B) > kMaxDynLds)
+    return fail(PK_ERR_UNSUPPORTED, "dense observe: %d landmarks and %d blobs need %zu bytes of LDS per particle, the workgroup has %zu",
+                lay.Lp, B, dense_lds_bytes(lay.Lp, B), (size_t)kMaxDynLds);
+  // block: ctl | blobs (4B doubles) | dir (2B doubles) | ids (B int32)
+  const size_t o_blobs = kCtlBytes;
+  const size_t o_dir = o_blobs + (size_t)B * 4 * sizeof(double);
+  const size_t o_ids = o_dir + (size_t)B * 2 * sizeof(double);
+  const size_t total = (o_ids + (size_t)B * sizeof(int32_t) + 15) & ~(size_t)15;
+  unsigned char* st = nullptr;
+  int slot = 0;
+  if ((rc = take_stage(f, total, &st, &slot))) return rc;
+  if ((rc = ensure_scan_capacity(f, total))) return rc;
+  if (ids_out && !ids && (rc = ensure_ids_capacity(f, B))) return rc;
+  memset(st, 0, kCtlBytes);
+  if (B > 0) {
+    memmove(st + o_blobs, blobs, (size_t)B * 4 * sizeof(double));
+    blob_directions(reinterpret_cast<const double*>(st + o_blobs), B, reinterpret_cast<double*>(st + o_dir));
+    if (ids) memcpy(st + o_ids, ids, (size_t)B * sizeof(int32_t));
+  }
+  if ((rc = upload_scan(f, st, total))) return rc;
+  if ((rc = note_upload(f, slot))) return rc;
+  ObserveExtras ex;
+  ex.reset = reset;
+  ex.gmax_key = ctl_gmax_key(f);
+  {
+    Span t(f, update ? PK_T_OBSERVE : PK_T_ASSOC);
+    launch_observe_dense(f->stream, f->d, reinterpret_cast<const double*>(f->scan_dev + o_blobs),
+                         reinterpret_cast<const double*>(f->scan_dev + o_dir), B,
+                         ids ? reinterpret_cast<const int32_t*>(f->scan_dev + o_ids) : nullptr,
+                         (ids_out && !ids) ? f->ids_dev : nullptr, f->qt16, update, ex);
+  }
+  PK_LAUNCH_CHECK("pk_observe (dense)");
+  if (update) {
+    f->src_identity = true;
+    f->gmax_fused = true;
+    f->route = PK_ROUTE_DENSE;
+  } else {
+    f->gmax_fused = false;  // the control words were overwritten by this upload
+  }
+  if (ids_out && B > 0) {
+    if (ids) {
+      for (int64_t p = 0; p < f->d.P; ++p) memcpy(ids_out + (size_t)p * B, ids, (size_t)B * 4);
+    } else {
+      PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
+      PK_HIP(hipStreamSynchronize(f->stream));
+    }
+  }
+  return PK_OK;
+}
+
 static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out,
                         bool reset) {
   if (!f) return fail(PK_ERR_INVALID, "pk_observe: NULL handle");
@@ -1076,6 +1236,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   if (ids)
     for (int b = 0; b < B; ++b)
       if (ids[b] < 0 || ids[b] > L) return fail(PK_ERR_INVALID, "pk_observe: ids[%d] = %d outside 0..%d", b, ids[b], L);
+  if (f->dense) return dense_observe(f, blobs, B, ids, ids_out, reset, true);
   ObserveExtras ex;
   ex.reset = reset;
   if (ids) {
@@ -1262,11 +1423,21 @@ int pk_stage_scan(pk_filter* f, const double* blobs, int32_t B) {
     if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_stage_scan: blob %d is not finite", i / 4);
   int rc;
   if ((rc = use_device(f))) return rc;
+  if (f->dense) {  // no tables to build: the blobs wait on the host
+    f->dense_staged.assign(blobs, blobs + 4 * (size_t)B);
+    return PK_OK;
+  }
+  f->dense_staged.clear();
   return stage_ml_scan(f, blobs, B);
 }
 
 int pk_observe_staged(pk_filter* f, int32_t fresh) {
   if (!f) return fail(PK_ERR_INVALID, "pk_observe_staged: NULL handle");
+  if (f->dense && !f->dense_staged.empty()) {
+    std::vector<double> b;
+    b.swap(f->dense_staged);
+    return observe_impl(f, b.data(), (int32_t)(b.size() / 4), nullptr, nullptr, fresh != 0);
+  }
   if (!f->staged.valid) return fail(PK_ERR_STATE, "pk_observe_staged: no staged scan (pk_stage_scan)");
   const double* blobs = reinterpret_cast<const double*>(f->staged.st + kCtlBytes);
   return observe_impl(f, blobs, f->staged.B, nullptr, nullptr, fresh != 0);
@@ -1281,6 +1452,7 @@ int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out)
   if ((rc = use_device(f))) return rc;
   for (int i = 0; i < 4 * B; ++i)
     if (!std::isfinite(blobs[i])) return fail(PK_ERR_INVALID, "pk_associate: blob %d is not finite", i / 4);
+  if (f->dense) return dense_observe(f, blobs, B, nullptr, ids_out, false, false);
   if ((rc = enqueue_association(f, blobs, B, true, false, nullptr))) return rc;
   PK_LAUNCH_CHECK("pk_associate");
   PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
@@ -1417,7 +1589,7 @@ int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64
   int rc;
   // Throughput mode with ML association: the host half of the scan upload first, then ONE launch
   // for the motion update and the upload of the scan block, then the observe kernels.
-  if (f && !z && !ids && B > 0 && blobs && f->map_loaded && f->upload_kernel && std::isfinite(v) && std::isfinite(w) &&
+  if (f && !f->dense && !z && !ids && B > 0 && blobs && f->map_loaded && f->upload_kernel && std::isfinite(v) && std::isfinite(w) &&
       std::isfinite(dt)) {
     bool finite = true;
     for (int i = 0; i < 4 * B && finite; ++i) finite = std::isfinite(blobs[i]);
@@ -1669,8 +1841,20 @@ int pk_probe(int32_t device, const double pose[3], const double mean[5], const d
   int ndev = pk_device_count();
   if (ndev <= 0) return fail(PK_ERR_HIP, "pk_probe: no HIP device visible (the HIP path has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(PK_ERR_INVALID, "pk_probe: device %d of %d", device, ndev);
-  int rc;
-  if ((rc = check_block_diagonal(cov, 0))) return rc;
+  const int cls = classify_covariance(cov, 0);
+  if (cls < 0) return cls;
+  for (int i = 0; i < 16; ++i)
+    if (!std::isfinite(Qt[i])) return fail(PK_ERR_INVALID, "pk_probe: Qt is not finite");
+  bool dense = cls == 1;
+  {
+    double scale = 0;
+    for (int i = 0; i < 4; ++i) scale = fmax(scale, fabs(Qt[i * 5]));
+    for (int j = 1; j < 4; ++j)
+      if (fabs(Qt[j]) > 1e-14 * scale || fabs(Qt[j * 4]) > 1e-14 * scale) dense = true;
+    for (int i = 1; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j)
+        if (fabs(Qt[i * 4 + j] - Qt[j * 4 + i]) > 1e-9 * (scale > 0 ? scale : 1.0)) dense = true;
+  }
   PK_HIP(hipSetDevice(device));
   double in[55];
   memcpy(in, pose, 3 * 8);
@@ -1683,7 +1867,10 @@ int pk_probe(int32_t device, const double pose[3], const double mean[5], const d
   PK_HIP(hipMalloc((void**)&dev, (55 + PK_PROBE_LEN) * sizeof(double)));
   hipError_t e = hipMemcpy(dev, in, sizeof(in), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    launch_probe(nullptr, dev, dev + 55);
+    if (dense)
+      launch_probe_dense(nullptr, dev, dev + 55);  // xy-rgb coupling or a coupled Qt: the dense formulas
+    else
+      launch_probe(nullptr, dev, dev + 55);
     e = hipMemcpy(out, dev + 55, PK_PROBE_LEN * sizeof(double), hipMemcpyDeviceToHost);
   }
   (void)hipFree(dev);

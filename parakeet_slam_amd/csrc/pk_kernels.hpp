@@ -216,6 +216,14 @@ void launch_summary_partials(hipStream_t s, DeviceState& d, double* partial_dev,
 void launch_materialise(hipStream_t s, DeviceState& d);
 void launch_broadcast_slot(hipStream_t s, DeviceState& d, const unsigned char* slot_dev);
 void launch_probe(hipStream_t s, const double* in_dev, double* out_dev);
+// the general dense path (pk_k_dense.hip): 30-row slots, full 5x5 covariances, any 4x4 Qt; one kernel does the (brute-force)
+// maximum-likelihood association -- or takes supplied ids --, the EKF updates in scan order and the log-weight.
+// update = false: association only (ids_out_dev), no state is touched.
+size_t dense_lds_bytes(int Lp, int B);
+void launch_observe_dense(hipStream_t s, DeviceState& d, const double* blobs_dev, const double* blobdir_dev, int B,
+                          const int32_t* ids_in_dev, int32_t* ids_out_dev, const double Qt[16], bool update,
+                          const ObserveExtras& ex);
+void launch_probe_dense(hipStream_t s, const double* in_dev, double* out_dev);
 // sharded resample
 // record header in front of the map slot: x, y, h, logw, slot_lo, slot_hi (the last two int64:
 // the global output slots this copy fills at its destination; 0, 0 when the caller plans on the host)

@@ -24,18 +24,26 @@ enum Field : int {
   F_COUNT_FIELDS = 14
 };
 
+// The DENSE layout (maps whose covariances couple position and colour, or are not symmetric: what the reference
+// accepts, prkt_core_v2.py:882-895, but its own update never produces from block-diagonal inputs) keeps the
+// reference's full state: rows 0-4 the mean, rows 5 + 5 i + j the covariance entry [i][j] -- 30 rows, 240 B per
+// landmark.  Only the slow, general dense kernels (pk_k_dense.hip) read it.
+constexpr int kDenseFields = 30;
+
 struct MapLayout {
   int L;              // landmarks per particle
   int Lp;             // padded to a multiple of 16 (rows on 128-byte lines; even, for 16-byte loads of two landmarks)
   size_t slot_bytes;  // multiple of 256
   size_t count_off;   // byte offset of the int32 counts inside a slot
+  int fields;         // rows of T per slot: F_COUNT_FIELDS (compact) or kDenseFields
 
-  static MapLayout make(int L, size_t scalar) {
+  static MapLayout make(int L, size_t scalar, int fields = F_COUNT_FIELDS) {
     MapLayout m;
     m.L = L;
     m.Lp = (L + 15) & ~15;
     if (m.Lp == 0) m.Lp = 16;
-    m.count_off = (size_t)F_COUNT_FIELDS * m.Lp * scalar;
+    m.fields = fields;
+    m.count_off = (size_t)fields * m.Lp * scalar;
     size_t raw = m.count_off + (size_t)m.Lp * sizeof(int32_t);
     m.slot_bytes = (raw + 255) & ~(size_t)255;
     return m;

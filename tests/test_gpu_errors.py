@@ -25,15 +25,15 @@ def test_call_order_and_argument_errors(lib):
         f.resample(1.0)
     assert e.value.status == lib.PK_ERR_INVALID  # u must be in [0, 1)
     bad = covs.copy()
-    bad[1, 0, 1] = 0.1  # asymmetric
+    bad[1, 0, 1] = np.inf
     with pytest.raises(lib.PkError) as e:
         f.upload_map(means, bad.reshape(3, 25))
-    assert e.value.status == lib.PK_ERR_UNSUPPORTED
+    assert e.value.status == lib.PK_ERR_INVALID  # not finite
     Qt = 0.1 * np.identity(4)
-    Qt[0, 2] = Qt[2, 0] = 0.01  # bearing-colour coupling
+    Qt[1, 2] = np.nan
     with pytest.raises(lib.PkError) as e:
         f.set_measurement_noise(Qt)
-    assert e.value.status == lib.PK_ERR_UNSUPPORTED
+    assert e.value.status == lib.PK_ERR_INVALID
     poses = np.zeros((16, 4))
     poses[3, 3] = -1.0
     with pytest.raises(lib.PkError):

@@ -280,12 +280,43 @@ def test_particle_assignment_and_motion_update(pk):
     fs.close()
 
 
-def test_unsupported_covariance_is_loud(pk):
-    cov = 0.25 * np.identity(5)
-    cov[0, 3] = cov[3, 0] = 0.01
-    with pytest.raises(pk.PkError) as ei:
-        pk.FastSLAM([pk.Feature(mean=np.zeros(5), covar=cov)], num_particles=4)
-    assert ei.value.status == -4
+def test_coupled_covariance_takes_the_dense_path(pk):
+    """A Feature whose covariance couples position and colour (prkt_core_v2.py:882-895 takes any 5x5) runs through
+    cam_cb on the general dense kernel; poses, weights and landmark states against the oracle on the same seeds."""
+    from oracle.fastslam_oracle import OracleFilter
+
+    rs = np.random.RandomState(31)
+    L, P = 5, 16
+    means = np.column_stack([rs.uniform(3, 9, L) * np.cos(np.linspace(-2, 2, L)), rs.uniform(3, 9, L) * np.sin(np.linspace(-2, 2, L)),
+                             rs.uniform(0, 255, (L, 3))])
+    covs = []
+    for _ in range(L):
+        a = rs.normal(size=(5, 5))
+        covs.append(0.1 * (a @ a.T) + 0.2 * np.identity(5))  # dense SPD: xy-rgb cross terms
+    covs = np.array(covs)
+    np.random.seed(5)
+    random.seed(5)
+    pk.msgs.Time.set_now(0.0)
+    fs = pk.FastSLAM([pk.Feature(mean=means[l], covar=covs[l]) for l in range(L)], num_particles=P)
+    tw = pk.msgs.Twist()
+    tw.linear.x, tw.angular.z = 0.2, 0.1
+    fs.last_control = tw
+    o = OracleFilter(P, means, covs)
+    np_rs = np.random.RandomState(5)
+    py_rs = random.Random(5)
+    rows = np.column_stack([np.arctan2(means[:, 1], means[:, 0]), means[:, 2:]])
+    for s in range(3):
+        pk.msgs.Time.set_now(0.1 * (s + 1))
+        fs.cam_cb(View(pk, rows))
+        o.step(0.2, 0.1, 0.1, np_rs.standard_normal((P, 3)), rows, py_rs.random())
+        assert fs._filter.observe_route() == "dense"
+        got = fs._filter.download_poses()
+        assert np.allclose(got[:, 0], o.x, rtol=1e-9, atol=1e-12) and np.allclose(got[:, 2], o.h, rtol=1e-9, atol=1e-12)
+        assert relerr(got[:, 3], o.weights()) < 1e-8
+    f3 = fs.particles[3].feature_set[2]
+    assert np.allclose(f3.mean, o.mean[3, 1], rtol=1e-9) and np.allclose(f3.covar, o.cov[3, 1], rtol=1e-8, atol=1e-12)
+    assert abs(f3.covar[0, 3]) > 1e-6  # the coupling is still there
+    fs.close()
 
 
 def test_snapshot_round_trip(pk, tmp_path):
