@@ -255,6 +255,16 @@ int pk_shard_block_totals_dev(pk_filter* f, const double* dev_gmax, int32_t weig
 int pk_shard_plan_dev(pk_filter* f, const double* dev_global_totals, int64_t n_global_blocks,
                       int64_t first_block, int64_t global_particles, double u, int32_t last_shard,
                       int32_t world, int64_t* dev_ranges);
+/* The same plan for shards of ANY size (the block-total plan above reproduces the 1-GPU ancestors only when shards are
+ * multiples of the 1024-particle scan block): the ranks all-gather their log-weights (pk_shard_logw_dev copies the shard's
+ * into a caller buffer), and every rank runs the 1-GPU scan kernels on the whole array -- same blocks, same additions,
+ * same bits on every rank and as on one GPU -- then derives its own particles' output slots.  8 B per particle of the
+ * whole filter travel per resample (the migrating particles' maps are 10^4 times that).
+ * pk_shard_download_offspring: the plan's table slot_hi[P + 1] (as pk_shard_offspring returns it), for tests. */
+int pk_shard_logw_dev(pk_filter* f, double* dev_out);
+int pk_shard_plan_global_dev(pk_filter* f, const double* dev_global_logw, int64_t global_particles, const double* dev_gmax,
+                             int32_t weight_domain, double u, int32_t last_shard, int32_t world, int64_t* dev_ranges);
+int pk_shard_download_offspring(pk_filter* f, int64_t* slot_hi);
 int pk_shard_pack_dev(pk_filter* f, const int64_t* ranges, int32_t world, int32_t rank, void* dev_buf);
 int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received);
 

@@ -70,6 +70,10 @@ SIGNATURES = {
     "pk_shard_block_totals_dev": (C.c_int, [_h, C.c_void_p, C.c_int32, C.c_void_p]),
     "pk_shard_plan_dev": (C.c_int, [_h, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_int32, C.c_int32,
                                     C.c_void_p]),
+    "pk_shard_logw_dev": (C.c_int, [_h, C.c_void_p]),
+    "pk_shard_plan_global_dev": (C.c_int, [_h, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                           C.c_void_p]),
+    "pk_shard_download_offspring": (C.c_int, [_h, _lp]),
     "pk_shard_pack_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p]),
     "pk_shard_adopt_dev": (C.c_int, [_h, C.c_int32, C.c_void_p, C.c_int64]),
     "pk_particle_bytes": (C.c_int64, [_h]),
@@ -318,6 +322,18 @@ class DeviceFilter(object):
         check(self._lib.pk_shard_plan_dev(self._h, C.c_void_p(gtotals_ptr), int(n_blocks), int(first_block),
                                           int(global_particles), float(u), 1 if last_shard else 0, int(world),
                                           C.c_void_p(ranges_ptr)))
+
+    def shard_logw_dev(self, out_ptr):
+        check(self._lib.pk_shard_logw_dev(self._h, C.c_void_p(out_ptr)))
+
+    def shard_plan_global_dev(self, glogw_ptr, global_particles, gmax_ptr, domain, u, last_shard, world, ranges_ptr):
+        check(self._lib.pk_shard_plan_global_dev(self._h, C.c_void_p(glogw_ptr), int(global_particles), C.c_void_p(gmax_ptr),
+                                                 int(domain), float(u), 1 if last_shard else 0, int(world), C.c_void_p(ranges_ptr)))
+
+    def shard_download_offspring(self):
+        out = np.empty(self.P + 1, dtype=np.int64)
+        check(self._lib.pk_shard_download_offspring(self._h, lptr(out)))
+        return out
 
     def shard_pack_dev(self, ranges, world, rank, buf_ptr):
         r = np.ascontiguousarray(ranges, dtype=np.int64)

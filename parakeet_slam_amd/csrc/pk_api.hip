@@ -93,6 +93,10 @@ struct pk_filter {
   double* g_totals = nullptr;   // sharded resample: every shard's block totals
   double* g_offsets = nullptr;
   int64_t gblocks_cap = 0;
+  double* gl_clocal = nullptr;  // global-scan mode of the sharded resample: block-local scans of ALL particles' weights
+  double* gl_totals = nullptr;
+  double* gl_offsets = nullptr;
+  int64_t gl_cap = 0;
   int64_t* hi_dev = nullptr;    // P + 1
   unsigned* plan_ticket = nullptr;  // workgroup counter of the one-launch shard plan
   int64_t* idx_dev = nullptr;   // P
@@ -895,7 +899,7 @@ int pk_destroy(pk_filter* f) {
   if (f->scan_dev) (void)hipFree(f->scan_dev);
   for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev})
     if (q) (void)hipFree(q);
-  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
+  for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
   void* rest[] = {d.immutable, f->z_dev,  f->ids_dev,
                   f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
@@ -1344,7 +1348,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     fh.n_flagged = ctl_n_flagged(f);
     fh.flags_only = true;
     CandTable cand;
-    if (al.regs && f->cand_lists) {
+    if (al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) {
       // the reference particle's candidate lists (particle 0 of the live generation), timed with the association
       if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 2))) return rc;
       Span t(f, PK_T_ASSOC);
@@ -1785,6 +1789,62 @@ int pk_shard_plan_dev(pk_filter* f, const double* dev_global_totals, int64_t n_g
   launch_offspring(f->stream, f->clocal, f->g_offsets, f->sum, first_block, f->d.P, global_particles, u,
                    last_shard ? 1 : 0, f->hi_dev);
   launch_shard_ranges(f->stream, f->hi_dev, f->d.P, world, dev_ranges);
+  return PK_OK;
+}
+
+// ---- the same plan from the scan of the WHOLE filter's weights: any shard size ----------------------------------------
+int pk_shard_logw_dev(pk_filter* f, double* dev_out) {
+  if (!f || !dev_out) return fail(PK_ERR_INVALID, "pk_shard_logw_dev: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipMemcpyAsync(dev_out, f->d.logw[f->d.cur], (size_t)f->d.P * sizeof(double), hipMemcpyDeviceToDevice, f->stream));
+  return PK_OK;
+}
+
+int pk_shard_plan_global_dev(pk_filter* f, const double* dev_global_logw, int64_t global_particles, const double* dev_gmax,
+                             int32_t weight_domain, double u, int32_t last_shard, int32_t world, int64_t* dev_ranges) {
+  if (!f || !dev_global_logw || !dev_ranges || world < 1) return fail(PK_ERR_INVALID, "pk_shard_plan_global_dev: bad argument");
+  if (weight_domain == PK_WEIGHTS_LOG && !dev_gmax) return fail(PK_ERR_INVALID, "pk_shard_plan_global_dev: NULL maximum");
+  if (!(u >= 0.0 && u < 1.0)) return fail(PK_ERR_INVALID, "pk_shard_plan_global_dev: u = %g outside [0,1)", u);
+  const int64_t P = f->d.P, goff = f->d.global_offset;
+  if (global_particles != (int64_t)world * P || goff < 0 || goff + P > global_particles)
+    return fail(PK_ERR_INVALID, "pk_shard_plan_global_dev: shard [%lld, +%lld) of %lld particles, world %d", (long long)goff,
+                (long long)P, (long long)global_particles, world);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const int64_t nbg = (global_particles + kScanBlock - 1) / kScanBlock;
+  if (global_particles > f->gl_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    for (double** q : {&f->gl_clocal, &f->gl_totals, &f->gl_offsets}) {
+      if (*q) (void)hipFree(*q);
+      *q = nullptr;
+    }
+    f->gl_cap = 0;
+    if ((rc = dev_alloc(f, &f->gl_clocal, (size_t)global_particles))) return rc;
+    if ((rc = dev_alloc(f, &f->gl_totals, (size_t)nbg))) return rc;
+    if ((rc = dev_alloc(f, &f->gl_offsets, (size_t)nbg + 1))) return rc;
+    f->gl_cap = global_particles;
+  }
+  if (!f->hi_dev && (rc = dev_alloc(f, &f->hi_dev, (size_t)P + 1))) return rc;
+  Span t(f, PK_T_WEIGHTS);
+  // exactly the kernels of the 1-GPU resample on the whole filter's log-weights: same blocks, same additions, same bits
+  launch_scan_local_of(f->stream, dev_global_logw, global_particles, dev_gmax ? dev_gmax : f->gmax, weight_domain, f->gl_clocal,
+                       f->gl_totals);
+  launch_scan_blocks(f->stream, f->gl_totals, nbg, f->gl_offsets, f->sum);
+  launch_offspring_global(f->stream, f->gl_clocal, f->gl_offsets, f->sum, goff, P, global_particles, u, last_shard ? 1 : 0,
+                          f->hi_dev);
+  launch_shard_ranges(f->stream, f->hi_dev, P, world, dev_ranges);
+  PK_LAUNCH_CHECK("pk_shard_plan_global_dev");
+  return PK_OK;
+}
+
+int pk_shard_download_offspring(pk_filter* f, int64_t* slot_hi) {
+  if (!f || !slot_hi) return fail(PK_ERR_INVALID, "pk_shard_download_offspring: NULL argument");
+  if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_download_offspring: no plan yet");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipMemcpyAsync(slot_hi, f->hi_dev, ((size_t)f->d.P + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
   return PK_OK;
 }
 

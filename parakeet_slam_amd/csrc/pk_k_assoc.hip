@@ -635,7 +635,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 }
 
 // ------------------------------------------------------------------ K2' candidate lists from a reference particle
-// See pk_kernels.hpp (CandTable).  A workgroup takes 64 landmarks of the reference particle; its four waves share the
+// See pk_kernels.hpp (CandTable).  A workgroup takes 64 landmarks of the reference particle; its sixteen waves share the
 // scan's blobs (uniform reads of the exact records), candidates are appended per landmark through LDS atomics.
 struct CandArgs {
   SlotSource ss;
@@ -650,7 +650,8 @@ struct CandArgs {
   int L, Lp, B;
 };
 
-__global__ void __launch_bounds__(256) k_candidates(CandArgs a) {
+constexpr int kCandThreads = 1024;  // 64 landmarks x 16 waves that share the scan's blobs
+__global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   __shared__ unsigned short s_c[64][kCandSlots];
   __shared__ int s_n[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -674,7 +675,7 @@ __global__ void __launch_bounds__(256) k_candidates(CandArgs a) {
   const double tc = rad * rad;
   if (w == 0) s_n[lane] = 0;
   __syncthreads();
-  const int chunk = (a.B + 3) / 4;
+  const int chunk = (a.B + kCandThreads / 64 - 1) / (kCandThreads / 64);
   const int t1 = min(a.B, (w + 1) * chunk);
   for (int t = w * chunk; t < t1; ++t) {  // wave-uniform: the records come through the scalar cache
     const double* rec = a.exact + 6 * (size_t)t;
@@ -745,7 +746,7 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
-  hipLaunchKernelGGL(k_candidates, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_candidates, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(kCandThreads), 0, s, a);
   if (a.bcnt && stray_dev) hipLaunchKernelGGL(k_cand_strays, dim3(1), dim3(256), 0, s, a.bcnt, B, stray_dev);
 }
 

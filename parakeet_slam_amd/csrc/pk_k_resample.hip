@@ -229,7 +229,9 @@ __global__ void __launch_bounds__(256) k_offspring(const double* __restrict__ cl
                                                    const double* sum, int64_t nb_global, int64_t first_block,
                                                    int64_t Pl, int64_t Pg, double u, int last_shard,
                                                    int64_t* __restrict__ hi, int world, int64_t* __restrict__ ranges,
-                                                   unsigned* __restrict__ ticket) {
+                                                   unsigned* __restrict__ ticket, int64_t goff) {
+  // goff >= 0: clocal and the blocks are those of the WHOLE filter (every rank scanned the all-gathered log-weights:
+  // exactly the 1-GPU scan whatever the shard size), this shard's particles are [goff, goff + Pl); first_block unused
   __shared__ double s_off[kAncMaxBlocks + 1];
   __shared__ int s_last;
   if (offsets == nullptr) {
@@ -257,9 +259,11 @@ __global__ void __launch_bounds__(256) k_offspring(const double* __restrict__ cl
     bool search = true;
     int64_t val = 0;
     if (i == 0) {
-      if (first_block == 0) {
+      if (goff >= 0 ? goff == 0 : first_block == 0) {
         val = 0;
         search = false;
+      } else if (goff >= 0) {
+        C = __dadd_rn(offsets[(goff - 1) / kScanBlock], clocal[goff - 1]);  // cumulative weight of everybody before this shard
       } else {
         C = offsets[first_block];
       }
@@ -268,6 +272,8 @@ __global__ void __launch_bounds__(256) k_offspring(const double* __restrict__ cl
       if (last_shard && j == Pl - 1) {  // the tail is clamped to the last particle, as k_ancestors does
         val = Pg;
         search = false;
+      } else if (goff >= 0) {
+        C = __dadd_rn(offsets[(goff + j) / kScanBlock], clocal[goff + j]);
       } else {
         C = __dadd_rn(offsets[first_block + j / kScanBlock], clocal[j]);
       }
@@ -343,7 +349,7 @@ void launch_offspring(hipStream_t s, const double* clocal_dev, const double* off
                       int64_t* hi_dev) {
   hipLaunchKernelGGL(k_offspring, dim3((unsigned)((P_local + 1 + 255) / 256)), dim3(256), 0, s, clocal_dev,
                      (const double*)nullptr, offsets_dev, sum_dev, (int64_t)0, first_block, P_local, P_global, u, last_shard,
-                     hi_dev, 0, (int64_t*)nullptr, (unsigned*)nullptr);
+                     hi_dev, 0, (int64_t*)nullptr, (unsigned*)nullptr, (int64_t)-1);
 }
 // offspring + block-total scan + per-destination ranges in ONE launch (n_global_blocks <= kAncestorsScanMaxBlocks)
 void launch_offspring_plan(hipStream_t s, const double* clocal_dev, const double* global_totals_dev,
@@ -351,7 +357,23 @@ void launch_offspring_plan(hipStream_t s, const double* clocal_dev, const double
                            int last_shard, int64_t* hi_dev, int world, int64_t* ranges_dev, unsigned* ticket_dev) {
   hipLaunchKernelGGL(k_offspring, dim3((unsigned)((P_local + 1 + 255) / 256)), dim3(256), 0, s, clocal_dev,
                      global_totals_dev, (const double*)nullptr, (const double*)nullptr, n_global_blocks, first_block,
-                     P_local, P_global, u, last_shard, hi_dev, world, ranges_dev, ticket_dev);
+                     P_local, P_global, u, last_shard, hi_dev, world, ranges_dev, ticket_dev, (int64_t)-1);
+}
+// The same on the scan of the WHOLE filter's weights (any shard size; see pk_shard_plan_global_dev): clocal_global /
+// the block offsets cover all P_global particles, this shard's are [goff, goff + P_local).
+void launch_offspring_global(hipStream_t s, const double* clocal_global_dev, const double* offsets_dev, const double* sum_dev,
+                             int64_t goff, int64_t P_local, int64_t P_global, double u, int last_shard, int64_t* hi_dev) {
+  hipLaunchKernelGGL(k_offspring, dim3((unsigned)((P_local + 1 + 255) / 256)), dim3(256), 0, s, clocal_global_dev,
+                     (const double*)nullptr, offsets_dev, sum_dev, (int64_t)0, (int64_t)0, P_local, P_global, u, last_shard,
+                     hi_dev, 0, (int64_t*)nullptr, (unsigned*)nullptr, goff);
+}
+// block-local scans of an arbitrary log-weight array (not the filter's own)
+void launch_scan_local_of(hipStream_t s, const double* logw_dev, int64_t n, const double* gmax_dev, int domain,
+                          double* clocal_dev, double* totals_dev) {
+  if (n == 0) return;
+  int nb = (int)((n + kScanBlock - 1) / kScanBlock);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, s, logw_dev, n, gmax_dev, domain, clocal_dev, totals_dev,
+                     (const unsigned long long*)nullptr);
 }
 
 // record = (x, y, h, logw) + map slot

@@ -234,6 +234,10 @@ void launch_offspring(hipStream_t s, const double* clocal_dev, const double* off
 void launch_offspring_plan(hipStream_t s, const double* clocal_dev, const double* global_totals_dev,
                            int64_t n_global_blocks, int64_t first_block, int64_t P_local, int64_t P_global, double u,
                            int last_shard, int64_t* hi_dev, int world, int64_t* ranges_dev, unsigned* ticket_dev);
+void launch_offspring_global(hipStream_t s, const double* clocal_global_dev, const double* offsets_dev, const double* sum_dev,
+                             int64_t goff, int64_t P_local, int64_t P_global, double u, int last_shard, int64_t* hi_dev);
+void launch_scan_local_of(hipStream_t s, const double* logw_dev, int64_t n, const double* gmax_dev, int domain,
+                          double* clocal_dev, double* totals_dev);
 void launch_pack(hipStream_t s, DeviceState& d, const int64_t* idx_dev, int64_t n, unsigned char* buf_dev);
 void launch_adopt(hipStream_t s, DeviceState& d, const int64_t* src_dev, const unsigned char* buf_dev);
 // device-resident variant of the exchange (no per-particle host metadata)

@@ -22,6 +22,12 @@ the same stream as the collectives; the host synchronises once per resample.
 The draw u is replicated (same value on every rank), as the north star asks.  With shards
 that are multiples of 1024 particles the ancestors are bit-identical to the 1-GPU run.
 
+Shards of any other size take the GLOBAL-SCAN variant of steps 2-3 (``global_scan``; chosen by
+itself when P_local % 1024 != 0): the ranks all-gather their log-weights (8 B per particle of
+the whole filter; the migrating maps of step 4 are 10^4 times that) and every rank runs the
+1-GPU scan kernels over the whole array -- the same 1024-particle blocks, the same additions,
+hence the same bits as one GPU -- and then derives its own particles' output slots from it.
+
 The collectives go through torch.distributed: backend "nccl" is RCCL over xGMI on ROCm
 (device tensors, all_to_all_single); "gloo" is used by the CPU / single-GPU tests.
 """
@@ -212,6 +218,13 @@ class HipShard(_lib.DeviceFilter):
         self.shard_plan_dev(gtotals_t.data_ptr(), gtotals_t.numel(), first_block, global_particles, u, last_shard, world,
                             ranges_t.data_ptr())
 
+    def logw_into(self, t):
+        self.shard_logw_dev(t.data_ptr())
+
+    def plan_global_into(self, glogw_t, global_particles, gmax_t, domain, u, last_shard, world, ranges_t):
+        self.shard_plan_global_dev(glogw_t.data_ptr(), global_particles, gmax_t.data_ptr() if gmax_t is not None else 0, domain,
+                                   u, last_shard, world, ranges_t.data_ptr())
+
     def pack_into(self, ranges, world, rank, buf):
         self.shard_pack_dev(ranges, world, rank, buf.data_ptr())
 
@@ -245,7 +258,7 @@ class ShardedFilter(object):
     """One shard of a FastSLAM filter: same methods as ``_lib.DeviceFilter`` for what bench.py
     and the tests use, with the resample made global across ranks."""
 
-    def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None):
+    def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None, global_scan=None):
         self.comm = comm if comm is not None else TorchComm()
         self.rank, self.world = self.comm.rank, self.comm.world
         self.P = int(particles_per_rank)
@@ -260,6 +273,11 @@ class ShardedFilter(object):
         self._gmax = f.new_f64(1)
         self._totals = f.new_f64(self.nb)
         self._gtotals = f.new_f64(self.nb * self.world)
+        # shards that do not end on scan-block boundaries: scan the whole filter's weights on every rank (module docstring)
+        self.global_scan = (self.P % SCAN_BLOCK != 0 and self.world > 1) if global_scan is None else bool(global_scan)
+        if self.global_scan:
+            self._logw = f.new_f64(self.P)
+            self._glogw = f.new_f64(self.P_global) if self.world > 1 else self._logw
         self._ranges = f.new_i64(2 * self.world)
         self._all_ranges = f.new_i64(2 * self.world * self.world)
         self._sums = f.new_f64(4)
@@ -350,13 +368,19 @@ class ShardedFilter(object):
             f.max_logw_into(gmax)
             if W > 1:
                 comm.all_reduce_max_(gmax)
-        f.block_totals_into(gmax, domain, self._totals)
-        if W > 1:
-            comm.all_gather_(self._gtotals, self._totals)
-            gtot = self._gtotals
+        if self.global_scan:
+            f.logw_into(self._logw)
+            if W > 1:
+                comm.all_gather_(self._glogw, self._logw)
+            f.plan_global_into(self._glogw, self.P_global, gmax, domain, u, R == W - 1, W, self._ranges)
         else:
-            gtot = self._totals
-        f.plan_into(gtot, R * self.nb, self.P_global, u, R == W - 1, W, self._ranges)
+            f.block_totals_into(gmax, domain, self._totals)
+            if W > 1:
+                comm.all_gather_(self._gtotals, self._totals)
+                gtot = self._gtotals
+            else:
+                gtot = self._totals
+            f.plan_into(gtot, R * self.nb, self.P_global, u, R == W - 1, W, self._ranges)
         if W > 1:
             comm.all_gather_(self._all_ranges, self._ranges)
             table = self._all_ranges
@@ -395,8 +419,11 @@ class ShardedFilter(object):
     def _global_ancestors(self, u, domain):
         """Tests only: global ancestor index of every local output slot, from the host-array
         variant of the same plan (pk_shard_offspring)."""
-        gt = self._gtotals if self.world > 1 else self._totals
-        hi = self.f.shard_offspring(gt.cpu().numpy(), self.rank * self.nb, self.P_global, u, self.rank == self.world - 1)
+        if self.global_scan:
+            hi = self.f.shard_download_offspring()  # the table the plan itself used
+        else:
+            gt = self._gtotals if self.world > 1 else self._totals
+            hi = self.f.shard_offspring(gt.cpu().numpy(), self.rank * self.nb, self.P_global, u, self.rank == self.world - 1)
         allhi = self.f.new_f64(self.P * self.world)
         mine = self.f.new_f64(self.P)
         mine.copy_(self._to_dev(hi[1:].astype(np.float64), mine))

@@ -111,6 +111,40 @@ class OracleShard(object):
 
     def plan_into(self, gtotals_t, first_block, P_global, u, last_shard, world, ranges_t):
         self.hi = self.shard_offspring(gtotals_t.numpy(), first_block, P_global, u, last_shard)
+        self._ranges_from_hi(world, ranges_t)
+
+    # ---- global-scan variant (shards of any size): the 1-GPU blocked scan on the all-gathered log-weights ----
+    def logw_into(self, t):
+        import torch
+
+        t.copy_(torch.from_numpy(self.o.logw.copy()))
+
+    def plan_global_into(self, glogw_t, P_global, gmax_t, domain, u, last_shard, world, ranges_t):
+        glogw = glogw_t.numpy()
+        gmax = float(gmax_t[0]) if gmax_t is not None else 0.0
+        w = np.exp(glogw - (gmax if domain == 1 and gmax > -np.inf else 0.0))
+        nb = (P_global + SCAN_BLOCK - 1) // SCAN_BLOCK
+        C = np.empty(P_global)
+        run = 0.0
+        for b in range(nb):  # block-local inclusive sums + the sequential exclusive scan of the block totals
+            c = np.cumsum(w[b * SCAN_BLOCK:(b + 1) * SCAN_BLOCK])
+            C[b * SCAN_BLOCK:b * SCAN_BLOCK + len(c)] = run + c
+            run = run + c[-1]
+        r = run / float(P_global)
+        t = u * r + np.arange(P_global, dtype=np.float64) * r
+        off, P = self.off, self.P
+        hi = np.empty(P + 1, dtype=np.int64)
+        hi[0] = 0 if off == 0 else np.searchsorted(t, C[off - 1], side="right")
+        hi[1:] = np.searchsorted(t, C[off:off + P], side="right")
+        if last_shard:
+            hi[-1] = P_global
+        self.hi = hi
+        self._ranges_from_hi(world, ranges_t)
+
+    def shard_download_offspring(self):
+        return self.hi.copy()
+
+    def _ranges_from_hi(self, world, ranges_t):
         hi, P = self.hi, self.P
         for d in range(world):
             start, end = d * P, (d + 1) * P

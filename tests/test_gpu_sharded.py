@@ -1,7 +1,8 @@
 """GPU (one device is enough): two processes, one HIP filter each on cuda:0, gloo between
 them -- the sharded resample of the real library against ONE filter holding all particles.
-With shards of 1024 particles the result must be bit-identical (same scan blocks, same
-sequential scan of the block totals, same comb).  Also: nccl (= RCCL) code path with one rank."""
+The result must be bit-identical (same scan blocks, same sequential scan of the block totals,
+same comb): shards of 1024 particles through the block-total plan, shards of 300 and 1500
+through the global-scan plan.  Also: nccl (= RCCL) code path with one rank."""
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
@@ -66,9 +67,11 @@ def worker(rank, world, store, P_local, L, steps, skew, use_ml, q):
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("skew,use_ml", [(0.0, False), (5.0, False), (2.0, True)])
-def test_two_shards_on_one_gpu_match_single_filter(skew, use_ml):
-    world, P_local, L, steps = 2, 1024, 12, 3
+@pytest.mark.parametrize("skew,use_ml,world,P_local", [(0.0, False, 2, 1024), (5.0, False, 2, 1024), (2.0, True, 2, 1024),
+                                                       # shards that end inside a scan block: the global-scan plan
+                                                       (5.0, False, 2, 300), (2.0, True, 3, 1500)])
+def test_two_shards_on_one_gpu_match_single_filter(skew, use_ml, world, P_local):
+    L, steps = 12, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     store = store_file()
