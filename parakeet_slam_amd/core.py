@@ -286,15 +286,86 @@ class FilterParticle(object):
     def no_match_weight(self):
         return NO_MATCH_WEIGHT
 
-    # -- new-landmark machinery (:546-746): out of scope, dead in the reference ----------
-    def add_orphaned_reading(self, state, blob):
-        self.hypothesis_set[self.next_id] = ((state, blob,))
+    # -- f4: new-landmark machinery (:546-746) ------------------------------------------------
+    # Host bookkeeping per unmatched blob, as in the reference (not part of the data-parallel path: inside the
+    # filter the device only applies the 0.1 weight of :95).  Restated with the reference's arithmetic order so
+    # that its own unit tests (test_prkt_ros2.py:228-381) hold exactly -- including the behaviour that makes the
+    # machinery a dead end there: find_nearest_reading walks ``potential_features`` (never filled by the filter)
+    # and returns the nearest entry's key, which is negative or 0, so add_hypothesis always files an orphan.
+    def add_hypothesis(self, state, blob):
+        """:546-564."""
+        pair_id = self.find_nearest_reading(state, blob)
+        if pair_id > 0:
+            self.add_new_feature(pair_id, state, blob)
+        else:
+            self.add_orphaned_reading(state, blob)
+
+    def find_nearest_reading(self, state, blob):
+        """:566-590: key of the stored reading at the smallest reading distance (first one on ties), 0 if none
+        is at a finite distance."""
+        best_id, best = 0, float('inf')
+        for id_, reading in self.potential_features.items():
+            d = self.reading_distance_function(reading[0], reading[1], state, blob)
+            if d < best:
+                best, best_id = d, id_
+        return best_id
+
+    def reading_distance_function(self, state1, blob1, state2, blob2):
+        """:592-609: colour distance of two readings whose rays cross, else inf."""
+        x1, y1, h1 = _state_pose(state1)
+        x2, y2, h2 = _state_pose(state2)
+        if not self.ray_intersect(x1, y1, blob1.bearing + h1, x2, y2, blob2.bearing + h2):
+            return float('inf')
+        return self.color_distance(blob1, blob2)
+
+    def ray_intersect(self, x1, y1, b1, x3, y3, b3):
+        """:611-643: do the half-lines (x1, y1, b1) and (x3, y3, b3) meet (both ray parameters >= 0)."""
+        ax, ay = math.cos(b1), math.sin(b1)
+        bx, by = math.cos(b3), math.sin(b3)
+        cross = ay * bx - ax * by
+        if cross == 0:
+            return False
+        v = (ax * y3 - ay * x3 + ay * x1 - ax * y1) / cross
+        if abs(ay) < abs(ax):
+            u = (x3 + bx * v - x1) / ax
+        else:
+            u = (y3 + by * v - y1) / ay
+        return u >= 0 and v >= 0
+
+    def color_distance(self, blob1, blob2):
+        """:645-654: Euclidean distance of the two colours."""
+        return math.sqrt(math.pow(blob1.color.r - blob2.color.r, 2) + math.pow(blob1.color.g - blob2.color.g, 2) +
+                         math.pow(blob1.color.b - blob2.color.b, 2))
+
+    def add_new_feature(self, old_id, state, blob):
+        """:656-686: a potential feature (negative id) where the stored reading old_id and this one cross, mean
+        colour of the two, identity covariance."""
+        old_state, old_blob = self.hypothesis_set[old_id]
+        x, y = self.cross_readings((old_state, old_blob), (state, blob))
+        mean = np.array([x, y, (old_blob.color.r + blob.color.r) / 2, (old_blob.color.g + blob.color.g) / 2,
+                         (old_blob.color.b + blob.color.b) / 2])
+        self.potential_features[-self.next_id] = Feature(mean=mean, covar=np.identity(5))
         self.next_id += 1
 
-    def add_hypothesis(self, state, blob):
-        # find_nearest_reading only ever returns ids <= 0 (:576-590), so the reference always
-        # ends here
-        self.add_orphaned_reading(state, blob)
+    def cross_readings(self, old_reading, new_reading):
+        """:688-737: intersection of the two LINES through the readings (also behind the observers), None when
+        they are parallel.  Line-line intersection through two points each, one unit step along the ray apart."""
+        x1, y1, h1 = _state_pose(old_reading[0])
+        h1 = h1 + old_reading[1].bearing
+        x2, y2 = x1 + math.cos(h1), y1 + math.sin(h1)
+        x3, y3, h3 = _state_pose(new_reading[0])
+        h3 = h3 + new_reading[1].bearing
+        x4, y4 = x3 + math.cos(h3), y3 + math.sin(h3)
+        d12, d34 = x1 * y2 - y1 * x2, x3 * y4 - x4 * y3
+        den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
+        if den == 0:
+            return None
+        return ((d12 * (x3 - x4) - (x1 - x2) * d34) / den, (d12 * (y3 - y4) - (y1 - y2) * d34) / den)
+
+    def add_orphaned_reading(self, state, blob):
+        """:739-746."""
+        self.hypothesis_set[self.next_id] = ((state, blob,))
+        self.next_id += 1
 
 
 # =============================================================================

@@ -2,6 +2,7 @@
 refuses to compute without a device (no CPU fallback), and its host-side RNG
 reproductions match NumPy / CPython bit for bit."""
 import ctypes
+import math
 import os
 import random
 import re
@@ -116,3 +117,73 @@ def test_reference_unavailable_is_only_a_skip():
     for fn in os.listdir(os.path.join(ROOT, "tests")):
         if fn.endswith(".py") and fn != "test_oracle_vs_reference_live.py":
             assert needle not in open(os.path.join(ROOT, "tests", fn)).read(), fn
+
+
+# ---- f4: the reference's own unit tests of the new-landmark geometry (test_prkt_ros2.py:228-381), restated on the
+# facade's host methods (prkt_core_v2.py:546-746); no GPU involved
+def _reading(pk, x=0.0, y=0.0, heading=None, bearing=0.0, rgb=(0, 0, 0)):
+    st = pk.msgs.Odometry()
+    st.pose.pose.position.x, st.pose.pose.position.y = x, y
+    if heading is not None:
+        st.pose.pose.orientation = pk.msgs.heading_to_quaternion(heading)
+    b = pk.msgs.Blob()
+    b.bearing = bearing
+    b.color.r, b.color.g, b.color.b = rgb
+    return st, b
+
+
+def test_find_nearest_reading_reference_test():
+    # test_prkt_ros2.py:228-274
+    import parakeet_slam_amd as pk
+
+    p = pk.FilterParticle()
+    p.potential_features[-1] = _reading(pk, bearing=.1)
+    q = _reading(pk, y=1, bearing=-.1)
+    assert p.find_nearest_reading(*q) == -1
+    p.potential_features[-3] = _reading(pk, y=1, bearing=-.1)  # parallel to the query
+    assert p.find_nearest_reading(*q) == -1
+    p.potential_features[-4] = _reading(pk, bearing=.1, rgb=(255, 255, 255))  # wrong colour
+    assert p.find_nearest_reading(*q) == -1
+    p.potential_features[-5] = p.potential_features[-4]
+    assert p.find_nearest_reading(*q) == -1
+    assert pk.FilterParticle().find_nearest_reading(*q) == 0  # nothing stored: :576
+
+
+def test_reading_distance_function_reference_test():
+    # test_prkt_ros2.py:276-311
+    import parakeet_slam_amd as pk
+
+    p = pk.FilterParticle()
+    a = _reading(pk)
+    assert p.reading_distance_function(*a, *_reading(pk, y=1)) == float("inf")               # parallel
+    assert p.reading_distance_function(*a, *_reading(pk, y=1, bearing=1.0)) == float("inf")  # diverging
+    assert p.reading_distance_function(*a, *_reading(pk, y=1, bearing=-1.0)) == 0.0
+    assert p.reading_distance_function(*a, *_reading(pk, y=1, bearing=-1.0, rgb=(5, 0, 0))) == 5.0
+
+
+def test_ray_intersect_and_cross_readings_reference_tests():
+    # test_prkt_ros2.py:313-346, :352-370
+    import parakeet_slam_amd as pk
+
+    p = pk.FilterParticle()
+    assert p.ray_intersect(0.0, 0.0, 0.0, 1.0, 0.0, math.pi / 2.0)
+    assert p.ray_intersect(0.0, 0.0, math.pi / 4, 1.0, 0.0, 3 * math.pi / 4)
+    assert not p.ray_intersect(0.0, 0.0, math.pi / 4, -1.0, 0.0, 3 * math.pi / 4)
+    old = _reading(pk)
+    got = p.cross_readings(old, _reading(pk, heading=math.pi / 2))
+    assert got is not None and got[0] == 0.0 and got[1] == 0.0
+    assert p.cross_readings(old, _reading(pk, y=-1.0, heading=0.0)) is None
+
+
+def test_add_hypothesis_files_orphans_and_add_new_feature_triangulates():
+    # :546-564 (always the orphan branch), :656-686
+    import parakeet_slam_amd as pk
+
+    p = pk.FilterParticle()
+    p.add_hypothesis(*_reading(pk, bearing=0.0, rgb=(10, 20, 30)))
+    p.add_hypothesis(*_reading(pk, y=1, bearing=-1.0))
+    assert sorted(p.hypothesis_set) == [1, 2] and p.next_id == 3 and not p.potential_features
+    p.add_new_feature(1, *_reading(pk, x=2.0, y=-2.0, heading=math.pi / 2, rgb=(30, 40, 50)))
+    f = p.potential_features[-3]
+    assert p.next_id == 4 and np.allclose(f.mean, [2.0, 0.0, 20, 30, 40], atol=1e-12) and np.array_equal(f.covar, np.identity(5))
+    assert p.get_feature_by_id(-3) is f

@@ -67,3 +67,64 @@ def test_resample_random_live(ref):
         u = random.Random(trial).random()
         anc = np.array([p._idx for p in fs.particles])
         assert np.array_equal(O.low_variance_ancestors(w, u), anc), trial
+
+
+def test_new_landmark_geometry_live(ref):
+    """f4 (prkt_core_v2.py:546-746): the facade's host restatement of the reading geometry against the live
+    reference on random readings.  The two sides extract the heading from the quaternion with different
+    (stubbed tf vs. closed form) arithmetic, hence the 1e-12 on the crossing point; verdicts must agree."""
+    from nav_msgs.msg import Odometry
+    from utils import heading_to_quaternion
+    from viz_feature_sim.msg import Blob
+
+    import parakeet_slam_amd.core as C
+
+    rs = np.random.RandomState(1)
+    rp, mp = ref.FilterParticle(), C.FilterParticle()
+
+    class IterDict(dict):  # py2 dict.iteritems, which prkt_core_v2.py:579 calls
+        def iteritems(self):
+            return iter(self.items())
+
+    rp.potential_features = IterDict()
+
+    def reading():
+        st = Odometry()
+        st.pose.pose.position.x, st.pose.pose.position.y = rs.uniform(-5, 5, 2)
+        st.pose.pose.orientation = heading_to_quaternion(rs.uniform(-3, 3))
+        b = Blob()
+        b.bearing = rs.uniform(-3, 3)
+        b.color.r, b.color.g, b.color.b = rs.uniform(0, 255, 3)
+        return st, b
+
+    crossing = 0
+    for i in range(1500):
+        a, b = reading(), reading()
+        want, got = rp.reading_distance_function(a[0], a[1], b[0], b[1]), mp.reading_distance_function(a[0], a[1], b[0], b[1])
+        assert want == got, i
+        crossing += want < float("inf")
+        assert rp.color_distance(a[1], b[1]) == mp.color_distance(a[1], b[1])
+        x, y = rp.cross_readings(a, b), mp.cross_readings(a, b)
+        assert np.allclose(x, y, rtol=1e-12, atol=1e-12), i
+        args = (rs.uniform(-3, 3), rs.uniform(-3, 3), a[1].bearing, rs.uniform(-3, 3), rs.uniform(-3, 3), b[1].bearing)
+        assert rp.ray_intersect(*args) == mp.ray_intersect(*args)
+    assert 200 < crossing < 1300
+    # the bookkeeping: orphans pile up, a stored reading in potential_features is found by its (negative) key
+    r1, r2, r3 = reading(), reading(), reading()
+    for p in (rp, mp):
+        p.add_hypothesis(*r1)
+        p.add_hypothesis(*r2)
+    assert sorted(rp.hypothesis_set) == sorted(mp.hypothesis_set) == [1, 2] and rp.next_id == mp.next_id == 3
+    for p in (rp, mp):
+        p.add_new_feature(1, *r3)
+    assert list(rp.potential_features) == list(mp.potential_features) == [-3]
+    assert np.array_equal(np.asarray(rp.potential_features[-3].covar), mp.potential_features[-3].covar)
+    assert np.allclose(np.asarray(rp.potential_features[-3].mean, dtype=float), mp.potential_features[-3].mean, rtol=1e-12)
+    # find_nearest_reading walks potential_features: the stored READINGS of the reference's own unit test (:228-274)
+    for p in (rp, mp):
+        p.potential_features.clear()
+        p.potential_features[-1] = r1
+        p.potential_features[-2] = r2
+    for k in range(50):
+        q = reading()
+        assert rp.find_nearest_reading(*q) == mp.find_nearest_reading(*q)
