@@ -1143,6 +1143,9 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
 // A particle in which a landmark passes more than kFastSlots blobs, or whose queue overflows in a round,
 // is flagged for the general kernels before anything of it has been written.
 constexpr int kRegsThreads = 1024;
+#ifndef PK_REGS_BOUND
+#define PK_REGS_BOUND kRegsThreads
+#endif
 constexpr int kRegsQueue = 1024;  // probability queue entries per settling round
 
 struct RegsArgs {
@@ -1166,9 +1169,12 @@ size_t regs_lds_bytes(int ncell, int B, int n9) {
   return tab + (((size_t)B * 4 + 15) & ~(size_t)15) + (size_t)B * 8 + (size_t)kRegsQueue * 36 + (size_t)kRegsQueue * 16 + 32;
 }
 
-// LDS of the candidate-list instance: the candidate records (32 B per landmark) stand where the grid tables stood
+// LDS of the candidate-list instance: where the grid tables stood, the lanes park the means of their two landmarks
+// (10 rows of 1024 doubles, 80 KB) between the phases that use them; the candidate records are read from L2
+constexpr size_t kRegsMeanPark = (size_t)10 * kRegsThreads * 8;
 size_t regs_cand_lds_bytes(int Lp, int B) {
-  return (size_t)Lp * 32 + (((size_t)B * 4 + 15) & ~(size_t)15) + (size_t)B * 8 + (size_t)kRegsQueue * 36 + (size_t)kRegsQueue * 16 + 32;
+  (void)Lp;
+  return kRegsMeanPark + (((size_t)B * 4 + 15) & ~(size_t)15) + (size_t)B * 8 + (size_t)kRegsQueue * 36 + (size_t)kRegsQueue * 16 + 32;
 }
 
 // Gates of one landmark (prkt_core_v2.py:433, :441) against the scan tables in LDS: the same walk as in
@@ -1501,7 +1507,7 @@ void debug_read_regs_stamps(unsigned long long* out, bool reset) {
 #endif
 
 template <bool CAND>
-__global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) {
+__global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kRegsThreads / kWave];
   __shared__ unsigned warm_dump[kWave];  // where the L2-warming loads of every wave land (never read)
@@ -1523,12 +1529,14 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
     Lp = R->f.Lp;
     L = R->f.L;
     lds.cs_bytes = CAND ? 0u : (unsigned)grid_cs_bytes(R->g.ncell);
-    lds.tab_bytes = CAND ? (unsigned)Lp * 32u : (unsigned)((lds.cs_bytes + (size_t)lds.B * 16 + (size_t)R->n9 * 2 + 15) & ~(size_t)15);
+    lds.tab_bytes = CAND ? (unsigned)kRegsMeanPark : (unsigned)((lds.cs_bytes + (size_t)lds.B * 16 + (size_t)R->n9 * 2 + 15) & ~(size_t)15);
     lds.best_off = lds.tab_bytes + (unsigned)(((size_t)lds.B * 4 + 15) & ~(size_t)15);
-    // the scan tables (grid walk) or the reference particle's candidate records: once per workgroup
-    const uint4* src = reinterpret_cast<const uint4*>(CAND ? reinterpret_cast<const unsigned char*>(R->cand) : R->tables);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (unsigned i = (unsigned)tid; i < lds.tab_bytes / 16; i += kRegsThreads) dst[i] = src[i];
+    // the scan tables of the grid walk: once per workgroup
+    if (!CAND) {
+      const uint4* src = reinterpret_cast<const uint4*>(R->tables);
+      uint4* dst = reinterpret_cast<uint4*>(smem);
+      for (unsigned i = (unsigned)tid; i < lds.tab_bytes / 16; i += kRegsThreads) dst[i] = src[i];
+    }
     const unsigned char* imm = R->f.immutable;
     immA = imm[min(tid, L - 1)] != 0;
     immB = imm[min(tid + kRegsThreads, L - 1)] != 0;
@@ -1538,7 +1546,6 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
   // never use or store it)
 
   for (int64_t p = blockIdx.x;; p += gridDim.x) {
-    double sx, sy;
     Landmark<double> A, Bq;
     // everything derived from the lane index is derived afresh for every particle: hoisted out of this loop
     // (LDS addresses, row offsets, queue-entry indices ...) those values filled the register file and spilled
@@ -1555,6 +1562,28 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
     auto row = [&](int f, unsigned off) {
       return *reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(sf + (size_t)f * Lp) + off);
     };
+    // Candidate lists: between the phases the means of the lane's two landmarks wait in LDS (each lane reads back what it
+    // wrote itself: no barrier involved), not in registers -- from the gates to the update they were the longest-lived
+    // values of the kernel, the ones the register allocator sent to scratch, and a scratch reload waits behind every row
+    // that is on its way from HBM (one in-order counter)
+    double* mpark = reinterpret_cast<double*>(smem);
+    auto park_means = [&](int h, const Landmark<double>& m) {
+      double* q = mpark + (size_t)(5 * h) * kRegsThreads + tid;
+      q[0 * kRegsThreads] = m.mx;
+      q[1 * kRegsThreads] = m.my;
+      q[2 * kRegsThreads] = m.mr;
+      q[3 * kRegsThreads] = m.mg;
+      q[4 * kRegsThreads] = m.mb;
+    };
+    auto unpark_means = [&](int h, Landmark<double>& m) {
+      const double* q = mpark + (size_t)(5 * h) * kRegsThreads + tid;
+      m.mx = q[0 * kRegsThreads];
+      m.my = q[1 * kRegsThreads];
+      m.mr = q[2 * kRegsThreads];
+      m.mg = q[3 * kRegsThreads];
+      m.mb = q[4 * kRegsThreads];
+    };
+    uint4 cA0 = {}, cA1 = {}, cB0 = {}, cB1 = {};  // the two landmarks' candidate records
     {
       RegsArgsPtr R = regs_args_now(rp);
       if (p >= R->P) break;
@@ -1562,8 +1591,6 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       const unsigned char* sslot = ss.at(R->f.src[p]);
       sf = reinterpret_cast<const double*>(sslot);
       sc = reinterpret_cast<const int*>(sslot + R->f.count_off);
-      sx = R->f.x[p];
-      sy = R->f.y[p];
       // ---- 1. the state is requested in three instalments, each one phase before it is needed (a row that is
       // requested now but used three phases later holds its registers all the way): the means of both landmarks
       // now, the first landmark's covariance rows behind its gates, the second one's behind the second gates
@@ -1577,6 +1604,10 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       Bq.mr = row(F_MR, oB);
       Bq.mg = row(F_MG, oB);
       Bq.mb = row(F_MB, oB);
+      if (CAND) {  // straight to their places in LDS: nothing of the state is held in a register across the zeroing and the barrier
+        park_means(0, A);
+        park_means(1, Bq);
+      }
     }
     {
       int* ccount = lds.ccount(smem);
@@ -1604,12 +1635,23 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       RegsArgsPtr R = regs_args_now(rp);
       const BlobGrid g = regs_blob_grid(R);
       const double* exact = R->f.exact;
-      const double sh = R->h[p];
+      // the particle's pose is read again in every phase that uses it (scalar loads, their own counter): kept in
+      // registers from the first phase to the last it was spilled to scratch, and scratch reloads queue behind the
+      // rows that are on their way from HBM
+      const double sx = R->f.x[p], sy = R->f.y[p], sh = R->h[p];
+      if (CAND) {  // the candidate records of both landmarks (L2), the first landmark's means
+        const uint4* crec = R->cand;
+        const int iA = 2 * min(lA, Lp - 1), iB = 2 * min(lB, Lp - 1);
+        cA0 = crec[iA];
+        cA1 = crec[iA + 1];
+        cB0 = crec[iB];
+        cB1 = crec[iB + 1];
+        unpark_means(0, A);
+      }
       PK_STAMP(r3)
       PK_RSTAMP(2, r2, r3)  // gate arguments (scalar loads)
       if (hasA) {
-        const uint4* crec = reinterpret_cast<const uint4*>(smem);
-        const RegsGated r = CAND ? regs_gates_cand(crec[2 * lA], crec[2 * lA + 1], exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh)
+        const RegsGated r = CAND ? regs_gates_cand(cA0, cA1, exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh)
                                  : regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, A.mx, A.my, A.mr, A.mg, A.mb, sx, sy, sh);
         pA01 = r.pass01;
         pA23 = r.pass23;
@@ -1636,9 +1678,9 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       if (!CAND) request_cov_a(pA01);
       PK_STAMP(r4)
       PK_RSTAMP(3, r3, r4)  // gates of the first landmark (waits for its means)
+      if (CAND) unpark_means(1, Bq);
       if (hasB) {
-        const uint4* crec = reinterpret_cast<const uint4*>(smem);
-        const RegsGated r = CAND ? regs_gates_cand(crec[2 * lB], crec[2 * lB + 1], exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh)
+        const RegsGated r = CAND ? regs_gates_cand(cB0, cB1, exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh)
                                  : regs_gates(g, lds.start(smem), lds.rec32(smem), lds.idx9(smem), exact, lds.ccount(smem), &wg_flag, Bq.mx, Bq.my, Bq.mr, Bq.mg, Bq.mb, sx, sy, sh);
         pB01 = r.pass01;
         pB23 = r.pass23;
@@ -1687,6 +1729,8 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
     PK_RSTAMP(6, r7, r8)  // warming requests, count of unseen blobs
     {
       RegsArgsPtr R = regs_args_now(rp);
+      const double sx = R->f.x[p], sy = R->f.y[p];
+      if (CAND) unpark_means(0, A);
       FastSlot sl[kFastSlots];
       const FastQueue fq = lds.queue(smem, lds.qn(smem));
       fast_prepare<false, int, kRegsQueue>(ra_unused.f, R->f.exact, A, sx, sy, pseA, hasA ? make_uint2(pA01, pA23) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), lds.ccount(smem), lds.best(smem), fq, sl);
@@ -1718,6 +1762,8 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
     PK_STAMP(r12)
     {
       RegsArgsPtr R = regs_args_now(rp);
+      const double sx = R->f.x[p], sy = R->f.y[p];
+      if (CAND) unpark_means(1, Bq);
       FastSlot sl[kFastSlots];
       const FastQueue fq = lds.queue(smem, lds.qn(smem) + 1);
       fast_prepare<false, int, kRegsQueue>(ra_unused.f, R->f.exact, Bq, sx, sy, pseB, hasB ? make_uint2(pB01, pB23) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), lds.ccount(smem), lds.best(smem), fq, sl);
@@ -1789,10 +1835,25 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
       const double* exact = R->f.exact;
       const unsigned short* order = R->f.order;
       const Noise<double> qt = regs_noise(R);
+      const double sx = R->f.x[p], sy = R->f.y[p];
       unsigned char* dslot = R->f.map_dst + (size_t)p * R->f.ss.slot_bytes;
       double* df = reinterpret_cast<double*>(dslot);
       int* dc = reinterpret_cast<int*>(dslot + R->f.count_off);
       Landmark<double> cur = A;
+      if (CAND) {
+        // the first landmark's means come back; where they stood, the rest of the second landmark waits out the first
+        // one's update (position block, expected bearing, blob and flag words): nothing of it is in a register then
+        unpark_means(0, cur);
+        asm volatile("" ::: "memory");  // the words below overwrite doubles that have just been read (type-based aliasing would let them pass)
+        double* q = mpark + tid;
+        q[0 * kRegsThreads] = Bq.pxx;
+        q[1 * kRegsThreads] = Bq.pxy;
+        q[2 * kRegsThreads] = Bq.pyy;
+        q[3 * kRegsThreads] = pseB;
+        reinterpret_cast<uint2*>(mpark + 4 * kRegsThreads)[tid] = make_uint2(pB01, pB23);  // the lane's own 8 bytes of the row
+        // (after fast_collect only the four flag bits of a slot's word are read)
+        reinterpret_cast<unsigned*>(park + 6 * kRegsThreads)[tid] = (qB01 & 0x000F000Fu) | ((qB23 & 0x000F000Fu) << 4);
+      }
       double pseC = pseA;
       unsigned pc01 = pA01, pc23 = pA23, qc01 = qA01, qc23 = qA23;
       bool immC = immA, hasC = hasA;
@@ -1809,14 +1870,25 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
           asm volatile("" : "+v"(off));
           regs_store_landmark(df, dc, Lp, off, cur);
         }
-        cur.mx = Bq.mx;
-        cur.my = Bq.my;
-        cur.mr = Bq.mr;
-        cur.mg = Bq.mg;
-        cur.mb = Bq.mb;
-        cur.pxx = Bq.pxx;
-        cur.pxy = Bq.pxy;
-        cur.pyy = Bq.pyy;
+        if (CAND) {
+          unpark_means(1, cur);
+        } else {
+          cur.mx = Bq.mx;
+          cur.my = Bq.my;
+          cur.mr = Bq.mr;
+          cur.mg = Bq.mg;
+          cur.mb = Bq.mb;
+        }
+        if (CAND) {
+          const double* q = mpark + tid;
+          cur.pxx = q[0 * kRegsThreads];
+          cur.pxy = q[1 * kRegsThreads];
+          cur.pyy = q[2 * kRegsThreads];
+        } else {
+          cur.pxx = Bq.pxx;
+          cur.pxy = Bq.pxy;
+          cur.pyy = Bq.pyy;
+        }
         cur.count = Bq.count;
         cur.crr = park[0 * kRegsThreads + tid];
         cur.crg = park[1 * kRegsThreads + tid];
@@ -1824,11 +1896,21 @@ __global__ void __launch_bounds__(kRegsThreads) k_step_regs(RegsArgs ra_unused) 
         cur.cgg = park[3 * kRegsThreads + tid];
         cur.cgb = park[4 * kRegsThreads + tid];
         cur.cbb = park[5 * kRegsThreads + tid];
-        pseC = pseB;
-        pc01 = pB01;
-        pc23 = pB23;
-        qc01 = qB01;
-        qc23 = qB23;
+        if (CAND) {
+          pseC = mpark[3 * kRegsThreads + tid];
+          const uint2 w = reinterpret_cast<const uint2*>(mpark + 4 * kRegsThreads)[tid];
+          pc01 = w.x;
+          pc23 = w.y;
+          const unsigned qp = reinterpret_cast<const unsigned*>(park + 6 * kRegsThreads)[tid];
+          qc01 = qp & 0x000F000Fu;
+          qc23 = (qp >> 4) & 0x000F000Fu;
+        } else {
+          pseC = pseB;
+          pc01 = pB01;
+          pc23 = pB23;
+          qc01 = qB01;
+          qc23 = qB23;
+        }
         immC = immB;
         hasC = hasB;
         lC = lB;
