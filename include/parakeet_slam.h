@@ -115,7 +115,7 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    -- k_candidates, once per scan -- instead of walking the colour grid; particles outside the
  *                    list's margins go the general way) or 0 (grid walk);
  *   "regs_warm"    = 0..2: how much of the NEXT particle's map slot k_step_regs touches ahead of time
- *                    (0 nothing -- the default: measured slower, DESIGN.md --, 1 the mean rows, 2 the whole slot) so that it waits in L2;
+ *                    (0 nothing, 1 the mean rows -- the default --, 2 the whole slot: measured slower) so that it waits in L2;
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */
 int pk_set_option(pk_filter* f, const char* name, int64_t value);
 

@@ -127,7 +127,7 @@ struct pk_filter {
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
   uint4* cand_dev = nullptr;  // [Lp][2] candidate records
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
-  int regs_warm = 0;     // k_step_regs: 0 no L2 warming of the next particle's slot (default: measured slower), 1 mean rows, 2 whole slot
+  int regs_warm = 1;     // k_step_regs: L2 warming of the next particle's slot: 0 none, 1 its mean rows (default), 2 the whole slot (measured slower)
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
   uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
   size_t sweep_cap = 0;

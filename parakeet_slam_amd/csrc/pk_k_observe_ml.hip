@@ -1437,6 +1437,12 @@ __device__ __forceinline__ void regs_store_landmark(double* df, int* dc, int Lp,
 // lanes, 340 v_readlane / v_writelane per particle): an empty asm makes the pointer opaque, so that nothing
 // loaded through it before is kept alive across it.
 typedef const __attribute__((address_space(4))) RegsArgs* RegsArgsPtr;
+// A particle's pose component through the constant address space: the poses are not written while this kernel runs, and
+// said so the (uniform) read becomes a scalar load -- its own counter, the scalar cache -- instead of a vector load that
+// queues behind the rows in flight.
+__device__ __forceinline__ double regs_pose(const double* a, int64_t p) {
+  return ((const __attribute__((address_space(4))) double*)a)[p];
+}
 __device__ __forceinline__ RegsArgsPtr regs_args_now(RegsArgsPtr rp) {
   asm volatile("" : "+s"(rp));
   return rp;
@@ -1638,7 +1644,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
       // the particle's pose is read again in every phase that uses it (scalar loads, their own counter): kept in
       // registers from the first phase to the last it was spilled to scratch, and scratch reloads queue behind the
       // rows that are on their way from HBM
-      const double sx = R->f.x[p], sy = R->f.y[p], sh = R->h[p];
+      const double sx = regs_pose(R->f.x, p), sy = regs_pose(R->f.y, p), sh = regs_pose(R->h, p);
       if (CAND) {  // the candidate records of both landmarks (L2), the first landmark's means
         const uint4* crec = R->cand;
         const int iA = 2 * min(lA, Lp - 1), iB = 2 * min(lB, Lp - 1);
@@ -1704,20 +1710,6 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
       lds_barrier();  // everybody has read the flag before the next particle clears it
       continue;
     }
-    {  // the next particle's map slot: one dword per 128-byte line, so that the lines wait in L2
-      RegsArgsPtr R = regs_args_now(rp);
-      const int warm = R->warm;
-      if (warm != 0 && p + gridDim.x < R->P) {
-        const SlotSource ss = regs_slot_source(R);
-        const size_t warm_lines = warm >= 2 ? ss.slot_bytes >> 7 : ((size_t)5 * Lp * 8 + 127) >> 7;  // slot_bytes: a multiple of 256
-        const unsigned char* nslot = ss.at(R->f.src[p + gridDim.x]);
-        for (size_t i = (size_t)tid; i < warm_lines; i += kRegsThreads)
-          // (address spaces spelled out: through generic pointers the builtin is accepted but M0, the LDS base of
-          // the transfer, is never set)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned*)(nslot + (i << 7)),
-                                           (__attribute__((address_space(3))) unsigned*)warm_dump, 4, 0, 0);
-      }
-    }
     // ---- 4. settling: one round per landmark of the lane -----------------------------------------------------
     int nun = 0;  // blobs no landmark passes
     {
@@ -1729,7 +1721,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
     PK_RSTAMP(6, r7, r8)  // warming requests, count of unseen blobs
     {
       RegsArgsPtr R = regs_args_now(rp);
-      const double sx = R->f.x[p], sy = R->f.y[p];
+      const double sx = regs_pose(R->f.x, p), sy = regs_pose(R->f.y, p);
       if (CAND) unpark_means(0, A);
       FastSlot sl[kFastSlots];
       const FastQueue fq = lds.queue(smem, lds.qn(smem));
@@ -1762,7 +1754,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
     PK_STAMP(r12)
     {
       RegsArgsPtr R = regs_args_now(rp);
-      const double sx = R->f.x[p], sy = R->f.y[p];
+      const double sx = regs_pose(R->f.x, p), sy = regs_pose(R->f.y, p);
       if (CAND) unpark_means(1, Bq);
       FastSlot sl[kFastSlots];
       const FastQueue fq = lds.queue(smem, lds.qn(smem) + 1);
@@ -1821,6 +1813,20 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
     double acc = (double)nun * Consts<double>::log_no_match;
     PK_STAMP(r16)
     PK_RSTAMP(11, r15, r16)  // bids: barriers, win, collect
+    {  // the next particle's map slot: one dword per 128-byte line, so that the lines wait in L2
+      RegsArgsPtr R = regs_args_now(rp);
+      const int warm = R->warm;
+      if (warm != 0 && p + gridDim.x < R->P) {
+        const SlotSource ss = regs_slot_source(R);
+        const size_t warm_lines = warm >= 2 ? ss.slot_bytes >> 7 : ((size_t)5 * Lp * 8 + 127) >> 7;  // slot_bytes: a multiple of 256
+        const unsigned char* nslot = ss.at(R->f.src[p + gridDim.x]);
+        for (size_t i = (size_t)tid; i < warm_lines; i += kRegsThreads)
+          // (address spaces spelled out: through generic pointers the builtin is accepted but M0, the LDS base of
+          // the transfer, is never set)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) unsigned*)(nslot + (i << 7)),
+                                           (__attribute__((address_space(3))) unsigned*)warm_dump, 4, 0, 0);
+      }
+    }
     // ---- 5. updates in scan order, stores: the first landmark, then the second ---------------------------------
     // (the second one's colour block waits in LDS meanwhile: the queue and its results are dead)
     double* park = lds.park(smem);
@@ -1835,7 +1841,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
       const double* exact = R->f.exact;
       const unsigned short* order = R->f.order;
       const Noise<double> qt = regs_noise(R);
-      const double sx = R->f.x[p], sy = R->f.y[p];
+      const double sx = regs_pose(R->f.x, p), sy = regs_pose(R->f.y, p);
       unsigned char* dslot = R->f.map_dst + (size_t)p * R->f.ss.slot_bytes;
       double* df = reinterpret_cast<double*>(dslot);
       int* dc = reinterpret_cast<int*>(dslot + R->f.count_off);
