@@ -1551,6 +1551,10 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
   // the lane's two landmarks: lA = tid and lB = tid + 1024 (lanes beyond the map re-read its last landmark and
   // never use or store it)
 
+  // The log-weight of a particle is finished one barrier late: the waves leave their partial sums in red[] and go on to
+  // request the next particle's rows; the barrier that separates the two particles' use of the LDS counters is passed
+  // with those requests in flight (the slowest wave's updates hide the others' first round trip).
+  int64_t prev = -1;  // the particle whose partial sums wait in red[] (-1: none, or it went to the general kernels)
   for (int64_t p = blockIdx.x;; p += gridDim.x) {
     Landmark<double> A, Bq;
     // everything derived from the lane index is derived afresh for every particle: hoisted out of this loop
@@ -1590,9 +1594,11 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
       m.mb = q[4 * kRegsThreads];
     };
     uint4 cA0 = {}, cA1 = {}, cB0 = {}, cB1 = {};  // the two landmarks' candidate records
+    bool done;
     {
       RegsArgsPtr R = regs_args_now(rp);
-      if (p >= R->P) break;
+      done = p >= R->P;
+      if (!done) {
       const SlotSource ss = regs_slot_source(R);
       const unsigned char* sslot = ss.at(R->f.src[p]);
       sf = reinterpret_cast<const double*>(sslot);
@@ -1610,11 +1616,29 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
       Bq.mr = row(F_MR, oB);
       Bq.mg = row(F_MG, oB);
       Bq.mb = row(F_MB, oB);
-      if (CAND) {  // straight to their places in LDS: nothing of the state is held in a register across the zeroing and the barrier
+      if (CAND) {
+        // straight to their places in LDS (the lane's own: whatever it kept there of the previous particle it has used): nothing
+        // of the state is held in a register across the barriers and the zeroing
         park_means(0, A);
         park_means(1, Bq);
       }
+      }
     }
+    lds_barrier();  // every wave is through with the previous particle: its bids have been read, its partial sums are in
+    if (prev >= 0 && tid == 0) {
+      RegsArgsPtr R = regs_args_now(rp);
+      double tot = red[0];
+#pragma unroll
+      for (int i = 1; i < kRegsThreads / kWave; ++i) tot += red[i];
+      double* logw = R->f.logw;
+      const double w = (R->f.reset ? 0.0 : logw[prev]) + tot;
+      logw[prev] = w;
+      unsigned long long* gk = R->f.gmax_key;
+      if (gk) atomicMax(gk + (prev & (kGmaxKeys - 1)), double_to_key(w));
+      R->f.src[prev] = (int32_t)prev;
+    }
+    if (done) break;
+    prev = -1;
     {
       int* ccount = lds.ccount(smem);
       unsigned long long* best = lds.best(smem);
@@ -1707,8 +1731,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
         R->pflag_out[p] = 1;
         atomicAdd(R->n_flagged, 1u);
       }
-      lds_barrier();  // everybody has read the flag before the next particle clears it
-      continue;
+      continue;  // (the barrier at the top of the next turn: everybody has read the flag before it is cleared)
     }
     // ---- 4. settling: one round per landmark of the lane -----------------------------------------------------
     int nun = 0;  // blobs no landmark passes
@@ -1776,7 +1799,6 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
         R->pflag_out[p] = 1;
         atomicAdd(R->n_flagged, 1u);
       }
-      lds_barrier();
       continue;
     }
     // which of the lane's blobs are contested (the counts then make room for the bids: win aliases ccount)
@@ -1924,15 +1946,10 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
     }
     PK_STAMP(r17)
     PK_RSTAMP(12, r16, r17)  // updates + stores issued
-    const double tot = block_sum_lds_only<kRegsThreads / kWave>(acc, red, tid);  // the stores stay in flight
-    if (tid == 0) {
-      RegsArgsPtr R = regs_args_now(rp);
-      double* logw = R->f.logw;
-      const double w = (R->f.reset ? 0.0 : logw[p]) + tot;
-      logw[p] = w;
-      unsigned long long* gk = R->f.gmax_key;
-      if (gk) atomicMax(gk + (p & (kGmaxKeys - 1)), double_to_key(w));
-      R->f.src[p] = (int32_t)p;
+    {
+      const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier (top of the loop)
+      if ((tid & (kWave - 1)) == 0) red[tid / kWave] = ws;
+      prev = p;
     }
     PK_STAMP(r18)
     PK_RSTAMP(13, r17, r18)  // block sum + tail
