@@ -364,6 +364,17 @@ void launch_observe_fast(hipStream_t s, DeviceState& d, int B, const double* exa
 //      general kernels and left untouched (nothing has been written by then);
 //   4. everything is settled and applied exactly as in k_observe_fast (the covariance rows were
 //      requested together with the means and arrived during the gates).
+// A particle's pose component through the constant address space: the poses are not written while this kernel runs, and
+// said so the (uniform) read becomes a scalar load -- its own counter, the scalar cache -- instead of a vector load that
+// queues behind the rows in flight.
+__device__ __forceinline__ double regs_pose(const double* a, int64_t p) {
+  return ((const __attribute__((address_space(4))) double*)a)[p];
+}
+// src[p] the same way: the entry is written by the kernels that read it, but only by the workgroup that owns particle p and
+// only after it has read it, so whichever copy a scalar cache holds is the current one.
+__device__ __forceinline__ int32_t regs_source(const int32_t* src, int64_t p) {
+  return ((const __attribute__((address_space(4))) int32_t*)src)[p];
+}
 struct FusedArgs {
   FastArgs f;                   // lmpass, bcount unused
   BlobGrid g;
@@ -445,13 +456,13 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
   unsigned long long* best = reinterpret_cast<unsigned long long*>(qbase + fast_queue_bytes());
   int* win = reinterpret_cast<int*>(best + B);
 
-  const unsigned char* sslot = a.ss.at(a.src[p]);
-  unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
-  const double* sf = reinterpret_cast<const double*>(sslot);
-  double* df = reinterpret_cast<double*>(dslot);
-  const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
-  int* dc = reinterpret_cast<int*>(dslot + a.count_off);
-  const double sx = a.x[p], sy = a.y[p], sh = fa.h[p];
+  // (the particle's own scalars -- src[p], its pose -- are fetched BEHIND the table requests: src[p] is a second, dependent
+  // scalar round trip that the table words do not have to wait for)
+  const double* sf;
+  double* df;
+  const int* sc;
+  int* dc;
+  double sx, sy, sh;
   const int l = tid;
   // ---- 1. tables -> LDS, own state ------------------------------------------------------------
   // All table words of the lane are requested in one batch (a copy loop of load / wait / LDS write
@@ -478,6 +489,17 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
       tw[j] = src[min(i, n16 - 1u)];
     }
     asm volatile("" ::: "memory");  // the table requests first: they come back first
+    {
+      const unsigned char* sslot = a.ss.at(regs_source(a.src, p));
+      unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+      sf = reinterpret_cast<const double*>(sslot);
+      df = reinterpret_cast<double*>(dslot);
+      sc = reinterpret_cast<const int*>(sslot + a.count_off);
+      dc = reinterpret_cast<int*>(dslot + a.count_off);
+      sx = regs_pose(a.x, p);
+      sy = regs_pose(a.y, p);
+      sh = regs_pose(fa.h, p);
+    }
     // unconditional too (lanes beyond the map read its last landmark and never use or store it):
     // straight-line code, so that the wait below is vmcnt(15) -- table words only
     A = load_landmark_means_first(sf, sc, Lp, min(l, Lp - 1));
@@ -1437,12 +1459,6 @@ __device__ __forceinline__ void regs_store_landmark(double* df, int* dc, int Lp,
 // lanes, 340 v_readlane / v_writelane per particle): an empty asm makes the pointer opaque, so that nothing
 // loaded through it before is kept alive across it.
 typedef const __attribute__((address_space(4))) RegsArgs* RegsArgsPtr;
-// A particle's pose component through the constant address space: the poses are not written while this kernel runs, and
-// said so the (uniform) read becomes a scalar load -- its own counter, the scalar cache -- instead of a vector load that
-// queues behind the rows in flight.
-__device__ __forceinline__ double regs_pose(const double* a, int64_t p) {
-  return ((const __attribute__((address_space(4))) double*)a)[p];
-}
 __device__ __forceinline__ RegsArgsPtr regs_args_now(RegsArgsPtr rp) {
   asm volatile("" : "+s"(rp));
   return rp;
