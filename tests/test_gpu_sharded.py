@@ -129,6 +129,25 @@ def _nccl_single(q):
         for s in range(2):
             sf.step(0.2, 0.1, 0.1, scans[s], 0.37, seed=3, draw=s, domain=1)
         sm = sf.summary()
+        # the global-scan plan (shards that end inside a scan block; bench.py's 100 000 particles per rank) through the same
+        # communicator: ancestors against the plain filter on the same weights
+        from parakeet_slam_amd import _lib
+
+        P2 = 1500
+        rs = np.random.RandomState(3)
+        poses = np.zeros((P2, 4))
+        poses[:, 3] = np.exp(rs.normal(0, 3, P2))
+        sg = ShardedFilter(P2, L, device=0, comm=comm, global_scan=True)
+        sg.upload_map(means, covs.reshape(L, 25))
+        sg.f.upload_poses(poses)
+        plain = _lib.DeviceFilter(P2, L)
+        plain.upload_map(means, covs.reshape(L, 25))
+        plain.upload_poses(poses)
+        for dom in (0, 1):
+            a = sg.resample(0.61, domain=dom, return_ancestors=True)
+            b = plain.resample(0.61, domain=dom, return_ancestors=True)
+            assert np.array_equal(a, b), "global-scan plan vs plain resample (domain %d)" % dom
+            assert np.array_equal(sg.download_poses(), plain.download_poses())
         dist.destroy_process_group()
         q.put(("ok", sm))
     except Exception:  # pragma: no cover
