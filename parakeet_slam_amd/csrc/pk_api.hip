@@ -125,7 +125,7 @@ struct pk_filter {
   uint4* brec_dev = nullptr;     // [bcand_cap] the lists
   int64_t bcand_cap = 0;
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
-  uint4* cand_dev = nullptr;  // [Lp][2] candidate records
+  uint4* cand_dev = nullptr;  // [Lp][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int regs_warm = 1;     // k_step_regs: L2 warming of the next particle's slot: 0 none, 1 its mean rows (default), 2 the whole slot (measured slower)
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
@@ -671,8 +671,20 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       fh.n_flagged = ctl_n_flagged(f);
     }
     Span t(f, PK_T_ASSOC);
+    CandTable cand;
+    if (fh.lmpass && f->cand_lists && f->d.lay.L < 65535) {
+      // the hand-off instance tests each landmark against the reference particle's candidate list (k_candidates, once per
+      // scan) instead of walking the colour grid; a list that overflows leaves the scan to the walk
+      if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
+      // (sixteen entries per list: with several thousand blobs around the robot eight overflow somewhere in every scan)
+      launch_candidates(f->stream, f->d, B, reinterpret_cast<const double*>(f->scan_dev + o_exact), 0, f->cand_dev, ctl_cand_over(f),
+                        nullptr, nullptr, nullptr, 2 * kCandSlots);
+      cand.rec = f->cand_dev;
+      cand.over = ctl_cand_over(f);
+      cand.slots = 2 * kCandSlots;
+    }
     launch_assoc_grid(f->stream, f->d, B, g, n9, f->scan_dev + o_tab, reinterpret_cast<const double*>(f->scan_dev + o_exact),
-                      f->ids_dev, finalize, fh);
+                      f->ids_dev, finalize, fh, cand);
     if (out) {
       out->fast = fh.lmpass != nullptr;
       out->exact = reinterpret_cast<const double*>(f->scan_dev + o_exact);
@@ -1308,7 +1320,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     FastHandoff fh = f->fh;
     fh.n_flagged = ctl_n_flagged(f);
     fh.flags_only = true;
-    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 2))) return rc;
+    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
     if (B > f->bcand_cap) {
       PK_HIP(hipStreamSynchronize(f->stream));
       if (f->bcnt_dev) (void)hipFree(f->bcnt_dev);
@@ -1350,7 +1362,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     CandTable cand;
     if (al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) {
       // the reference particle's candidate lists (particle 0 of the live generation), timed with the association
-      if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 2))) return rc;
+      if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
       Span t(f, PK_T_ASSOC);
       launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f));
       cand.rec = f->cand_dev;

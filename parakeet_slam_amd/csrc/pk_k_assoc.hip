@@ -163,6 +163,11 @@ struct AssocGridArgs {
   unsigned char* pflag;   // [P]      1 = general path
   const unsigned char* only_flagged;  // GENERAL instance: skip particles whose flag is 0
   unsigned* n_flagged;                // count of flagged particles (zeroed by the scan upload)
+  // hand-off instance: the candidate lists of a reference particle (CandTable, pk_kernels.hpp) stand in for the walk through
+  // the colour grid as long as no list overflowed (*cand_over == 0); NULL: always the grid
+  const uint4* cand_rec;
+  const unsigned* cand_over;
+  int cand_slots;  // kCandSlots (records of two uint4) or 2 kCandSlots (three)
 };
 
 // tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
@@ -219,6 +224,8 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
     uint4* dst = reinterpret_cast<uint4*>(smem);
     for (size_t i = threadIdx.x; i < tab_bytes / 16; i += THREADS) dst[i] = src[i];
   }
+  // hand-off instance: gates from the reference particle's candidate lists (workgroup-uniform choice, once per launch)
+  const bool use_cand = !GENERAL && ga.cand_rec != nullptr && *ga.cand_over == 0u;
   for (int64_t p = blockIdx.x; p < ga.P; p += gridDim.x) {
     if (GENERAL && ga.only_flagged && !ga.only_flagged[p]) continue;  // workgroup-uniform
     const unsigned char* slot = a.ss.at(a.src[p]);
@@ -310,6 +317,45 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
           ++npass;
         }
       };
+      if (!GENERAL && use_cand) {
+        // ---- candidate lists (k_step_regs' gates, pk_k_observe_ml.hip: regs_gates_cand): the landmark's expected bearing
+        // and colour must lie within the margins of the reference particle's -- else the particle goes the general way --
+        // and then only the listed blobs can pass; exact float64 gates on those, two records per L2 round trip
+        const bool wide = ga.cand_slots > kCandSlots;
+        const uint4* crec = ga.cand_rec + (wide ? 3 : 2) * (size_t)l;
+        const uint4 ref = crec[0], cl = crec[1];
+        uint4 cl2 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (wide) cl2 = crec[2];
+        const double deb = eb - (double)__uint_as_float(ref.x);  // 2 pi off: the other side of a branch cut, listed too
+        const bool inside = (fabs(deb) <= kCandBearing || fabs(deb - Consts<double>::two_pi) <= kCandBearing ||
+                             fabs(deb + Consts<double>::two_pi) <= kCandBearing) &&
+                            fabs(mr - (double)__uint_as_float(ref.y)) <= kCandColour &&
+                            fabs(mg - (double)__uint_as_float(ref.z)) <= kCandColour &&
+                            fabs(mb - (double)__uint_as_float(ref.w)) <= kCandColour;
+        if (!inside) wg_flag = 1;
+        unsigned c0 = cl.x, c1 = cl.y, c2 = cl.z, c3 = cl.w, c4 = cl2.x, c5 = cl2.y, c6 = cl2.z, c7 = cl2.w;  // filled from the front
+#pragma unroll 1
+        for (int k = 0; k < 2 * kCandSlots; k += 2) {
+          const int ta = (int)(c0 & 0xFFFFu), tb = (int)(c0 >> 16);
+          if (ta == 0xFFFF) break;
+          c0 = c1;
+          c1 = c2;
+          c2 = c3;
+          c3 = c4;
+          c4 = c5;
+          c5 = c6;
+          c6 = c7;
+          c7 = 0xFFFFFFFFu;
+          const double* ra = ga.exact + 6 * (size_t)ta;
+          const double* rb = ga.exact + 6 * (size_t)(tb == 0xFFFF ? ta : tb);
+          const double2 a01 = *reinterpret_cast<const double2*>(ra);
+          const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
+          const double2 b01 = *reinterpret_cast<const double2*>(rb);
+          const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
+          exact_gates(ta, a01, a23);
+          if (tb != 0xFFFF) exact_gates(tb, b01, b23);
+        }
+      } else {
       // ---- phase 1 (LDS only) ---------------------------------------------------------
       if (DUP) {
         // column (r, g) clamped into the grid: its list holds every blob within one cell in r
@@ -406,6 +452,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
           }
         }
       }
+      }  // grid walk
       if (!GENERAL) {
         const unsigned long long pb = (unsigned long long)__double_as_longlong(pse);
         if (SLOTS == 4) {
@@ -567,7 +614,7 @@ static void launch_assoc_grid_t(hipStream_t s, const AssocGridArgs& ga, size_t l
 
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev, bool finalize,
-                       const FastHandoff& fh) {
+                       const FastHandoff& fh, const CandTable& cand) {
   if (d.P == 0 || B == 0) return;
   AssocGridArgs ga;
   AssocArgs& a = ga.a;
@@ -594,6 +641,9 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   ga.pflag = fh.pflag;
   ga.n_flagged = fh.n_flagged;
   ga.only_flagged = nullptr;
+  ga.cand_rec = cand.rec;
+  ga.cand_over = cand.rec ? cand.over : nullptr;
+  ga.cand_slots = cand.slots;
   auto go = [&](auto general, auto slots) {
     constexpr bool G = decltype(general)::value;
     constexpr int S = decltype(slots)::value;
@@ -634,6 +684,12 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   }
 }
 
+void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev, bool finalize,
+                       const FastHandoff& fh) {
+  launch_assoc_grid(s, d, B, grid, n9, tables_dev, exact_dev, ids_dev, finalize, fh, CandTable{});
+}
+
 // ------------------------------------------------------------------ K2' candidate lists from a reference particle
 // See pk_kernels.hpp (CandTable).  A workgroup takes 64 landmarks of the reference particle; its sixteen waves share the
 // scan's blobs (uniform reads of the exact records), candidates are appended per landmark through LDS atomics.
@@ -642,7 +698,7 @@ struct CandArgs {
   const int32_t* src;
   const double *x, *y, *h;
   const double* exact;  // [B][6] in cell order: bearing, r, g, b, ux, uy
-  uint4* rec;           // [Lp][2]
+  uint4* rec;           // [Lp][2] (SLOTS = kCandSlots) or [Lp][3] (twice as many)
   unsigned* over;
   unsigned* bcnt;            // [B] entries of each blob's inverse list (cleared by the launcher), or NULL
   unsigned short* blist;     // [B][kCandSlots] landmarks listing each blob (0xFFFF-filled by the launcher)
@@ -651,8 +707,10 @@ struct CandArgs {
 };
 
 constexpr int kCandThreads = 1024;  // 64 landmarks x 16 waves that share the scan's blobs
+template <int SLOTS>
 __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
-  __shared__ unsigned short s_c[64][kCandSlots];
+  static_assert(SLOTS == kCandSlots || SLOTS == 2 * kCandSlots, "records of two or three uint4");
+  __shared__ unsigned short s_c[64][SLOTS];
   __shared__ int s_n[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int l = blockIdx.x * 64 + lane;
@@ -690,20 +748,23 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
     const bool near = fabs(db) <= tb || fabs(db - Consts<double>::two_pi) <= tb || fabs(db + Consts<double>::two_pi) <= tb;
     if (has && near && dr * dr + dg * dg + dc * dc <= tc) {
       const int n = atomicAdd(&s_n[lane], 1);
-      if (n < kCandSlots) s_c[lane][n] = (unsigned short)t;
+      if (n < SLOTS) s_c[lane][n] = (unsigned short)t;
     }
   }
   __syncthreads();
   if (w == 0 && l < a.Lp) {
     const int n = has ? s_n[lane] : 0;
-    unsigned short c[kCandSlots];
+    unsigned short c[SLOTS];
 #pragma unroll
-    for (int k = 0; k < kCandSlots; ++k) c[k] = k < n ? s_c[lane][k] : (unsigned short)0xFFFF;
-    a.rec[2 * (size_t)l] = make_uint4(__float_as_uint(ebf), __float_as_uint(rf), __float_as_uint(gf), __float_as_uint(bf));
-    a.rec[2 * (size_t)l + 1] = make_uint4((unsigned)c[0] | ((unsigned)c[1] << 16), (unsigned)c[2] | ((unsigned)c[3] << 16),
-                                          (unsigned)c[4] | ((unsigned)c[5] << 16), (unsigned)c[6] | ((unsigned)c[7] << 16));
-    if (n > kCandSlots) atomicAdd(a.over, 1u);
-    if (a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
+    for (int k = 0; k < SLOTS; ++k) c[k] = k < n ? s_c[lane][k] : (unsigned short)0xFFFF;
+    uint4* out = a.rec + (1 + SLOTS / 8) * (size_t)l;
+    out[0] = make_uint4(__float_as_uint(ebf), __float_as_uint(rf), __float_as_uint(gf), __float_as_uint(bf));
+#pragma unroll
+    for (int j = 0; j < SLOTS / 8; ++j)
+      out[1 + j] = make_uint4((unsigned)c[8 * j + 0] | ((unsigned)c[8 * j + 1] << 16), (unsigned)c[8 * j + 2] | ((unsigned)c[8 * j + 3] << 16),
+                              (unsigned)c[8 * j + 4] | ((unsigned)c[8 * j + 5] << 16), (unsigned)c[8 * j + 6] | ((unsigned)c[8 * j + 7] << 16));
+    if (n > SLOTS) atomicAdd(a.over, 1u);
+    if (SLOTS == kCandSlots && a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
       for (int k = 0; k < min(n, kCandSlots); ++k) {
         const unsigned t = s_c[lane][k];
         const unsigned m = atomicAdd(&a.bcnt[t], 1u);
@@ -725,8 +786,12 @@ __global__ void __launch_bounds__(256) k_cand_strays(const unsigned* bcnt, int B
 }
 
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
-                       unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev) {
+                       unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev, int slots) {
   if (d.P == 0 || d.lay.Lp == 0) return;
+  if (slots > kCandSlots) {  // the wide records carry no inverse lists
+    bcnt_dev = nullptr;
+    brec_dev = nullptr;
+  }
   if (bcnt_dev && brec_dev) {
     (void)hipMemsetAsync(bcnt_dev, 0, (size_t)B * sizeof(unsigned), s);
     (void)hipMemsetAsync(brec_dev, 0xFF, (size_t)B * sizeof(uint4), s);
@@ -746,7 +811,10 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
-  hipLaunchKernelGGL(k_candidates, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(kCandThreads), 0, s, a);
+  if (slots > kCandSlots)
+    hipLaunchKernelGGL(k_candidates<2 * kCandSlots>, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(kCandThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_candidates<kCandSlots>, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(kCandThreads), 0, s, a);
   if (a.bcnt && stray_dev) hipLaunchKernelGGL(k_cand_strays, dim3(1), dim3(256), 0, s, a.bcnt, B, stray_dev);
 }
 

@@ -172,10 +172,16 @@ struct CandTable {
   const uint4* brec = nullptr;        // [B] blob records (k_step_owner), or NULL
   const unsigned* over = nullptr;     // != 0: some list has more entries than slots -> grid walk for this scan
   const unsigned* n_stray = nullptr;  // blobs on no landmark's list
+  int slots = kCandSlots;             // entries per list: kCandSlots ([Lp][2] records) or twice that ([Lp][3]; no inverse lists)
 };
+// launch_assoc_grid whose hand-off instance takes its gates from the candidate lists (while no list overflowed)
+void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
+                       const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev,
+                       bool finalize, const FastHandoff& fh, const CandTable& cand);
 // bcnt_dev / brec_dev: NULL, or u32[B] / uint4[B] (cleared / filled with 0xFF by this call); stray_dev: their count
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
-                       unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr);
+                       unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr,
+                       int slots = kCandSlots);
 // K2 + K3 without synchronisation between the landmarks of a particle (pk_k_owner.hip): any L, any B whose candidate
 // lists fit; one 256-lane workgroup per particle.  Returns at once when *cand.over != 0.
 void launch_step_owner(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
