@@ -677,8 +677,9 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       // scan) instead of walking the colour grid; a list that overflows leaves the scan to the walk
       if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
       // (sixteen entries per list: with several thousand blobs around the robot eight overflow somewhere in every scan)
+      launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
       launch_candidates(f->stream, f->d, B, reinterpret_cast<const double*>(f->scan_dev + o_exact), 0, f->cand_dev, ctl_cand_over(f),
-                        nullptr, nullptr, nullptr, 2 * kCandSlots);
+                        nullptr, nullptr, nullptr, 2 * kCandSlots, f->out4);
       cand.rec = f->cand_dev;
       cand.over = ctl_cand_over(f);
       cand.slots = 2 * kCandSlots;
@@ -1336,7 +1337,9 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     CandTable cand;
     {
       Span t(f, PK_T_ASSOC);  // the reference particle's candidate lists, both ways
-      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f));
+      launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
+      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
+                        kCandSlots, f->out4);
     }
     cand.rec = f->cand_dev;
     cand.brec = f->brec_dev;
@@ -1364,7 +1367,8 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
       // the reference particle's candidate lists (particle 0 of the live generation), timed with the association
       if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
       Span t(f, PK_T_ASSOC);
-      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f));
+      launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
+      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
       cand.rec = f->cand_dev;
       cand.over = ctl_cand_over(f);
     }

@@ -704,6 +704,8 @@ struct CandArgs {
   unsigned short* blist;     // [B][kCandSlots] landmarks listing each blob (0xFFFF-filled by the launcher)
   int64_t ref;
   int L, Lp, B;
+  const double* pose4;  // sums of x, y, sin h, cos h over the P particles (k_summary_*): the reference POSE is their mean, or NULL
+  int64_t P;
 };
 
 constexpr int kCandThreads = 1024;  // 64 landmarks x 16 waves that share the scan's blobs
@@ -716,7 +718,16 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   const int l = blockIdx.x * 64 + lane;
   const unsigned char* slot = a.ss.at(a.src[a.ref]);
   const double* f = reinterpret_cast<const double*>(slot);
-  const double sx = a.x[a.ref], sy = a.y[a.ref], sh = a.h[a.ref];
+  // the reference: particle ref's MAP seen from the MEAN pose of the particles (circular mean of the heading, as summary
+  // :254-276 takes it) -- the particles' expected bearings scatter around it with their heading spread, and a particle
+  // drawn at random (particle 0 itself) sits one sigma off the middle: twice the margin for the same cloud
+  double sx = a.x[a.ref], sy = a.y[a.ref], sh = a.h[a.ref];
+  if (a.pose4) {
+    const double n = (double)a.P;
+    sx = a.pose4[0] / n;
+    sy = a.pose4[1] / n;
+    sh = atan2(a.pose4[2], a.pose4[3]);
+  }
   float ebf = 0.f, rf = 0.f, gf = 0.f, bf = 0.f;
   const bool has = l < a.L;
   if (has) {
@@ -786,7 +797,8 @@ __global__ void __launch_bounds__(256) k_cand_strays(const unsigned* bcnt, int B
 }
 
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
-                       unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev, int slots) {
+                       unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev, int slots,
+                       const double* pose_sums4_dev) {
   if (d.P == 0 || d.lay.Lp == 0) return;
   if (slots > kCandSlots) {  // the wide records carry no inverse lists
     bcnt_dev = nullptr;
@@ -808,6 +820,8 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.rec = rec_dev;
   a.over = over_dev;
   a.ref = ref_particle;
+  a.pose4 = pose_sums4_dev;
+  a.P = d.P;
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;

@@ -181,7 +181,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 // bcnt_dev / brec_dev: NULL, or u32[B] / uint4[B] (cleared / filled with 0xFF by this call); stray_dev: their count
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr,
-                       int slots = kCandSlots);
+                       int slots = kCandSlots, const double* pose_sums4_dev = nullptr);
 // K2 + K3 without synchronisation between the landmarks of a particle (pk_k_owner.hip): any L, any B whose candidate
 // lists fit; one 256-lane workgroup per particle.  Returns at once when *cand.over != 0.
 void launch_step_owner(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
