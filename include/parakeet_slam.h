@@ -114,6 +114,8 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "cand_lists"   = 1 (default: k_step_regs tests each landmark against the candidate list of a reference particle
  *                    -- k_candidates, once per scan -- instead of walking the colour grid; particles outside the
  *                    list's margins go the general way) or 0 (grid walk);
+ *   "regs_retry"   = 1 (default: particles k_step_regs flags -- a landmark passing more than four blobs -- get a second
+ *                    chance on the eight-slot hand-off + k_observe_sweep before the general kernels) or 0;
  *   "regs_warm"    = 0..2: how much of the NEXT particle's map slot k_step_regs touches ahead of time
  *                    (0 nothing, 1 the mean rows -- the default --, 2 the whole slot: measured slower) so that it waits in L2;
  *   "observe_landmarks_per_lane" = 0 (default), 1 or 2  (process-wide). */

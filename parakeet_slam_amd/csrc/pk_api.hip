@@ -127,6 +127,7 @@ struct pk_filter {
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
   uint4* cand_dev = nullptr;  // [Lp][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
+  int regs_retry = 1;    // k_step_regs: 1 = the particles it flags get a second chance (eight-slot hand-off + k_observe_sweep) before the general kernels
   int regs_warm = 1;     // k_step_regs: L2 warming of the next particle's slot: 0 none, 1 its mean rows (default), 2 the whole slot (measured slower)
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
   uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
@@ -502,6 +503,7 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
 struct AssocLaunch {
   bool fused = false;  // nothing launched yet: k_step_fused does gates + EKF in one kernel
   bool regs = false;   // nothing launched yet: k_step_regs does the same for 512 < L <= 2048
+  bool retry = false;  // with regs: the hand-off lists for the flagged particles' second chance are allocated
   bool owner = false;  // nothing launched yet: k_step_owner (candidate lists both ways, no barriers), any L
   BlobGrid grid{};
   int n9 = 0;
@@ -649,7 +651,10 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
     }
     if (out && want_fast && !finalize && f->fast_observe == 1 && f->regs_step && f->d.lay.L > kFastMaxL &&
         f->d.lay.L <= kRegsMaxL && B > 0 && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds) {
-      if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
+      // the flags, and -- when the two-sweep kernel can take this scan -- eight-slot hand-off lists for the second chance of
+      // the particles k_step_regs flags (allocated here, not at the first flagged particle in the middle of a run)
+      out->retry = f->regs_retry && observe_sweep_plan(f->d, B).grid > 0;
+      if ((rc = ensure_handoff(f, B, out->retry ? kSweepSlots : kFastSlots, out->retry))) return rc;
       out->regs = true;
       out->grid = g;
       out->n9 = n9;
@@ -1380,6 +1385,30 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
         launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand);
       else
         launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
+      if (al.regs && al.retry) {
+        // second chance for what k_step_regs flagged (some landmark passes more than its four register slots -- 2 us per
+        // particle in the general kernels, and up to 9 % of the particles at some poses of the bench's trajectory): the
+        // hand-off instance with eight slots and k_observe_sweep, both on the flagged particles only
+        const SweepPlan plan = observe_sweep_plan(f->d, B);
+        const size_t need = (size_t)plan.grid * plan.results_per_wg;
+        if (need > f->sweep_cap) {
+          PK_HIP(hipStreamSynchronize(f->stream));
+          if (f->sweep_results) (void)hipFree(f->sweep_results);
+          f->sweep_results = nullptr;
+          f->sweep_cap = 0;
+          if ((rc = dev_alloc(f, &f->sweep_results, need))) return rc;
+          f->sweep_cap = need;
+        }
+        FastHandoff fr = f->fh;
+        fr.slots = kSweepSlots;
+        fr.retry = true;
+        fr.n_flagged = ctl_n_flagged(f);
+        launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fr, cand);
+        ObserveExtras e3 = e1;
+        e3.sweep_only_value = 2;
+        e3.n_flagged = ctl_n_flagged(f);
+        launch_observe_sweep(f->stream, f->d, B, al.exact, al.order, fr, f->qt, e3, plan, f->sweep_results);
+      }
     }
     // the particles it flagged (a landmark passing more than kFastSlots blobs): general kernels,
     // both timed in the association slot
@@ -1517,6 +1546,11 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "regs_step")) {
     f->regs_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "regs_retry")) {
+    if (value != 0 && value != 1) return fail(PK_ERR_INVALID, "regs_retry: 0 or 1");
+    f->regs_retry = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "regs_warm")) {

@@ -168,6 +168,7 @@ struct AssocGridArgs {
   const uint4* cand_rec;
   const unsigned* cand_over;
   int cand_slots;  // kCandSlots (records of two uint4) or 2 kCandSlots (three)
+  int retry;       // hand-off instance: only the particles whose flag is 1; leaves 2 (handed off) or 1 (general kernels)
 };
 
 // tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
@@ -208,6 +209,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
   const BlobGrid& g = ga.g;
   const int B = a.B;
   if (GENERAL && ga.only_flagged && *ga.n_flagged == 0u) return;  // nothing was flagged
+  if (!GENERAL && ga.retry && *ga.n_flagged == 0u) return;
   const size_t cs_bytes = grid_cs_bytes(g.ncell);
   const size_t tab_bytes = cs_bytes + (size_t)B * 16 + (DUP ? (size_t)ga.n9 * 2 : 0);  // the part kept in LDS
   const unsigned short* start = reinterpret_cast<const unsigned short*>(smem);
@@ -227,7 +229,8 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
   // hand-off instance: gates from the reference particle's candidate lists (workgroup-uniform choice, once per launch)
   const bool use_cand = !GENERAL && ga.cand_rec != nullptr && *ga.cand_over == 0u;
   for (int64_t p = blockIdx.x; p < ga.P; p += gridDim.x) {
-    if (GENERAL && ga.only_flagged && !ga.only_flagged[p]) continue;  // workgroup-uniform
+    if (GENERAL && ga.only_flagged && ga.only_flagged[p] != 1) continue;  // workgroup-uniform
+    if (!GENERAL && ga.retry && ga.pflag[p] != 1) continue;
     const unsigned char* slot = a.ss.at(a.src[p]);
     const double* f = reinterpret_cast<const double*>(slot);
     const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
@@ -476,8 +479,12 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         ga.bcount[(size_t)p * B + t] = (unsigned char)(n > 255 ? 255 : n);
       }
       if (threadIdx.x == 0) {
-        ga.pflag[p] = (unsigned char)(wg_flag != 0);
-        if (wg_flag) atomicAdd(ga.n_flagged, 1u);
+        if (ga.retry) {  // (already counted by the kernel that flagged it)
+          ga.pflag[p] = (unsigned char)(wg_flag != 0 ? 1 : 2);
+        } else {
+          ga.pflag[p] = (unsigned char)(wg_flag != 0);
+          if (wg_flag) atomicAdd(ga.n_flagged, 1u);
+        }
       }
       __syncthreads();
       continue;  // k_observe_fast (or, if flagged, the GENERAL instance) takes it from here
@@ -644,6 +651,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   ga.cand_rec = cand.rec;
   ga.cand_over = cand.rec ? cand.over : nullptr;
   ga.cand_slots = cand.slots;
+  ga.retry = fh.retry ? 1 : 0;
   auto go = [&](auto general, auto slots) {
     constexpr bool G = decltype(general)::value;
     constexpr int S = decltype(slots)::value;
@@ -671,6 +679,8 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   if (fh.flags_only) {
     ga.only_flagged = fh.pflag;
     go(std::true_type{}, Slots4{});  // k_step_fused did the others
+  } else if (fh.lmpass && fh.retry) {
+    go(std::false_type{}, Slots8{});  // the flagged particles only; the caller runs the sweep and the general kernels
   } else if (fh.lmpass) {
     // gate tests + hand-off for every particle
     if (fh.slots == kSweepSlots)

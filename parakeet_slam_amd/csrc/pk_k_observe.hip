@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kObsThreads / kWave];
   const int64_t p = blockIdx.x;
-  if (a.only_flagged && (*a.n_flagged == 0u || !a.only_flagged[p])) return;  // workgroup-uniform
+  if (a.only_flagged && (*a.n_flagged == 0u || a.only_flagged[p] != 1)) return;  // workgroup-uniform
   const int tid = threadIdx.x;
   const int32_t sp = a.src[p];
   const unsigned char* sslot = a.ss.at(sp);

@@ -804,6 +804,8 @@ struct SweepArgs {
   int reset;
   unsigned long long* gmax_key;
   Noise<double> qt;
+  int only_value;               // 0: the particles whose flag is 0; else only the particles with this flag (second chance, 2)
+  const unsigned* n_flagged;    // with only_value: nothing to do when 0
 };
 
 __host__ __device__ inline size_t sweep_lds_bytes(int B, int qcap) {
@@ -855,8 +857,9 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
   unsigned char* bc = reinterpret_cast<unsigned char*>(win + B);
   uint4* results = a.results + (size_t)blockIdx.x * SLOTS * (size_t)Lp;
 
+  if (a.only_value && *a.n_flagged == 0u) return;
   for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
-    if (a.pflag[p]) continue;  // workgroup-uniform: the general kernels take this particle
+    if (a.only_value ? a.pflag[p] != a.only_value : a.pflag[p] != 0) continue;  // workgroup-uniform: not this launch's particle
     const unsigned char* sslot = a.ss.at(a.src[p]);
     unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
     const double* sf = reinterpret_cast<const double*>(sslot);
@@ -1126,6 +1129,8 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
   a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
+  a.only_value = ex.sweep_only_value;
+  a.n_flagged = ex.n_flagged;
   // never more workgroups than are resident at once (results_dev is sized for plan.grid)
   static size_t asked_lds = ~(size_t)0;
   static int asked_per_cu = 0;

@@ -99,14 +99,19 @@ struct FastHandoff {
   int slots = 4;                    // gate-passing blobs a landmark can hand over: kFastSlots or kSweepSlots
   bool flags_only = false;          // pflag / n_flagged come from k_step_fused: run the general instance on the flagged only
   unsigned char* bcount = nullptr;  // [P][B]
-  unsigned char* pflag = nullptr;   // [P]
+  unsigned char* pflag = nullptr;   // [P] 0: done by the fast kernel, 1: for the general kernels, 2: handed off on the second chance
   unsigned* n_flagged = nullptr;    // number of flagged particles of this scan
+  // Second chance for the particles a one-pass kernel flagged (a landmark passing more than its four register slots): the
+  // hand-off instance with eight slots works on the particles whose flag is 1 only and leaves 2 where it succeeded (for
+  // k_observe_sweep, ObserveExtras::sweep_only_value) and 1 where not even eight slots do (general kernels).
+  bool retry = false;
 };
 constexpr int kGmaxKeys = 256;  // the running max of the log-weights is kept in this many keys (one scan-block thread each)
 // Optional behaviour of one observe launch.
 struct ObserveExtras {
-  const unsigned char* only_flagged = nullptr;  // general kernel: only the particles flagged by the fast path
+  const unsigned char* only_flagged = nullptr;  // general kernel: only the particles flagged by the fast path (flag == 1)
   const unsigned* n_flagged = nullptr;
+  int sweep_only_value = 0;                     // k_observe_sweep: 0 = the particles whose flag is 0, else only those with this flag
   bool flip = true;                             // swap the map buffers after this launch
   bool reset = false;                           // weights restart from 1 (fused pk_reset_weights)
   unsigned long long* gmax_key = nullptr;       // keep the running max of the new log-weights here

@@ -291,6 +291,41 @@ def test_sweep_observe_up_to_eight_blobs_per_landmark_and_beyond(lib):
     check_fast(lib, 5, means, covs, poses, blobs2)
 
 
+def test_regs_flagged_particles_get_a_second_chance_before_the_general_kernels(lib):
+    """k_step_regs keeps four gate-passing blobs per landmark in registers; particles in which some landmark passes more are
+    flagged.  With "regs_retry" (default) they go through the eight-slot hand-off + k_observe_sweep, without it through the
+    general kernels: same maps, weights to rounding, and the oracle's."""
+    rs = np.random.RandomState(17)
+    L = 1400
+    means, covs = synthetic_world(L)
+    g = np.arange(L // 7)
+    lattice = np.stack([g % 6, (g // 6) % 6, g // 36], axis=1) * 40.0 + 10.0
+    means[:, 2:] = np.repeat(lattice, 7, axis=0) + rs.uniform(-2, 2, (L, 3))
+    perm = rs.permutation(L)
+    means, covs = means[perm], covs[perm]
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    P = 6
+    poses = rand_poses(rs, P, 0.1)
+    assert 5 <= max_passers(means, blobs, poses) <= 8
+    out = {}
+    for retry in (1, 0):
+        f = lib.DeviceFilter(P, L)
+        f.set_option("regs_retry", retry)
+        f.upload_map(means, covs.reshape(L, 25))
+        f.upload_poses(poses)
+        f.observe(blobs)
+        assert f.observe_route() == "ml_regs" and f.observe_flagged()[0] == P  # every particle has such a landmark
+        out[retry] = (f.download_poses(), f.download_landmarks())
+        f.close()
+    a, b = out[1], out[0]
+    assert np.array_equal(a[0][:, :3], b[0][:, :3]) and np.allclose(a[0][:, 3], b[0][:, 3], rtol=1e-11, atol=0)
+    assert np.allclose(a[1][0], b[1][0], rtol=1e-12, atol=1e-14) and np.allclose(a[1][1], b[1][1], rtol=1e-11, atol=1e-15)
+    assert np.array_equal(a[1][2], b[1][2])
+    o = oracle_state(P, means, covs, poses, blobs)
+    assert np.allclose(a[0][:, 3], o.weights(), rtol=1e-9, atol=0)
+    assert np.allclose(a[1][0], o.mean, rtol=1e-10, atol=1e-12) and np.array_equal(a[1][2], o.count)
+
+
 def test_sweep_observe_everything_contested_across_chunks(lib):
     # three bearing neighbours share each colour: every blob is contested by three landmarks, the
     # rivals sit in other landmark chunks (permuted order), and there are more contested pairs
