@@ -49,6 +49,10 @@ typedef enum pk_status {
 } pk_status;
 
 /* weight_domain of pk_resample */
+/* Flag in a landmark's count word (pk_upload_landmarks / pk_download_landmarks): a POTENTIAL feature -- the reference's
+ * negative ids, prkt_core_v2.py:109-118: matched and updated like any landmark, but a match multiplies the particle's
+ * weight by 0.1 instead of the importance factor; the kernels clear the flag when the update count passes 5 (:113-117). */
+#define PK_LANDMARK_POTENTIAL 0x40000000
 #define PK_WEIGHTS_LINEAR 0 /* w = exp(logw): the reference's quantity, underflows like it */
 #define PK_WEIGHTS_LOG 1    /* w = exp(logw - max logw): same ancestors unless the former underflows */
 

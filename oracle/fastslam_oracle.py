@@ -282,6 +282,8 @@ class OracleFilter(object):
         )
         self.Qt = 0.1 * np.identity(4) if Qt is None else np.asarray(Qt, dtype=np.float64)
         self.n_unmatched = np.zeros(P, dtype=np.int64)  # next_id growth, :745-746
+        # potential features (negative ids in the reference, :109-118): matched and updated, weigh 0.1, promoted at count > 5
+        self.potential = np.zeros((P, self.L), dtype=bool)
 
     # -- a2 -----------------------------------------------------------------
     @staticmethod
@@ -366,7 +368,10 @@ class OracleFilter(object):
             self.mean[pi[mut], li[mut]] = nm[mut]
             self.cov[pi[mut], li[mut]] = nc[mut]
             self.count[pi[mut], li[mut]] += 2  # :914 and :930
-            self.logw[pi] += aux["logweight"]
+            pot = self.potential[pi, li]
+            self.logw[pi] += np.where(pot, math.log(NO_MATCH_WEIGHT), aux["logweight"])  # :111-112 / :121
+            promote = pot & (self.count[pi, li] > 5)  # :113-117
+            self.potential[pi[promote], li[promote]] = False
         return ids
 
     def reset_weights(self):
@@ -400,6 +405,7 @@ class OracleFilter(object):
         self.mean = self.mean[anc]
         self.cov = self.cov[anc]
         self.count = self.count[anc]
+        self.potential = self.potential[anc]
         self.n_unmatched = self.n_unmatched[anc]
 
     # -- a14 ----------------------------------------------------------------

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(HERE, "libparakeet_slam.so")
 PK_OK = 0
 PK_ERR_INVALID, PK_ERR_HIP, PK_ERR_STATE, PK_ERR_UNSUPPORTED, PK_ERR_NOMEM = -1, -2, -3, -4, -5
 PK_WEIGHTS_LINEAR, PK_WEIGHTS_LOG = 0, 1
+PK_LANDMARK_POTENTIAL = 0x40000000  # flag in a landmark's count word: potential feature (prkt_core_v2.py:109-118)
 PK_T_NAMES = ("motion", "assoc", "observe", "weights", "resample", "summary", "materialise")
 PK_T_COUNT = len(PK_T_NAMES)
 PK_PROBE_LEN = 79

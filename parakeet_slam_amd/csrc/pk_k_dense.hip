@@ -130,7 +130,8 @@ __device__ __forceinline__ double dense_ekf_update(DenseLm& f, double sx, double
   double maha = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) maha += d[i] * (Qi[4 * i] * d[0] + Qi[4 * i + 1] * d[1] + Qi[4 * i + 2] * d[2] + Qi[4 * i + 3] * d[3]);
-  const double logw = -0.5 * (Consts<double>::log_two_pi + 0.5 * log(fro2)) - 0.5 * maha;
+  double logw = -0.5 * (Consts<double>::log_two_pi + 0.5 * log(fro2)) - 0.5 * maha;
+  if (f.count & kPotentialBit) logw = Consts<double>::log_no_match;  // :111-112
   if (aux) {
     aux->zhat0 = zhat0;
     aux->h0 = h0;
@@ -149,7 +150,7 @@ __device__ __forceinline__ double dense_ekf_update(DenseLm& f, double sx, double
         N[5 * i + j] = f.S[5 * i + j] - (K[4 * i] * HS[j] + K[4 * i + 1] * HS[5 + j] + K[4 * i + 2] * HS[10 + j] + K[4 * i + 3] * HS[15 + j]);
 #pragma unroll
     for (int i = 0; i < 25; ++i) f.S[i] = N[i];
-    f.count += 2;  // :914 and :930
+    count_update(f.count);
   }
   return logw;
 }

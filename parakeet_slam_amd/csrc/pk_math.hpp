@@ -28,8 +28,18 @@ struct Landmark {
   T mx, my, mr, mg, mb;
   T pxx, pxy, pyy;
   T crr, crg, crb, cgg, cgb, cbb;
-  int count;
+  int count;  // update_count | kPotentialBit
 };
+
+// A POTENTIAL feature (the reference's negative ids, prkt_core_v2.py:109-118): matched and updated like any landmark, but
+// the particle's weight takes the unmatched-blob factor instead of the importance factor, until its update count passes
+// 5 and it joins the full feature set (:113-117).  The flag rides in the count word (PK_LANDMARK_POTENTIAL in the header):
+// every kernel only ever adds 2 to that word, so it travels through all of them unchanged.
+constexpr int kPotentialBit = 0x40000000;
+__device__ __forceinline__ void count_update(int& count) {
+  count += 2;  // :914 and :930
+  if ((count & kPotentialBit) && (count & ~kPotentialBit) > 5) count &= ~kPotentialBit;  // :113-117 promotion
+}
 
 // Measurement noise Qt (prkt_core_v2.py:50-53) in the same block structure.
 template <typename T>
@@ -258,6 +268,7 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
   T v2 = qci.c * d1 + qci.e * d2 + qci.f * d3;
   T maha = d0 * d0 * iq00 + (d1 * v0 + d2 * v1 + d3 * v2);
   T logw = T(-0.5) * (Consts<T>::log_two_pi + T(0.5) * log_few_ulp(fro2)) - T(0.5) * maha;
+  if (f.count & kPotentialBit) logw = (T)Consts<double>::log_no_match;  // :111-112 "update as if the feature not seen"
   T k0 = a0 * iq00, k1 = a1 * iq00;
 
   if (aux) {
@@ -324,7 +335,7 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
     f.cgg = ngg;
     f.cgb = ngb;
     f.cbb = nbb;
-    f.count += 2;  // :914 and :930
+    count_update(f.count);
   }
   return logw;
 }
