@@ -427,6 +427,109 @@ class OracleFilter(object):
 
 
 # ----------------------------------------------------------------------------
+# f4: new-landmark machinery (prkt_core_v2.py:546-746)
+# ----------------------------------------------------------------------------
+EMPTY_COLOUR = 2.0 ** 100  # colour of a landmark slot that holds nothing yet: fails every colour gate (:441), exact in float32
+
+
+def ray_intersect(x1, y1, b1, x3, y3, b3):
+    """:611-643 -- do the half-lines meet (both ray parameters >= 0)."""
+    ax, ay = math.cos(b1), math.sin(b1)
+    bx, by = math.cos(b3), math.sin(b3)
+    den = ay * bx - ax * by
+    if den == 0:
+        return False
+    v = (ax * y3 - ay * x3 + ay * x1 - ax * y1) / den
+    if abs(ay) < abs(ax):
+        u = (x3 + bx * v - x1) / ax
+    else:
+        u = (y3 + by * v - y1) / ay
+    return u >= 0 and v >= 0
+
+
+def colour_distance(c1, c2):
+    """:645-654."""
+    return math.sqrt(math.pow(c1[0] - c2[0], 2) + math.pow(c1[1] - c2[1], 2) + math.pow(c1[2] - c2[2], 2))
+
+
+def cross_readings(x1, y1, h1, x3, y3, h3):
+    """:688-737 -- intersection of the two LINES (world bearings h1, h3), None when parallel."""
+    x2, y2 = x1 + math.cos(h1), y1 + math.sin(h1)
+    x4, y4 = x3 + math.cos(h3), y3 + math.sin(h3)
+    t0, t3 = x1 * y2 - y1 * x2, x3 * y4 - x4 * y3
+    den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
+    if den == 0:
+        return None
+    return ((t0 * (x3 - x4) - (x1 - x2) * t3) / den, (t0 * (y3 - y4) - (y1 - y2) * t3) / den)
+
+
+class GrowingOracle(object):
+    """OracleFilter with spare landmark slots and the new-landmark bookkeeping of :546-746 per particle, with the ONE change
+    that makes it work: ``find_nearest_reading`` walks the orphaned readings (``hypothesis_set``), not
+    ``potential_features`` (:579), and a reading pairs with the nearest stored one -- rays crossing, colour distance
+    below ``pair_threshold`` -- as the docstring at :566-575 describes.  A pair becomes a potential feature at the rays'
+    crossing (:656-686: mean colour, identity covariance) in the particle's next spare slot; potential features match and
+    update, weigh 0.1 and are promoted past update_count 5 (:109-118, in OracleFilter.observe).  The stored reading stays
+    (the reference never removes one)."""
+
+    def __init__(self, num_particles, means, covs, spare, pair_threshold):
+        means = np.asarray(means, dtype=np.float64).reshape(-1, 5)
+        L0 = means.shape[0]
+        covs = np.asarray(covs, dtype=np.float64).reshape(L0, 5, 5)
+        em = np.zeros((spare, 5))
+        em[:, 2:] = EMPTY_COLOUR
+        ec = np.broadcast_to(np.identity(5), (spare, 5, 5))
+        self.f = OracleFilter(num_particles, np.vstack([means, em]), np.concatenate([covs, ec]))
+        self.L0, self.spare, self.thr = L0, spare, float(pair_threshold)
+        P = int(num_particles)
+        self.hyp = [[] for _ in range(P)]        # per particle: (id, x, y, heading, bearing, r, g, b)
+        self.next_id = [L0 + 1] * P              # :298
+        self.used = [0] * P                      # spare slots in use
+        self.slot_id = [dict() for _ in range(P)]  # spare slot -> feature id (potential: the reference's -id)
+
+    def add_hypothesis(self, i, blob):
+        f = self.f
+        x, y, h = float(f.x[i]), float(f.y[i]), float(f.h[i])
+        best, best_d = None, float("inf")
+        for rd in self.hyp[i]:
+            if not ray_intersect(rd[1], rd[2], rd[4] + rd[3], x, y, blob[0] + h):
+                continue
+            d = colour_distance(rd[5:8], blob[1:4])
+            if d < best_d:
+                best, best_d = rd, d
+        if best is not None and best_d < self.thr and self.used[i] < self.spare:
+            xy = cross_readings(best[1], best[2], best[3] + best[4], x, y, h + blob[0])
+            if xy is not None:
+                slot = self.L0 + self.used[i]
+                self.used[i] += 1
+                f.mean[i, slot] = (xy[0], xy[1], (best[5] + blob[1]) / 2, (best[6] + blob[2]) / 2, (best[7] + blob[3]) / 2)
+                f.cov[i, slot] = np.identity(5)
+                f.count[i, slot] = 0
+                f.potential[i, slot] = True
+                self.slot_id[i][slot] = self.next_id[i]
+                self.next_id[i] += 1
+                return
+        self.hyp[i].append((self.next_id[i], x, y, h, float(blob[0]), float(blob[1]), float(blob[2]), float(blob[3])))
+        self.next_id[i] += 1
+
+    def observe(self, blobs):
+        """:84-124 for every particle: association + updates, then the unmatched blobs in scan order (:92-95)."""
+        blobs = np.asarray(blobs, dtype=np.float64).reshape(-1, 4)
+        ids = self.f.observe(blobs)
+        for i in range(self.f.P):
+            for b in np.nonzero(ids[i] == 0)[0]:
+                self.add_hypothesis(i, blobs[b])
+        return ids
+
+    def gather(self, anc):
+        self.f.gather(anc)
+        self.hyp = [list(self.hyp[a]) for a in anc]
+        self.next_id = [self.next_id[a] for a in anc]
+        self.used = [self.used[a] for a in anc]
+        self.slot_id = [dict(self.slot_id[a]) for a in anc]
+
+
+# ----------------------------------------------------------------------------
 # synthetic scene (SURVEY 8d)
 # ----------------------------------------------------------------------------
 def synthetic_world(L, seed=123):

@@ -351,10 +351,13 @@ class FilterParticle(object):
         """:688-737: intersection of the two LINES through the readings (also behind the observers), None when
         they are parallel.  Line-line intersection through two points each, one unit step along the ray apart."""
         x1, y1, h1 = _state_pose(old_reading[0])
-        h1 = h1 + old_reading[1].bearing
-        x2, y2 = x1 + math.cos(h1), y1 + math.sin(h1)
         x3, y3, h3 = _state_pose(new_reading[0])
-        h3 = h3 + new_reading[1].bearing
+        return self._cross_lines(x1, y1, h1 + old_reading[1].bearing, x3, y3, h3 + new_reading[1].bearing)
+
+    @staticmethod
+    def _cross_lines(x1, y1, h1, x3, y3, h3):
+        """The arithmetic of cross_readings on plain numbers (world-frame bearings h1, h3)."""
+        x2, y2 = x1 + math.cos(h1), y1 + math.sin(h1)
         x4, y4 = x3 + math.cos(h3), y3 + math.sin(h3)
         d12, d34 = x1 * y2 - y1 * x2, x3 * y4 - x4 * y3
         den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
@@ -415,10 +418,20 @@ class FastSLAM(object):
     ``random.random()`` -- the reference's own streams, so ``np.random.seed(s);
     random.seed(s)`` reproduces the reference bit for bit in the draws;
     rng="device": Philox noise generated on the GPU (no host->device upload).
+
+    new_landmarks=True (with spare_landmarks=S slots per particle): the new-landmark initialisation of :546-746 and the
+    potential-feature rule of :109-118, made to work (in the reference ``find_nearest_reading`` walks
+    ``potential_features`` where the readings are in ``hypothesis_set``, so nothing is ever paired): an unmatched blob is
+    paired with the nearest stored reading of the particle -- rays crossing, colour distance below ``pair_threshold`` --
+    and becomes a potential feature at the crossing, else it is stored as an orphaned reading.  Matching, the EKF
+    update, the 0.1 weight of a potential feature and its promotion past update_count 5 run in the device kernels (a
+    flag in the landmark's count word); the per-unmatched-blob bookkeeping is host work per particle, as in the reference.
     """
 
+    EMPTY_COLOUR = 2.0 ** 100  # colour of a spare slot that holds nothing yet: fails every colour gate (:441), exact in float32
+
     def __init__(self, preset_features=[], num_particles=50, device=0, weight_domain="linear", rng="global",
-                 seed=0, publish_debug=None):
+                 seed=0, publish_debug=None, new_landmarks=False, spare_landmarks=0, pair_threshold=30.0):
         self._lock = threading.RLock()
         self.last_control = Twist()
         self.last_update = msgs.now()
@@ -427,12 +440,27 @@ class FastSLAM(object):
         self._features = list(preset_features)
         self._ids = list(range(1, len(self._features) + 1))  # load_feature_list :294-299
         L = len(self._features)
-        self._filter = _lib.DeviceFilter(self.num_particles, L, device=self._device)
-        if L:
-            means = np.array([np.asarray(f.mean, dtype=np.float64).reshape(5) for f in self._features])
-            covs = np.array([np.asarray(f.covar, dtype=np.float64).reshape(25) for f in self._features])
-            imm = np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8)
+        self._grow = bool(new_landmarks)
+        self._spare = int(spare_landmarks) if self._grow else 0
+        self._pair_threshold = float(pair_threshold)
+        self._L0 = L
+        self._filter = _lib.DeviceFilter(self.num_particles, L + self._spare, device=self._device)
+        if L + self._spare:
+            means = np.zeros((L + self._spare, 5))
+            covs = np.tile(np.identity(5).reshape(25), (L + self._spare, 1))
+            imm = np.zeros(L + self._spare, dtype=np.uint8)
+            if L:
+                means[:L] = np.array([np.asarray(f.mean, dtype=np.float64).reshape(5) for f in self._features])
+                covs[:L] = np.array([np.asarray(f.covar, dtype=np.float64).reshape(25) for f in self._features])
+                imm[:L] = np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8)
+            means[L:, 2:] = self.EMPTY_COLOUR
             self._filter.upload_map(means, covs, imm)
+        P = self.num_particles
+        # per-particle host bookkeeping of the growing mode (follows the particles through every resample)
+        self._hyp = [[] for _ in range(P)]            # orphaned readings: (id, x, y, heading, bearing, r, g, b)  (:739-746)
+        self._next_id = [L + 1] * P                   # FilterParticle.next_id (:298)
+        self._used = [0] * P                          # spare slots in use
+        self._slot_id = [dict() for _ in range(P)]    # spare slot -> feature id
         self.Qt = _default_Qt()
         self._domain = {"linear": _lib.PK_WEIGHTS_LINEAR, "log": _lib.PK_WEIGHTS_LOG}[weight_domain]
         if rng not in ("global", "device"):
@@ -471,21 +499,37 @@ class FastSLAM(object):
             p.weight = float(w)
             p.Qt = self.Qt
             p._device = self._device
-            p.next_id = len(self._ids) + 1
+            p.next_id = self._next_id[i]
             filt, ids, feats, lock = self._filter, self._ids, self._features, self._lock
+            slot_id = dict(self._slot_id[i])
+            if self._grow:
+                for rd in self._hyp[i]:
+                    b = Blob()
+                    b.bearing = rd[4]
+                    b.color.r, b.color.g, b.color.b = rd[5], rd[6], rd[7]
+                    p.hypothesis_set[rd[0]] = (_make_state(rd[1], rd[2], rd[3]), b)
 
-            def loader():
+            def load_all():
                 with lock:
                     m, c, k = filt.download_landmarks(i, i + 1)
-                out = {}
+                full, potential = {}, {}
                 for j, id_ in enumerate(ids):
                     f = Feature(mean=m[0, j], covar=c[0, j])
-                    f.update_count = int(k[0, j])
+                    f.update_count = int(k[0, j]) & ~_lib.PK_LANDMARK_POTENTIAL
                     f.__immutable__ = bool(feats[j].__immutable__)
-                    out[id_] = f
-                return out
+                    full[id_] = f
+                for slot, id_ in slot_id.items():
+                    f = Feature(mean=m[0, slot], covar=c[0, slot])
+                    f.update_count = int(k[0, slot]) & ~_lib.PK_LANDMARK_POTENTIAL
+                    if int(k[0, slot]) & _lib.PK_LANDMARK_POTENTIAL:
+                        potential[-id_] = f  # :685
+                    else:
+                        full[id_] = f        # promoted (:115-116)
+                return full, potential
 
-            p.feature_set = _FeatureSet(loader)
+            p.feature_set = _FeatureSet(lambda: load_all()[0])
+            if slot_id:
+                p.potential_features = load_all()[1]
             return p
 
     def _store_particle(self, i, particle):
@@ -497,11 +541,17 @@ class FastSLAM(object):
             poses[i] = (x, y, h, float(particle.weight))
             self._filter.upload_poses(poses)
             L = len(self._ids)
-            if L and len(particle.feature_set) == L:
+            if L and all(k in particle.feature_set for k in self._ids):
                 fs_ = [particle.feature_set[k] for k in self._ids]
                 means = np.array([np.asarray(f.mean, dtype=np.float64) for f in fs_]).reshape(1, L, 5)
                 covs = np.array([np.asarray(f.covar, dtype=np.float64) for f in fs_]).reshape(1, L, 25)
                 cnts = np.array([int(f.update_count) for f in fs_], dtype=np.int32).reshape(1, L)
+                if self._spare:  # the preset landmarks only: the spare slots keep what the filter put there
+                    m, c, k = self._filter.download_landmarks(i, i + 1)
+                    m[:, :L], k[:, :L] = means, cnts
+                    c = c.reshape(1, -1, 25)
+                    c[:, :L] = covs
+                    means, covs, cnts = m, c, k
                 self._filter.upload_landmarks(i, i + 1, means, covs, cnts)
             self._touch()
 
@@ -524,11 +574,53 @@ class FastSLAM(object):
             self._filter.set_measurement_noise(self.Qt)
             # :73 weight = 1 (the reset is fused into the observe kernels: pk_observe_fresh; the motion
             # update in between does not read the weights), :84-124 association + EKF + weights
-            self._filter.observe(blobs, fresh=True)
+            if self._grow and len(blobs):
+                self.last_ids = self._filter.observe(blobs, fresh=True, return_ids=True)
+                self._touch()
+                self._new_landmarks(blobs, self.last_ids)  # :92-95 for every particle's unmatched blobs
+            else:
+                self._filter.observe(blobs, fresh=True)
             self._touch()
             if self._publish:
                 self._publish_all(self.particle_track_pub, self._poses())  # :126-127
             self.low_variance_resample()  # :137
+
+    def _new_landmarks(self, blobs, ids):
+        """add_hypothesis (:546-564) for every unmatched blob of every particle, in scan order, with the working pairing
+        rule (class docstring).  New potential features are written into the particle's next spare slot."""
+        poses = self._poses()
+        scratch = FilterParticle()
+        for i in np.nonzero((ids == 0).any(axis=1))[0]:
+            i = int(i)
+            x, y, h = float(poses[i, 0]), float(poses[i, 1]), float(poses[i, 2])
+            fresh = []
+            for b in np.nonzero(ids[i] == 0)[0]:
+                z = blobs[b]
+                best, best_d = None, float('inf')
+                for rd in self._hyp[i]:  # find_nearest_reading :566-590 over the stored readings
+                    if not scratch.ray_intersect(rd[1], rd[2], rd[4] + rd[3], x, y, float(z[0]) + h):  # :592-609
+                        continue
+                    d = math.sqrt(math.pow(rd[5] - z[1], 2) + math.pow(rd[6] - z[2], 2) + math.pow(rd[7] - z[3], 2))
+                    if d < best_d:
+                        best, best_d = rd, d
+                xy = None
+                if best is not None and best_d < self._pair_threshold and self._used[i] + len(fresh) < self._spare:
+                    xy = scratch._cross_lines(best[1], best[2], best[3] + best[4], x, y, h + float(z[0]))  # :688-737
+                if xy is not None:  # add_new_feature :656-686
+                    slot = self._L0 + self._used[i] + len(fresh)
+                    fresh.append((slot, (xy[0], xy[1], (best[5] + z[1]) / 2, (best[6] + z[2]) / 2, (best[7] + z[3]) / 2)))
+                    self._slot_id[i][slot] = self._next_id[i]
+                else:  # add_orphaned_reading :739-746
+                    self._hyp[i].append((self._next_id[i], x, y, h, float(z[0]), float(z[1]), float(z[2]), float(z[3])))
+                self._next_id[i] += 1
+            if fresh:
+                m, c, k = self._filter.download_landmarks(i, i + 1)
+                for slot, mean in fresh:
+                    m[0, slot] = mean
+                    c[0, slot] = np.identity(5)
+                    k[0, slot] = _lib.PK_LANDMARK_POTENTIAL  # update_count 0, potential
+                self._filter.upload_landmarks(i, i + 1, m, c.reshape(1, -1, 25), k)
+                self._used[i] += len(fresh)
 
     def odom_motion_update(self, odom):
         pass  # :140-146 alpha feature, empty in the reference
@@ -582,7 +674,13 @@ class FastSLAM(object):
             if self._publish:
                 self._publish_all(self.aged_particles_pub, self._poses())  # :237
             u = _pyrandom.random()  # :226
-            self.last_ancestors = self._filter.resample(u, domain=self._domain, return_ancestors=self._publish)
+            self.last_ancestors = self._filter.resample(u, domain=self._domain, return_ancestors=self._publish or self._grow)
+            if self._grow:
+                anc = [int(a) for a in self.last_ancestors]
+                self._hyp = [list(self._hyp[a]) for a in anc]
+                self._next_id = [self._next_id[a] for a in anc]
+                self._used = [self._used[a] for a in anc]
+                self._slot_id = [dict(self._slot_id[a]) for a in anc]
             self._touch()
             if self._publish:
                 self._publish_all(self.resampled_particles_pub, self._poses())  # :242
@@ -600,16 +698,17 @@ class FastSLAM(object):
         with self._lock:
             poses = self._filter.download_poses()
             m, c, k = self._filter.download_landmarks()
+            book = np.array([self._hyp, self._next_id, self._used, self._slot_id], dtype=object)
             np.savez_compressed(
-                path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
+                path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64), new_landmarks=book,
                 immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),
                 last_control=np.array([float(self.last_control.linear.x), float(self.last_control.angular.z)]),
                 last_update=float(self.last_update.to_sec()), draw=self._draw)
 
     def load_state(self, path):
         with self._lock:
-            d = np.load(path)
-            P, L = self.num_particles, len(self._ids)
+            d = np.load(path, allow_pickle=True)
+            P, L = self.num_particles, self._L0 + self._spare
             if d["poses"].shape != (P, 4) or d["means"].shape != (P, L, 5):
                 raise ValueError("snapshot is for %s particles x %s landmarks, this filter has %d x %d"
                                  % (d["poses"].shape[0], d["means"].shape[1], P, L))
@@ -620,6 +719,9 @@ class FastSLAM(object):
             self.last_control.linear.x = float(d["last_control"][0])
             self.last_control.angular.z = float(d["last_control"][1])
             self._draw = int(d["draw"])
+            if "new_landmarks" in d.files and self._grow:
+                hyp, nid, used, sid = d["new_landmarks"]
+                self._hyp, self._next_id, self._used, self._slot_id = [list(h) for h in hyp], list(nid), list(used), [dict(x) for x in sid]
             self._touch()
 
     def close(self):

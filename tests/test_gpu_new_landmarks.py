@@ -68,3 +68,80 @@ def test_potential_features_with_supplied_ids_and_on_the_dense_layout(lib):
     assert got == "known_ids" and 0 < left < start
     got, left, start = run(lib, 16, 24, {}, dense=True)
     assert got == "dense" and 0 < left < start
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole of f4 through the facade: unknown landmarks are triangulated from two sightings (:546-746 with the working pairing
+# rule), tracked as potential features (device kernels), promoted past update_count 5 -- against the NumPy GrowingOracle.
+class _View(object):
+    def __init__(self, pk, blobs):
+        class Scan(object):
+            pass
+
+        self.last_sensor_reading = Scan()
+        obs = []
+        for b in blobs:
+            z = pk.msgs.Blob()
+            z.bearing = float(b[0])
+            z.color.r, z.color.g, z.color.b = float(b[1]), float(b[2]), float(b[3])
+            obs.append(z)
+        self.last_sensor_reading.observes = obs
+
+
+def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
+    import random
+
+    import parakeet_slam_amd as pk
+    from oracle.fastslam_oracle import GrowingOracle, low_variance_ancestors
+
+    L0, U, P, spare, steps, thr = 10, 3, 12, 5, 8, 30.0
+    v, w, dt = 0.8, 0.35, 0.5
+    world, covs = synthetic_world(L0 + U)
+    known, kcov = world[:L0], covs[:L0]
+    np.random.seed(5)
+    random.seed(5)
+    pk.msgs.Time.set_now(0.0)
+    fs = pk.FastSLAM([pk.Feature(mean=m.copy(), covar=c.copy()) for m, c in zip(known, kcov)], num_particles=P,
+                     weight_domain="log", new_landmarks=True, spare_landmarks=spare, pair_threshold=thr)
+    tw = pk.msgs.Twist()
+    tw.linear.x, tw.angular.z = v, w
+    fs.last_control = tw
+    o = GrowingOracle(P, known, kcov, spare, thr)
+    np_rs = np.random.RandomState(5)  # the facade draws from numpy.random / random seeded the same way
+    py_rs = random.Random(5)
+    pose = (0.0, 0.0, 0.0)
+    created = promoted = 0
+    for s in range(steps):
+        pose = truth_step(pose, v, w, dt)
+        blobs = synthetic_scan(world, pose)  # the scan sees the three unknown landmarks too
+        pk.msgs.Time.set_now(dt * (s + 1))
+        fs.cam_cb(_View(pk, blobs))
+        o.f.reset_weights()
+        o.f.motion(v, w, dt, np_rs.standard_normal((P, 3)))
+        oids = o.observe(blobs)
+        assert np.array_equal(np.asarray(fs.last_ids), oids), "step %d: association differs" % s
+        wts = np.exp(o.f.logw - o.f.logw.max())
+        anc = low_variance_ancestors(wts, py_rs.random())
+        assert np.array_equal(np.asarray(fs.last_ancestors), anc), s
+        o.gather(anc)
+        m, c, k = fs._filter.download_landmarks()
+        assert np.array_equal((k & lib.PK_LANDMARK_POTENTIAL) != 0, o.f.potential), s
+        assert np.array_equal(k & ~lib.PK_LANDMARK_POTENTIAL, o.f.count), s
+        assert np.allclose(m, o.f.mean, rtol=1e-9, atol=1e-9), s
+        assert fs._next_id == o.next_id and fs._used == o.used
+        assert [len(h) for h in fs._hyp] == [len(h) for h in o.hyp]
+        created = max(created, max(o.used))
+        promoted = max(promoted, int(((o.f.count[:, L0:] > 5) & ~o.f.potential[:, L0:]).sum()))
+    assert created >= 2, "the unknown landmarks were never triangulated"
+    assert promoted >= 1, "no potential feature reached the full feature set"
+    # the object view (:278-292): promoted features under their positive id, potential ones under the negative one
+    p0 = fs.particles[0]
+    ids_full = [i for i in p0.feature_set.keys() if i > L0]
+    assert len(ids_full) + len(p0.potential_features) == o.used[0]
+    assert all(i < 0 for i in p0.potential_features) and len(p0.hypothesis_set) == len(o.hyp[0])
+    assert p0.next_id == o.next_id[0]
+    # the features sit on the rays they were triangulated from: seen from the pose of the step that created them they were
+    # at the blobs' bearings; after the updates they still are within the bearing gate of the true landmarks' directions
+    got = np.array([f.mean[:2] for i, f in list(p0.feature_set.items()) + list(p0.potential_features.items()) if abs(i) > L0])
+    assert len(got) == o.used[0] and np.isfinite(got).all()
+    fs.close()

@@ -107,7 +107,18 @@ def test_new_landmark_geometry_live(ref):
         x, y = rp.cross_readings(a, b), mp.cross_readings(a, b)
         assert np.allclose(x, y, rtol=1e-12, atol=1e-12), i
         args = (rs.uniform(-3, 3), rs.uniform(-3, 3), a[1].bearing, rs.uniform(-3, 3), rs.uniform(-3, 3), b[1].bearing)
-        assert rp.ray_intersect(*args) == mp.ray_intersect(*args)
+        assert rp.ray_intersect(*args) == mp.ray_intersect(*args) == O.ray_intersect(*args)
+        # the oracle's restatement (what GrowingOracle runs on), on the same readings
+        from utils import quaternion_to_heading
+
+        ha, hb = quaternion_to_heading(a[0].pose.pose.orientation), quaternion_to_heading(b[0].pose.pose.orientation)
+        pa, pb = a[0].pose.pose.position, b[0].pose.pose.position
+        ox = O.cross_readings(pa.x, pa.y, ha + a[1].bearing, pb.x, pb.y, hb + b[1].bearing)
+        assert (ox is None) == (x is None) and (x is None or np.allclose(ox, x, rtol=1e-12, atol=1e-12))
+        ca, cb = (a[1].color.r, a[1].color.g, a[1].color.b), (b[1].color.r, b[1].color.g, b[1].color.b)
+        assert O.colour_distance(ca, cb) == rp.color_distance(a[1], b[1])
+        inter = O.ray_intersect(pa.x, pa.y, a[1].bearing + ha, pb.x, pb.y, b[1].bearing + hb)
+        assert (O.colour_distance(ca, cb) if inter else float("inf")) == want
     assert 200 < crossing < 1300
     # the bookkeeping: orphans pile up, a stored reading in potential_features is found by its (negative) key
     r1, r2, r3 = reading(), reading(), reading()
