@@ -427,7 +427,24 @@ def main():
     # the timed region.  Two event records cost the stream ~8 us: every launch is bracketed when a step
     # takes milliseconds, every 4th when it takes a fraction of one.
     stride = 1 if float(P) * L >= 5e7 or K < 16 else 4
+    if sharded:
+        filt.synchronize()
+        filt.total_migrated = 0
     elapsed, tm, route, one_step = timed_steps(filt, _lib, P, L, K, W, scans, ws, us, ids, barrier, stride)
+    migrated = None
+    if sharded:  # particles whose output slot lies on another rank: pose + whole map travel (the all-to-all's volume)
+        filt.synchronize()
+        t = torch.tensor([float(filt.total_migrated)], dtype=torch.float64, device="cuda:%d" % local_rank)
+        if world > 1:
+            import torch.distributed as dist
+
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(t)
+            else:  # gloo rehearsal: host tensor
+                t = t.cpu()
+                dist.all_reduce(t)
+        migrated = float(t.item()) / max(K, 1)
+        migrated_bytes = migrated * filt.f.particle_bytes()
     summary = filt.summary()
     flagged = filt.observe_flagged() if hasattr(filt, "observe_flagged") else None
     # validity probe (untimed): share of the blobs of the last timed scan that the particles, as they
@@ -625,6 +642,9 @@ def main():
             "summary": list(summary),
             "matched_fraction_last_timed_scan": matched,  # validity: the scans stayed matchable to the end
         }
+        if migrated is not None:
+            out["migrated_particles_per_step"] = migrated  # all ranks together: each one is a pose + a whole map slot on the wire
+            out["migrated_bytes_per_step"] = migrated_bytes
         if second is not None:
             out["configs1"] = second
         if cpu is not None:

@@ -332,6 +332,7 @@ int materialise(pk_filter* f) {
     launch_materialise(f->stream, f->d);
   }
   f->src_identity = true;
+  f->d.alt = nullptr;  // every slot now lives in the shard's own buffer
   return PK_OK;
 }
 
@@ -1226,6 +1227,7 @@ static int dense_observe(pk_filter* f, const double* blobs, int32_t B, const int
   PK_LAUNCH_CHECK("pk_observe (dense)");
   if (update) {
     f->src_identity = true;
+    f->d.alt = nullptr;  // every map slot was just rewritten from its source: the receive buffer of the last exchange is free
     f->gmax_fused = true;
     f->route = PK_ROUTE_DENSE;
   } else {
@@ -1307,6 +1309,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     }
     PK_LAUNCH_CHECK("pk_observe");
     f->src_identity = true;
+    f->d.alt = nullptr;  // every map slot was just rewritten from its source: the receive buffer of the last exchange is free
     f->gmax_fused = true;
     f->route = PK_ROUTE_KNOWN_IDS;
     if (ids_out)
@@ -1448,6 +1451,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   }
   PK_LAUNCH_CHECK("pk_observe");
   f->src_identity = true;
+  f->d.alt = nullptr;  // every map slot was just rewritten from its source: the receive buffer of the last exchange is free
   f->gmax_fused = true;
   if (ids_out && B > 0) {
     PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));

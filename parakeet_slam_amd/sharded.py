@@ -284,6 +284,7 @@ class ShardedFilter(object):
         self._recv_keepalive = None
         self._pending = None  # a resample whose exchange has been planned on the GPU but not carried out yet
         self.last_migrated = 0
+        self.total_migrated = 0  # particles this rank sent to other ranks since the counter was last cleared (bench.py)
 
     def _ctx(self):
         return self.f.on_stream() if hasattr(self.f, "on_stream") else _nullcontext()
@@ -406,6 +407,7 @@ class ShardedFilter(object):
             recv_counts = [int(counts[s, R]) if s != R else 0 for s in range(W)]
             n_send, n_recv = sum(send_counts), sum(recv_counts)
             self.last_migrated = n_send
+            self.total_migrated += n_send
             recv = None
             moving = int(counts.sum() - np.trace(counts))  # same number on every rank (all-gathered table)
             if W > 1 and moving > 0:  # every rank takes part in the exchange, even with nothing of its own to move
