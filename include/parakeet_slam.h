@@ -274,6 +274,21 @@ int pk_shard_download_offspring(pk_filter* f, int64_t* slot_hi);
 int pk_shard_pack_dev(pk_filter* f, const int64_t* ranges, int32_t world, int32_t rank, void* dev_buf);
 int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received);
 
+/* The split step of the sharded filter: the exchange of the migrating particles (each a whole map) runs while the
+ * particles that stay on this rank are already being worked on.  The output slots a shard fills with its OWN particles form
+ * one contiguous run (ancestors are monotone in the slot index): pk_shard_local_span_dev copies its two global bounds
+ * (slot_hi[0], slot_hi[P] of the plan) into a caller's device buffer; pk_shard_adopt_local_dev makes the new generation
+ * current with those slots filled, pk_shard_adopt_remote_dev fills the others from the received records;
+ * pk_motion_range / pk_observe_staged_range are pk_motion (device noise) / pk_observe_staged on the particles [p0, p1) only:
+ * `first` consumes the staged scan (it must take the register route: pk_staged_takes_regs), `last` runs what the one-pass
+ * kernel flagged over ALL particles and closes the step.  The reference has one process (prkt_core_v2.py:59-137). */
+int pk_shard_local_span_dev(pk_filter* f, int64_t* dev_out2);
+int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank);
+int pk_shard_adopt_remote_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received);
+int pk_motion_range(pk_filter* f, double v, double w, double dt, uint64_t seed, uint64_t draw, int64_t p0, int64_t p1);
+int pk_staged_takes_regs(pk_filter* f); /* 1: the staged scan will take k_step_regs, 0: not (or nothing staged) */
+int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1, int32_t first, int32_t last);
+
 /* ---- single-triple probe ------------------------------------------------------
  * Runs the device functions the kernels are built from on ONE (pose, landmark, blob):
  * the scalar methods of FilterParticle the reference's unit tests call.

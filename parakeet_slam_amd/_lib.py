@@ -77,6 +77,12 @@ SIGNATURES = {
     "pk_shard_download_offspring": (C.c_int, [_h, _lp]),
     "pk_shard_pack_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p]),
     "pk_shard_adopt_dev": (C.c_int, [_h, C.c_int32, C.c_void_p, C.c_int64]),
+    "pk_shard_local_span_dev": (C.c_int, [_h, C.c_void_p]),
+    "pk_shard_adopt_local_dev": (C.c_int, [_h, C.c_int32]),
+    "pk_shard_adopt_remote_dev": (C.c_int, [_h, C.c_int32, C.c_void_p, C.c_int64]),
+    "pk_motion_range": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64]),
+    "pk_staged_takes_regs": (C.c_int, [_h]),
+    "pk_observe_staged_range": (C.c_int, [_h, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "pk_particle_bytes": (C.c_int64, [_h]),
     "pk_pack_particles": (C.c_int, [_h, _lp, C.c_int64, C.c_void_p]),
     "pk_adopt_particles": (C.c_int, [_h, _lp, C.c_void_p, C.c_int64]),
@@ -342,6 +348,25 @@ class DeviceFilter(object):
 
     def shard_adopt_dev(self, rank, recv_ptr, n_received):
         check(self._lib.pk_shard_adopt_dev(self._h, int(rank), C.c_void_p(recv_ptr), int(n_received)))
+
+    # -- the split step (the exchange overlapped with the work on the particles that stay) --
+    def shard_local_span_dev(self, out_ptr):
+        check(self._lib.pk_shard_local_span_dev(self._h, C.c_void_p(out_ptr)))
+
+    def shard_adopt_local_dev(self, rank):
+        check(self._lib.pk_shard_adopt_local_dev(self._h, int(rank)))
+
+    def shard_adopt_remote_dev(self, rank, recv_ptr, n_received):
+        check(self._lib.pk_shard_adopt_remote_dev(self._h, int(rank), C.c_void_p(recv_ptr), int(n_received)))
+
+    def motion_range(self, v, w, dt, seed, draw, p0, p1):
+        check(self._lib.pk_motion_range(self._h, float(v), float(w), float(dt), int(seed), int(draw), int(p0), int(p1)))
+
+    def staged_takes_regs(self):
+        return bool(self._lib.pk_staged_takes_regs(self._h))
+
+    def observe_staged_range(self, fresh, p0, p1, first, last):
+        check(self._lib.pk_observe_staged_range(self._h, 1 if fresh else 0, int(p0), int(p1), 1 if first else 0, 1 if last else 0))
 
     ROUTES = {0: "none", 1: "known_ids", 2: "ml_general", 3: "ml_handoff", 4: "ml_sweep", 5: "ml_fused", 6: "ml_regs", 7: "ml_owner", 8: "dense"}
 

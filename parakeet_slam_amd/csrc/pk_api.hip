@@ -69,6 +69,21 @@ struct TimedSpan {
 
 }  // namespace
 
+struct AssocLaunch {
+  bool fused = false;  // nothing launched yet: k_step_fused does gates + EKF in one kernel
+  bool regs = false;   // nothing launched yet: k_step_regs does the same for 512 < L <= 2048
+  bool retry = false;  // with regs: the hand-off lists for the flagged particles' second chance are allocated
+  bool owner = false;  // nothing launched yet: k_step_owner (candidate lists both ways, no barriers), any L
+  BlobGrid grid{};
+  int n9 = 0;
+  const unsigned char* tables = nullptr;
+  bool fast = false;  // hand-off written: k_observe_fast can run
+  const double* blobs = nullptr;
+  const double* dir = nullptr;
+  const double* exact = nullptr;
+  const unsigned short* order = nullptr;
+};
+
 struct pk_filter {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -127,6 +142,14 @@ struct pk_filter {
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
   uint4* cand_dev = nullptr;  // [Lp][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
+  // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
+  struct Split {
+    bool active = false;
+    AssocLaunch al;
+    CandTable cand;
+    int B = 0;
+    bool reset = false;
+  } split;
   int regs_retry = 1;    // k_step_regs: 1 = the particles it flags get a second chance (eight-slot hand-off + k_observe_sweep) before the general kernels
   int regs_warm = 1;     // k_step_regs: L2 warming of the next particle's slot: 0 none, 1 its mean rows (default), 2 the whole slot (measured slower)
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
@@ -500,22 +523,6 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
   *n9_out = n9;
 }
 
-// Upload one scan for maximum-likelihood association and enqueue the association kernel.
-struct AssocLaunch {
-  bool fused = false;  // nothing launched yet: k_step_fused does gates + EKF in one kernel
-  bool regs = false;   // nothing launched yet: k_step_regs does the same for 512 < L <= 2048
-  bool retry = false;  // with regs: the hand-off lists for the flagged particles' second chance are allocated
-  bool owner = false;  // nothing launched yet: k_step_owner (candidate lists both ways, no barriers), any L
-  BlobGrid grid{};
-  int n9 = 0;
-  const unsigned char* tables = nullptr;
-  bool fast = false;  // hand-off written: k_observe_fast can run
-  const double* blobs = nullptr;
-  const double* dir = nullptr;
-  const double* exact = nullptr;
-  const unsigned short* order = nullptr;
-};
-
 int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true) {
   const int64_t need_l = lists ? f->d.P * (int64_t)f->d.lay.Lp * (slots == kSweepSlots ? 2 : 1) : 0;
   const int64_t need_b = lists ? f->d.P * (int64_t)std::max(B, 1) : 0;
@@ -591,6 +598,13 @@ int stage_ml_scan(pk_filter* f, const double* blobs, int B) {
   sg.slot = slot;
   sg.valid = true;
   return PK_OK;
+}
+
+// Will a production observe of a scan with these tables take the register route (k_step_regs)?
+static bool regs_route_taken(pk_filter* f, const BlobGrid& g, int B, int n9) {
+  if (f->fast_observe != 1 || B <= 0 || f->d.lay.L >= 65535) return false;
+  if (f->owner_step == 2 || (f->owner_step == 1 && f->d.lay.L > kFastMaxL)) return false;  // k_step_owner first
+  return f->regs_step && f->d.lay.L > kFastMaxL && f->d.lay.L <= kRegsMaxL && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds;
 }
 
 // Upload one scan for maximum-likelihood association (one block) and enqueue the association.
@@ -1244,6 +1258,79 @@ static int dense_observe(pk_filter* f, const double* blobs, int32_t B, const int
   return PK_OK;
 }
 
+// ---- the one-pass routes (k_step_fused / k_step_regs) in three pieces, so that the sharded filter can run the middle one
+// on a part of the particles while the rest are still on the wire (pk_observe_staged_range) -------------------------------
+// 1. the reference particle's candidate lists (register route), timed with the association
+static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand) {
+  int rc;
+  if (al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) {
+    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
+    Span t(f, PK_T_ASSOC);
+    launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
+    launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
+    cand->rec = f->cand_dev;
+    cand->over = ctl_cand_over(f);
+  }
+  return PK_OK;
+}
+// 2. the one-pass kernel on the particles [p0, p1) (the fused kernel: the whole range only)
+static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const ObserveExtras& ex, const CandTable& cand, int64_t p0,
+                          int64_t p1) {
+  FastHandoff fh = f->fh;
+  fh.n_flagged = ctl_n_flagged(f);
+  fh.flags_only = true;
+  Span t(f, PK_T_OBSERVE);
+  ObserveExtras e1 = ex;
+  e1.flip = false;
+  if (al.regs)
+    launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1);
+  else
+    launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
+  return PK_OK;
+}
+// 3. what the one-pass kernel flagged, over all particles: second chance, then the general kernels (which swap the map buffers)
+static int onepass_finish(pk_filter* f, const AssocLaunch& al, int B, const ObserveExtras& ex, const CandTable& cand) {
+  int rc;
+  FastHandoff fh = f->fh;
+  fh.n_flagged = ctl_n_flagged(f);
+  fh.flags_only = true;
+  if (al.regs && al.retry) {
+    // second chance for what k_step_regs flagged (some landmark passes more than its four register slots -- 2 us per
+    // particle in the general kernels, and up to 9 % of the particles at some poses of the bench's trajectory): the
+    // hand-off instance with eight slots and k_observe_sweep, both on the flagged particles only
+    Span t(f, PK_T_OBSERVE);
+    const SweepPlan plan = observe_sweep_plan(f->d, B);
+    const size_t need = (size_t)plan.grid * plan.results_per_wg;
+    if (need > f->sweep_cap) {
+      PK_HIP(hipStreamSynchronize(f->stream));
+      if (f->sweep_results) (void)hipFree(f->sweep_results);
+      f->sweep_results = nullptr;
+      f->sweep_cap = 0;
+      if ((rc = dev_alloc(f, &f->sweep_results, need))) return rc;
+      f->sweep_cap = need;
+    }
+    FastHandoff fr = f->fh;
+    fr.slots = kSweepSlots;
+    fr.retry = true;
+    fr.n_flagged = ctl_n_flagged(f);
+    launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fr, cand);
+    ObserveExtras e3 = ex;
+    e3.flip = false;
+    e3.sweep_only_value = 2;
+    e3.n_flagged = ctl_n_flagged(f);
+    launch_observe_sweep(f->stream, f->d, B, al.exact, al.order, fr, f->qt, e3, plan, f->sweep_results);
+  }
+  // the particles still flagged (a landmark passing more blobs than any slot count): general kernels, both timed in the
+  // association slot
+  Span t(f, PK_T_ASSOC);
+  launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fh);
+  ObserveExtras e2 = ex;
+  e2.only_flagged = f->fh.pflag;
+  e2.n_flagged = ctl_n_flagged(f);
+  launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
+  return PK_OK;
+}
+
 static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int32_t* ids, int32_t* ids_out,
                         bool reset) {
   if (!f) return fail(PK_ERR_INVALID, "pk_observe: NULL handle");
@@ -1367,60 +1454,10 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     e2.n_flagged = ctl_n_flagged(f);
     launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
   } else if (al.fused || al.regs) {
-    FastHandoff fh = f->fh;
-    fh.n_flagged = ctl_n_flagged(f);
-    fh.flags_only = true;
     CandTable cand;
-    if (al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) {
-      // the reference particle's candidate lists (particle 0 of the live generation), timed with the association
-      if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
-      Span t(f, PK_T_ASSOC);
-      launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
-      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
-      cand.rec = f->cand_dev;
-      cand.over = ctl_cand_over(f);
-    }
-    {
-      Span t(f, PK_T_OBSERVE);
-      ObserveExtras e1 = ex;
-      e1.flip = false;
-      if (al.regs)
-        launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand);
-      else
-        launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
-      if (al.regs && al.retry) {
-        // second chance for what k_step_regs flagged (some landmark passes more than its four register slots -- 2 us per
-        // particle in the general kernels, and up to 9 % of the particles at some poses of the bench's trajectory): the
-        // hand-off instance with eight slots and k_observe_sweep, both on the flagged particles only
-        const SweepPlan plan = observe_sweep_plan(f->d, B);
-        const size_t need = (size_t)plan.grid * plan.results_per_wg;
-        if (need > f->sweep_cap) {
-          PK_HIP(hipStreamSynchronize(f->stream));
-          if (f->sweep_results) (void)hipFree(f->sweep_results);
-          f->sweep_results = nullptr;
-          f->sweep_cap = 0;
-          if ((rc = dev_alloc(f, &f->sweep_results, need))) return rc;
-          f->sweep_cap = need;
-        }
-        FastHandoff fr = f->fh;
-        fr.slots = kSweepSlots;
-        fr.retry = true;
-        fr.n_flagged = ctl_n_flagged(f);
-        launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fr, cand);
-        ObserveExtras e3 = e1;
-        e3.sweep_only_value = 2;
-        e3.n_flagged = ctl_n_flagged(f);
-        launch_observe_sweep(f->stream, f->d, B, al.exact, al.order, fr, f->qt, e3, plan, f->sweep_results);
-      }
-    }
-    // the particles it flagged (a landmark passing more than kFastSlots blobs): general kernels,
-    // both timed in the association slot
-    Span t(f, PK_T_ASSOC);
-    launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fh);
-    ObserveExtras e2 = ex;
-    e2.only_flagged = f->fh.pflag;
-    e2.n_flagged = ctl_n_flagged(f);
-    launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
+    if ((rc = onepass_prepare(f, al, B, &cand))) return rc;
+    if ((rc = onepass_launch(f, al, B, ex, cand, 0, f->d.P))) return rc;
+    if ((rc = onepass_finish(f, al, B, ex, cand))) return rc;
   } else {
     Span t(f, PK_T_OBSERVE);
     if (al.fast) {
@@ -1494,6 +1531,61 @@ int pk_observe_staged(pk_filter* f, int32_t fresh) {
   if (!f->staged.valid) return fail(PK_ERR_STATE, "pk_observe_staged: no staged scan (pk_stage_scan)");
   const double* blobs = reinterpret_cast<const double*>(f->staged.st + kCtlBytes);
   return observe_impl(f, blobs, f->staged.B, nullptr, nullptr, fresh != 0);
+}
+
+int pk_staged_takes_regs(pk_filter* f) {
+  if (!f || f->dense || !f->staged.valid || !f->staged.use_grid) return 0;
+  return regs_route_taken(f, f->staged.g, f->staged.B, f->staged.n9) ? 1 : 0;
+}
+
+int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1, int32_t first, int32_t last) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_observe_staged_range: NULL handle");
+  if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "pk_observe_staged_range: bad particle range [%lld, %lld)", (long long)p0, (long long)p1);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  pk_filter::Split& sp = f->split;
+  if (first) {
+    if (sp.active) return fail(PK_ERR_STATE, "pk_observe_staged_range: the previous split observe was not finished (last = 1)");
+    if (!pk_staged_takes_regs(f))
+      return fail(PK_ERR_STATE, "pk_observe_staged_range: needs a staged scan that takes the register route (pk_staged_takes_regs)");
+    const double* blobs = reinterpret_cast<const double*>(f->staged.st + kCtlBytes);
+    sp.B = f->staged.B;
+    sp.reset = fresh != 0;
+    sp.al = AssocLaunch();
+    if ((rc = enqueue_association(f, blobs, sp.B, false, true, &sp.al))) return rc;
+    if (!sp.al.regs) return fail(PK_ERR_STATE, "pk_observe_staged_range: the scan did not take the register route");
+    f->route = PK_ROUTE_ML_REGS;
+    sp.cand = CandTable();
+    if ((rc = onepass_prepare(f, sp.al, sp.B, &sp.cand))) return rc;
+    sp.active = true;
+  } else if (!sp.active) {
+    return fail(PK_ERR_STATE, "pk_observe_staged_range: no split observe in progress (first = 1)");
+  }
+  ObserveExtras ex;
+  ex.reset = sp.reset;
+  ex.gmax_key = ctl_gmax_key(f);
+  if (p1 > p0 && (rc = onepass_launch(f, sp.al, sp.B, ex, sp.cand, p0, p1))) return rc;
+  if (last) {
+    sp.active = false;
+    if ((rc = onepass_finish(f, sp.al, sp.B, ex, sp.cand))) return rc;
+    PK_LAUNCH_CHECK("pk_observe_staged_range");
+    f->src_identity = true;
+    f->d.alt = nullptr;
+    f->gmax_fused = true;
+  }
+  return PK_OK;
+}
+
+int pk_motion_range(pk_filter* f, double v, double w, double dt, uint64_t seed, uint64_t draw, int64_t p0, int64_t p1) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_motion_range: NULL handle");
+  if (!std::isfinite(v) || !std::isfinite(w) || !std::isfinite(dt)) return fail(PK_ERR_INVALID, "pk_motion_range: non-finite control");
+  if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "pk_motion_range: bad particle range [%lld, %lld)", (long long)p0, (long long)p1);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  Span t(f, PK_T_MOTION);
+  launch_motion_range(f->stream, f->d, v, w, dt, seed, draw, p0, p1);
+  PK_LAUNCH_CHECK("pk_motion_range");
+  return PK_OK;
 }
 
 int pk_associate(pk_filter* f, const double* blobs, int32_t B, int32_t* ids_out) {
@@ -1945,6 +2037,51 @@ int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t
                    n_received, f->rlohi_dev);
   f->src_identity = false;
   f->gmax_fused = false;
+  return PK_OK;
+}
+
+int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
+  if (!f || rank < 0) return fail(PK_ERR_INVALID, "pk_shard_adopt_local_dev: bad argument");
+  if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_local_dev: call pk_shard_plan_dev first");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first
+    f->src_identity = false;
+    if ((rc = materialise(f))) return rc;
+  }
+  Span t(f, PK_T_RESAMPLE);
+  launch_adopt_dev(f->stream, f->d, f->hi_dev, (int64_t)rank * f->d.P, nullptr, 0, nullptr, 1);
+  f->src_identity = false;
+  f->gmax_fused = false;
+  return PK_OK;
+}
+
+int pk_shard_adopt_remote_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
+  if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_remote_dev: bad argument");
+  if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_remote_dev: call pk_shard_plan_dev first");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (n_received > f->rlohi_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    if (f->rlohi_dev) (void)hipFree(f->rlohi_dev);
+    f->rlohi_dev = nullptr;
+    f->rlohi_cap = 0;
+    if ((rc = dev_alloc(f, &f->rlohi_dev, (size_t)(2 * n_received + 2 * n_received / 4 + 16)))) return rc;
+    f->rlohi_cap = n_received + n_received / 4;
+  }
+  Span t(f, PK_T_RESAMPLE);
+  launch_adopt_dev(f->stream, f->d, f->hi_dev, (int64_t)rank * f->d.P, static_cast<const unsigned char*>(dev_recv), n_received,
+                   f->rlohi_dev, 2);
+  return PK_OK;
+}
+
+int pk_shard_local_span_dev(pk_filter* f, int64_t* dev_out2) {
+  if (!f || !dev_out2) return fail(PK_ERR_INVALID, "pk_shard_local_span_dev: NULL argument");
+  if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_local_span_dev: no plan yet");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipMemcpyAsync(dev_out2, f->hi_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(dev_out2 + 1, f->hi_dev + f->d.P, sizeof(int64_t), hipMemcpyDeviceToDevice, f->stream));
   return PK_OK;
 }
 

@@ -70,6 +70,20 @@ void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt,
                      static_cast<uint4*>(up_dst_dev), static_cast<const uint4*>(up_src_host_mapped), n16);
 }
 
+// The same for the particles [p0, p1) only (device noise; the Philox counters use the global particle index, so the draws
+// are those of the whole-range launch).
+void launch_motion_range(hipStream_t s, DeviceState& d, double v, double w, double dt, uint64_t seed, uint64_t draw,
+                         int64_t p0, int64_t p1) {
+  if (p1 <= p0) return;
+  double sd = fabs(.05 * v) + fabs(.005 * w) + .0005;  // :185
+  double sh = fabs(.025 * w) + fabs(.005 * v) + .0005;  // :190,:193
+  const int64_t n = p1 - p0;
+  int blocks = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(k_motion, dim3((unsigned)blocks), dim3(256), 0, s, d.x[d.cur] + p0, d.y[d.cur] + p0, d.h[d.cur] + p0, n, v, w,
+                     dt, sd, sh, (const double*)nullptr, seed, draw, d.global_offset + p0, blocks, (uint4*)nullptr,
+                     (const uint4*)nullptr, (int64_t)0);
+}
+
 __global__ void k_fill(double* p, int64_t n, double v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

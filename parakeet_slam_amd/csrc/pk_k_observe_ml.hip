@@ -1184,7 +1184,8 @@ struct RegsArgs {
   unsigned* n_flagged;
   int n9;
   int warm;                     // 0: no L2 warming of the next particle's slot, 1: mean rows, 2: whole slot
-  int64_t P;
+  int64_t P;                    // end of the particle range of this launch
+  int64_t p_begin;              // its start (0 but for the split step of the sharded filter)
   const uint4* cand;            // candidate lists of the reference particle (CandTable), or NULL
   const unsigned* cand_over;    // != 0: the lists overflowed, this scan takes the grid walk
 };
@@ -1576,7 +1577,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
   // request the next particle's rows; the barrier that separates the two particles' use of the LDS counters is passed
   // with those requests in flight (the slowest wave's updates hide the others' first round trip).
   int64_t prev = -1;  // the particle whose partial sums wait in red[] (-1: none, or it went to the general kernels)
-  for (int64_t p = blockIdx.x;; p += gridDim.x) {
+  for (int64_t p = regs_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x) {
     Landmark<double> A, Bq;
     // everything derived from the lane index is derived afresh for every particle: hoisted out of this loop
     // (LDS addresses, row offsets, queue-entry indices ...) those values filled the register file and spilled
@@ -1983,8 +1984,9 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
 
 void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
-                      const ObserveExtras& ex, int warm, const CandTable& cand) {
-  if (d.P == 0) return;
+                      const ObserveExtras& ex, int warm, const CandTable& cand, int64_t p0, int64_t p1) {
+  if (p1 < 0) p1 = d.P;
+  if (d.P == 0 || p1 <= p0) return;
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
     for (const void* fn : {reinterpret_cast<const void*>(k_step_regs<false>), reinterpret_cast<const void*>(k_step_regs<true>)})
@@ -2018,7 +2020,8 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
   ra.n_flagged = fh.n_flagged;
   ra.n9 = n9;
   ra.warm = warm;
-  ra.P = d.P;
+  ra.P = p1;
+  ra.p_begin = p0;
   ra.cand = cand.rec;
   ra.cand_over = cand.rec ? cand.over : nullptr;
   // persistent grid: the workgroups that are resident at once (one per CU: 1024 lanes x 128 VGPRs)
@@ -2033,7 +2036,7 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
     (void)hipGetLastError();
   }
   int64_t grid_n = n_cu;
-  if (grid_n > d.P) grid_n = d.P;
+  if (grid_n > p1 - p0) grid_n = p1 - p0;
   if (cand.rec)
     hipLaunchKernelGGL(k_step_regs<true>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_cand_lds_bytes(d.lay.Lp, B), s, ra);
   hipLaunchKernelGGL(k_step_regs<false>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_lds_bytes(grid.ncell, B, n9), s, ra);

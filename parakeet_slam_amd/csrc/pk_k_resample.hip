@@ -532,11 +532,14 @@ __global__ void __launch_bounds__(256) k_adopt_dev(const double* __restrict__ x,
                                                    double* __restrict__ lw2, int32_t* __restrict__ src2,
                                                    const int64_t* __restrict__ hi, int64_t slot_start,
                                                    const unsigned char* __restrict__ buf, size_t stride,
-                                                   const int64_t* __restrict__ rlohi, int64_t n_recv, int64_t P) {
+                                                   const int64_t* __restrict__ rlohi, int64_t n_recv, int64_t P, int mode) {
+  // mode 0: every slot; 1: only the slots filled by this shard's own particles; 2: only those filled by received records
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   const int64_t K = slot_start + k;
-  if (K >= hi[0] && K < hi[P]) {
+  const bool local = K >= hi[0] && K < hi[P];
+  if ((mode == 1 && !local) || (mode == 2 && local)) return;
+  if (local) {
     int64_t lo = 0, up = P - 1;  // first j with hi[j + 1] > K
     while (lo < up) {
       const int64_t mid = (lo + up) >> 1;
@@ -568,20 +571,23 @@ __global__ void __launch_bounds__(256) k_adopt_dev(const double* __restrict__ x,
   }
 }
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
-                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev) {
+                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode) {
   if (d.P == 0) return;
-  const int c = d.cur, n = c ^ 1;
+  // mode 2 (the received part of a split adoption) writes into the generation mode 1 has already made current
+  const int n = mode == 2 ? d.cur : d.cur ^ 1, c = n ^ 1;
   const size_t stride = kPoseRecordBytes + d.lay.slot_bytes;
-  if (n_recv > 0)
+  if (n_recv > 0 && mode != 1)
     hipLaunchKernelGGL(k_extract_lohi, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, buf_dev, stride, n_recv,
                        rlohi_dev);
   hipLaunchKernelGGL(k_adopt_dev, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
                      d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], hi_dev, slot_start, buf_dev,
-                     stride, rlohi_dev, n_recv, d.P);
+                     stride, rlohi_dev, n_recv, d.P, mode);
   d.cur = n;
-  d.alt = n_recv > 0 ? buf_dev : nullptr;
-  d.alt_stride = stride;
-  d.alt_off = kPoseRecordBytes;
+  if (mode != 1) {
+    d.alt = n_recv > 0 ? buf_dev : nullptr;
+    d.alt_stride = stride;
+    d.alt_off = kPoseRecordBytes;
+  }
 }
 
 }  // namespace pk

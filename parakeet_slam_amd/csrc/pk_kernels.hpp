@@ -56,6 +56,8 @@ constexpr int kScanBlock = 1024;  // particles per weight-scan block (256 thread
 void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt, const double* z_dev,
                    uint64_t seed, uint64_t draw, int64_t global_offset, void* up_dst_dev = nullptr,
                    const void* up_src_host_mapped = nullptr, size_t up_bytes = 0);
+void launch_motion_range(hipStream_t s, DeviceState& d, double v, double w, double dt, uint64_t seed, uint64_t draw,
+                         int64_t p0, int64_t p1);
 void launch_reset_weights(hipStream_t s, DeviceState& d);
 // K2: maximum-likelihood association -> ids[P*B]
 // (a) reference kernel: every (landmark, blob) pair is gate-tested
@@ -200,7 +202,7 @@ size_t regs_cand_lds_bytes(int Lp, int B);
 // grid-walk instance (returns at once when *cand.over == 0)
 void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
-                      const ObserveExtras& ex, int warm, const CandTable& cand = CandTable());
+                      const ObserveExtras& ex, int warm, const CandTable& cand = CandTable(), int64_t p0 = 0, int64_t p1 = -1);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued
@@ -255,8 +257,10 @@ void launch_adopt(hipStream_t s, DeviceState& d, const int64_t* src_dev, const u
 void launch_shard_ranges(hipStream_t s, const int64_t* hi_dev, int64_t P_local, int world, int64_t* ranges_dev);
 void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t j0, int64_t n, int64_t slot_start,
                        int64_t slot_end, unsigned char* buf_dev);
+// mode 0: the whole new generation; 1: only the slots this shard's own particles fill (the generation becomes current);
+// 2: only the slots filled by received records (into the generation mode 1 made current)
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
-                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev);
+                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode = 0);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
 // scan block: pinned (device-mapped) host memory -> HBM by a kernel, in stream order
 void launch_upload(hipStream_t s, void* dst_dev, const void* src_host_mapped, size_t bytes);

@@ -22,6 +22,11 @@ the same stream as the collectives; the host synchronises once per resample.
 The draw u is replicated (same value on every rank), as the north star asks.  With shards
 that are multiples of 1024 particles the ancestors are bit-identical to the 1-GPU run.
 
+``ShardedFilter.step`` overlaps step 4 with the next step's work (``split_step``, on when the scan takes the register
+route): the output slots a shard fills with its OWN particles form one contiguous run (ancestors are monotone in the slot
+index), so the motion update and k_step_regs start on that run while the migrating particles -- a whole map each, the
+bulk of a step's bytes on the wire -- are still travelling, and the slots at either end follow when they have arrived.
+
 Shards of any other size take the GLOBAL-SCAN variant of steps 2-3 (``global_scan``; chosen by
 itself when P_local % 1024 != 0): the ranks all-gather their log-weights (8 B per particle of
 the whole filter; the migrating maps of step 4 are 10^4 times that) and every rank runs the
@@ -173,6 +178,19 @@ class TorchComm(object):
             recv[: n_recv * record_bytes] = torch.from_numpy(got).to(send.device)
         return recv
 
+    def all_to_all_records_async(self, send, send_counts, recv_counts, record_bytes):
+        """The same, not waited for: returns (recv, work); ``work.wait()`` makes the current stream wait for the transfer
+        (None: already complete -- the gloo stand-in of the tests is synchronous)."""
+        if not self.direct:
+            return self.all_to_all_records(send, send_counts, recv_counts, record_bytes), None
+        torch = self.torch
+        n_recv, n_send = int(sum(recv_counts)), int(sum(send_counts))
+        recv = torch.empty(max(n_recv, 1) * record_bytes, dtype=torch.uint8, device=send.device)
+        work = self.dist.all_to_all_single(recv[: n_recv * record_bytes], send[: n_send * record_bytes],
+                                           [c * record_bytes for c in recv_counts],
+                                           [c * record_bytes for c in send_counts], async_op=True)
+        return recv, work
+
     def barrier(self):
         self.dist.barrier()
 
@@ -231,6 +249,16 @@ class HipShard(_lib.DeviceFilter):
     def adopt_from(self, rank, recv, n_received):
         self.shard_adopt_dev(rank, recv.data_ptr() if (recv is not None and n_received) else 0, n_received)
 
+    # -- the split step --
+    def local_span_into(self, t2):
+        self.shard_local_span_dev(t2.data_ptr())
+
+    def adopt_local(self, rank):
+        self.shard_adopt_local_dev(rank)
+
+    def adopt_remote(self, rank, recv, n_received):
+        self.shard_adopt_remote_dev(rank, recv.data_ptr() if (recv is not None and n_received) else 0, n_received)
+
     def start_host_read(self, t):
         """Begin copying a small device tensor to pinned host memory on the shard's stream; returns a
         handle for finish_host_read.  Lets the caller do host work before it has to wait."""
@@ -258,7 +286,7 @@ class ShardedFilter(object):
     """One shard of a FastSLAM filter: same methods as ``_lib.DeviceFilter`` for what bench.py
     and the tests use, with the resample made global across ranks."""
 
-    def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None, global_scan=None):
+    def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None, global_scan=None, split_step=None):
         self.comm = comm if comm is not None else TorchComm()
         self.rank, self.world = self.comm.rank, self.comm.world
         self.P = int(particles_per_rank)
@@ -278,8 +306,12 @@ class ShardedFilter(object):
         if self.global_scan:
             self._logw = f.new_f64(self.P)
             self._glogw = f.new_f64(self.P_global) if self.world > 1 else self._logw
-        self._ranges = f.new_i64(2 * self.world)
-        self._all_ranges = f.new_i64(2 * self.world * self.world)
+        # per destination (j0, j1), then the global bounds of the slots this shard's own particles fill (the split step)
+        self._row = 2 * self.world + 2
+        self._ranges = f.new_i64(self._row)
+        self._all_ranges = f.new_i64(self._row * self.world)
+        self.split_step = (self.world > 1) if split_step is None else bool(split_step)
+        self.split_steps_done = 0
         self._sums = f.new_f64(4)
         self._recv_keepalive = None
         self._pending = None  # a resample whose exchange has been planned on the GPU but not carried out yet
@@ -382,6 +414,8 @@ class ShardedFilter(object):
             else:
                 gtot = self._totals
             f.plan_into(gtot, R * self.nb, self.P_global, u, R == W - 1, W, self._ranges)
+        if hasattr(f, "local_span_into"):
+            f.local_span_into(self._ranges[2 * W:])
         if W > 1:
             comm.all_gather_(self._all_ranges, self._ranges)
             table = self._all_ranges
@@ -391,25 +425,36 @@ class ShardedFilter(object):
         handle = f.start_host_read(table) if hasattr(f, "start_host_read") else None
         self._pending = (table, handle)
 
+    def _read_plan(self):
+        """The pending plan's range table on the host: (pairs[source][destination] -> (j0, j1), send / receive counts of this
+        rank, number of records that change rank anywhere, local slot run [a, b) of this rank)."""
+        table, handle = self._pending
+        self._pending = None
+        f, W, R = self.f, self.world, self.rank
+        host = f.finish_host_read(handle) if handle is not None else table.cpu().numpy()
+        rows = np.asarray(host).reshape(W, self._row)
+        allr = rows[:, :2 * W].reshape(W, W, 2)  # [source][destination] -> (j0, j1)
+        counts = allr[:, :, 1] - allr[:, :, 0]
+        send_counts = [int(counts[R, d]) if d != R else 0 for d in range(W)]
+        recv_counts = [int(counts[s, R]) if s != R else 0 for s in range(W)]
+        moving = int(counts.sum() - np.trace(counts))  # same number on every rank (all-gathered table)
+        lo, up = int(rows[R, 2 * W]) - R * self.P, int(rows[R, 2 * W + 1]) - R * self.P
+        a = min(max(lo, 0), self.P)
+        b = min(max(up, a), self.P)
+        return allr, send_counts, recv_counts, moving, a, b
+
     def _complete(self):
         """Carry out the exchange of a planned resample: read the range table, all-to-all of the
         migrating particles, adoption."""
         if self._pending is None:
             return
-        table, handle = self._pending
-        self._pending = None
         with self._ctx():
             f, comm, W, R = self.f, self.comm, self.world, self.rank
-            host = f.finish_host_read(handle) if handle is not None else table.cpu().numpy()
-            allr = np.asarray(host).reshape(W, W, 2)  # [source][destination] -> (j0, j1)
-            counts = allr[:, :, 1] - allr[:, :, 0]
-            send_counts = [int(counts[R, d]) if d != R else 0 for d in range(W)]
-            recv_counts = [int(counts[s, R]) if s != R else 0 for s in range(W)]
+            allr, send_counts, recv_counts, moving, _a, _b = self._read_plan()
             n_send, n_recv = sum(send_counts), sum(recv_counts)
             self.last_migrated = n_send
             self.total_migrated += n_send
             recv = None
-            moving = int(counts.sum() - np.trace(counts))  # same number on every rank (all-gathered table)
             if W > 1 and moving > 0:  # every rank takes part in the exchange, even with nothing of its own to move
                 send = f.alloc_records(n_send)
                 if n_send:
@@ -417,6 +462,35 @@ class ShardedFilter(object):
                 recv = comm.all_to_all_records(send, send_counts, recv_counts, f.particle_bytes())
             f.adopt_from(R, recv, n_recv)
             self._recv_keepalive = recv if n_recv else None
+
+    def _complete_and_step_split(self, v, w, dt, seed, draw):
+        """The pending exchange AND the motion + observe of the next step, overlapped: the particles that stay on this rank
+        (output slots [a, b) of the new generation) are moved and observed while the migrating ones travel; the slots at
+        either end follow.  The staged scan must take the register route."""
+        with self._ctx():
+            f, comm, W, R = self.f, self.comm, self.world, self.rank
+            allr, send_counts, recv_counts, moving, a, b = self._read_plan()
+            n_send, n_recv = sum(send_counts), sum(recv_counts)
+            self.last_migrated = n_send
+            self.total_migrated += n_send
+            recv, work = None, None
+            if W > 1 and moving > 0:
+                send = f.alloc_records(n_send)
+                if n_send:
+                    f.pack_into(allr[R].reshape(-1), W, R, send)  # from the OLD generation: before the adoption below
+                recv, work = comm.all_to_all_records_async(send, send_counts, recv_counts, f.particle_bytes())
+            f.adopt_local(R)
+            f.motion_range(v, w, dt, seed, draw, a, b)
+            f.observe_staged_range(True, a, b, True, False)  # weight reset (:73) fused in; consumes the staged scan
+            if work is not None:
+                work.wait()  # the stream waits for the records, the host does not
+            f.adopt_remote(R, recv, n_recv)
+            f.motion_range(v, w, dt, seed, draw, 0, a)
+            f.motion_range(v, w, dt, seed, draw, b, self.P)
+            f.observe_staged_range(True, 0, a, False, False)
+            f.observe_staged_range(True, b, self.P, False, True)
+            self._recv_keepalive = recv if n_recv else None  # read by the launches above: freed in stream order later
+            self.split_steps_done += 1
 
     def _global_ancestors(self, u, domain):
         """Tests only: global ancestor index of every local output slot, from the host-array
@@ -450,13 +524,17 @@ class ShardedFilter(object):
         if ids is None and hasattr(self.f, "stage_scan") and len(blobs) > 0:
             self.f.stage_scan(blobs)
             staged = True
-        self._complete()
-        self.f.motion(v, w, dt, z=z, seed=seed, draw=draw)
-        if staged:
-            self.f.observe_staged(fresh=True)  # weight reset (:73) fused into the observe kernels
-            self._recv_keepalive = None
+        if (staged and self.split_step and z is None and self._pending is not None and hasattr(self.f, "staged_takes_regs")
+                and self.f.staged_takes_regs()):
+            self._complete_and_step_split(v, w, dt, seed, draw)
         else:
-            self.observe(blobs, ids=ids, fresh=True)
+            self._complete()
+            self.f.motion(v, w, dt, z=z, seed=seed, draw=draw)
+            if staged:
+                self.f.observe_staged(fresh=True)  # weight reset (:73) fused into the observe kernels
+                self._recv_keepalive = None
+            else:
+                self.observe(blobs, ids=ids, fresh=True)
         self.resample(u, domain=domain, defer=True)
 
     def summary(self):

@@ -144,6 +144,10 @@ class OracleShard(object):
     def shard_download_offspring(self):
         return self.hi.copy()
 
+    def local_span_into(self, t2):
+        t2[0] = int(self.hi[0])
+        t2[1] = int(self.hi[self.P])
+
     def _ranges_from_hi(self, world, ranges_t):
         hi, P = self.hi, self.P
         for d in range(world):

@@ -110,6 +110,7 @@ def _nccl_single(q):
         os.environ.setdefault("MASTER_PORT", "29581")
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1)
+        from parakeet_slam_amd import _lib as _lib_mod
         from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
 
         comm = TorchComm()
@@ -122,6 +123,10 @@ def _nccl_single(q):
         assert np.array_equal(out.cpu().numpy(), np.arange(4.0))
         rec = comm.all_to_all_records(torch.arange(16, dtype=torch.uint8, device="cuda"), [2], [2], 8)
         assert np.array_equal(rec.cpu().numpy()[:16], np.arange(16))
+        rec2, work = comm.all_to_all_records_async(torch.arange(16, 32, dtype=torch.uint8, device="cuda"), [2], [2], 8)
+        assert work is not None
+        work.wait()
+        assert np.array_equal(rec2.cpu().numpy()[:16], np.arange(16, 32))
         L = 8
         means, covs, scans = scenario(L, 2)
         sf = ShardedFilter(2048, L, device=0, comm=comm)
@@ -129,6 +134,21 @@ def _nccl_single(q):
         for s in range(2):
             sf.step(0.2, 0.1, 0.1, scans[s], 0.37, seed=3, draw=s, domain=1)
         sm = sf.summary()
+        # the split step (exchange overlapped with the work on the particles that stay) with one rank: everything stays, the
+        # range launches cover [0, P) in one piece -- same state as the plain filter, exactly
+        Ls = 600
+        ms, cs, scs = _fast_scenario(Ls, 3)
+        s1 = ShardedFilter(1500, Ls, device=0, comm=comm, split_step=True)
+        s1.upload_map(ms, cs.reshape(Ls, 25))
+        p1 = _lib_mod.DeviceFilter(1500, Ls)
+        p1.upload_map(ms, cs.reshape(Ls, 25))
+        for st in range(3):
+            s1.step(_V, _W, 0.1, scs[st], 0.37, seed=4, draw=st, domain=1)
+            p1.step(_V, _W, 0.1, scs[st], 0.37, seed=4, draw=st, domain=1)
+        assert s1.split_steps_done == 2
+        assert np.array_equal(s1.download_poses(), p1.download_poses())
+        for xa, xb in zip(s1.download_landmarks(), p1.download_landmarks()):
+            assert np.array_equal(xa, xb)
         # the global-scan plan (shards that end inside a scan block; bench.py's 100 000 particles per rank) through the same
         # communicator: ancestors against the plain filter on the same weights
         from parakeet_slam_amd import _lib
@@ -215,4 +235,98 @@ def test_one_launch_shard_plan_matches_the_host_variant(lib, P, world, rank, oth
         f.shard_plan_dev(gt_dev.data_ptr(), gt.size, rank * nb, P * world, u, rank == world - 1, world, ranges.data_ptr())
         f.synchronize()
         assert np.array_equal(ranges.cpu().numpy(), want), (ranges.cpu().numpy(), want)
+    f.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ShardedFilter.step with the exchange overlapped (split step): the particles that stay on a rank are moved and observed
+# while the migrating ones travel.  Same result as the step that waits for the exchange first -- exactly -- and as one
+# filter holding all particles (to rounding: the shards build their candidate lists around their own reference).
+_V, _W = 1.5, 0.6  # fast enough for the motion noise to spread the weights: particles change rank at every resample
+
+
+def _fast_scenario(L, steps):
+    from oracle.fastslam_oracle import synthetic_scan, synthetic_world, truth_step
+
+    means, covs = synthetic_world(L)
+    pose, scans = (0.0, 0.0, 0.0), []
+    for _ in range(steps):
+        pose = truth_step(pose, _V, _W, 0.1)
+        scans.append(synthetic_scan(means, pose))
+    return means, covs, scans
+
+
+def _step_worker(rank, world, store, P_local, L, steps, split, q):
+    try:
+        init_gloo(rank, world, store)
+        from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
+
+        means, covs, scans = _fast_scenario(L, steps)
+        _z, us = noise(P_local * world, steps, 11)
+        sf = ShardedFilter(P_local, L, device=0, comm=TorchComm(), split_step=split)
+        sf.upload_map(means, covs.reshape(L, 25))
+        for s in range(steps):
+            sf.step(_V, _W, 0.1, scans[s], float(us[s]), seed=9, draw=s, domain=1)
+        sm = sf.summary()
+        m, c, k = sf.download_landmarks()
+        q.put((rank, (sf.download_poses(), m, c, k, sm, sf.split_steps_done, sf.total_migrated)))
+    except Exception:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "ERR " + traceback.format_exc()))
+
+
+def _run_step_workers(world, P_local, L, steps, split):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    store = store_file()
+    procs = [ctx.Process(target=_step_worker, args=(r, world, store, P_local, L, steps, split, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, res = q.get(timeout=600)
+        assert not isinstance(res, str), res
+        got[r] = res
+    for p in procs:
+        p.join(timeout=60)
+    return got
+
+
+@pytest.mark.parametrize("world,P_local", [(2, 1024), (3, 700)])
+def test_split_step_overlaps_the_exchange_and_changes_nothing(world, P_local):
+    from parakeet_slam_amd import _lib
+
+    L, steps = 600, 5
+    a = _run_step_workers(world, P_local, L, steps, True)
+    b = _run_step_workers(world, P_local, L, steps, False)
+    moved = 0
+    for r in range(world):
+        assert a[r][5] == steps - 1 and b[r][5] == 0  # every step after the first took the split path / none did
+        # poses, maps, counts: exactly; the log-weights to rounding -- the shard's candidate lists are built around the mean
+        # pose of what is resident when the first part starts, so a particle may be flagged in one run and not in the other,
+        # and the fallback kernels add the same terms in another order (same maps bit for bit)
+        assert np.array_equal(a[r][0][:, :3], b[r][0][:, :3]), "split step differs from the plain sharded step (rank %d)" % r
+        assert np.allclose(np.log(a[r][0][:, 3]), np.log(b[r][0][:, 3]), rtol=1e-12, atol=1e-12)
+        for x, y in zip(a[r][1:4], b[r][1:4]):
+            assert np.array_equal(x, y), "split step differs from the plain sharded step (rank %d)" % r
+        assert np.allclose(a[r][4], b[r][4], rtol=1e-13, atol=1e-14)
+        moved += a[r][6]
+    assert moved > 0, "no particle changed rank: the test did not exercise the exchange"
+    # and one filter with all the particles
+    means, covs, scans = _fast_scenario(L, steps)
+    P = world * P_local
+    _z, us = noise(P, steps, 11)
+    f = _lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    for s in range(steps):
+        f.step(_V, _W, 0.1, scans[s], float(us[s]), seed=9, draw=s, domain=1)
+    poses = np.concatenate([a[r][0] for r in range(world)])
+    ref = f.download_poses()
+    assert np.allclose(poses[:, :3], ref[:, :3], rtol=1e-12, atol=1e-13)
+    assert np.allclose(np.log(poses[:, 3]), np.log(ref[:, 3]), rtol=1e-9, atol=1e-9)
+    m = np.concatenate([a[r][1] for r in range(world)])
+    rm, rc, rk = f.download_landmarks()
+    assert np.allclose(m, rm, rtol=1e-11, atol=1e-12) and np.array_equal(np.concatenate([a[r][3] for r in range(world)]), rk)
+    assert np.allclose(a[0][4], f.summary(), rtol=1e-12, atol=1e-13)
     f.close()
