@@ -1297,8 +1297,9 @@ static int onepass_finish(pk_filter* f, const AssocLaunch& al, int B, const Obse
   if (al.regs && al.retry) {
     // second chance for what k_step_regs flagged (some landmark passes more than its four register slots -- 2 us per
     // particle in the general kernels, and up to 9 % of the particles at some poses of the bench's trajectory): the
-    // hand-off instance with eight slots and k_observe_sweep, both on the flagged particles only
-    Span t(f, PK_T_OBSERVE);
+    // hand-off instance with eight slots and k_observe_sweep, both on the flagged particles only (timed with the other
+    // fallbacks in the association slot: the observe slot holds the one-pass kernel alone, one span per launch)
+    Span t(f, PK_T_ASSOC);
     const SweepPlan plan = observe_sweep_plan(f->d, B);
     const size_t need = (size_t)plan.grid * plan.results_per_wg;
     if (need > f->sweep_cap) {
