@@ -118,6 +118,9 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "cand_lists"   = 1 (default: k_step_regs tests each landmark against the candidate list of a reference particle
  *                    -- k_candidates, once per scan -- instead of walking the colour grid; particles outside the
  *                    list's margins go the general way) or 0 (grid walk);
+ *   "split_reserve_cus" = 0..128 (default 16): CUs the first part of a split step (pk_observe_staged_range, first = 1,
+ *                    last = 0) leaves without a workgroup -- k_step_regs holds a CU's whole register file for the whole
+ *                    launch, and the all-to-all that is to run meanwhile needs CUs of its own;
  *   "regs_retry"   = 1 (default: particles k_step_regs flags -- a landmark passing more than four blobs -- get a second
  *                    chance on the eight-slot hand-off + k_observe_sweep before the general kernels) or 0;
  *   "regs_warm"    = 0..2: how much of the NEXT particle's map slot k_step_regs touches ahead of time

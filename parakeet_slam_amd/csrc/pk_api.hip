@@ -150,6 +150,7 @@ struct pk_filter {
     int B = 0;
     bool reset = false;
   } split;
+  int split_reserve_cus = 16;  // CUs the first part of a split step leaves free for the all-to-all's kernels
   int regs_retry = 1;    // k_step_regs: 1 = the particles it flags get a second chance (eight-slot hand-off + k_observe_sweep) before the general kernels
   int regs_warm = 1;     // k_step_regs: L2 warming of the next particle's slot: 0 none, 1 its mean rows (default), 2 the whole slot (measured slower)
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
@@ -1275,7 +1276,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
 }
 // 2. the one-pass kernel on the particles [p0, p1) (the fused kernel: the whole range only)
 static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const ObserveExtras& ex, const CandTable& cand, int64_t p0,
-                          int64_t p1) {
+                          int64_t p1, int reserve_cus = 0) {
   FastHandoff fh = f->fh;
   fh.n_flagged = ctl_n_flagged(f);
   fh.flags_only = true;
@@ -1283,7 +1284,8 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
   ObserveExtras e1 = ex;
   e1.flip = false;
   if (al.regs)
-    launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1);
+    launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
+                     reserve_cus);
   else
     launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
   return PK_OK;
@@ -1565,7 +1567,8 @@ int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1,
   ObserveExtras ex;
   ex.reset = sp.reset;
   ex.gmax_key = ctl_gmax_key(f);
-  if (p1 > p0 && (rc = onepass_launch(f, sp.al, sp.B, ex, sp.cand, p0, p1))) return rc;
+  // the first part of a split step runs while the exchange is in flight: it leaves some CUs to the collective's kernels
+  if (p1 > p0 && (rc = onepass_launch(f, sp.al, sp.B, ex, sp.cand, p0, p1, (first && !last) ? f->split_reserve_cus : 0))) return rc;
   if (last) {
     sp.active = false;
     if ((rc = onepass_finish(f, sp.al, sp.B, ex, sp.cand))) return rc;
@@ -1643,6 +1646,11 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "regs_step")) {
     f->regs_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "split_reserve_cus")) {
+    if (value < 0 || value > 128) return fail(PK_ERR_INVALID, "split_reserve_cus: 0..128");
+    f->split_reserve_cus = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "regs_retry")) {

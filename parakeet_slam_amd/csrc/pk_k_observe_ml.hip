@@ -1984,7 +1984,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
 
 void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
-                      const ObserveExtras& ex, int warm, const CandTable& cand, int64_t p0, int64_t p1) {
+                      const ObserveExtras& ex, int warm, const CandTable& cand, int64_t p0, int64_t p1, int reserve_cus) {
   if (p1 < 0) p1 = d.P;
   if (d.P == 0 || p1 <= p0) return;
   static bool attr_set[kMaxDevices] = {false};
@@ -2035,7 +2035,9 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
       n_cu = 256;
     (void)hipGetLastError();
   }
-  int64_t grid_n = n_cu;
+  // reserve_cus: leave that many CUs without a workgroup -- this kernel's workgroups hold a CU's whole register file for the
+  // whole launch, and a collective that is to run meanwhile (the sharded filter's all-to-all) needs somewhere to run
+  int64_t grid_n = n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0);
   if (grid_n > p1 - p0) grid_n = p1 - p0;
   if (cand.rec)
     hipLaunchKernelGGL(k_step_regs<true>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_cand_lds_bytes(d.lay.Lp, B), s, ra);

@@ -202,7 +202,8 @@ size_t regs_cand_lds_bytes(int Lp, int B);
 // grid-walk instance (returns at once when *cand.over == 0)
 void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
-                      const ObserveExtras& ex, int warm, const CandTable& cand = CandTable(), int64_t p0 = 0, int64_t p1 = -1);
+                      const ObserveExtras& ex, int warm, const CandTable& cand = CandTable(), int64_t p0 = 0, int64_t p1 = -1,
+                      int reserve_cus = 0);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued
