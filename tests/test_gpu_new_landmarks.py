@@ -144,4 +144,20 @@ def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
     # at the blobs' bearings; after the updates they still are within the bearing gate of the true landmarks' directions
     got = np.array([f.mean[:2] for i, f in list(p0.feature_set.items()) + list(p0.potential_features.items()) if abs(i) > L0])
     assert len(got) == o.used[0] and np.isfinite(got).all()
+    # snapshot round trip in the growing mode: landmarks (spare slots and flags included) and the host bookkeeping
+    import os
+    import tempfile
+
+    path = os.path.join(tempfile.mkdtemp(), "grow.npz")
+    fs.save_state(path)
+    fs2 = pk.FastSLAM([pk.Feature(mean=m.copy(), covar=c.copy()) for m, c in zip(known, kcov)], num_particles=P,
+                      weight_domain="log", new_landmarks=True, spare_landmarks=spare, pair_threshold=thr)
+    fs2.load_state(path)
+    for xa, xb in zip(fs._filter.download_landmarks(), fs2._filter.download_landmarks()):
+        assert np.array_equal(xa, xb)
+    assert fs2._next_id == fs._next_id and fs2._used == fs._used and fs2._slot_id == fs._slot_id
+    assert [list(map(tuple, h)) for h in fs2._hyp] == [list(map(tuple, h)) for h in fs._hyp]
+    q0 = fs2.particles[0]
+    assert set(q0.potential_features) == set(p0.potential_features) and set(q0.feature_set.keys()) == set(p0.feature_set.keys())
+    fs2.close()
     fs.close()
