@@ -139,6 +139,43 @@ def test_config2_routes_agree_at_full_size(lib, config2_default, name, opts):
         assert np.array_equal(ka, kb)
 
 
+def test_config2_second_chance_route_at_the_poses_that_need_it(lib):
+    """Around steps 44-62 of the bench's trajectory up to 9 % of the particles have a landmark that passes more than four
+    blobs (k_step_regs' register slots).  With "regs_retry" they are settled by the eight-slot hand-off + k_observe_sweep,
+    without it by the general kernels: same ancestors, same maps, weights to rounding -- at full size."""
+    import bench
+
+    S = 50
+    means, covs, scans = bench.synthetic_inputs(L2, S + 1)
+    ws = bench.synthetic_controls(S + 1)
+    out = {}
+    for retry in (1, 0):
+        f = lib.DeviceFilter(P2, L2)
+        f.set_option("regs_retry", retry)
+        f.upload_map(means, covs.reshape(L2, 25))
+        rnd = random.Random(7)
+        flagged, ancs = [], []
+        for s in range(S):
+            f.reset_weights()
+            f.motion(0.2, ws[s], 0.1, seed=7, draw=s)
+            f.observe(scans[s])
+            flagged.append(f.observe_flagged()[0])
+            anc = f.resample(rnd.random(), domain=lib.PK_WEIGHTS_LOG, return_ancestors=(s >= 44))
+            if s >= 44:
+                ancs.append(anc)
+        out[retry] = (flagged, ancs, f.download_poses(), f.download_landmarks(0, 64), f.summary())
+        f.close()
+    a, b = out[1], out[0]
+    assert a[0] == b[0] and max(a[0]) > P2 // 100, "the trajectory no longer reaches the poses this test is about"
+    for x, y in zip(a[1], b[1]):
+        assert np.array_equal(x, y), "ancestors differ between the second-chance and the general fallback"
+    assert np.array_equal(a[2][:, :3], b[2][:, :3])
+    for x, y in zip(a[3][:2], b[3][:2]):
+        assert np.allclose(x, y, rtol=1e-11, atol=1e-13)
+    assert np.array_equal(a[3][2], b[3][2])
+    assert np.allclose(a[4], b[4], rtol=1e-12, atol=1e-13)
+
+
 def test_config2_replay_is_bit_identical(lib, config2_default):
     a, b = config2_default, run_config2(lib, 3, {})
     assert np.array_equal(a["poses"], b["poses"])
