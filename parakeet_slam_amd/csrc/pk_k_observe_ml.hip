@@ -1170,6 +1170,7 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
 // A particle in which a landmark passes more than kFastSlots blobs, or whose queue overflows in a round,
 // is flagged for the general kernels before anything of it has been written.
 constexpr int kRegsThreads = 1024;
+// (diagnostic builds only: -DPK_REGS_BOUND=512 lifts the 128-register cap to show what the allocator would like to have)
 #ifndef PK_REGS_BOUND
 #define PK_REGS_BOUND kRegsThreads
 #endif
