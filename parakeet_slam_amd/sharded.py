@@ -480,15 +480,20 @@ class ShardedFilter(object):
                     f.pack_into(allr[R].reshape(-1), W, R, send)  # from the OLD generation: before the adoption below
                 recv, work = comm.all_to_all_records_async(send, send_counts, recv_counts, f.particle_bytes())
             f.adopt_local(R)
-            f.motion_range(v, w, dt, seed, draw, a, b)
-            f.observe_staged_range(True, a, b, True, False)  # weight reset (:73) fused in; consumes the staged scan
-            if work is not None:
-                work.wait()  # the stream waits for the records, the host does not
-            f.adopt_remote(R, recv, n_recv)
-            f.motion_range(v, w, dt, seed, draw, 0, a)
-            f.motion_range(v, w, dt, seed, draw, b, self.P)
-            f.observe_staged_range(True, 0, a, False, False)
-            f.observe_staged_range(True, b, self.P, False, True)
+            if recv is None:  # nobody changes rank this time: every slot is filled locally, one launch over all of them
+                f.adopt_remote(R, None, 0)
+                f.motion_range(v, w, dt, seed, draw, 0, self.P)
+                f.observe_staged_range(True, 0, self.P, True, True)
+            else:
+                f.motion_range(v, w, dt, seed, draw, a, b)
+                f.observe_staged_range(True, a, b, True, False)  # weight reset (:73) fused in; consumes the staged scan
+                if work is not None:
+                    work.wait()  # the stream waits for the records, the host does not
+                f.adopt_remote(R, recv, n_recv)
+                f.motion_range(v, w, dt, seed, draw, 0, a)
+                f.motion_range(v, w, dt, seed, draw, b, self.P)
+                f.observe_staged_range(True, 0, a, False, False)
+                f.observe_staged_range(True, b, self.P, False, True)
             self._recv_keepalive = recv if n_recv else None  # read by the launches above: freed in stream order later
             self.split_steps_done += 1
 
