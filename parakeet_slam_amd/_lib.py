@@ -94,6 +94,7 @@ SIGNATURES = {
     "pk_observe_route": (C.c_int, [_h]),
     "pk_download_sources": (C.c_int, [_h, _ip]),
     "pk_observe_flagged": (C.c_int, [_h, _lp, _lp]),
+    "pk_observe_published": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_create_python": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_destroy": (C.c_int, [_h]),
@@ -379,6 +380,12 @@ class DeviceFilter(object):
         a, b = C.c_int64(), C.c_int64()
         check(self._lib.pk_observe_flagged(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def observe_published(self):
+        """True when k_step_pub (static publish / subscribe settling) worked on the last register-route scan."""
+        v = C.c_int32()
+        check(self._lib.pk_observe_published(self._h, C.byref(v)))
+        return bool(v.value)
 
     def download_sources(self):
         """Map slot each particle's landmarks currently live in (pk_download_sources)."""

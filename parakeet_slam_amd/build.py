@@ -16,14 +16,14 @@ import sys
 # Per-file extra flags.  The ML observe kernels are register-bound: with MachineLICM on, the back end hoists
 # constant materialisations and address arithmetic out of every loop and keeps them live around it
 # (k_observe_sweep: 168 VGPRs + 96 B of scratch against 129 / none; k_step_fused: 121 against 99).
-EXTRA_FLAGS = {"pk_k_observe_ml.hip": ["-mllvm", "-disable-machine-licm"]}
+EXTRA_FLAGS = {"pk_k_observe_ml.hip": ["-mllvm", "-disable-machine-licm"], "pk_k_step_pub.hip": ["-mllvm", "-disable-machine-licm"]}
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libparakeet_slam.so")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 
-HIP_SOURCES = ["pk_k_motion.hip", "pk_k_assoc.hip", "pk_k_observe.hip", "pk_k_observe_ml.hip", "pk_k_owner.hip", "pk_k_dense.hip", "pk_k_resample.hip", "pk_api.hip"]
+HIP_SOURCES = ["pk_k_motion.hip", "pk_k_assoc.hip", "pk_k_observe.hip", "pk_k_observe_ml.hip", "pk_k_step_pub.hip", "pk_k_owner.hip", "pk_k_dense.hip", "pk_k_resample.hip", "pk_api.hip"]
 CXX_SOURCES = ["pk_rng.cpp"]  # host-only, no FMA contraction: must match NumPy/CPython bit for bit
 HEADERS = [
     "pk_math.hpp", "pk_layout.hpp", "pk_kernels.hpp", "pk_philox.hpp", "pk_device.hpp",

@@ -25,7 +25,7 @@ int pk_upload_landmarks(pk_filter* f, int64_t p0, int64_t p1, const double* mean
 }
 
 #ifdef PK_STAMPS
-namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); void debug_read_fused_stamps(unsigned long long* out, bool reset); void debug_read_regs_stamps(unsigned long long* out, bool reset); }
+namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); void debug_read_fused_stamps(unsigned long long* out, bool reset); void debug_read_regs_stamps(unsigned long long* out, bool reset); void debug_read_pub_stamps(unsigned long long* out, bool reset); }
 #endif
 
 namespace {
@@ -142,6 +142,9 @@ struct pk_filter {
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
   uint4* cand_dev = nullptr;  // [Lp][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
+  int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
+  uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
+  unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
   struct Split {
     bool active = false;
@@ -150,6 +153,7 @@ struct pk_filter {
     int B = 0;
     bool reset = false;
   } split;
+  int pub_ecap = 0;       // k_step_pub was prepared for the current scan with this many publish entries (0: not prepared)
   int split_reserve_cus = 16;  // CUs the first part of a split step leaves free for the all-to-all's kernels
   int regs_retry = 1;    // k_step_regs: 1 = the particles it flags get a second chance (eight-slot hand-off + k_observe_sweep) before the general kernels
   int regs_warm = 1;     // k_step_regs: L2 warming of the next particle's slot: 0 none, 1 its mean rows (default), 2 the whole slot (measured slower)
@@ -259,7 +263,7 @@ int use_device(pk_filter* f) {
 //   known ids:  [first Lp i32] [next B i32]
 //   ML:         [dir 2B f64] [exact 6B f64] [association tables]
 // The copy also zeroes ctl, which is how every observe starts with a fresh max / count.
-constexpr size_t kCtlBytes = 8 * kGmaxKeys + 16;  // running-max keys, then the flagged-particle count
+constexpr size_t kCtlBytes = 8 * kGmaxKeys + 32;  // running-max keys, then the flagged-particle count and the route control words
 int ensure_scan_capacity(pk_filter* f, size_t bytes) {
   if (bytes <= f->scan_cap) return PK_OK;
   PK_HIP(hipStreamSynchronize(f->stream));
@@ -552,6 +556,10 @@ inline unsigned long long* ctl_gmax_key(pk_filter* f) { return reinterpret_cast<
 inline unsigned* ctl_n_flagged(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys); }
 inline unsigned* ctl_cand_over(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 4); }
 inline unsigned* ctl_n_stray(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 8); }
+// written by k_cand_entries: != 0 -> k_step_pub stands back (a candidate list overflowed, or the publish table does not fit LDS)
+inline unsigned* ctl_skip_pub(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 12); }
+// != 0 -> the candidate-list instance of k_step_regs stands back (k_step_pub runs, or the grid walk does)
+inline unsigned* ctl_skip_cand(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 16); }
 
 // Host half of the ML scan upload: blobs, ray directions, exact records and the association tables
 // are laid out in a pinned staging slot (no device work; may synchronise only to grow buffers).
@@ -931,7 +939,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->binfo_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1262,15 +1270,48 @@ static int dense_observe(pk_filter* f, const double* blobs, int32_t B, const int
 // ---- the one-pass routes (k_step_fused / k_step_regs) in three pieces, so that the sharded filter can run the middle one
 // on a part of the particles while the rest are still on the wire (pk_observe_staged_range) -------------------------------
 // 1. the reference particle's candidate lists (register route), timed with the association
+static int ensure_inverse_lists(pk_filter* f, int B) {
+  int rc;
+  if (B > f->bcand_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    for (void* q : {(void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->binfo_dev})
+      if (q) (void)hipFree(q);
+    f->bcnt_dev = nullptr;
+    f->brec_dev = nullptr;
+    f->binfo_dev = nullptr;
+    f->bcand_cap = 0;
+    const int64_t cap = (int64_t)B + B / 4 + 64;
+    if ((rc = dev_alloc(f, &f->bcnt_dev, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(f, &f->binfo_dev, (size_t)cap))) return rc;
+    f->bcand_cap = cap;
+  }
+  return PK_OK;
+}
 static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand) {
   int rc;
+  f->pub_ecap = 0;
   if (al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) {
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
+    const int ecap = f->pub_step ? step_pub_entry_capacity(B) : 0;
+    if (ecap > 0) {
+      if (!f->erec_dev && (rc = dev_alloc(f, &f->erec_dev, (size_t)f->d.lay.Lp))) return rc;
+      if ((rc = ensure_inverse_lists(f, B))) return rc;
+    }
     Span t(f, PK_T_ASSOC);
     launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
-    launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
     cand->rec = f->cand_dev;
     cand->over = ctl_cand_over(f);
+    if (ecap > 0) {  // candidate lists both ways, and the publish table's layout
+      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
+                        kCandSlots, f->out4);
+      launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, ctl_cand_over(f),
+                          ctl_skip_pub(f), ctl_skip_cand(f), ecap);
+      cand->skip_cand = ctl_skip_cand(f);
+      f->pub_ecap = ecap;
+    } else {
+      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
+    }
   }
   return PK_OK;
 }
@@ -1283,10 +1324,13 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
   Span t(f, PK_T_OBSERVE);
   ObserveExtras e1 = ex;
   e1.flip = false;
-  if (al.regs)
+  if (al.regs) {
+    if (f->pub_ecap > 0 && cand.rec)
+      launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->binfo_dev, ctl_skip_pub(f), f->pub_ecap,
+                      p0, p1, reserve_cus);
     launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
                      reserve_cus);
-  else
+  } else
     launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
   return PK_OK;
 }
@@ -1420,18 +1464,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     fh.n_flagged = ctl_n_flagged(f);
     fh.flags_only = true;
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
-    if (B > f->bcand_cap) {
-      PK_HIP(hipStreamSynchronize(f->stream));
-      if (f->bcnt_dev) (void)hipFree(f->bcnt_dev);
-      if (f->brec_dev) (void)hipFree(f->brec_dev);
-      f->bcnt_dev = nullptr;
-      f->brec_dev = nullptr;
-      f->bcand_cap = 0;
-      const int64_t cap = (int64_t)B + B / 4 + 64;
-      if ((rc = dev_alloc(f, &f->bcnt_dev, (size_t)cap))) return rc;
-      if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
-      f->bcand_cap = cap;
-    }
+    if ((rc = ensure_inverse_lists(f, B))) return rc;
     CandTable cand;
     {
       Span t(f, PK_T_ASSOC);  // the reference particle's candidate lists, both ways
@@ -1642,6 +1675,10 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "cand_lists")) {
     f->cand_lists = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "pub_step")) {
+    f->pub_step = value != 0;
     return PK_OK;
   }
   if (!strcmp(name, "regs_step")) {
@@ -2143,6 +2180,7 @@ __attribute__((visibility("default"))) int pk_debug_stamps(unsigned long long* o
   pk::debug_read_stamps(out, reset != 0);            // out[0..15]: k_assoc_grid
   pk::debug_read_fused_stamps(out + 16, reset != 0);  // out[16..31]: k_step_fused
   pk::debug_read_regs_stamps(out + 32, reset != 0);   // out[32..47]: k_step_regs
+  pk::debug_read_pub_stamps(out + 48, reset != 0);    // out[48..63]: k_step_pub
   return PK_OK;
 }
 #endif
@@ -2191,6 +2229,19 @@ int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow) {
   }
   if (flagged) *flagged = w[0];
   if (cand_overflow) *cand_overflow = w[1];
+  return PK_OK;
+}
+int pk_observe_published(pk_filter* f, int32_t* published) {
+  if (!f || !published) return fail(PK_ERR_INVALID, "pk_observe_published: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  *published = 0;
+  if (f->scan_dev && f->route == PK_ROUTE_ML_REGS && f->pub_ecap > 0) {
+    unsigned w = 1u;
+    PK_HIP(hipMemcpyAsync(&w, ctl_skip_pub(f), sizeof(w), hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+    *published = w == 0u ? 1 : 0;
+  }
   return PK_OK;
 }
 int pk_download_sources(pk_filter* f, int32_t* src) {

@@ -1189,6 +1189,7 @@ struct RegsArgs {
   int64_t p_begin;              // its start (0 but for the split step of the sharded filter)
   const uint4* cand;            // candidate lists of the reference particle (CandTable), or NULL
   const unsigned* cand_over;    // != 0: the lists overflowed, this scan takes the grid walk
+  const unsigned* cand_skip;    // != 0: the candidate-list instance stands back (lists overflowed, or k_step_pub takes the scan)
 };
 
 // LDS: tables | ccount int[B] (later: win) | best u64[B] | queue inputs 36 B x kRegsQueue | results u64[2 kRegsQueue] | counters
@@ -1552,7 +1553,7 @@ __global__ void __launch_bounds__(PK_REGS_BOUND) k_step_regs(RegsArgs ra_unused)
     // which instance works on this scan: candidate lists, unless some landmark's list overflowed (workgroup-uniform)
     {
       const unsigned* over = R->cand_over;
-      if (CAND ? *over != 0u : (over != nullptr && *over == 0u)) return;
+      if (CAND ? *R->cand_skip != 0u : (over != nullptr && *over == 0u)) return;
     }
     lds.B = R->f.B;
     Lp = R->f.Lp;
@@ -2025,6 +2026,7 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
   ra.p_begin = p0;
   ra.cand = cand.rec;
   ra.cand_over = cand.rec ? cand.over : nullptr;
+  ra.cand_skip = cand.rec ? (cand.skip_cand ? cand.skip_cand : cand.over) : nullptr;
   // persistent grid: the workgroups that are resident at once (one per CU: 1024 lanes x 128 VGPRs)
   static int n_cu = 0;
   if (n_cu == 0) {

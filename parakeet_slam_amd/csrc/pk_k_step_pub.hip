@@ -1,0 +1,739 @@
+// K2 + K3 in ONE pass with the settling of contested blobs turned into a STATIC publish / subscribe through LDS:
+// k_step_pub (512 < L <= 2048), and k_cand_entries, which lays the publish table out once per scan.
+//
+// Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update; see DESIGN.md section 4.
+// No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
+//
+// What couples the landmarks of a particle in maximum-likelihood association (prkt_core_v2.py:353-381) is a blob that
+// passes the gates of several landmarks: it goes to the most probable one, the earliest on a tie (:377), to nobody when
+// every probability is 0 (:369).  k_step_regs settles that with per-blob counters, a probability queue, bids and eight
+// workgroup barriers per particle -- one particle per CU in lock step.  Here WHO can contend for a blob is known before
+// the particle is looked at: the reference particle's candidate lists (k_candidates), landmark -> blobs and blob ->
+// landmarks.  So every (landmark, blob) pair that can be contested owns a fixed 8-byte entry of an LDS table for the
+// whole scan (blob t: entries offs[t] .. offs[t] + n[t] - 1, one per landmark of its inverse list, ascending):
+//   publish    the landmark's lane writes its verdict there -- +inf when the blob does not pass its gates or has
+//              probability 0, else the pair's KEY = -2 log(probability) up to rounding --
+//   barrier
+//   subscribe  and reads the rivals' entries of the blobs it passes: the smallest key takes the blob, the lowest
+//              landmark on equal keys.
+// No atomics, no queue, two barriers per particle (the second only hands the table to the next particle), and between
+// them only the short subscribe phase: the long phases -- rows arriving, gates, keys / EKF updates, stores -- run without
+// any synchronisation, so the waves of a workgroup drift apart and one wave's memory time is another's arithmetic.
+//
+// Keys instead of probabilities: the reference compares pr = (500 exp(-a2/2)) (500 exp(-a3/2)) / 250000 (:439-455);
+// -2 log pr = a2 + a3 orders the same way wherever the two differ by more than rounding.  The kernel therefore FLAGS a
+// particle for the general kernels (exact probabilities, as before) whenever keys of two contenders are closer than 1e-7
+// without being identical (identical landmarks give identical keys: a tie, :377), and wherever pr would be subnormal
+// (keys beyond 1400) with a second contender; whether pr is > 0 at all (:369, strict) is decided from the keys with
+// margins on both sides of the float64 underflow edge and evaluated exactly inside them.
+//
+// Shape: persistent 512-lane workgroups, one per CU, FOUR landmarks per lane (two adjacent pairs, 16-byte row accesses),
+// the particle's whole map in registers from its single coalesced load to its single coalesced store; 8 waves x 256
+// VGPRs are the CU's register file, and 256 registers hold a lane's four landmarks (116) plus the update's working set
+// without parking anything in LDS.
+#include "pk_device.hpp"
+
+namespace pk {
+
+constexpr int kPubThreads = 512;
+constexpr int kPubWaves = kPubThreads / kWave;
+constexpr int kPubSlots = 4;  // gate-passing blobs a landmark keeps; more: the particle is flagged
+
+typedef double Double2 __attribute__((ext_vector_type(2)));
+typedef int Int2 __attribute__((ext_vector_type(2)));
+
+// A particle's pose component / source slot through the constant address space: uniform reads become scalar loads (their
+// own counter, the scalar cache) instead of vector loads that queue behind the rows in flight.  The poses are not written
+// while the kernel runs; src[p] is written only by the workgroup that owns particle p, after it has read it.
+__device__ __forceinline__ double pose_scalar(const double* a, int64_t p) {
+  return ((const __attribute__((address_space(4))) double*)a)[p];
+}
+__device__ __forceinline__ int32_t regs_source_pub(const int32_t* src, int64_t p) {
+  return ((const __attribute__((address_space(4))) int32_t*)src)[p];
+}
+
+struct PubArgs {
+  SlotSource ss;
+  unsigned char* map_dst;
+  size_t count_off;
+  int32_t* src;
+  const double *x, *y, *h;
+  double* logw;
+  const double* exact;          // [B][6] cell order: bearing, r, g, b, ux, uy
+  const unsigned short* order;  // [B] cell order -> scan order
+  const unsigned char* immutable;
+  const uint4* cand;            // [Lp][2]: reference (eb, r, g, b as float) | 8 x u16 blobs
+  const uint4* erec;            // [Lp]: 8 x u16 publish entries of those blobs (0xFFFF: nobody else lists the blob)
+  const unsigned* binfo;        // [B]: offs | n << 16
+  const unsigned* skip;         // != 0: this scan is not ours (a list overflowed, or the table does not fit)
+  unsigned char* pflag_out;     // [P] 1 = general route
+  unsigned* n_flagged;
+  int64_t P, p_begin;
+  int L, Lp, B;
+  int ecap;                     // entries of the publish table in LDS
+  int reset;
+  unsigned long long* gmax_key;
+  Noise<double> qt;
+};
+
+// dynamic LDS: exact records 48 B | publish table 8 ecap | binfo 4 B | order 2 B | any 2 x B (all padded to 16)
+__host__ __device__ inline size_t pub_fixed_lds_bytes(int B) {
+  const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
+  return Bp * 48 + Bp * 4 + Bp * 2 + 2 * Bp;
+}
+size_t step_pub_lds_bytes(int B, int ecap) { return pub_fixed_lds_bytes(B) + (size_t)ecap * 8; }
+int step_pub_entry_capacity(int B) {
+  const size_t fixed = pub_fixed_lds_bytes(B);
+  if (fixed + 64 * 8 > kMaxDynLds) return 0;
+  const size_t e = (kMaxDynLds - fixed) / 8;
+  return (int)(e > 65534 ? 65534 : e);
+}
+
+// ------------------------------------------------------------------ the publish table's layout, once per scan
+// One workgroup.  (a) every blob's inverse list sorted ascending (rank = landmark order: the tie rule of :377),
+// (b) exclusive scan of the list lengths of the blobs at least two landmarks list -> offs, (c) every landmark's
+// candidates get their entry index.  Control words: skip_pub (a list overflowed, or more entries than the LDS table
+// holds) and skip_cand (k_step_regs' candidate-list instance stands back when this route runs).
+struct CandEntriesArgs {
+  const uint4* cand;      // [Lp][2]
+  uint4* erec;            // [Lp]
+  unsigned* bcnt;         // [B]
+  uint4* brec;            // [B] 8 x u16, sorted in place
+  unsigned* binfo;        // [B]
+  const unsigned* over;   // candidate-list overflow
+  unsigned* skip_pub;
+  unsigned* skip_cand;
+  int L, Lp, B, ecap;
+};
+
+__global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
+  __shared__ unsigned s_part[1024];
+  __shared__ unsigned s_total;
+  const int tid = threadIdx.x;
+  const int chunk = (a.B + 1023) / 1024;
+  const int t0 = tid * chunk, t1 = min(a.B, t0 + chunk);
+  unsigned mine = 0;
+  for (int t = t0; t < t1; ++t) {
+    const unsigned n = min(a.bcnt[t], (unsigned)kCandSlots);
+    uint4 w = a.brec[t];
+    unsigned short v[8] = {(unsigned short)(w.x & 0xFFFFu), (unsigned short)(w.x >> 16), (unsigned short)(w.y & 0xFFFFu), (unsigned short)(w.y >> 16),
+                           (unsigned short)(w.z & 0xFFFFu), (unsigned short)(w.z >> 16), (unsigned short)(w.w & 0xFFFFu), (unsigned short)(w.w >> 16)};
+    // insertion sort of eight (empty = 0xFFFF sorts to the back)
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+#pragma unroll
+      for (int j = i; j > 0; --j)
+        if (v[j] < v[j - 1]) {
+          const unsigned short x = v[j];
+          v[j] = v[j - 1];
+          v[j - 1] = x;
+        }
+    w.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+    w.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+    w.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
+    w.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
+    a.brec[t] = w;
+    mine += n >= 2u ? n : 0u;
+  }
+  s_part[tid] = mine;
+  __syncthreads();
+  if (tid == 0) {  // sequential scan of 1024 partial sums: once per scan, a microsecond
+    unsigned run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const unsigned v = s_part[i];
+      s_part[i] = run;
+      run += v;
+    }
+    s_total = run;
+  }
+  __syncthreads();
+  {
+    unsigned run = s_part[tid];
+    for (int t = t0; t < t1; ++t) {
+      const unsigned n = min(a.bcnt[t], (unsigned)kCandSlots);
+      const unsigned c = n >= 2u ? n : 0u;
+      a.binfo[t] = (run & 0xFFFFu) | (n << 16);
+      run += c;
+    }
+  }
+  const bool fits = *a.over == 0u && s_total <= (unsigned)a.ecap && s_total < 0xFFFFu;
+  if (tid == 0) {
+    *a.skip_pub = fits ? 0u : 1u;
+    *a.skip_cand = (*a.over != 0u || fits) ? 1u : 0u;
+  }
+  __syncthreads();  // brec / binfo written above are read below by other threads of this (the only) workgroup
+  __threadfence_block();
+  for (int l = tid; l < a.Lp; l += 1024) {
+    const uint4 cw = a.cand[2 * (size_t)l + 1];
+    const unsigned cws[4] = {cw.x, cw.y, cw.z, cw.w};
+    unsigned short e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned t = (cws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+      unsigned ev = 0xFFFFu;
+      if (l < a.L && t != 0xFFFFu && fits) {
+        const unsigned bi = __hip_atomic_load(&a.binfo[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned n = bi >> 16;
+        if (n >= 2u) {
+          const uint4 bw = a.brec[t];
+          const unsigned bws[4] = {bw.x, bw.y, bw.z, bw.w};
+          unsigned rank = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rank += ((bws[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) < (unsigned)l ? 1u : 0u;
+          ev = (bi & 0xFFFFu) + rank;
+        }
+      }
+      e[k] = (unsigned short)ev;
+    }
+    a.erec[l] = make_uint4((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
+                           (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16));
+  }
+}
+
+void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
+                         uint4* brec_dev, unsigned* binfo_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
+                         unsigned* skip_cand_dev, int ecap) {
+  CandEntriesArgs a;
+  a.cand = cand_dev;
+  a.erec = erec_dev;
+  a.bcnt = bcnt_dev;
+  a.brec = brec_dev;
+  a.binfo = binfo_dev;
+  a.over = over_dev;
+  a.skip_pub = skip_pub_dev;
+  a.skip_cand = skip_cand_dev;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.ecap = ecap;
+  hipLaunchKernelGGL(k_cand_entries, dim3(1), dim3(1024), 0, s, a);
+}
+
+// ------------------------------------------------------------------ per-landmark pieces of k_step_pub
+// What a lane keeps about one landmark's (<= 4) gate-passing blobs between the phases.
+struct PubSlots {
+  unsigned tw0, tw1;  // the blobs (cell order), 16 bits each, filled from the front; 0xFFFF: none
+  unsigned ew0, ew1;  // their publish entries; 0xFFFF: no other landmark lists the blob
+  unsigned st;        // 4 bits per slot: 1 probability > 0, 2 fragile (subnormal probability / evaluated at the edge), 4 take
+};
+__device__ __forceinline__ unsigned pub_half(unsigned w0, unsigned w1, int s) { return ((s < 2 ? w0 : w1) >> (16 * (s & 1))) & 0xFFFFu; }
+
+__device__ __forceinline__ double pub_inf() { return __longlong_as_double(0x7FF0000000000000ll); }
+
+// Gates of one landmark (prkt_core_v2.py:433, :441) against its candidate list: as regs_gates_cand, the records read
+// from the LDS copy of the scan; candidates that fail are published as "not a contender" on the spot.
+__device__ __forceinline__ void pub_gates(PubSlots& q, double& pse_out, const uint4 ref, const uint4 cw, const uint4 ew,
+                                          const double* ex, double* pub, int* flag, double mx, double my, double mr, double mg,
+                                          double mb, double sx, double sy, double sh) {
+  const double pse = atan2(my - sy, mx - sx);
+  pse_out = pse;
+  const double eb = pse - sh;  // :408
+  // (written so that a NaN anywhere breaks the margin)
+  const double deb = eb - (double)__uint_as_float(ref.x);  // 2 pi off: the other side of a branch cut, listed too (k_candidates)
+  const bool inside = (fabs(deb) <= kCandBearing || fabs(deb - Consts<double>::two_pi) <= kCandBearing ||
+                       fabs(deb + Consts<double>::two_pi) <= kCandBearing) &&
+                      fabs(mr - (double)__uint_as_float(ref.y)) <= kCandColour &&
+                      fabs(mg - (double)__uint_as_float(ref.z)) <= kCandColour && fabs(mb - (double)__uint_as_float(ref.w)) <= kCandColour;
+  int npass = 0;
+  unsigned tw0 = 0xFFFFFFFFu, tw1 = 0xFFFFFFFFu, ew0 = 0xFFFFFFFFu, ew1 = 0xFFFFFFFFu;
+  auto test = [&](unsigned t, unsigned e, const double2& z01, const double2& z23) {
+    if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
+      if (npass == 0) {
+        tw0 = (tw0 & 0xFFFF0000u) | t;
+        ew0 = (ew0 & 0xFFFF0000u) | e;
+      }
+      if (npass == 1) {
+        tw0 = (tw0 & 0x0000FFFFu) | (t << 16);
+        ew0 = (ew0 & 0x0000FFFFu) | (e << 16);
+      }
+      if (npass == 2) {
+        tw1 = (tw1 & 0xFFFF0000u) | t;
+        ew1 = (ew1 & 0xFFFF0000u) | e;
+      }
+      if (npass == 3) {
+        tw1 = (tw1 & 0x0000FFFFu) | (t << 16);
+        ew1 = (ew1 & 0x0000FFFFu) | (e << 16);
+      }
+      ++npass;
+    } else if (e != 0xFFFFu) {
+      pub[e] = pub_inf();
+    }
+  };
+  unsigned c0 = cw.x, c1 = cw.y, c2 = cw.z, c3 = cw.w;  // the list is filled from the front
+  unsigned e0 = ew.x, e1 = ew.y, e2 = ew.z, e3 = ew.w;
+#pragma unroll 1
+  for (int k = 0; k < kCandSlots; k += 2) {
+    const unsigned ta = c0 & 0xFFFFu, tb = c0 >> 16;
+    if (ta == 0xFFFFu) break;
+    const unsigned ea = e0 & 0xFFFFu, eb2 = e0 >> 16;
+    c0 = c1;
+    c1 = c2;
+    c2 = c3;
+    c3 = 0xFFFFFFFFu;
+    e0 = e1;
+    e1 = e2;
+    e2 = e3;
+    e3 = 0xFFFFFFFFu;
+    const double* ra = ex + 6 * ta;
+    const double* rb = ex + 6 * (tb == 0xFFFFu ? ta : tb);
+    const double2 a01 = *reinterpret_cast<const double2*>(ra);
+    const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
+    const double2 b01 = *reinterpret_cast<const double2*>(rb);
+    const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
+    test(ta, ea, a01, a23);
+    if (tb != 0xFFFFu) test(tb, eb2, b01, b23);
+  }
+  if (!inside || npass > kPubSlots) *flag = 1;
+  q.tw0 = tw0;
+  q.tw1 = tw1;
+  q.ew0 = ew0;
+  q.ew1 = ew1;
+  q.st = 0u;
+}
+
+// Verdicts of one landmark on its gate-passing blobs: published for the blobs other landmarks list too, any[t] = 1 where
+// the probability is > 0 (the blob will be matched by somebody: no 0.1 factor, :94-95).
+__device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm, double pse, const double* ex, double* pub,
+                                         unsigned char* any, int* flag, double sx, double sy) {
+  if ((q.tw0 & 0xFFFFu) == 0xFFFFu) return;
+  const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+  double det3;
+  const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+  const bool sane = det2 > 1e-60 && det2 < 1e60 && det3 > 1e-60 && det3 < 1e60;  // NaN: false
+  bool weird = !sane;
+  const double r2 = 1.0 / det2, r3 = 1.0 / det3;
+  // log det = (e + log2 m) ln 2 with m in [0.5, 1): bounded above by e ln 2, below by (e - 1) ln 2 -- all the underflow
+  // tests need of the two logs; the key itself takes ONE log, of the product
+  int e2i, e3i;
+  (void)frexp(det2, &e2i);
+  (void)frexp(det3, &e3i);
+  constexpr double ln2 = 0.69314718055994530942;
+  const double a2base = 2.0 * Consts<double>::log_two_pi + (double)e2i * ln2;  // >= 2 log 2pi + log det2
+  const double a3base = 3.0 * Consts<double>::log_two_pi + (double)e3i * ln2;
+  const double kbase = 5.0 * Consts<double>::log_two_pi + log_few_ulp(det2 * det3);
+  unsigned st = 0u;
+#pragma unroll 1
+  for (int s = 0; s < kPubSlots; ++s) {
+    const unsigned t = pub_half(q.tw0, q.tw1, s);
+    if (t == 0xFFFFu) break;
+    const unsigned e = pub_half(q.ew0, q.ew1, s);
+    const double* rec = ex + 6 * t;
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+    // prob_position_match :457-494, prob_color_match :524-544
+    const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
+    double nx, ny;
+    closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+    const double ex_ = nx - lm.mx, ey = ny - lm.my;
+    const double num2 = lm.pyy * ex_ * ex_ - 2.0 * lm.pxy * ex_ * ey + lm.pxx * ey * ey;  // maha2 = num2 / det2
+    const double num3 = sym3_quad(adj3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);     // maha3 = num3 / det3
+    const double maha2 = num2 * r2, maha3 = num3 * r3;
+    const double key = kbase + (maha2 + maha3);
+    const double a2hi = a2base + maha2, a3hi = a3base + maha3;
+    // pr = fl(fl(bp cp) / 250000), bp = 500 exp(-a2 / 2), cp = 500 exp(-a3 / 2): bp = 0 from a2 > 1490.27 on, the
+    // quotient rounds to 0 from a2 + a3 > 1488.88 on.  Outside the margins below the answer is certain; inside
+    // (a strip 1.5-3.4 wide) the probability is evaluated as the reference does
+    const bool nonneg = num2 >= 0.0 && num3 >= 0.0;  // indefinite covariances, NaN: false
+    weird |= angle_ok && !nonneg;
+    const bool sure_pos = angle_ok && nonneg && key < 1488.0 && a2hi < 1489.0 && a3hi < 1489.0;
+    const bool sure_zero = !angle_ok || key > 1489.5 || a2hi - ln2 > 1491.0 || a3hi - ln2 > 1491.0;
+    bool positive = sure_pos;
+    bool fragile = key > 1400.0 || a2hi > 1400.0 || a3hi > 1400.0;
+    if (!sure_pos && !sure_zero) {
+      double d2 = det2, d3 = det3;
+      asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
+      positive = pr_from_parts(d2, d3, num2, num3) > 0.0;
+      fragile = true;
+    }
+    if (e != 0xFFFFu) pub[e] = positive ? key : pub_inf();
+    if (positive) any[t] = 1;
+    st |= ((positive ? 1u : 0u) | (fragile ? 2u : 0u)) << (4 * s);
+  }
+  if (weird) *flag = 1;
+  q.st = st;
+}
+
+// The rivals' verdicts on the blobs this landmark passes with probability > 0: it takes a blob iff no rival has a
+// smaller key, nor an equal key with a lower landmark index (:377).
+__device__ __forceinline__ void pub_settle(PubSlots& q, const double* pub, const unsigned* binfo, int* flag) {
+  if ((q.st & 0x1111u) == 0u) return;
+  unsigned st = q.st;
+  bool doubt = false;
+#pragma unroll 1
+  for (int s = 0; s < kPubSlots; ++s) {
+    const unsigned t = pub_half(q.tw0, q.tw1, s);
+    if (t == 0xFFFFu) break;
+    const unsigned mine_st = (st >> (4 * s)) & 0xFu;
+    if (!(mine_st & 1u)) continue;
+    const unsigned e = pub_half(q.ew0, q.ew1, s);
+    bool take = true;
+    if (e != 0xFFFFu) {
+      const double mine = pub[e];
+      const unsigned bi = binfo[t];
+      const unsigned offs = bi & 0xFFFFu, n = bi >> 16, rank = e - offs;
+      bool rival = false;
+      for (unsigned r = 0; r < n; ++r) {
+        if (r == rank) continue;
+        const double v = pub[offs + r];
+        if (v < mine || (v == mine && r < rank)) take = false;
+        doubt |= fabs(v - mine) < 1e-7 && v != mine;  // too close to call on keys: the general kernels compare probabilities
+        rival |= v < pub_inf();
+      }
+      // a winner whose probability is subnormal (or was evaluated at the underflow edge) next to another contender: keys
+      // order such probabilities only roughly (a fragile LOSER is harmless: the winner's key is smaller by far)
+      doubt |= take && rival && (mine_st & 2u);
+    }
+    if (take) st |= 4u << (4 * s);
+  }
+  if (doubt) *flag = 1;
+  q.st = st;
+}
+
+// The blobs taken, applied in scan order (:88): regs_apply with the take bits.
+__device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
+                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
+  double acc = 0.0;
+  if ((q.st & 0x4444u) == 0u) return acc;
+  unsigned key[kPubSlots];
+#pragma unroll
+  for (int s = 0; s < kPubSlots; ++s) {
+    key[s] = 0xFFFFFFFFu;
+    if ((q.st >> (4 * s)) & 4u) {
+      const unsigned t = pub_half(q.tw0, q.tw1, s);
+      key[s] = ((unsigned)order[t] << 16) | t;
+    }
+  }
+  auto cswap = [&](unsigned& u, unsigned& v) {
+    const unsigned lo = min(u, v), hi = max(u, v);
+    u = lo;
+    v = hi;
+  };
+  cswap(key[0], key[1]);
+  cswap(key[2], key[3]);
+  cswap(key[0], key[2]);
+  cswap(key[1], key[3]);
+  cswap(key[1], key[2]);
+  bool fresh = true;
+#pragma unroll 1
+  for (int it = 0; it < kPubSlots; ++it) {
+    const unsigned kk = key[0];
+    if (kk == 0xFFFFFFFFu) break;
+    key[0] = key[1];
+    key[1] = key[2];
+    key[2] = key[3];
+    key[3] = 0xFFFFFFFFu;
+    const double* rec = ex + 6 * (kk & 0xFFFFu);
+    const double2 z01 = *reinterpret_cast<const double2*>(rec);
+    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+    acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+    fresh = imm;
+  }
+  return acc;
+}
+
+// Diagnostic build only (-DPK_STAMPS): per-phase cycle sums of k_step_pub (slots 48.. of pk_debug_stamps).
+#ifdef PK_STAMPS
+__device__ unsigned long long pk_pstamp_acc[16];
+#define PK_PSTAMP(slot, a, b) \
+  if ((threadIdx.x & 63) == 0) atomicAdd(&pk_pstamp_acc[slot], (b) - (a));
+void debug_read_pub_stamps(unsigned long long* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_pstamp_acc), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pk_pstamp_acc), z, sizeof(z));
+  }
+}
+#else
+#define PK_PSTAMP(slot, a, b)
+#endif
+
+// ------------------------------------------------------------------ the kernel
+// NP: adjacent landmark pairs per lane (2: maps up to 2048 landmarks; 1: up to 1024)
+template <int NP>
+__global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[2][kPubWaves];
+  __shared__ int wg_flag[2];
+  if (*a.skip != 0u) return;  // workgroup-uniform: another route takes this scan
+  const int tid = threadIdx.x;
+  const int B = a.B, Lp = a.Lp, L = a.L;
+  const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
+  double* ex = reinterpret_cast<double*>(smem);
+  double* pub = ex + 6 * Bp;
+  unsigned* binfo = reinterpret_cast<unsigned*>(pub + a.ecap);
+  unsigned short* order = reinterpret_cast<unsigned short*>(binfo + Bp);
+  unsigned char* any = reinterpret_cast<unsigned char*>(order + Bp);  // [2][Bp]
+  // ---- the scan's tables: once per workgroup
+  for (int i = tid; i < 6 * B; i += kPubThreads) ex[i] = a.exact[i];
+  for (int i = tid; i < B; i += kPubThreads) {
+    binfo[i] = a.binfo[i];
+    order[i] = a.order[i];
+  }
+  for (unsigned i = (unsigned)tid; i < 2 * Bp / 4; i += kPubThreads) reinterpret_cast<unsigned*>(any)[i] = 0u;
+  if (tid == 0) {
+    wg_flag[0] = 0;
+    wg_flag[1] = 0;
+  }
+  // the lane's landmarks: pair q = landmarks 1024 q + 2 tid, + 1 (lanes beyond the map re-read its last pair and never
+  // use or store it)
+  int lbase[NP];
+  bool imm[2 * NP], has[2 * NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const int l0 = 2 * kPubThreads * q + 2 * tid;
+    lbase[q] = min(l0, Lp - 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      has[2 * q + j] = l0 + j < L;
+      imm[2 * q + j] = a.immutable[min(l0 + j, L - 1)] != 0;
+    }
+  }
+  __syncthreads();
+
+  int64_t prev = -1;  // the particle whose partial sums wait in red[] (-1: none, or it went to the general kernels)
+  int cur = 0;        // parity of the particle: which any[] / flag / red[] it uses
+  for (int64_t p = a.p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
+    const bool done = p >= a.P;
+    Landmark<double> S[2 * NP];
+    PubSlots Q[2 * NP];
+    double pse[2 * NP];
+    double sx = 0.0, sy = 0.0, sh = 0.0;
+    unsigned char* anyc = any + (size_t)cur * Bp;
+    PK_STAMP(s0)
+#ifdef PK_STAMPS
+    unsigned long long s3 = s0;
+#endif
+    if (!done) {
+      const unsigned char* sslot = a.ss.at(regs_source_pub(a.src, p));
+      const double* sf = reinterpret_cast<const double*>(sslot);
+      const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
+      sx = pose_scalar(a.x, p);
+      sy = pose_scalar(a.y, p);
+      sh = pose_scalar(a.h, p);
+      // ---- 1. requests: candidate records (L2), the means of all four landmarks, then the covariance rows
+      uint4 cref[2 * NP], ccw[2 * NP], cew[2 * NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const uint4* cr = a.cand + 2 * (size_t)lbase[q];
+        const uint4* er = a.erec + lbase[q];
+        cref[2 * q] = cr[0];
+        ccw[2 * q] = cr[1];
+        cref[2 * q + 1] = cr[2];
+        ccw[2 * q + 1] = cr[3];
+        cew[2 * q] = er[0];
+        cew[2 * q + 1] = er[1];
+      }
+      asm volatile("" ::: "memory");
+      auto row2 = [&](int f, int lb) { return *reinterpret_cast<const Double2*>(sf + (size_t)f * Lp + lb); };
+#define PK_PUB_LOAD(field, F)                   \
+  {                                             \
+    const Double2 v = row2(F, lbase[q]);        \
+    S[2 * q].field = v.x;                       \
+    S[2 * q + 1].field = v.y;                   \
+  }
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        PK_PUB_LOAD(mx, F_MX)
+        PK_PUB_LOAD(my, F_MY)
+        PK_PUB_LOAD(mr, F_MR)
+        PK_PUB_LOAD(mg, F_MG)
+        PK_PUB_LOAD(mb, F_MB)
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        PK_PUB_LOAD(pxx, F_PXX)
+        PK_PUB_LOAD(pxy, F_PXY)
+        PK_PUB_LOAD(pyy, F_PYY)
+        PK_PUB_LOAD(crr, F_CRR)
+        PK_PUB_LOAD(crg, F_CRG)
+        PK_PUB_LOAD(crb, F_CRB)
+        PK_PUB_LOAD(cgg, F_CGG)
+        PK_PUB_LOAD(cgb, F_CGB)
+        PK_PUB_LOAD(cbb, F_CBB)
+        const Int2 c = *reinterpret_cast<const Int2*>(sc + lbase[q]);
+        S[2 * q].count = c.x;
+        S[2 * q + 1].count = c.y;
+      }
+#undef PK_PUB_LOAD
+      asm volatile("" ::: "memory");
+      PK_STAMP(s1)
+      PK_PSTAMP(0, s0, s1)  // scalars, requests
+      // ---- 2. gates of the four landmarks (means only), failing candidates published at once
+#pragma unroll
+      for (int i = 0; i < 2 * NP; ++i) {
+        Q[i] = PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+        pse[i] = 0.0;
+        if (has[i])
+          pub_gates(Q[i], pse[i], cref[i], ccw[i], cew[i], ex, pub, &wg_flag[cur], S[i].mx, S[i].my, S[i].mr, S[i].mg, S[i].mb, sx, sy, sh);
+      }
+      PK_STAMP(s2)
+      PK_PSTAMP(1, s1, s2)  // gates (waits for the candidate records and the means)
+      // ---- 3. verdicts on the gate-passing blobs (first use of the covariance rows)
+#pragma unroll
+      for (int i = 0; i < 2 * NP; ++i) pub_keys(Q[i], S[i], pse[i], ex, pub, anyc, &wg_flag[cur], sx, sy);
+#ifdef PK_STAMPS
+      PK_STAMP(s3b)
+      s3 = s3b;
+      PK_PSTAMP(2, s2, s3)  // verdicts (waits for the covariance rows)
+#endif
+    }
+    lds_barrier();  // A: every verdict of this particle is in the table
+    PK_STAMP(s4)
+    PK_PSTAMP(3, s3, s4)  // barrier A
+    if (prev >= 0 && tid == 0) {  // the previous particle's log-weight (its partial sums were written before A)
+      double tot = red[cur ^ 1][0];
+#pragma unroll
+      for (int i = 1; i < kPubWaves; ++i) tot += red[cur ^ 1][i];
+      const double w = (a.reset ? 0.0 : a.logw[prev]) + tot;
+      a.logw[prev] = w;
+      if (a.gmax_key) atomicMax(a.gmax_key + (prev & (kGmaxKeys - 1)), double_to_key(w));
+      a.src[prev] = (int32_t)prev;
+    }
+    if (done) break;
+    prev = -1;
+    // ---- 4. subscribe: the rivals' verdicts; blobs nobody matches; the next particle's any[] / flag cleared
+    double acc;
+    {
+      int nun = 0;
+      for (unsigned w = (unsigned)tid; w < Bp / 4; w += kPubThreads) {
+        const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
+      }
+      acc = (double)nun * Consts<double>::log_no_match;  // unseen features: weight *= 0.1 each (:94-95)
+      unsigned* anyn = reinterpret_cast<unsigned*>(any + (size_t)(cur ^ 1) * Bp);
+      for (unsigned w = (unsigned)tid; w < Bp / 4; w += kPubThreads) anyn[w] = 0u;
+      if (tid == 0) wg_flag[cur ^ 1] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NP; ++i) pub_settle(Q[i], pub, binfo, &wg_flag[cur]);
+    PK_STAMP(s5)
+    PK_PSTAMP(4, s4, s5)  // unseen blobs, subscribe
+    lds_barrier();  // B: every verdict has been read (the table is the next particle's), every flag is set
+    PK_STAMP(s6)
+    PK_PSTAMP(5, s5, s6)  // barrier B
+    if (wg_flag[cur]) {  // workgroup-uniform: nothing has been written; the general kernels take the particle
+      if (tid == 0) {
+        a.pflag_out[p] = 1;
+        atomicAdd(a.n_flagged, 1u);
+      }
+      continue;
+    }
+    if (tid == 0) a.pflag_out[p] = 0;
+    // ---- 5. updates in scan order, stores
+    {
+      unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+      double* df = reinterpret_cast<double*>(dslot);
+      int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int i = 2 * q + j;
+          acc += pub_apply(Q[i], ex, order, a.qt, S[i], imm[i], sx, sy, pse[i]);
+        }
+        const int l0 = 2 * kPubThreads * q + 2 * tid;
+        if (l0 < Lp) {
+#define PK_PUB_STORE(field, F)                                                                     \
+  {                                                                                                \
+    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                        \
+    __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0));         \
+  }
+          PK_PUB_STORE(mx, F_MX)
+          PK_PUB_STORE(my, F_MY)
+          PK_PUB_STORE(mr, F_MR)
+          PK_PUB_STORE(mg, F_MG)
+          PK_PUB_STORE(mb, F_MB)
+          PK_PUB_STORE(pxx, F_PXX)
+          PK_PUB_STORE(pxy, F_PXY)
+          PK_PUB_STORE(pyy, F_PYY)
+          PK_PUB_STORE(crr, F_CRR)
+          PK_PUB_STORE(crg, F_CRG)
+          PK_PUB_STORE(crb, F_CRB)
+          PK_PUB_STORE(cgg, F_CGG)
+          PK_PUB_STORE(cgb, F_CGB)
+          PK_PUB_STORE(cbb, F_CBB)
+#undef PK_PUB_STORE
+          const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
+          __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
+        }
+      }
+    }
+    PK_STAMP(s7)
+    PK_PSTAMP(6, s6, s7)  // updates, stores issued
+    {
+      const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier A
+      if ((tid & (kWave - 1)) == 0) red[cur][tid / kWave] = ws;
+      prev = p;
+    }
+    PK_STAMP(s8)
+    PK_PSTAMP(7, s7, s8)  // wave sum
+    PK_PSTAMP(8, s0, s8)  // particle
+#ifdef PK_STAMPS
+    if ((tid & 63) == 0) atomicAdd(&pk_pstamp_acc[9], 1ull);
+#endif
+  }
+}
+
+void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
+                     const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
+                     const unsigned* binfo_dev, const unsigned* skip_dev, int ecap, int64_t p0, int64_t p1, int reserve_cus) {
+  if (p1 < 0) p1 = d.P;
+  if (d.P == 0 || p1 <= p0) return;
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
+    for (const void* fn : {reinterpret_cast<const void*>(k_step_pub<1>), reinterpret_cast<const void*>(k_step_pub<2>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess) (void)hipGetLastError();
+  }
+  PubArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.h = d.h[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.immutable = d.immutable;
+  a.cand = cand.rec;
+  a.erec = erec_dev;
+  a.binfo = binfo_dev;
+  a.skip = skip_dev;
+  a.pflag_out = fh.pflag;
+  a.n_flagged = fh.n_flagged;
+  a.P = p1;
+  a.p_begin = p0;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.ecap = ecap;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    else
+      n_cu = 256;
+    (void)hipGetLastError();
+  }
+  // persistent grid: one workgroup per CU (512 lanes x 256 VGPRs); reserve_cus as in launch_step_regs
+  int64_t grid_n = n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0);
+  if (grid_n > p1 - p0) grid_n = p1 - p0;
+  const size_t lds = step_pub_lds_bytes(B, ecap);
+  if (d.lay.Lp <= 2 * kPubThreads)
+    hipLaunchKernelGGL(k_step_pub<1>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
+  else
+    hipLaunchKernelGGL(k_step_pub<2>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
+}
+
+}  // namespace pk

@@ -178,6 +178,7 @@ struct CandTable {
   const uint4* rec = nullptr;         // [Lp][2] landmark records
   const uint4* brec = nullptr;        // [B] blob records (k_step_owner), or NULL
   const unsigned* over = nullptr;     // != 0: some list has more entries than slots -> grid walk for this scan
+  const unsigned* skip_cand = nullptr; // k_step_regs' candidate-list instance stands back when != 0 (NULL: when *over != 0)
   const unsigned* n_stray = nullptr;  // blobs on no landmark's list
   int slots = kCandSlots;             // entries per list: kCandSlots ([Lp][2] records) or twice that ([Lp][3]; no inverse lists)
 };
@@ -204,6 +205,18 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
                       const ObserveExtras& ex, int warm, const CandTable& cand = CandTable(), int64_t p0 = 0, int64_t p1 = -1,
                       int reserve_cus = 0);
+// K2 + K3 in one pass with STATIC publish / subscribe settling (pk_k_step_pub.hip): 512 < L <= kRegsMaxL, candidate lists
+// both ways (cand.rec, and the inverse lists that launch_cand_entries turns into the publish table's layout: erec, binfo).
+// 512-lane persistent workgroups, four landmarks per lane, two barriers per particle.  Returns at once when *skip != 0.
+int step_pub_entry_capacity(int B);  // publish-table entries that fit LDS beside the scan's tables (0: the scan does not fit)
+size_t step_pub_lds_bytes(int B, int ecap);
+void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
+                         uint4* brec_dev, unsigned* binfo_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
+                         unsigned* skip_cand_dev, int ecap);
+void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
+                     const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
+                     const unsigned* binfo_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
+                     int reserve_cus = 0);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued

@@ -4,7 +4,16 @@ import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from parakeet_slam_amd import _lib
+from parakeet_slam_amd import _lib, build as _build
+# the stamps library is rebuilt whenever a source is newer than it (a stale one used to leave a traceback in profiles/)
+_so = os.path.join(ROOT, "parakeet_slam_amd", "libparakeet_slam_stamps.so")
+_srcs = [os.path.join(_build.CSRC, x) for x in os.listdir(_build.CSRC) if x.endswith((".hip", ".hpp", ".cpp"))] + [os.path.join(ROOT, "include", "parakeet_slam.h")]
+if not os.path.exists(_so) or any(os.path.getmtime(x) > os.path.getmtime(_so) for x in _srcs):
+    try:
+        _build.build_stamps(verbose=False)
+    except Exception as e:  # noqa: BLE001
+        print("gpu_stamps: cannot build the stamps library: %s" % e, file=sys.stderr)
+        sys.exit(2)
 _lib.LIB_PATH = os.path.join(ROOT, "parakeet_slam_amd", "libparakeet_slam_stamps.so")
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 import bench
@@ -12,12 +21,12 @@ P = int(os.environ.get("ST_P", 10000)); L = int(os.environ.get("ST_L", 500))
 means, covs, scans = bench.synthetic_inputs(L, 6)
 f = _lib.DeviceFilter(P, L)
 f.upload_map(means, covs.reshape(L, 25))
-for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM"):
+for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_PUB_STEP"):
     if os.environ.get(name):
         f.set_option(name[7:].lower(), int(os.environ[name]))
 so = _lib.load()
 so.pk_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-buf = (ctypes.c_ulonglong * 48)()
+buf = (ctypes.c_ulonglong * 64)()
 for s in range(3):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
@@ -25,6 +34,15 @@ for s in range(3, 6):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
+print("git", os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "(no git on this box)", "P", P, "L", L)
+if v[48 + 8] > 0:  # k_step_pub ran (512 < L <= 2048, publish table in LDS)
+    pn = ["scalars, requests", "gates (waits for candidate records, means)", "verdicts (waits for covariance rows)", "barrier A",
+          "unseen blobs, subscribe", "barrier B", "updates, stores issued", "wave sum", "particle (wave lifetime)"]
+    life = v[48 + 8]
+    for i, n in enumerate(pn):
+        print("pub %-44s %12.4g  %5.1f%%" % (n, v[48 + i], 100 * v[48 + i] / life))
+    print("pub cycles per particle and wave: %.0f" % (life / max(v[48 + 9], 1.0)))
+    sys.exit(0)
 if v[32 + 14] > 0:  # k_step_regs ran (512 < L <= 2048)
     rn = ["scalars, requests, zeroing", "barrier", "gate arguments (scalar loads)", "gates 1st landmark (waits for means)",
           "gates 2nd landmark", "barrier behind the gates", "warming, unseen blobs", "round 1: prepare (waits for cov rows)",
