@@ -67,6 +67,19 @@ def build_stamps(verbose=True):
     return out
 
 
+def build_variant(name, defines, verbose=True):
+    """Diagnostic A/B build: every source in one hipcc call with extra -D flags -> libpk_<name>.so (git-ignored, never loaded
+    by the package; bench.py takes it through PK_BENCH_LIB, scripts/gpu_ab_lib.sh)."""
+    hipcc = _hipcc()
+    out = os.path.join(HERE, "libpk_%s.so" % name)
+    srcs = [os.path.join(CSRC, x) for x in HIP_SOURCES + CXX_SOURCES]
+    cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS["pk_k_observe_ml.hip"] + list(defines) + ["-shared", "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=True):
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
@@ -96,6 +109,9 @@ def build(force=False, verbose=True):
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         print(build_stamps())
+    elif "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
     else:
         build(force="--force" in sys.argv)
         print(LIB)

@@ -25,7 +25,7 @@
 // particle for the general kernels (exact probabilities, as before) whenever keys of two contenders are closer than 1e-7
 // without being identical (identical landmarks give identical keys: a tie, :377), and wherever pr would be subnormal
 // (keys beyond 1400) with a second contender; whether pr is > 0 at all (:369, strict) is decided from the keys with
-// margins on both sides of the float64 underflow edge and evaluated exactly inside them.
+// margins on both sides of the float64 underflow edge (keys 1489 ... 1491.5) and evaluated exactly inside them.
 //
 // Shape: persistent 512-lane workgroups, one per CU, FOUR landmarks per lane (two adjacent pairs, 16-byte row accesses),
 // the particle's whole map in registers from its single coalesced load to its single coalesced store; 8 waves x 256
@@ -35,6 +35,12 @@
 
 namespace pk {
 
+// Diagnostic builds only (python -m parakeet_slam_amd.build --variant NAME -DPK_PUB_ABLATE=n, never shipped): phases left out
+// from the back -- 1 no EKF updates, 2 nor subscribe, 3 nor verdicts, 4 nor gates (rows in, barriers, rows out) -- to see
+// what each costs in place.  Results are wrong by construction.
+#ifndef PK_PUB_ABLATE
+#define PK_PUB_ABLATE 0
+#endif
 constexpr int kPubThreads = 512;
 constexpr int kPubWaves = kPubThreads / kWave;
 constexpr int kPubSlots = 4;  // gate-passing blobs a landmark keeps; more: the particle is flagged
@@ -76,12 +82,13 @@ struct PubArgs {
   Noise<double> qt;
 };
 
-// dynamic LDS: exact records 48 B | publish table 8 ecap | binfo 4 B | order 2 B | any 2 x B (all padded to 16)
+// dynamic LDS: exact records 48 B | publish table 8 (ecap + 2: a dump entry, padding) | binfo 4 B | order 2 B |
+// any 2 x (B + 16: a dump byte) (B padded to 16)
 __host__ __device__ inline size_t pub_fixed_lds_bytes(int B) {
   const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
-  return Bp * 48 + Bp * 4 + Bp * 2 + 2 * Bp;
+  return Bp * 48 + 16 + Bp * 4 + Bp * 2 + 2 * (Bp + 16);
 }
-size_t step_pub_lds_bytes(int B, int ecap) { return pub_fixed_lds_bytes(B) + (size_t)ecap * 8; }
+size_t step_pub_lds_bytes(int B, int ecap) { return pub_fixed_lds_bytes(B) + (size_t)ecap * 8; }  // (the 16 spare bytes: the dump entry)
 int step_pub_entry_capacity(int B) {
   const size_t fixed = pub_fixed_lds_bytes(B);
   if (fixed + 64 * 8 > kMaxDynLds) return 0;
@@ -210,21 +217,33 @@ void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4
 }
 
 // ------------------------------------------------------------------ per-landmark pieces of k_step_pub
-// What a lane keeps about one landmark's (<= 4) gate-passing blobs between the phases.
+// Control flow is kept WAVE-UNIFORM wherever it can be: loops end on a ballot, bodies are predicated, the entries a lane has
+// nothing to say about go to a dump entry of the table -- a divergent branch costs a handful of scalar instructions, and a
+// first version that branched per candidate and per slot issued as many scalar as vector instructions.
+//
+// What a lane keeps about one landmark's (<= 4) gate-passing blobs between the phases: per slot blob | entry << 16
+// (0xFFFF: none / no other landmark lists the blob), most recent first, empty slots at the back.
 struct PubSlots {
-  unsigned tw0, tw1;  // the blobs (cell order), 16 bits each, filled from the front; 0xFFFF: none
-  unsigned ew0, ew1;  // their publish entries; 0xFFFF: no other landmark lists the blob
-  unsigned st;        // 4 bits per slot: 1 probability > 0, 2 fragile (subnormal probability / evaluated at the edge), 4 take
+  unsigned s0, s1, s2, s3;
+  unsigned st;  // 4 bits per slot: 1 probability > 0, 2 fragile (subnormal probability / evaluated at the edge), 4 take
 };
-__device__ __forceinline__ unsigned pub_half(unsigned w0, unsigned w1, int s) { return ((s < 2 ? w0 : w1) >> (16 * (s & 1))) & 0xFFFFu; }
+__device__ __forceinline__ void pub_rotate(PubSlots& q) {  // slot 0 goes to the back, its state bits with it
+  const unsigned w = q.s0;
+  q.s0 = q.s1;
+  q.s1 = q.s2;
+  q.s2 = q.s3;
+  q.s3 = w;
+  q.st = ((q.st >> 4) | (q.st << 12)) & 0xFFFFu;
+}
 
 __device__ __forceinline__ double pub_inf() { return __longlong_as_double(0x7FF0000000000000ll); }
 
 // Gates of one landmark (prkt_core_v2.py:433, :441) against its candidate list: as regs_gates_cand, the records read
-// from the LDS copy of the scan; candidates that fail are published as "not a contender" on the spot.
+// from the LDS copy of the scan; candidates that fail are published as "not a contender" on the spot (a passing one's entry
+// is overwritten by pub_keys).  dump: the table's spare entry.
 __device__ __forceinline__ void pub_gates(PubSlots& q, double& pse_out, const uint4 ref, const uint4 cw, const uint4 ew,
-                                          const double* ex, double* pub, int* flag, double mx, double my, double mr, double mg,
-                                          double mb, double sx, double sy, double sh) {
+                                          const double* ex, double* pub, unsigned dump, int* flag, double mx, double my, double mr,
+                                          double mg, double mb, double sx, double sy, double sh) {
   const double pse = atan2(my - sy, mx - sx);
   pse_out = pse;
   const double eb = pse - sh;  // :408
@@ -235,37 +254,14 @@ __device__ __forceinline__ void pub_gates(PubSlots& q, double& pse_out, const ui
                       fabs(mr - (double)__uint_as_float(ref.y)) <= kCandColour &&
                       fabs(mg - (double)__uint_as_float(ref.z)) <= kCandColour && fabs(mb - (double)__uint_as_float(ref.w)) <= kCandColour;
   int npass = 0;
-  unsigned tw0 = 0xFFFFFFFFu, tw1 = 0xFFFFFFFFu, ew0 = 0xFFFFFFFFu, ew1 = 0xFFFFFFFFu;
-  auto test = [&](unsigned t, unsigned e, const double2& z01, const double2& z23) {
-    if (!(fabs(z01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, z01.y, z23.x, z23.y)) > 300.0)) {
-      if (npass == 0) {
-        tw0 = (tw0 & 0xFFFF0000u) | t;
-        ew0 = (ew0 & 0xFFFF0000u) | e;
-      }
-      if (npass == 1) {
-        tw0 = (tw0 & 0x0000FFFFu) | (t << 16);
-        ew0 = (ew0 & 0x0000FFFFu) | (e << 16);
-      }
-      if (npass == 2) {
-        tw1 = (tw1 & 0xFFFF0000u) | t;
-        ew1 = (ew1 & 0xFFFF0000u) | e;
-      }
-      if (npass == 3) {
-        tw1 = (tw1 & 0x0000FFFFu) | (t << 16);
-        ew1 = (ew1 & 0x0000FFFFu) | (e << 16);
-      }
-      ++npass;
-    } else if (e != 0xFFFFu) {
-      pub[e] = pub_inf();
-    }
-  };
+  unsigned s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
   unsigned c0 = cw.x, c1 = cw.y, c2 = cw.z, c3 = cw.w;  // the list is filled from the front
   unsigned e0 = ew.x, e1 = ew.y, e2 = ew.z, e3 = ew.w;
 #pragma unroll 1
   for (int k = 0; k < kCandSlots; k += 2) {
     const unsigned ta = c0 & 0xFFFFu, tb = c0 >> 16;
-    if (ta == 0xFFFFu) break;
-    const unsigned ea = e0 & 0xFFFFu, eb2 = e0 >> 16;
+    if (__ballot(ta != 0xFFFFu) == 0ull) break;  // wave-uniform
+    const unsigned ea = e0 & 0xFFFFu, eb2 = e0 >> 16;  // (0xFFFF where the blob is: k_cand_entries)
     c0 = c1;
     c1 = c2;
     c2 = c3;
@@ -274,33 +270,46 @@ __device__ __forceinline__ void pub_gates(PubSlots& q, double& pse_out, const ui
     e1 = e2;
     e2 = e3;
     e3 = 0xFFFFFFFFu;
-    const double* ra = ex + 6 * ta;
-    const double* rb = ex + 6 * (tb == 0xFFFFu ? ta : tb);
+    const bool va = ta != 0xFFFFu, vb = tb != 0xFFFFu;
+    const double* ra = ex + 6 * (va ? ta : 0u);
+    const double* rb = ex + 6 * (vb ? tb : 0u);
     const double2 a01 = *reinterpret_cast<const double2*>(ra);
     const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
     const double2 b01 = *reinterpret_cast<const double2*>(rb);
     const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
-    test(ta, ea, a01, a23);
-    if (tb != 0xFFFFu) test(tb, eb2, b01, b23);
+    const bool pa = va && !(fabs(a01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, a01.y, a23.x, a23.y)) > 300.0);
+    const bool pb = vb && !(fabs(b01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, b01.y, b23.x, b23.y)) > 300.0);
+    pub[(pa || ea == 0xFFFFu) ? dump : ea] = pub_inf();
+    pub[(pb || eb2 == 0xFFFFu) ? dump : eb2] = pub_inf();
+    const unsigned wa = ta | (ea << 16), wb = tb | (eb2 << 16);
+    s3 = pa ? s2 : s3;
+    s2 = pa ? s1 : s2;
+    s1 = pa ? s0 : s1;
+    s0 = pa ? wa : s0;
+    s3 = pb ? s2 : s3;
+    s2 = pb ? s1 : s2;
+    s1 = pb ? s0 : s1;
+    s0 = pb ? wb : s0;
+    npass += (pa ? 1 : 0) + (pb ? 1 : 0);
   }
   if (!inside || npass > kPubSlots) *flag = 1;
-  q.tw0 = tw0;
-  q.tw1 = tw1;
-  q.ew0 = ew0;
-  q.ew1 = ew1;
+  q.s0 = s0;
+  q.s1 = s1;
+  q.s2 = s2;
+  q.s3 = s3;
   q.st = 0u;
 }
 
 // Verdicts of one landmark on its gate-passing blobs: published for the blobs other landmarks list too, any[t] = 1 where
-// the probability is > 0 (the blob will be matched by somebody: no 0.1 factor, :94-95).
+// the probability is > 0 (the blob will be matched by somebody: no 0.1 factor, :94-95).  any[anydump]: a byte nobody reads.
 __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm, double pse, const double* ex, double* pub,
-                                         unsigned char* any, int* flag, double sx, double sy) {
-  if ((q.tw0 & 0xFFFFu) == 0xFFFFu) return;
+                                         unsigned dump, unsigned char* any, unsigned anydump, int* flag, double sx, double sy) {
+  if (__ballot((q.s0 & 0xFFFFu) != 0xFFFFu) == 0ull) return;  // wave-uniform: nobody's landmark passes a blob
   const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
   double det3;
   const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
   const bool sane = det2 > 1e-60 && det2 < 1e60 && det3 > 1e-60 && det3 < 1e60;  // NaN: false
-  bool weird = !sane;
+  bool weird = false;
   const double r2 = 1.0 / det2, r3 = 1.0 / det3;
   // log det = (e + log2 m) ln 2 with m in [0.5, 1): bounded above by e ln 2, below by (e - 1) ln 2 -- all the underflow
   // tests need of the two logs; the key itself takes ONE log, of the product
@@ -311,13 +320,13 @@ __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm
   const double a2base = 2.0 * Consts<double>::log_two_pi + (double)e2i * ln2;  // >= 2 log 2pi + log det2
   const double a3base = 3.0 * Consts<double>::log_two_pi + (double)e3i * ln2;
   const double kbase = 5.0 * Consts<double>::log_two_pi + log_few_ulp(det2 * det3);
-  unsigned st = 0u;
+  int done = 0;
 #pragma unroll 1
-  for (int s = 0; s < kPubSlots; ++s) {
-    const unsigned t = pub_half(q.tw0, q.tw1, s);
-    if (t == 0xFFFFu) break;
-    const unsigned e = pub_half(q.ew0, q.ew1, s);
-    const double* rec = ex + 6 * t;
+  for (; done < kPubSlots; ++done) {
+    const unsigned t = q.s0 & 0xFFFFu, e = q.s0 >> 16;
+    const bool valid = t != 0xFFFFu;
+    if (__ballot(valid) == 0ull) break;  // wave-uniform
+    const double* rec = ex + 6 * (valid ? t : 0u);
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
     const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
@@ -331,78 +340,84 @@ __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm
     const double maha2 = num2 * r2, maha3 = num3 * r3;
     const double key = kbase + (maha2 + maha3);
     const double a2hi = a2base + maha2, a3hi = a3base + maha3;
-    // pr = fl(fl(bp cp) / 250000), bp = 500 exp(-a2 / 2), cp = 500 exp(-a3 / 2): bp = 0 from a2 > 1490.27 on, the
-    // quotient rounds to 0 from a2 + a3 > 1488.88 on.  Outside the margins below the answer is certain; inside
-    // (a strip 1.5-3.4 wide) the probability is evaluated as the reference does
+    // pr = fl(fl(bp cp) / 250000), bp = 500 exp(-a2 / 2), cp = 500 exp(-a3 / 2): bp rounds to 0 from a2 > 1490.27 on
+    // (exp(-745.13) = 2^-1075, half the smallest subnormal), the quotient from a2 + a3 > 1490.27 on.  Outside the margins
+    // below the answer is certain; inside (a strip 2.5-3.2 wide) the probability is evaluated as the reference does
     const bool nonneg = num2 >= 0.0 && num3 >= 0.0;  // indefinite covariances, NaN: false
-    weird |= angle_ok && !nonneg;
-    const bool sure_pos = angle_ok && nonneg && key < 1488.0 && a2hi < 1489.0 && a3hi < 1489.0;
-    const bool sure_zero = !angle_ok || key > 1489.5 || a2hi - ln2 > 1491.0 || a3hi - ln2 > 1491.0;
-    bool positive = sure_pos;
+    weird |= valid && (!sane || (angle_ok && !nonneg));
+    const bool sure_pos = angle_ok && nonneg && key < 1489.0 && a2hi < 1489.0 && a3hi < 1489.0;
+    const bool sure_zero = !angle_ok || key > 1491.5 || a2hi - ln2 > 1491.5 || a3hi - ln2 > 1491.5;
+    bool positive = valid && sure_pos;
     bool fragile = key > 1400.0 || a2hi > 1400.0 || a3hi > 1400.0;
-    if (!sure_pos && !sure_zero) {
-      double d2 = det2, d3 = det3;
-      asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
-      positive = pr_from_parts(d2, d3, num2, num3) > 0.0;
-      fragile = true;
+    const bool edge = valid && !sure_pos && !sure_zero;
+    if (__ballot(edge) != 0ull) {  // wave-uniform, rare
+      if (edge) {
+        double d2 = det2, d3 = det3;
+        asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
+        positive = pr_from_parts(d2, d3, num2, num3) > 0.0;
+        fragile = true;
+      }
     }
-    if (e != 0xFFFFu) pub[e] = positive ? key : pub_inf();
-    if (positive) any[t] = 1;
-    st |= ((positive ? 1u : 0u) | (fragile ? 2u : 0u)) << (4 * s);
+    pub[e == 0xFFFFu ? dump : e] = positive ? key : pub_inf();  // (an empty slot's entry field is 0xFFFF)
+    any[positive ? t : anydump] = 1;
+    q.st |= (positive ? 1u : 0u) | (fragile ? 2u : 0u);
+    pub_rotate(q);
   }
+  for (; done < kPubSlots; ++done) pub_rotate(q);  // wave-uniform trip count: back to the original order
   if (weird) *flag = 1;
-  q.st = st;
 }
 
 // The rivals' verdicts on the blobs this landmark passes with probability > 0: it takes a blob iff no rival has a
 // smaller key, nor an equal key with a lower landmark index (:377).
-__device__ __forceinline__ void pub_settle(PubSlots& q, const double* pub, const unsigned* binfo, int* flag) {
-  if ((q.st & 0x1111u) == 0u) return;
-  unsigned st = q.st;
+__device__ __forceinline__ void pub_settle(PubSlots& q, const double* pub, unsigned dump, const unsigned* binfo, int* flag) {
+  if (__ballot((q.st & 0x1111u) != 0u) == 0ull) return;  // wave-uniform
   bool doubt = false;
+  int done = 0;
 #pragma unroll 1
-  for (int s = 0; s < kPubSlots; ++s) {
-    const unsigned t = pub_half(q.tw0, q.tw1, s);
-    if (t == 0xFFFFu) break;
-    const unsigned mine_st = (st >> (4 * s)) & 0xFu;
-    if (!(mine_st & 1u)) continue;
-    const unsigned e = pub_half(q.ew0, q.ew1, s);
-    bool take = true;
-    if (e != 0xFFFFu) {
-      const double mine = pub[e];
-      const unsigned bi = binfo[t];
-      const unsigned offs = bi & 0xFFFFu, n = bi >> 16, rank = e - offs;
+  for (; done < kPubSlots; ++done) {
+    const unsigned t = q.s0 & 0xFFFFu, e = q.s0 >> 16;
+    if (__ballot(t != 0xFFFFu) == 0ull) break;  // wave-uniform
+    const bool pos = t != 0xFFFFu && (q.st & 1u);
+    const bool shared = pos && e != 0xFFFFu;
+    bool lose = false;
+    if (__ballot(shared) != 0ull) {  // wave-uniform
+      const double mine = pub[shared ? e : dump];
+      const unsigned bi = binfo[shared ? t : 0u];
+      const unsigned offs = bi & 0xFFFFu, n = shared ? (bi >> 16) : 0u, rank = e - offs;
       bool rival = false;
-      for (unsigned r = 0; r < n; ++r) {
-        if (r == rank) continue;
-        const double v = pub[offs + r];
-        if (v < mine || (v == mine && r < rank)) take = false;
-        doubt |= fabs(v - mine) < 1e-7 && v != mine;  // too close to call on keys: the general kernels compare probabilities
+#pragma unroll 1
+      for (unsigned r = 0; __ballot(r < n) != 0ull; ++r) {  // wave-uniform
+        const bool on = r < n && r != rank;
+        const double got = pub[on ? offs + r : dump];
+        const double v = on ? got : pub_inf();  // (lanes that are not in the loop: mine is whatever the dump entry holds)
+        lose |= on && (v < mine || (v == mine && r < rank));
+        doubt |= on && fabs(v - mine) < 1e-7 && v != mine;  // too close to call on keys: the general kernels compare probabilities
         rival |= v < pub_inf();
       }
       // a winner whose probability is subnormal (or was evaluated at the underflow edge) next to another contender: keys
       // order such probabilities only roughly (a fragile LOSER is harmless: the winner's key is smaller by far)
-      doubt |= take && rival && (mine_st & 2u);
+      doubt |= shared && !lose && rival && (q.st & 2u);
     }
-    if (take) st |= 4u << (4 * s);
+    if (pos && !lose) q.st |= 4u;
+    pub_rotate(q);
   }
+  for (; done < kPubSlots; ++done) pub_rotate(q);
   if (doubt) *flag = 1;
-  q.st = st;
 }
 
 // The blobs taken, applied in scan order (:88): regs_apply with the take bits.
 __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
                                             Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
   double acc = 0.0;
-  if ((q.st & 0x4444u) == 0u) return acc;
+  if (__ballot((q.st & 0x4444u) != 0u) == 0ull) return acc;  // wave-uniform
+  const unsigned sw[kPubSlots] = {q.s0, q.s1, q.s2, q.s3};
   unsigned key[kPubSlots];
 #pragma unroll
   for (int s = 0; s < kPubSlots; ++s) {
-    key[s] = 0xFFFFFFFFu;
-    if ((q.st >> (4 * s)) & 4u) {
-      const unsigned t = pub_half(q.tw0, q.tw1, s);
-      key[s] = ((unsigned)order[t] << 16) | t;
-    }
+    const bool take = ((q.st >> (4 * s)) & 4u) != 0u;
+    const unsigned t = sw[s] & 0xFFFFu;
+    const unsigned o = order[take ? t : 0u];
+    key[s] = take ? ((o << 16) | t) : 0xFFFFFFFFu;
   }
   auto cswap = [&](unsigned& u, unsigned& v) {
     const unsigned lo = min(u, v), hi = max(u, v);
@@ -418,17 +433,19 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
 #pragma unroll 1
   for (int it = 0; it < kPubSlots; ++it) {
     const unsigned kk = key[0];
-    if (kk == 0xFFFFFFFFu) break;
+    if (__ballot(kk != 0xFFFFFFFFu) == 0ull) break;  // wave-uniform
     key[0] = key[1];
     key[1] = key[2];
     key[2] = key[3];
     key[3] = 0xFFFFFFFFu;
-    const double* rec = ex + 6 * (kk & 0xFFFFu);
-    const double2 z01 = *reinterpret_cast<const double2*>(rec);
-    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
-    BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
-    acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
-    fresh = imm;
+    if (kk != 0xFFFFFFFFu) {
+      const double* rec = ex + 6 * (kk & 0xFFFFu);
+      const double2 z01 = *reinterpret_cast<const double2*>(rec);
+      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+      BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+      acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+      fresh = imm;
+    }
   }
   return acc;
 }
@@ -451,147 +468,187 @@ void debug_read_pub_stamps(unsigned long long* out, bool reset) {
 #endif
 
 // ------------------------------------------------------------------ the kernel
+// The kernel's arguments are read from the kernarg segment where they are needed, phase by phase, instead of sitting in
+// ~80 SGPRs for the whole particle loop (the register allocator spilled 108 of them into VGPR lanes): an empty asm makes
+// the pointer opaque, so that nothing loaded through it before is kept alive across it.
+typedef const __attribute__((address_space(4))) PubArgs* PubArgsPtr;
+__device__ __forceinline__ PubArgsPtr pub_args_now(PubArgsPtr rp) {
+  asm volatile("" : "+s"(rp));
+  return rp;
+}
+__device__ __forceinline__ SlotSource pub_slot_source(PubArgsPtr R) {
+  return SlotSource{R->ss.map, R->ss.slot_bytes, R->ss.alt, R->ss.alt_stride, R->ss.alt_off};
+}
+__device__ __forceinline__ Noise<double> pub_noise(PubArgsPtr R) {
+  return Noise<double>{R->qt.q00, R->qt.rr, R->qt.rg, R->qt.rb, R->qt.gg, R->qt.gb, R->qt.bb, R->qt.diag};
+}
+
 // NP: adjacent landmark pairs per lane (2: maps up to 2048 landmarks; 1: up to 1024)
 template <int NP>
-__global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a) {
+__global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[2][kPubWaves];
   __shared__ int wg_flag[2];
-  if (*a.skip != 0u) return;  // workgroup-uniform: another route takes this scan
-  const int tid = threadIdx.x;
-  const int B = a.B, Lp = a.Lp, L = a.L;
-  const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
-  double* ex = reinterpret_cast<double*>(smem);
-  double* pub = ex + 6 * Bp;
-  unsigned* binfo = reinterpret_cast<unsigned*>(pub + a.ecap);
-  unsigned short* order = reinterpret_cast<unsigned short*>(binfo + Bp);
-  unsigned char* any = reinterpret_cast<unsigned char*>(order + Bp);  // [2][Bp]
-  // ---- the scan's tables: once per workgroup
-  for (int i = tid; i < 6 * B; i += kPubThreads) ex[i] = a.exact[i];
-  for (int i = tid; i < B; i += kPubThreads) {
-    binfo[i] = a.binfo[i];
-    order[i] = a.order[i];
+  PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  const int tid0 = threadIdx.x;
+  int B, Lp, L, ecap;
+  {
+    PubArgsPtr R = pub_args_now(rp);
+    if (*R->skip != 0u) return;  // workgroup-uniform: another route takes this scan
+    B = R->B;
+    Lp = R->Lp;
+    L = R->L;
+    ecap = R->ecap;
   }
-  for (unsigned i = (unsigned)tid; i < 2 * Bp / 4; i += kPubThreads) reinterpret_cast<unsigned*>(any)[i] = 0u;
-  if (tid == 0) {
-    wg_flag[0] = 0;
-    wg_flag[1] = 0;
-  }
-  // the lane's landmarks: pair q = landmarks 1024 q + 2 tid, + 1 (lanes beyond the map re-read its last pair and never
-  // use or store it)
-  int lbase[NP];
-  bool imm[2 * NP], has[2 * NP];
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    const int l0 = 2 * kPubThreads * q + 2 * tid;
-    lbase[q] = min(l0, Lp - 2);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      has[2 * q + j] = l0 + j < L;
-      imm[2 * q + j] = a.immutable[min(l0 + j, L - 1)] != 0;
+  const unsigned Bp = ((unsigned)B + 15u) & ~15u;
+  // LDS offsets (bytes): exact | pub (ecap + 2 entries) | binfo | order | any[2][Bp + 16]
+  const unsigned o_pub = Bp * 48u, o_binfo = o_pub + ((unsigned)ecap + 2u) * 8u, o_order = o_binfo + Bp * 4u, o_any = o_order + Bp * 2u;
+  const unsigned dump = (unsigned)ecap, anydump = Bp;
+  {
+    const int tid = tid0;
+    PubArgsPtr R = pub_args_now(rp);
+    // ---- the scan's tables: once per workgroup
+    double* ex = reinterpret_cast<double*>(smem);
+    const double* gex = R->exact;
+    for (int i = tid; i < 6 * B; i += kPubThreads) ex[i] = gex[i];
+    unsigned* binfo = reinterpret_cast<unsigned*>(smem + o_binfo);
+    unsigned short* order = reinterpret_cast<unsigned short*>(smem + o_order);
+    const unsigned* gb = R->binfo;
+    const unsigned short* go = R->order;
+    for (int i = tid; i < B; i += kPubThreads) {
+      binfo[i] = gb[i];
+      order[i] = go[i];
+    }
+    for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
+    if (tid == 0) {
+      wg_flag[0] = 0;
+      wg_flag[1] = 0;
     }
   }
   __syncthreads();
 
   int64_t prev = -1;  // the particle whose partial sums wait in red[] (-1: none, or it went to the general kernels)
   int cur = 0;        // parity of the particle: which any[] / flag / red[] it uses
-  for (int64_t p = a.p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
-    const bool done = p >= a.P;
+  for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
+    // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
+    // occupy registers for the whole kernel)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    double* ex = reinterpret_cast<double*>(smem);
+    double* pub = reinterpret_cast<double*>(smem + o_pub);
+    const unsigned* binfo = reinterpret_cast<const unsigned*>(smem + o_binfo);
+    const unsigned short* order = reinterpret_cast<const unsigned short*>(smem + o_order);
+    unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
     Landmark<double> S[2 * NP];
     PubSlots Q[2 * NP];
     double pse[2 * NP];
-    double sx = 0.0, sy = 0.0, sh = 0.0;
-    unsigned char* anyc = any + (size_t)cur * Bp;
+    bool done;
     PK_STAMP(s0)
 #ifdef PK_STAMPS
     unsigned long long s3 = s0;
 #endif
-    if (!done) {
-      const unsigned char* sslot = a.ss.at(regs_source_pub(a.src, p));
-      const double* sf = reinterpret_cast<const double*>(sslot);
-      const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
-      sx = pose_scalar(a.x, p);
-      sy = pose_scalar(a.y, p);
-      sh = pose_scalar(a.h, p);
-      // ---- 1. requests: candidate records (L2), the means of all four landmarks, then the covariance rows
-      uint4 cref[2 * NP], ccw[2 * NP], cew[2 * NP];
+    {
+      PubArgsPtr R = pub_args_now(rp);
+      done = p >= R->P;
+      if (!done) {
+        const SlotSource ss = pub_slot_source(R);
+        const unsigned char* sslot = ss.at(regs_source_pub(R->src, p));
+        const double* sf = reinterpret_cast<const double*>(sslot);
+        const int* sc = reinterpret_cast<const int*>(sslot + R->count_off);
+        const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
+        // the lane's landmarks: pair q = landmarks 1024 q + 2 tid, + 1 (lanes beyond the map re-read its last pair and
+        // never use or store it)
+        int lbase[NP];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const uint4* cr = a.cand + 2 * (size_t)lbase[q];
-        const uint4* er = a.erec + lbase[q];
-        cref[2 * q] = cr[0];
-        ccw[2 * q] = cr[1];
-        cref[2 * q + 1] = cr[2];
-        ccw[2 * q + 1] = cr[3];
-        cew[2 * q] = er[0];
-        cew[2 * q + 1] = er[1];
-      }
-      asm volatile("" ::: "memory");
-      auto row2 = [&](int f, int lb) { return *reinterpret_cast<const Double2*>(sf + (size_t)f * Lp + lb); };
-#define PK_PUB_LOAD(field, F)                   \
-  {                                             \
-    const Double2 v = row2(F, lbase[q]);        \
-    S[2 * q].field = v.x;                       \
-    S[2 * q + 1].field = v.y;                   \
+        for (int q = 0; q < NP; ++q) lbase[q] = min(2 * kPubThreads * q + 2 * tid, Lp - 2);
+        // ---- 1. requests: candidate records (L2), the means of all four landmarks, then the covariance rows
+        uint4 cref[2 * NP], ccw[2 * NP], cew[2 * NP];
+        {
+          const uint4* cand = R->cand;
+          const uint4* erec = R->erec;
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            const uint4* cr = cand + 2 * (size_t)lbase[q];
+            const uint4* er = erec + lbase[q];
+            cref[2 * q] = cr[0];
+            ccw[2 * q] = cr[1];
+            cref[2 * q + 1] = cr[2];
+            ccw[2 * q + 1] = cr[3];
+            cew[2 * q] = er[0];
+            cew[2 * q + 1] = er[1];
+          }
+        }
+        asm volatile("" ::: "memory");
+        auto row2 = [&](int f, int lb) { return *reinterpret_cast<const Double2*>(sf + (size_t)f * Lp + lb); };
+#define PK_PUB_LOAD(field, F)            \
+  {                                      \
+    const Double2 v = row2(F, lbase[q]); \
+    S[2 * q].field = v.x;                \
+    S[2 * q + 1].field = v.y;            \
   }
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        PK_PUB_LOAD(mx, F_MX)
-        PK_PUB_LOAD(my, F_MY)
-        PK_PUB_LOAD(mr, F_MR)
-        PK_PUB_LOAD(mg, F_MG)
-        PK_PUB_LOAD(mb, F_MB)
-      }
-      asm volatile("" ::: "memory");
+        for (int q = 0; q < NP; ++q) {
+          PK_PUB_LOAD(mx, F_MX)
+          PK_PUB_LOAD(my, F_MY)
+          PK_PUB_LOAD(mr, F_MR)
+          PK_PUB_LOAD(mg, F_MG)
+          PK_PUB_LOAD(mb, F_MB)
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        PK_PUB_LOAD(pxx, F_PXX)
-        PK_PUB_LOAD(pxy, F_PXY)
-        PK_PUB_LOAD(pyy, F_PYY)
-        PK_PUB_LOAD(crr, F_CRR)
-        PK_PUB_LOAD(crg, F_CRG)
-        PK_PUB_LOAD(crb, F_CRB)
-        PK_PUB_LOAD(cgg, F_CGG)
-        PK_PUB_LOAD(cgb, F_CGB)
-        PK_PUB_LOAD(cbb, F_CBB)
-        const Int2 c = *reinterpret_cast<const Int2*>(sc + lbase[q]);
-        S[2 * q].count = c.x;
-        S[2 * q + 1].count = c.y;
-      }
+        for (int q = 0; q < NP; ++q) {
+          PK_PUB_LOAD(pxx, F_PXX)
+          PK_PUB_LOAD(pxy, F_PXY)
+          PK_PUB_LOAD(pyy, F_PYY)
+          PK_PUB_LOAD(crr, F_CRR)
+          PK_PUB_LOAD(crg, F_CRG)
+          PK_PUB_LOAD(crb, F_CRB)
+          PK_PUB_LOAD(cgg, F_CGG)
+          PK_PUB_LOAD(cgb, F_CGB)
+          PK_PUB_LOAD(cbb, F_CBB)
+          const Int2 c = *reinterpret_cast<const Int2*>(sc + lbase[q]);
+          S[2 * q].count = c.x;
+          S[2 * q + 1].count = c.y;
+        }
 #undef PK_PUB_LOAD
-      asm volatile("" ::: "memory");
-      PK_STAMP(s1)
-      PK_PSTAMP(0, s0, s1)  // scalars, requests
-      // ---- 2. gates of the four landmarks (means only), failing candidates published at once
+        asm volatile("" ::: "memory");
+        PK_STAMP(s1)
+        PK_PSTAMP(0, s0, s1)  // scalars, requests
+        // ---- 2. gates of the four landmarks (means only), failing candidates published at once
 #pragma unroll
-      for (int i = 0; i < 2 * NP; ++i) {
-        Q[i] = PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
-        pse[i] = 0.0;
-        if (has[i])
-          pub_gates(Q[i], pse[i], cref[i], ccw[i], cew[i], ex, pub, &wg_flag[cur], S[i].mx, S[i].my, S[i].mr, S[i].mg, S[i].mb, sx, sy, sh);
-      }
-      PK_STAMP(s2)
-      PK_PSTAMP(1, s1, s2)  // gates (waits for the candidate records and the means)
-      // ---- 3. verdicts on the gate-passing blobs (first use of the covariance rows)
+        for (int i = 0; i < 2 * NP; ++i) {
+          Q[i] = PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
+          pse[i] = 0.0;
+          if (PK_PUB_ABLATE < 4 && 2 * kPubThreads * (i >> 1) + 2 * tid + (i & 1) < L)
+            pub_gates(Q[i], pse[i], cref[i], ccw[i], cew[i], ex, pub, dump, &wg_flag[cur], S[i].mx, S[i].my, S[i].mr, S[i].mg, S[i].mb, sx, sy, sh);
+        }
+        PK_STAMP(s2)
+        PK_PSTAMP(1, s1, s2)  // gates (waits for the candidate records and the means)
+        // ---- 3. verdicts on the gate-passing blobs (first use of the covariance rows)
 #pragma unroll
-      for (int i = 0; i < 2 * NP; ++i) pub_keys(Q[i], S[i], pse[i], ex, pub, anyc, &wg_flag[cur], sx, sy);
+        for (int i = 0; i < 2 * NP; ++i)
+          if (PK_PUB_ABLATE < 3) pub_keys(Q[i], S[i], pse[i], ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
 #ifdef PK_STAMPS
-      PK_STAMP(s3b)
-      s3 = s3b;
-      PK_PSTAMP(2, s2, s3)  // verdicts (waits for the covariance rows)
+        PK_STAMP(s3b)
+        s3 = s3b;
+        PK_PSTAMP(2, s2, s3)  // verdicts (waits for the covariance rows)
 #endif
+      }
     }
     lds_barrier();  // A: every verdict of this particle is in the table
     PK_STAMP(s4)
     PK_PSTAMP(3, s3, s4)  // barrier A
     if (prev >= 0 && tid == 0) {  // the previous particle's log-weight (its partial sums were written before A)
+      PubArgsPtr R = pub_args_now(rp);
       double tot = red[cur ^ 1][0];
 #pragma unroll
       for (int i = 1; i < kPubWaves; ++i) tot += red[cur ^ 1][i];
-      const double w = (a.reset ? 0.0 : a.logw[prev]) + tot;
-      a.logw[prev] = w;
-      if (a.gmax_key) atomicMax(a.gmax_key + (prev & (kGmaxKeys - 1)), double_to_key(w));
-      a.src[prev] = (int32_t)prev;
+      double* logw = R->logw;
+      const double w = (R->reset ? 0.0 : logw[prev]) + tot;
+      logw[prev] = w;
+      unsigned long long* gk = R->gmax_key;
+      if (gk) atomicMax(gk + (prev & (kGmaxKeys - 1)), double_to_key(w));
+      R->src[prev] = (int32_t)prev;
     }
     if (done) break;
     prev = -1;
@@ -599,49 +656,56 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a) {
     double acc;
     {
       int nun = 0;
-      for (unsigned w = (unsigned)tid; w < Bp / 4; w += kPubThreads) {
+      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) {
         const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
 #pragma unroll
         for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
       }
       acc = (double)nun * Consts<double>::log_no_match;  // unseen features: weight *= 0.1 each (:94-95)
-      unsigned* anyn = reinterpret_cast<unsigned*>(any + (size_t)(cur ^ 1) * Bp);
-      for (unsigned w = (unsigned)tid; w < Bp / 4; w += kPubThreads) anyn[w] = 0u;
+      unsigned* anyn = reinterpret_cast<unsigned*>(smem + o_any + (unsigned)(cur ^ 1) * (Bp + 16u));
+      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
 #pragma unroll
-    for (int i = 0; i < 2 * NP; ++i) pub_settle(Q[i], pub, binfo, &wg_flag[cur]);
+    for (int i = 0; i < 2 * NP; ++i)
+      if (PK_PUB_ABLATE < 2) pub_settle(Q[i], pub, dump, binfo, &wg_flag[cur]);
     PK_STAMP(s5)
     PK_PSTAMP(4, s4, s5)  // unseen blobs, subscribe
     lds_barrier();  // B: every verdict has been read (the table is the next particle's), every flag is set
     PK_STAMP(s6)
     PK_PSTAMP(5, s5, s6)  // barrier B
-    if (wg_flag[cur]) {  // workgroup-uniform: nothing has been written; the general kernels take the particle
+    if (wg_flag[cur] && PK_PUB_ABLATE == 0) {  // workgroup-uniform: nothing has been written; the general kernels take the particle
       if (tid == 0) {
-        a.pflag_out[p] = 1;
-        atomicAdd(a.n_flagged, 1u);
+        PubArgsPtr R = pub_args_now(rp);
+        R->pflag_out[p] = 1;
+        atomicAdd(R->n_flagged, 1u);
       }
       continue;
     }
-    if (tid == 0) a.pflag_out[p] = 0;
     // ---- 5. updates in scan order, stores
     {
-      unsigned char* dslot = a.map_dst + (size_t)p * a.ss.slot_bytes;
+      PubArgsPtr R = pub_args_now(rp);
+      if (tid == 0) R->pflag_out[p] = 0;
+      const Noise<double> qt = pub_noise(R);
+      const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
+      unsigned char* dslot = R->map_dst + (size_t)p * R->ss.slot_bytes;
       double* df = reinterpret_cast<double*>(dslot);
-      int* dc = reinterpret_cast<int*>(dslot + a.count_off);
+      int* dc = reinterpret_cast<int*>(dslot + R->count_off);
+      const unsigned char* immutable = R->immutable;
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
+        const int l0 = 2 * kPubThreads * q + 2 * tid;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int i = 2 * q + j;
-          acc += pub_apply(Q[i], ex, order, a.qt, S[i], imm[i], sx, sy, pse[i]);
+          const bool imm = immutable[min(l0 + j, L - 1)] != 0;
+          if (PK_PUB_ABLATE < 1) acc += pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
         }
-        const int l0 = 2 * kPubThreads * q + 2 * tid;
         if (l0 < Lp) {
-#define PK_PUB_STORE(field, F)                                                                     \
-  {                                                                                                \
-    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                        \
-    __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0));         \
+#define PK_PUB_STORE(field, F)                                                             \
+  {                                                                                        \
+    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                \
+    __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
   }
           PK_PUB_STORE(mx, F_MX)
           PK_PUB_STORE(my, F_MY)
