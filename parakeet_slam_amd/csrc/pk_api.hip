@@ -145,6 +145,7 @@ struct pk_filter {
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
+  unsigned* glist_dev = nullptr; // [bcand_cap + 1] the same for the blobs several landmarks list, compacted; then their number
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
   struct Split {
     bool active = false;
@@ -939,7 +940,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->binfo_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->binfo_dev, (void*)f->glist_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1274,16 +1275,18 @@ static int ensure_inverse_lists(pk_filter* f, int B) {
   int rc;
   if (B > f->bcand_cap) {
     PK_HIP(hipStreamSynchronize(f->stream));
-    for (void* q : {(void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->binfo_dev})
+    for (void* q : {(void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->binfo_dev, (void*)f->glist_dev})
       if (q) (void)hipFree(q);
     f->bcnt_dev = nullptr;
     f->brec_dev = nullptr;
     f->binfo_dev = nullptr;
+    f->glist_dev = nullptr;
     f->bcand_cap = 0;
     const int64_t cap = (int64_t)B + B / 4 + 64;
     if ((rc = dev_alloc(f, &f->bcnt_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->binfo_dev, (size_t)cap))) return rc;
+    if ((rc = dev_alloc(f, &f->glist_dev, (size_t)cap + 1))) return rc;
     f->bcand_cap = cap;
   }
   return PK_OK;
@@ -1305,7 +1308,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     if (ecap > 0) {  // candidate lists both ways, and the publish table's layout
       launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
                         kCandSlots, f->out4);
-      launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, ctl_cand_over(f),
+      launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
                           ctl_skip_pub(f), ctl_skip_cand(f), ecap);
       cand->skip_cand = ctl_skip_cand(f);
       f->pub_ecap = ecap;
@@ -1326,7 +1329,7 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
   e1.flip = false;
   if (al.regs) {
     if (f->pub_ecap > 0 && cand.rec)
-      launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->binfo_dev, ctl_skip_pub(f), f->pub_ecap,
+      launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
                       p0, p1, reserve_cus);
     launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
                      reserve_cus);

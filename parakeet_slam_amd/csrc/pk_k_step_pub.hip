@@ -70,7 +70,7 @@ struct PubArgs {
   const unsigned char* immutable;
   const uint4* cand;            // [Lp][2]: reference (eb, r, g, b as float) | 8 x u16 blobs
   const uint4* erec;            // [Lp]: 8 x u16 publish entries of those blobs (0xFFFF: nobody else lists the blob)
-  const unsigned* binfo;        // [B]: offs | n << 16
+  const unsigned* glist;        // [B + 1]: the blobs at least two landmarks list: first entry | contenders << 16; [B]: how many
   const unsigned* skip;         // != 0: this scan is not ours (a list overflowed, or the table does not fit)
   unsigned char* pflag_out;     // [P] 1 = general route
   unsigned* n_flagged;
@@ -106,7 +106,8 @@ struct CandEntriesArgs {
   uint4* erec;            // [Lp]
   unsigned* bcnt;         // [B]
   uint4* brec;            // [B] 8 x u16, sorted in place
-  unsigned* binfo;        // [B]
+  unsigned* binfo;        // [B] per blob: first entry | contenders << 16 (scratch of this kernel)
+  unsigned* glist;        // [B] the blobs at least two landmarks list, compacted: first entry | contenders << 16; [B] = their number
   const unsigned* over;   // candidate-list overflow
   unsigned* skip_pub;
   unsigned* skip_cand;
@@ -114,12 +115,12 @@ struct CandEntriesArgs {
 };
 
 __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
-  __shared__ unsigned s_part[1024];
+  __shared__ unsigned s_part[1024], s_gpart[1024];
   __shared__ unsigned s_total;
   const int tid = threadIdx.x;
   const int chunk = (a.B + 1023) / 1024;
   const int t0 = tid * chunk, t1 = min(a.B, t0 + chunk);
-  unsigned mine = 0;
+  unsigned mine = 0, gmine = 0;
   for (int t = t0; t < t1; ++t) {
     const unsigned n = min(a.bcnt[t], (unsigned)kCandSlots);
     uint4 w = a.brec[t];
@@ -141,25 +142,31 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     w.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
     a.brec[t] = w;
     mine += n >= 2u ? n : 0u;
+    gmine += n >= 2u ? 1u : 0u;
   }
   s_part[tid] = mine;
+  s_gpart[tid] = gmine;
   __syncthreads();
   if (tid == 0) {  // sequential scan of 1024 partial sums: once per scan, a microsecond
-    unsigned run = 0;
+    unsigned run = 0, grun = 0;
     for (int i = 0; i < 1024; ++i) {
-      const unsigned v = s_part[i];
+      const unsigned v = s_part[i], g = s_gpart[i];
       s_part[i] = run;
+      s_gpart[i] = grun;
       run += v;
+      grun += g;
     }
     s_total = run;
+    a.glist[a.B] = grun;
   }
   __syncthreads();
   {
-    unsigned run = s_part[tid];
+    unsigned run = s_part[tid], grun = s_gpart[tid];
     for (int t = t0; t < t1; ++t) {
       const unsigned n = min(a.bcnt[t], (unsigned)kCandSlots);
       const unsigned c = n >= 2u ? n : 0u;
       a.binfo[t] = (run & 0xFFFFu) | (n << 16);
+      if (n >= 2u) a.glist[grun++] = (run & 0xFFFFu) | (n << 16);
       run += c;
     }
   }
@@ -198,7 +205,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
 }
 
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
-                         uint4* brec_dev, unsigned* binfo_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
+                         uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap) {
   CandEntriesArgs a;
   a.cand = cand_dev;
@@ -206,6 +213,7 @@ void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4
   a.bcnt = bcnt_dev;
   a.brec = brec_dev;
   a.binfo = binfo_dev;
+  a.glist = glist_dev;
   a.over = over_dev;
   a.skip_pub = skip_pub_dev;
   a.skip_cand = skip_cand_dev;
@@ -225,7 +233,7 @@ void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4
 // (0xFFFF: none / no other landmark lists the blob), most recent first, empty slots at the back.
 struct PubSlots {
   unsigned s0, s1, s2, s3;
-  unsigned st;  // 4 bits per slot: 1 probability > 0, 2 fragile (subnormal probability / evaluated at the edge), 4 take
+  unsigned st;  // 4 bits per slot: 1 probability > 0, 4 take
 };
 __device__ __forceinline__ void pub_rotate(PubSlots& q) {  // slot 0 goes to the back, its state bits with it
   const unsigned w = q.s0;
@@ -308,7 +316,9 @@ __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm
   const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
   double det3;
   const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
-  const bool sane = det2 > 1e-60 && det2 < 1e60 && det3 > 1e-60 && det3 < 1e60;  // NaN: false
+  // (determinants within 1e-20 ... 1e60: then log det >= -46, and a pair with a subnormal factor -- a2 or a3 beyond 1400 --
+  // has a key beyond 1350: the settling tells fragile winners by their key alone)
+  const bool sane = det2 > 1e-20 && det2 < 1e60 && det3 > 1e-20 && det3 < 1e60;  // NaN: false
   bool weird = false;
   const double r2 = 1.0 / det2, r3 = 1.0 / det3;
   // log det = (e + log2 m) ln 2 with m in [0.5, 1): bounded above by e ln 2, below by (e - 1) ln 2 -- all the underflow
@@ -348,61 +358,79 @@ __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm
     const bool sure_pos = angle_ok && nonneg && key < 1489.0 && a2hi < 1489.0 && a3hi < 1489.0;
     const bool sure_zero = !angle_ok || key > 1491.5 || a2hi - ln2 > 1491.5 || a3hi - ln2 > 1491.5;
     bool positive = valid && sure_pos;
-    bool fragile = key > 1400.0 || a2hi > 1400.0 || a3hi > 1400.0;
     const bool edge = valid && !sure_pos && !sure_zero;
     if (__ballot(edge) != 0ull) {  // wave-uniform, rare
       if (edge) {
         double d2 = det2, d3 = det3;
         asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
         positive = pr_from_parts(d2, d3, num2, num3) > 0.0;
-        fragile = true;
       }
     }
     pub[e == 0xFFFFu ? dump : e] = positive ? key : pub_inf();  // (an empty slot's entry field is 0xFFFF)
     any[positive ? t : anydump] = 1;
-    q.st |= (positive ? 1u : 0u) | (fragile ? 2u : 0u);
+    q.st |= positive ? 1u : 0u;
     pub_rotate(q);
   }
   for (; done < kPubSlots; ++done) pub_rotate(q);  // wave-uniform trip count: back to the original order
   if (weird) *flag = 1;
 }
 
-// The rivals' verdicts on the blobs this landmark passes with probability > 0: it takes a blob iff no rival has a
-// smaller key, nor an equal key with a lower landmark index (:377).
-__device__ __forceinline__ void pub_settle(PubSlots& q, const double* pub, unsigned dump, const unsigned* binfo, int* flag) {
-  if (__ballot((q.st & 0x1111u) != 0u) == 0ull) return;  // wave-uniform
+// Settling, BLOB-parallel: one lane per blob that several landmarks list (a few per lane, their entries one contiguous
+// run of the table, read in one batch).  The smallest key takes the blob, the lowest landmark -- the lowest rank -- on
+// equal keys (:377); its entry is overwritten with the marker -inf, which is what the landmark's lane looks for afterwards.
+// Too close to call on keys (two contenders within 1e-7 that are not identical), or a winner whose probability is
+// subnormal (key beyond 1350: keys order such probabilities only roughly) next to another contender: the particle is
+// flagged and the general kernels compare probabilities.  (A first version let every landmark's lane read its rivals'
+// entries one after the other: 40 % of the kernel's time went into those dependent LDS round trips.)
+__device__ __forceinline__ double pub_marker() { return __longlong_as_double((long long)0xFFF0000000000000ull); }
+__device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist, unsigned G, double* pub, unsigned dump, int* flag) {
   bool doubt = false;
-  int done = 0;
 #pragma unroll 1
-  for (; done < kPubSlots; ++done) {
-    const unsigned t = q.s0 & 0xFFFFu, e = q.s0 >> 16;
-    if (__ballot(t != 0xFFFFu) == 0ull) break;  // wave-uniform
-    const bool pos = t != 0xFFFFu && (q.st & 1u);
-    const bool shared = pos && e != 0xFFFFu;
-    bool lose = false;
-    if (__ballot(shared) != 0ull) {  // wave-uniform
-      const double mine = pub[shared ? e : dump];
-      const unsigned bi = binfo[shared ? t : 0u];
-      const unsigned offs = bi & 0xFFFFu, n = shared ? (bi >> 16) : 0u, rank = e - offs;
-      bool rival = false;
-#pragma unroll 1
-      for (unsigned r = 0; __ballot(r < n) != 0ull; ++r) {  // wave-uniform
-        const bool on = r < n && r != rank;
-        const double got = pub[on ? offs + r : dump];
-        const double v = on ? got : pub_inf();  // (lanes that are not in the loop: mine is whatever the dump entry holds)
-        lose |= on && (v < mine || (v == mine && r < rank));
-        doubt |= on && fabs(v - mine) < 1e-7 && v != mine;  // too close to call on keys: the general kernels compare probabilities
-        rival |= v < pub_inf();
-      }
-      // a winner whose probability is subnormal (or was evaluated at the underflow edge) next to another contender: keys
-      // order such probabilities only roughly (a fragile LOSER is harmless: the winner's key is smaller by far)
-      doubt |= shared && !lose && rival && (q.st & 2u);
+  for (unsigned g = (unsigned)tid; __ballot(g < G) != 0ull; g += kPubThreads) {  // wave-uniform
+    const bool on = g < G;
+    const unsigned gi = glist[on ? g : 0u];
+    const unsigned offs = gi & 0xFFFFu, n = on ? (gi >> 16) : 0u;
+    double v[kCandSlots];
+#pragma unroll
+    for (int r = 0; r < kCandSlots; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
+    double best = pub_inf();
+    unsigned wr = 0u;
+#pragma unroll
+    for (int r = 0; r < kCandSlots; ++r) {
+      v[r] = (unsigned)r < n ? v[r] : pub_inf();
+      const bool better = v[r] < best;  // strict: on equal keys the earlier rank stays (:377)
+      wr = better ? (unsigned)r : wr;
+      best = better ? v[r] : best;
     }
-    if (pos && !lose) q.st |= 4u;
-    pub_rotate(q);
+    int contenders = 0;
+    bool close = false;
+#pragma unroll
+    for (int r = 0; r < kCandSlots; ++r) {
+      contenders += v[r] < pub_inf() ? 1 : 0;
+      close |= v[r] != best && v[r] - best < 1e-7;  // within 1e-7 of the winner without being identical to it
+    }
+    doubt |= close || (contenders >= 2 && best > 1350.0);
+    if (best < pub_inf()) pub[offs + wr] = pub_marker();
   }
-  for (; done < kPubSlots; ++done) pub_rotate(q);
   if (doubt) *flag = 1;
+}
+
+// Which of its blobs this landmark takes: those it passes with probability > 0 and either nobody else lists, or whose
+// entry carries the winner's marker.
+__device__ __forceinline__ void pub_take(PubSlots& q, const double* pub, unsigned dump) {
+  const unsigned sw[kPubSlots] = {q.s0, q.s1, q.s2, q.s3};
+  double m[kPubSlots];
+#pragma unroll
+  for (int s = 0; s < kPubSlots; ++s) {
+    const unsigned e = sw[s] >> 16;
+    m[s] = pub[e == 0xFFFFu ? dump : e];
+  }
+#pragma unroll
+  for (int s = 0; s < kPubSlots; ++s) {
+    const unsigned e = sw[s] >> 16;
+    const bool pos = ((q.st >> (4 * s)) & 1u) != 0u;
+    if (pos && (e == 0xFFFFu || m[s] == pub_marker())) q.st |= 4u << (4 * s);
+  }
 }
 
 // The blobs taken, applied in scan order (:88): regs_apply with the take bits.
@@ -501,9 +529,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
     ecap = R->ecap;
   }
   const unsigned Bp = ((unsigned)B + 15u) & ~15u;
-  // LDS offsets (bytes): exact | pub (ecap + 2 entries) | binfo | order | any[2][Bp + 16]
+  // LDS offsets (bytes): exact | pub (ecap + 2 entries) | glist (binfo's place) | order | any[2][Bp + 16]
   const unsigned o_pub = Bp * 48u, o_binfo = o_pub + ((unsigned)ecap + 2u) * 8u, o_order = o_binfo + Bp * 4u, o_any = o_order + Bp * 2u;
   const unsigned dump = (unsigned)ecap, anydump = Bp;
+  unsigned G;  // blobs that several landmarks list
   {
     const int tid = tid0;
     PubArgsPtr R = pub_args_now(rp);
@@ -511,12 +540,13 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
     double* ex = reinterpret_cast<double*>(smem);
     const double* gex = R->exact;
     for (int i = tid; i < 6 * B; i += kPubThreads) ex[i] = gex[i];
-    unsigned* binfo = reinterpret_cast<unsigned*>(smem + o_binfo);
+    unsigned* glist = reinterpret_cast<unsigned*>(smem + o_binfo);
     unsigned short* order = reinterpret_cast<unsigned short*>(smem + o_order);
-    const unsigned* gb = R->binfo;
+    const unsigned* gb = R->glist;
     const unsigned short* go = R->order;
+    G = gb[B];
     for (int i = tid; i < B; i += kPubThreads) {
-      binfo[i] = gb[i];
+      glist[i] = (unsigned)i < G ? gb[i] : 0u;
       order[i] = go[i];
     }
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
@@ -536,7 +566,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
     asm volatile("" : "+v"(tid));
     double* ex = reinterpret_cast<double*>(smem);
     double* pub = reinterpret_cast<double*>(smem + o_pub);
-    const unsigned* binfo = reinterpret_cast<const unsigned*>(smem + o_binfo);
+    const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_binfo);
     const unsigned short* order = reinterpret_cast<const unsigned short*>(smem + o_order);
     unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
     Landmark<double> S[2 * NP];
@@ -652,7 +682,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
     }
     if (done) break;
     prev = -1;
-    // ---- 4. subscribe: the rivals' verdicts; blobs nobody matches; the next particle's any[] / flag cleared
+    // ---- 4. settling, one lane per contested blob; blobs nobody matches; the next particle's any[] / flag cleared
     double acc;
     {
       int nun = 0;
@@ -666,14 +696,16 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
+    if (PK_PUB_ABLATE < 2) pub_settle_blobs(tid, glist, G, pub, dump, &wg_flag[cur]);
+    PK_STAMP(s5)
+    PK_PSTAMP(4, s4, s5)  // unseen blobs, settling
+    lds_barrier();  // B: every winner is marked, every flag is set
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i)
-      if (PK_PUB_ABLATE < 2) pub_settle(Q[i], pub, dump, binfo, &wg_flag[cur]);
-    PK_STAMP(s5)
-    PK_PSTAMP(4, s4, s5)  // unseen blobs, subscribe
-    lds_barrier();  // B: every verdict has been read (the table is the next particle's), every flag is set
+      if (PK_PUB_ABLATE < 2) pub_take(Q[i], pub, dump);
+    lds_barrier();  // C: every marker has been read -- the table is the next particle's
     PK_STAMP(s6)
-    PK_PSTAMP(5, s5, s6)  // barrier B
+    PK_PSTAMP(5, s5, s6)  // barrier B, markers, barrier C
     if (wg_flag[cur] && PK_PUB_ABLATE == 0) {  // workgroup-uniform: nothing has been written; the general kernels take the particle
       if (tid == 0) {
         PubArgsPtr R = pub_args_now(rp);
@@ -745,7 +777,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
 
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
-                     const unsigned* binfo_dev, const unsigned* skip_dev, int ecap, int64_t p0, int64_t p1, int reserve_cus) {
+                     const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0, int64_t p1, int reserve_cus) {
   if (p1 < 0) p1 = d.P;
   if (d.P == 0 || p1 <= p0) return;
   static bool attr_set[kMaxDevices] = {false};
@@ -767,7 +799,7 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   a.immutable = d.immutable;
   a.cand = cand.rec;
   a.erec = erec_dev;
-  a.binfo = binfo_dev;
+  a.glist = glist_dev;
   a.skip = skip_dev;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;

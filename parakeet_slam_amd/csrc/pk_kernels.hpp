@@ -211,11 +211,11 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
 int step_pub_entry_capacity(int B);  // publish-table entries that fit LDS beside the scan's tables (0: the scan does not fit)
 size_t step_pub_lds_bytes(int B, int ecap);
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
-                         uint4* brec_dev, unsigned* binfo_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
+                         uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap);
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
-                     const unsigned* binfo_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
+                     const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
                      int reserve_cus = 0);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
