@@ -263,6 +263,7 @@ __device__ __forceinline__ void pub_gates(PubSlots& q, double& pse_out, const ui
                       fabs(mg - (double)__uint_as_float(ref.z)) <= kCandColour && fabs(mb - (double)__uint_as_float(ref.w)) <= kCandColour;
   int npass = 0;
   unsigned s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
+  float dmin = 3.0e38f;  // colour distance of the blob in slot 0: the best colour match stands in front (pub_keys)
   unsigned c0 = cw.x, c1 = cw.y, c2 = cw.z, c3 = cw.w;  // the list is filled from the front
   unsigned e0 = ew.x, e1 = ew.y, e2 = ew.z, e3 = ew.w;
 #pragma unroll 1
@@ -285,19 +286,31 @@ __device__ __forceinline__ void pub_gates(PubSlots& q, double& pse_out, const ui
     const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
     const double2 b01 = *reinterpret_cast<const double2*>(rb);
     const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
-    const bool pa = va && !(fabs(a01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, a01.y, a23.x, a23.y)) > 300.0);
-    const bool pb = vb && !(fabs(b01.x - eb) > 0.5) && !(fabs(color_distance2(mr, mg, mb, b01.y, b23.x, b23.y)) > 300.0);
+    const double cda = color_distance2(mr, mg, mb, a01.y, a23.x, a23.y), cdb = color_distance2(mr, mg, mb, b01.y, b23.x, b23.y);
+    const bool pa = va && !(fabs(a01.x - eb) > 0.5) && !(fabs(cda) > 300.0);
+    const bool pb = vb && !(fabs(b01.x - eb) > 0.5) && !(fabs(cdb) > 300.0);
     pub[(pa || ea == 0xFFFFu) ? dump : ea] = pub_inf();
     pub[(pb || eb2 == 0xFFFFu) ? dump : eb2] = pub_inf();
     const unsigned wa = ta | (ea << 16), wb = tb | (eb2 << 16);
-    s3 = pa ? s2 : s3;
-    s2 = pa ? s1 : s2;
-    s1 = pa ? s0 : s1;
-    s0 = pa ? wa : s0;
-    s3 = pb ? s2 : s3;
-    s2 = pb ? s1 : s2;
-    s1 = pb ? s0 : s1;
-    s0 = pb ? wb : s0;
+    // a passing blob goes to the front when its colour is the closest so far, else behind the front one
+    {
+      const float d = (float)cda;
+      const bool front = pa && d < dmin;
+      s3 = pa ? s2 : s3;
+      s2 = pa ? s1 : s2;
+      s1 = pa ? (front ? s0 : wa) : s1;
+      s0 = front ? wa : s0;
+      dmin = front ? d : dmin;
+    }
+    {
+      const float d = (float)cdb;
+      const bool front = pb && d < dmin;
+      s3 = pb ? s2 : s3;
+      s2 = pb ? s1 : s2;
+      s1 = pb ? (front ? s0 : wb) : s1;
+      s0 = front ? wb : s0;
+      dmin = front ? d : dmin;
+    }
     npass += (pa ? 1 : 0) + (pb ? 1 : 0);
   }
   if (!inside || npass > kPubSlots) *flag = 1;
@@ -320,7 +333,15 @@ __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm
   // has a key beyond 1350: the settling tells fragile winners by their key alone)
   const bool sane = det2 > 1e-20 && det2 < 1e60 && det3 > 1e-20 && det3 < 1e60;  // NaN: false
   bool weird = false;
-  const double r2 = 1.0 / det2, r3 = 1.0 / det3;
+  // 1 / det to a few ulp (v_rcp_f64 and two Newton steps: the full division sequence is twice as long; the keys are
+  // compared with each other only, all made the same way)
+  auto recip = [](double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+  };
+  const double r2 = recip(det2), r3 = recip(det3);
   // log det = (e + log2 m) ln 2 with m in [0.5, 1): bounded above by e ln 2, below by (e - 1) ln 2 -- all the underflow
   // tests need of the two logs; the key itself takes ONE log, of the product
   int e2i, e3i;
@@ -330,6 +351,15 @@ __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm
   const double a2base = 2.0 * Consts<double>::log_two_pi + (double)e2i * ln2;  // >= 2 log 2pi + log det2
   const double a3base = 3.0 * Consts<double>::log_two_pi + (double)e3i * ln2;
   const double kbase = 5.0 * Consts<double>::log_two_pi + log_few_ulp(det2 * det3);
+  // A colour block that is certainly positive definite (Sylvester) has d' C^-1 d >= |d|^2 / lmax(C), and lmax(C) is at most
+  // the largest absolute row sum (Gershgorin): with the position term >= 0 that bounds the key from below by
+  // kbase + |d|^2 / rowmax, and a blob whose bound lies beyond the underflow edge has probability 0 whatever the rest says.  Once a landmark has been seen a few times its colour block is tight
+  // and every look-alike's blob ends here: when that holds for all lanes of the wave the round is skipped
+  // (both blocks positive definite: adj3.f = crr cgg - crg^2, the determinants > 0 are part of sane)
+  const bool pd3 = sane && lm.crr > 0.0 && adj3.f > 0.0 && lm.pxx > 0.0;
+  const double itr3 = pd3 ? recip(fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))),
+                                       lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
+                          : 0.0;
   int done = 0;
 #pragma unroll 1
   for (; done < kPubSlots; ++done) {
@@ -339,34 +369,43 @@ __device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm
     const double* rec = ex + 6 * (valid ? t : 0u);
     const double2 z01 = *reinterpret_cast<const double2*>(rec);
     const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
-    const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
-    // prob_position_match :457-494, prob_color_match :524-544
-    const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
-    double nx, ny;
-    closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
-    const double ex_ = nx - lm.mx, ey = ny - lm.my;
-    const double num2 = lm.pyy * ex_ * ex_ - 2.0 * lm.pxy * ex_ * ey + lm.pxx * ey * ey;  // maha2 = num2 / det2
-    const double num3 = sym3_quad(adj3, z01.y - lm.mr, z23.x - lm.mg, z23.y - lm.mb);     // maha3 = num3 / det3
-    const double maha2 = num2 * r2, maha3 = num3 * r3;
-    const double key = kbase + (maha2 + maha3);
-    const double a2hi = a2base + maha2, a3hi = a3base + maha3;
-    // pr = fl(fl(bp cp) / 250000), bp = 500 exp(-a2 / 2), cp = 500 exp(-a3 / 2): bp rounds to 0 from a2 > 1490.27 on
-    // (exp(-745.13) = 2^-1075, half the smallest subnormal), the quotient from a2 + a3 > 1490.27 on.  Outside the margins
-    // below the answer is certain; inside (a strip 2.5-3.2 wide) the probability is evaluated as the reference does
-    const bool nonneg = num2 >= 0.0 && num3 >= 0.0;  // indefinite covariances, NaN: false
-    weird |= valid && (!sane || (angle_ok && !nonneg));
-    const bool sure_pos = angle_ok && nonneg && key < 1489.0 && a2hi < 1489.0 && a3hi < 1489.0;
-    const bool sure_zero = !angle_ok || key > 1491.5 || a2hi - ln2 > 1491.5 || a3hi - ln2 > 1491.5;
-    bool positive = valid && sure_pos;
-    const bool edge = valid && !sure_pos && !sure_zero;
-    if (__ballot(edge) != 0ull) {  // wave-uniform, rare
-      if (edge) {
-        double d2 = det2, d3 = det3;
-        asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
-        positive = pr_from_parts(d2, d3, num2, num3) > 0.0;
+    const double d1 = z01.y - lm.mr, d2c = z23.x - lm.mg, d3c = z23.y - lm.mb;
+    const bool far = pd3 && kbase + (d1 * d1 + d2c * d2c + d3c * d3c) * itr3 > 1492.0;  // key > 1492: probability 0
+    bool positive = false;
+    if (__ballot(valid && !far) != 0ull) {  // wave-uniform
+      const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
+      // prob_position_match :457-494, prob_color_match :524-544
+      const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
+      double nx, ny;
+      closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+      const double ex_ = nx - lm.mx, ey = ny - lm.my;
+      const double num2 = lm.pyy * ex_ * ex_ - 2.0 * lm.pxy * ex_ * ey + lm.pxx * ey * ey;  // maha2 = num2 / det2
+      const double num3 = sym3_quad(adj3, d1, d2c, d3c);                                     // maha3 = num3 / det3
+      const double maha2 = num2 * r2, maha3 = num3 * r3;
+      const double key = kbase + (maha2 + maha3);
+      const double a2hi = a2base + maha2, a3hi = a3base + maha3;
+      // pr = fl(fl(bp cp) / 250000), bp = 500 exp(-a2 / 2), cp = 500 exp(-a3 / 2): bp rounds to 0 from a2 > 1490.27 on
+      // (exp(-745.13) = 2^-1075, half the smallest subnormal), the quotient from a2 + a3 > 1490.27 on.  Outside the margins
+      // below the answer is certain; inside (a strip 2.5-3.2 wide) the probability is evaluated as the reference does
+      const bool nonneg = fmin(num2, num3) >= 0.0;  // indefinite covariances, NaN: false
+      weird |= valid && (!sane || (angle_ok && !nonneg));
+      const double amax = fmax(a2hi, a3hi);
+      const bool sure_pos = angle_ok && nonneg && fmax(key, amax) < 1489.0;
+      const bool sure_zero = !angle_ok || fmax(key, amax - ln2) > 1491.5;
+      positive = valid && sure_pos;
+      const bool edge = valid && !sure_pos && !sure_zero;
+      if (__ballot(edge) != 0ull) {  // wave-uniform, rare
+        if (edge) {
+          double d2 = det2, d3 = det3;
+          asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
+          positive = pr_from_parts(d2, d3, num2, num3) > 0.0;
+        }
       }
+      pub[(e == 0xFFFFu) ? dump : e] = positive ? key : pub_inf();  // (an empty slot's entry field is 0xFFFF)
+    } else {
+      weird |= valid && !sane;
+      pub[(e == 0xFFFFu) ? dump : e] = pub_inf();
     }
-    pub[e == 0xFFFFu ? dump : e] = positive ? key : pub_inf();  // (an empty slot's entry field is 0xFFFF)
     any[positive ? t : anydump] = 1;
     q.st |= positive ? 1u : 0u;
     pub_rotate(q);
@@ -481,8 +520,9 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
 // Diagnostic build only (-DPK_STAMPS): per-phase cycle sums of k_step_pub (slots 48.. of pk_debug_stamps).
 #ifdef PK_STAMPS
 __device__ unsigned long long pk_pstamp_acc[16];
-#define PK_PSTAMP(slot, a, b) \
-  if ((threadIdx.x & 63) == 0) atomicAdd(&pk_pstamp_acc[slot], (b) - (a));
+// (summed in scalar registers, one atomic per wave and slot at the very end: an atomic per stamp put 2 048 waves in a
+// queue for sixteen addresses and, the vector memory counter being one in-order counter, every row behind them)
+#define PK_PSTAMP(slot, a, b) pst[slot] += (b) - (a);
 void debug_read_pub_stamps(unsigned long long* out, bool reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_pstamp_acc), sizeof(unsigned long long) * 16);
@@ -559,6 +599,9 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
 
   int64_t prev = -1;  // the particle whose partial sums wait in red[] (-1: none, or it went to the general kernels)
   int cur = 0;        // parity of the particle: which any[] / flag / red[] it uses
+#ifdef PK_STAMPS
+  unsigned long long pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
     // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
     // occupy registers for the whole kernel)
@@ -616,6 +659,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
     S[2 * q].field = v.x;                \
     S[2 * q + 1].field = v.y;            \
   }
+        // (pair by pair, means before covariance rows: the first pair's gates and verdicts are worked out while the second
+        // pair's rows are still on their way -- the vector memory counter retires in order)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
           PK_PUB_LOAD(mx, F_MX)
@@ -623,10 +668,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
           PK_PUB_LOAD(mr, F_MR)
           PK_PUB_LOAD(mg, F_MG)
           PK_PUB_LOAD(mb, F_MB)
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
+          asm volatile("" ::: "memory");
           PK_PUB_LOAD(pxx, F_PXX)
           PK_PUB_LOAD(pxy, F_PXY)
           PK_PUB_LOAD(pyy, F_PYY)
@@ -639,29 +681,37 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
           const Int2 c = *reinterpret_cast<const Int2*>(sc + lbase[q]);
           S[2 * q].count = c.x;
           S[2 * q + 1].count = c.y;
+          asm volatile("" ::: "memory");
         }
 #undef PK_PUB_LOAD
-        asm volatile("" ::: "memory");
         PK_STAMP(s1)
         PK_PSTAMP(0, s0, s1)  // scalars, requests
-        // ---- 2. gates of the four landmarks (means only), failing candidates published at once
-#pragma unroll
-        for (int i = 0; i < 2 * NP; ++i) {
-          Q[i] = PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};
-          pse[i] = 0.0;
-          if (PK_PUB_ABLATE < 4 && 2 * kPubThreads * (i >> 1) + 2 * tid + (i & 1) < L)
-            pub_gates(Q[i], pse[i], cref[i], ccw[i], cew[i], ex, pub, dump, &wg_flag[cur], S[i].mx, S[i].my, S[i].mr, S[i].mg, S[i].mb, sx, sy, sh);
+        // ---- 2. per pair: gates of its two landmarks (means only; failing candidates published at once), then their verdicts
+        // on the gate-passing blobs (first use of the covariance rows)
+        // (written out per landmark: as nested unrolled loops the slot words were not promoted to registers)
+#define PK_PUB_GATES(i)                                                                                                              \
+  Q[i] = PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};                                                             \
+  pse[i] = 0.0;                                                                                                                      \
+  if (PK_PUB_ABLATE < 4 && 2 * kPubThreads * ((i) >> 1) + 2 * tid + ((i) & 1) < L)                                                    \
+    pub_gates(Q[i], pse[i], cref[i], ccw[i], cew[i], ex, pub, dump, &wg_flag[cur], S[i].mx, S[i].my, S[i].mr, S[i].mg, S[i].mb, sx, sy, sh);
+#define PK_PUB_KEYS(i) \
+  if (PK_PUB_ABLATE < 3) pub_keys(Q[i], S[i], pse[i], ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        PK_PUB_GATES(0)
+        PK_PUB_GATES(1)
+        PK_PUB_KEYS(0)
+        PK_PUB_KEYS(1)
+        if constexpr (NP > 1) {
+          PK_PUB_GATES(2)
+          PK_PUB_GATES(3)
+          PK_PUB_KEYS(2)
+          PK_PUB_KEYS(3)
         }
+#undef PK_PUB_GATES
+#undef PK_PUB_KEYS
         PK_STAMP(s2)
-        PK_PSTAMP(1, s1, s2)  // gates (waits for the candidate records and the means)
-        // ---- 3. verdicts on the gate-passing blobs (first use of the covariance rows)
-#pragma unroll
-        for (int i = 0; i < 2 * NP; ++i)
-          if (PK_PUB_ABLATE < 3) pub_keys(Q[i], S[i], pse[i], ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        PK_PSTAMP(1, s1, s2)  // gates and verdicts
 #ifdef PK_STAMPS
-        PK_STAMP(s3b)
-        s3 = s3b;
-        PK_PSTAMP(2, s2, s3)  // verdicts (waits for the covariance rows)
+        s3 = s2;
 #endif
       }
     }
@@ -770,9 +820,13 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
     PK_PSTAMP(7, s7, s8)  // wave sum
     PK_PSTAMP(8, s0, s8)  // particle
 #ifdef PK_STAMPS
-    if ((tid & 63) == 0) atomicAdd(&pk_pstamp_acc[9], 1ull);
+    pst[9] += 1ull;
 #endif
   }
+#ifdef PK_STAMPS
+  if ((tid0 & 63) == 0)
+    for (int k = 0; k < 10; ++k) atomicAdd(&pk_pstamp_acc[k], pst[k]);
+#endif
 }
 
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
