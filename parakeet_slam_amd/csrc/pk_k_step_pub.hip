@@ -246,171 +246,242 @@ __device__ __forceinline__ void pub_rotate(PubSlots& q) {  // slot 0 goes to the
 
 __device__ __forceinline__ double pub_inf() { return __longlong_as_double(0x7FF0000000000000ll); }
 
-// Gates of one landmark (prkt_core_v2.py:433, :441) against its candidate list: as regs_gates_cand, the records read
-// from the LDS copy of the scan; candidates that fail are published as "not a contender" on the spot (a passing one's entry
-// is overwritten by pub_keys).  dump: the table's spare entry.
-__device__ __forceinline__ void pub_gates(PubSlots& q, double& pse_out, const uint4 ref, const uint4 cw, const uint4 ew,
-                                          const double* ex, double* pub, unsigned dump, int* flag, double mx, double my, double mr,
-                                          double mg, double mb, double sx, double sy, double sh) {
-  const double pse = atan2(my - sy, mx - sx);
-  pse_out = pse;
-  const double eb = pse - sh;  // :408
-  // (written so that a NaN anywhere breaks the margin)
-  const double deb = eb - (double)__uint_as_float(ref.x);  // 2 pi off: the other side of a branch cut, listed too (k_candidates)
-  const bool inside = (fabs(deb) <= kCandBearing || fabs(deb - Consts<double>::two_pi) <= kCandBearing ||
-                       fabs(deb + Consts<double>::two_pi) <= kCandBearing) &&
-                      fabs(mr - (double)__uint_as_float(ref.y)) <= kCandColour &&
-                      fabs(mg - (double)__uint_as_float(ref.z)) <= kCandColour && fabs(mb - (double)__uint_as_float(ref.w)) <= kCandColour;
-  int npass = 0;
-  unsigned s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu, s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
-  float dmin = 3.0e38f;  // colour distance of the blob in slot 0: the best colour match stands in front (pub_keys)
-  unsigned c0 = cw.x, c1 = cw.y, c2 = cw.z, c3 = cw.w;  // the list is filled from the front
-  unsigned e0 = ew.x, e1 = ew.y, e2 = ew.z, e3 = ew.w;
+// Gates (prkt_core_v2.py:433, :441) of the TWO landmarks of a pair against their candidate lists: as regs_gates_cand, the
+// records read from the LDS copy of the scan, two candidates of each landmark per round (four independent chains: with two
+// waves per SIMD the instruction stream itself has to cover the arithmetic and LDS latencies); candidates that fail are
+// published as "not a contender" on the spot (a passing one's entry is overwritten by pub_keys).  dump: the table's spare
+// entry.  has: the landmark exists (lanes beyond the map carry empty lists).
+struct PubGateIn {
+  uint4 ref, cw, ew;
+  double mx, my, mr, mg, mb;
+  bool has;
+};
+__device__ __forceinline__ void pub_gates2(PubSlots (&q)[2], double (&pse_out)[2], const PubGateIn (&in)[2], const double* ex,
+                                           double* pub, unsigned dump, int* flag, double sx, double sy, double sh) {
+  double eb[2];
+  bool inside[2];
+  unsigned c0[2], c1[2], c2[2], c3[2], e0[2], e1[2], e2[2], e3[2];
+  unsigned s0[2], s1[2], s2[2], s3[2];
+  float dmin[2];  // colour distance of the blob in slot 0: the best colour match stands in front (pub_keys)
+  int npass[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const double pse = atan2(in[j].my - sy, in[j].mx - sx);
+    pse_out[j] = pse;
+    eb[j] = pse - sh;  // :408
+    // (written so that a NaN anywhere breaks the margin)
+    const double deb = eb[j] - (double)__uint_as_float(in[j].ref.x);  // 2 pi off: the other side of a branch cut, listed too (k_candidates)
+    inside[j] = (fabs(deb) <= kCandBearing || fabs(deb - Consts<double>::two_pi) <= kCandBearing ||
+                 fabs(deb + Consts<double>::two_pi) <= kCandBearing) &&
+                fabs(in[j].mr - (double)__uint_as_float(in[j].ref.y)) <= kCandColour &&
+                fabs(in[j].mg - (double)__uint_as_float(in[j].ref.z)) <= kCandColour &&
+                fabs(in[j].mb - (double)__uint_as_float(in[j].ref.w)) <= kCandColour;
+    // the list is filled from the front; a landmark beyond the map has none
+    c0[j] = in[j].has ? in[j].cw.x : 0xFFFFFFFFu;
+    c1[j] = in[j].cw.y;
+    c2[j] = in[j].cw.z;
+    c3[j] = in[j].cw.w;
+    e0[j] = in[j].ew.x;
+    e1[j] = in[j].ew.y;
+    e2[j] = in[j].ew.z;
+    e3[j] = in[j].ew.w;
+    s0[j] = s1[j] = s2[j] = s3[j] = 0xFFFFFFFFu;
+    dmin[j] = 3.0e38f;
+    npass[j] = 0;
+  }
 #pragma unroll 1
   for (int k = 0; k < kCandSlots; k += 2) {
-    const unsigned ta = c0 & 0xFFFFu, tb = c0 >> 16;
-    if (__ballot(ta != 0xFFFFu) == 0ull) break;  // wave-uniform
-    const unsigned ea = e0 & 0xFFFFu, eb2 = e0 >> 16;  // (0xFFFF where the blob is: k_cand_entries)
-    c0 = c1;
-    c1 = c2;
-    c2 = c3;
-    c3 = 0xFFFFFFFFu;
-    e0 = e1;
-    e1 = e2;
-    e2 = e3;
-    e3 = 0xFFFFFFFFu;
-    const bool va = ta != 0xFFFFu, vb = tb != 0xFFFFu;
-    const double* ra = ex + 6 * (va ? ta : 0u);
-    const double* rb = ex + 6 * (vb ? tb : 0u);
-    const double2 a01 = *reinterpret_cast<const double2*>(ra);
-    const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
-    const double2 b01 = *reinterpret_cast<const double2*>(rb);
-    const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
-    const double cda = color_distance2(mr, mg, mb, a01.y, a23.x, a23.y), cdb = color_distance2(mr, mg, mb, b01.y, b23.x, b23.y);
-    const bool pa = va && !(fabs(a01.x - eb) > 0.5) && !(fabs(cda) > 300.0);
-    const bool pb = vb && !(fabs(b01.x - eb) > 0.5) && !(fabs(cdb) > 300.0);
-    pub[(pa || ea == 0xFFFFu) ? dump : ea] = pub_inf();
-    pub[(pb || eb2 == 0xFFFFu) ? dump : eb2] = pub_inf();
-    const unsigned wa = ta | (ea << 16), wb = tb | (eb2 << 16);
-    // a passing blob goes to the front when its colour is the closest so far, else behind the front one
-    {
-      const float d = (float)cda;
-      const bool front = pa && d < dmin;
-      s3 = pa ? s2 : s3;
-      s2 = pa ? s1 : s2;
-      s1 = pa ? (front ? s0 : wa) : s1;
-      s0 = front ? wa : s0;
-      dmin = front ? d : dmin;
+    if (__ballot((c0[0] & c0[1] & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: both lists are through
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned ta = c0[j] & 0xFFFFu, tb = c0[j] >> 16;
+      const unsigned ea = e0[j] & 0xFFFFu, eb2 = e0[j] >> 16;  // (0xFFFF where the blob is: k_cand_entries)
+      c0[j] = c1[j];
+      c1[j] = c2[j];
+      c2[j] = c3[j];
+      c3[j] = 0xFFFFFFFFu;
+      e0[j] = e1[j];
+      e1[j] = e2[j];
+      e2[j] = e3[j];
+      e3[j] = 0xFFFFFFFFu;
+      const bool va = ta != 0xFFFFu, vb = tb != 0xFFFFu;
+      const double* ra = ex + 6 * (va ? ta : 0u);
+      const double* rb = ex + 6 * (vb ? tb : 0u);
+      const double2 a01 = *reinterpret_cast<const double2*>(ra);
+      const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
+      const double2 b01 = *reinterpret_cast<const double2*>(rb);
+      const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
+      const double cda = color_distance2(in[j].mr, in[j].mg, in[j].mb, a01.y, a23.x, a23.y);
+      const double cdb = color_distance2(in[j].mr, in[j].mg, in[j].mb, b01.y, b23.x, b23.y);
+      const bool pa = va && !(fabs(a01.x - eb[j]) > 0.5) && !(fabs(cda) > 300.0);
+      const bool pb = vb && !(fabs(b01.x - eb[j]) > 0.5) && !(fabs(cdb) > 300.0);
+      pub[(pa || ea == 0xFFFFu) ? dump : ea] = pub_inf();
+      pub[(pb || eb2 == 0xFFFFu) ? dump : eb2] = pub_inf();
+      const unsigned wa = ta | (ea << 16), wb = tb | (eb2 << 16);
+      // a passing blob goes to the front when its colour is the closest so far, else behind the front one
+      {
+        const float d = (float)cda;
+        const bool front = pa && d < dmin[j];
+        s3[j] = pa ? s2[j] : s3[j];
+        s2[j] = pa ? s1[j] : s2[j];
+        s1[j] = pa ? (front ? s0[j] : wa) : s1[j];
+        s0[j] = front ? wa : s0[j];
+        dmin[j] = front ? d : dmin[j];
+      }
+      {
+        const float d = (float)cdb;
+        const bool front = pb && d < dmin[j];
+        s3[j] = pb ? s2[j] : s3[j];
+        s2[j] = pb ? s1[j] : s2[j];
+        s1[j] = pb ? (front ? s0[j] : wb) : s1[j];
+        s0[j] = front ? wb : s0[j];
+        dmin[j] = front ? d : dmin[j];
+      }
+      npass[j] += (pa ? 1 : 0) + (pb ? 1 : 0);
     }
-    {
-      const float d = (float)cdb;
-      const bool front = pb && d < dmin;
-      s3 = pb ? s2 : s3;
-      s2 = pb ? s1 : s2;
-      s1 = pb ? (front ? s0 : wb) : s1;
-      s0 = front ? wb : s0;
-      dmin = front ? d : dmin;
-    }
-    npass += (pa ? 1 : 0) + (pb ? 1 : 0);
   }
-  if (!inside || npass > kPubSlots) *flag = 1;
-  q.s0 = s0;
-  q.s1 = s1;
-  q.s2 = s2;
-  q.s3 = s3;
-  q.st = 0u;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (in[j].has && (!inside[j] || npass[j] > kPubSlots)) *flag = 1;
+    q[j].s0 = s0[j];
+    q[j].s1 = s1[j];
+    q[j].s2 = s2[j];
+    q[j].s3 = s3[j];
+    q[j].st = 0u;
+  }
 }
 
-// Verdicts of one landmark on its gate-passing blobs: published for the blobs other landmarks list too, any[t] = 1 where
-// the probability is > 0 (the blob will be matched by somebody: no 0.1 factor, :94-95).  any[anydump]: a byte nobody reads.
-__device__ __forceinline__ void pub_keys(PubSlots& q, const Landmark<double>& lm, double pse, const double* ex, double* pub,
-                                         unsigned dump, unsigned char* any, unsigned anydump, int* flag, double sx, double sy) {
-  if (__ballot((q.s0 & 0xFFFFu) != 0xFFFFu) == 0ull) return;  // wave-uniform: nobody's landmark passes a blob
-  const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
-  double det3;
-  const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
-  // (determinants within 1e-20 ... 1e60: then log det >= -46, and a pair with a subnormal factor -- a2 or a3 beyond 1400 --
-  // has a key beyond 1350: the settling tells fragile winners by their key alone)
-  const bool sane = det2 > 1e-20 && det2 < 1e60 && det3 > 1e-20 && det3 < 1e60;  // NaN: false
-  bool weird = false;
-  // 1 / det to a few ulp (v_rcp_f64 and two Newton steps: the full division sequence is twice as long; the keys are
-  // compared with each other only, all made the same way)
-  auto recip = [](double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
-  };
-  const double r2 = recip(det2), r3 = recip(det3);
-  // log det = (e + log2 m) ln 2 with m in [0.5, 1): bounded above by e ln 2, below by (e - 1) ln 2 -- all the underflow
-  // tests need of the two logs; the key itself takes ONE log, of the product
-  int e2i, e3i;
-  (void)frexp(det2, &e2i);
-  (void)frexp(det3, &e3i);
+// Verdicts of the two landmarks of a pair on their gate-passing blobs: published for the blobs other landmarks list too,
+// any[t] = 1 where the probability is > 0 (the blob will be matched by somebody: no 0.1 factor, :94-95).  any[anydump]: a
+// byte nobody reads.  One slot of each landmark per round, side by side (two independent chains).
+__device__ __forceinline__ double pub_recip(double x) {
+  // 1 / x to a few ulp (v_rcp_f64 and two Newton steps: the full division sequence is twice as long; the keys are compared
+  // with each other only, all made the same way)
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ void pub_keys2(PubSlots (&q)[2], const Landmark<double>& lmA, const Landmark<double>& lmB,
+                                          const double (&pse)[2], const double* ex, double* pub, unsigned dump, unsigned char* any,
+                                          unsigned anydump, int* flag, double sx, double sy) {
+  if (__ballot(((q[0].s0 & q[1].s0) & 0xFFFFu) != 0xFFFFu) == 0ull) return;  // wave-uniform: nobody's landmark passes a blob
   constexpr double ln2 = 0.69314718055994530942;
-  const double a2base = 2.0 * Consts<double>::log_two_pi + (double)e2i * ln2;  // >= 2 log 2pi + log det2
-  const double a3base = 3.0 * Consts<double>::log_two_pi + (double)e3i * ln2;
-  const double kbase = 5.0 * Consts<double>::log_two_pi + log_few_ulp(det2 * det3);
-  // A colour block that is certainly positive definite (Sylvester) has d' C^-1 d >= |d|^2 / lmax(C), and lmax(C) is at most
-  // the largest absolute row sum (Gershgorin): with the position term >= 0 that bounds the key from below by
-  // kbase + |d|^2 / rowmax, and a blob whose bound lies beyond the underflow edge has probability 0 whatever the rest says.  Once a landmark has been seen a few times its colour block is tight
-  // and every look-alike's blob ends here: when that holds for all lanes of the wave the round is skipped
-  // (both blocks positive definite: adj3.f = crr cgg - crg^2, the determinants > 0 are part of sane)
-  const bool pd3 = sane && lm.crr > 0.0 && adj3.f > 0.0 && lm.pxx > 0.0;
-  const double itr3 = pd3 ? recip(fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))),
+  const Landmark<double>* lmp[2] = {&lmA, &lmB};
+  double det2[2], det3[2], r2[2], r3[2], a2base[2], a3base[2], kbase[2], itr3[2];
+  Sym3<double> adj3[2];
+  bool sane[2], pd3[2];
+  bool weird = false;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const Landmark<double>& lm = *lmp[j];
+    det2[j] = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+    adj3[j] = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3[j]);
+    // (determinants within 1e-20 ... 1e60: then log det >= -46, and a pair with a subnormal factor -- a2 or a3 beyond 1400
+    // -- has a key beyond 1350: the settling tells fragile winners by their key alone)
+    sane[j] = det2[j] > 1e-20 && det2[j] < 1e60 && det3[j] > 1e-20 && det3[j] < 1e60;  // NaN: false
+    r2[j] = pub_recip(det2[j]);
+    r3[j] = pub_recip(det3[j]);
+    // log det = (e + log2 m) ln 2 with m in [0.5, 1): bounded above by e ln 2, below by (e - 1) ln 2 -- all the underflow
+    // tests need of the two logs; the key itself takes ONE log, of the product
+    int e2i, e3i;
+    (void)frexp(det2[j], &e2i);
+    (void)frexp(det3[j], &e3i);
+    a2base[j] = 2.0 * Consts<double>::log_two_pi + (double)e2i * ln2;  // >= 2 log 2pi + log det2
+    a3base[j] = 3.0 * Consts<double>::log_two_pi + (double)e3i * ln2;
+    kbase[j] = 5.0 * Consts<double>::log_two_pi + log_few_ulp(det2[j] * det3[j]);
+    // A colour block that is certainly positive definite (Sylvester) has d' C^-1 d >= |d|^2 / lmax(C), and lmax(C) is at
+    // most the largest absolute row sum (Gershgorin): with the position term >= 0 that bounds the key from below by
+    // kbase + |d|^2 / rowmax, and a blob whose bound lies beyond the underflow edge has probability 0 whatever the rest
+    // says.  Once a landmark has been seen a few times its colour block is tight and every look-alike's blob ends here:
+    // when that holds for all lanes of the wave the round's arithmetic is skipped
+    // (both blocks positive definite: adj3.f = crr cgg - crg^2, the determinants > 0 are part of sane)
+    pd3[j] = sane[j] && lm.crr > 0.0 && adj3[j].f > 0.0 && lm.pxx > 0.0;
+    itr3[j] = pd3[j] ? pub_recip(fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))),
                                        lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
-                          : 0.0;
+                     : 0.0;
+  }
   int done = 0;
 #pragma unroll 1
   for (; done < kPubSlots; ++done) {
-    const unsigned t = q.s0 & 0xFFFFu, e = q.s0 >> 16;
-    const bool valid = t != 0xFFFFu;
-    if (__ballot(valid) == 0ull) break;  // wave-uniform
-    const double* rec = ex + 6 * (valid ? t : 0u);
-    const double2 z01 = *reinterpret_cast<const double2*>(rec);
-    const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
-    const double d1 = z01.y - lm.mr, d2c = z23.x - lm.mg, d3c = z23.y - lm.mb;
-    const bool far = pd3 && kbase + (d1 * d1 + d2c * d2c + d3c * d3c) * itr3 > 1492.0;  // key > 1492: probability 0
-    bool positive = false;
-    if (__ballot(valid && !far) != 0ull) {  // wave-uniform
-      const double2 dir = *reinterpret_cast<const double2*>(rec + 4);
-      // prob_position_match :457-494, prob_color_match :524-544
-      const bool angle_ok = !(fabs(pse - z01.x) > Consts<double>::half_pi);  // :473-475
-      double nx, ny;
-      closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
-      const double ex_ = nx - lm.mx, ey = ny - lm.my;
-      const double num2 = lm.pyy * ex_ * ex_ - 2.0 * lm.pxy * ex_ * ey + lm.pxx * ey * ey;  // maha2 = num2 / det2
-      const double num3 = sym3_quad(adj3, d1, d2c, d3c);                                     // maha3 = num3 / det3
-      const double maha2 = num2 * r2, maha3 = num3 * r3;
-      const double key = kbase + (maha2 + maha3);
-      const double a2hi = a2base + maha2, a3hi = a3base + maha3;
-      // pr = fl(fl(bp cp) / 250000), bp = 500 exp(-a2 / 2), cp = 500 exp(-a3 / 2): bp rounds to 0 from a2 > 1490.27 on
-      // (exp(-745.13) = 2^-1075, half the smallest subnormal), the quotient from a2 + a3 > 1490.27 on.  Outside the margins
-      // below the answer is certain; inside (a strip 2.5-3.2 wide) the probability is evaluated as the reference does
-      const bool nonneg = fmin(num2, num3) >= 0.0;  // indefinite covariances, NaN: false
-      weird |= valid && (!sane || (angle_ok && !nonneg));
-      const double amax = fmax(a2hi, a3hi);
-      const bool sure_pos = angle_ok && nonneg && fmax(key, amax) < 1489.0;
-      const bool sure_zero = !angle_ok || fmax(key, amax - ln2) > 1491.5;
-      positive = valid && sure_pos;
-      const bool edge = valid && !sure_pos && !sure_zero;
-      if (__ballot(edge) != 0ull) {  // wave-uniform, rare
-        if (edge) {
-          double d2 = det2, d3 = det3;
-          asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
-          positive = pr_from_parts(d2, d3, num2, num3) > 0.0;
-        }
-      }
-      pub[(e == 0xFFFFu) ? dump : e] = positive ? key : pub_inf();  // (an empty slot's entry field is 0xFFFF)
-    } else {
-      weird |= valid && !sane;
-      pub[(e == 0xFFFFu) ? dump : e] = pub_inf();
+    if (__ballot(((q[0].s0 & q[1].s0) & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: both landmarks are through
+    unsigned t[2], e[2];
+    bool valid[2], far[2], positive[2];
+    double2 z01[2], z23[2];
+    double d1[2], d2c[2], d3c[2];
+    const double* rec[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const Landmark<double>& lm = *lmp[j];
+      t[j] = q[j].s0 & 0xFFFFu;
+      e[j] = q[j].s0 >> 16;
+      valid[j] = t[j] != 0xFFFFu;
+      rec[j] = ex + 6 * (valid[j] ? t[j] : 0u);
+      z01[j] = *reinterpret_cast<const double2*>(rec[j]);
+      z23[j] = *reinterpret_cast<const double2*>(rec[j] + 2);
+      d1[j] = z01[j].y - lm.mr;
+      d2c[j] = z23[j].x - lm.mg;
+      d3c[j] = z23[j].y - lm.mb;
+      far[j] = pd3[j] && kbase[j] + (d1[j] * d1[j] + d2c[j] * d2c[j] + d3c[j] * d3c[j]) * itr3[j] > 1492.0;  // key > 1492: probability 0
+      positive[j] = false;
     }
-    any[positive ? t : anydump] = 1;
-    q.st |= positive ? 1u : 0u;
-    pub_rotate(q);
+    if (__ballot((valid[0] && !far[0]) || (valid[1] && !far[1])) != 0ull) {  // wave-uniform
+      double key[2], num2[2], num3[2];
+      bool edge[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const Landmark<double>& lm = *lmp[j];
+        const double2 dir = *reinterpret_cast<const double2*>(rec[j] + 4);
+        // prob_position_match :457-494, prob_color_match :524-544
+        const bool angle_ok = !(fabs(pse[j] - z01[j].x) > Consts<double>::half_pi);  // :473-475
+        double nx, ny;
+        closest_point(lm.mx, lm.my, sx, sy, dir.x, dir.y, nx, ny);
+        const double ex_ = nx - lm.mx, ey = ny - lm.my;
+        num2[j] = lm.pyy * ex_ * ex_ - 2.0 * lm.pxy * ex_ * ey + lm.pxx * ey * ey;  // maha2 = num2 / det2
+        num3[j] = sym3_quad(adj3[j], d1[j], d2c[j], d3c[j]);                         // maha3 = num3 / det3
+        const double maha2 = num2[j] * r2[j], maha3 = num3[j] * r3[j];
+        key[j] = kbase[j] + (maha2 + maha3);
+        const double a2hi = a2base[j] + maha2, a3hi = a3base[j] + maha3;
+        // pr = fl(fl(bp cp) / 250000), bp = 500 exp(-a2 / 2), cp = 500 exp(-a3 / 2): bp rounds to 0 from a2 > 1490.27 on
+        // (exp(-745.13) = 2^-1075, half the smallest subnormal), the quotient from a2 + a3 > 1490.27 on.  Outside the
+        // margins below the answer is certain; inside (a strip 2.5-3.2 wide) the probability is evaluated as the reference does
+        const bool nonneg = fmin(num2[j], num3[j]) >= 0.0;  // indefinite covariances, NaN: false
+        weird |= valid[j] && (!sane[j] || (angle_ok && !nonneg));
+        const double amax = fmax(a2hi, a3hi);
+        const bool sure_pos = angle_ok && nonneg && fmax(key[j], amax) < 1489.0;
+        const bool sure_zero = !angle_ok || fmax(key[j], amax - ln2) > 1491.5;
+        positive[j] = valid[j] && sure_pos;
+        edge[j] = valid[j] && !sure_pos && !sure_zero;
+      }
+      if (__ballot(edge[0] || edge[1]) != 0ull) {  // wave-uniform, rare
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (edge[j]) {
+            double d2 = det2[j], d3 = det3[j];
+            asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
+            positive[j] = pr_from_parts(d2, d3, num2[j], num3[j]) > 0.0;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pub[(e[j] == 0xFFFFu) ? dump : e[j]] = positive[j] ? key[j] : pub_inf();  // (an empty slot's entry field is 0xFFFF)
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        weird |= valid[j] && !sane[j];
+        pub[(e[j] == 0xFFFFu) ? dump : e[j]] = pub_inf();
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      any[positive[j] ? t[j] : anydump] = 1;
+      q[j].st |= positive[j] ? 1u : 0u;
+      pub_rotate(q[j]);
+    }
   }
-  for (; done < kPubSlots; ++done) pub_rotate(q);  // wave-uniform trip count: back to the original order
+  for (; done < kPubSlots; ++done) {  // wave-uniform trip count: back to the original order
+    pub_rotate(q[0]);
+    pub_rotate(q[1]);
+  }
   if (weird) *flag = 1;
 }
 
@@ -635,22 +706,21 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) lbase[q] = min(2 * kPubThreads * q + 2 * tid, Lp - 2);
         // ---- 1. requests: candidate records (L2), the means of all four landmarks, then the covariance rows
+        // (the first pair's now, in front of the rows; the second pair's behind the first pair's verdicts -- by then every row has
+        // arrived, and twelve registers fewer are live while the verdicts are worked out)
         uint4 cref[2 * NP], ccw[2 * NP], cew[2 * NP];
-        {
-          const uint4* cand = R->cand;
-          const uint4* erec = R->erec;
-#pragma unroll
-          for (int q = 0; q < NP; ++q) {
-            const uint4* cr = cand + 2 * (size_t)lbase[q];
-            const uint4* er = erec + lbase[q];
-            cref[2 * q] = cr[0];
-            ccw[2 * q] = cr[1];
-            cref[2 * q + 1] = cr[2];
-            ccw[2 * q + 1] = cr[3];
-            cew[2 * q] = er[0];
-            cew[2 * q + 1] = er[1];
-          }
-        }
+        auto request_cand = [&](int q) {
+          PubArgsPtr R2 = pub_args_now(rp);
+          const uint4* cr = R2->cand + 2 * (size_t)lbase[q];
+          const uint4* er = R2->erec + lbase[q];
+          cref[2 * q] = cr[0];
+          ccw[2 * q] = cr[1];
+          cref[2 * q + 1] = cr[2];
+          ccw[2 * q + 1] = cr[3];
+          cew[2 * q] = er[0];
+          cew[2 * q + 1] = er[1];
+        };
+        request_cand(0);
         asm volatile("" ::: "memory");
         auto row2 = [&](int f, int lb) { return *reinterpret_cast<const Double2*>(sf + (size_t)f * Lp + lb); };
 #define PK_PUB_LOAD(field, F)            \
@@ -688,26 +758,30 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
         PK_PSTAMP(0, s0, s1)  // scalars, requests
         // ---- 2. per pair: gates of its two landmarks (means only; failing candidates published at once), then their verdicts
         // on the gate-passing blobs (first use of the covariance rows)
-        // (written out per landmark: as nested unrolled loops the slot words were not promoted to registers)
-#define PK_PUB_GATES(i)                                                                                                              \
-  Q[i] = PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u};                                                             \
-  pse[i] = 0.0;                                                                                                                      \
-  if (PK_PUB_ABLATE < 4 && 2 * kPubThreads * ((i) >> 1) + 2 * tid + ((i) & 1) < L)                                                    \
-    pub_gates(Q[i], pse[i], cref[i], ccw[i], cew[i], ex, pub, dump, &wg_flag[cur], S[i].mx, S[i].my, S[i].mr, S[i].mg, S[i].mb, sx, sy, sh);
-#define PK_PUB_KEYS(i) \
-  if (PK_PUB_ABLATE < 3) pub_keys(Q[i], S[i], pse[i], ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
-        PK_PUB_GATES(0)
-        PK_PUB_GATES(1)
-        PK_PUB_KEYS(0)
-        PK_PUB_KEYS(1)
+        // (written out per pair: as nested unrolled loops the slot words were not promoted to registers)
+#define PK_PUB_PAIR(q)                                                                                                           \
+  {                                                                                                                              \
+    const int l0 = 2 * kPubThreads * (q) + 2 * tid;                                                                              \
+    const PubGateIn gi[2] = {{cref[2 * (q)], ccw[2 * (q)], cew[2 * (q)], S[2 * (q)].mx, S[2 * (q)].my, S[2 * (q)].mr, S[2 * (q)].mg, \
+                              S[2 * (q)].mb, l0 < L},                                                                            \
+                             {cref[2 * (q) + 1], ccw[2 * (q) + 1], cew[2 * (q) + 1], S[2 * (q) + 1].mx, S[2 * (q) + 1].my,         \
+                              S[2 * (q) + 1].mr, S[2 * (q) + 1].mg, S[2 * (q) + 1].mb, l0 + 1 < L}};                               \
+    PubSlots qq[2] = {PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u},                                            \
+                      PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}};                                           \
+    double pp[2] = {0.0, 0.0};                                                                                                   \
+    if (PK_PUB_ABLATE < 4) pub_gates2(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);                                      \
+    if (PK_PUB_ABLATE < 3) pub_keys2(qq, S[2 * (q)], S[2 * (q) + 1], pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);     \
+    Q[2 * (q)] = qq[0];                                                                                                          \
+    Q[2 * (q) + 1] = qq[1];                                                                                                      \
+    pse[2 * (q)] = pp[0];                                                                                                        \
+    pse[2 * (q) + 1] = pp[1];                                                                                                    \
+  }
+        PK_PUB_PAIR(0)
         if constexpr (NP > 1) {
-          PK_PUB_GATES(2)
-          PK_PUB_GATES(3)
-          PK_PUB_KEYS(2)
-          PK_PUB_KEYS(3)
+          request_cand(NP - 1);
+          PK_PUB_PAIR(1)
         }
-#undef PK_PUB_GATES
-#undef PK_PUB_KEYS
+#undef PK_PUB_PAIR
         PK_STAMP(s2)
         PK_PSTAMP(1, s1, s2)  // gates and verdicts
 #ifdef PK_STAMPS
