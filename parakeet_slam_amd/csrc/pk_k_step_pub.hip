@@ -547,7 +547,20 @@ __device__ __forceinline__ void pub_take(PubSlots& q, const double* pub, unsigne
 __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
                                             Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
   double acc = 0.0;
-  if (__ballot((q.st & 0x4444u) != 0u) == 0ull) return acc;  // wave-uniform
+  const unsigned tk = q.st & 0x4444u;
+  if (__ballot(tk != 0u) == 0ull) return acc;  // wave-uniform
+  if (__ballot((tk & (tk - 1u)) != 0u) == 0ull) {
+    // wave-uniform, the usual case: no landmark takes more than one blob -- no scan-order sort, no loop
+    if (tk != 0u) {
+      const unsigned w = (tk & 0x0004u) ? q.s0 : (tk & 0x0040u) ? q.s1 : (tk & 0x0400u) ? q.s2 : q.s3;
+      const double* rec = ex + 6 * (w & 0xFFFFu);
+      const double2 z01 = *reinterpret_cast<const double2*>(rec);
+      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+      BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+      acc = ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, &pse);
+    }
+    return acc;
+  }
   const unsigned sw[kPubSlots] = {q.s0, q.s1, q.s2, q.s3};
   unsigned key[kPubSlots];
 #pragma unroll
@@ -858,11 +871,19 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
           if (PK_PUB_ABLATE < 1) acc += pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
         }
         if (l0 < Lp) {
+#ifdef PK_PUB_PLAIN_STORES  // diagnostic variant
+#define PK_PUB_STORE(field, F)                                               \
+  {                                                                          \
+    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                  \
+    *reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0) = v;               \
+  }
+#else
 #define PK_PUB_STORE(field, F)                                                             \
   {                                                                                        \
     const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                \
     __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
   }
+#endif
           PK_PUB_STORE(mx, F_MX)
           PK_PUB_STORE(my, F_MY)
           PK_PUB_STORE(mr, F_MR)
