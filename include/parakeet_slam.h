@@ -112,6 +112,13 @@ int64_t pk_device_bytes(const pk_filter* f);
  *   "regs_step"    = 1 (default: with "fast_observe" = 1, 512 < L <= 2048 and scan tables that fit LDS,
  *                    gates + settling + EKF update of a particle run in ONE pass, k_step_regs, with the
  *                    particle's whole map in registers) or 0 (k_assoc_grid hand-off + k_observe_sweep);
+ *   "pub_step"     = 1 (default: the register route settles contested blobs by static publish / subscribe -- k_step_pub,
+ *                    the inverse candidate lists lay a per-scan table out in LDS, every landmark publishes its verdicts
+ *                    there, one lane per contested blob picks the winner; two landmark pairs per lane, 512 lanes -- while
+ *                    the table fits LDS and no candidate list overflows; decided per scan on the device,
+ *                    pk_observe_published) or 0 (k_step_regs: per-blob counters, probability queue, bids);
+ *   "pub_entry_limit" = 0 (default: what LDS holds) or n: treat the publish table as n entries small (tests: scans
+ *                    whose table does not fit fall back to k_step_regs);
  *   "owner_step"   = 0, 1 (maps of more than 512 landmarks) or 2 (every map): k_step_owner -- candidate lists of a
  *                    reference particle in both directions, every landmark settles its own blobs against its rivals,
  *                    no synchronisation between the landmarks of a particle;

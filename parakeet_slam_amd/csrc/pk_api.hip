@@ -143,6 +143,7 @@ struct pk_filter {
   uint4* cand_dev = nullptr;  // [Lp][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
+  int pub_entry_limit = 0;  // > 0: the publish table is treated as this small (tests: scans whose table "does not fit" fall back to k_step_regs)
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
   unsigned* glist_dev = nullptr; // [bcand_cap + 1] the same for the blobs several landmarks list, compacted; then their number
@@ -1296,7 +1297,8 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
   f->pub_ecap = 0;
   if (al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) {
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
-    const int ecap = f->pub_step ? step_pub_entry_capacity(B) : 0;
+    int ecap = f->pub_step ? step_pub_entry_capacity(B) : 0;
+    if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     if (ecap > 0) {
       if (!f->erec_dev && (rc = dev_alloc(f, &f->erec_dev, (size_t)f->d.lay.Lp))) return rc;
       if ((rc = ensure_inverse_lists(f, B))) return rc;
@@ -1682,6 +1684,11 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "pub_step")) {
     f->pub_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "pub_entry_limit")) {
+    if (value < 0 || value > 65534) return fail(PK_ERR_INVALID, "pub_entry_limit: 0 (what LDS holds) .. 65534");
+    f->pub_entry_limit = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "regs_step")) {

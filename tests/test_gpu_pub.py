@@ -1,0 +1,216 @@
+"""GPU: k_step_pub -- the register route (512 < L <= 2048) with contested blobs settled by static publish / subscribe
+(match_one's argmax, prkt_core_v2.py:353-381, strict '>' from 0.0 and the earliest landmark on a tie).  The kernel
+compares KEYS (-2 log probability) instead of probabilities and hands a particle to the general kernels wherever keys
+cannot be trusted to order like probabilities: the cases below sit exactly there."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.fastslam_oracle import OracleFilter, synthetic_scan, synthetic_world
+
+pytestmark = pytest.mark.gpu
+
+
+def run(lib, means, covs, poses, blobs, opts=None, immutable=None):
+    L, P = means.shape[0], poses.shape[0]
+    f = lib.DeviceFilter(P, L)
+    for k, v in (opts or {}).items():
+        f.set_option(k, v)
+    f.upload_map(means, covs.reshape(L, 25), immutable)
+    f.upload_poses(poses)
+    if (opts or {}).get("fast_observe", 1) == 0:
+        ids = f.observe(blobs, return_ids=True)
+    else:
+        ids = None
+        f.observe(blobs)
+    out = dict(logw=f.download_log_weights(), maps=f.download_landmarks(), route=f.observe_route(), flagged=f.observe_flagged()[0],
+               published=f.observe_published(), ids=ids)
+    f.close()
+    return out
+
+
+def poses_around(rs, P, spread=0.05):
+    poses = np.zeros((P, 4))
+    poses[:, 0] = rs.normal(0, spread, P)
+    poses[:, 1] = rs.normal(0, spread, P)
+    poses[:, 2] = rs.normal(0, 0.01, P)
+    poses[:, 3] = 1.0
+    return poses
+
+
+def same_state(a, b, logw_rtol=1e-12):
+    assert np.allclose(a["logw"], b["logw"], rtol=logw_rtol, atol=1e-9)
+    for x, y in zip(a["maps"], b["maps"]):
+        assert np.array_equal(x, y)  # same update function on the same inputs: bit for bit
+
+
+def against_oracle(got, means, covs, poses, blobs, immutable=None):
+    o = OracleFilter(poses.shape[0], means, covs, immutable)
+    o.x, o.y, o.h = poses[:, 0].copy(), poses[:, 1].copy(), poses[:, 2].copy()
+    o.observe(blobs)
+    m, c, k = got["maps"]
+    assert np.allclose(got["logw"], o.logw, rtol=1e-10, atol=1e-9)
+    assert np.allclose(m, o.mean, rtol=1e-10, atol=1e-12) and np.allclose(c, o.cov, rtol=1e-9, atol=1e-13) and np.array_equal(k, o.count)
+
+
+@pytest.mark.parametrize("L,P", [(700, 6), (1024, 4), (1026, 4), (2000, 3), (2048, 3)])
+def test_pub_is_the_default_instance_and_agrees_with_regs_and_the_general_kernels(lib, L, P):
+    rs = np.random.RandomState(900 + L)
+    means, covs = synthetic_world(L)
+    n = len(means[3::7])
+    means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))  # look-alikes three bearings apart: contested blobs
+    imm = (rs.uniform(size=L) < 0.1).astype(np.uint8)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))[rs.permutation(L)]
+    poses = poses_around(rs, P, 0.2)
+    pub = run(lib, means, covs, poses, blobs, immutable=imm)
+    regs = run(lib, means, covs, poses, blobs, {"pub_step": 0}, immutable=imm)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0}, immutable=imm)
+    assert pub["route"] == "ml_regs" and (pub["published"] or L == 2048)  # (2 048 blobs with look-alikes: the table does not fit LDS)
+    assert regs["route"] == "ml_regs" and not regs["published"]
+    assert pub["flagged"] == regs["flagged"]  # both keep four gate-passing blobs per landmark; some landmarks here pass 5-7
+    same_state(pub, regs)
+    same_state(pub, gen, 1e-11)
+    against_oracle(pub, means, covs, poses, blobs, imm)
+
+
+def test_a_publish_table_that_does_not_fit_leaves_the_scan_to_k_step_regs(lib):
+    rs = np.random.RandomState(7)
+    L = 900
+    means, covs = synthetic_world(L)
+    n = len(means[3::7])
+    means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    poses = poses_around(rs, 4, 0.1)
+    small = run(lib, means, covs, poses, blobs, {"pub_entry_limit": 64})
+    full = run(lib, means, covs, poses, blobs)
+    assert full["published"] and not small["published"] and small["route"] == "ml_regs"
+    same_state(small, full)
+
+
+def test_identical_landmarks_tie_and_the_earliest_takes_the_blob(lib):
+    # exact duplicates publish identical keys: a tie, settled by landmark order (:377), nobody flagged
+    rs = np.random.RandomState(21)
+    base, bcov = synthetic_world(1100)
+    means = np.vstack([base, base[:60]])
+    covs = np.vstack([bcov, bcov[:60]])
+    blobs = synthetic_scan(base, (0.01, 0.0, 0.0))
+    poses = poses_around(rs, 5, 0.1)
+    pub = run(lib, means, covs, poses, blobs)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["published"] and pub["flagged"] == 0
+    same_state(pub, gen, 1e-11)
+    m, c, k = pub["maps"]
+    assert (k[:, :60] == 2).all() and (k[:, 1100:] == 0).all()  # the earlier copy took every contested blob
+
+
+def test_keys_too_close_to_call_send_the_particle_to_the_general_kernels(lib):
+    # two landmarks that differ by 1e-6 in one colour mean contest one blob: their keys differ by 4e-12 -- far inside the
+    # 1e-7 margin and not identical -- so every particle is flagged, and the general kernels' probabilities decide
+    rs = np.random.RandomState(3)
+    L = 600
+    means, covs = synthetic_world(L)
+    means = np.vstack([means, means[40:41]])
+    covs = np.vstack([covs, covs[40:41]])
+    means[L, 2] += 1e-6
+    blobs = synthetic_scan(means[:L], (0.0, 0.0, 0.0))
+    poses = poses_around(rs, 6, 0.1)
+    pub = run(lib, means, covs, poses, blobs)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["published"] and pub["flagged"] == 6
+    same_state(pub, gen, 1e-11)
+    against_oracle(pub, means, covs, poses, blobs)
+
+
+@pytest.mark.parametrize("target", [1470.0, 1488.5, 1489.6, 1490.2, 1490.4, 1491.0, 1492.5, 1520.0])
+def test_probabilities_around_the_float64_underflow_edge(lib, target):
+    # one landmark whose own blob is so far off in colour (inside the gate) that its probability lands around the smallest
+    # subnormal: -2 log pr = target.  Positive below 1490.27, zero above; between 1489 and 1491.5 the kernel evaluates the
+    # probability as the reference does.  Matched or not must agree with the general kernels and the oracle.
+    rs = np.random.RandomState(int(target * 10))
+    L = 640
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    P = 4
+    poses = np.zeros((P, 4))
+    poses[:, 3] = 1.0  # on the spot: the position term is 0 for every landmark
+    lm = 17
+    d2 = 200.0  # squared colour distance of landmark 17's blob (gate: 300)
+    # key = 5 log 2pi + log det2 + log det3 + d2 / c with covariances 0.25 I_2 and c I_3
+    kconst = 5.0 * math.log(2.0 * math.pi) + math.log(0.25 * 0.25)
+    lo, hi = 1e-3, 0.25
+    for _ in range(200):  # bisection on c: the key falls as c grows (d2 / c dominates 3 log c)
+        c = 0.5 * (lo + hi)
+        key = kconst + 3.0 * math.log(c) + d2 / c
+        lo, hi = (c, hi) if key > target else (lo, c)
+    covs[lm, 2:, 2:] = np.identity(3) * c
+    blobs[lm, 1] += math.sqrt(d2)
+    blobs[lm, 1:] = np.clip(blobs[lm, 1:], -1e9, 1e9)
+    pub = run(lib, means, covs, poses, blobs)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["published"] and pub["flagged"] == 0
+    same_state(pub, gen, 1e-11)
+    against_oracle(pub, means, covs, poses, blobs)
+    matched = gen["ids"][:, lm] == lm + 1
+    if target <= 1489.0:
+        assert matched.all()
+    if target >= 1491.5:
+        assert not matched.any()
+
+
+def test_a_subnormal_winner_next_to_another_contender_is_left_to_the_general_kernels(lib):
+    # two look-alikes whose probabilities for one blob are both subnormal-small (keys ~1420 and ~1450): keys order such
+    # probabilities only roughly -- the particle is flagged
+    rs = np.random.RandomState(11)
+    L = 640
+    means, covs = synthetic_world(L)
+    means = np.vstack([means, means[30:31]])
+    covs = np.vstack([covs, covs[30:31]])
+    kconst = 5.0 * math.log(2.0 * math.pi) + math.log(0.25 * 0.25)
+    d2 = 150.0
+    for idx, target in ((30, 1420.0), (L, 1450.0)):
+        lo, hi = 1e-3, 0.25
+        for _ in range(200):
+            c = 0.5 * (lo + hi)
+            key = kconst + 3.0 * math.log(c) + d2 / c
+            lo, hi = (c, hi) if key > target else (lo, c)
+        covs[idx, 2:, 2:] = np.identity(3) * c
+    blobs = synthetic_scan(means[:L], (0.0, 0.0, 0.0))
+    blobs[30, 1] += math.sqrt(d2)
+    poses = np.zeros((3, 4))
+    poses[:, 3] = 1.0
+    pub = run(lib, means, covs, poses, blobs)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["published"] and pub["flagged"] == 3
+    same_state(pub, gen, 1e-11)
+    against_oracle(pub, means, covs, poses, blobs)
+
+
+def test_whole_steps_with_resampling_pub_against_regs(lib):
+    # a short run at a register-route map size: ancestors identical, maps bit for bit
+    L, P = 1500, 512
+    means, covs = synthetic_world(L)
+    outs = []
+    for opts in ({}, {"pub_step": 0}):
+        f = lib.DeviceFilter(P, L)
+        for k, v in opts.items():
+            f.set_option(k, v)
+        f.upload_map(means, covs.reshape(L, 25))
+        pose = (0.0, 0.0, 0.0)
+        anc = []
+        from oracle.fastslam_oracle import truth_step
+        for s in range(4):
+            pose = truth_step(pose, 0.2, 0.1, 0.1)
+            blobs = synthetic_scan(means, pose)
+            f.reset_weights()
+            f.motion(0.2, 0.1, 0.1, seed=5, draw=s)
+            f.observe(blobs)
+            anc.append(f.resample(0.37 + 0.1 * s, return_ancestors=True, domain=lib.PK_WEIGHTS_LOG))
+        outs.append((anc, f.download_poses(), f.download_landmarks(), f.observe_published()))
+        f.close()
+    assert outs[0][3] and not outs[1][3]
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][1][:, :3], outs[1][1][:, :3])
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(x, y)
