@@ -83,7 +83,9 @@ ROUTE_KERNEL = {
                 "log-weight; the association kernel is separate)",
     "ml_general": "k_observe<ML general> (fused EKF update + log-weight)",
 }
-ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_regs": "step_regs", "ml_owner": "step_owner",
+ROUTE_KERNEL["ml_regs_pub"] = ("k_step_pub (512 < L <= 2048: a particle's whole map in registers, four landmarks per lane; association gates + "
+                               "contested blobs settled by static publish / subscribe through LDS + EKF update + log-weight in ONE pass over the map)")
+ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_regs": "step_regs", "ml_regs_pub": "step_pub", "ml_owner": "step_owner",
                      "ml_handoff": "observe_ml", "ml_sweep": "observe_sweep"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_UPDATE = 224  # 14 fp64 read + 14 written per particle.landmark
@@ -297,6 +299,36 @@ def timed_steps(filt, lib, P, L, K, W, scans, ws, us, ids, barrier, stride):
     return elapsed, tm, route, one_step
 
 
+def per_step_replay(filt, lib, P, L, means, covs, scans, ws, us, ids, first, last, slow=(44, 62)):
+    """The same trajectory once more, OUTSIDE the headline's timed region, one step at a time with the stream drained
+    around each: wall time per step, particles handed to the fall-back kernels per step.  The timed region itself runs
+    asynchronously and cannot be looked into without disturbing it; the replay is bit-identical (same seeds, same draws).
+    Returns statistics over the trajectory steps [first, last) -- the timed window -- and over the stretch `slow`, where
+    the scene hands the fall-backs the most particles."""
+    filt.upload_map(means, covs.reshape(L, 25))
+    filt.upload_poses(np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (P, 1)))
+    end = min(len(scans), max(last, slow[1] + 1))
+    ms, fl = [], []
+    for s in range(end):
+        filt.synchronize()
+        t0 = time.perf_counter()
+        filt.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, ids=ids, domain=lib.PK_WEIGHTS_LOG)
+        filt.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        fl.append(int(filt.observe_flagged()[0]) if ids is None and hasattr(filt, "observe_flagged") else 0)
+
+    def stats(a, b):
+        a, b = max(a, 0), min(b, end)
+        if b <= a:
+            return None
+        m, f = np.array(ms[a:b]), np.array(fl[a:b])
+        return {"trajectory_steps": [a, b - 1], "ms_mean": float(m.mean()), "ms_p95": float(np.percentile(m, 95)), "ms_max": float(m.max()),
+                "flagged_particles_mean": float(f.mean()), "flagged_particles_max": int(f.max())}
+
+    return {"what": "untimed replay of the same trajectory, one synchronised step at a time (host wall clock around each step)",
+            "timed_window": stats(first, last), "slow_window": stats(slow[0], slow[1] + 1)}
+
+
 def roofline_object(P, L, route, obs_ms, obs_n, stride, K, copy_gbs):
     obs_avg_s = (obs_ms / max(obs_n, 1)) * 1e-3
     alg_bytes = float(P) * L * BYTES_PER_UPDATE
@@ -389,8 +421,9 @@ def main():
     P, L = args.particles, args.landmarks
     K, W = args.steps, args.warmup
     EXTRA = 32  # untimed steps after the timed region (association share, unique sources, supplied-ids route)
-    means, covs, scans = synthetic_inputs(L, K + W + EXTRA)
-    ws = synthetic_controls(K + W + EXTRA)
+    NSC = max(K + W + EXTRA, 64)  # (the per-step replay runs through trajectory step 62)
+    means, covs, scans = synthetic_inputs(L, NSC)
+    ws = synthetic_controls(NSC)
     ids = np.arange(1, L + 1, dtype=np.int32) if args.assoc == "known" else None
     sharded = world > 1 or args.force_sharded
 
@@ -408,13 +441,13 @@ def main():
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
     for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_CAND_LISTS", "PK_OPT_OWNER_STEP",
-                 "PK_OPT_REGS_RETRY", "PK_OPT_SPLIT_RESERVE_CUS"):  # tuning experiments only
+                 "PK_OPT_REGS_RETRY", "PK_OPT_SPLIT_RESERVE_CUS", "PK_OPT_PUB_STEP"):  # tuning experiments only
         if os.environ.get(name):
             filt.set_option(name[7:].lower(), int(os.environ[name]))
     if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only
         filt.set_option("observe_landmarks_per_lane", int(os.environ["PK_OBSERVE_NV"]))
     rnd = random.Random(7)
-    us = [rnd.random() for _ in range(K + W + EXTRA)]
+    us = [rnd.random() for _ in range(NSC)]
 
     def barrier():
         if world > 1:
@@ -448,6 +481,8 @@ def main():
         migrated_bytes = migrated * filt.f.particle_bytes()
     summary = filt.summary()
     flagged = filt.observe_flagged() if hasattr(filt, "observe_flagged") else None
+    if route == "ml_regs" and hasattr(filt, "observe_published") and filt.observe_published():
+        route = "ml_regs_pub"  # which instance of the register route worked on the scans is decided on the device
     # validity probe (untimed): share of the blobs of the last timed scan that the particles, as they
     # stand now, still associate with some landmark (the workload degenerates when this collapses)
     matched = None
@@ -532,6 +567,9 @@ def main():
             "unit": "GB/s",
             "traffic": measured_traffic(P, L, "observe_known"),
         }
+    replay = None
+    if not sharded and not args.no_probes:
+        replay = per_step_replay(filt, _lib, P, L, means, covs, scans, ws, us, ids, W, W + K)
     filt.close()
     del filt
 
@@ -584,6 +622,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    backend_name = "none"
+    if sharded:
+        import torch.distributed as dist
+
+        backend_name = "%s%s" % (dist.get_backend(), " (= RCCL over xGMI)" if dist.get_backend() == "nccl" else "")
     if rank == 0:
         total_updates = float(P) * world * L * K
         obs_ms, obs_n = tm["observe"]
@@ -634,8 +677,8 @@ def main():
                 "blobs": L,
                 "assoc": args.assoc,
                 "global_particles": P * world,
-                "parallelism": "particles sharded over %d GPU(s), one process per GPU; RCCL all-reduce(max) + "
-                "all-gather(block weight totals) + all-to-all(migrating particles) per resample" % world if sharded
+                "parallelism": "particles sharded over %d GPU(s), one process per GPU; backend %s: all-reduce(max) + "
+                "all-gather(block weight totals) + all-to-all(migrating particles) per resample" % (world, backend_name) if sharded
                 else "single GPU",
             },
             "roofline": roof,
@@ -643,6 +686,10 @@ def main():
             "summary": list(summary),
             "matched_fraction_last_timed_scan": matched,  # validity: the scans stayed matchable to the end
         }
+        if replay is not None:
+            out["per_step"] = replay
+            if replay.get("slow_window"):
+                out["slow_window_ms_per_step"] = replay["slow_window"]["ms_mean"]
         if migrated is not None:
             out["migrated_particles_per_step"] = migrated  # all ranks together: each one is a pose + a whole map slot on the wire
             out["migrated_bytes_per_step"] = migrated_bytes
