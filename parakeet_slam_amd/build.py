@@ -13,10 +13,13 @@ import shutil
 import subprocess
 import sys
 
-# Per-file extra flags.  The ML observe kernels are register-bound: with MachineLICM on, the back end hoists
-# constant materialisations and address arithmetic out of every loop and keeps them live around it
-# (k_observe_sweep: 168 VGPRs + 96 B of scratch against 129 / none; k_step_fused: 121 against 99).
-EXTRA_FLAGS = {"pk_k_observe_ml.hip": ["-mllvm", "-disable-machine-licm"], "pk_k_step_pub.hip": ["-mllvm", "-disable-machine-licm"]}
+# Per-file extra flags.
+# The ML kernels are register-bound: with MachineLICM on, the back end hoists constant materialisations and address
+# arithmetic out of every loop and keeps them live around it (k_observe_sweep: 168 VGPRs + 96 B of scratch against 129 / none;
+# k_step_fused: 121 against 99; k_assoc_grid<768, ...>: 168 + 44-52 B of scratch against 137-141 / none, and its 512-lane
+# instances 207 against 121).
+_NO_LICM = ["-mllvm", "-disable-machine-licm"]
+EXTRA_FLAGS = {"pk_k_observe_ml.hip": _NO_LICM, "pk_k_step_pub.hip": _NO_LICM, "pk_k_assoc.hip": _NO_LICM}
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")

@@ -698,16 +698,30 @@ class FastSLAM(object):
         with self._lock:
             poses = self._filter.download_poses()
             m, c, k = self._filter.download_landmarks()
-            book = np.array([self._hyp, self._next_id, self._used, self._slot_id], dtype=object)
+            extra = {}
+            if self._grow:
+                # the new-landmark bookkeeping as plain numeric arrays (a snapshot never needs pickle to load): every
+                # particle's orphaned readings (8 numbers each) back to back with per-particle offsets, the id counters,
+                # and the (particle, slot, id) triples of the spare slots in use
+                offs = np.zeros(self.num_particles + 1, dtype=np.int64)
+                offs[1:] = np.cumsum([len(h) for h in self._hyp])
+                flat = [rd for h in self._hyp for rd in h]
+                extra = dict(
+                    nl_readings=np.asarray(flat, dtype=np.float64).reshape(len(flat), 8),
+                    nl_offsets=offs,
+                    nl_next_id=np.asarray(self._next_id, dtype=np.int64),
+                    nl_used=np.asarray(self._used, dtype=np.int64),
+                    nl_slot_id=np.asarray([(i, s, v) for i, d in enumerate(self._slot_id) for s, v in sorted(d.items())],
+                                          dtype=np.int64).reshape(-1, 3))
             np.savez_compressed(
-                path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64), new_landmarks=book,
+                path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
                 immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),
                 last_control=np.array([float(self.last_control.linear.x), float(self.last_control.angular.z)]),
-                last_update=float(self.last_update.to_sec()), draw=self._draw)
+                last_update=float(self.last_update.to_sec()), draw=self._draw, **extra)
 
     def load_state(self, path):
         with self._lock:
-            d = np.load(path, allow_pickle=True)
+            d = np.load(path, allow_pickle=False)  # numeric arrays only: loading a snapshot never runs code
             P, L = self.num_particles, self._L0 + self._spare
             if d["poses"].shape != (P, 4) or d["means"].shape != (P, L, 5):
                 raise ValueError("snapshot is for %s particles x %s landmarks, this filter has %d x %d"
@@ -719,9 +733,20 @@ class FastSLAM(object):
             self.last_control.linear.x = float(d["last_control"][0])
             self.last_control.angular.z = float(d["last_control"][1])
             self._draw = int(d["draw"])
-            if "new_landmarks" in d.files and self._grow:
-                hyp, nid, used, sid = d["new_landmarks"]
-                self._hyp, self._next_id, self._used, self._slot_id = [list(h) for h in hyp], list(nid), list(used), [dict(x) for x in sid]
+            if "nl_offsets" in d.files and self._grow:
+                offs, rd = d["nl_offsets"], d["nl_readings"]
+                if offs.shape != (P + 1,) or rd.shape != (int(offs[-1]), 8) or d["nl_next_id"].shape != (P,):
+                    raise ValueError("snapshot: malformed new-landmark bookkeeping")
+
+                def reading(r):  # (id, x, y, heading, bearing, r, g, b): the id is an integer
+                    return (int(r[0]),) + tuple(float(v) for v in r[1:])
+
+                self._hyp = [[reading(r) for r in rd[offs[i]:offs[i + 1]]] for i in range(P)]
+                self._next_id = [int(v) for v in d["nl_next_id"]]
+                self._used = [int(v) for v in d["nl_used"]]
+                self._slot_id = [dict() for _ in range(P)]
+                for i, slot, fid in d["nl_slot_id"]:
+                    self._slot_id[int(i)][int(slot)] = int(fid)
             self._touch()
 
     def close(self):

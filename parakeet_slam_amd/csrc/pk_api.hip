@@ -155,6 +155,7 @@ struct pk_filter {
     int B = 0;
     bool reset = false;
   } split;
+  bool adopt_local_done = false;  // pk_shard_adopt_local_dev made the new generation current; pk_shard_adopt_remote_dev may fill it
   int pub_ecap = 0;       // k_step_pub was prepared for the current scan with this many publish entries (0: not prepared)
   int split_reserve_cus = 16;  // CUs the first part of a split step leaves free for the all-to-all's kernels
   int regs_retry = 1;    // k_step_regs: 1 = the particles it flags get a second chance (eight-slot hand-off + k_observe_sweep) before the general kernels
@@ -792,9 +793,13 @@ int relayout(pk_filter* f, bool dense, bool keep) {
     if ((rc = materialise(f))) return rc;
     if (!dense)  // dense -> compact drops what the compact layout cannot hold: only when nothing is coupled
       return fail(PK_ERR_STATE, "relayout: a dense map cannot be folded back into the compact layout");
-    means.resize((size_t)P * L * 5);
-    covs.resize((size_t)P * L * 25);
-    counts.resize((size_t)P * L);
+    try {  // the conversion goes through the host (a rare path): P L 30 doubles -- 48 GB at 100 000 x 2 000
+      means.resize((size_t)P * L * 5);
+      covs.resize((size_t)P * L * 25);
+      counts.resize((size_t)P * L);
+    } catch (const std::bad_alloc&) {
+      return fail(PK_ERR_NOMEM, "relayout: no host memory to stage %lld x %d landmarks for the layout conversion", (long long)P, L);
+    }
     if ((rc = pk_download_landmarks(f, 0, P, means.data(), covs.data(), counts.data()))) return rc;
   }
   PK_HIP(hipStreamSynchronize(f->stream));
@@ -1126,19 +1131,28 @@ int pk_upload_landmarks(pk_filter* f, int64_t p0, int64_t p1, const double* mean
   int rc;
   if ((rc = use_device(f))) return rc;
   if ((rc = materialise(f))) return rc;
-  const MapLayout& lay = f->d.lay;
-  const int L = lay.L;
-  if (covs && !f->dense) {
+  const int L = f->d.lay.L;
+  // finite means and covariances whatever the layout (as pk_upload_map checks them); the layout decision only while compact
+  if (means)
+    for (int64_t o = 0; o < (p1 - p0) * L * 5; ++o)
+      if (!std::isfinite(means[o])) return fail(PK_ERR_INVALID, "pk_upload_landmarks: mean of landmark %d not finite", (int)((o / 5) % L) + 1);
+  if (covs) {
     bool need_dense = false;
     for (int64_t o = 0; o < (p1 - p0) * L; ++o) {
       const int c = classify_covariance(covs + (size_t)o * 25, (int)(o % L));
       if (c < 0) return c;
       need_dense |= c == 1;
     }
-    if (need_dense && (rc = relayout(f, true, true))) return rc;
+    if (need_dense && !f->dense && (rc = relayout(f, true, true))) return rc;
   }
+  const MapLayout& lay = f->d.lay;  // (after the conversion)
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(64u << 20) / (int64_t)lay.slot_bytes);
-  std::vector<unsigned char> host((size_t)std::min<int64_t>(chunk, p1 - p0) * lay.slot_bytes);
+  std::vector<unsigned char> host;
+  try {
+    host.resize((size_t)std::min<int64_t>(chunk, p1 - p0) * lay.slot_bytes);
+  } catch (const std::bad_alloc&) {
+    return fail(PK_ERR_NOMEM, "pk_upload_landmarks: no host memory for the staging buffer");
+  }
   for (int64_t q0 = p0; q0 < p1; q0 += chunk) {
     int64_t q1 = std::min(p1, q0 + chunk);
     unsigned char* dev = f->d.map[f->d.mcur] + (size_t)q0 * lay.slot_bytes;
@@ -1388,6 +1402,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   if (!f) return fail(PK_ERR_INVALID, "pk_observe: NULL handle");
   if (B < 0 || (B > 0 && !blobs)) return fail(PK_ERR_INVALID, "pk_observe: bad blobs");
   if (!f->map_loaded) return fail(PK_ERR_STATE, "pk_observe: no map uploaded (pk_upload_map)");
+  if (f->split.active) return fail(PK_ERR_STATE, "pk_observe: a split observe is in progress (pk_observe_staged_range with last = 1 ends it)");
   int rc;
   if ((rc = use_device(f))) return rc;
   const MapLayout& lay = f->d.lay;
@@ -1606,7 +1621,10 @@ int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1,
   ex.reset = sp.reset;
   ex.gmax_key = ctl_gmax_key(f);
   // the first part of a split step runs while the exchange is in flight: it leaves some CUs to the collective's kernels
-  if (p1 > p0 && (rc = onepass_launch(f, sp.al, sp.B, ex, sp.cand, p0, p1, (first && !last) ? f->split_reserve_cus : 0))) return rc;
+  if (p1 > p0 && (rc = onepass_launch(f, sp.al, sp.B, ex, sp.cand, p0, p1, (first && !last) ? f->split_reserve_cus : 0))) {
+    sp.active = false;  // a failed piece ends the split observe: the filter is not left waiting for a "last" that cannot come
+    return rc;
+  }
   if (last) {
     sp.active = false;
     if ((rc = onepass_finish(f, sp.al, sp.B, ex, sp.cand))) return rc;
@@ -1727,6 +1745,7 @@ int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestor
   if (!(u >= 0.0 && u < 1.0)) return fail(PK_ERR_INVALID, "pk_resample: u = %g outside [0,1)", u);
   if (weight_domain != PK_WEIGHTS_LINEAR && weight_domain != PK_WEIGHTS_LOG)
     return fail(PK_ERR_INVALID, "pk_resample: weight_domain %d", weight_domain);
+  if (f->split.active) return fail(PK_ERR_STATE, "pk_resample: a split observe is in progress (half the particles observed)");
   int rc;
   if ((rc = use_device(f))) return rc;
   DeviceState& d = f->d;
@@ -2109,12 +2128,16 @@ int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
   launch_adopt_dev(f->stream, f->d, f->hi_dev, (int64_t)rank * f->d.P, nullptr, 0, nullptr, 1);
   f->src_identity = false;
   f->gmax_fused = false;
+  f->adopt_local_done = true;
   return PK_OK;
 }
 
 int pk_shard_adopt_remote_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
   if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_remote_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_remote_dev: call pk_shard_plan_dev first");
+  if (!f->adopt_local_done)
+    return fail(PK_ERR_STATE, "pk_shard_adopt_remote_dev: pk_shard_adopt_local_dev first (it makes the new generation current)");
+  f->adopt_local_done = false;
   int rc;
   if ((rc = use_device(f))) return rc;
   if (n_received > f->rlohi_cap) {

@@ -2042,9 +2042,14 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
   // whole launch, and a collective that is to run meanwhile (the sharded filter's all-to-all) needs somewhere to run
   int64_t grid_n = n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0);
   if (grid_n > p1 - p0) grid_n = p1 - p0;
-  if (cand.rec)
+  if (cand.rec) {
     hipLaunchKernelGGL(k_step_regs<true>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_cand_lds_bytes(d.lay.Lp, B), s, ra);
-  hipLaunchKernelGGL(k_step_regs<false>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_lds_bytes(grid.ncell, B, n9), s, ra);
+    // a scan in which some candidate list overflowed: every particle goes to the fall-back kernels (second chance on the
+    // eight-slot hand-off, then the general kernels)
+    launch_flag_range_if(s, cand.over, fh.pflag, fh.n_flagged, p0, p1);
+  } else {
+    hipLaunchKernelGGL(k_step_regs<false>, dim3((unsigned)grid_n), dim3(kRegsThreads), regs_lds_bytes(grid.ncell, B, n9), s, ra);
+  }
 }
 
 }  // namespace pk

@@ -199,8 +199,9 @@ void launch_step_owner(hipStream_t s, DeviceState& d, int B, const double* exact
 constexpr int kRegsMaxL = 2048;
 size_t regs_lds_bytes(int ncell, int B, int n9);
 size_t regs_cand_lds_bytes(int Lp, int B);
-// cand.rec != NULL: two launches -- the candidate-list instance (returns at once when *cand.over != 0) and the
-// grid-walk instance (returns at once when *cand.over == 0)
+// cand.rec != NULL: the candidate-list instance (returns at once when *cand.skip_cand != 0), and a scan in which a list
+// overflowed hands all its particles to the fall-back kernels (the grid-walk instance -- cand.rec == NULL, option
+// "cand_lists" = 0 -- still spills eight registers and is no default route's kernel any more)
 void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9, const unsigned char* tables_dev,
                       const double* exact_dev, const unsigned short* order_dev, const FastHandoff& fh, const NoiseD& qt,
                       const ObserveExtras& ex, int warm, const CandTable& cand = CandTable(), int64_t p0 = 0, int64_t p1 = -1,
@@ -217,6 +218,8 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                      const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
                      int reserve_cus = 0);
+// every particle of [p0, p1) flagged for the fall-back kernels when *over != 0 (a candidate list overflowed)
+void launch_flag_range_if(hipStream_t s, const unsigned* over_dev, unsigned char* pflag_dev, unsigned* n_flagged_dev, int64_t p0, int64_t p1);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued

@@ -150,6 +150,8 @@ def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
 
     path = os.path.join(tempfile.mkdtemp(), "grow.npz")
     fs.save_state(path)
+    with np.load(path, allow_pickle=False) as snap:  # plain numeric arrays: loading a snapshot never needs pickle
+        assert all(snap[k].dtype != object for k in snap.files) and "nl_readings" in snap.files
     fs2 = pk.FastSLAM([pk.Feature(mean=m.copy(), covar=c.copy()) for m, c in zip(known, kcov)], num_particles=P,
                       weight_domain="log", new_landmarks=True, spare_landmarks=spare, pair_threshold=thr)
     fs2.load_state(path)
