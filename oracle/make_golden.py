@@ -19,6 +19,10 @@ produced do).  Each fixture stores inputs and the reference's outputs:
                      ancestors, summaries, strided landmark sample)
   motion.npz         motion_update sequences incl. heading wrap
   resample.npz       low_variance_resample ancestor lists for crafted weights
+  step_potential.npz the potential-feature branch of cam_cb (:109-118, :366-367): reference particles whose
+                     `potential_features` are populated by hand (negative ids, update_count 0..6, one immutable),
+                     P=12, 5 full + 4 potential landmarks per particle, 3 steps: ids (negative for potential
+                     matches), weights, per-slot means / covariances / counts / potential flags, promotions
 
 Versions used for the committed fixtures: Python 3.10.12, NumPy 2.2.6, SciPy 1.15.3.
 """
@@ -344,6 +348,153 @@ def scene_config1():
     return run_steps(P, means, covs, [0] * L, steps, v, w, [dt] * S, seed=7, lsel=lsel)
 
 
+def scene_potential():
+    """cam_cb with POTENTIAL features (prkt_core_v2.py:109-118; match_one lists them behind the full features, :366-367).
+    The filter itself never fills `potential_features`, so they are put there by hand: slot
+    L0 + j of particle i is the reference's potential feature -(L0 + 1 + j), with its own mean per particle (the full
+    features' noise-free positions displaced), update_count 0 / 2 / 6 / 4 and the last of them immutable.  A potential feature
+    matched by a blob is updated, the particle's weight takes 0.1, and past update_count 5 it moves to feature_set under
+    its positive id -- i.e. slot + 1.  (No potential feature is sighted twice in one scan: the reference's loop would look
+    a promoted feature up under its old negative id and raise KeyError.)"""
+    rs = np.random.RandomState(41)
+    full = np.array([
+        [6.0, 1.0, 200, 30, 40],
+        [4.0, 5.0, 20, 220, 60],
+        [-3.0, 6.0, 90, 90, 240],
+        [-7.0, -1.0, 250, 250, 10],
+        [5.0, -5.0, 180, 60, 200],
+    ], dtype=np.float64)
+    hidden = np.array([  # true landmarks the potential features stand for
+        [-2.0, -6.0, 10, 128, 128],
+        [8.0, 4.0, 120, 10, 90],
+        [1.0, 9.0, 60, 180, 30],
+        [-8.0, 3.0, 30, 60, 120],
+    ], dtype=np.float64)
+    L0, NP = len(full), len(hidden)
+    fcov = np.broadcast_to(0.25 * np.identity(5), (L0, 5, 5)).copy()
+    P, S = 12, 3
+    v, w, dt = 0.2, 0.1, 0.1
+    count0 = np.array([0, 2, 6, 4])          # update_count of the four potential features at the start
+    pot_imm = np.array([0, 0, 0, 1])          # the last potential feature is immutable in every particle: updated never, promoted
+                                              # never (its count stays), it weighs 0.1 at every sighting
+    np.random.seed(13)
+    pyrandom.seed(13)
+    zstream = np.random.RandomState(13)
+    rospy.Time.set_now(0.0)
+    fs = build_filter(P, full, fcov, [0, 0, 0, 1, 0])
+    pot_mean0 = np.empty((P, NP, 5))
+    pot_cov0 = np.empty((P, NP, 5, 5))
+    for i, p in enumerate(fs.particles):
+        p.potential_features = IterDict()
+        for j in range(NP):
+            m = hidden[j].copy()
+            m[:2] += rs.normal(0, 0.15, 2)      # triangulated somewhere near the truth, differently in every particle
+            m[2:] += rs.normal(0, 1.0, 3)
+            c = np.identity(5) * rs.uniform(0.5, 1.5)  # add_new_feature starts from the identity (:676-686)
+            f = core.Feature(mean=m.copy(), covar=c.copy())
+            f.update_count = int(count0[j])
+            if pot_imm[j]:
+                f.__immutable__ = True
+            p.potential_features[-(L0 + 1 + j)] = f
+            pot_mean0[i, j] = m
+            pot_cov0[i, j] = c
+        p.next_id = L0 + NP + 1
+    tw = Twist()
+    tw.linear.x = v
+    tw.angular.z = w
+    fs.last_control = tw
+
+    def slots(fs):
+        mean = np.empty((P, L0 + NP, 5))
+        cov = np.empty((P, L0 + NP, 5, 5))
+        cnt = np.empty((P, L0 + NP), dtype=np.int64)
+        pot = np.zeros((P, L0 + NP), dtype=bool)
+        for i, p in enumerate(fs.particles):
+            for sl in range(L0 + NP):
+                if (sl + 1) in p.feature_set:
+                    f = p.feature_set[sl + 1]
+                else:
+                    f = p.potential_features[-(sl + 1)]
+                    pot[i, sl] = True
+                mean[i, sl] = np.asarray(f.mean, dtype=np.float64)
+                cov[i, sl] = np.asarray(f.covar, dtype=np.float64)
+                cnt[i, sl] = f.update_count
+        return mean, cov, cnt, pot
+
+    rec = Recorder()
+    out = dict(z=[], post_motion=[], ids=[], weights=[], u=[], ancestors=[], post_resample=[], mean=[], cov=[], count=[], potential=[],
+               blobs=[], pre_mean=[], pre_count=[], pre_potential=[])
+    pose = (0.0, 0.0, 0.0)
+    try:
+        for s in range(S):
+            pose = truth_step(pose, v, w, dt)
+            scan = synthetic_scan(np.vstack([full, hidden]), pose)
+            # (every blob matches something: with potential features present an unmatched blob sends the reference into
+            # find_nearest_reading, :576-590, which takes the Feature objects for stored readings and raises TypeError)
+            dup = scan[1].copy()  # a full feature sighted twice (sequential double update); potential ones only once
+            dup[0] += 0.015
+            dup[1:] += [0.5, -0.5, 0.25]
+            blobs = np.vstack([scan[:4], scan[4:][::-1], dup[None]])
+            rospy.Time.advance(dt)
+            view = View(blobs)
+            n0 = len(rec.normals)
+            captured = {}
+            orig_motion_update = fs.motion_update
+
+            def mu(tw_, _orig=orig_motion_update, _c=captured):
+                _orig(tw_)
+                _c["post_motion"] = poses_of(fs)
+                _c["ids"] = np.array([[pr[0] for pr in p.match_features_to_scan(view.last_sensor_reading)] for p in fs.particles],
+                                     dtype=np.int32)
+                _c["pre"] = slots(fs)
+
+            fs.motion_update = mu
+            orig_resample = fs.low_variance_resample
+
+            def rs_(_orig=orig_resample, _c=captured):
+                _c["weights"] = np.array([float(p.weight) for p in fs.particles])
+                _c["post"] = slots(fs)  # before the resample: per particle as it was updated
+                for i, p in enumerate(fs.particles):
+                    p._golden_index = i
+                _orig()
+                _c["ancestors"] = np.array([p._golden_index for p in fs.particles], dtype=np.int64)
+
+            fs.low_variance_resample = rs_
+            fs.cam_cb(view)
+            fs.motion_update = orig_motion_update
+            fs.low_variance_resample = orig_resample
+            drawn = rec.normals[n0:]
+            assert len(drawn) == 3 * P
+            z = zstream.standard_normal(3 * P).reshape(P, 3)
+            scales = np.array([d[0] for d in drawn]).reshape(P, 3)
+            vals = np.array([d[1] for d in drawn]).reshape(P, 3)
+            assert np.array_equal(0.0 + scales * z, vals)
+            out["z"].append(z)
+            out["blobs"].append(blobs)
+            out["post_motion"].append(captured["post_motion"])
+            out["ids"].append(captured["ids"])
+            out["pre_mean"].append(captured["pre"][0])
+            out["pre_count"].append(captured["pre"][2])
+            out["pre_potential"].append(captured["pre"][3])
+            out["weights"].append(captured["weights"])
+            out["mean"].append(captured["post"][0])
+            out["cov"].append(captured["post"][1])
+            out["count"].append(captured["post"][2])
+            out["potential"].append(captured["post"][3])
+            out["u"].append(rec.uniforms[-1])
+            out["ancestors"].append(captured["ancestors"])
+            out["post_resample"].append(poses_of(fs))
+    finally:
+        rec.restore()
+    res = {k: np.array(vv) for k, vv in out.items()}
+    ids = res["ids"]
+    assert (ids < 0).any() and (ids > L0).any(), "the scene must show potential matches and promoted ones"
+    res.update(P=P, L0=L0, NP=NP, v=v, w=w, dt=dt, seed=13, full_means=full, full_covs=fcov, full_immutable=np.array([0, 0, 0, 1, 0], dtype=np.uint8),
+               pot_mean0=pot_mean0, pot_cov0=pot_cov0, pot_count0=count0, pot_immutable=pot_imm.astype(np.uint8),
+               Qt=np.array(fs.Qt))
+    return res
+
+
 def gen_motion():
     """motion_update only (prkt_core_v2.py:148-208), incl. heading wrap through +-pi."""
     P = 32
@@ -426,6 +577,8 @@ def main():
     print("step_small done", time.time() - t0)
     np.savez_compressed(os.path.join(OUT, "step_refscene.npz"), **scene_reference())
     print("step_refscene done", time.time() - t0)
+    np.savez_compressed(os.path.join(OUT, "step_potential.npz"), **scene_potential())
+    print("step_potential done", time.time() - t0)
     if "--skip-config1" not in sys.argv:
         np.savez_compressed(os.path.join(OUT, "step_config1.npz"), **scene_config1())
         print("step_config1 done", time.time() - t0)

@@ -163,3 +163,76 @@ def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
     assert set(q0.potential_features) == set(p0.potential_features) and set(q0.feature_set.keys()) == set(p0.feature_set.keys())
     fs2.close()
     fs.close()
+
+
+@pytest.mark.parametrize("opts,route", [({}, "ml_fused"), ({"fused_step": 0}, "ml_handoff"), ({"fast_observe": 0}, "ml_general")])
+def test_potential_features_against_the_reference_golden(lib, opts, route):
+    """tests/golden/step_potential.npz: cam_cb of the unmodified reference with hand-populated potential_features
+    (oracle/make_golden.py::scene_potential).  The same start through pk_upload_landmarks(PK_LANDMARK_POTENTIAL): ids (the
+    reference's -(slot + 1) is the device's slot + 1), weights, means, covariances, counts, which features are still
+    potential after every step, ancestors."""
+    from conftest import load_golden
+
+    g = load_golden("step_potential")
+    P, L0, NP = int(g["P"]), int(g["L0"]), int(g["NP"])
+    L = L0 + NP
+    means = np.vstack([g["full_means"], g["pot_mean0"][0]])
+    covs = np.concatenate([g["full_covs"], g["pot_cov0"][0]])
+    imm = np.concatenate([g["full_immutable"], g["pot_immutable"]])
+    f = lib.DeviceFilter(P, L)
+    for k, v in opts.items():
+        f.set_option(k, v)
+    f.upload_map(means, covs.reshape(L, 25), imm)
+    m, c, k = f.download_landmarks()
+    m[:, L0:] = g["pot_mean0"]
+    c[:, L0:] = g["pot_cov0"]
+    k[:, L0:] = g["pot_count0"].astype(np.int32) | lib.PK_LANDMARK_POTENTIAL
+    f.upload_landmarks(0, P, m, c, k.astype(np.int32))
+    for s in range(len(g["u"])):
+        f.reset_weights()
+        f.motion(float(g["v"]), float(g["w"]), float(g["dt"]), z=g["z"][s])
+        ids = f.observe(g["blobs"][s], return_ids=True)
+        assert np.array_equal(ids, np.abs(g["ids"][s]))
+        poses = f.download_poses()
+        assert np.allclose(poses[:, 3], g["weights"][s], rtol=1e-9, atol=0)
+        gm, gc, gk = f.download_landmarks()
+        assert np.allclose(gm, g["mean"][s], rtol=1e-10, atol=1e-12)
+        assert np.allclose(gc, g["cov"][s], rtol=1e-9, atol=1e-13)
+        assert np.array_equal(gk & ~lib.PK_LANDMARK_POTENTIAL, g["count"][s])
+        assert np.array_equal((gk & lib.PK_LANDMARK_POTENTIAL) != 0, g["potential"][s])
+        anc = f.resample(float(g["u"][s]), return_ancestors=True)
+        assert np.array_equal(anc, g["ancestors"][s])
+    f.close()
+
+
+@pytest.mark.parametrize("opts,route", [({}, "ml_fused"), ({"fused_step": 0}, "ml_handoff")])
+def test_potential_golden_on_the_production_routes_without_ids(lib, opts, route):
+    # the same fixture with no ids asked for: the one-pass / hand-off kernels themselves (asking for ids selects the general route)
+    from conftest import load_golden
+
+    g = load_golden("step_potential")
+    P, L0, NP = int(g["P"]), int(g["L0"]), int(g["NP"])
+    L = L0 + NP
+    means = np.vstack([g["full_means"], g["pot_mean0"][0]])
+    covs = np.concatenate([g["full_covs"], g["pot_cov0"][0]])
+    f = lib.DeviceFilter(P, L)
+    for k, v in opts.items():
+        f.set_option(k, v)
+    f.upload_map(means, covs.reshape(L, 25), np.concatenate([g["full_immutable"], g["pot_immutable"]]))
+    m, c, k = f.download_landmarks()
+    m[:, L0:] = g["pot_mean0"]
+    c[:, L0:] = g["pot_cov0"]
+    k[:, L0:] = g["pot_count0"].astype(np.int32) | lib.PK_LANDMARK_POTENTIAL
+    f.upload_landmarks(0, P, m, c, k.astype(np.int32))
+    for s in range(len(g["u"])):
+        f.reset_weights()
+        f.motion(float(g["v"]), float(g["w"]), float(g["dt"]), z=g["z"][s])
+        f.observe(g["blobs"][s])
+        assert f.observe_route() == route
+        assert np.allclose(f.download_poses()[:, 3], g["weights"][s], rtol=1e-9, atol=0)
+        gm, gc, gk = f.download_landmarks()
+        assert np.allclose(gm, g["mean"][s], rtol=1e-10, atol=1e-12)
+        assert np.array_equal(gk & ~lib.PK_LANDMARK_POTENTIAL, g["count"][s])
+        assert np.array_equal((gk & lib.PK_LANDMARK_POTENTIAL) != 0, g["potential"][s])
+        assert np.array_equal(f.resample(float(g["u"][s]), return_ancestors=True), g["ancestors"][s])
+    f.close()

@@ -89,3 +89,50 @@ def test_log_domain_matches_linear_when_nothing_underflows():
         _, a2 = f2.step(float(g["v"]), float(g["w"]), float(g["dts"][s]), g["z"][s], g["blobs"][s], float(g["u"][s]),
                         domain="log")
         assert np.array_equal(a1, a2)
+
+
+def potential_filter(g):
+    """The oracle loaded with the step_potential fixture's start: five full features, and in slots 5..8 of every
+    particle the potential features the reference carried under the ids -6..-9 (prkt_core_v2.py:109-118)."""
+    P, L0, NP = int(g["P"]), int(g["L0"]), int(g["NP"])
+    means = np.vstack([g["full_means"], g["pot_mean0"][0]])
+    covs = np.concatenate([g["full_covs"], g["pot_cov0"][0]])
+    imm = np.concatenate([g["full_immutable"], g["pot_immutable"]])
+    f = O.OracleFilter(P, means, covs, imm, g["Qt"])
+    f.mean[:, L0:] = g["pot_mean0"]
+    f.cov[:, L0:] = g["pot_cov0"]
+    f.count[:, L0:] = g["pot_count0"]
+    f.potential[:, L0:] = True
+    return f
+
+
+def test_potential_feature_branch_against_the_reference():
+    """What pins OracleFilter.potential (and through it the device rule): cam_cb of the unmodified reference with
+    hand-populated potential_features -- matched like full features (listed behind them, :366-367), updated, weight
+    0.1 instead of the importance factor (:111-112), promoted to the positive id past update_count 5 (:113-117)."""
+    g = load_golden("step_potential")
+    P, L0 = int(g["P"]), int(g["L0"])
+    f = potential_filter(g)
+    ar = np.arange(P)[:, None]
+    saw_potential = saw_promoted = False
+    for s in range(len(g["u"])):
+        f.reset_weights()
+        f.motion(float(g["v"]), float(g["w"]), float(g["dt"]), g["z"][s])
+        assert np.allclose(np.stack([f.x, f.y, f.h], 1), g["post_motion"][s][:, :3], rtol=0, atol=1e-15)
+        assert relerr(f.mean, g["pre_mean"][s]) < 1e-13 and np.array_equal(f.count, g["pre_count"][s])
+        assert np.array_equal(f.potential, g["pre_potential"][s])
+        pre_pot = f.potential.copy()
+        ids = f.observe(g["blobs"][s])
+        ref = g["ids"][s]
+        assert (ref != 0).all() and np.array_equal(ids, np.abs(ref))  # the reference's negative id -(slot + 1): the same slot
+        assert np.array_equal(ref < 0, pre_pot[ar, np.abs(ref) - 1])   # ... negative exactly while the feature is potential
+        saw_potential |= bool((ref < 0).any())
+        saw_promoted |= bool((ref > L0).any())
+        assert relerr(f.weights(), g["weights"][s]) < 1e-12
+        assert relerr(f.mean, g["mean"][s]) < 1e-13
+        assert np.allclose(f.cov, g["cov"][s], rtol=1e-12, atol=1e-15)
+        assert np.array_equal(f.count, g["count"][s]) and np.array_equal(f.potential, g["potential"][s])
+        anc = f.resample(float(g["u"][s]))
+        assert np.array_equal(anc, g["ancestors"][s])
+    assert saw_potential and saw_promoted
+    assert g["potential"][-1][:, L0 + 3].all() and (g["count"][-1][:, L0 + 3] == g["pot_count0"][3]).all()  # the immutable one: never
