@@ -8,5 +8,6 @@ kernels for gfx950 reached through the C ABI in ``include/parakeet_slam.h``.
 """
 from ._lib import DeviceFilter, HostRng, PkError, probe  # noqa: F401
 from .core import FastSLAM, Feature, FilterParticle  # noqa: F401
+from .multi import ShardedFastSLAM  # noqa: F401  (FastSLAM(..., devices=[...]): one child process per GPU)
 
-__all__ = ["FastSLAM", "FilterParticle", "Feature", "DeviceFilter", "PkError", "probe", "HostRng"]
+__all__ = ["FastSLAM", "FilterParticle", "Feature", "DeviceFilter", "PkError", "probe", "HostRng", "ShardedFastSLAM"]

@@ -430,8 +430,21 @@ class FastSLAM(object):
 
     EMPTY_COLOUR = 2.0 ** 100  # colour of a spare slot that holds nothing yet: fails every colour gate (:441), exact in float32
 
+    def __new__(cls, preset_features=[], *args, **kwargs):
+        # FastSLAM(preset_features, devices=[0, 1, ...]): the same class surface with the particles sharded over several
+        # GPUs, one child process per device (multi.py; SURVEY section 5's `devices=` keyword)
+        devices = kwargs.get("devices")
+        if devices is not None and len(list(devices)) > 1:
+            from .multi import ShardedFastSLAM
+
+            kw = {k: v for k, v in kwargs.items() if k in ("num_particles", "devices", "weight_domain", "rng", "seed", "backend", "_shard_factory")}
+            return ShardedFastSLAM(preset_features, **kw)
+        return super(FastSLAM, cls).__new__(cls)
+
     def __init__(self, preset_features=[], num_particles=50, device=0, weight_domain="linear", rng="global",
-                 seed=0, publish_debug=None, new_landmarks=False, spare_landmarks=0, pair_threshold=30.0):
+                 seed=0, publish_debug=None, new_landmarks=False, spare_landmarks=0, pair_threshold=30.0, devices=None):
+        if devices is not None and len(list(devices)) == 1:
+            device = list(devices)[0]
         self._lock = threading.RLock()
         self.last_control = Twist()
         self.last_update = msgs.now()

@@ -21,9 +21,9 @@ class OracleShard(object):
     sequential scan of the global totals, owner-computes offspring).  Lets the exchange logic
     run under gloo on a machine without a GPU.  Never used by the product."""
 
-    def __init__(self, P, means, covs):
+    def __init__(self, P, means, covs, immutable=None):
         self.P = P
-        self.o = OracleFilter(P, means, covs)
+        self.o = OracleFilter(P, means, covs, immutable)
         self.L = self.o.L
         self.off = 0
         self.device = -1
@@ -47,6 +47,10 @@ class OracleShard(object):
 
     def download_poses(self):
         return np.stack([self.o.x, self.o.y, self.o.h, self.o.weights()], 1)
+
+    def download_landmarks(self, p0=0, p1=None):
+        p1 = self.P if p1 is None else p1
+        return self.o.mean[p0:p1].copy(), self.o.cov[p0:p1].copy(), self.o.count[p0:p1].copy()
 
     def pose_sums(self):
         return np.array([self.o.x.sum(), self.o.y.sum(), np.sin(self.o.h).sum(), np.cos(self.o.h).sum()])
@@ -225,3 +229,8 @@ def store_file():
     os.close(fd)
     os.unlink(path)
     return path
+
+
+def make_oracle_shard(P, means, covs, immutable=None):
+    """Shard factory for ShardedFastSLAM's CPU rehearsal (module-level: picklable for the spawned ranks)."""
+    return OracleShard(P, means, covs, immutable)

@@ -330,3 +330,54 @@ def test_split_step_overlaps_the_exchange_and_changes_nothing(world, P_local):
     assert np.allclose(m, rm, rtol=1e-11, atol=1e-12) and np.array_equal(np.concatenate([a[r][3] for r in range(world)]), rk)
     assert np.allclose(a[0][4], f.summary(), rtol=1e-12, atol=1e-13)
     f.close()
+
+
+def test_fastslam_devices_keyword_two_ranks_on_one_gpu_match_the_single_gpu_facade():
+    """FastSLAM(preset_features, devices=[0, 0]): the front end spawns one child per entry (here both on the one device, gloo
+    between them), each with a HipShard.  Same trajectory as FastSLAM(device=0): the Philox motion noise is drawn per global
+    particle index, the resample draw is made in the front end and replicated."""
+    import random
+
+    import parakeet_slam_amd as pk
+    from oracle.fastslam_oracle import synthetic_scan, synthetic_world, truth_step
+
+    class View(object):
+        def __init__(self, blobs):
+            class Scan(object):
+                pass
+
+            self.last_sensor_reading = Scan()
+            obs = []
+            for b in blobs:
+                o = pk.msgs.Blob()
+                o.bearing = float(b[0])
+                o.color.r, o.color.g, o.color.b = float(b[1]), float(b[2]), float(b[3])
+                obs.append(o)
+            self.last_sensor_reading.observes = obs
+
+    L, P, steps = 40, 2048, 4
+    means, covs = synthetic_world(L)
+    feats = [pk.Feature(mean=means[l].copy(), covar=covs[l].copy()) for l in range(L)]
+    out = []
+    for devices in ([0, 0], None):
+        random.seed(5)
+        pk.msgs.Time.set_now(0.0)
+        if devices:
+            fs = pk.FastSLAM(feats, num_particles=P, devices=devices, weight_domain="log", rng="device", seed=3, backend="gloo")
+            assert isinstance(fs, pk.ShardedFastSLAM)
+        else:
+            fs = pk.FastSLAM(feats, num_particles=P, device=0, weight_domain="log", rng="device", seed=3)
+        tw = pk.msgs.Twist()
+        tw.linear.x, tw.angular.z = 0.2, 0.1
+        fs.last_control = tw
+        pose, sums = (0.0, 0.0, 0.0), []
+        for s in range(steps):
+            pose = truth_step(pose, 0.2, 0.1, 0.1)
+            pk.msgs.Time.set_now(0.1 * (s + 1))
+            fs.cam_cb(View(synthetic_scan(means, pose)))
+            sums.append(fs.summary())
+        p0 = fs.particles[P - 1]
+        out.append((np.array(sums), np.asarray(p0.feature_set[3].mean, dtype=np.float64).copy(), p0.state.pose.pose.position.x))
+        fs.close()
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-12, atol=1e-13)
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
