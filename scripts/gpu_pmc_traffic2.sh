@@ -21,6 +21,11 @@ for s in range(3):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, ids=ids, domain=1)   # supplied ids
 for s in range(3, 6):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)            # production ML route
+if 512 < L <= 2048:
+    f.set_option("pub_step", 0)
+    for s in range(3, 6):
+        f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)        # k_step_regs instead of k_step_pub
+    f.set_option("pub_step", 1)
 if L > 512:
     f.set_option("regs_step", 0)
 else:
@@ -44,6 +49,7 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 def key_of(k):
     if 'k_observe<true' in k or 'k_observe_single' in k: return 'observe_known'
     if 'k_step_fused' in k: return 'step_fused'
+    if 'k_step_pub' in k: return 'step_pub'
     if 'k_step_regs' in k: return 'step_regs'
     if 'k_observe_fast' in k: return 'observe_ml'
     if 'k_observe_sweep' in k: return 'observe_sweep'
@@ -66,7 +72,7 @@ for k, v in res.items():
     raw[k] = {c: (sum(x) / len(x), len(x)) for c, x in v.items()}
     if 'FETCH_SIZE' in raw[k] and 'WRITE_SIZE' in raw[k]:
         out[k] = (2.0 * raw[k]['FETCH_SIZE'][0] + raw[k]['WRITE_SIZE'][0]) * 1024.0
-doc = {"config": {"particles": P, "landmarks": L, "blobs": L},
+doc = {"git": os.environ.get("PK_GIT_SHA", "unknown"), "config": {"particles": P, "landmarks": L, "blobs": L},
        "what": "HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (rocprofv3 --pmc, one counter per pass, "
                "gfx950 corrections of MI355X_MICROARCH.md); FETCH_SIZE counts reads served by the Infinity Cache too",
        "algorithmic_bytes_per_launch": P * L * 224, "slot_bytes": slot,

@@ -34,7 +34,7 @@ for s in range(3, 6):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
-print("git", os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "(no git on this box)", "P", P, "L", L)
+print("git", os.environ.get("PK_GIT_SHA") or os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "unknown", "P", P, "L", L)
 if v[48 + 8] > 0:  # k_step_pub ran (512 < L <= 2048, publish table in LDS)
     pn = ["scalars, requests", "gates (waits for candidate records, means)", "verdicts (waits for covariance rows)", "barrier A",
           "unseen blobs, subscribe", "barrier B", "updates, stores issued", "wave sum", "particle (wave lifetime)"]
