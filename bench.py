@@ -85,7 +85,9 @@ ROUTE_KERNEL = {
 }
 ROUTE_KERNEL["ml_regs_pub"] = ("k_step_pub (512 < L <= 2048: a particle's whole map in registers, four landmarks per lane; association gates + "
                                "contested blobs settled by static publish / subscribe through LDS + EKF update + log-weight in ONE pass over the map)")
-ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_regs": "step_regs", "ml_regs_pub": "step_pub", "ml_owner": "step_owner",
+ROUTE_KERNEL["ml_fused_pub"] = ("k_step_pub<256 lanes> (L <= 512: two landmarks per lane, three workgroups per CU; association gates + contested blobs settled by "
+                                "static publish / subscribe through LDS + EKF update + log-weight in ONE pass over the map)")
+ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_fused_pub": "step_pub", "ml_regs": "step_regs", "ml_regs_pub": "step_pub", "ml_owner": "step_owner",
                      "ml_handoff": "observe_ml", "ml_sweep": "observe_sweep"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_UPDATE = 224  # 14 fp64 read + 14 written per particle.landmark
@@ -481,8 +483,8 @@ def main():
         migrated_bytes = migrated * filt.f.particle_bytes()
     summary = filt.summary()
     flagged = filt.observe_flagged() if hasattr(filt, "observe_flagged") else None
-    if route == "ml_regs" and hasattr(filt, "observe_published") and filt.observe_published():
-        route = "ml_regs_pub"  # which instance of the register route worked on the scans is decided on the device
+    if route in ("ml_regs", "ml_fused") and hasattr(filt, "observe_published") and filt.observe_published():
+        route += "_pub"  # which instance of the one-pass route worked on the scans is decided on the device
     # validity probe (untimed): share of the blobs of the last timed scan that the particles, as they
     # stand now, still associate with some landmark (the workload degenerates when this collapses)
     matched = None
@@ -584,6 +586,8 @@ def main():
         f2.upload_map(m2, c2.reshape(L2, 25))
         e2, tm2, route2, _ = timed_steps(f2, _lib, P2, L2, K2, W2, s2, synthetic_controls(K2 + W2),
                                           [rnd.random() for _ in range(K2 + W2)], None, barrier2(torch, f2), 4)
+        if route2 in ("ml_regs", "ml_fused") and f2.observe_published():
+            route2 += "_pub"
         second = {
             "workload": workload_name(P2, L2, "ml"),
             "value": float(P2) * L2 * K2 / e2,

@@ -117,6 +117,9 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    there, one lane per contested blob picks the winner; two landmark pairs per lane, 512 lanes -- while
  *                    the table fits LDS and no candidate list overflows; decided per scan on the device,
  *                    pk_observe_published) or 0 (k_step_regs: per-blob counters, probability queue, bids);
+ *   "pub_small"    = 0 (default) or 1: maps of at most 512 landmarks through k_step_pub's 256-lane instance (three workgroups per
+ *                    CU) instead of k_step_fused -- built, exact, and no faster (the kernel 1 % slower, the step 50 us longer
+ *                    for the candidate-list launches at 10 000 x 500);
  *   "pub_entry_limit" = 0 (default: what LDS holds) or n: treat the publish table as n entries small (tests: scans
  *                    whose table does not fit fall back to k_step_regs);
  *   "owner_step"   = 0, 1 (maps of more than 512 landmarks) or 2 (every map): k_step_owner -- candidate lists of a

@@ -143,6 +143,7 @@ struct pk_filter {
   uint4* cand_dev = nullptr;  // [Lp][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
+  int pub_small = 0;     // L <= 512: k_step_pub<256 lanes> instead of k_step_fused (measured: the kernel 1 % slower, the step 50 us longer)
   int pub_entry_limit = 0;  // > 0: the publish table is treated as this small (tests: scans whose table "does not fit" fall back to k_step_regs)
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
@@ -1309,9 +1310,12 @@ static int ensure_inverse_lists(pk_filter* f, int B) {
 static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand) {
   int rc;
   f->pub_ecap = 0;
-  if (al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) {
+  // the register route; with "pub_small" (off: measured) also the L <= 512 route through the publish /
+  // subscribe instance of three 256-lane workgroups per CU
+  const bool small_pub = al.fused && f->pub_small && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
+  if ((al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) || small_pub) {
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
-    int ecap = f->pub_step ? step_pub_entry_capacity(B) : 0;
+    int ecap = !f->pub_step ? 0 : al.fused ? step_pub_entry_capacity_small(B) : step_pub_entry_capacity(B);
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     if (ecap > 0) {
       if (!f->erec_dev && (rc = dev_alloc(f, &f->erec_dev, (size_t)f->d.lay.Lp))) return rc;
@@ -1349,8 +1353,13 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
                       p0, p1, reserve_cus);
     launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
                      reserve_cus);
-  } else
-    launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1);
+  } else {
+    if (f->pub_ecap > 0 && cand.rec)
+      launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
+                      p0, p1, reserve_cus);
+    launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1,
+                      (f->pub_ecap > 0 && cand.rec) ? ctl_skip_pub(f) : nullptr);
+  }
   return PK_OK;
 }
 // 3. what the one-pass kernel flagged, over all particles: second chance, then the general kernels (which swap the map buffers)
@@ -1702,6 +1711,10 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "pub_step")) {
     f->pub_step = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "pub_small")) {
+    f->pub_small = value != 0;
     return PK_OK;
   }
   if (!strcmp(name, "pub_entry_limit")) {
@@ -2269,7 +2282,7 @@ int pk_observe_published(pk_filter* f, int32_t* published) {
   int rc;
   if ((rc = use_device(f))) return rc;
   *published = 0;
-  if (f->scan_dev && f->route == PK_ROUTE_ML_REGS && f->pub_ecap > 0) {
+  if (f->scan_dev && (f->route == PK_ROUTE_ML_REGS || f->route == PK_ROUTE_ML_FUSED) && f->pub_ecap > 0) {
     unsigned w = 1u;
     PK_HIP(hipMemcpyAsync(&w, ctl_skip_pub(f), sizeof(w), hipMemcpyDeviceToHost, f->stream));
     PK_HIP(hipStreamSynchronize(f->stream));

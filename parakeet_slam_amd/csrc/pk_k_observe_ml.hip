@@ -383,6 +383,7 @@ struct FusedArgs {
   unsigned char* pflag_out;     // [P] 1 = general route
   unsigned* n_flagged;
   int n9;
+  const unsigned* pub_skipped;  // NULL, or: == 0 -> k_step_pub takes this scan, this kernel stands back
 };
 
 // exact_lds: the exact records [B][6] and the order table are staged in LDS too (one contiguous
@@ -419,6 +420,7 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
   __shared__ int wg_flag;
   const FastArgs& a = fa.f;
   const BlobGrid& g = fa.g;
+  if (fa.pub_skipped && *fa.pub_skipped == 0u) return;  // workgroup-uniform: the publish / subscribe instance works on this scan
   // Every argument the first loads depend on is wanted at once: one batch of kernarg loads and one
   // wait, not seven dependent round trips through the scalar cache before the first request leaves.
   // A pure asm (no side effects: a volatile one in front of them would turn the scalar loads of
@@ -723,7 +725,7 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
 
 void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
-                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex) {
+                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const unsigned* pub_skipped_dev) {
   if (d.P == 0) return;
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
@@ -758,6 +760,7 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   fa.pflag_out = fh.pflag;
   fa.n_flagged = fh.n_flagged;
   fa.n9 = n9;
+  fa.pub_skipped = pub_skipped_dev;
   // exact records + order table in LDS as well when two workgroups per CU still fit
   const bool exact_lds = fused_lds_bytes(grid.ncell, B, n9, true) <= kFusedMaxLds;
   const size_t lds = fused_lds_bytes(grid.ncell, B, n9, exact_lds);

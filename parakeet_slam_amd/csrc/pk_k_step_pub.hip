@@ -41,8 +41,8 @@ namespace pk {
 #ifndef PK_PUB_ABLATE
 #define PK_PUB_ABLATE 0
 #endif
-constexpr int kPubThreads = 512;
-constexpr int kPubWaves = kPubThreads / kWave;
+constexpr int kPubThreads = 512;        // the large instances' workgroup
+constexpr int kPubSmallThreads = 256;   // ... the L <= 512 instance's
 constexpr int kPubSlots = 4;  // gate-passing blobs a landmark keeps; more: the particle is flagged
 
 typedef double Double2 __attribute__((ext_vector_type(2)));
@@ -94,6 +94,12 @@ int step_pub_entry_capacity(int B) {
   if (fixed + 64 * 8 > kMaxDynLds) return 0;
   const size_t e = (kMaxDynLds - fixed) / 8;
   return (int)(e > 65534 ? 65534 : e);
+}
+
+int step_pub_entry_capacity_small(int B) {
+  const size_t budget = 52 * 1024, fixed = pub_fixed_lds_bytes(B);  // three workgroups per CU
+  if (fixed + 64 * 8 > budget) return 0;
+  return (int)((budget - fixed) / 8);
 }
 
 // ------------------------------------------------------------------ the publish table's layout, once per scan
@@ -256,16 +262,17 @@ struct PubGateIn {
   double mx, my, mr, mg, mb;
   bool has;
 };
-__device__ __forceinline__ void pub_gates2(PubSlots (&q)[2], double (&pse_out)[2], const PubGateIn (&in)[2], const double* ex,
+template <int N>
+__device__ __forceinline__ void pub_gatesN(PubSlots (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
                                            double* pub, unsigned dump, int* flag, double sx, double sy, double sh) {
-  double eb[2];
-  bool inside[2];
-  unsigned c0[2], c1[2], c2[2], c3[2], e0[2], e1[2], e2[2], e3[2];
-  unsigned s0[2], s1[2], s2[2], s3[2];
-  float dmin[2];  // colour distance of the blob in slot 0: the best colour match stands in front (pub_keys)
-  int npass[2];
+  double eb[N];
+  bool inside[N];
+  unsigned c0[N], c1[N], c2[N], c3[N], e0[N], e1[N], e2[N], e3[N];
+  unsigned s0[N], s1[N], s2[N], s3[N];
+  float dmin[N];  // colour distance of the blob in slot 0: the best colour match stands in front (pub_keys)
+  int npass[N];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < N; ++j) {
     const double pse = atan2(in[j].my - sy, in[j].mx - sx);
     pse_out[j] = pse;
     eb[j] = pse - sh;  // :408
@@ -291,9 +298,12 @@ __device__ __forceinline__ void pub_gates2(PubSlots (&q)[2], double (&pse_out)[2
   }
 #pragma unroll 1
   for (int k = 0; k < kCandSlots; k += 2) {
-    if (__ballot((c0[0] & c0[1] & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: both lists are through
+    unsigned call = c0[0];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 1; j < N; ++j) call &= c0[j];
+    if (__ballot((call & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: every list is through
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
       const unsigned ta = c0[j] & 0xFFFFu, tb = c0[j] >> 16;
       const unsigned ea = e0[j] & 0xFFFFu, eb2 = e0[j] >> 16;  // (0xFFFF where the blob is: k_cand_entries)
       c0[j] = c1[j];
@@ -341,7 +351,7 @@ __device__ __forceinline__ void pub_gates2(PubSlots (&q)[2], double (&pse_out)[2
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < N; ++j) {
     if (in[j].has && (!inside[j] || npass[j] > kPubSlots)) *flag = 1;
     q[j].s0 = s0[j];
     q[j].s1 = s1[j];
@@ -362,18 +372,23 @@ __device__ __forceinline__ double pub_recip(double x) {
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
-__device__ __forceinline__ void pub_keys2(PubSlots (&q)[2], const Landmark<double>& lmA, const Landmark<double>& lmB,
-                                          const double (&pse)[2], const double* ex, double* pub, unsigned dump, unsigned char* any,
+template <int N>
+__device__ __forceinline__ void pub_keysN(PubSlots (&q)[N], const Landmark<double>* const (&lmp)[N],
+                                          const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
                                           unsigned anydump, int* flag, double sx, double sy) {
-  if (__ballot(((q[0].s0 & q[1].s0) & 0xFFFFu) != 0xFFFFu) == 0ull) return;  // wave-uniform: nobody's landmark passes a blob
+  {
+    unsigned sall = q[0].s0;
+#pragma unroll
+    for (int j = 1; j < N; ++j) sall &= q[j].s0;
+    if (__ballot((sall & 0xFFFFu) != 0xFFFFu) == 0ull) return;  // wave-uniform: nobody's landmark passes a blob
+  }
   constexpr double ln2 = 0.69314718055994530942;
-  const Landmark<double>* lmp[2] = {&lmA, &lmB};
-  double det2[2], det3[2], r2[2], r3[2], a2base[2], a3base[2], kbase[2], itr3[2];
-  Sym3<double> adj3[2];
-  bool sane[2], pd3[2];
+  double det2[N], det3[N], r2[N], r3[N], a2base[N], a3base[N], kbase[N], itr3[N];
+  Sym3<double> adj3[N];
+  bool sane[N], pd3[N];
   bool weird = false;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < N; ++j) {
     const Landmark<double>& lm = *lmp[j];
     det2[j] = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
     adj3[j] = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3[j]);
@@ -404,14 +419,17 @@ __device__ __forceinline__ void pub_keys2(PubSlots (&q)[2], const Landmark<doubl
   int done = 0;
 #pragma unroll 1
   for (; done < kPubSlots; ++done) {
-    if (__ballot(((q[0].s0 & q[1].s0) & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: both landmarks are through
-    unsigned t[2], e[2];
-    bool valid[2], far[2], positive[2];
-    double2 z01[2], z23[2];
-    double d1[2], d2c[2], d3c[2];
-    const double* rec[2];
+    unsigned sall = q[0].s0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 1; j < N; ++j) sall &= q[j].s0;
+    if (__ballot((sall & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: every landmark is through
+    unsigned t[N], e[N];
+    bool valid[N], far[N], positive[N];
+    double2 z01[N], z23[N];
+    double d1[N], d2c[N], d3c[N];
+    const double* rec[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
       const Landmark<double>& lm = *lmp[j];
       t[j] = q[j].s0 & 0xFFFFu;
       e[j] = q[j].s0 >> 16;
@@ -425,11 +443,14 @@ __device__ __forceinline__ void pub_keys2(PubSlots (&q)[2], const Landmark<doubl
       far[j] = pd3[j] && kbase[j] + (d1[j] * d1[j] + d2c[j] * d2c[j] + d3c[j] * d3c[j]) * itr3[j] > 1492.0;  // key > 1492: probability 0
       positive[j] = false;
     }
-    if (__ballot((valid[0] && !far[0]) || (valid[1] && !far[1])) != 0ull) {  // wave-uniform
-      double key[2], num2[2], num3[2];
-      bool edge[2];
+    bool heavy = false;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < N; ++j) heavy |= valid[j] && !far[j];
+    if (__ballot(heavy) != 0ull) {  // wave-uniform
+      double key[N], num2[N], num3[N];
+      bool edge[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
         const Landmark<double>& lm = *lmp[j];
         const double2 dir = *reinterpret_cast<const double2*>(rec[j] + 4);
         // prob_position_match :457-494, prob_color_match :524-544
@@ -453,9 +474,12 @@ __device__ __forceinline__ void pub_keys2(PubSlots (&q)[2], const Landmark<doubl
         positive[j] = valid[j] && sure_pos;
         edge[j] = valid[j] && !sure_pos && !sure_zero;
       }
-      if (__ballot(edge[0] || edge[1]) != 0ull) {  // wave-uniform, rare
+      bool anyedge = false;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < N; ++j) anyedge |= edge[j];
+      if (__ballot(anyedge) != 0ull) {  // wave-uniform, rare
+#pragma unroll
+        for (int j = 0; j < N; ++j)
           if (edge[j]) {
             double d2 = det2[j], d3 = det3[j];
             asm volatile("" : "+v"(d2), "+v"(d3));  // opaque: keeps the logs and exps of this rare branch out of the common path
@@ -463,24 +487,24 @@ __device__ __forceinline__ void pub_keys2(PubSlots (&q)[2], const Landmark<doubl
           }
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) pub[(e[j] == 0xFFFFu) ? dump : e[j]] = positive[j] ? key[j] : pub_inf();  // (an empty slot's entry field is 0xFFFF)
+      for (int j = 0; j < N; ++j) pub[(e[j] == 0xFFFFu) ? dump : e[j]] = positive[j] ? key[j] : pub_inf();  // (an empty slot's entry field is 0xFFFF)
     } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < N; ++j) {
         weird |= valid[j] && !sane[j];
         pub[(e[j] == 0xFFFFu) ? dump : e[j]] = pub_inf();
       }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < N; ++j) {
       any[positive[j] ? t[j] : anydump] = 1;
       q[j].st |= positive[j] ? 1u : 0u;
       pub_rotate(q[j]);
     }
   }
   for (; done < kPubSlots; ++done) {  // wave-uniform trip count: back to the original order
-    pub_rotate(q[0]);
-    pub_rotate(q[1]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) pub_rotate(q[j]);
   }
   if (weird) *flag = 1;
 }
@@ -493,10 +517,11 @@ __device__ __forceinline__ void pub_keys2(PubSlots (&q)[2], const Landmark<doubl
 // flagged and the general kernels compare probabilities.  (A first version let every landmark's lane read its rivals'
 // entries one after the other: 40 % of the kernel's time went into those dependent LDS round trips.)
 __device__ __forceinline__ double pub_marker() { return __longlong_as_double((long long)0xFFF0000000000000ull); }
+template <int THREADS>
 __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist, unsigned G, double* pub, unsigned dump, int* flag) {
   bool doubt = false;
 #pragma unroll 1
-  for (unsigned g = (unsigned)tid; __ballot(g < G) != 0ull; g += kPubThreads) {  // wave-uniform
+  for (unsigned g = (unsigned)tid; __ballot(g < G) != 0ull; g += THREADS) {  // wave-uniform
     const bool on = g < G;
     const unsigned gi = glist[on ? g : 0u];
     const unsigned offs = gi & 0xFFFFu, n = on ? (gi >> 16) : 0u;
@@ -601,6 +626,48 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
   return acc;
 }
 
+// The same with ONE copy of the update code, in a loop that nearly always turns once (the 256-lane instance: 145 VGPRs
+// instead of 181; on the large instance 0.7 % slower than the two-path form above).
+__device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
+                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
+  double acc = 0.0;
+  unsigned tk = q.st & 0x4444u;
+  bool fresh = true;
+#pragma unroll 1
+  for (int it = 0; it < kPubSlots; ++it) {
+    if (__ballot(tk != 0u) == 0ull) break;  // wave-uniform
+    unsigned w, bit;
+    if (__ballot((tk & (tk - 1u)) != 0u) == 0ull) {  // wave-uniform, the usual case: at most one blob left per landmark
+      w = (tk & 0x0004u) ? q.s0 : (tk & 0x0040u) ? q.s1 : (tk & 0x0400u) ? q.s2 : q.s3;
+      bit = tk;
+    } else {  // the one that comes first in the scan
+      const unsigned sw[kPubSlots] = {q.s0, q.s1, q.s2, q.s3};
+      unsigned best = 0xFFFFFFFFu;
+      w = 0u;
+      bit = 0u;
+#pragma unroll
+      for (int s = 0; s < kPubSlots; ++s) {
+        const bool on = ((tk >> (4 * s)) & 4u) != 0u;
+        const unsigned o = order[on ? (sw[s] & 0xFFFFu) : 0u];
+        const bool first = on && o < best;
+        best = first ? o : best;
+        w = first ? sw[s] : w;
+        bit = first ? (4u << (4 * s)) : bit;
+      }
+    }
+    if (tk != 0u) {
+      const double* rec = ex + 6 * (w & 0xFFFFu);
+      const double2 z01 = *reinterpret_cast<const double2*>(rec);
+      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+      BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
+      acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+      fresh = imm;
+    }
+    tk &= ~bit;
+  }
+  return acc;
+}
+
 // Diagnostic build only (-DPK_STAMPS): per-phase cycle sums of k_step_pub (slots 48.. of pk_debug_stamps).
 #ifdef PK_STAMPS
 __device__ unsigned long long pk_pstamp_acc[16];
@@ -635,9 +702,12 @@ __device__ __forceinline__ Noise<double> pub_noise(PubArgsPtr R) {
   return Noise<double>{R->qt.q00, R->qt.rr, R->qt.rg, R->qt.rb, R->qt.gg, R->qt.gb, R->qt.bb, R->qt.diag};
 }
 
-// NP: adjacent landmark pairs per lane (2: maps up to 2048 landmarks; 1: up to 1024)
-template <int NP>
-__global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
+// NP: adjacent landmark pairs per lane, THREADS: lanes of the workgroup -- <2, 512>: maps up to 2 048 landmarks, one workgroup
+// per CU (256 VGPRs); <1, 512>: up to 1 024; <1, 256>: up to 512 landmarks, 143 VGPRs: three workgroups per CU work on three
+// particles side by side (the L <= 512 route: what k_step_fused does with a grid walk, a probability queue and seven barriers)
+template <int NP, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(PubArgs a_unused) {
+  constexpr int kPubThreads = THREADS, kPubWaves = THREADS / kWave;
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[2][kPubWaves];
   __shared__ int wg_flag[2];
@@ -782,8 +852,22 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
     PubSlots qq[2] = {PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u},                                            \
                       PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}};                                           \
     double pp[2] = {0.0, 0.0};                                                                                                   \
-    if (PK_PUB_ABLATE < 4) pub_gates2(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);                                      \
-    if (PK_PUB_ABLATE < 3) pub_keys2(qq, S[2 * (q)], S[2 * (q) + 1], pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);     \
+    if constexpr (THREADS == kPubSmallThreads) { /* three workgroups per CU: one landmark at a time (168 VGPRs) */                 \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                                           \
+        const PubGateIn g1[1] = {gi[j_]};                                                                                          \
+        PubSlots q1[1] = {qq[j_]};                                                                                                 \
+        double p1[1] = {0.0};                                                                                                      \
+        const Landmark<double>* const l1[1] = {&S[2 * (q) + j_]};                                                                   \
+        if (PK_PUB_ABLATE < 4) pub_gatesN<1>(q1, p1, g1, ex, pub, dump, &wg_flag[cur], sx, sy, sh);                                \
+        if (PK_PUB_ABLATE < 3) pub_keysN<1>(q1, l1, p1, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                      \
+        qq[j_] = q1[0];                                                                                                            \
+        pp[j_] = p1[0];                                                                                                            \
+      }                                                                                                                            \
+    } else {                                                                                                                       \
+      const Landmark<double>* const l2[2] = {&S[2 * (q)], &S[2 * (q) + 1]};                                                        \
+      if (PK_PUB_ABLATE < 4) pub_gatesN<2>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);                                  \
+      if (PK_PUB_ABLATE < 3) pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                        \
+    }                                                                                                                              \
     Q[2 * (q)] = qq[0];                                                                                                          \
     Q[2 * (q) + 1] = qq[1];                                                                                                      \
     pse[2 * (q)] = pp[0];                                                                                                        \
@@ -833,7 +917,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
-    if (PK_PUB_ABLATE < 2) pub_settle_blobs(tid, glist, G, pub, dump, &wg_flag[cur]);
+    if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur]);
     PK_STAMP(s5)
     PK_PSTAMP(4, s4, s5)  // unseen blobs, settling
     lds_barrier();  // B: every winner is marked, every flag is set
@@ -868,10 +952,18 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub(PubArgs a_unused) {
         for (int j = 0; j < 2; ++j) {
           const int i = 2 * q + j;
           const bool imm = immutable[min(l0 + j, L - 1)] != 0;
-          if (PK_PUB_ABLATE < 1) acc += pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
+          if (PK_PUB_ABLATE < 1)
+            acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i])
+                                               : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
         }
         if (l0 < Lp) {
-#ifdef PK_PUB_PLAIN_STORES  // diagnostic variant
+#if defined(PK_PUB_STORE_FLAVOUR)  // diagnostic variants: -DPK_PUB_STORE_FLAVOUR='"sc1"' ...
+#define PK_PUB_STORE(field, F)                                                                                         \
+  {                                                                                                                    \
+    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                                            \
+    asm volatile("global_store_dwordx4 %0, %1, off " PK_PUB_STORE_FLAVOUR ::"v"(df + (size_t)F * Lp + l0), "v"(v) : "memory"); \
+  }
+#elif defined(PK_PUB_PLAIN_STORES)  // diagnostic variant
 #define PK_PUB_STORE(field, F)                                               \
   {                                                                          \
     const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                  \
@@ -931,7 +1023,8 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   if (d.P == 0 || p1 <= p0) return;
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
-    for (const void* fn : {reinterpret_cast<const void*>(k_step_pub<1>), reinterpret_cast<const void*>(k_step_pub<2>)})
+    for (const void* fn : {reinterpret_cast<const void*>(k_step_pub<1, kPubSmallThreads>), reinterpret_cast<const void*>(k_step_pub<1, kPubThreads>),
+                           reinterpret_cast<const void*>(k_step_pub<2, kPubThreads>)})
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess) (void)hipGetLastError();
   }
   PubArgs a;
@@ -971,14 +1064,20 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
       n_cu = 256;
     (void)hipGetLastError();
   }
-  // persistent grid: one workgroup per CU (512 lanes x 256 VGPRs); reserve_cus as in launch_step_regs
-  int64_t grid_n = n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0);
-  if (grid_n > p1 - p0) grid_n = p1 - p0;
+  // persistent grid: one workgroup per CU (512 lanes x 256 VGPRs), three of the 256-lane instance (143 VGPRs; LDS permitting);
+  // reserve_cus as in launch_step_regs
   const size_t lds = step_pub_lds_bytes(B, ecap);
-  if (d.lay.Lp <= 2 * kPubThreads)
-    hipLaunchKernelGGL(k_step_pub<1>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
+  const bool small = d.lay.Lp <= 2 * kPubSmallThreads;
+  int per_cu = 1;
+  if (small) per_cu = (int)std::min<size_t>(3, std::max<size_t>(1, (160 * 1024 - 1024) / (lds + 256)));
+  int64_t grid_n = (int64_t)(n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0)) * per_cu;
+  if (grid_n > p1 - p0) grid_n = p1 - p0;
+  if (small)
+    hipLaunchKernelGGL((k_step_pub<1, kPubSmallThreads>), dim3((unsigned)grid_n), dim3(kPubSmallThreads), lds, s, a);
+  else if (d.lay.Lp <= 2 * kPubThreads)
+    hipLaunchKernelGGL((k_step_pub<1, kPubThreads>), dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
   else
-    hipLaunchKernelGGL(k_step_pub<2>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
+    hipLaunchKernelGGL((k_step_pub<2, kPubThreads>), dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
 }
 
 }  // namespace pk

@@ -157,7 +157,7 @@ size_t fused_lds_bytes(int ncell, int B, int n9, bool exact_lds = false);
 constexpr size_t kFusedMaxLds = 78 * 1024;
 void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, const unsigned short* order_dev,
-                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex);
+                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const unsigned* pub_skipped_dev = nullptr);
 // Candidate lists from a reference particle (k_candidates).  All particles of a filter see the same scan and hold
 // nearly the same map (same initial map, same blobs matched), so the blobs that can pass a landmark's two gates
 // (prkt_core_v2.py:433, :441) are nearly the same for every particle.  Once per scan, for every landmark of ONE
@@ -210,6 +210,7 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
 // both ways (cand.rec, and the inverse lists that launch_cand_entries turns into the publish table's layout: erec, binfo).
 // 512-lane persistent workgroups, four landmarks per lane, two barriers per particle.  Returns at once when *skip != 0.
 int step_pub_entry_capacity(int B);  // publish-table entries that fit LDS beside the scan's tables (0: the scan does not fit)
+int step_pub_entry_capacity_small(int B);  // ... with three 256-lane workgroups per CU (the L <= 512 instance)
 size_t step_pub_lds_bytes(int B, int ecap);
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,

@@ -214,3 +214,24 @@ def test_whole_steps_with_resampling_pub_against_regs(lib):
     assert np.array_equal(outs[0][1][:, :3], outs[1][1][:, :3])
     for x, y in zip(outs[0][2], outs[1][2]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("L,P", [(7, 40), (255, 20), (500, 12), (512, 8)])
+def test_the_256_lane_instance_for_small_maps_is_exact_too(lib, L, P):
+    # "pub_small" = 1: L <= 512 through k_step_pub<256 lanes> (three workgroups per CU) instead of k_step_fused -- not the default
+    # (no faster), kept exact
+    rs = np.random.RandomState(300 + L)
+    means, covs = synthetic_world(L)
+    if L > 20:
+        n = len(means[3::7])
+        means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    blobs = np.vstack([blobs, blobs[:2] + [0.01, 0.5, -0.5, 0.25]])  # two landmarks sighted twice: sequential double updates
+    poses = poses_around(rs, P, 0.2)
+    pub = run(lib, means, covs, poses, blobs, {"pub_small": 1})
+    fused = run(lib, means, covs, poses, blobs)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["route"] == "ml_fused" and pub["published"] and not fused["published"]
+    same_state(pub, fused)
+    same_state(pub, gen, 1e-11)
+    against_oracle(pub, means, covs, poses, blobs)
