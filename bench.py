@@ -87,7 +87,9 @@ ROUTE_KERNEL["ml_regs_pub"] = ("k_step_pub (512 < L <= 2048: a particle's whole 
                                "contested blobs settled by static publish / subscribe through LDS + EKF update + log-weight in ONE pass over the map)")
 ROUTE_KERNEL["ml_fused_pub"] = ("k_step_pub<256 lanes> (L <= 512: two landmarks per lane, three workgroups per CU; association gates + contested blobs settled by "
                                 "static publish / subscribe through LDS + EKF update + log-weight in ONE pass over the map)")
-ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_fused_pub": "step_pub", "ml_regs": "step_regs", "ml_regs_pub": "step_pub", "ml_owner": "step_owner",
+ROUTE_KERNEL["ml_pub_big"] = ("k_step_pub_big (2048 < L <= 6144: two passes over a particle's map, pair by pair -- gates + verdicts published, contested "
+                             "blobs settled through LDS, then rows in again from L2 + EKF update + log-weight + rows out: ONE kernel, no separate association kernel)")
+ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_fused_pub": "step_pub", "ml_regs": "step_regs", "ml_regs_pub": "step_pub", "ml_pub_big": "step_pub_big", "ml_owner": "step_owner",
                      "ml_handoff": "observe_ml", "ml_sweep": "observe_sweep"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_UPDATE = 224  # 14 fp64 read + 14 written per particle.landmark

@@ -339,6 +339,8 @@ enum {
   PK_ROUTE_ML_REGS = 6,      /* k_step_regs: the same in one pass for 512 < L <= 2048, two landmarks per lane */
   PK_ROUTE_DENSE = 8,        /* k_observe_dense: the general dense path (covariances that couple position and colour, or a
                                 coupled Qt): association, 4x4 / 5x5 update and weight in one slow, general kernel */
+  PK_ROUTE_ML_PUB_BIG = 9,   /* k_step_pub_big: maps of 2 049 ... 6 144 landmarks -- publish / subscribe settling in two passes over the map
+                              * (the second one from L2 / Infinity Cache); what it leaves goes through k_observe_sweep */
   PK_ROUTE_ML_OWNER = 7      /* k_step_owner: every landmark settles its own blobs against the rivals named by the
                                 reference particle's candidate lists; no synchronisation inside a particle, any L */
 };

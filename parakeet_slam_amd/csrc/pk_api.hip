@@ -74,6 +74,7 @@ struct AssocLaunch {
   bool regs = false;   // nothing launched yet: k_step_regs does the same for 512 < L <= 2048
   bool retry = false;  // with regs: the hand-off lists for the flagged particles' second chance are allocated
   bool owner = false;  // nothing launched yet: k_step_owner (candidate lists both ways, no barriers), any L
+  bool big = false;    // nothing launched yet: k_step_pub_big (2 048 < L <= 6 144: publish / subscribe in two passes over the map)
   BlobGrid grid{};
   int n9 = 0;
   const unsigned char* tables = nullptr;
@@ -146,6 +147,7 @@ struct pk_filter {
   int pub_small = 0;     // L <= 512: k_step_pub<256 lanes> instead of k_step_fused (measured: the kernel 1 % slower, the step 50 us longer)
   int pub_entry_limit = 0;  // > 0: the publish table is treated as this small (tests: scans whose table "does not fit" fall back to k_step_regs)
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
+  uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
   unsigned* glist_dev = nullptr; // [bcand_cap + 1] the same for the blobs several landmarks list, compacted; then their number
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
@@ -692,6 +694,22 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
       return PK_OK;
     }
+    if (out && want_fast && !finalize && f->fast_observe == 1 && f->pub_step && f->cand_lists && f->d.lay.L > kRegsMaxL &&
+        f->d.lay.L <= kPubBigMaxL && B > 0 && step_pub_big_entry_capacity(B) > 0 && observe_sweep_plan(f->d, B).grid > 0) {
+      // maps beyond the register route: publish / subscribe in two passes (k_step_pub_big); what it flags -- or the whole scan,
+      // when a sixteen-entry list overflows or the publish table does not fit LDS -- goes through the eight-slot hand-off
+      // and k_observe_sweep, then the general kernels
+      if ((rc = ensure_handoff(f, B, kSweepSlots, true))) return rc;
+      out->big = true;
+      out->retry = true;
+      out->grid = g;
+      out->n9 = n9;
+      out->tables = f->scan_dev + o_tab;
+      out->exact = reinterpret_cast<const double*>(f->scan_dev + o_exact);
+      const size_t cs_b = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
+      out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
+      return PK_OK;
+    }
     if (want_fast && !finalize && f->fast_observe && B > 0 &&
         (sweep ? observe_sweep_plan(f->d, B).grid > 0 : observe_fast_lds_bytes(B) <= kMaxDynLds)) {
       // eight hand-off slots per landmark for the large scans (a landmark's colour neighbourhood gets
@@ -947,7 +965,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->binfo_dev, (void*)f->glist_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1287,8 +1305,9 @@ static int dense_observe(pk_filter* f, const double* blobs, int32_t B, const int
 // ---- the one-pass routes (k_step_fused / k_step_regs) in three pieces, so that the sharded filter can run the middle one
 // on a part of the particles while the rest are still on the wire (pk_observe_staged_range) -------------------------------
 // 1. the reference particle's candidate lists (register route), timed with the association
-static int ensure_inverse_lists(pk_filter* f, int B) {
+static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
   int rc;
+  B = B * (slots / kCandSlots);  // (capacity in units of eight-entry lists: sixteen-entry lists take two)
   if (B > f->bcand_cap) {
     PK_HIP(hipStreamSynchronize(f->stream));
     for (void* q : {(void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->binfo_dev, (void*)f->glist_dev})
@@ -1313,6 +1332,24 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
   // the register route; with "pub_small" (off: measured) also the L <= 512 route through the publish /
   // subscribe instance of three 256-lane workgroups per CU
   const bool small_pub = al.fused && f->pub_small && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
+  if (al.big) {  // sixteen-entry lists both ways and the publish table's layout
+    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
+    if (!f->erec_dev2 && (rc = dev_alloc(f, &f->erec_dev2, (size_t)f->d.lay.Lp * 2))) return rc;
+    if ((rc = ensure_inverse_lists(f, B, 2 * kCandSlots))) return rc;
+    int ecap = step_pub_big_entry_capacity(B);
+    if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
+    Span t(f, PK_T_ASSOC);
+    launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
+    launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
+                      2 * kCandSlots, f->out4);
+    launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
+                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots);
+    cand->rec = f->cand_dev;
+    cand->over = ctl_cand_over(f);
+    cand->slots = 2 * kCandSlots;
+    f->pub_ecap = ecap;
+    return PK_OK;
+  }
   if ((al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) || small_pub) {
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
     int ecap = !f->pub_step ? 0 : al.fused ? step_pub_entry_capacity_small(B) : step_pub_entry_capacity(B);
@@ -1347,7 +1384,11 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
   Span t(f, PK_T_OBSERVE);
   ObserveExtras e1 = ex;
   e1.flip = false;
-  if (al.regs) {
+  if (al.big) {
+    launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_pub(f), f->pub_ecap);
+    // a scan the kernel stood back from (a list overflowed, the table did not fit): every particle to the fall-back kernels
+    launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, 0, f->d.P);
+  } else if (al.regs) {
     if (f->pub_ecap > 0 && cand.rec)
       launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
                       p0, p1, reserve_cus);
@@ -1368,7 +1409,7 @@ static int onepass_finish(pk_filter* f, const AssocLaunch& al, int B, const Obse
   FastHandoff fh = f->fh;
   fh.n_flagged = ctl_n_flagged(f);
   fh.flags_only = true;
-  if (al.regs && al.retry) {
+  if ((al.regs || al.big) && al.retry) {
     // second chance for what k_step_regs flagged (some landmark passes more than its four register slots -- 2 us per
     // particle in the general kernels, and up to 9 % of the particles at some poses of the bench's trajectory): the
     // hand-off instance with eight slots and k_observe_sweep, both on the flagged particles only (timed with the other
@@ -1484,6 +1525,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
   ex.gmax_key = ctl_gmax_key(f);
   f->route = al.owner ? PK_ROUTE_ML_OWNER
+             : al.big ? PK_ROUTE_ML_PUB_BIG
              : al.fused ? PK_ROUTE_ML_FUSED
              : al.regs ? PK_ROUTE_ML_REGS
              : !al.fast ? PK_ROUTE_ML_GENERAL
@@ -1518,7 +1560,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
     e2.only_flagged = f->fh.pflag;
     e2.n_flagged = ctl_n_flagged(f);
     launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
-  } else if (al.fused || al.regs) {
+  } else if (al.fused || al.regs || al.big) {
     CandTable cand;
     if ((rc = onepass_prepare(f, al, B, &cand))) return rc;
     if ((rc = onepass_launch(f, al, B, ex, cand, 0, f->d.P))) return rc;
@@ -2282,7 +2324,7 @@ int pk_observe_published(pk_filter* f, int32_t* published) {
   int rc;
   if ((rc = use_device(f))) return rc;
   *published = 0;
-  if (f->scan_dev && (f->route == PK_ROUTE_ML_REGS || f->route == PK_ROUTE_ML_FUSED) && f->pub_ecap > 0) {
+  if (f->scan_dev && (f->route == PK_ROUTE_ML_REGS || f->route == PK_ROUTE_ML_FUSED || f->route == PK_ROUTE_ML_PUB_BIG) && f->pub_ecap > 0) {
     unsigned w = 1u;
     PK_HIP(hipMemcpyAsync(&w, ctl_skip_pub(f), sizeof(w), hipMemcpyDeviceToHost, f->stream));
     PK_HIP(hipStreamSynchronize(f->stream));

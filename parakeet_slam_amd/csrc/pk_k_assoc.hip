@@ -711,7 +711,8 @@ struct CandArgs {
   uint4* rec;           // [Lp][2] (SLOTS = kCandSlots) or [Lp][3] (twice as many)
   unsigned* over;
   unsigned* bcnt;            // [B] entries of each blob's inverse list (cleared by the launcher), or NULL
-  unsigned short* blist;     // [B][kCandSlots] landmarks listing each blob (0xFFFF-filled by the launcher)
+  unsigned short* blist;     // [B][inv_slots] landmarks listing each blob (0xFFFF-filled by the launcher)
+  int inv_slots;             // entries per inverse list: kCandSlots, or as many as SLOTS
   int64_t ref;
   int L, Lp, B;
   const double* pose4;  // sums of x, y, sin h, cos h over the P particles (k_summary_*): the reference POSE is their mean, or NULL
@@ -785,12 +786,12 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
       out[1 + j] = make_uint4((unsigned)c[8 * j + 0] | ((unsigned)c[8 * j + 1] << 16), (unsigned)c[8 * j + 2] | ((unsigned)c[8 * j + 3] << 16),
                               (unsigned)c[8 * j + 4] | ((unsigned)c[8 * j + 5] << 16), (unsigned)c[8 * j + 6] | ((unsigned)c[8 * j + 7] << 16));
     if (n > SLOTS) atomicAdd(a.over, 1u);
-    if (SLOTS == kCandSlots && a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
-      for (int k = 0; k < min(n, kCandSlots); ++k) {
+    if (a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
+      for (int k = 0; k < min(n, SLOTS); ++k) {
         const unsigned t = s_c[lane][k];
         const unsigned m = atomicAdd(&a.bcnt[t], 1u);
-        if (m < (unsigned)kCandSlots)
-          a.blist[(size_t)t * kCandSlots + m] = (unsigned short)l;
+        if (m < (unsigned)a.inv_slots)
+          a.blist[(size_t)t * a.inv_slots + m] = (unsigned short)l;
         else
           atomicAdd(a.over, 1u);
       }
@@ -810,15 +811,13 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
                        unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev, int slots,
                        const double* pose_sums4_dev) {
   if (d.P == 0 || d.lay.Lp == 0) return;
-  if (slots > kCandSlots) {  // the wide records carry no inverse lists
-    bcnt_dev = nullptr;
-    brec_dev = nullptr;
-  }
+  // (inverse lists as wide as the lists themselves: brec_dev holds B x slots u16)
   if (bcnt_dev && brec_dev) {
     (void)hipMemsetAsync(bcnt_dev, 0, (size_t)B * sizeof(unsigned), s);
-    (void)hipMemsetAsync(brec_dev, 0xFF, (size_t)B * sizeof(uint4), s);
+    (void)hipMemsetAsync(brec_dev, 0xFF, (size_t)B * (size_t)slots * sizeof(unsigned short), s);
   }
   CandArgs a;
+  a.inv_slots = slots;
   a.bcnt = brec_dev ? bcnt_dev : nullptr;
   a.blist = reinterpret_cast<unsigned short*>(brec_dev);
   a.ss = slot_source(d);

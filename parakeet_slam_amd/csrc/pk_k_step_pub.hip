@@ -108,10 +108,10 @@ int step_pub_entry_capacity_small(int B) {
 // candidates get their entry index.  Control words: skip_pub (a list overflowed, or more entries than the LDS table
 // holds) and skip_cand (k_step_regs' candidate-list instance stands back when this route runs).
 struct CandEntriesArgs {
-  const uint4* cand;      // [Lp][2]
-  uint4* erec;            // [Lp]
+  const uint4* cand;      // [Lp][1 + SLOTS / 8]
+  unsigned short* erec;   // [Lp][SLOTS]
   unsigned* bcnt;         // [B]
-  uint4* brec;            // [B] 8 x u16, sorted in place
+  unsigned short* brec;   // [B][SLOTS], sorted in place
   unsigned* binfo;        // [B] per blob: first entry | contenders << 16 (scratch of this kernel)
   unsigned* glist;        // [B] the blobs at least two landmarks list, compacted: first entry | contenders << 16; [B] = their number
   const unsigned* over;   // candidate-list overflow
@@ -120,6 +120,8 @@ struct CandEntriesArgs {
   int L, Lp, B, ecap;
 };
 
+// SLOTS: entries per candidate list and per inverse list (kCandSlots, or twice that for the scans of several thousand blobs)
+template <int SLOTS>
 __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   __shared__ unsigned s_part[1024], s_gpart[1024];
   __shared__ unsigned s_total;
@@ -128,13 +130,14 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   const int t0 = tid * chunk, t1 = min(a.B, t0 + chunk);
   unsigned mine = 0, gmine = 0;
   for (int t = t0; t < t1; ++t) {
-    const unsigned n = min(a.bcnt[t], (unsigned)kCandSlots);
-    uint4 w = a.brec[t];
-    unsigned short v[8] = {(unsigned short)(w.x & 0xFFFFu), (unsigned short)(w.x >> 16), (unsigned short)(w.y & 0xFFFFu), (unsigned short)(w.y >> 16),
-                           (unsigned short)(w.z & 0xFFFFu), (unsigned short)(w.z >> 16), (unsigned short)(w.w & 0xFFFFu), (unsigned short)(w.w >> 16)};
-    // insertion sort of eight (empty = 0xFFFF sorts to the back)
+    const unsigned n = min(a.bcnt[t], (unsigned)SLOTS);
+    unsigned short* row = a.brec + (size_t)t * SLOTS;
+    unsigned short v[SLOTS];
 #pragma unroll
-    for (int i = 1; i < 8; ++i)
+    for (int i = 0; i < SLOTS; ++i) v[i] = row[i];
+    // insertion sort (empty = 0xFFFF sorts to the back)
+#pragma unroll
+    for (int i = 1; i < SLOTS; ++i)
 #pragma unroll
       for (int j = i; j > 0; --j)
         if (v[j] < v[j - 1]) {
@@ -142,11 +145,8 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
           v[j] = v[j - 1];
           v[j - 1] = x;
         }
-    w.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
-    w.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
-    w.z = (unsigned)v[4] | ((unsigned)v[5] << 16);
-    w.w = (unsigned)v[6] | ((unsigned)v[7] << 16);
-    a.brec[t] = w;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) row[i] = v[i];
     mine += n >= 2u ? n : 0u;
     gmine += n >= 2u ? 1u : 0u;
   }
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   {
     unsigned run = s_part[tid], grun = s_gpart[tid];
     for (int t = t0; t < t1; ++t) {
-      const unsigned n = min(a.bcnt[t], (unsigned)kCandSlots);
+      const unsigned n = min(a.bcnt[t], (unsigned)SLOTS);
       const unsigned c = n >= 2u ? n : 0u;
       a.binfo[t] = (run & 0xFFFFu) | (n << 16);
       if (n >= 2u) a.glist[grun++] = (run & 0xFFFFu) | (n << 16);
@@ -183,41 +183,38 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   }
   __syncthreads();  // brec / binfo written above are read below by other threads of this (the only) workgroup
   __threadfence_block();
+  constexpr int RW = 1 + SLOTS / 8;  // uint4 per landmark record
   for (int l = tid; l < a.Lp; l += 1024) {
-    const uint4 cw = a.cand[2 * (size_t)l + 1];
-    const unsigned cws[4] = {cw.x, cw.y, cw.z, cw.w};
-    unsigned short e[8];
+    const unsigned* cws = reinterpret_cast<const unsigned*>(a.cand + RW * (size_t)l + 1);
+    unsigned short* e = a.erec + (size_t)l * SLOTS;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < SLOTS; ++k) {
       const unsigned t = (cws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
       unsigned ev = 0xFFFFu;
       if (l < a.L && t != 0xFFFFu && fits) {
         const unsigned bi = __hip_atomic_load(&a.binfo[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned n = bi >> 16;
         if (n >= 2u) {
-          const uint4 bw = a.brec[t];
-          const unsigned bws[4] = {bw.x, bw.y, bw.z, bw.w};
+          const unsigned short* row = a.brec + (size_t)t * SLOTS;
           unsigned rank = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) rank += ((bws[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) < (unsigned)l ? 1u : 0u;
+          for (int j = 0; j < SLOTS; ++j) rank += (unsigned)row[j] < (unsigned)l ? 1u : 0u;
           ev = (bi & 0xFFFFu) + rank;
         }
       }
       e[k] = (unsigned short)ev;
     }
-    a.erec[l] = make_uint4((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16),
-                           (unsigned)e[4] | ((unsigned)e[5] << 16), (unsigned)e[6] | ((unsigned)e[7] << 16));
   }
 }
 
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
-                         unsigned* skip_cand_dev, int ecap) {
+                         unsigned* skip_cand_dev, int ecap, int slots) {
   CandEntriesArgs a;
   a.cand = cand_dev;
-  a.erec = erec_dev;
+  a.erec = reinterpret_cast<unsigned short*>(erec_dev);
   a.bcnt = bcnt_dev;
-  a.brec = brec_dev;
+  a.brec = reinterpret_cast<unsigned short*>(brec_dev);
   a.binfo = binfo_dev;
   a.glist = glist_dev;
   a.over = over_dev;
@@ -227,7 +224,10 @@ void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4
   a.Lp = d.lay.Lp;
   a.B = B;
   a.ecap = ecap;
-  hipLaunchKernelGGL(k_cand_entries, dim3(1), dim3(1024), 0, s, a);
+  if (slots > kCandSlots)
+    hipLaunchKernelGGL(k_cand_entries<2 * kCandSlots>, dim3(1), dim3(1024), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_cand_entries<kCandSlots>, dim3(1), dim3(1024), 0, s, a);
 }
 
 // ------------------------------------------------------------------ per-landmark pieces of k_step_pub
@@ -237,17 +237,23 @@ void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4
 //
 // What a lane keeps about one landmark's (<= 4) gate-passing blobs between the phases: per slot blob | entry << 16
 // (0xFFFF: none / no other landmark lists the blob), most recent first, empty slots at the back.
-struct PubSlots {
-  unsigned s0, s1, s2, s3;
+template <int SL>
+struct PubSlotsT {
+  unsigned s[SL];
   unsigned st;  // 4 bits per slot: 1 probability > 0, 4 take
 };
-__device__ __forceinline__ void pub_rotate(PubSlots& q) {  // slot 0 goes to the back, its state bits with it
-  const unsigned w = q.s0;
-  q.s0 = q.s1;
-  q.s1 = q.s2;
-  q.s2 = q.s3;
-  q.s3 = w;
-  q.st = ((q.st >> 4) | (q.st << 12)) & 0xFFFFu;
+using PubSlots = PubSlotsT<kPubSlots>;
+constexpr PubSlots kPubNoSlots = {{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, 0u};
+template <int SL>
+__device__ __forceinline__ void pub_rotate(PubSlotsT<SL>& q) {  // slot 0 goes to the back, its state bits with it
+  const unsigned w = q.s[0];
+#pragma unroll
+  for (int k = 0; k + 1 < SL; ++k) q.s[k] = q.s[k + 1];
+  q.s[SL - 1] = w;
+  if constexpr (SL == 8)
+    q.st = (q.st >> 4) | (q.st << 28);
+  else
+    q.st = ((q.st >> 4) | (q.st << (4 * SL - 4))) & ((1u << (4 * SL)) - 1u);
 }
 
 __device__ __forceinline__ double pub_inf() { return __longlong_as_double(0x7FF0000000000000ll); }
@@ -258,17 +264,20 @@ __device__ __forceinline__ double pub_inf() { return __longlong_as_double(0x7FF0
 // published as "not a contender" on the spot (a passing one's entry is overwritten by pub_keys).  dump: the table's spare
 // entry.  has: the landmark exists (lanes beyond the map carry empty lists).
 struct PubGateIn {
-  uint4 ref, cw, ew;
+  uint4 ref;
+  uint4 cw[2], ew[2];  // the candidate blobs and their publish entries, 16 bits each ([1] only with sixteen-entry lists)
   double mx, my, mr, mg, mb;
   bool has;
 };
-template <int N>
-__device__ __forceinline__ void pub_gatesN(PubSlots (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
+// N: landmarks worked on side by side; W4: uint4 words per list (1: eight candidates, 2: sixteen)
+template <int N, int W4 = 1, int SL = kPubSlots>
+__device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
                                            double* pub, unsigned dump, int* flag, double sx, double sy, double sh) {
+  constexpr int NW = 4 * W4;  // 32-bit words per list, two candidates each
   double eb[N];
   bool inside[N];
-  unsigned c0[N], c1[N], c2[N], c3[N], e0[N], e1[N], e2[N], e3[N];
-  unsigned s0[N], s1[N], s2[N], s3[N];
+  unsigned c[N][NW], e[N][NW];
+  unsigned sl[N][SL];
   float dmin[N];  // colour distance of the blob in slot 0: the best colour match stands in front (pub_keys)
   int npass[N];
 #pragma unroll
@@ -284,36 +293,40 @@ __device__ __forceinline__ void pub_gatesN(PubSlots (&q)[N], double (&pse_out)[N
                 fabs(in[j].mg - (double)__uint_as_float(in[j].ref.z)) <= kCandColour &&
                 fabs(in[j].mb - (double)__uint_as_float(in[j].ref.w)) <= kCandColour;
     // the list is filled from the front; a landmark beyond the map has none
-    c0[j] = in[j].has ? in[j].cw.x : 0xFFFFFFFFu;
-    c1[j] = in[j].cw.y;
-    c2[j] = in[j].cw.z;
-    c3[j] = in[j].cw.w;
-    e0[j] = in[j].ew.x;
-    e1[j] = in[j].ew.y;
-    e2[j] = in[j].ew.z;
-    e3[j] = in[j].ew.w;
-    s0[j] = s1[j] = s2[j] = s3[j] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < W4; ++w) {
+      c[j][4 * w + 0] = in[j].cw[w].x;
+      c[j][4 * w + 1] = in[j].cw[w].y;
+      c[j][4 * w + 2] = in[j].cw[w].z;
+      c[j][4 * w + 3] = in[j].cw[w].w;
+      e[j][4 * w + 0] = in[j].ew[w].x;
+      e[j][4 * w + 1] = in[j].ew[w].y;
+      e[j][4 * w + 2] = in[j].ew[w].z;
+      e[j][4 * w + 3] = in[j].ew[w].w;
+    }
+    c[j][0] = in[j].has ? c[j][0] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) sl[j][k] = 0xFFFFFFFFu;
     dmin[j] = 3.0e38f;
     npass[j] = 0;
   }
 #pragma unroll 1
-  for (int k = 0; k < kCandSlots; k += 2) {
-    unsigned call = c0[0];
+  for (int k = 0; k < NW; ++k) {
+    unsigned call = c[0][0];
 #pragma unroll
-    for (int j = 1; j < N; ++j) call &= c0[j];
+    for (int j = 1; j < N; ++j) call &= c[j][0];
     if (__ballot((call & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: every list is through
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const unsigned ta = c0[j] & 0xFFFFu, tb = c0[j] >> 16;
-      const unsigned ea = e0[j] & 0xFFFFu, eb2 = e0[j] >> 16;  // (0xFFFF where the blob is: k_cand_entries)
-      c0[j] = c1[j];
-      c1[j] = c2[j];
-      c2[j] = c3[j];
-      c3[j] = 0xFFFFFFFFu;
-      e0[j] = e1[j];
-      e1[j] = e2[j];
-      e2[j] = e3[j];
-      e3[j] = 0xFFFFFFFFu;
+      const unsigned ta = c[j][0] & 0xFFFFu, tb = c[j][0] >> 16;
+      const unsigned ea = e[j][0] & 0xFFFFu, eb2 = e[j][0] >> 16;  // (0xFFFF where the blob is: k_cand_entries)
+#pragma unroll
+      for (int w = 0; w + 1 < NW; ++w) {
+        c[j][w] = c[j][w + 1];
+        e[j][w] = e[j][w + 1];
+      }
+      c[j][NW - 1] = 0xFFFFFFFFu;
+      e[j][NW - 1] = 0xFFFFFFFFu;
       const bool va = ta != 0xFFFFu, vb = tb != 0xFFFFu;
       const double* ra = ex + 6 * (va ? ta : 0u);
       const double* rb = ex + 6 * (vb ? tb : 0u);
@@ -332,19 +345,19 @@ __device__ __forceinline__ void pub_gatesN(PubSlots (&q)[N], double (&pse_out)[N
       {
         const float d = (float)cda;
         const bool front = pa && d < dmin[j];
-        s3[j] = pa ? s2[j] : s3[j];
-        s2[j] = pa ? s1[j] : s2[j];
-        s1[j] = pa ? (front ? s0[j] : wa) : s1[j];
-        s0[j] = front ? wa : s0[j];
+#pragma unroll
+        for (int k = SL - 1; k >= 2; --k) sl[j][k] = pa ? sl[j][k - 1] : sl[j][k];
+        sl[j][1] = pa ? (front ? sl[j][0] : wa) : sl[j][1];
+        sl[j][0] = front ? wa : sl[j][0];
         dmin[j] = front ? d : dmin[j];
       }
       {
         const float d = (float)cdb;
         const bool front = pb && d < dmin[j];
-        s3[j] = pb ? s2[j] : s3[j];
-        s2[j] = pb ? s1[j] : s2[j];
-        s1[j] = pb ? (front ? s0[j] : wb) : s1[j];
-        s0[j] = front ? wb : s0[j];
+#pragma unroll
+        for (int k = SL - 1; k >= 2; --k) sl[j][k] = pb ? sl[j][k - 1] : sl[j][k];
+        sl[j][1] = pb ? (front ? sl[j][0] : wb) : sl[j][1];
+        sl[j][0] = front ? wb : sl[j][0];
         dmin[j] = front ? d : dmin[j];
       }
       npass[j] += (pa ? 1 : 0) + (pb ? 1 : 0);
@@ -352,11 +365,9 @@ __device__ __forceinline__ void pub_gatesN(PubSlots (&q)[N], double (&pse_out)[N
   }
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    if (in[j].has && (!inside[j] || npass[j] > kPubSlots)) *flag = 1;
-    q[j].s0 = s0[j];
-    q[j].s1 = s1[j];
-    q[j].s2 = s2[j];
-    q[j].s3 = s3[j];
+    if (in[j].has && (!inside[j] || npass[j] > SL)) *flag = 1;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) q[j].s[k] = sl[j][k];
     q[j].st = 0u;
   }
 }
@@ -372,14 +383,14 @@ __device__ __forceinline__ double pub_recip(double x) {
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
-template <int N>
-__device__ __forceinline__ void pub_keysN(PubSlots (&q)[N], const Landmark<double>* const (&lmp)[N],
+template <int N, int SL = kPubSlots>
+__device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
                                           unsigned anydump, int* flag, double sx, double sy) {
   {
-    unsigned sall = q[0].s0;
+    unsigned sall = q[0].s[0];
 #pragma unroll
-    for (int j = 1; j < N; ++j) sall &= q[j].s0;
+    for (int j = 1; j < N; ++j) sall &= q[j].s[0];
     if (__ballot((sall & 0xFFFFu) != 0xFFFFu) == 0ull) return;  // wave-uniform: nobody's landmark passes a blob
   }
   constexpr double ln2 = 0.69314718055994530942;
@@ -418,10 +429,10 @@ __device__ __forceinline__ void pub_keysN(PubSlots (&q)[N], const Landmark<doubl
   }
   int done = 0;
 #pragma unroll 1
-  for (; done < kPubSlots; ++done) {
-    unsigned sall = q[0].s0;
+  for (; done < SL; ++done) {
+    unsigned sall = q[0].s[0];
 #pragma unroll
-    for (int j = 1; j < N; ++j) sall &= q[j].s0;
+    for (int j = 1; j < N; ++j) sall &= q[j].s[0];
     if (__ballot((sall & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: every landmark is through
     unsigned t[N], e[N];
     bool valid[N], far[N], positive[N];
@@ -431,8 +442,8 @@ __device__ __forceinline__ void pub_keysN(PubSlots (&q)[N], const Landmark<doubl
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       const Landmark<double>& lm = *lmp[j];
-      t[j] = q[j].s0 & 0xFFFFu;
-      e[j] = q[j].s0 >> 16;
+      t[j] = q[j].s[0] & 0xFFFFu;
+      e[j] = q[j].s[0] >> 16;
       valid[j] = t[j] != 0xFFFFu;
       rec[j] = ex + 6 * (valid[j] ? t[j] : 0u);
       z01[j] = *reinterpret_cast<const double2*>(rec[j]);
@@ -502,7 +513,7 @@ __device__ __forceinline__ void pub_keysN(PubSlots (&q)[N], const Landmark<doubl
       pub_rotate(q[j]);
     }
   }
-  for (; done < kPubSlots; ++done) {  // wave-uniform trip count: back to the original order
+  for (; done < SL; ++done) {  // wave-uniform trip count: back to the original order
 #pragma unroll
     for (int j = 0; j < N; ++j) pub_rotate(q[j]);
   }
@@ -517,7 +528,7 @@ __device__ __forceinline__ void pub_keysN(PubSlots (&q)[N], const Landmark<doubl
 // flagged and the general kernels compare probabilities.  (A first version let every landmark's lane read its rivals'
 // entries one after the other: 40 % of the kernel's time went into those dependent LDS round trips.)
 __device__ __forceinline__ double pub_marker() { return __longlong_as_double((long long)0xFFF0000000000000ull); }
-template <int THREADS>
+template <int THREADS, int SLOTS = kCandSlots>
 __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist, unsigned G, double* pub, unsigned dump, int* flag) {
   bool doubt = false;
 #pragma unroll 1
@@ -525,13 +536,13 @@ __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist,
     const bool on = g < G;
     const unsigned gi = glist[on ? g : 0u];
     const unsigned offs = gi & 0xFFFFu, n = on ? (gi >> 16) : 0u;
-    double v[kCandSlots];
+    double v[SLOTS];
 #pragma unroll
-    for (int r = 0; r < kCandSlots; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
+    for (int r = 0; r < SLOTS; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
     double best = pub_inf();
     unsigned wr = 0u;
 #pragma unroll
-    for (int r = 0; r < kCandSlots; ++r) {
+    for (int r = 0; r < SLOTS; ++r) {
       v[r] = (unsigned)r < n ? v[r] : pub_inf();
       const bool better = v[r] < best;  // strict: on equal keys the earlier rank stays (:377)
       wr = better ? (unsigned)r : wr;
@@ -540,7 +551,7 @@ __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist,
     int contenders = 0;
     bool close = false;
 #pragma unroll
-    for (int r = 0; r < kCandSlots; ++r) {
+    for (int r = 0; r < SLOTS; ++r) {
       contenders += v[r] < pub_inf() ? 1 : 0;
       close |= v[r] != best && v[r] - best < 1e-7;  // within 1e-7 of the winner without being identical to it
     }
@@ -553,7 +564,7 @@ __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist,
 // Which of its blobs this landmark takes: those it passes with probability > 0 and either nobody else lists, or whose
 // entry carries the winner's marker.
 __device__ __forceinline__ void pub_take(PubSlots& q, const double* pub, unsigned dump) {
-  const unsigned sw[kPubSlots] = {q.s0, q.s1, q.s2, q.s3};
+  const unsigned sw[kPubSlots] = {q.s[0], q.s[1], q.s[2], q.s[3]};
   double m[kPubSlots];
 #pragma unroll
   for (int s = 0; s < kPubSlots; ++s) {
@@ -577,7 +588,7 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
   if (__ballot((tk & (tk - 1u)) != 0u) == 0ull) {
     // wave-uniform, the usual case: no landmark takes more than one blob -- no scan-order sort, no loop
     if (tk != 0u) {
-      const unsigned w = (tk & 0x0004u) ? q.s0 : (tk & 0x0040u) ? q.s1 : (tk & 0x0400u) ? q.s2 : q.s3;
+      const unsigned w = (tk & 0x0004u) ? q.s[0] : (tk & 0x0040u) ? q.s[1] : (tk & 0x0400u) ? q.s[2] : q.s[3];
       const double* rec = ex + 6 * (w & 0xFFFFu);
       const double2 z01 = *reinterpret_cast<const double2*>(rec);
       const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
@@ -586,7 +597,7 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
     }
     return acc;
   }
-  const unsigned sw[kPubSlots] = {q.s0, q.s1, q.s2, q.s3};
+  const unsigned sw[kPubSlots] = {q.s[0], q.s[1], q.s[2], q.s[3]};
   unsigned key[kPubSlots];
 #pragma unroll
   for (int s = 0; s < kPubSlots; ++s) {
@@ -638,10 +649,10 @@ __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double
     if (__ballot(tk != 0u) == 0ull) break;  // wave-uniform
     unsigned w, bit;
     if (__ballot((tk & (tk - 1u)) != 0u) == 0ull) {  // wave-uniform, the usual case: at most one blob left per landmark
-      w = (tk & 0x0004u) ? q.s0 : (tk & 0x0040u) ? q.s1 : (tk & 0x0400u) ? q.s2 : q.s3;
+      w = (tk & 0x0004u) ? q.s[0] : (tk & 0x0040u) ? q.s[1] : (tk & 0x0400u) ? q.s[2] : q.s[3];
       bit = tk;
     } else {  // the one that comes first in the scan
-      const unsigned sw[kPubSlots] = {q.s0, q.s1, q.s2, q.s3};
+      const unsigned sw[kPubSlots] = {q.s[0], q.s[1], q.s[2], q.s[3]};
       unsigned best = 0xFFFFFFFFu;
       w = 0u;
       bit = 0u;
@@ -845,12 +856,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #define PK_PUB_PAIR(q)                                                                                                           \
   {                                                                                                                              \
     const int l0 = 2 * kPubThreads * (q) + 2 * tid;                                                                              \
-    const PubGateIn gi[2] = {{cref[2 * (q)], ccw[2 * (q)], cew[2 * (q)], S[2 * (q)].mx, S[2 * (q)].my, S[2 * (q)].mr, S[2 * (q)].mg, \
-                              S[2 * (q)].mb, l0 < L},                                                                            \
-                             {cref[2 * (q) + 1], ccw[2 * (q) + 1], cew[2 * (q) + 1], S[2 * (q) + 1].mx, S[2 * (q) + 1].my,         \
-                              S[2 * (q) + 1].mr, S[2 * (q) + 1].mg, S[2 * (q) + 1].mb, l0 + 1 < L}};                               \
-    PubSlots qq[2] = {PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u},                                            \
-                      PubSlots{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u}};                                           \
+    const PubGateIn gi[2] = {{cref[2 * (q)], {ccw[2 * (q)], ccw[2 * (q)]}, {cew[2 * (q)], cew[2 * (q)]}, S[2 * (q)].mx, S[2 * (q)].my,    \
+                              S[2 * (q)].mr, S[2 * (q)].mg, S[2 * (q)].mb, l0 < L},                                               \
+                             {cref[2 * (q) + 1], {ccw[2 * (q) + 1], ccw[2 * (q) + 1]}, {cew[2 * (q) + 1], cew[2 * (q) + 1]},       \
+                              S[2 * (q) + 1].mx, S[2 * (q) + 1].my, S[2 * (q) + 1].mr, S[2 * (q) + 1].mg, S[2 * (q) + 1].mb,       \
+                              l0 + 1 < L}};                                                                                      \
+    PubSlots qq[2] = {kPubNoSlots,                                            \
+                      kPubNoSlots};                                           \
     double pp[2] = {0.0, 0.0};                                                                                                   \
     if constexpr (THREADS == kPubSmallThreads) { /* three workgroups per CU: one landmark at a time (168 VGPRs) */                 \
       _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                                           \
@@ -1014,6 +1026,362 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   if ((tid0 & 63) == 0)
     for (int k = 0; k < 10; ++k) atomicAdd(&pk_pstamp_acc[k], pst[k]);
 #endif
+}
+
+// ------------------------------------------------------------------ maps beyond 2 048 landmarks: the same, in two passes
+// A particle of 5 000 landmarks is 1.16 MB of state: it fits neither the CU's registers nor its LDS, so the map cannot stay
+// on chip between the verdicts and the updates.  k_step_pub_big walks the map twice, pair by pair (1 024 landmarks a turn):
+//   pass 1  rows in -> gates -> verdicts published -- the rows are dropped, what stays in registers is the seven words per
+//           landmark the second pass needs (the gate-passing blobs with their entries, the expected bearing);
+//   barriers, blob-parallel settling, markers (as in k_step_pub);
+//   pass 2  rows in again (L2 / Infinity Cache: the same workgroup read them microseconds ago) -> updates -> rows out.
+// HBM sees the state once on the way in (the second read is a cache hit, which the FETCH_SIZE counter still counts) and once
+// on the way out.  The scan's exact records (48 B x B: 240 KB at 5 000 blobs) do not fit LDS beside the publish table; they
+// are read from L2.  Candidate and inverse lists of sixteen entries (eight overflow somewhere in every scan of several
+// thousand blobs).  NCH: pairs per lane, Lp <= 1 024 NCH.
+constexpr int kPubBigSlots = 2 * kCandSlots;
+// Gate-passing blobs a landmark may have in pass 1: among several thousand random colours some landmark of every particle
+// passes five to seven.  Only those with a probability > 0 -- once the colour blocks have tightened,
+// the landmark's own blob and the odd look-alike -- are carried to pass 2, at most kPubSlots of them.
+constexpr int kPubBigGateSlots = 8;
+__device__ __forceinline__ PubSlots pub_keep_positive(const PubSlotsT<kPubBigGateSlots>& g, int* flag) {
+  PubSlots o = kPubNoSlots;
+#pragma unroll
+  for (int k = kPubBigGateSlots - 1; k >= 0; --k) {  // (back to front: the order of the slots is kept)
+    const bool pos = ((g.st >> (4 * k)) & 1u) != 0u;
+    o.s[3] = pos ? o.s[2] : o.s[3];
+    o.s[2] = pos ? o.s[1] : o.s[2];
+    o.s[1] = pos ? o.s[0] : o.s[1];
+    o.s[0] = pos ? g.s[k] : o.s[0];
+    o.st = pos ? ((o.st << 4) | 1u) : o.st;
+  }
+  if (__popc(g.st & 0x11111111u) > kPubSlots) *flag = 1;
+  return o;
+}
+__host__ __device__ inline size_t pub_big_fixed_lds_bytes(int B) {
+  const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
+  return 16 + Bp * 4 + Bp * 2 + 2 * (Bp + 16);
+}
+int step_pub_big_entry_capacity(int B) {
+  const size_t fixed = pub_big_fixed_lds_bytes(B);
+  if (fixed + 64 * 8 > kMaxDynLds) return 0;
+  const size_t e = (kMaxDynLds - fixed) / 8;
+  return (int)(e > 65534 ? 65534 : e);
+}
+size_t step_pub_big_lds_bytes(int B, int ecap) { return pub_big_fixed_lds_bytes(B) + (size_t)ecap * 8; }
+
+template <int NCH>
+__global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double red[2][kPubThreads / kWave];
+  __shared__ int wg_flag[2];
+  constexpr int kPubWaves = kPubThreads / kWave;
+  PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  const int tid0 = threadIdx.x;
+  int B, Lp, L, ecap;
+  {
+    PubArgsPtr R = pub_args_now(rp);
+    if (*R->skip != 0u) return;  // workgroup-uniform: another route takes this scan
+    B = R->B;
+    Lp = R->Lp;
+    L = R->L;
+    ecap = R->ecap;
+  }
+  const unsigned Bp = ((unsigned)B + 15u) & ~15u;
+  // LDS offsets (bytes): pub (ecap + 2 entries) | glist | order | any[2][Bp + 16]
+  const unsigned o_glist = ((unsigned)ecap + 2u) * 8u, o_order = o_glist + Bp * 4u, o_any = o_order + Bp * 2u;
+  const unsigned dump = (unsigned)ecap, anydump = Bp;
+  unsigned G;
+  {
+    const int tid = tid0;
+    PubArgsPtr R = pub_args_now(rp);
+    unsigned* glist = reinterpret_cast<unsigned*>(smem + o_glist);
+    unsigned short* order = reinterpret_cast<unsigned short*>(smem + o_order);
+    const unsigned* gb = R->glist;
+    const unsigned short* go = R->order;
+    G = gb[B];
+    for (int i = tid; i < B; i += kPubThreads) {
+      glist[i] = (unsigned)i < G ? gb[i] : 0u;
+      order[i] = go[i];
+    }
+    for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
+    if (tid == 0) {
+      wg_flag[0] = 0;
+      wg_flag[1] = 0;
+    }
+  }
+  __syncthreads();
+
+  int64_t prev = -1;
+  int cur = 0;
+  for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    double* pub = reinterpret_cast<double*>(smem);
+    const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_glist);
+    const unsigned short* order = reinterpret_cast<const unsigned short*>(smem + o_order);
+    unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
+    PubSlots Q[2 * NCH];
+    double pse[2 * NCH];
+    bool done;
+    {
+      PubArgsPtr R = pub_args_now(rp);
+      done = p >= R->P;
+    }
+    // the rows of the pair at landmark lb_ of this particle's source slot
+#define PK_BIG_ROWS(SA, SB, lb_)                                                                      \
+  {                                                                                                   \
+    PubArgsPtr R2 = pub_args_now(rp);                                                                 \
+    const SlotSource ss_ = pub_slot_source(R2);                                                       \
+    const unsigned char* sslot_ = ss_.at(regs_source_pub(R2->src, p));                                \
+    const double* sf_ = reinterpret_cast<const double*>(sslot_);                                      \
+    const int* sc_ = reinterpret_cast<const int*>(sslot_ + R2->count_off);                            \
+    PK_BIG_LOAD(SA, SB, mx, F_MX, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, my, F_MY, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, mr, F_MR, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, mg, F_MG, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, mb, F_MB, lb_)                                                                \
+    asm volatile("" ::: "memory");                                                                    \
+    PK_BIG_LOAD(SA, SB, pxx, F_PXX, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, pxy, F_PXY, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, pyy, F_PYY, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, crr, F_CRR, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, crg, F_CRG, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, crb, F_CRB, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, cgg, F_CGG, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, cgb, F_CGB, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, cbb, F_CBB, lb_)                                                              \
+    const Int2 c_ = *reinterpret_cast<const Int2*>(sc_ + (lb_));                                      \
+    SA.count = c_.x;                                                                                  \
+    SB.count = c_.y;                                                                                  \
+    asm volatile("" ::: "memory");                                                                    \
+  }
+#define PK_BIG_LOAD(SA, SB, field, F, lb_)                                                            \
+  {                                                                                                   \
+    const Double2 v_ = *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_));               \
+    SA.field = v_.x;                                                                                  \
+    SB.field = v_.y;                                                                                  \
+  }
+    // ---- pass 1: gates and verdicts, pair by pair
+#define PK_BIG_PASS1(q)                                                                                                       \
+  if (NCH > (q) && 2 * kPubThreads * (q) < Lp) { /* workgroup-uniform */                                                      \
+    const int l0 = 2 * kPubThreads * (q) + 2 * tid;                                                                           \
+    const int lb = min(l0, Lp - 2);                                                                                           \
+    PubArgsPtr R = pub_args_now(rp);                                                                                          \
+    const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);                             \
+    const uint4* cr = R->cand + 3 * (size_t)lb;                                                                               \
+    const uint4* er = R->erec + 2 * (size_t)lb;                                                                               \
+    PubGateIn gi[2];                                                                                                          \
+    gi[0].ref = cr[0];                                                                                                        \
+    gi[0].cw[0] = cr[1];                                                                                                      \
+    gi[0].cw[1] = cr[2];                                                                                                      \
+    gi[1].ref = cr[3];                                                                                                        \
+    gi[1].cw[0] = cr[4];                                                                                                      \
+    gi[1].cw[1] = cr[5];                                                                                                      \
+    gi[0].ew[0] = er[0];                                                                                                      \
+    gi[0].ew[1] = er[1];                                                                                                      \
+    gi[1].ew[0] = er[2];                                                                                                      \
+    gi[1].ew[1] = er[3];                                                                                                      \
+    asm volatile("" ::: "memory");                                                                                            \
+    Landmark<double> SA, SB;                                                                                                  \
+    PK_BIG_ROWS(SA, SB, lb)                                                                                                   \
+    gi[0].mx = SA.mx;                                                                                                         \
+    gi[0].my = SA.my;                                                                                                         \
+    gi[0].mr = SA.mr;                                                                                                         \
+    gi[0].mg = SA.mg;                                                                                                         \
+    gi[0].mb = SA.mb;                                                                                                         \
+    gi[0].has = l0 < L;                                                                                                       \
+    gi[1].mx = SB.mx;                                                                                                         \
+    gi[1].my = SB.my;                                                                                                         \
+    gi[1].mr = SB.mr;                                                                                                         \
+    gi[1].mg = SB.mg;                                                                                                         \
+    gi[1].mb = SB.mb;                                                                                                         \
+    gi[1].has = l0 + 1 < L;                                                                                                   \
+    PubSlotsT<kPubBigGateSlots> qq[2];                                                                                        \
+    double pp[2] = {0.0, 0.0};                                                                                                \
+    const Landmark<double>* const l2[2] = {&SA, &SB};                                                                         \
+    pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);                                             \
+    pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                       \
+    Q[2 * (q)] = pub_keep_positive(qq[0], &wg_flag[cur]);                                                                     \
+    Q[2 * (q) + 1] = pub_keep_positive(qq[1], &wg_flag[cur]);                                                                 \
+    pse[2 * (q)] = pp[0];                                                                                                     \
+    pse[2 * (q) + 1] = pp[1];                                                                                                 \
+  } else if (NCH > (q)) {                                                                                                     \
+    Q[2 * (q)] = Q[2 * (q) + 1] = kPubNoSlots;                             \
+    pse[2 * (q)] = pse[2 * (q) + 1] = 0.0;                                                                                    \
+  }
+    if (!done) {
+      PK_BIG_PASS1(0)
+      PK_BIG_PASS1(1)
+      PK_BIG_PASS1(2)
+      PK_BIG_PASS1(3)
+      PK_BIG_PASS1(4)
+      PK_BIG_PASS1(5)
+      PK_BIG_PASS1(6)
+      PK_BIG_PASS1(7)
+    }
+#undef PK_BIG_PASS1
+    lds_barrier();  // A: every verdict of this particle is in the table
+    if (prev >= 0 && tid == 0) {  // the previous particle's log-weight (its partial sums were written before A)
+      PubArgsPtr R = pub_args_now(rp);
+      double tot = red[cur ^ 1][0];
+#pragma unroll
+      for (int i = 1; i < kPubWaves; ++i) tot += red[cur ^ 1][i];
+      double* logw = R->logw;
+      const double w = (R->reset ? 0.0 : logw[prev]) + tot;
+      logw[prev] = w;
+      unsigned long long* gk = R->gmax_key;
+      if (gk) atomicMax(gk + (prev & (kGmaxKeys - 1)), double_to_key(w));
+      R->src[prev] = (int32_t)prev;
+    }
+    if (done) break;
+    prev = -1;
+    double acc;
+    {
+      int nun = 0;
+      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) {
+        const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
+      }
+      acc = (double)nun * Consts<double>::log_no_match;  // unseen features: weight *= 0.1 each (:94-95)
+      unsigned* anyn = reinterpret_cast<unsigned*>(smem + o_any + (unsigned)(cur ^ 1) * (Bp + 16u));
+      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
+      if (tid == 0) wg_flag[cur ^ 1] = 0;
+    }
+    pub_settle_blobs<kPubThreads, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur]);
+    lds_barrier();  // B: every winner is marked, every flag is set
+#pragma unroll
+    for (int i = 0; i < 2 * NCH; ++i) pub_take(Q[i], pub, dump);
+    lds_barrier();  // C: every marker has been read -- the table is the next particle's
+    if (wg_flag[cur]) {  // workgroup-uniform: nothing has been written; the fall-back kernels take the particle
+      if (tid == 0) {
+        PubArgsPtr R = pub_args_now(rp);
+        R->pflag_out[p] = 1;
+        atomicAdd(R->n_flagged, 1u);
+      }
+      continue;
+    }
+    if (tid == 0) pub_args_now(rp)->pflag_out[p] = 0;
+    // ---- pass 2: rows in again, updates in scan order, rows out
+#define PK_BIG_PASS2(q)                                                                                                       \
+  if (NCH > (q) && 2 * kPubThreads * (q) < Lp) { /* workgroup-uniform */                                                      \
+    const int l0 = 2 * kPubThreads * (q) + 2 * tid;                                                                           \
+    const int lb = min(l0, Lp - 2);                                                                                           \
+    Landmark<double> SA, SB;                                                                                                  \
+    PK_BIG_ROWS(SA, SB, lb)                                                                                                   \
+    PubArgsPtr R = pub_args_now(rp);                                                                                          \
+    const Noise<double> qt = pub_noise(R);                                                                                    \
+    const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);                                                        \
+    const unsigned char* immutable = R->immutable;                                                                            \
+    acc += pub_apply_loop(Q[2 * (q)], R->exact, order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[2 * (q)]);          \
+    acc += pub_apply_loop(Q[2 * (q) + 1], pub_args_now(rp)->exact, order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, \
+                          pse[2 * (q) + 1]);                                                                                  \
+    if (l0 < Lp) {                                                                                                            \
+      PubArgsPtr R3 = pub_args_now(rp);                                                                                       \
+      unsigned char* dslot = R3->map_dst + (size_t)p * R3->ss.slot_bytes;                                                     \
+      double* df = reinterpret_cast<double*>(dslot);                                                                          \
+      int* dc = reinterpret_cast<int*>(dslot + R3->count_off);                                                                \
+      PK_BIG_STORE(mx, F_MX)                                                                                                  \
+      PK_BIG_STORE(my, F_MY)                                                                                                  \
+      PK_BIG_STORE(mr, F_MR)                                                                                                  \
+      PK_BIG_STORE(mg, F_MG)                                                                                                  \
+      PK_BIG_STORE(mb, F_MB)                                                                                                  \
+      PK_BIG_STORE(pxx, F_PXX)                                                                                                \
+      PK_BIG_STORE(pxy, F_PXY)                                                                                                \
+      PK_BIG_STORE(pyy, F_PYY)                                                                                                \
+      PK_BIG_STORE(crr, F_CRR)                                                                                                \
+      PK_BIG_STORE(crg, F_CRG)                                                                                                \
+      PK_BIG_STORE(crb, F_CRB)                                                                                                \
+      PK_BIG_STORE(cgg, F_CGG)                                                                                                \
+      PK_BIG_STORE(cgb, F_CGB)                                                                                                \
+      PK_BIG_STORE(cbb, F_CBB)                                                                                                \
+      const Int2 c2_ = {SA.count, SB.count};                                                                                  \
+      __builtin_nontemporal_store(c2_, reinterpret_cast<Int2*>(dc + l0));                                                     \
+    }                                                                                                                         \
+  }
+#define PK_BIG_STORE(field, F)                                                             \
+  {                                                                                        \
+    const Double2 v_ = {SA.field, SB.field};                                               \
+    __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
+  }
+    PK_BIG_PASS2(0)
+    PK_BIG_PASS2(1)
+    PK_BIG_PASS2(2)
+    PK_BIG_PASS2(3)
+    PK_BIG_PASS2(4)
+    PK_BIG_PASS2(5)
+    PK_BIG_PASS2(6)
+    PK_BIG_PASS2(7)
+#undef PK_BIG_PASS2
+#undef PK_BIG_STORE
+#undef PK_BIG_ROWS
+#undef PK_BIG_LOAD
+    {
+      const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier A
+      if ((tid & (kWave - 1)) == 0) red[cur][tid / kWave] = ws;
+      prev = p;
+    }
+  }
+}
+
+void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
+                         const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
+                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap) {
+  if (d.P == 0) return;
+  static bool attr_set[kMaxDevices] = {false};
+  if (first_time_on_this_device(attr_set)) {
+    for (const void* fn : {reinterpret_cast<const void*>(k_step_pub_big<3>), reinterpret_cast<const void*>(k_step_pub_big<5>),
+                           reinterpret_cast<const void*>(k_step_pub_big<6>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDynLds) != hipSuccess) (void)hipGetLastError();
+  }
+  PubArgs a;
+  a.ss = slot_source(d);
+  a.map_dst = d.map[d.mcur ^ 1];
+  a.count_off = d.lay.count_off;
+  a.src = d.src[d.cur];
+  a.x = d.x[d.cur];
+  a.y = d.y[d.cur];
+  a.h = d.h[d.cur];
+  a.logw = d.logw[d.cur];
+  a.exact = exact_dev;
+  a.order = order_dev;
+  a.immutable = d.immutable;
+  a.cand = cand.rec;
+  a.erec = erec_dev;
+  a.glist = glist_dev;
+  a.skip = skip_dev;
+  a.pflag_out = fh.pflag;
+  a.n_flagged = fh.n_flagged;
+  a.P = d.P;
+  a.p_begin = 0;
+  a.L = d.lay.L;
+  a.Lp = d.lay.Lp;
+  a.B = B;
+  a.ecap = ecap;
+  a.reset = ex.reset ? 1 : 0;
+  a.gmax_key = ex.gmax_key;
+  a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    else
+      n_cu = 256;
+    (void)hipGetLastError();
+  }
+  int64_t grid_n = n_cu;
+  if (grid_n > d.P) grid_n = d.P;
+  const size_t lds = step_pub_big_lds_bytes(B, ecap);
+  const int nch = (d.lay.Lp + 2 * kPubThreads - 1) / (2 * kPubThreads);
+  if (nch <= 3)
+    hipLaunchKernelGGL(k_step_pub_big<3>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
+  else if (nch <= 5)
+    hipLaunchKernelGGL(k_step_pub_big<5>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
+  else
+    hipLaunchKernelGGL(k_step_pub_big<6>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
 }
 
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,

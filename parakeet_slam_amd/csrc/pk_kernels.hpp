@@ -186,7 +186,7 @@ struct CandTable {
 void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid, int n9,
                        const unsigned char* tables_dev, const double* exact_dev, int32_t* ids_dev,
                        bool finalize, const FastHandoff& fh, const CandTable& cand);
-// bcnt_dev / brec_dev: NULL, or u32[B] / uint4[B] (cleared / filled with 0xFF by this call); stray_dev: their count
+// bcnt_dev / brec_dev: NULL, or u32[B] / u16[B][slots] (cleared / filled with 0xFF by this call); stray_dev: their count
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr,
                        int slots = kCandSlots, const double* pose_sums4_dev = nullptr);
@@ -214,13 +214,21 @@ int step_pub_entry_capacity_small(int B);  // ... with three 256-lane workgroups
 size_t step_pub_lds_bytes(int B, int ecap);
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
-                         unsigned* skip_cand_dev, int ecap);
+                         unsigned* skip_cand_dev, int ecap, int slots = kCandSlots);
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                      const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
                      int reserve_cus = 0);
 // every particle of [p0, p1) flagged for the fall-back kernels when *over != 0 (a candidate list overflowed)
 void launch_flag_range_if(hipStream_t s, const unsigned* over_dev, unsigned char* pflag_dev, unsigned* n_flagged_dev, int64_t p0, int64_t p1);
+// The same for maps beyond kRegsMaxL landmarks (up to kPubBigMaxL), in two passes over the map (the second from L2 / Infinity
+// Cache); candidate and inverse lists of 2 kCandSlots entries: cand.rec [Lp][3], erec [Lp][2].
+constexpr int kPubBigMaxL = 6144;  // six pairs per lane: beyond that the slot words of a lane no longer fit its registers
+int step_pub_big_entry_capacity(int B);
+size_t step_pub_big_lds_bytes(int B, int ecap);
+void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
+                         const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
+                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued

@@ -176,8 +176,8 @@ def test_large_map_slices_production_route_vs_general_vs_known(lib, Lb, Pb):
             f.observe(blobs, ids=ids)
         out[name] = (f.download_poses(), f.download_landmarks(0, 24), f.observe_route())
         f.close()
-    # the production route: one pass with the map in registers up to 2 048 landmarks, hand-off + two sweeps above
-    assert out["sweep"][2] == ("ml_regs" if Lb <= 2048 else "ml_sweep")
+    # the production route: one pass with the map in registers up to 2 048 landmarks, publish / subscribe in two passes above
+    assert out["sweep"][2] == ("ml_regs" if Lb <= 2048 else "ml_pub_big")
     assert out["general"][2] == "ml_general" and out["known"][2] == "known_ids"
 
     def same(a, b, rows):

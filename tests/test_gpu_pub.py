@@ -235,3 +235,51 @@ def test_the_256_lane_instance_for_small_maps_is_exact_too(lib, L, P):
     same_state(pub, fused)
     same_state(pub, gen, 1e-11)
     against_oracle(pub, means, covs, poses, blobs)
+
+
+@pytest.mark.parametrize("L,P", [(2049, 3), (3000, 3), (4096, 2), (5000, 4)])
+def test_two_pass_instance_for_maps_beyond_2048_landmarks(lib, L, P):
+    """k_step_pub_big (2 048 < L <= 6 144): sixteen-entry candidate lists both ways, verdicts published in a first pass over
+    the map, updates in a second -- against the two-sweep route it replaces as the default, the general kernels and the oracle."""
+    rs = np.random.RandomState(1200 + L)
+    means, covs = synthetic_world(L)
+    n = len(means[3::7])
+    means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))  # look-alikes: contested blobs
+    imm = (rs.uniform(size=L) < 0.1).astype(np.uint8)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))[rs.permutation(L)]
+    poses = poses_around(rs, P, 0.05)
+    big = run(lib, means, covs, poses, blobs, immutable=imm)
+    sweep = run(lib, means, covs, poses, blobs, {"pub_step": 0}, immutable=imm)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0}, immutable=imm)
+    assert big["route"] == "ml_pub_big" and sweep["route"] == "ml_sweep" and gen["route"] == "ml_general"
+    same_state(big, sweep, 1e-11)
+    same_state(big, gen, 1e-11)
+    if L <= 3000:  # (the NumPy oracle takes a while at 5 000 x 5 000)
+        against_oracle(big, means, covs, poses, blobs, imm)
+
+
+def test_two_pass_instance_whole_steps_against_the_sweep_route(lib):
+    L, P = 2600, 256
+    means, covs = synthetic_world(L)
+    outs = []
+    from oracle.fastslam_oracle import truth_step
+    for opts in ({}, {"pub_step": 0}):
+        f = lib.DeviceFilter(P, L)
+        for k, v in opts.items():
+            f.set_option(k, v)
+        f.upload_map(means, covs.reshape(L, 25))
+        pose, anc = (0.0, 0.0, 0.0), []
+        for s in range(4):
+            pose = truth_step(pose, 0.2, 0.1, 0.1)
+            f.reset_weights()
+            f.motion(0.2, 0.1, 0.1, seed=5, draw=s)
+            f.observe(synthetic_scan(means, pose))
+            anc.append(f.resample(0.37 + 0.1 * s, return_ancestors=True, domain=lib.PK_WEIGHTS_LOG))
+        outs.append((anc, f.download_poses(), f.download_landmarks(), f.observe_route(), f.observe_published(), f.observe_flagged()))
+        f.close()
+    assert outs[0][3] == "ml_pub_big" and outs[0][4] and outs[1][3] == "ml_sweep"
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][1][:, :3], outs[1][1][:, :3])
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(x, y)
