@@ -49,6 +49,7 @@ res = collections.defaultdict(lambda: collections.defaultdict(list))
 def key_of(k):
     if 'k_observe<true' in k or 'k_observe_single' in k: return 'observe_known'
     if 'k_step_fused' in k: return 'step_fused'
+    if 'k_step_pub_big' in k: return 'step_pub_big'
     if 'k_step_pub' in k: return 'step_pub'
     if 'k_step_regs' in k: return 'step_regs'
     if 'k_observe_fast' in k: return 'observe_ml'
