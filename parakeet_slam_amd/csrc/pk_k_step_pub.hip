@@ -1144,6 +1144,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
     PubSlots Q[2 * NCH];
     double pse[2 * NCH];
+#pragma unroll
+    for (int i = 0; i < 2 * NCH; ++i) {
+      Q[i] = kPubNoSlots;
+      pse[i] = 0.0;
+    }
     bool done;
     {
       PubArgsPtr R = pub_args_now(rp);
@@ -1184,70 +1189,74 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     SB.field = v_.y;                                                                                  \
   }
     // ---- pass 1: gates and verdicts, pair by pair
-#define PK_BIG_PASS1(q)                                                                                                       \
-  if (NCH > (q) && 2 * kPubThreads * (q) < Lp) { /* workgroup-uniform */                                                      \
-    const int l0 = 2 * kPubThreads * (q) + 2 * tid;                                                                           \
-    const int lb = min(l0, Lp - 2);                                                                                           \
-    PubArgsPtr R = pub_args_now(rp);                                                                                          \
-    const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);                             \
-    const uint4* cr = R->cand + 3 * (size_t)lb;                                                                               \
-    const uint4* er = R->erec + 2 * (size_t)lb;                                                                               \
-    PubGateIn gi[2];                                                                                                          \
-    gi[0].ref = cr[0];                                                                                                        \
-    gi[0].cw[0] = cr[1];                                                                                                      \
-    gi[0].cw[1] = cr[2];                                                                                                      \
-    gi[1].ref = cr[3];                                                                                                        \
-    gi[1].cw[0] = cr[4];                                                                                                      \
-    gi[1].cw[1] = cr[5];                                                                                                      \
-    gi[0].ew[0] = er[0];                                                                                                      \
-    gi[0].ew[1] = er[1];                                                                                                      \
-    gi[1].ew[0] = er[2];                                                                                                      \
-    gi[1].ew[1] = er[3];                                                                                                      \
-    asm volatile("" ::: "memory");                                                                                            \
-    Landmark<double> SA, SB;                                                                                                  \
-    PK_BIG_ROWS(SA, SB, lb)                                                                                                   \
-    gi[0].mx = SA.mx;                                                                                                         \
-    gi[0].my = SA.my;                                                                                                         \
-    gi[0].mr = SA.mr;                                                                                                         \
-    gi[0].mg = SA.mg;                                                                                                         \
-    gi[0].mb = SA.mb;                                                                                                         \
-    gi[0].has = l0 < L;                                                                                                       \
-    gi[1].mx = SB.mx;                                                                                                         \
-    gi[1].my = SB.my;                                                                                                         \
-    gi[1].mr = SB.mr;                                                                                                         \
-    gi[1].mg = SB.mg;                                                                                                         \
-    gi[1].mb = SB.mb;                                                                                                         \
-    gi[1].has = l0 + 1 < L;                                                                                                   \
-    PubSlotsT<kPubBigGateSlots> qq[2];                                                                                        \
-    double pp[2] = {0.0, 0.0};                                                                                                \
-    const Landmark<double>* const l2[2] = {&SA, &SB};                                                                         \
-    pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);                                             \
-    pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                       \
-    Q[2 * (q)] = pub_keep_positive(qq[0], &wg_flag[cur]);                                                                     \
-    Q[2 * (q) + 1] = pub_keep_positive(qq[1], &wg_flag[cur]);                                                                 \
-    pse[2 * (q)] = pp[0];                                                                                                     \
-    pse[2 * (q) + 1] = pp[1];                                                                                                 \
-  } else if (NCH > (q)) {                                                                                                     \
-    Q[2 * (q)] = Q[2 * (q) + 1] = kPubNoSlots;                             \
-    pse[2 * (q)] = pse[2 * (q) + 1] = 0.0;                                                                                    \
-  }
+    // (ONE copy of the pair's code in a loop that is not unrolled -- written out per pair the kernel was 143 KB of
+    // instructions, more than twice the instruction cache two CUs share -- with the carried words ROTATING through the
+    // register arrays: a pair's results enter at the back, after NCH turns pair 0 stands in front again)
     if (!done) {
-      PK_BIG_PASS1(0)
-      {
-        PubArgsPtr R4 = pub_args_now(rp);
-        const int64_t pn = p + gridDim.x;
-        nsrc = regs_source_pub(R4->src, pn < R4->P ? pn : R4->P - 1);
-        asm volatile("" : "+s"(nsrc));
+#pragma unroll 1
+      for (int q = 0; q < NCH; ++q) {
+        PubSlots qa = kPubNoSlots, qb = kPubNoSlots;
+        double pa = 0.0, pb = 0.0;
+        if (2 * kPubThreads * q < Lp) {  // workgroup-uniform
+          const int l0 = 2 * kPubThreads * q + 2 * tid;
+          const int lb = min(l0, Lp - 2);
+          PubArgsPtr R = pub_args_now(rp);
+          const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
+          const uint4* cr = R->cand + 3 * (size_t)lb;
+          const uint4* er = R->erec + 2 * (size_t)lb;
+          PubGateIn gi[2];
+          gi[0].ref = cr[0];
+          gi[0].cw[0] = cr[1];
+          gi[0].cw[1] = cr[2];
+          gi[1].ref = cr[3];
+          gi[1].cw[0] = cr[4];
+          gi[1].cw[1] = cr[5];
+          gi[0].ew[0] = er[0];
+          gi[0].ew[1] = er[1];
+          gi[1].ew[0] = er[2];
+          gi[1].ew[1] = er[3];
+          asm volatile("" ::: "memory");
+          Landmark<double> SA, SB;
+          PK_BIG_ROWS(SA, SB, lb)
+          if (q == 0) {  // the next particle's source slot (as in k_step_pub)
+            PubArgsPtr R4 = pub_args_now(rp);
+            const int64_t pn = p + gridDim.x;
+            nsrc = regs_source_pub(R4->src, pn < R4->P ? pn : R4->P - 1);
+            asm volatile("" : "+s"(nsrc));
+          }
+          gi[0].mx = SA.mx;
+          gi[0].my = SA.my;
+          gi[0].mr = SA.mr;
+          gi[0].mg = SA.mg;
+          gi[0].mb = SA.mb;
+          gi[0].has = l0 < L;
+          gi[1].mx = SB.mx;
+          gi[1].my = SB.my;
+          gi[1].mr = SB.mr;
+          gi[1].mg = SB.mg;
+          gi[1].mb = SB.mb;
+          gi[1].has = l0 + 1 < L;
+          PubSlotsT<kPubBigGateSlots> qq[2];
+          double pp[2] = {0.0, 0.0};
+          const Landmark<double>* const l2[2] = {&SA, &SB};
+          pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
+          pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+          qa = pub_keep_positive(qq[0], &wg_flag[cur]);
+          qb = pub_keep_positive(qq[1], &wg_flag[cur]);
+          pa = pp[0];
+          pb = pp[1];
+        }
+#pragma unroll
+        for (int i = 0; i + 2 < 2 * NCH; ++i) {
+          Q[i] = Q[i + 2];
+          pse[i] = pse[i + 2];
+        }
+        Q[2 * NCH - 2] = qa;
+        Q[2 * NCH - 1] = qb;
+        pse[2 * NCH - 2] = pa;
+        pse[2 * NCH - 1] = pb;
       }
-      PK_BIG_PASS1(1)
-      PK_BIG_PASS1(2)
-      PK_BIG_PASS1(3)
-      PK_BIG_PASS1(4)
-      PK_BIG_PASS1(5)
-      PK_BIG_PASS1(6)
-      PK_BIG_PASS1(7)
     }
-#undef PK_BIG_PASS1
     lds_barrier();  // A: every verdict of this particle is in the table
     if (prev >= 0 && tid == 0) {  // the previous particle's log-weight (its partial sums were written before A)
       PubArgsPtr R = pub_args_now(rp);
@@ -1291,56 +1300,53 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     }
     if (tid == 0) pub_args_now(rp)->pflag_out[p] = 0;
     // ---- pass 2: rows in again, updates in scan order, rows out
-#define PK_BIG_PASS2(q)                                                                                                       \
-  if (NCH > (q) && 2 * kPubThreads * (q) < Lp) { /* workgroup-uniform */                                                      \
-    const int l0 = 2 * kPubThreads * (q) + 2 * tid;                                                                           \
-    const int lb = min(l0, Lp - 2);                                                                                           \
-    Landmark<double> SA, SB;                                                                                                  \
-    PK_BIG_ROWS(SA, SB, lb)                                                                                                   \
-    PubArgsPtr R = pub_args_now(rp);                                                                                          \
-    const Noise<double> qt = pub_noise(R);                                                                                    \
-    const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);                                                        \
-    const unsigned char* immutable = R->immutable;                                                                            \
-    acc += pub_apply_loop(Q[2 * (q)], R->exact, order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[2 * (q)]);          \
-    acc += pub_apply_loop(Q[2 * (q) + 1], pub_args_now(rp)->exact, order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, \
-                          pse[2 * (q) + 1]);                                                                                  \
-    if (l0 < Lp) {                                                                                                            \
-      PubArgsPtr R3 = pub_args_now(rp);                                                                                       \
-      unsigned char* dslot = R3->map_dst + (size_t)p * R3->ss.slot_bytes;                                                     \
-      double* df = reinterpret_cast<double*>(dslot);                                                                          \
-      int* dc = reinterpret_cast<int*>(dslot + R3->count_off);                                                                \
-      PK_BIG_STORE(mx, F_MX)                                                                                                  \
-      PK_BIG_STORE(my, F_MY)                                                                                                  \
-      PK_BIG_STORE(mr, F_MR)                                                                                                  \
-      PK_BIG_STORE(mg, F_MG)                                                                                                  \
-      PK_BIG_STORE(mb, F_MB)                                                                                                  \
-      PK_BIG_STORE(pxx, F_PXX)                                                                                                \
-      PK_BIG_STORE(pxy, F_PXY)                                                                                                \
-      PK_BIG_STORE(pyy, F_PYY)                                                                                                \
-      PK_BIG_STORE(crr, F_CRR)                                                                                                \
-      PK_BIG_STORE(crg, F_CRG)                                                                                                \
-      PK_BIG_STORE(crb, F_CRB)                                                                                                \
-      PK_BIG_STORE(cgg, F_CGG)                                                                                                \
-      PK_BIG_STORE(cgb, F_CGB)                                                                                                \
-      PK_BIG_STORE(cbb, F_CBB)                                                                                                \
-      const Int2 c2_ = {SA.count, SB.count};                                                                                  \
-      __builtin_nontemporal_store(c2_, reinterpret_cast<Int2*>(dc + l0));                                                     \
-    }                                                                                                                         \
-  }
 #define PK_BIG_STORE(field, F)                                                             \
   {                                                                                        \
     const Double2 v_ = {SA.field, SB.field};                                               \
     __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
   }
-    PK_BIG_PASS2(0)
-    PK_BIG_PASS2(1)
-    PK_BIG_PASS2(2)
-    PK_BIG_PASS2(3)
-    PK_BIG_PASS2(4)
-    PK_BIG_PASS2(5)
-    PK_BIG_PASS2(6)
-    PK_BIG_PASS2(7)
-#undef PK_BIG_PASS2
+#pragma unroll 1
+    for (int q = 0; q < NCH; ++q) {
+      if (2 * kPubThreads * q < Lp) {  // workgroup-uniform
+        const int l0 = 2 * kPubThreads * q + 2 * tid;
+        const int lb = min(l0, Lp - 2);
+        Landmark<double> SA, SB;
+        PK_BIG_ROWS(SA, SB, lb)
+        PubArgsPtr R = pub_args_now(rp);
+        const Noise<double> qt = pub_noise(R);
+        const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
+        const unsigned char* immutable = R->immutable;
+        acc += pub_apply_loop(Q[0], R->exact, order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0]);
+        acc += pub_apply_loop(Q[1], pub_args_now(rp)->exact, order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1]);
+        if (l0 < Lp) {
+          PubArgsPtr R3 = pub_args_now(rp);
+          unsigned char* dslot = R3->map_dst + (size_t)p * R3->ss.slot_bytes;
+          double* df = reinterpret_cast<double*>(dslot);
+          int* dc = reinterpret_cast<int*>(dslot + R3->count_off);
+          PK_BIG_STORE(mx, F_MX)
+          PK_BIG_STORE(my, F_MY)
+          PK_BIG_STORE(mr, F_MR)
+          PK_BIG_STORE(mg, F_MG)
+          PK_BIG_STORE(mb, F_MB)
+          PK_BIG_STORE(pxx, F_PXX)
+          PK_BIG_STORE(pxy, F_PXY)
+          PK_BIG_STORE(pyy, F_PYY)
+          PK_BIG_STORE(crr, F_CRR)
+          PK_BIG_STORE(crg, F_CRG)
+          PK_BIG_STORE(crb, F_CRB)
+          PK_BIG_STORE(cgg, F_CGG)
+          PK_BIG_STORE(cgb, F_CGB)
+          PK_BIG_STORE(cbb, F_CBB)
+          const Int2 c2_ = {SA.count, SB.count};
+          __builtin_nontemporal_store(c2_, reinterpret_cast<Int2*>(dc + l0));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i + 2 < 2 * NCH; ++i) {  // the next pair's words to the front
+        Q[i] = Q[i + 2];
+        pse[i] = pse[i + 2];
+      }
+    }
 #undef PK_BIG_STORE
 #undef PK_BIG_ROWS
 #undef PK_BIG_LOAD
