@@ -775,6 +775,49 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #ifdef PK_STAMPS
   unsigned long long pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+  // the 14 rows + counts of the lane's pair q_ (landmarks lb_, lb_ + 1) of the slot at sslot_
+#define PK_PUB_ROW(q_, field, F)                                                                  \
+  {                                                                                               \
+    const Double2 v_ = *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + lbq_);            \
+    S[2 * (q_)].field = v_.x;                                                                     \
+    S[2 * (q_) + 1].field = v_.y;                                                                 \
+  }
+#define PK_PUB_LOAD_PAIR(q_, sslot_, coff_, lb_)                                                  \
+  {                                                                                               \
+    const double* sf_ = reinterpret_cast<const double*>(sslot_);                                  \
+    const int* sc_ = reinterpret_cast<const int*>((sslot_) + (coff_));                            \
+    const int lbq_ = (lb_);                                                                       \
+    PK_PUB_ROW(q_, mx, F_MX)                                                                      \
+    PK_PUB_ROW(q_, my, F_MY)                                                                      \
+    PK_PUB_ROW(q_, mr, F_MR)                                                                      \
+    PK_PUB_ROW(q_, mg, F_MG)                                                                      \
+    PK_PUB_ROW(q_, mb, F_MB)                                                                      \
+    asm volatile("" ::: "memory");                                                                \
+    PK_PUB_ROW(q_, pxx, F_PXX)                                                                    \
+    PK_PUB_ROW(q_, pxy, F_PXY)                                                                    \
+    PK_PUB_ROW(q_, pyy, F_PYY)                                                                    \
+    PK_PUB_ROW(q_, crr, F_CRR)                                                                    \
+    PK_PUB_ROW(q_, crg, F_CRG)                                                                    \
+    PK_PUB_ROW(q_, crb, F_CRB)                                                                    \
+    PK_PUB_ROW(q_, cgg, F_CGG)                                                                    \
+    PK_PUB_ROW(q_, cgb, F_CGB)                                                                    \
+    PK_PUB_ROW(q_, cbb, F_CBB)                                                                    \
+    const Int2 c_ = *reinterpret_cast<const Int2*>(sc_ + lbq_);                                   \
+    S[2 * (q_)].count = c_.x;                                                                     \
+    S[2 * (q_) + 1].count = c_.y;                                                                 \
+    asm volatile("" ::: "memory");                                                                \
+  }
+  // The lane's FIRST pair of the next particle is asked for as soon as this particle's first pair has been stored -- into
+  // the registers that store has just freed -- so its rows fly while the second pair is updated and stored.
+  Landmark<double> S[2 * NP];
+  constexpr int kPipe = 1;  // pairs asked for ahead (both: 58 registers spilled)
+  {
+    PubArgsPtr R = pub_args_now(rp);
+    const unsigned char* ns = pub_slot_source(R).at(nsrc);
+    const int coff = R->count_off;
+#pragma unroll
+    for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(2 * kPubThreads * q + 2 * tid0, Lp - 2))
+  }
   for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
     // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
     // occupy registers for the whole kernel)
@@ -785,7 +828,6 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_binfo);
     const unsigned short* order = reinterpret_cast<const unsigned short*>(smem + o_order);
     unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
-    Landmark<double> S[2 * NP];
     PubSlots Q[2 * NP];
     double pse[2 * NP];
     bool done;
@@ -799,8 +841,6 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       if (!done) {
         const SlotSource ss = pub_slot_source(R);
         const unsigned char* sslot = ss.at(nsrc);
-        const double* sf = reinterpret_cast<const double*>(sslot);
-        const int* sc = reinterpret_cast<const int*>(sslot + R->count_off);
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
         // the lane's landmarks: pair q = landmarks 1024 q + 2 tid, + 1 (lanes beyond the map re-read its last pair and
         // never use or store it)
@@ -824,38 +864,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         };
         request_cand(0);
         asm volatile("" ::: "memory");
-        auto row2 = [&](int f, int lb) { return *reinterpret_cast<const Double2*>(sf + (size_t)f * Lp + lb); };
-#define PK_PUB_LOAD(field, F)            \
-  {                                      \
-    const Double2 v = row2(F, lbase[q]); \
-    S[2 * q].field = v.x;                \
-    S[2 * q + 1].field = v.y;            \
-  }
         // (pair by pair, means before covariance rows: the first pair's gates and verdicts are worked out while the second
         // pair's rows are still on their way -- the vector memory counter retires in order)
+        {
+          const int coff = R->count_off;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          PK_PUB_LOAD(mx, F_MX)
-          PK_PUB_LOAD(my, F_MY)
-          PK_PUB_LOAD(mr, F_MR)
-          PK_PUB_LOAD(mg, F_MG)
-          PK_PUB_LOAD(mb, F_MB)
-          asm volatile("" ::: "memory");
-          PK_PUB_LOAD(pxx, F_PXX)
-          PK_PUB_LOAD(pxy, F_PXY)
-          PK_PUB_LOAD(pyy, F_PYY)
-          PK_PUB_LOAD(crr, F_CRR)
-          PK_PUB_LOAD(crg, F_CRG)
-          PK_PUB_LOAD(crb, F_CRB)
-          PK_PUB_LOAD(cgg, F_CGG)
-          PK_PUB_LOAD(cgb, F_CGB)
-          PK_PUB_LOAD(cbb, F_CBB)
-          const Int2 c = *reinterpret_cast<const Int2*>(sc + lbase[q]);
-          S[2 * q].count = c.x;
-          S[2 * q + 1].count = c.y;
-          asm volatile("" ::: "memory");
+          for (int q = kPipe; q < NP; ++q) PK_PUB_LOAD_PAIR(q, sslot, coff, lbase[q])
         }
-#undef PK_PUB_LOAD
         {  // the next particle's source slot (pinned here: the wait for it passes under the wait for the first rows)
           PubArgsPtr R4 = pub_args_now(rp);
           const int64_t pn = p + gridDim.x;
@@ -959,6 +974,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         R->pflag_out[p] = 1;
         atomicAdd(R->n_flagged, 1u);
       }
+      {  // (the next particle's first pair is asked for on this way out as well)
+        PubArgsPtr R6 = pub_args_now(rp);
+        const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+        const int coff = R6->count_off;
+#pragma unroll
+        for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
+      }
       continue;
     }
     // ---- 5. updates in scan order, stores
@@ -1019,6 +1041,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #undef PK_PUB_STORE
           const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
           __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
+        }
+        if (q < kPipe) {  // the next particle's pair, into the registers just stored
+          PubArgsPtr R6 = pub_args_now(rp);
+          const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+          PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
         }
       }
     }
