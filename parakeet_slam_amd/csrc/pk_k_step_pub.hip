@@ -1153,40 +1153,12 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   }
   __syncthreads();
 
-  int64_t prev = -1;
-  int cur = 0;
-  int32_t nsrc;  // the next particle's source slot, asked for a whole particle ahead (as in k_step_pub)
-  {
-    PubArgsPtr R = pub_args_now(rp);
-    const int64_t p0 = R->p_begin + blockIdx.x;
-    nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
-  }
-  for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int32_t csrc = nsrc;
-    double* pub = reinterpret_cast<double*>(smem);
-    const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_glist);
-    const unsigned short* order = reinterpret_cast<const unsigned short*>(smem + o_order);
-    unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
-    PubSlots Q[2 * NCH];
-    double pse[2 * NCH];
-#pragma unroll
-    for (int i = 0; i < 2 * NCH; ++i) {
-      Q[i] = kPubNoSlots;
-      pse[i] = 0.0;
-    }
-    bool done;
-    {
-      PubArgsPtr R = pub_args_now(rp);
-      done = p >= R->P;
-    }
     // the rows of the pair at landmark lb_ of this particle's source slot
-#define PK_BIG_ROWS(SA, SB, lb_)                                                                      \
+#define PK_BIG_ROWS(SA, SB, lb_, src_)                                                                \
   {                                                                                                   \
     PubArgsPtr R2 = pub_args_now(rp);                                                                 \
     const SlotSource ss_ = pub_slot_source(R2);                                                       \
-    const unsigned char* sslot_ = ss_.at(csrc);                                                       \
+    const unsigned char* sslot_ = ss_.at(src_);                                                       \
     const double* sf_ = reinterpret_cast<const double*>(sslot_);                                      \
     const int* sc_ = reinterpret_cast<const int*>(sslot_ + R2->count_off);                            \
     PK_BIG_LOAD(SA, SB, mx, F_MX, lb_)                                                                \
@@ -1215,6 +1187,43 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     SA.field = v_.x;                                                                                  \
     SB.field = v_.y;                                                                                  \
   }
+  int64_t prev = -1;
+  int cur = 0;
+  int32_t nsrc;  // the next particle's source slot, asked for a whole particle ahead (as in k_step_pub)
+  {
+    PubArgsPtr R = pub_args_now(rp);
+    const int64_t p0 = R->p_begin + blockIdx.x;
+    nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
+  }
+  // The rows of a pair are asked for as soon as the pair before it is through (into the registers it has just let go):
+  // pair q + 1 behind pair q's verdicts in pass 1, pass 2's first pair behind the last verdicts (its rows fly during the
+  // barriers and the settling), pair q + 1 behind pair q's stores in pass 2, and the NEXT particle's first pair behind the
+  // last stores.
+  Landmark<double> SA, SB;
+  {
+    const int lb0 = min(2 * tid0, Lp - 2);
+    PK_BIG_ROWS(SA, SB, lb0, nsrc)
+  }
+  for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int32_t csrc = nsrc;
+    double* pub = reinterpret_cast<double*>(smem);
+    const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_glist);
+    const unsigned short* order = reinterpret_cast<const unsigned short*>(smem + o_order);
+    unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
+    PubSlots Q[2 * NCH];
+    double pse[2 * NCH];
+#pragma unroll
+    for (int i = 0; i < 2 * NCH; ++i) {
+      Q[i] = kPubNoSlots;
+      pse[i] = 0.0;
+    }
+    bool done;
+    {
+      PubArgsPtr R = pub_args_now(rp);
+      done = p >= R->P;
+    }
     // ---- pass 1: gates and verdicts, pair by pair
     // (ONE copy of the pair's code in a loop that is not unrolled -- written out per pair the kernel was 143 KB of
     // instructions, more than twice the instruction cache two CUs share -- with the carried words ROTATING through the
@@ -1243,8 +1252,6 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[1].ew[0] = er[2];
           gi[1].ew[1] = er[3];
           asm volatile("" ::: "memory");
-          Landmark<double> SA, SB;
-          PK_BIG_ROWS(SA, SB, lb)
           if (q == 0) {  // the next particle's source slot (as in k_step_pub)
             PubArgsPtr R4 = pub_args_now(rp);
             const int64_t pn = p + gridDim.x;
@@ -1272,6 +1279,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
           pa = pp[0];
           pb = pp[1];
+          {  // the next pair of this pass, or the first one of pass 2
+            const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
+            const int ln = min((more ? 2 * kPubThreads * (q + 1) : 0) + 2 * tid, Lp - 2);
+            PK_BIG_ROWS(SA, SB, ln, csrc)
+          }
         }
 #pragma unroll
         for (int i = 0; i + 2 < 2 * NCH; ++i) {
@@ -1323,6 +1335,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         R->pflag_out[p] = 1;
         atomicAdd(R->n_flagged, 1u);
       }
+      {  // (the registers hold this particle's first pair: the next particle's instead)
+        const int lb0 = min(2 * tid, Lp - 2);
+        PK_BIG_ROWS(SA, SB, lb0, nsrc)
+      }
       continue;
     }
     if (tid == 0) pub_args_now(rp)->pflag_out[p] = 0;
@@ -1336,9 +1352,6 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     for (int q = 0; q < NCH; ++q) {
       if (2 * kPubThreads * q < Lp) {  // workgroup-uniform
         const int l0 = 2 * kPubThreads * q + 2 * tid;
-        const int lb = min(l0, Lp - 2);
-        Landmark<double> SA, SB;
-        PK_BIG_ROWS(SA, SB, lb)
         PubArgsPtr R = pub_args_now(rp);
         const Noise<double> qt = pub_noise(R);
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
@@ -1366,6 +1379,12 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           PK_BIG_STORE(cbb, F_CBB)
           const Int2 c2_ = {SA.count, SB.count};
           __builtin_nontemporal_store(c2_, reinterpret_cast<Int2*>(dc + l0));
+        }
+        {  // the next pair, or the next particle's first one
+          const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
+          const int ln = min((more ? 2 * kPubThreads * (q + 1) : 0) + 2 * tid, Lp - 2);
+          const int32_t sn = more ? csrc : nsrc;
+          PK_BIG_ROWS(SA, SB, ln, sn)
         }
       }
 #pragma unroll
