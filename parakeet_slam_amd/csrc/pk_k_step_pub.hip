@@ -13,18 +13,22 @@
 // whole scan (blob t: entries offs[t] .. offs[t] + n[t] - 1, one per landmark of its inverse list, ascending):
 //   publish    the landmark's lane writes its verdict there -- +inf when the blob does not pass its gates or has
 //              probability 0, else the pair's KEY = -2 log(probability) up to rounding --
-//   barrier
-//   subscribe  and reads the rivals' entries of the blobs it passes: the smallest key takes the blob, the lowest
-//              landmark on equal keys.
-// No atomics, no queue, two barriers per particle (the second only hands the table to the next particle), and between
-// them only the short subscribe phase: the long phases -- rows arriving, gates, keys / EKF updates, stores -- run without
-// any synchronisation, so the waves of a workgroup drift apart and one wave's memory time is another's arithmetic.
+//   barrier A
+//   settle     one lane per contested blob reads the blob's run of entries in one batch: the smallest key takes the
+//              blob, the lowest landmark on equal keys; the winner's entry is overwritten with the marker -inf
+//   barrier B
+//   subscribe  every landmark's lane reads the entries of the blobs it passes: the marker means "yours"
+//   barrier C  (hands the table to the next particle).
+// No atomics, no queue, three barriers per particle that stand close together (k_step_regs: eight), and between C and the
+// next A the long phases -- rows arriving, gates, keys, EKF updates, stores -- run without any synchronisation, so the waves
+// of a workgroup drift apart and one wave's memory time is another's arithmetic.  (A first version let every landmark's
+// lane read its rivals' entries itself, one after the other: 40 % of the kernel's time went into those dependent LDS reads.)
 //
 // Keys instead of probabilities: the reference compares pr = (500 exp(-a2/2)) (500 exp(-a3/2)) / 250000 (:439-455);
 // -2 log pr = a2 + a3 orders the same way wherever the two differ by more than rounding.  The kernel therefore FLAGS a
 // particle for the general kernels (exact probabilities, as before) whenever keys of two contenders are closer than 1e-7
 // without being identical (identical landmarks give identical keys: a tie, :377), and wherever pr would be subnormal
-// (keys beyond 1400) with a second contender; whether pr is > 0 at all (:369, strict) is decided from the keys with
+// (keys beyond 1350) with a second contender; whether pr is > 0 at all (:369, strict) is decided from the keys with
 // margins on both sides of the float64 underflow edge (keys 1489 ... 1491.5) and evaluated exactly inside them.
 //
 // Shape: persistent 512-lane workgroups, one per CU, FOUR landmarks per lane (two adjacent pairs, 16-byte row accesses),
