@@ -26,7 +26,9 @@ if 512 < L <= 2048:
     for s in range(3, 6):
         f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)        # k_step_regs instead of k_step_pub
     f.set_option("pub_step", 1)
-if L > 512:
+if L > 2048:
+    f.set_option("pub_step", 0)                                                # the two-kernel route instead of k_step_pub_big
+elif L > 512:
     f.set_option("regs_step", 0)
 else:
     f.set_option("fused_step", 0)
