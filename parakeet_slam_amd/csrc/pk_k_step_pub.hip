@@ -314,23 +314,17 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
     dmin[j] = 3.0e38f;
     npass[j] = 0;
   }
-#pragma unroll 1
+#pragma unroll  // (written out: the list words are addressed statically -- shifted through the registers every round they cost 1.3 %)
   for (int k = 0; k < NW; ++k) {
-    unsigned call = c[0][0];
+    const int kk = k;
+    unsigned call = c[0][kk];
 #pragma unroll
-    for (int j = 1; j < N; ++j) call &= c[j][0];
+    for (int j = 1; j < N; ++j) call &= c[j][kk];
     if (__ballot((call & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: every list is through
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const unsigned ta = c[j][0] & 0xFFFFu, tb = c[j][0] >> 16;
-      const unsigned ea = e[j][0] & 0xFFFFu, eb2 = e[j][0] >> 16;  // (0xFFFF where the blob is: k_cand_entries)
-#pragma unroll
-      for (int w = 0; w + 1 < NW; ++w) {
-        c[j][w] = c[j][w + 1];
-        e[j][w] = e[j][w + 1];
-      }
-      c[j][NW - 1] = 0xFFFFFFFFu;
-      e[j][NW - 1] = 0xFFFFFFFFu;
+      const unsigned ta = c[j][kk] & 0xFFFFu, tb = c[j][kk] >> 16;
+      const unsigned ea = e[j][kk] & 0xFFFFu, eb2 = e[j][kk] >> 16;  // (0xFFFF where the blob is: k_cand_entries)
       const bool va = ta != 0xFFFFu, vb = tb != 0xFFFFu;
       const double* ra = ex + 6 * (va ? ta : 0u);
       const double* rb = ex + 6 * (vb ? tb : 0u);
