@@ -834,12 +834,16 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     unsigned long long s3 = s0;
 #endif
     {
+      // (no branch on `done` in front of the requests: every kernel argument they need comes in one batch; a workgroup
+      // that has run out of particles asks for the last particle's rows once more and drops them)
       PubArgsPtr R = pub_args_now(rp);
-      done = p >= R->P;
-      if (!done) {
+      const int64_t Pn = R->P;
+      done = p >= Pn;
+      const int64_t pc = done ? Pn - 1 : p;
+      {
         const SlotSource ss = pub_slot_source(R);
         const unsigned char* sslot = ss.at(nsrc);
-        const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
+        const double sx = pose_scalar(R->x, pc), sy = pose_scalar(R->y, pc), sh = pose_scalar(R->h, pc);
         // the lane's landmarks: pair q = landmarks 1024 q + 2 tid, + 1 (lanes beyond the map re-read its last pair and
         // never use or store it)
         int lbase[NP];
@@ -912,10 +916,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     pse[2 * (q)] = pp[0];                                                                                                        \
     pse[2 * (q) + 1] = pp[1];                                                                                                    \
   }
-        PK_PUB_PAIR(0)
-        if constexpr (NP > 1) {
-          request_cand(NP - 1);
-          PK_PUB_PAIR(1)
+        if (!done) {  // workgroup-uniform
+          PK_PUB_PAIR(0)
+          if constexpr (NP > 1) {
+            request_cand(NP - 1);
+            PK_PUB_PAIR(1)
+          }
         }
 #undef PK_PUB_PAIR
         PK_STAMP(s2)
