@@ -87,10 +87,11 @@ struct PubArgs {
 };
 
 // dynamic LDS: exact records 48 B | publish table 8 (ecap + 2: a dump entry, padding) | binfo 4 B | order 2 B |
-// any 2 x (B + 16: a dump byte) (B padded to 16)
+// any 2 x (B + 16: a dump byte) (B padded to 16) | the landmarks' immutable flags, 1 B each (kPubImmBytes)
+constexpr size_t kPubImmBytes = 2048;  // k_step_pub: maps up to 2 048 landmarks
 __host__ __device__ inline size_t pub_fixed_lds_bytes(int B) {
   const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
-  return Bp * 48 + 16 + Bp * 4 + Bp * 2 + 2 * (Bp + 16);
+  return Bp * 48 + 16 + Bp * 4 + Bp * 2 + 2 * (Bp + 16) + kPubImmBytes;
 }
 size_t step_pub_lds_bytes(int B, int ecap) { return pub_fixed_lds_bytes(B) + (size_t)ecap * 8; }  // (the 16 spare bytes: the dump entry)
 int step_pub_entry_capacity(int B) {
@@ -734,6 +735,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   const unsigned Bp = ((unsigned)B + 15u) & ~15u;
   // LDS offsets (bytes): exact | pub (ecap + 2 entries) | glist (binfo's place) | order | any[2][Bp + 16]
   const unsigned o_pub = Bp * 48u, o_binfo = o_pub + ((unsigned)ecap + 2u) * 8u, o_order = o_binfo + Bp * 4u, o_any = o_order + Bp * 2u;
+  const unsigned o_imm = o_any + 2u * (Bp + 16u);
   const unsigned dump = (unsigned)ecap, anydump = Bp;
   unsigned G;  // blobs that several landmarks list
   {
@@ -753,6 +755,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       order[i] = go[i];
     }
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
+    // the immutable flags (:909, :926): read in the update phase, where a global load would come back behind every store
+    // and row request in flight (one in-order vector memory counter)
+    const unsigned char* gi = R->immutable;
+    for (int i = tid; i < Lp; i += kPubThreads) smem[o_imm + (unsigned)i] = i < L ? gi[i] : (unsigned char)0;
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -996,14 +1002,14 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       unsigned char* dslot = R->map_dst + (size_t)p * R->ss.slot_bytes;
       double* df = reinterpret_cast<double*>(dslot);
       int* dc = reinterpret_cast<int*>(dslot + R->count_off);
-      const unsigned char* immutable = R->immutable;
+      const unsigned char* immutable = smem + o_imm;
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         const int l0 = 2 * kPubThreads * q + 2 * tid;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int i = 2 * q + j;
-          const bool imm = immutable[min(l0 + j, L - 1)] != 0;
+          const bool imm = immutable[min(l0 + j, Lp - 1)] != 0;
           if (PK_PUB_ABLATE < 1)
             acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i])
                                                : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
@@ -1103,9 +1109,11 @@ __device__ __forceinline__ PubSlots pub_keep_positive(const PubSlotsT<kPubBigGat
   if (__popc(g.st & 0x11111111u) > kPubSlots) *flag = 1;
   return o;
 }
+// (at B = 5 000 the publish table needs some 15 000 entries: the scan-order table -- read only where a landmark takes two
+// blobs -- stays in global memory, and there is no room for the immutable flags either)
 __host__ __device__ inline size_t pub_big_fixed_lds_bytes(int B) {
   const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
-  return 16 + Bp * 4 + Bp * 2 + 2 * (Bp + 16);
+  return 16 + Bp * 4 + 2 * (Bp + 16);
 }
 int step_pub_big_entry_capacity(int B) {
   const size_t fixed = pub_big_fixed_lds_bytes(B);
@@ -1133,22 +1141,17 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     ecap = R->ecap;
   }
   const unsigned Bp = ((unsigned)B + 15u) & ~15u;
-  // LDS offsets (bytes): pub (ecap + 2 entries) | glist | order | any[2][Bp + 16]
-  const unsigned o_glist = ((unsigned)ecap + 2u) * 8u, o_order = o_glist + Bp * 4u, o_any = o_order + Bp * 2u;
+  // LDS offsets (bytes): pub (ecap + 2 entries) | glist | any[2][Bp + 16]
+  const unsigned o_glist = ((unsigned)ecap + 2u) * 8u, o_any = o_glist + Bp * 4u;
   const unsigned dump = (unsigned)ecap, anydump = Bp;
   unsigned G;
   {
     const int tid = tid0;
     PubArgsPtr R = pub_args_now(rp);
     unsigned* glist = reinterpret_cast<unsigned*>(smem + o_glist);
-    unsigned short* order = reinterpret_cast<unsigned short*>(smem + o_order);
     const unsigned* gb = R->glist;
-    const unsigned short* go = R->order;
     G = gb[B];
-    for (int i = tid; i < B; i += kPubThreads) {
-      glist[i] = (unsigned)i < G ? gb[i] : 0u;
-      order[i] = go[i];
-    }
+    for (int i = tid; i < B; i += kPubThreads) glist[i] = (unsigned)i < G ? gb[i] : 0u;
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
     if (tid == 0) {
       wg_flag[0] = 0;
@@ -1214,7 +1217,6 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     const int32_t csrc = nsrc;
     double* pub = reinterpret_cast<double*>(smem);
     const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_glist);
-    const unsigned short* order = reinterpret_cast<const unsigned short*>(smem + o_order);
     unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
     PubSlots Q[2 * NCH];
     double pse[2 * NCH];
@@ -1360,8 +1362,12 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         const Noise<double> qt = pub_noise(R);
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
         const unsigned char* immutable = R->immutable;
-        acc += pub_apply_loop(Q[0], R->exact, order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0]);
-        acc += pub_apply_loop(Q[1], pub_args_now(rp)->exact, order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1]);
+        // (the scan-order table in global memory: see pub_big_fixed_lds_bytes)
+        acc += pub_apply_loop(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0]);
+        {
+          PubArgsPtr R8 = pub_args_now(rp);
+          acc += pub_apply_loop(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1]);
+        }
         if (l0 < Lp) {
           PubArgsPtr R3 = pub_args_now(rp);
           unsigned char* dslot = R3->map_dst + (size_t)p * R3->ss.slot_bytes;
