@@ -915,7 +915,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     } else {                                                                                                                       \
       const Landmark<double>* const l2[2] = {&S[2 * (q)], &S[2 * (q) + 1]};                                                        \
       if (PK_PUB_ABLATE < 4) pub_gatesN<2>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);                                  \
+      PK_STAMP(sk0_)                                                                                                               \
       if (PK_PUB_ABLATE < 3) pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                        \
+      PK_STAMP(sk1_)                                                                                                               \
+      PK_PSTAMP(2, sk0_, sk1_) /* keys: part of the gates-and-verdicts slot */                                                     \
     }                                                                                                                              \
     Q[2 * (q)] = qq[0];                                                                                                          \
     Q[2 * (q) + 1] = qq[1];                                                                                                      \

@@ -36,7 +36,7 @@ f.synchronize(); so.pk_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
 print("git", os.environ.get("PK_GIT_SHA") or os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "unknown", "P", P, "L", L)
 if v[48 + 8] > 0:  # k_step_pub ran (512 < L <= 2048, publish table in LDS)
-    pn = ["scalars, requests", "gates (waits for candidate records, means)", "verdicts (waits for covariance rows)", "barrier A",
+    pn = ["scalars, requests", "gates (waits for candidate records, means)", "  of which: keys of the gate-passing blobs", "barrier A",
           "unseen blobs, subscribe", "barrier B", "updates, stores issued", "wave sum", "particle (wave lifetime)"]
     life = v[48 + 8]
     for i, n in enumerate(pn):
