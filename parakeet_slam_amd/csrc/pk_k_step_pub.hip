@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
   }
 #ifdef PK_STAMPS
-  unsigned long long pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   // the 14 rows + counts of the lane's pair q_ (landmarks lb_, lb_ + 1) of the slot at sslot_
 #define PK_PUB_ROW(q_, field, F)                                                                  \
@@ -1017,6 +1017,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
             acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i])
                                                : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
         }
+        PK_STAMP(su0_)
         if (l0 < Lp) {
 #if defined(PK_PUB_STORE_FLAVOUR)  // diagnostic variants: -DPK_PUB_STORE_FLAVOUR='"sc1"' ...
 #define PK_PUB_STORE(field, F)                                                                                         \
@@ -1060,6 +1061,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           const unsigned char* ns = pub_slot_source(R6).at(nsrc);
           PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
         }
+        PK_STAMP(su1_)
+        PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
       }
     }
     PK_STAMP(s7)
@@ -1078,7 +1081,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   }
 #ifdef PK_STAMPS
   if ((tid0 & 63) == 0)
-    for (int k = 0; k < 10; ++k) atomicAdd(&pk_pstamp_acc[k], pst[k]);
+    for (int k = 0; k < 12; ++k) atomicAdd(&pk_pstamp_acc[k], pst[k]);
 #endif
 }
 

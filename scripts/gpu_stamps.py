@@ -41,6 +41,7 @@ if v[48 + 8] > 0:  # k_step_pub ran (512 < L <= 2048, publish table in LDS)
     life = v[48 + 8]
     for i, n in enumerate(pn):
         print("pub %-44s %12.4g  %5.1f%%" % (n, v[48 + i], 100 * v[48 + i] / life))
+    print("pub %-44s %12.4g  %5.1f%%" % ("  of the updates: stores + next rows issued", v[48 + 10], 100 * v[48 + 10] / life))
     print("pub cycles per particle and wave: %.0f" % (life / max(v[48 + 9], 1.0)))
     sys.exit(0)
 if v[32 + 14] > 0:  # k_step_regs ran (512 < L <= 2048)
