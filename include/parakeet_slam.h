@@ -359,7 +359,7 @@ int pk_download_sources(pk_filter* f, int32_t* src);
 int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow);
 /* Which instance of the register route (PK_ROUTE_ML_REGS) worked on the last scan (instrumentation; the choice is made
  * on the device, per scan): *published = 1 when k_step_pub did -- contested blobs (prkt_core_v2.py:353-381) settled by
- * static publish / subscribe through LDS, two barriers per particle -- 0 when k_step_regs did (the publish table did
+ * static publish / subscribe through LDS, three barriers per particle -- 0 when k_step_regs did (the publish table did
  * not fit LDS, a candidate list overflowed, or "pub_step" is off).  Synchronises the stream. */
 int pk_observe_published(pk_filter* f, int32_t* published);
 
