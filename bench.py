@@ -75,8 +75,6 @@ ROUTE_KERNEL = {
     "ml_fused": "k_step_fused (association gates + settling of contested blobs + EKF update + log-weight in ONE kernel)",
     "ml_regs": "k_step_regs (L <= 2048: a particle's whole map in registers, two landmarks per lane; association "
                "gates + settling of contested blobs + EKF update + log-weight in ONE pass over the map)",
-    "ml_owner": "k_step_owner (candidate lists of a reference particle both ways; every landmark settles its own blobs against "
-                "its rivals: association gates + settling + EKF update + log-weight in ONE pass, no synchronisation inside a particle)",
     "ml_handoff": "k_observe_fast (EKF update + log-weight + settling of contested associations; includes the "
                   "near-empty general k_observe launch for flagged particles; the association kernel is separate)",
     "ml_sweep": "k_observe_sweep (two sweeps over landmark chunks: settling of contested associations, EKF update + "
@@ -89,7 +87,7 @@ ROUTE_KERNEL["ml_fused_pub"] = ("k_step_pub<256 lanes> (L <= 512: two landmarks 
                                 "static publish / subscribe through LDS + EKF update + log-weight in ONE pass over the map)")
 ROUTE_KERNEL["ml_pub_big"] = ("k_step_pub_big (2048 < L <= 6144: two passes over a particle's map, pair by pair -- gates + verdicts published, contested "
                              "blobs settled through LDS, then rows in again from L2 + EKF update + log-weight + rows out: ONE kernel, no separate association kernel)")
-ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_fused_pub": "step_pub", "ml_regs": "step_regs", "ml_regs_pub": "step_pub", "ml_pub_big": "step_pub_big", "ml_owner": "step_owner",
+ROUTE_TRAFFIC_KEY = {"known_ids": "observe_known", "ml_fused": "step_fused", "ml_fused_pub": "step_pub", "ml_regs": "step_regs", "ml_regs_pub": "step_pub", "ml_pub_big": "step_pub_big",
                      "ml_handoff": "observe_ml", "ml_sweep": "observe_sweep"}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_UPDATE = 224  # 14 fp64 read + 14 written per particle.landmark
@@ -444,7 +442,7 @@ def main():
     else:
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
-    for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_CAND_LISTS", "PK_OPT_OWNER_STEP",
+    for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_CAND_LISTS",
                  "PK_OPT_REGS_RETRY", "PK_OPT_SPLIT_RESERVE_CUS", "PK_OPT_PUB_STEP", "PK_OPT_PUB_SMALL"):  # tuning experiments only
         if os.environ.get(name):
             filt.set_option(name[7:].lower(), int(os.environ[name]))

@@ -122,9 +122,6 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    for the candidate-list launches at 10 000 x 500);
  *   "pub_entry_limit" = 0 (default: what LDS holds) or n: treat the publish table as n entries small (tests: scans
  *                    whose table does not fit fall back to k_step_regs);
- *   "owner_step"   = 0, 1 (maps of more than 512 landmarks) or 2 (every map): k_step_owner -- candidate lists of a
- *                    reference particle in both directions, every landmark settles its own blobs against its rivals,
- *                    no synchronisation between the landmarks of a particle;
  *   "cand_lists"   = 1 (default: k_step_regs tests each landmark against the candidate list of a reference particle
  *                    -- k_candidates, once per scan -- instead of walking the colour grid; particles outside the
  *                    list's margins go the general way) or 0 (grid walk);
@@ -341,8 +338,7 @@ enum {
                                 coupled Qt): association, 4x4 / 5x5 update and weight in one slow, general kernel */
   PK_ROUTE_ML_PUB_BIG = 9,   /* k_step_pub_big: maps of 2 049 ... 6 144 landmarks -- publish / subscribe settling in two passes over the map
                               * (the second one from L2 / Infinity Cache); what it leaves goes through k_observe_sweep */
-  PK_ROUTE_ML_OWNER = 7      /* k_step_owner: every landmark settles its own blobs against the rivals named by the
-                                reference particle's candidate lists; no synchronisation inside a particle, any L */
+  /* (7 was k_step_owner, removed in round 3) */
 };
 int pk_observe_route(const pk_filter* f);
 /* The map indirection of the live generation (instrumentation): src[P], the map slot each particle's

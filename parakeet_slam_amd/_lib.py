@@ -369,7 +369,7 @@ class DeviceFilter(object):
     def observe_staged_range(self, fresh, p0, p1, first, last):
         check(self._lib.pk_observe_staged_range(self._h, 1 if fresh else 0, int(p0), int(p1), 1 if first else 0, 1 if last else 0))
 
-    ROUTES = {0: "none", 1: "known_ids", 2: "ml_general", 3: "ml_handoff", 4: "ml_sweep", 5: "ml_fused", 6: "ml_regs", 7: "ml_owner", 8: "dense", 9: "ml_pub_big"}
+    ROUTES = {0: "none", 1: "known_ids", 2: "ml_general", 3: "ml_handoff", 4: "ml_sweep", 5: "ml_fused", 6: "ml_regs", 8: "dense", 9: "ml_pub_big"}
 
     def observe_route(self):
         """Kernels the last observe / step used for association + EKF update (pk_observe_route)."""

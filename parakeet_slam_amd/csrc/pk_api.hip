@@ -73,7 +73,6 @@ struct AssocLaunch {
   bool fused = false;  // nothing launched yet: k_step_fused does gates + EKF in one kernel
   bool regs = false;   // nothing launched yet: k_step_regs does the same for 512 < L <= 2048
   bool retry = false;  // with regs: the hand-off lists for the flagged particles' second chance are allocated
-  bool owner = false;  // nothing launched yet: k_step_owner (candidate lists both ways, no barriers), any L
   bool big = false;    // nothing launched yet: k_step_pub_big (2 048 < L <= 6 144: publish / subscribe in two passes over the map)
   BlobGrid grid{};
   int n9 = 0;
@@ -136,7 +135,6 @@ struct pk_filter {
   int route = PK_ROUTE_NONE;  // kernels used by the last observe
   int upload_kernel = 1; // per-scan block: read from pinned host memory by a kernel (1) or hipMemcpyAsync (0)
   int fused_step = 1;    // L <= 512 and small scan tables: k_step_fused instead of hand-off + k_observe_fast
-  int owner_step = 0;    // k_step_owner (no synchronisation between a particle's landmarks): 0 off, 1 for L > 512, 2 for every L
   unsigned* bcnt_dev = nullptr;  // [bcand_cap] entries of the blobs' inverse candidate lists
   uint4* brec_dev = nullptr;     // [bcand_cap] the lists
   int64_t bcand_cap = 0;
@@ -618,7 +616,6 @@ int stage_ml_scan(pk_filter* f, const double* blobs, int B) {
 // Will a production observe of a scan with these tables take the register route (k_step_regs)?
 static bool regs_route_taken(pk_filter* f, const BlobGrid& g, int B, int n9) {
   if (f->fast_observe != 1 || B <= 0 || f->d.lay.L >= 65535) return false;
-  if (f->owner_step == 2 || (f->owner_step == 1 && f->d.lay.L > kFastMaxL)) return false;  // k_step_owner first
   return f->regs_step && f->d.lay.L > kFastMaxL && f->d.lay.L <= kRegsMaxL && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds;
 }
 
@@ -655,18 +652,6 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
   if (use_grid) {
     FastHandoff fh{};
     const bool sweep = f->d.lay.L > kFastMaxL || f->fast_observe >= 2;
-    if (out && want_fast && !finalize && f->fast_observe == 1 && B > 0 && f->d.lay.L < 65535 &&
-        (f->owner_step == 2 || (f->owner_step == 1 && f->d.lay.L > kFastMaxL))) {
-      if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
-      out->owner = true;
-      out->grid = g;
-      out->n9 = n9;
-      out->tables = f->scan_dev + o_tab;
-      out->exact = reinterpret_cast<const double*>(f->scan_dev + o_exact);
-      const size_t cs_b = ((size_t)(g.ncell + 1) * 2 + 15) & ~(size_t)15;
-      out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
-      return PK_OK;
-    }
     if (out && want_fast && !finalize && f->fast_observe == 1 && f->fused_step && !sweep && B > 0 && n9 > 0 &&
         fused_lds_bytes(g.ncell, B, n9) <= kFusedMaxLds) {
       if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
@@ -1524,43 +1509,12 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   AssocLaunch al;
   if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
   ex.gmax_key = ctl_gmax_key(f);
-  f->route = al.owner ? PK_ROUTE_ML_OWNER
-             : al.big ? PK_ROUTE_ML_PUB_BIG
+  f->route = al.big ? PK_ROUTE_ML_PUB_BIG
              : al.fused ? PK_ROUTE_ML_FUSED
              : al.regs ? PK_ROUTE_ML_REGS
              : !al.fast ? PK_ROUTE_ML_GENERAL
              : (f->d.lay.L > kFastMaxL || f->fast_observe >= 2) ? PK_ROUTE_ML_SWEEP : PK_ROUTE_ML_HANDOFF;
-  if (al.owner) {
-    FastHandoff fh = f->fh;
-    fh.n_flagged = ctl_n_flagged(f);
-    fh.flags_only = true;
-    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
-    if ((rc = ensure_inverse_lists(f, B))) return rc;
-    CandTable cand;
-    {
-      Span t(f, PK_T_ASSOC);  // the reference particle's candidate lists, both ways
-      launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
-      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
-                        kCandSlots, f->out4);
-    }
-    cand.rec = f->cand_dev;
-    cand.brec = f->brec_dev;
-    cand.over = ctl_cand_over(f);
-    cand.n_stray = ctl_n_stray(f);
-    {
-      Span t(f, PK_T_OBSERVE);
-      ObserveExtras e1 = ex;
-      e1.flip = false;
-      launch_step_owner(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand);
-    }
-    // flagged particles (outside the lists' margins; every particle when a list overflowed): general kernels
-    Span t(f, PK_T_ASSOC);
-    launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fh);
-    ObserveExtras e2 = ex;
-    e2.only_flagged = f->fh.pflag;
-    e2.n_flagged = ctl_n_flagged(f);
-    launch_observe(f->stream, f->d, al.blobs, al.dir, B, nullptr, nullptr, 0, f->ids_dev, f->qt, e2);
-  } else if (al.fused || al.regs || al.big) {
+  if (al.fused || al.regs || al.big) {
     CandTable cand;
     if ((rc = onepass_prepare(f, al, B, &cand))) return rc;
     if ((rc = onepass_launch(f, al, B, ex, cand, 0, f->d.P))) return rc;
@@ -1740,11 +1694,6 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "fused_step")) {
     f->fused_step = value != 0;
-    return PK_OK;
-  }
-  if (!strcmp(name, "owner_step")) {
-    if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "owner_step: 0 (off), 1 (maps of more than 512 landmarks) or 2 (every map)");
-    f->owner_step = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "cand_lists")) {

@@ -841,4 +841,19 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   if (a.bcnt && stray_dev) hipLaunchKernelGGL(k_cand_strays, dim3(1), dim3(256), 0, s, a.bcnt, B, stray_dev);
 }
 
+// A candidate list overflowed (a landmark with more than kCandSlots blobs inside the widened gates, or a blob listed by
+// more landmarks): the candidate-list kernels stand back, and every particle is handed to the general kernels.
+// (the particles [p0, p1) of a ranged launch; the count is added to)
+__global__ void __launch_bounds__(256) k_flag_range_if(const unsigned* over, unsigned char* pflag, unsigned* n_flagged, int64_t p0, int64_t p1) {
+  if (*over == 0u) return;
+  const int64_t p = p0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < p1) pflag[p] = 1;
+  if (p == p0) atomicAdd(n_flagged, (unsigned)(p1 - p0));
+}
+void launch_flag_range_if(hipStream_t s, const unsigned* over_dev, unsigned char* pflag_dev, unsigned* n_flagged_dev, int64_t p0, int64_t p1) {
+  if (p1 <= p0) return;
+  hipLaunchKernelGGL(k_flag_range_if, dim3((unsigned)((p1 - p0 + 255) / 256)), dim3(256), 0, s, over_dev, pflag_dev, n_flagged_dev, p0, p1);
+}
+
+
 }  // namespace pk

@@ -173,10 +173,10 @@ constexpr int kCandSlots = 8;
 constexpr double kCandBearing = 0.2;   // rad: |expected bearing - reference's| of every particle, else flagged (the particles' HEADING spread goes here: sigma 0.02 rad after 25 steps of the bench)
 constexpr double kCandColour = 1.5;    // per channel: |colour mean - reference's|
 // The inverse lists, blob -> the (<= kCandSlots) landmarks that list it, 16 B per blob (8 x u16, 0xFFFF = empty, filled from
-// the front in arbitrary order), let a landmark find its RIVALS for a blob without any per-particle table (k_step_owner).
+// the front in arbitrary order), are what k_cand_entries lays the publish table of k_step_pub out from.
 struct CandTable {
   const uint4* rec = nullptr;         // [Lp][2] landmark records
-  const uint4* brec = nullptr;        // [B] blob records (k_step_owner), or NULL
+  const uint4* brec = nullptr;        // [B] blob records (the inverse lists), or NULL
   const unsigned* over = nullptr;     // != 0: some list has more entries than slots -> grid walk for this scan
   const unsigned* skip_cand = nullptr; // k_step_regs' candidate-list instance stands back when != 0 (NULL: when *over != 0)
   const unsigned* n_stray = nullptr;  // blobs on no landmark's list
@@ -190,11 +190,10 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr,
                        int slots = kCandSlots, const double* pose_sums4_dev = nullptr);
-// K2 + K3 without synchronisation between the landmarks of a particle (pk_k_owner.hip): any L, any B whose candidate
-// lists fit; one 256-lane workgroup per particle.  Returns at once when *cand.over != 0.
-void launch_step_owner(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
-                       const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand);
-// The same for 512 < L <= kRegsMaxL: persistent 1024-lane workgroups, a particle's whole map in registers (two
+// K2 + K3 in one pass (pk_k_observe_ml.hip, pk_k_step_pub.hip).  (k_step_owner, a barrier-free variant in which every
+// landmark settled its blobs against the rivals named by the two-way lists, was measured at 56 ms against 13 and removed
+// in round 3: DESIGN.md section 4.)
+// 512 < L <= kRegsMaxL: persistent 1024-lane workgroups, a particle's whole map in registers (two
 // landmarks per lane), state read once; warm: how much of the next particle's slot is pulled into L2 ahead of time.
 constexpr int kRegsMaxL = 2048;
 size_t regs_lds_bytes(int ncell, int B, int n9);

@@ -170,11 +170,10 @@ def test_observe_with_both_kernels_gives_identical_state(lib):
 
 
 # ---------------------------------------------------------------- fast hand-off path (L <= 512)
-def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1, fused=1, owner=0, want_flagged=False):
+def observe_state(lib, P, means, covs, poses, blobs, fast, immutable=None, dup=1, fused=1, want_flagged=False):
     L = means.shape[0]
     f = lib.DeviceFilter(P, L)
     f.set_option("fast_observe", fast)
-    f.set_option("owner_step", owner)  # 2: k_step_owner for every map size
     f.set_option("assoc_dup", dup)
     f.set_option("fused_step", fused)
     f.set_option("regs_step", fused)  # "one kernel": k_step_fused (L <= 512) / k_step_regs (L <= 2048); 0: hand-off + second kernel
@@ -210,10 +209,9 @@ def check_fast(lib, P, means, covs, poses, blobs, immutable=None):
     gen = observe_state(lib, P, means, covs, poses, blobs, 0, immutable)
     sweep = observe_state(lib, P, means, covs, poses, blobs, 2, immutable)
     sweep8 = observe_state(lib, P, means, covs, poses, blobs, 3, immutable)
-    own = observe_state(lib, P, means, covs, poses, blobs, 1, immutable, owner=2)  # k_step_owner (+ general kernels for flagged particles)
     o = oracle_state(P, means, covs, poses, blobs, immutable)
-    assert np.array_equal(own[0][:, :3], gen[0][:, :3]) and np.allclose(own[0][:, 3], gen[0][:, 3], rtol=1e-11, atol=0)
-    for x, y in zip(own[1], gen[1]):
+    assert np.array_equal(fast[0][:, :3], gen[0][:, :3]) and np.allclose(fast[0][:, 3], gen[0][:, 3], rtol=1e-11, atol=0)
+    for x, y in zip(fast[1], gen[1]):
         assert np.array_equal(x, y)  # same device functions on the same inputs: the maps agree bit for bit
     for sw in (sweep, sweep8):
         assert np.allclose(sw[0], gen[0], rtol=1e-11, atol=0)
@@ -389,10 +387,11 @@ def test_sweep_observe_ties_across_chunks_keep_the_earliest(lib):
 
 
 @pytest.mark.parametrize("L,P", [(40, 64), (500, 32), (1400, 8), (2000, 6), (3000, 4)])
-def test_owner_route_tight_cloud_settles_contested_blobs_itself(lib, L, P):
+def test_one_pass_routes_tight_cloud_settle_contested_blobs_themselves(lib, L, P):
     """Particles as close together as a filter's are after a resample (centimetres, hundredths of a radian): everyone sits
-    inside the margins of the reference particle's candidate lists, k_step_owner flags nobody, and what it decides --
-    look-alike landmarks a few bearings apart contest every seventh blob -- is what the oracle and the general kernels decide."""
+    inside the margins of the reference particle's candidate lists, and what the one-pass route of the map's size (k_step_fused,
+    k_step_pub, k_step_pub_big -- with the second chance for what they flag) decides -- look-alike landmarks a few bearings apart contest every
+    seventh blob -- is what the oracle and the general kernels decide."""
     rs = np.random.RandomState(900 + L)
     means, covs = synthetic_world(L)
     n = len(means[3::7])
@@ -406,10 +405,12 @@ def test_owner_route_tight_cloud_settles_contested_blobs_itself(lib, L, P):
     poses = np.zeros((P, 4))
     poses[:, :3] = np.array([0.02, -0.01, 0.01]) + rs.normal(0, [0.02, 0.02, 0.01], (P, 3))
     poses[:, 3] = 1.0
-    own = observe_state(lib, P, means, covs, poses, blobs, 1, imm, owner=2, want_flagged=True)
-    assert own[3] == "ml_owner"
-    if L <= 2000:  # (at 3 000 landmarks this world's look-alike groups overflow a candidate list: everybody goes the general way)
-        assert own[2] == (0, 0), "nobody flagged, no list overflow"
+    own = observe_state(lib, P, means, covs, poses, blobs, 1, imm, want_flagged=True)
+    assert own[3] == ("ml_fused" if L <= 512 else "ml_regs" if L <= 2048 else "ml_pub_big")
+    if L <= 512:
+        assert own[2] == (0, 0), "k_step_fused: nobody flagged"
+    elif L <= 2048:  # k_step_pub hands particles with a landmark that passes more than four look-alike blobs to the second chance
+        assert own[2][1] == 0, "no candidate list overflows"
     gen = observe_state(lib, P, means, covs, poses, blobs, 0, imm)
     o = oracle_state(P, means, covs, poses, blobs, imm)
     assert np.allclose(own[0][:, 3], o.weights(), rtol=1e-9, atol=0)

@@ -121,12 +121,12 @@ def test_config2_resample_properties_tracking_and_oracle_ancestors(lib, config2_
     assert np.isfinite(out["poses"]).all()
 
 
-@pytest.mark.parametrize("name,opts", [("sweep", {"regs_step": 0}), ("general", {"fast_observe": 0}), ("owner", {"owner_step": 1}),
-                                       ("regs", {"owner_step": 0})])
+@pytest.mark.parametrize("name,opts", [("sweep", {"regs_step": 0}), ("general", {"fast_observe": 0}), ("regs", {"pub_step": 0}),
+                                       ("pub", {})])
 def test_config2_routes_agree_at_full_size(lib, config2_default, name, opts):
     a, b = config2_default, run_config2(lib, 3, opts)
-    assert b["route"] == {"sweep": "ml_sweep", "general": "ml_general", "owner": "ml_owner", "regs": "ml_regs"}[name]
-    if name in ("owner", "regs"):
+    assert b["route"] == {"sweep": "ml_sweep", "general": "ml_general", "regs": "ml_regs", "pub": "ml_regs"}[name]
+    if name in ("pub", "regs"):
         for n_flagged, cand_over in b["flagged"]:
             assert cand_over == 0 and n_flagged <= P2 // 100
     for s in range(3):

@@ -56,7 +56,7 @@ def run(lib, P, L, opts, dense=False, ids=None, steps=2, seed=3):
 
 
 @pytest.mark.parametrize("L,opts,route", [(40, {}, "ml_fused"), (40, {"fused_step": 0}, "ml_handoff"), (40, {"fast_observe": 0}, "ml_general"),
-                                          (700, {}, "ml_regs"), (700, {"regs_step": 0}, "ml_sweep"), (700, {"owner_step": 1}, "ml_owner")])
+                                          (700, {}, "ml_regs"), (700, {"regs_step": 0}, "ml_sweep"), (700, {"pub_step": 0}, "ml_regs"), (2500, {}, "ml_pub_big")])
 def test_potential_features_weigh_a_tenth_and_are_promoted(lib, L, opts, route):
     got, left, start = run(lib, 48, L, opts)
     assert got == route

@@ -88,13 +88,12 @@ def test_random_world_all_routes(lib, seed):
         "sweep8": {"fast_observe": 3},
         "general": {"fast_observe": 0},
         "general_brute": {"fast_observe": 0, "assoc_kernel": 1},
-        "owner": {"owner_step": 2},
         "regs_without_pub": {"pub_step": 0},  # L > 512: k_step_regs instead of k_step_pub (L <= 512: the default route again)
     }
     got = {name: device_state(lib, case, opts) for name, opts in routes.items()}
     assert got["default"][2] == ("ml_fused" if L <= 512 else "ml_regs")
     assert got["two_kernel"][2] == ("ml_handoff" if L <= 512 else "ml_sweep")
-    assert got["general"][2] == "ml_general" and got["owner"][2] == "ml_owner"
+    assert got["general"][2] == "ml_general"
     for name, (logw, (m, c, k), _) in got.items():
         assert np.allclose(logw, o.logw, rtol=1e-10, atol=1e-9), name  # log domain: the weights themselves underflow
         assert np.allclose(m, o.mean, rtol=1e-9, atol=1e-11), name
@@ -114,8 +113,7 @@ def test_random_world_large_maps_one_pass_route(lib, seed, L, P):
     o.x, o.y, o.h = poses[:, 0].copy(), poses[:, 1].copy(), poses[:, 2].copy()
     o.logw = np.log(poses[:, 3])
     o.observe(blobs)
-    routes = {"default": {}, "regs_without_pub": {"pub_step": 0}, "sweep": {"regs_step": 0}, "general": {"fast_observe": 0},
-              "owner": {"owner_step": 1}}
+    routes = {"default": {}, "regs_without_pub": {"pub_step": 0}, "sweep": {"regs_step": 0}, "general": {"fast_observe": 0}}
     got = {name: device_state(lib, case, opts) for name, opts in routes.items()}
     # the one-pass route needs the scan tables AND its probability queue in LDS (about 2 000 blobs, depending on
     # how the colours fill the grid); larger scans take the two-sweep route
