@@ -411,7 +411,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(os.environ.get("PK_BENCH_BACKEND", "nccl"))  # "nccl" = RCCL over xGMI
+        dist.init_process_group(os.environ.get("PK_BENCH_BACKEND", "gloo" if same_gpu else "nccl"))  # "nccl" = RCCL over xGMI (RCCL refuses two ranks on one device)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
         world = dist.get_world_size()
