@@ -170,3 +170,36 @@ def test_staged_scan_discarded_by_a_supplied_ids_observe(lib):
     assert all(np.array_equal(a, b) for a, b in zip(f.download_landmarks(), g.download_landmarks()))
     f.close()
     g.close()
+
+
+def test_upload_landmarks_refuses_non_finite_values_in_both_layouts(lib):
+    """pk_upload_landmarks validates what it is given like pk_upload_map does (Feature.__init__ :882-895 takes anything; a NaN
+    mean or covariance would sit in HBM until some later step turned every weight into NaN) -- in the compact layout and,
+    since round 3, in the dense one as well -- and leaves the loaded maps untouched."""
+    P, L = 6, 4
+    means = np.array([[5.0, 0, 10, 20, 30], [0, 5.0, 100, 20, 30], [-5.0, 0, 10, 200, 30], [0, -5.0, 10, 20, 230]])
+    covs = np.broadcast_to(0.25 * np.identity(5), (L, 5, 5)).copy()
+    for dense in (False, True):
+        f = lib.DeviceFilter(P, L)
+        c0 = covs.copy()
+        if dense:
+            c0[1, 0, 3] = c0[1, 3, 0] = 0.01  # position-colour coupling: the dense 30-row layout
+        f.upload_map(means, c0.reshape(L, 25))
+        before = f.download_landmarks()
+        m = np.broadcast_to(means, (1, L, 5)).copy()
+        c = np.broadcast_to(c0.reshape(L, 25), (1, L, 25)).copy()
+        bad_m, bad_c = m.copy(), c.copy()
+        bad_m[0, 2, 1] = np.nan
+        bad_c[0, 3, 6] = np.inf
+        for kw in ({"means": bad_m}, {"covs": bad_c}, {"means": m, "covs": bad_c}):
+            with pytest.raises(lib.PkError) as e:
+                f.upload_landmarks(2, 3, **kw)
+            assert e.value.status == lib.PK_ERR_INVALID, (dense, list(kw))
+        after = f.download_landmarks()
+        for a, b in zip(before, after):
+            assert np.array_equal(a, b)
+        f.upload_landmarks(2, 3, means=m, covs=c)  # the handle still takes good values
+        f.observe(np.array([[0.1, 10, 20, 30.0]]))
+        assert f.observe_route() == ("dense" if dense else "ml_fused")
+        assert np.isfinite(f.download_poses()).all()
+        f.close()
