@@ -358,6 +358,12 @@ int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow);
  * static publish / subscribe through LDS, three barriers per particle -- 0 when k_step_regs did (the publish table did
  * not fit LDS, a candidate list overflowed, or "pub_step" is off).  Synchronises the stream. */
 int pk_observe_published(pk_filter* f, int32_t* published);
+/* Per particle, how the last one-pass maximum-likelihood observe (k_step_fused / k_step_pub / k_step_pub_big / k_step_regs)
+ * dealt with it (instrumentation; what the full-size oracle audits of tests/test_gpu_audit.py pick their samples by):
+ * flags[P], 0 = settled by the one-pass kernel itself, 2 = redone by the second-chance route (eight-slot hand-off +
+ * k_observe_sweep), 1 = redone by the general kernels.  The particles are match_features_to_scan's, prkt_core_v2.py:317-351,
+ * whatever the route.  All zeros when the last observe took another route.  Synchronises the stream. */
+int pk_observe_flags(pk_filter* f, uint8_t* flags);
 
 /* ---- host-side reproductions of the reference's RNG streams (no GPU needed) ------
  * numpy.random.seed(s); numpy.random.normal(0,1,n)  (legacy MT19937 + polar method), the

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pk_download_sources": (C.c_int, [_h, _ip]),
     "pk_observe_flagged": (C.c_int, [_h, _lp, _lp]),
     "pk_observe_published": (C.c_int, [_h, C.POINTER(C.c_int32)]),
+    "pk_observe_flags": (C.c_int, [_h, _bp]),
     "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_create_python": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_destroy": (C.c_int, [_h]),
@@ -386,6 +387,12 @@ class DeviceFilter(object):
         v = C.c_int32()
         check(self._lib.pk_observe_published(self._h, C.byref(v)))
         return bool(v.value)
+
+    def observe_flags(self):
+        """Per particle: 0 = settled by the one-pass kernel, 2 = second-chance route, 1 = general kernels (pk_observe_flags)."""
+        out = np.zeros(self.P, dtype=np.uint8)
+        check(self._lib.pk_observe_flags(self._h, out.ctypes.data_as(_bp)))
+        return out
 
     def download_sources(self):
         """Map slot each particle's landmarks currently live in (pk_download_sources)."""

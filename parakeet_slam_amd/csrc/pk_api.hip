@@ -139,7 +139,7 @@ struct pk_filter {
   uint4* brec_dev = nullptr;     // [bcand_cap] the lists
   int64_t bcand_cap = 0;
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
-  uint4* cand_dev = nullptr;  // [Lp][3] candidate records (two or three uint4 per landmark in use)
+  uint4* cand_dev = nullptr;  // [Lp + kCandSpare][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
   int pub_small = 0;     // L <= 512: k_step_pub<256 lanes> instead of k_step_fused (measured: the kernel 1 % slower, the step 50 us longer)
@@ -711,7 +711,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
     if (fh.lmpass && f->cand_lists && f->d.lay.L < 65535) {
       // the hand-off instance tests each landmark against the reference particle's candidate list (k_candidates, once per
       // scan) instead of walking the colour grid; a list that overflows leaves the scan to the walk
-      if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
+      if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
       // (sixteen entries per list: with several thousand blobs around the robot eight overflow somewhere in every scan)
       launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
       launch_candidates(f->stream, f->d, B, reinterpret_cast<const double*>(f->scan_dev + o_exact), 0, f->cand_dev, ctl_cand_over(f),
@@ -1318,8 +1318,8 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
   // subscribe instance of three 256-lane workgroups per CU
   const bool small_pub = al.fused && f->pub_small && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
   if (al.big) {  // sixteen-entry lists both ways and the publish table's layout
-    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
-    if (!f->erec_dev2 && (rc = dev_alloc(f, &f->erec_dev2, (size_t)f->d.lay.Lp * 2))) return rc;
+    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
+    if (!f->erec_dev2 && (rc = dev_alloc(f, &f->erec_dev2, ((size_t)f->d.lay.Lp + kCandSpare) * 2))) return rc;
     if ((rc = ensure_inverse_lists(f, B, 2 * kCandSlots))) return rc;
     int ecap = step_pub_big_entry_capacity(B);
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
@@ -1336,11 +1336,11 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     return PK_OK;
   }
   if ((al.regs && f->cand_lists && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds) || small_pub) {
-    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, (size_t)f->d.lay.Lp * 3))) return rc;
+    if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
     int ecap = !f->pub_step ? 0 : al.fused ? step_pub_entry_capacity_small(B) : step_pub_entry_capacity(B);
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     if (ecap > 0) {
-      if (!f->erec_dev && (rc = dev_alloc(f, &f->erec_dev, (size_t)f->d.lay.Lp))) return rc;
+      if (!f->erec_dev && (rc = dev_alloc(f, &f->erec_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
       if ((rc = ensure_inverse_lists(f, B))) return rc;
     }
     Span t(f, PK_T_ASSOC);
@@ -2266,6 +2266,19 @@ int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow) {
   }
   if (flagged) *flagged = w[0];
   if (cand_overflow) *cand_overflow = w[1];
+  return PK_OK;
+}
+int pk_observe_flags(pk_filter* f, uint8_t* flags) {
+  if (!f || !flags) return fail(PK_ERR_INVALID, "pk_observe_flags: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const bool onepass = f->route == PK_ROUTE_ML_REGS || f->route == PK_ROUTE_ML_FUSED || f->route == PK_ROUTE_ML_PUB_BIG;
+  if (onepass && f->fh.pflag) {
+    PK_HIP(hipMemcpyAsync(flags, f->fh.pflag, (size_t)f->d.P, hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+  } else {
+    memset(flags, 0, (size_t)f->d.P);
+  }
   return PK_OK;
 }
 int pk_observe_published(pk_filter* f, int32_t* published) {

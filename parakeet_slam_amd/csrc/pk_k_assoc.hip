@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
     }
   }
   __syncthreads();
-  if (w == 0 && l < a.Lp) {
+  if (w == 0 && l < a.Lp + kCandSpare) {  // (the spare records: empty lists)
     const int n = has ? s_n[lane] : 0;
     unsigned short c[SLOTS];
 #pragma unroll
@@ -835,9 +835,9 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.Lp = d.lay.Lp;
   a.B = B;
   if (slots > kCandSlots)
-    hipLaunchKernelGGL(k_candidates<2 * kCandSlots>, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(kCandThreads), 0, s, a);
+    hipLaunchKernelGGL(k_candidates<2 * kCandSlots>, dim3((unsigned)((d.lay.Lp + kCandSpare + 63) / 64)), dim3(kCandThreads), 0, s, a);
   else
-    hipLaunchKernelGGL(k_candidates<kCandSlots>, dim3((unsigned)((d.lay.Lp + 63) / 64)), dim3(kCandThreads), 0, s, a);
+    hipLaunchKernelGGL(k_candidates<kCandSlots>, dim3((unsigned)((d.lay.Lp + kCandSpare + 63) / 64)), dim3(kCandThreads), 0, s, a);
   if (a.bcnt && stray_dev) hipLaunchKernelGGL(k_cand_strays, dim3(1), dim3(256), 0, s, a.bcnt, B, stray_dev);
 }
 

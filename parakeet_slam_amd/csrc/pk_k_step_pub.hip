@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   __syncthreads();  // brec / binfo written above are read below by other threads of this (the only) workgroup
   __threadfence_block();
   constexpr int RW = 1 + SLOTS / 8;  // uint4 per landmark record
-  for (int l = tid; l < a.Lp; l += 1024) {
+  for (int l = tid; l < a.Lp + kCandSpare; l += 1024) {  // (the spare records get empty entry words)
     const unsigned* cws = reinterpret_cast<const unsigned*>(a.cand + RW * (size_t)l + 1);
     unsigned short* e = a.erec + (size_t)l * SLOTS;
 #pragma unroll
@@ -297,7 +297,7 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
                 fabs(in[j].mr - (double)__uint_as_float(in[j].ref.y)) <= kCandColour &&
                 fabs(in[j].mg - (double)__uint_as_float(in[j].ref.z)) <= kCandColour &&
                 fabs(in[j].mb - (double)__uint_as_float(in[j].ref.w)) <= kCandColour;
-    // the list is filled from the front; a landmark beyond the map has none
+    // the list is filled from the front; a landmark beyond the map has none (its lane reads the table's spare records)
 #pragma unroll
     for (int w = 0; w < W4; ++w) {
       c[j][4 * w + 0] = in[j].cw[w].x;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
       e[j][4 * w + 2] = in[j].ew[w].z;
       e[j][4 * w + 3] = in[j].ew[w].w;
     }
-    c[j][0] = in[j].has ? c[j][0] : 0xFFFFFFFFu;
+    c[j][0] = in[j].has ? c[j][0] : 0xFFFFFFFFu;  // (belt and braces: one conditional move)
 #pragma unroll
     for (int k = 0; k < SL; ++k) sl[j][k] = 0xFFFFFFFFu;
     dmin[j] = 3.0e38f;
@@ -884,8 +884,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         uint4 cref[2 * NP], ccw[2 * NP], cew[2 * NP];
         auto request_cand = [&](int q) {
           PubArgsPtr R2 = pub_args_now(rp);
-          const uint4* cr = R2->cand + 2 * (size_t)lbase[q];
-          const uint4* er = R2->erec + lbase[q];
+          // (lanes beyond the map: the spare records behind the table, whose lists are empty -- the ROWS such a lane holds are
+          // the last pair's once more, and with that pair's lists it would gate, take and weigh the pair's blobs a second time)
+          const int lc = min(2 * kPubThreads * q + 2 * tid, Lp);
+          const uint4* cr = R2->cand + 2 * (size_t)lc;
+          const uint4* er = R2->erec + lc;
           cref[2 * q] = cr[0];
           ccw[2 * q] = cr[1];
           cref[2 * q + 1] = cr[2];
@@ -1270,11 +1273,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         double pa = 0.0, pb = 0.0;
         if (2 * kPubThreads * q < Lp) {  // workgroup-uniform
           const int l0 = 2 * kPubThreads * q + 2 * tid;
-          const int lb = min(l0, Lp - 2);
           PubArgsPtr R = pub_args_now(rp);
           const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
-          const uint4* cr = R->cand + 3 * (size_t)lb;
-          const uint4* er = R->erec + 2 * (size_t)lb;
+          const int lc = min(l0, Lp);  // (lanes beyond the map: the spare records, empty lists -- see k_step_pub)
+          const uint4* cr = R->cand + 3 * (size_t)lc;
+          const uint4* er = R->erec + 2 * (size_t)lc;
           PubGateIn gi[2];
           gi[0].ref = cr[0];
           gi[0].cw[0] = cr[1];

@@ -170,6 +170,9 @@ void launch_step_fused(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 // candidates switches the whole scan back to the grid walk (cand_over).  Record per landmark, 32 B:
 //   float ebref, r, g, b  |  kCandSlots x u16 blob (cell order) or 0xFFFF
 constexpr int kCandSlots = 8;
+// Every candidate / entry table carries kCandSpare records with EMPTY lists behind its Lp landmarks: the lanes of k_step_pub /
+// k_step_pub_big that stand beyond the map read those (index Lp), so they never see a real landmark's candidates.
+constexpr int kCandSpare = 2;
 constexpr double kCandBearing = 0.2;   // rad: |expected bearing - reference's| of every particle, else flagged (the particles' HEADING spread goes here: sigma 0.02 rad after 25 steps of the bench)
 constexpr double kCandColour = 1.5;    // per channel: |colour mean - reference's|
 // The inverse lists, blob -> the (<= kCandSlots) landmarks that list it, 16 B per blob (8 x u16, 0xFFFF = empty, filled from

@@ -23,6 +23,8 @@ def load_golden(name):
 def lib():
     from parakeet_slam_amd import _lib
 
+    if os.environ.get("PK_TEST_LIB"):  # diagnostics only: the suite against another build of the library (an A/B, a regression check)
+        _lib.LIB_PATH = os.path.join(ROOT, "parakeet_slam_amd", os.environ["PK_TEST_LIB"])
     return _lib
 
 

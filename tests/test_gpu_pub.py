@@ -283,3 +283,39 @@ def test_two_pass_instance_whole_steps_against_the_sweep_route(lib):
     assert np.array_equal(outs[0][1][:, :3], outs[1][1][:, :3])
     for x, y in zip(outs[0][2], outs[1][2]):
         assert np.array_equal(x, y)
+
+
+def crowded_tail_scene(L, rs, n_extra=3):
+    """A scene that loads the LAST pair of the map: landmarks L - 2 and L - 1 are look-alikes (every blob of either is
+    contested: it owns a publish entry), and landmark L - 1 is sighted 1 + n_extra times, so its candidate list holds at least four
+    blobs that all match it -- wherever k_candidates' atomics put them, two or more sit at list index >= 2."""
+    means, covs = synthetic_world(L)
+    means[L - 2, 2:] = means[L - 1, 2:] + [1.5, -1.0, 0.5]
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    extra = np.repeat(blobs[L - 1:L], n_extra, axis=0)
+    extra[:, 0] += 0.004 * (1 + np.arange(n_extra))
+    extra[:, 1:] += rs.uniform(-0.4, 0.4, (n_extra, 3))
+    blobs = np.vstack([blobs, extra])[rs.permutation(L + n_extra)]
+    return means, covs, blobs
+
+
+@pytest.mark.parametrize("L,opts", [(2000, {}), (1920, {}), (1536, {}), (1999, {}), (1008, {}), (768, {}), (496, {"pub_small": 1}),
+                                    (384, {"pub_small": 1}), (5008, {}), (4096, {}), (3072, {})])
+def test_lanes_beyond_the_map_do_not_repeat_the_last_pair(lib, L, opts):
+    """The lanes of k_step_pub / k_step_pub_big that stand beyond the map hold the last pair's rows once more.  With that
+    pair's candidate lists (round 3: only list word 0 was blanked) they gated, took and WEIGHED its blobs at list index >= 2
+    a second time, and from another wave (Lp a multiple of 128) overwrote keys the pair's own lane had published.  Map sizes
+    where the last pair is real (L = Lp or Lp - 1) and the workgroup has lanes to spare, every instance of the kernel;
+    match_features_to_scan :317-351 / the weight product :95,:124 against the oracle."""
+    rs = np.random.RandomState(4000 + L)
+    means, covs, blobs = crowded_tail_scene(L, rs)
+    P = 3 if L <= 2048 else 2
+    poses = poses_around(rs, P, 0.05)
+    pub = run(lib, means, covs, poses, blobs, opts)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["published"] and pub["flagged"] == 0  # the production kernel itself did the work
+    assert pub["route"] == ("ml_pub_big" if L > 2048 else "ml_fused" if L <= 512 else "ml_regs")
+    assert (gen["ids"] == L).sum(axis=1).min() >= 3  # the last landmark really takes several blobs
+    same_state(pub, gen, 1e-11)
+    if L <= 2048:  # (the big maps against the oracle: test_gpu_audit.py, particle by particle)
+        against_oracle(pub, means, covs, poses, blobs)
