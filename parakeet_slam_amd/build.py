@@ -57,13 +57,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+CXX_FLAGS = ["-x", "c++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall"]
+
+
+def _cxx_objects(hipcc, verbose=True):
+    """The host-only sources, compiled with THEIR flags (no FMA contraction: pk_rng.cpp must stay bit-exact with NumPy) --
+    for the diagnostic one-call builds too, which used to push them through the HIP flags."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    objs = []
+    for src in CXX_SOURCES:
+        path, obj = os.path.join(CSRC, src), os.path.join(OBJDIR, src + ".o")
+        if _stale(obj, [path, os.path.abspath(__file__)]):
+            cmd = [hipcc] + CXX_FLAGS + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    return objs
+
+
 def build_stamps(verbose=True):
     """Diagnostic build with in-kernel cycle stamps (-DPK_STAMPS) -> libparakeet_slam_stamps.so.
     Never loaded by the package; scripts/gpu_stamps.py uses it to read per-phase shares."""
     hipcc = _hipcc()
     out = os.path.join(HERE, "libparakeet_slam_stamps.so")
-    srcs = [os.path.join(CSRC, x) for x in HIP_SOURCES + CXX_SOURCES]
-    cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS["pk_k_observe_ml.hip"] + ["-DPK_STAMPS", "-shared", "-o", out] + srcs
+    srcs = [os.path.join(CSRC, x) for x in HIP_SOURCES]
+    cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS["pk_k_observe_ml.hip"] + ["-DPK_STAMPS", "-shared", "-o", out] + srcs + _cxx_objects(hipcc, verbose)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -75,8 +94,8 @@ def build_variant(name, defines, verbose=True):
     by the package; bench.py takes it through PK_BENCH_LIB, scripts/gpu_ab_lib.sh)."""
     hipcc = _hipcc()
     out = os.path.join(HERE, "libpk_%s.so" % name)
-    srcs = [os.path.join(CSRC, x) for x in HIP_SOURCES + CXX_SOURCES]
-    cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS["pk_k_observe_ml.hip"] + list(defines) + ["-shared", "-o", out] + srcs
+    srcs = [os.path.join(CSRC, x) for x in HIP_SOURCES]
+    cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS["pk_k_observe_ml.hip"] + list(defines) + ["-shared", "-o", out] + srcs + _cxx_objects(hipcc, verbose)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -96,8 +115,7 @@ def build(force=False, verbose=True):
             if src.endswith(".hip"):
                 cmd = [hipcc] + HIPCC_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
             else:
-                cmd = [hipcc, "-x", "c++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-                       "-ffp-contract=off", "-Wall", "-c", path, "-o", obj]
+                cmd = [hipcc] + CXX_FLAGS + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

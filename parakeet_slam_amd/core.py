@@ -18,6 +18,7 @@ What is different on purpose:
 from __future__ import annotations
 
 import copy as _copy
+import inspect as _inspect
 import math
 import random as _pyrandom
 import threading
@@ -430,15 +431,32 @@ class FastSLAM(object):
 
     EMPTY_COLOUR = 2.0 ** 100  # colour of a spare slot that holds nothing yet: fails every colour gate (:441), exact in float32
 
-    def __new__(cls, preset_features=[], *args, **kwargs):
+    def __new__(cls, *args, **kwargs):
         # FastSLAM(preset_features, devices=[0, 1, ...]): the same class surface with the particles sharded over several
-        # GPUs, one child process per device (multi.py; SURVEY section 5's `devices=` keyword)
-        devices = kwargs.get("devices")
+        # GPUs, one child process per device (multi.py; SURVEY section 5's `devices=` keyword).  The arguments are bound
+        # against FastSLAM's OWN signature -- positional ones included -- and forwarded with FastSLAM's defaults (weight_domain
+        # "linear", rng "global"); what the sharded facade cannot do is refused, not dropped.
+        extra = {k: kwargs.pop(k) for k in ("backend", "_shard_factory") if k in kwargs}
+        try:
+            ba = _inspect.signature(cls.__init__).bind(None, *args, **kwargs)
+        except TypeError:
+            return super(FastSLAM, cls).__new__(cls)  # __init__ raises the same TypeError with its own wording
+        ba.apply_defaults()
+        a = ba.arguments
+        devices = a.get("devices")
         if devices is not None and len(list(devices)) > 1:
             from .multi import ShardedFastSLAM
 
-            kw = {k: v for k, v in kwargs.items() if k in ("num_particles", "devices", "weight_domain", "rng", "seed", "backend", "_shard_factory")}
-            return ShardedFastSLAM(preset_features, **kw)
+            if a["new_landmarks"] or a["spare_landmarks"]:
+                raise ValueError("FastSLAM(devices=[...]): new_landmarks / spare_landmarks are not supported on several GPUs "
+                                 "(the per-particle bookkeeping of prkt_core_v2.py:546-746 lives on the single-GPU facade)")
+            if a["device"] not in (0, list(devices)[0]):
+                raise ValueError("FastSLAM: give either device= or devices=, not both")
+            return ShardedFastSLAM(a["preset_features"], num_particles=a["num_particles"], devices=list(devices),
+                                   weight_domain=a["weight_domain"], rng=a["rng"], seed=a["seed"],
+                                   publish_debug=a["publish_debug"], **extra)
+        if extra:
+            raise TypeError("FastSLAM: %s only apply with devices=[...] naming several GPUs" % ", ".join(sorted(extra)))
         return super(FastSLAM, cls).__new__(cls)
 
     def __init__(self, preset_features=[], num_particles=50, device=0, weight_domain="linear", rng="global",
@@ -483,6 +501,7 @@ class FastSLAM(object):
         self._draw = 0
         self._gen = 0
         self._pose_cache = None
+        self._probe = None
         self.particles = _ParticleList(self)
         self.last_ids = None
         r = msgs.ros()
@@ -665,15 +684,15 @@ class FastSLAM(object):
         one-particle filter."""
         dt = dt.to_sec()
         x, y, h = _state_pose(particle.state)
-        f = _lib.DeviceFilter(1, 0, device=self._device)
-        try:
+        with self._lock:
+            if self._probe is None:  # one one-particle filter per FastSLAM, made on first use (a stream + buffers: ~ms to create)
+                self._probe = _lib.DeviceFilter(1, 0, device=self._device)
+            f = self._probe
             f.upload_poses(np.array([[x, y, h, 1.0]]))
             z = self._noise(1)
             f.motion(float(twist.linear.x), float(twist.angular.z), dt, z=z, seed=self._seed, draw=self._draw)
             self._draw += 1
             nx, ny, nh, _ = f.download_poses()[0]
-        finally:
-            f.close()
         new_particle = _copy.deepcopy(particle)
         new_particle.state = _copy.deepcopy(particle.state)
         new_particle.state.pose.pose.position.x = nx
@@ -739,6 +758,22 @@ class FastSLAM(object):
             if d["poses"].shape != (P, 4) or d["means"].shape != (P, L, 5):
                 raise ValueError("snapshot is for %s particles x %s landmarks, this filter has %d x %d"
                                  % (d["poses"].shape[0], d["means"].shape[1], P, L))
+            if self._grow and "nl_offsets" not in d.files:
+                # (snapshots of before round 3 kept the bookkeeping as a pickled object array "new_landmarks": not read any
+                # more -- and a growing filter whose maps are replaced while its bookkeeping stays is inconsistent)
+                raise ValueError("snapshot: no new-landmark bookkeeping (nl_* arrays) for a filter with new_landmarks=True%s"
+                                 % ("; it was written in the old pickled format" if "new_landmarks" in d.files else ""))
+            have_nl = "nl_offsets" in d.files and self._grow
+            if have_nl:  # everything is checked before anything is assigned
+                offs, rd = d["nl_offsets"], d["nl_readings"]
+                used, slot_id = d["nl_used"], d["nl_slot_id"]
+                if (offs.shape != (P + 1,) or offs[0] != 0 or np.any(np.diff(offs) < 0) or rd.shape != (int(offs[-1]), 8)
+                        or d["nl_next_id"].shape != (P,) or used.shape != (P,) or slot_id.ndim != 2 or slot_id.shape[1] != 3):
+                    raise ValueError("snapshot: malformed new-landmark bookkeeping")
+                if (np.any(used < 0) or np.any(used > self._spare) or np.any(slot_id[:, 0] < 0) or np.any(slot_id[:, 0] >= P)
+                        or np.any(slot_id[:, 1] < self._L0) or np.any(slot_id[:, 1] >= L)):
+                    raise ValueError("snapshot: new-landmark bookkeeping names particles / spare slots this filter does not have")
+
             self._filter.upload_poses(d["poses"])
             if L:
                 self._filter.upload_landmarks(0, P, d["means"], d["covs"].reshape(P, L, 25), d["counts"])
@@ -746,10 +781,8 @@ class FastSLAM(object):
             self.last_control.linear.x = float(d["last_control"][0])
             self.last_control.angular.z = float(d["last_control"][1])
             self._draw = int(d["draw"])
-            if "nl_offsets" in d.files and self._grow:
+            if have_nl:
                 offs, rd = d["nl_offsets"], d["nl_readings"]
-                if offs.shape != (P + 1,) or rd.shape != (int(offs[-1]), 8) or d["nl_next_id"].shape != (P,):
-                    raise ValueError("snapshot: malformed new-landmark bookkeeping")
 
                 def reading(r):  # (id, x, y, heading, bearing, r, g, b): the id is an integer
                     return (int(r[0]),) + tuple(float(v) for v in r[1:])
@@ -763,4 +796,7 @@ class FastSLAM(object):
             self._touch()
 
     def close(self):
+        if self._probe is not None:
+            self._probe.close()
+            self._probe = None
         self._filter.close()

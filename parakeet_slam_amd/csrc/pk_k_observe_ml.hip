@@ -2031,16 +2031,7 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
   ra.cand_over = cand.rec ? cand.over : nullptr;
   ra.cand_skip = cand.rec ? (cand.skip_cand ? cand.skip_cand : cand.over) : nullptr;
   // persistent grid: the workgroups that are resident at once (one per CU: 1024 lanes x 128 VGPRs)
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-    else
-      n_cu = 256;
-    (void)hipGetLastError();
-  }
+  const int n_cu = device_cu_count();
   // reserve_cus: leave that many CUs without a workgroup -- this kernel's workgroups hold a CU's whole register file for the
   // whole launch, and a collective that is to run meanwhile (the sharded filter's all-to-all) needs somewhere to run
   int64_t grid_n = n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0);

@@ -1483,16 +1483,7 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
   a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-    else
-      n_cu = 256;
-    (void)hipGetLastError();
-  }
+  const int n_cu = device_cu_count();
   int64_t grid_n = n_cu;
   if (grid_n > d.P) grid_n = d.P;
   const size_t lds = step_pub_big_lds_bytes(B, ecap);
@@ -1543,16 +1534,7 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   a.reset = ex.reset ? 1 : 0;
   a.gmax_key = ex.gmax_key;
   a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-    else
-      n_cu = 256;
-    (void)hipGetLastError();
-  }
+  const int n_cu = device_cu_count();
   // persistent grid: one workgroup per CU (512 lanes x 256 VGPRs), three of the 256-lane instance (143 VGPRs; LDS permitting);
   // reserve_cus as in launch_step_regs
   const size_t lds = step_pub_lds_bytes(B, ecap);

@@ -95,6 +95,20 @@ inline bool first_time_on_this_device(bool (&done)[kMaxDevices]) {
   done[dev] = true;
   return true;
 }  // 160 KiB per workgroup minus the kernels' static __shared__
+// Compute units of the CURRENT device (what sizes the persistent grids), cached per device: a process may drive filters on
+// devices with different CU counts.
+inline int device_cu_count() {
+  static int n_cu[kMaxDevices] = {0};
+  int dev = 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices;
+  if (known && n_cu[dev] > 0) return n_cu[dev];
+  int n = 256;
+  hipDeviceProp_t prop;
+  if (known && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+  (void)hipGetLastError();
+  if (known) n_cu[dev] = n;
+  return n;
+}
 // Hand-off from the association kernel to k_observe_fast (all three NULL = not used).
 struct FastHandoff {
   uint4* lmpass = nullptr;          // [P][Lp] (slots = 4) or [P][Lp][2] (slots = 8): see k_assoc_grid

@@ -8,29 +8,41 @@ BEFORE anything in this process could have initialised HIP; nothing is ever ``ex
 shard of the particles with their whole maps (``ShardedFilter``, sharded.py: RCCL over xGMI between the children) and
 serves commands from a pipe:
 
-    step     one cam_cb (:59-137): weight reset, motion with the previous control (:163), association + EKF + weights,
-             global systematic resample -- the draw u (``random.random()``, :226) is made HERE and sent to every rank
-             (the replicated draw of the north star), as are the scan, Qt and, in the reference's RNG mode, each shard's
-             slice of the ``numpy.random`` normals (:185-193)
-    motion   motion_update (:148-166)
-    summary  (:254-276): every rank all-reduces four pose sums; rank 0 answers
-    poses / landmarks   views for ``particles[i]`` (lazy, like the single-GPU facade)
+    step          one cam_cb (:59-137): weight reset, motion with the previous control (:163), association + EKF + weights,
+                  global systematic resample -- the draw u (``random.random()``, :226) is made HERE and sent to every rank
+                  (the replicated draw of the north star), as are the scan, Qt and, in the reference's RNG mode, each
+                  shard's slice of the ``numpy.random`` normals (:185-193)
+    observe       the same without the resample (the debug publishers of :126-127, :237 want the poses in between)
+    resample      low_variance_resample (:210-252) on the weights as they stand
+    motion        motion_update (:148-166)
+    summary       (:254-276): every rank all-reduces four pose sums; rank 0 answers
+    poses / landmarks / set_particle / set_state   views for ``particles[i]`` (lazy, like the single-GPU facade),
+                  ``particles[i] = p`` (:162) on the owning rank, snapshots
+    motion_model  :168-208 on one host particle (rank 0's device; nothing of the filter changes)
 
 Particles are independent until the resample (:216-252), so nothing else crosses ranks.
+
+Failure handling: a rank that raises answers ("ERR", traceback); the front end always reads ONE reply from EVERY rank
+before it looks at any of them, so the pipes never fall out of step; on any error, timeout or dead child it marks itself
+failed, stops the children (a rank that failed before a collective leaves its peers blocked inside RCCL: they are
+terminated by handle) and every later call raises.
 """
 from __future__ import annotations
 
+import copy as _copy
 import multiprocessing as mp
+import multiprocessing.connection as mpc
 import os
 import random as _pyrandom
 import tempfile
 import threading
+import time
 import traceback
 
 import numpy as np
 
 from . import msgs
-from .msgs import Twist
+from .msgs import Odometry, Twist
 
 
 def _worker_main(rank, world, device, store_path, backend, P_local, L, means, covs, imm, domain, shard_factory, conn):
@@ -49,6 +61,7 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
         sf = ShardedFilter(P_local, L, device=device, comm=TorchComm(), shard=shard)
         if L:
             sf.upload_map(means, covs.reshape(L, 25), imm)
+        probe = None  # a one-particle filter for motion_model, made on first use and kept
         conn.send(("ok", None))
         while True:
             cmd = conn.recv()
@@ -56,9 +69,17 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
             try:
                 if op == "step":
                     _, v, w, dt, z, seed, draw, blobs, qt, u = cmd
-                    if hasattr(sf.f, "set_measurement_noise"):
-                        sf.f.set_measurement_noise(qt)
+                    sf.set_measurement_noise(qt)
                     sf.step(v, w, dt, blobs, u, z=z, seed=seed, draw=draw, domain=domain)
+                    conn.send(("ok", None))
+                elif op == "observe":
+                    _, v, w, dt, z, seed, draw, blobs, qt = cmd
+                    sf.set_measurement_noise(qt)
+                    sf.motion(v, w, dt, z=z, seed=seed, draw=draw)
+                    sf.observe(blobs, fresh=True)
+                    conn.send(("ok", None))
+                elif op == "resample":
+                    sf.resample(cmd[1], domain=domain)
                     conn.send(("ok", None))
                 elif op == "motion":
                     _, v, w, dt, z, seed, draw = cmd
@@ -70,6 +91,34 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
                     conn.send(("ok", sf.download_poses()))
                 elif op == "landmarks":
                     conn.send(("ok", sf.download_landmarks(cmd[1], cmd[2])))
+                elif op == "set_particle":
+                    _, j, pose, m, c, k = cmd
+                    poses = sf.download_poses()
+                    poses[j] = pose
+                    sf.upload_poses(poses)
+                    if m is not None:
+                        sf.upload_landmarks(j, j + 1, m, c, k)
+                    conn.send(("ok", None))
+                elif op == "set_state":
+                    _, poses, m, c, k = cmd
+                    sf.upload_poses(poses)
+                    if m is not None:
+                        sf.upload_landmarks(0, P_local, m, c, k)
+                    conn.send(("ok", None))
+                elif op == "motion_model":
+                    _, pose, v, w, dt, z, seed, draw = cmd
+                    if probe is None:
+                        if shard_factory is not None:
+                            probe = shard_factory(1, means, covs, imm)
+                        else:
+                            from . import _lib
+
+                            probe = _lib.DeviceFilter(1, 0, device=device)
+                    probe.upload_poses(np.array([[pose[0], pose[1], pose[2], 1.0]]))
+                    probe.motion(v, w, dt, z=z, seed=seed, draw=draw)
+                    conn.send(("ok", probe.download_poses()[0]))
+                elif op == "fail":  # tests: a rank that raises in the middle of a command
+                    raise RuntimeError("rank %d was asked to fail" % rank)
                 elif op == "close":
                     conn.send(("ok", None))
                     break
@@ -77,6 +126,8 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
                     conn.send(("ERR", "unknown command %r" % (op,)))
             except Exception:  # noqa: BLE001 -- reported to the front end, which raises
                 conn.send(("ERR", traceback.format_exc()))
+        if probe is not None and hasattr(probe, "close"):
+            probe.close()
         if hasattr(sf.f, "close"):
             sf.f.close()
         dist.destroy_process_group()
@@ -88,7 +139,8 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
 
 
 class _ShardedParticleList(object):
-    """``fs.particles``: list-like, read-only views fetched from the owning rank on demand."""
+    """``fs.particles``: list-like views fetched from the owning rank on demand; ``particles[i] = p`` (:162) writes the
+    host particle's pose, weight and landmark estimates into slot i on the rank that owns it."""
 
     def __init__(self, owner):
         self._o = owner
@@ -99,28 +151,40 @@ class _ShardedParticleList(object):
     def __iter__(self):
         return (self[i] for i in range(len(self)))
 
-    def __getitem__(self, i):
+    def _index(self, i):
         n = len(self)
         if i < 0:
             i += n
         if not 0 <= i < n:
             raise IndexError("particle index out of range")
-        return self._o._particle_view(i)
+        return i
+
+    def __getitem__(self, i):
+        return self._o._particle_view(self._index(i))
+
+    def __setitem__(self, i, particle):
+        self._o._store_particle(self._index(i), particle)
+
+    def __repr__(self):
+        return "<%d particles on GPUs %s>" % (len(self), self._o.devices)
 
 
 class ShardedFastSLAM(object):
     """prkt_core_v2.py:37-276 with the particles sharded over ``devices`` (one child process per GPU).
 
     ShardedFastSLAM(preset_features=[], num_particles=50, devices=(0, 1), weight_domain="log", rng="device", seed=0,
-                    backend="nccl")
+                    backend="nccl", publish_debug=None)
 
     ``num_particles`` must be a multiple of ``len(devices)``.  rng as in ``FastSLAM``: "device" (Philox per global particle
     index: the noise does not depend on the shard count) or "global" (the reference's own ``numpy.random`` / ``random``
-    streams, drawn here and handed to the shards).  ``backend="gloo"`` with ``_shard_factory`` is the CPU rehearsal the
-    tests use."""
+    streams, drawn here and handed to the shards).  publish_debug as in ``FastSLAM``: the three debug publishers of
+    :55-57 (/particle_track :126-127, /aged_particles :237, /resampled_particles :242) fed from pose downloads gathered over
+    the ranks.  ``backend="gloo"`` with ``_shard_factory`` is the CPU rehearsal the tests use.
+
+    (``FastSLAM(..., devices=[...])`` arrives here with FastSLAM's OWN defaults -- weight_domain "linear", rng "global".)"""
 
     def __init__(self, preset_features=[], num_particles=50, devices=(0, 1), weight_domain="log", rng="device", seed=0,
-                 backend="nccl", _shard_factory=None):
+                 backend="nccl", publish_debug=None, _shard_factory=None):
         from . import _lib  # constants only; loads nothing
 
         self._lock = threading.RLock()
@@ -146,42 +210,103 @@ class ShardedFastSLAM(object):
         self._domain = {"linear": _lib.PK_WEIGHTS_LINEAR, "log": _lib.PK_WEIGHTS_LOG}[weight_domain]
         self._rng, self._seed, self._draw = rng, int(seed), 0
         self._pose_cache = None
+        r = msgs.ros()
+        self._publish = (r is not None) if publish_debug is None else bool(publish_debug)
+        if r is not None:  # :55-57
+            self.aged_particles_pub = r.Publisher('/aged_particles', Odometry, queue_size=1)
+            self.resampled_particles_pub = r.Publisher('/resampled_particles', Odometry, queue_size=1)
+            self.particle_track_pub = r.Publisher('/particle_track', Odometry, queue_size=1)
+        else:
+            self.aged_particles_pub = self.resampled_particles_pub = self.particle_track_pub = None
+            self._publish = False
         ctx = mp.get_context("spawn")  # fresh interpreters: no child inherits (or replaces) a process that touched a GPU
         fd, self._store = tempfile.mkstemp(prefix="pk_store_")
         os.close(fd)
         os.unlink(self._store)
         self._conns, self._procs = [], []
-        for r, dev in enumerate(self.devices):
+        self._closed, self._failed = False, None
+        self._unsent = set()
+        for rk, dev in enumerate(self.devices):
             a, b = ctx.Pipe()
-            p = ctx.Process(target=_worker_main, args=(r, world, dev, self._store, backend, self._P_local, L, means, covs, imm,
+            p = ctx.Process(target=_worker_main, args=(rk, world, dev, self._store, backend, self._P_local, L, means, covs, imm,
                                                        self._domain, _shard_factory, b), daemon=True)
             p.start()
             self._conns.append(a)
             self._procs.append(p)
-        self._closed = False
-        try:
-            self._collect("start")
-        except Exception:
-            self.close()
-            raise
+        self._collect("start")
         self.particles = _ShardedParticleList(self)
 
     # ------------------------------------------------------------------ plumbing
-    def _collect(self, what, timeout=600.0):
-        out = []
-        for r, c in enumerate(self._conns):
-            if not c.poll(timeout):
-                raise RuntimeError("rank %d did not answer '%s' within %.0f s" % (r, what, timeout))
-            status, payload = c.recv()
+    def _check_open(self):
+        if self._failed is not None:
+            raise RuntimeError("this ShardedFastSLAM has failed and was shut down: %s" % self._failed)
+        if self._closed:
+            raise RuntimeError("this ShardedFastSLAM is closed")
+
+    def _post(self, r, cmd):
+        """Send one command to rank r; a pipe that is gone (the child died) is remembered for _collect."""
+        try:
+            self._conns[r].send(cmd)
+        except (BrokenPipeError, OSError):
+            self._unsent.add(r)
+
+    def _collect(self, what, timeout=600.0, ranks=None):
+        """ONE reply from every rank asked, whatever the others say; then errors, if any.  A dead child is noticed at once
+        (its pipe would stay silent for the whole timeout)."""
+        ranks = list(range(len(self._conns))) if ranks is None else list(ranks)
+        replies, errors = {}, []
+        for r in sorted(self._unsent.intersection(ranks)):
+            errors.append("rank %d is gone: '%s' could not be sent (exit code %r)" % (r, what, self._procs[r].exitcode))
+        pending = {r: self._conns[r] for r in ranks if r not in self._unsent}
+        self._unsent = set()
+        deadline = time.monotonic() + timeout
+        while pending:
+            ready = mpc.wait(list(pending.values()), timeout=0.5)
+            for c in ready:
+                r = next(k for k, v in pending.items() if v is c)
+                try:
+                    replies[r] = c.recv()
+                except (EOFError, OSError):
+                    errors.append("rank %d closed its pipe during '%s' (exit code %r)" % (r, what, self._procs[r].exitcode))
+                del pending[r]
+            if ready:
+                continue
+            for r in list(pending):
+                if not self._procs[r].is_alive() and not pending[r].poll(0):
+                    errors.append("rank %d died during '%s' (exit code %r)" % (r, what, self._procs[r].exitcode))
+                    del pending[r]
+            if errors and pending:
+                # a rank is gone or has failed: its peers may be waiting for it inside a collective -- give them a moment, no more
+                deadline = min(deadline, time.monotonic() + 5.0)
+            if pending and time.monotonic() > deadline:
+                for r in pending:
+                    errors.append("rank %d did not answer '%s' in time" % (r, what))
+                pending.clear()
+            if not errors:  # a reported failure shortens everybody else's wait as well
+                for r, rep in replies.items():
+                    if rep[0] != "ok":
+                        deadline = min(deadline, time.monotonic() + 5.0)
+                        break
+        for r in sorted(replies):
+            status, payload = replies[r]
             if status != "ok":
-                raise RuntimeError("rank %d failed in '%s':\n%s" % (r, what, payload))
-            out.append(payload)
-        return out
+                errors.append("rank %d failed in '%s':\n%s" % (r, what, payload))
+        if errors:
+            self._failed = "; ".join(e.splitlines()[0] for e in errors)
+            self._shutdown(graceful=False)
+            raise RuntimeError("\n".join(errors))
+        return [replies[r][1] for r in ranks]
 
     def _all(self, *cmd):
-        for c in self._conns:
-            c.send(cmd)
+        self._check_open()
+        for r in range(len(self._conns)):
+            self._post(r, cmd)
         return self._collect(cmd[0])
+
+    def _one(self, r, *cmd):
+        self._check_open()
+        self._post(r, cmd)
+        return self._collect(cmd[0], ranks=[r])[0]
 
     def _noise(self):
         if self._rng == "global":  # numpy.random.normal(0, s, 1) x 3 per particle, particle-major (:185-193)
@@ -189,20 +314,43 @@ class ShardedFastSLAM(object):
             return [z[r * self._P_local:(r + 1) * self._P_local] for r in range(len(self.devices))]
         return [None] * len(self.devices)
 
+    def _publish_all(self, pub, poses):
+        if not self._publish or pub is None:
+            return
+        from .core import _make_state
+
+        for x, y, h, _w in poses:
+            st = _make_state(x, y, h)
+            st.header.frame_id = 'odom'
+            pub.publish(st)
+
     # ------------------------------------------------------------------ the reference's surface
     def cam_cb(self, ros_view):
         """One filter step (:59-137)."""
         with self._lock:
+            self._check_open()
             dt = msgs.now() - self.last_update  # :158, the motion update of :75-77
             v, w = float(self.last_control.linear.x), float(self.last_control.angular.z)
             observes = list(ros_view.last_sensor_reading.observes)  # :82
             blobs = np.array([[float(b.bearing), float(b.color.r), float(b.color.g), float(b.color.b)] for b in observes],
                              dtype=np.float64).reshape(-1, 4)
             zs = self._noise()
-            u = _pyrandom.random()  # :226 -- drawn once, here, and replicated to every rank
             qt = np.asarray(self.Qt, dtype=np.float64).reshape(4, 4)
-            for r, c in enumerate(self._conns):
-                c.send(("step", v, w, float(dt.to_sec()), zs[r], self._seed, self._draw, blobs, qt, float(u)))
+            if self._publish:
+                # the debug publishers want the poses between the weighting and the resample: two commands, and ONE gathered
+                # pose download that feeds /particle_track (:126-127) and /aged_particles (:237)
+                for r in range(len(self._conns)):
+                    self._post(r, ("observe", v, w, float(dt.to_sec()), zs[r], self._seed, self._draw, blobs, qt))
+                self._collect("observe")
+                self._pose_cache = None
+                self._publish_all(self.particle_track_pub, self.download_poses())
+                self._draw += 1
+                self.last_update = self.last_update + dt
+                self.low_variance_resample()
+                return
+            u = _pyrandom.random()  # :226 -- drawn once, here, and replicated to every rank
+            for r in range(len(self._conns)):
+                self._post(r, ("step", v, w, float(dt.to_sec()), zs[r], self._seed, self._draw, blobs, qt, float(u)))
             self._collect("step")
             self._draw += 1
             self.last_update = self.last_update + dt  # :165 (last_control stays: cam_cb moves with it, :77)
@@ -211,16 +359,48 @@ class ShardedFastSLAM(object):
     def motion_update(self, new_twist):
         """:148-166: moves every particle with the PREVIOUS control, then takes the new one."""
         with self._lock:
+            self._check_open()
             dt = msgs.now() - self.last_update
             v, w = float(self.last_control.linear.x), float(self.last_control.angular.z)
             zs = self._noise()
-            for r, c in enumerate(self._conns):
-                c.send(("motion", v, w, float(dt.to_sec()), zs[r], self._seed, self._draw))
+            for r in range(len(self._conns)):
+                self._post(r, ("motion", v, w, float(dt.to_sec()), zs[r], self._seed, self._draw))
             self._collect("motion")
             self._draw += 1
             self.last_update = self.last_update + dt
             self.last_control = new_twist
             self._pose_cache = None
+
+    def motion_model(self, particle, twist, dt):
+        """Move ONE host particle (:168-208) and return the moved copy; the filter's particles are not touched.  Runs the
+        motion kernel on a one-particle filter of rank 0's device."""
+        from .core import _state_pose
+        from .msgs import heading_to_quaternion
+
+        with self._lock:
+            x, y, h = _state_pose(particle.state)
+            z = np.random.standard_normal((1, 3)) if self._rng == "global" else None
+            nx, ny, nh, _ = self._one(0, "motion_model", (x, y, h), float(twist.linear.x), float(twist.angular.z),
+                                      float(dt.to_sec()), z, self._seed, self._draw)
+            self._draw += 1
+        new_particle = _copy.deepcopy(particle)
+        new_particle.state = _copy.deepcopy(particle.state)
+        new_particle.state.pose.pose.position.x = float(nx)
+        new_particle.state.pose.pose.position.y = float(ny)
+        new_particle.state.pose.pose.orientation = heading_to_quaternion(float(nh))
+        return new_particle
+
+    def low_variance_resample(self):
+        """:210-252 over all shards on the weights as they stand: one draw u (:226), made here, replicated to every rank."""
+        with self._lock:
+            self._check_open()
+            if self._publish:
+                self._publish_all(self.aged_particles_pub, self.download_poses())  # :237
+            u = _pyrandom.random()
+            self._all("resample", float(u))
+            self._pose_cache = None
+            if self._publish:
+                self._publish_all(self.resampled_particles_pub, self.download_poses())  # :242
 
     def summary(self):
         """:254-276 over all shards."""
@@ -246,15 +426,11 @@ class ShardedFastSLAM(object):
             p.weight = float(w)
             p.Qt = self.Qt
             r, j = divmod(i, self._P_local)
-            conn, feats, lock, L = self._conns[r], self._features, self._lock, self._L
+            feats, lock, L, one = self._features, self._lock, self._L, self._one
 
             def load_all():
                 with lock:
-                    conn.send(("landmarks", j, j + 1))
-                    status, payload = conn.recv()
-                if status != "ok":
-                    raise RuntimeError(payload)
-                m, c, k = payload
+                    m, c, k = one(r, "landmarks", j, j + 1)
                 full = {}
                 for l in range(L):
                     f = Feature(mean=m[0, l], covar=c[0, l])
@@ -266,29 +442,92 @@ class ShardedFastSLAM(object):
             p.feature_set = _FeatureSet(load_all)
             return p
 
-    def close(self):
+    def _store_particle(self, i, particle):
+        """``fs.particles[i] = particle`` (:162): pose, weight and -- when the particle carries all L of them -- landmark
+        estimates go to slot i of the rank that owns it."""
+        from .core import _state_pose
+
+        with self._lock:
+            x, y, h = _state_pose(particle.state)
+            r, j = divmod(i, self._P_local)
+            L = self._L
+            m = c = k = None
+            ids = range(1, L + 1)
+            if L and all(q in particle.feature_set for q in ids):
+                fs_ = [particle.feature_set[q] for q in ids]
+                m = np.array([np.asarray(f.mean, dtype=np.float64) for f in fs_]).reshape(1, L, 5)
+                c = np.array([np.asarray(f.covar, dtype=np.float64) for f in fs_]).reshape(1, L, 25)
+                k = np.array([int(f.update_count) for f in fs_], dtype=np.int32).reshape(1, L)
+            self._one(r, "set_particle", j, (x, y, h, float(particle.weight)), m, c, k)
+            self._pose_cache = None
+
+    # ------------------------------------------------------------------ snapshot / restore (the single-GPU facade's format)
+    def save_state(self, path):
+        with self._lock:
+            poses = self.download_poses()
+            parts = self._all("landmarks", 0, self._P_local)
+            m = np.concatenate([p[0] for p in parts])
+            c = np.concatenate([p[1] for p in parts])
+            k = np.concatenate([p[2] for p in parts])
+            np.savez_compressed(
+                path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
+                immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),
+                last_control=np.array([float(self.last_control.linear.x), float(self.last_control.angular.z)]),
+                last_update=float(self.last_update.to_sec()), draw=self._draw)
+
+    def load_state(self, path):
+        with self._lock:
+            self._check_open()
+            d = np.load(path, allow_pickle=False)
+            P, L, Pl = self.num_particles, self._L, self._P_local
+            if d["poses"].shape != (P, 4) or d["means"].shape != (P, L, 5):
+                raise ValueError("snapshot is for %s particles x %s landmarks, this filter has %d x %d"
+                                 % (d["poses"].shape[0], d["means"].shape[1], P, L))
+            for r in range(len(self._conns)):
+                s = slice(r * Pl, (r + 1) * Pl)
+                self._post(r, ("set_state", d["poses"][s], d["means"][s] if L else None,
+                           d["covs"][s].reshape(Pl, L, 25) if L else None, d["counts"][s].astype(np.int32) if L else None))
+            self._collect("set_state")
+            self.Qt = d["Qt"].copy()
+            self.last_control.linear.x = float(d["last_control"][0])
+            self.last_control.angular.z = float(d["last_control"][1])
+            self._draw = int(d["draw"])
+            self._pose_cache = None
+
+    # ------------------------------------------------------------------ shutdown
+    def _shutdown(self, graceful):
         if self._closed:
             return
         self._closed = True
-        for c in self._conns:
-            try:
-                c.send(("close",))
-            except Exception:  # noqa: BLE001
-                pass
-        for c in self._conns:
-            try:
-                if c.poll(30.0):
-                    c.recv()
-            except Exception:  # noqa: BLE001
-                pass
+        if graceful:
+            for c in self._conns:
+                try:
+                    c.send(("close",))
+                except Exception:  # noqa: BLE001
+                    pass
+            for c in self._conns:
+                try:
+                    if c.poll(30.0):
+                        c.recv()
+                except Exception:  # noqa: BLE001
+                    pass
         for p in self._procs:
-            p.join(timeout=30)
+            p.join(timeout=30 if graceful else 0.2)
             if p.is_alive():
                 p.terminate()  # our own child, by handle
+                p.join(timeout=10)
+        for c in self._conns:
+            try:
+                c.close()
+            except Exception:  # noqa: BLE001
+                pass
         try:
             os.unlink(self._store)
         except OSError:
             pass
+
+    def close(self):
+        self._shutdown(graceful=self._failed is None)
 
     def __del__(self):
         try:

@@ -363,6 +363,16 @@ class ShardedFilter(object):
         self._complete()
         return self.f.download_poses()
 
+    def upload_poses(self, xyhw):
+        self._complete()
+        return self.f.upload_poses(xyhw)
+
+    def upload_landmarks(self, p0, p1, means=None, covs=None, counts=None):
+        self._complete()
+        out = self.f.upload_landmarks(p0, p1, means, covs, counts)
+        self._recv_keepalive = None  # (the upload materialised the map: adopted records were copied into the shard's own slots)
+        return out
+
     def download_landmarks(self, *a, **k):
         self._complete()
         out = self.f.download_landmarks(*a, **k)

@@ -48,6 +48,24 @@ class OracleShard(object):
     def download_poses(self):
         return np.stack([self.o.x, self.o.y, self.o.h, self.o.weights()], 1)
 
+    def upload_poses(self, xyhw):
+        a = np.asarray(xyhw, dtype=np.float64).reshape(self.P, 4)
+        self.o.x, self.o.y, self.o.h = a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy()
+        with np.errstate(divide="ignore"):
+            self.o.logw = np.log(a[:, 3])
+
+    def upload_landmarks(self, p0, p1, means=None, covs=None, counts=None):
+        n = p1 - p0
+        if means is not None:
+            self.o.mean[p0:p1] = np.asarray(means, dtype=np.float64).reshape(n, self.L, 5)
+        if covs is not None:
+            self.o.cov[p0:p1] = np.asarray(covs, dtype=np.float64).reshape(n, self.L, 5, 5)
+        if counts is not None:
+            self.o.count[p0:p1] = np.asarray(counts).reshape(n, self.L)
+
+    def set_measurement_noise(self, Qt):
+        self.o.Qt = np.asarray(Qt, dtype=np.float64).reshape(4, 4)
+
     def download_landmarks(self, p0=0, p1=None):
         p1 = self.P if p1 is None else p1
         return self.o.mean[p0:p1].copy(), self.o.cov[p0:p1].copy(), self.o.count[p0:p1].copy()

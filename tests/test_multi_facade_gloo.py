@@ -90,3 +90,143 @@ def test_devices_keyword_runs_the_reference_trajectory_on_sharded_ranks(pk, worl
 def test_devices_must_divide_the_particles(pk):
     with pytest.raises(ValueError):
         pk.FastSLAM([], num_particles=5, devices=[0, 1], backend="gloo", _shard_factory=make_oracle_shard)
+
+
+def small_filter(pk, P=8, world=2, L=3, **kw):
+    pk.msgs.Time.set_now(0.0)
+    feats = [pk.Feature(mean=np.array([5.0 + l, 1.0 - l, 10.0 * l, 20.0, 30.0]), covar=0.25 * np.identity(5)) for l in range(L)]
+    return pk.FastSLAM(feats, P, devices=list(range(world)), backend="gloo", _shard_factory=make_oracle_shard, **kw)
+
+
+def test_devices_keyword_binds_positional_arguments_and_keeps_fastslam_defaults(pk):
+    """FastSLAM(feats, 1000, devices=[0, 1]) ran with 50 particles (positional arguments were dropped) and
+    with other defaults than FastSLAM's; unsupported options were ignored without a word."""
+    from parakeet_slam_amd import _lib
+    from parakeet_slam_amd.multi import ShardedFastSLAM
+
+    fs = small_filter(pk, P=8)
+    try:
+        assert isinstance(fs, ShardedFastSLAM) and fs.num_particles == 8
+        assert fs._rng == "global" and fs._domain == _lib.PK_WEIGHTS_LINEAR  # FastSLAM's defaults, not ShardedFastSLAM's
+    finally:
+        fs.close()
+    with pytest.raises(ValueError):
+        small_filter(pk, new_landmarks=True, spare_landmarks=4)
+    with pytest.raises(TypeError):
+        pk.FastSLAM([], 8, backend="gloo")  # (raised before anything touches a GPU)
+
+
+def test_sharded_surface_motion_model_resample_and_particle_assignment(pk):
+    """The rest of the class surface SURVEY 8(b) lists: motion_model (prkt_core_v2.py:168-208), low_variance_resample
+    (:210-252), particles[i] = p (:162) -- on the rank that owns slot i."""
+    P = 8
+    fs = small_filter(pk, P=P, seed=3)
+    try:
+        np.random.seed(5)
+        random.seed(5)
+        # motion_model: a moved COPY; the filter's particles stay where they are
+        before = fs.download_poses().copy()
+        tw = pk.msgs.Twist()
+        tw.linear.x = 1.0
+        p0 = fs.particles[0]
+        moved = fs.motion_model(p0, tw, pk.msgs.Duration(0.5))
+        assert abs(moved.state.pose.pose.position.x - 0.5) < 0.2 and p0.state.pose.pose.position.x == 0.0
+        assert np.array_equal(fs.download_poses(), before)
+        # particles[i] = p: slot 5 lives on rank 1
+        q = fs.particles[5]
+        q.state.pose.pose.position.x = 3.25
+        q.state.pose.pose.position.y = -1.5
+        q.weight = 7.0
+        f2 = q.feature_set[2]
+        f2.mean = np.array([9.0, 8.0, 7.0, 6.0, 5.0])
+        f2.update_count = 4
+        fs.particles[5] = q
+        got = fs.download_poses()
+        assert np.allclose(got[5], [3.25, -1.5, 0.0, 7.0]) and np.array_equal(got[[0, 4, 6]], before[[0, 4, 6]])
+        back = fs.particles[5].feature_set[2]
+        assert np.array_equal(back.mean, f2.mean) and back.update_count == 4
+        assert np.allclose(fs.particles[4].feature_set[2].mean, [6.0, 0.0, 10.0, 20.0, 30.0])
+        # low_variance_resample on the weights as they stand: slot 5 weighs 7 of 14 -> it fills half of the slots (:233-250)
+        fs.low_variance_resample()
+        after = fs.download_poses()
+        n5 = int(np.sum(after[:, 0] == 3.25))
+        assert 3 <= n5 <= 5 and np.all(np.diff(np.flatnonzero(after[:, 0] == 3.25)) == 1)  # systematic: one contiguous run
+        assert fs.particles[int(np.flatnonzero(after[:, 0] == 3.25)[0])].feature_set[2].update_count == 4  # the map travelled with it
+        # snapshot round trip in the single-GPU facade's format
+        import os
+        import tempfile
+
+        path = os.path.join(tempfile.mkdtemp(), "snap.npz")
+        fs.save_state(path)
+        fs.particles[0] = q
+        fs.load_state(path)
+        assert np.array_equal(fs.download_poses(), after)
+    finally:
+        fs.close()
+
+
+def test_a_failing_rank_shuts_the_facade_down_instead_of_desynchronising_it(pk):
+    """_collect raised at the first ERR without draining the other ranks' replies, so every later command
+    read a stale reply.  Now every rank's reply is read, the facade is marked failed, the children are stopped."""
+    fs = small_filter(pk)
+    try:
+        fs._conns[0].send(("poses",))
+        fs._conns[1].send(("fail",))
+        with pytest.raises(RuntimeError, match="asked to fail"):
+            fs._collect("poses")
+        assert fs._closed and fs._failed
+        assert not any(p.is_alive() for p in fs._procs)
+        with pytest.raises(RuntimeError, match="failed and was shut down"):
+            fs.summary()
+    finally:
+        fs.close()
+
+
+def test_a_dead_rank_is_reported_at_once(pk):
+    import time
+
+    fs = small_filter(pk)
+    try:
+        fs._procs[1].terminate()
+        fs._procs[1].join(10)
+        t0 = time.monotonic()
+        with pytest.raises(RuntimeError, match="rank 1"):
+            fs.summary()  # rank 0 waits in the all-reduce for a peer that is gone: not for the 600 s of the old poll
+        assert time.monotonic() - t0 < 60
+        assert not any(p.is_alive() for p in fs._procs)
+    finally:
+        fs.close()
+
+
+def test_sharded_publishers_in_ros_mode():
+    """/particle_track (:126-127), /aged_particles (:237), /resampled_particles (:242): once per particle per cam_cb from
+    gathered pose downloads.  Fresh interpreter: the rospy stub must be in place before the package binds its types."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from oracle import ros_stubs
+ros_stubs.install()
+import rospy
+from viz_feature_sim.msg import Blob, VizScan
+import parakeet_slam_amd as pk
+from sharded_common import make_oracle_shard
+if __name__ == "__main__":
+    rospy.Time.set_now(0.0)
+    feats = [pk.Feature(mean=np.array([5.0, 1, 10, 20, 30]), covar=0.25 * np.identity(5))]
+    fs = pk.FastSLAM(feats, 12, devices=[0, 1], backend="gloo", _shard_factory=make_oracle_shard)
+    class Node: pass
+    node = Node(); node.last_sensor_reading = VizScan([Blob(0.2, 10, 20, 30)])
+    rospy.Time.advance(0.1)
+    fs.cam_cb(node)
+    ok = fs.particle_track_pub.count == 12 and fs.aged_particles_pub.count == 12 and fs.resampled_particles_pub.count == 12
+    s = fs.summary()
+    fs.close()
+    print("SHARDED-ROS-MODE-OK" if ok else "COUNTS", fs.particle_track_pub.count, fs.aged_particles_pub.count, fs.resampled_particles_pub.count, s)
+''' % (root, os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "SHARDED-ROS-MODE-OK" in out.stdout, out.stdout + out.stderr
