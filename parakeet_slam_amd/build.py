@@ -72,7 +72,7 @@ def _cxx_objects(hipcc, verbose=True):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        objs.append("-Wl," + obj)  # (straight to the linker: hipcc would take a bare .o for another HIP source)
     return objs
 
 

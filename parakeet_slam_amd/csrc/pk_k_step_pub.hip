@@ -886,7 +886,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           PubArgsPtr R2 = pub_args_now(rp);
           // (lanes beyond the map: the spare records behind the table, whose lists are empty -- the ROWS such a lane holds are
           // the last pair's once more, and with that pair's lists it would gate, take and weigh the pair's blobs a second time)
+#ifdef PK_DIAG_TAIL_LISTS  // diagnostic build only: round 3's indexing, to show that the regression test bites
+          const int lc = lbase[q];
+#else
           const int lc = min(2 * kPubThreads * q + 2 * tid, Lp);
+#endif
           const uint4* cr = R2->cand + 2 * (size_t)lc;
           const uint4* er = R2->erec + lc;
           cref[2 * q] = cr[0];
@@ -1275,7 +1279,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           const int l0 = 2 * kPubThreads * q + 2 * tid;
           PubArgsPtr R = pub_args_now(rp);
           const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
+#ifdef PK_DIAG_TAIL_LISTS
+          const int lc = min(l0, Lp - 2);
+#else
           const int lc = min(l0, Lp);  // (lanes beyond the map: the spare records, empty lists -- see k_step_pub)
+#endif
           const uint4* cr = R->cand + 3 * (size_t)lc;
           const uint4* er = R->erec + 2 * (size_t)lc;
           PubGateIn gi[2];

@@ -78,38 +78,42 @@ def pick(rs, flags, n_plain, n_flagged):
 
 def test_config2_sampled_particles_against_the_oracle_on_the_bench_trajectory(lib):
     """100 000 x 2 000 on the bench's own trajectory (seed 7, device Philox motion noise, resample every step): audits at
-    steps 1, 3 and inside the slow stretch -- there half of the sample are particles the one-pass kernel did NOT settle
-    itself the step before (the scene decides that, so they are likely not to be settled by it this step either)."""
+    steps 1, 3 and inside the slow stretch.  The run is made twice (it replays bit for bit): the first pass only notes which
+    particles the one-pass kernel hands to the fall-back routes at the audited steps, so that the second pass can sample
+    those particles -- half of the sample where there are any -- BEFORE their observe."""
     P, L = 100000, 2000
     last = 50
+    steps = (1, 3, 47, last)
     means, covs, scans = synthetic_inputs(L, last + 1)
     ws = synthetic_controls(last + 1)
     rnd = random.Random(7)
     us = [rnd.random() for _ in range(last + 1)]
     rs = np.random.RandomState(11)
     f = lib.DeviceFilter(P, L)
-    f.upload_map(means, covs.reshape(L, 25))
-    audited, slow_flagged = [], 0
-    for s in range(last + 1):
-        if s in (1, 3, 47, last):
-            f.reset_weights()
-            f.motion(0.2, ws[s], 0.1, seed=7, draw=s)
-            flags = f.observe_flags() if s > 0 else np.zeros(P, dtype=np.uint8)
-            sample = pick(rs, flags, 8 if s < 40 else 4, 4)
-            info = audit_observe(lib, f, scans[s], sample, L, means, covs)
-            assert info["route"] == "ml_regs" and info["published"], info
-            assert info["matched"] > 0.9
-            now = info["flags"][sample]
-            audited.append((s, len(sample), int((now != 0).sum()), info["flagged"][0]))
-            if s >= 40:
-                slow_flagged += int((now != 0).sum())
-            f.resample(us[s], domain=lib.PK_WEIGHTS_LOG)
-        else:
-            f.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, domain=lib.PK_WEIGHTS_LOG)
+    flags_at = {}
+    for attempt in (0, 1):
+        f.upload_map(means, covs.reshape(L, 25))
+        f.upload_poses(np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (P, 1)))
+        audited = []
+        for s in range(last + 1):
+            if attempt == 1 and s in steps:
+                f.reset_weights()
+                f.motion(0.2, ws[s], 0.1, seed=7, draw=s)
+                sample = pick(rs, flags_at[s], 8 if s < 40 else 4, 4)
+                info = audit_observe(lib, f, scans[s], sample, L, means, covs)
+                assert info["route"] == "ml_regs" and info["published"], info
+                assert info["matched"] > 0.9
+                assert np.array_equal(info["flags"], flags_at[s]), "the replay did not flag the same particles"
+                audited.append((s, len(sample), int((flags_at[s][sample] != 0).sum()), info["flagged"][0]))
+                f.resample(us[s], domain=lib.PK_WEIGHTS_LOG)
+            else:
+                f.step(0.2, ws[s], 0.1, scans[s], us[s], seed=7, draw=s, domain=lib.PK_WEIGHTS_LOG)
+                if attempt == 0 and s in steps:
+                    flags_at[s] = f.observe_flags()  # (written by the observe; the resample does not touch them)
     f.close()
     print("audited (step, particles, of them not settled by the one-pass kernel, flagged in the whole filter):", audited)
-    # the audits of the slow stretch really covered the fall-back routes as well
-    assert slow_flagged >= 1 or all(a[3] == 0 for a in audited if a[0] >= 40)
+    for s, n, n_other, n_all in audited:  # the audits cover the fall-back routes wherever the step used them
+        assert n_other == min(4, n_all)
 
 
 def test_pub_big_sampled_particles_against_the_oracle_at_5000_landmarks(lib):
@@ -127,7 +131,7 @@ def test_pub_big_sampled_particles_against_the_oracle_at_5000_landmarks(lib):
         if s in (2, 4):
             f.reset_weights()
             f.motion(0.2, ws[s], 0.1, seed=7, draw=s)
-            sample = pick(rs, f.observe_flags(), 4, 2)
+            sample = pick(rs, np.zeros(P, dtype=np.uint8), 4, 0)  # (nothing is flagged at this shape in the steady state)
             info = audit_observe(lib, f, scans[s], sample, L, means, covs)
             assert info["route"] == "ml_pub_big" and info["published"], info
             assert info["matched"] > 0.9
