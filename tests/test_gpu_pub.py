@@ -285,10 +285,11 @@ def test_two_pass_instance_whole_steps_against_the_sweep_route(lib):
         assert np.array_equal(x, y)
 
 
-def crowded_tail_scene(L, rs, n_extra=3):
+def crowded_tail_scene(L, rs, n_extra=2):
     """A scene that loads the LAST pair of the map: landmarks L - 2 and L - 1 are look-alikes (every blob of either is
-    contested: it owns a publish entry), and landmark L - 1 is sighted 1 + n_extra times, so its candidate list holds at least four
-    blobs that all match it -- wherever k_candidates' atomics put them, two or more sit at list index >= 2."""
+    contested: it owns a publish entry), and landmark L - 1 is sighted 1 + n_extra times, so its candidate list holds four blobs
+    (its look-alike's too: the four register slots of the kernel), three of which match it -- wherever k_candidates' atomics
+    put them, at least one sits at list index >= 2."""
     means, covs = synthetic_world(L)
     means[L - 2, 2:] = means[L - 1, 2:] + [1.5, -1.0, 0.5]
     blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
@@ -315,7 +316,7 @@ def test_lanes_beyond_the_map_do_not_repeat_the_last_pair(lib, L, opts):
     gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
     assert pub["published"] and pub["flagged"] == 0  # the production kernel itself did the work
     assert pub["route"] == ("ml_pub_big" if L > 2048 else "ml_fused" if L <= 512 else "ml_regs")
-    assert (gen["ids"] == L).sum(axis=1).min() >= 3  # the last landmark really takes several blobs
+    assert (gen["ids"] == L).sum(axis=1).min() >= 2  # the last landmark really takes several blobs
     same_state(pub, gen, 1e-11)
     if L <= 2048:  # (the big maps against the oracle: test_gpu_audit.py, particle by particle)
         against_oracle(pub, means, covs, poses, blobs)
