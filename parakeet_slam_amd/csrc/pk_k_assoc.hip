@@ -54,7 +54,7 @@ __device__ __forceinline__ void assoc_pass(const AssocArgs& a, const double* f, 
     lm.mg = f[F_MG * a.Lp + l];
     lm.mb = f[F_MB * a.Lp + l];
     bool have_cov = false;
-    double pse = atan2(lm.my - sy, lm.mx - sx);
+    double pse = pk_atan2(lm.my - sy, lm.mx - sx);
     double eb = pse - sh;  // :408
     for (int b = 0; b < a.B; ++b) {
       BlobT<double> z{a.blobs[4 * b], a.blobs[4 * b + 1], a.blobs[4 * b + 2], a.blobs[4 * b + 3]};
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         nmb = f[F_MB * a.Lp + ln];
       }
       PK_STAMP(ta0)
-      const double pse = atan2(my - sy, mx - sx);
+      const double pse = pk_atan2(my - sy, mx - sx);
       const double eb = pse - sh;  // :408
       const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
       // same cell function as the host (floor((v - lo) * inv_h)): inside the colour gate
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
         if (fabs(color_distance2(f[F_MR * a.Lp + l2], f[F_MG * a.Lp + l2], f[F_MB * a.Lp + l2], zr, zg, zbl)) > 300.0)
           continue;
         const double mx = f[F_MX * a.Lp + l2], my = f[F_MY * a.Lp + l2];
-        const double eb = atan2(my - sy, mx - sx) - sh;
+        const double eb = pk_atan2(my - sy, mx - sx) - sh;
         if (fabs(zb - eb) > 0.5) continue;
         const double pr = full_match_probability(f, a.Lp, l2, sx, sy, sh, rec);
         if (pr > pm) {
@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   const bool has = l < a.L;
   if (has) {
     const double mx = f[(size_t)F_MX * a.Lp + l], my = f[(size_t)F_MY * a.Lp + l];
-    ebf = (float)(atan2(my - sy, mx - sx) - sh);  // :408 for the reference particle
+    ebf = (float)(pk_atan2(my - sy, mx - sx) - sh);  // :408 for the reference particle
     rf = (float)f[(size_t)F_MR * a.Lp + l];
     gf = (float)f[(size_t)F_MG * a.Lp + l];
     bf = (float)f[(size_t)F_MB * a.Lp + l];

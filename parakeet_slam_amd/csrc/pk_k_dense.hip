@@ -81,7 +81,7 @@ struct DenseAux {
 __device__ __forceinline__ double dense_ekf_update(DenseLm& f, double sx, double sy, const BlobT<double>& z, const double* Qt,
                                                    bool immutable, DenseAux* aux = nullptr) {
   const double dx = f.m[0] - sx, dy = f.m[1] - sy;
-  const double zhat0 = atan2(dy, dx);  // :871 world frame
+  const double zhat0 = pk_atan2(dy, dx);  // :871 world frame
   const double q = dx * dx + dy * dy;
   double h0 = 0.0, h1 = 0.0;
   if (q != 0.0) {
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) k_observe_dense(DenseArgs a) {
       for (int l = tid; l < a.L; l += 256) {
         const DenseLm d = dense_load(sf, sc, Lp, l);
         const Landmark<double> lm = dense_blocks(d);
-        const double pse = atan2(lm.my - sy, lm.mx - sx);
+        const double pse = pk_atan2(lm.my - sy, lm.mx - sx);
         const double eb = pse - sh;  // :408
         for (int b = 0; b < B; ++b) {
           const BlobT<double> z{a.blobs[4 * b], a.blobs[4 * b + 1], a.blobs[4 * b + 2], a.blobs[4 * b + 3]};
@@ -327,7 +327,7 @@ __global__ void k_probe_dense(const double* __restrict__ in, double* __restrict_
   for (int i = 0; i < 79; ++i) out[i] = 0.0;
   const Landmark<double> lm = dense_blocks(f);
   out[0] = probability_of_match(lm, sx, sy, sh, z, ux, uy);
-  const double pse = atan2(lm.my - sy, lm.mx - sx);
+  const double pse = pk_atan2(lm.my - sy, lm.mx - sx);
   out[1] = prob_position_match(lm, sx, sy, pse, z.bearing, ux, uy, out + 2);
   out[4] = prob_color_match(lm, z.r, z.g, z.b);
   DenseAux aux;

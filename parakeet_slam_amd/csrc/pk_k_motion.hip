@@ -212,7 +212,7 @@ __global__ void k_probe(const double* __restrict__ in, double* __restrict__ out)
   const double ux = in[53], uy = in[54];  // unit((cos b, sin b, 0)), host side like the kernels' input
   for (int i = 0; i < 79; ++i) out[i] = 0.0;
   out[0] = probability_of_match(f, sx, sy, sh, z, ux, uy);
-  double pse = atan2(f.my - sy, f.mx - sx);
+  double pse = pk_atan2(f.my - sy, f.mx - sx);
   out[1] = prob_position_match(f, sx, sy, pse, z.bearing, ux, uy, out + 2);
   out[4] = prob_color_match(f, z.r, z.g, z.b);
   EkfAux<double> aux;

@@ -82,7 +82,7 @@ __device__ __forceinline__ double apply_blobs(Landmark<double>& lm, int l, doubl
   const int b0 = first[l];
   if (b0 < 0) return acc;
   const bool imm = a.immutable[l] != 0;
-  const double pse = atan2(lm.my - sy, lm.mx - sx);
+  const double pse = pk_atan2(lm.my - sy, lm.mx - sx);
   if (!KNOWN) {
     for (int b = b0; b >= 0; b = next[b]) {
       const BlobT<double> z = load_blob(a.blobs, b);

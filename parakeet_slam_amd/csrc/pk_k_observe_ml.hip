@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
     const double mx = A.mx, my = A.my, mr = A.mr, mg = A.mg, mb = A.mb;
     PK_STAMP(g0)
     PK_FSTAMP_ADD(1, f1, g0)  // wait for the means
-    pseA = atan2(my - sy, mx - sx);
+    pseA = pk_atan2(my - sy, mx - sx);
     const double eb = pseA - sh;  // :408
     const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
     int c[3];
@@ -1222,7 +1222,7 @@ __device__ __forceinline__ RegsGated regs_gates(const BlobGrid& g, const unsigne
                                                 double mx, double my, double mr, double mg, double mb, double sx, double sy,
                                                 double sh) {
   unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;
-  const double pse = atan2(my - sy, mx - sx);
+  const double pse = pk_atan2(my - sy, mx - sx);
   const double eb = pse - sh;  // :408
   const float mr32 = (float)mr, mg32 = (float)mg, mb32 = (float)mb, eb32 = (float)eb;
   int c[3];
@@ -1316,7 +1316,7 @@ __device__ __forceinline__ RegsGated regs_gates_cand(uint4 ref, uint4 cands, con
                                                      double mx, double my, double mr, double mg, double mb, double sx,
                                                      double sy, double sh) {
   unsigned pass01 = 0xFFFFFFFFu, pass23 = 0xFFFFFFFFu;
-  const double pse = atan2(my - sy, mx - sx);
+  const double pse = pk_atan2(my - sy, mx - sx);
   const double eb = pse - sh;  // :408
   // (written so that a NaN anywhere breaks the margin)
   const double deb = eb - (double)__uint_as_float(ref.x);  // 2 pi off: the other side of a branch cut, listed too (k_candidates)

@@ -45,6 +45,9 @@ namespace pk {
 #ifndef PK_PUB_ABLATE
 #define PK_PUB_ABLATE 0
 #endif
+#ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
+#define PK_PUB_ILV 0
+#endif
 constexpr int kPubThreads = 512;        // the large instances' workgroup
 constexpr int kPubSmallThreads = 256;   // ... the L <= 512 instance's
 constexpr int kPubSlots = 4;  // gate-passing blobs a landmark keeps; more: the particle is flagged
@@ -287,7 +290,7 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
   int npass[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const double pse = atan2(in[j].my - sy, in[j].mx - sx);
+    const double pse = pk_atan2(in[j].my - sy, in[j].mx - sx);
     pse_out[j] = pse;
     eb[j] = pse - sh;  // :408
     // (written so that a NaN anywhere breaks the margin)
@@ -395,13 +398,13 @@ __device__ __forceinline__ double pub_log(double x) {
   e = low ? e - 1 : e;
   const double s = (m - 1.0) * pub_recip(m + 1.0);
   const double z = s * s;  // <= 0.0295
-  double p = 1.0 / 15.0;
-  p = p * z + 1.0 / 13.0;
-  p = p * z + 1.0 / 11.0;
-  p = p * z + 1.0 / 9.0;
-  p = p * z + 1.0 / 7.0;
-  p = p * z + 1.0 / 5.0;
-  p = p * z + 1.0 / 3.0;
+  double p = 1.0 / 15.0;  // (fma_k: the coefficients through scalar registers, pk_math.hpp)
+  p = fma_k(p, z, 1.0 / 13.0);
+  p = fma_k(p, z, 1.0 / 11.0);
+  p = fma_k(p, z, 1.0 / 9.0);
+  p = fma_k(p, z, 1.0 / 7.0);
+  p = fma_k(p, z, 1.0 / 5.0);
+  p = fma_k(p, z, 1.0 / 3.0);
   const double lm = 2.0 * s + 2.0 * s * (z * p);  // 2 atanh(s); the series' remainder: 2 s z^8 / 17 < 3e-14
   return (double)e * 0.69314718055994530942 + lm;
 }
@@ -1036,6 +1039,95 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       double* df = reinterpret_cast<double*>(dslot);
       int* dc = reinterpret_cast<int*>(dslot + R->count_off);
       const unsigned char* immutable = smem + o_imm;
+#if PK_PUB_ILV
+      if constexpr (NP == 2 && THREADS == kPubThreads) {
+        // The rows of pair 0 go out -- and the next particle's pair 0 is asked for -- BETWEEN the updates of pair 1's two
+        // landmarks, a third at a time, instead of in one burst of thirty vector-memory instructions: behind barrier C all
+        // eight waves reach that burst together, the CU's one texture-addresser path takes ~16 cycles per 1 KB instruction,
+        // and a wave that stands in that queue issues no arithmetic (12.7 % of a particle's time by the stamps, round 3).
+        // In thirds the queue has drained by the time the wave comes back with the next one.
+        const int l00 = 2 * tid, l01 = 2 * kPubThreads + 2 * tid;
+#define PK_ILV_APPLY(i, l)                                                                                    \
+  if (PK_PUB_ABLATE < 1) acc += pub_apply(Q[i], ex, order, qt, S[i], immutable[min((l), Lp - 1)] != 0, sx, sy, pse[i]);
+#define PK_ILV_STORE(q, l0_, field, F)                                                                        \
+  {                                                                                                           \
+    const Double2 v = {S[2 * (q)].field, S[2 * (q) + 1].field};                                               \
+    __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + (l0_)));                  \
+  }
+        PK_ILV_APPLY(0, l00)
+        PK_ILV_APPLY(1, l00 + 1)
+        asm volatile("" ::: "memory");
+        if (l00 < Lp) {
+          PK_ILV_STORE(0, l00, mx, F_MX)
+          PK_ILV_STORE(0, l00, my, F_MY)
+          PK_ILV_STORE(0, l00, mr, F_MR)
+          PK_ILV_STORE(0, l00, mg, F_MG)
+          PK_ILV_STORE(0, l00, mb, F_MB)
+#if PK_PUB_ILV >= 2
+        }
+        asm volatile("" ::: "memory");
+        PK_ILV_APPLY(2, l01)
+        asm volatile("" ::: "memory");
+        if (l00 < Lp) {
+#endif
+          PK_ILV_STORE(0, l00, pxx, F_PXX)
+          PK_ILV_STORE(0, l00, pxy, F_PXY)
+          PK_ILV_STORE(0, l00, pyy, F_PYY)
+          PK_ILV_STORE(0, l00, crr, F_CRR)
+          PK_ILV_STORE(0, l00, crg, F_CRG)
+#if PK_PUB_ILV == 1
+        }
+        asm volatile("" ::: "memory");
+        PK_ILV_APPLY(2, l01)
+        asm volatile("" ::: "memory");
+        if (l00 < Lp) {
+#endif
+          PK_ILV_STORE(0, l00, crb, F_CRB)
+          PK_ILV_STORE(0, l00, cgg, F_CGG)
+          PK_ILV_STORE(0, l00, cgb, F_CGB)
+          PK_ILV_STORE(0, l00, cbb, F_CBB)
+          const Int2 c = {S[0].count, S[1].count};
+          __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l00));
+        }
+#if PK_PUB_ILV == 1
+        {  // the next particle's first pair, into the registers just stored
+          PubArgsPtr R6 = pub_args_now(rp);
+          const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
+        }
+        PK_ILV_APPLY(3, l01 + 1)
+#else
+        asm volatile("" ::: "memory");
+        PK_ILV_APPLY(3, l01 + 1)
+        {  // the next particle's first pair, into the registers just stored
+          PubArgsPtr R6 = pub_args_now(rp);
+          const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
+        }
+#endif
+        asm volatile("" ::: "memory");
+        if (l01 < Lp) {
+          PK_ILV_STORE(1, l01, mx, F_MX)
+          PK_ILV_STORE(1, l01, my, F_MY)
+          PK_ILV_STORE(1, l01, mr, F_MR)
+          PK_ILV_STORE(1, l01, mg, F_MG)
+          PK_ILV_STORE(1, l01, mb, F_MB)
+          PK_ILV_STORE(1, l01, pxx, F_PXX)
+          PK_ILV_STORE(1, l01, pxy, F_PXY)
+          PK_ILV_STORE(1, l01, pyy, F_PYY)
+          PK_ILV_STORE(1, l01, crr, F_CRR)
+          PK_ILV_STORE(1, l01, crg, F_CRG)
+          PK_ILV_STORE(1, l01, crb, F_CRB)
+          PK_ILV_STORE(1, l01, cgg, F_CGG)
+          PK_ILV_STORE(1, l01, cgb, F_CGB)
+          PK_ILV_STORE(1, l01, cbb, F_CBB)
+          const Int2 c = {S[2].count, S[3].count};
+          __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l01));
+        }
+#undef PK_ILV_APPLY
+#undef PK_ILV_STORE
+      } else
+#endif
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         const int l0 = 2 * kPubThreads * q + 2 * tid;

@@ -99,6 +99,70 @@ __device__ __forceinline__ T wrap_heading(T h) {
   return atan2(s, c);
 }
 
+// a * b + K, one rounding, with the CONSTANT K in a scalar register pair (VOP3 v_fma_f64 takes one scalar operand).  Left to
+// itself the compiler writes a Horner step `p = p * z + K` as v_fmac_f64 (VOP2: the addend is the destination), which wants
+// K in vector registers first: two v_mov_b32 of 32-bit literals and the multiply-add -- three VALU issue slots (twelve
+// cycles of a wave64 SIMD) where one does, in kernels whose gates / keys phases are float64-issue-bound.
+// The two s_mov_b32 that load K issue on the scalar unit, beside the other wave's vector instructions.  Same value as the
+// contracted expression (one fused multiply-add either way).
+__device__ __forceinline__ double fma_k(double a, double b, double k) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PK_NO_SCALAR_FMA)
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+  return r;
+#else
+  return __builtin_fma(a, b, k);
+#endif
+}
+
+// atan2 for the EXPECTED BEARING of a landmark (prkt_core_v2.py:408, :473, :871: math.atan2(fy - sy, fx - sx)), within
+// 2 ulp, in ~47 float64 instructions against the library's ~100 + 40 constant moves (every particle x landmark pays
+// one, in the issue-bound gates phase of the one-pass kernels).  ONE division for both range reductions:
+//   t = min(|x|, |y|) / max(|x|, |y|) in [0, 1];  beyond tan(pi / 8):  atan t = pi / 4 + atan((t - 1) / (t + 1)), and
+//   (t - 1) / (t + 1) = (mn - mx) / (mn + mx) -- the same quotient with another numerator and denominator --
+// so r = num / den lies in [-tan(pi / 8), tan(pi / 8)] and atan r = r + r s Q(s), s = r^2, Q of degree 10 (coefficients:
+// scripts/fit_atan_poly.py, polynomial error 9e-18 relative, 0.64 ulp evaluated in float64).  The quotient by v_rcp_f64, two
+// Newton steps and one residual correction (< 1 ulp).  Then the octant: pi / 2 - a where |y| > |x|, pi - a where x < 0
+// (hi + lo constants), the sign of y.  atan2(0, 0) = 0 like the library's for +0; NaN in gives NaN out (v_max / v_min drop
+// NaNs: restored by hand -- the kernels rely on a NaN state failing every comparison).  Infinite arguments are not handled (a
+// state is finite or NaN).  EVERY observe kernel takes its expected bearings here, so the routes stay bit-identical to each
+// other; the motion model's heading wrap and summary keep the library's atan2 (O(P) work, utils.py:8-35).
+__device__ __forceinline__ double pk_atan2(double y, double x) {
+#if defined(PK_LIBM_ATAN2)  // diagnostic build: the library's
+  return atan2(y, x);
+#else
+  const double ax = fabs(x), ay = fabs(y);
+  const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+  const bool upper = mn > 0.41421356237309503 * mx;  // tan(pi / 8)
+  const double num = upper ? mn - mx : mn;
+  double den = upper ? mn + mx : mx;
+  den = mx == 0.0 ? 1.0 : den;  // atan2(0, 0) = 0
+  double rc = __builtin_amdgcn_rcp(den);
+  rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+  rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+  double r = num * rc;
+  r = __builtin_fma(__builtin_fma(-den, r, num), rc, r);
+  const double s = r * r;
+  double q = -0x1.3a25edd998780p-6;
+  q = fma_k(q, s, 0x1.415d4935ee1ffp-5);
+  q = fma_k(q, s, -0x1.a09769c825878p-5);
+  q = fma_k(q, s, 0x1.dfe5c951ef847p-5);
+  q = fma_k(q, s, -0x1.10fa6e9b77db9p-4);
+  q = fma_k(q, s, 0x1.3b126231f5ee5p-4);
+  q = fma_k(q, s, -0x1.745d0b1c2ae99p-4);
+  q = fma_k(q, s, 0x1.c71c7184c78c8p-4);
+  q = fma_k(q, s, -0x1.2492492434d72p-3);
+  q = fma_k(q, s, 0x1.9999999999310p-3);
+  q = fma_k(q, s, -0x1.5555555555555p-2);
+  double a = __builtin_fma(r * s, q, r);  // atan r
+  a = upper ? 0x1.921fb54442d18p-1 + (a + 0x1.1a62633145c07p-55) : a;        // + pi / 4
+  a = ay > ax ? (0x1.921fb54442d18p+0 - a) + 0x1.1a62633145c07p-54 : a;      // pi / 2 - a
+  a = x < 0.0 ? (0x1.921fb54442d18p+1 - a) + 0x1.1a62633145c07p-53 : a;      // pi - a
+  a += 0.0 * (x + y);  // NaN in, NaN out
+  return __builtin_copysign(a, y);
+#endif
+}
+
 // closest_point, prkt_core_v2.py:496-522.  (ux, uy) = unit((cos b, sin b, 0)),
 // utils.py:68-76, precomputed per blob.
 template <typename T>
@@ -152,7 +216,7 @@ __device__ __forceinline__ T color_distance2(T mr, T mg, T mb, T r, T g, T b) {
 template <typename T>
 __device__ __forceinline__ T probability_of_match(const Landmark<T>& f, T sx, T sy, T heading,
                                                   const BlobT<T>& z, T ux, T uy) {
-  T pse = atan2(f.my - sy, f.mx - sx);
+  T pse = pk_atan2(f.my - sy, f.mx - sx);
   T delb = z.bearing - (pse - heading);  // :408-415, never wrapped (:416-423 commented out)
   if (fabs(delb) > T(0.5)) return T(0);  // :433
   T cd = color_distance2(f.mr, f.mg, f.mb, z.r, z.g, z.b);
@@ -181,15 +245,15 @@ __device__ __forceinline__ double log_few_ulp(double x) {
   const double s = (m - 1.0) / (m + 1.0);
   const double z = s * s;
   double p = 1.0 / 21.0;
-  p = p * z + 1.0 / 19.0;
-  p = p * z + 1.0 / 17.0;
-  p = p * z + 1.0 / 15.0;
-  p = p * z + 1.0 / 13.0;
-  p = p * z + 1.0 / 11.0;
-  p = p * z + 1.0 / 9.0;
-  p = p * z + 1.0 / 7.0;
-  p = p * z + 1.0 / 5.0;
-  p = p * z + 1.0 / 3.0;
+  p = fma_k(p, z, 1.0 / 19.0);
+  p = fma_k(p, z, 1.0 / 17.0);
+  p = fma_k(p, z, 1.0 / 15.0);
+  p = fma_k(p, z, 1.0 / 13.0);
+  p = fma_k(p, z, 1.0 / 11.0);
+  p = fma_k(p, z, 1.0 / 9.0);
+  p = fma_k(p, z, 1.0 / 7.0);
+  p = fma_k(p, z, 1.0 / 5.0);
+  p = fma_k(p, z, 1.0 / 3.0);
   const double lm = 2.0 * s + 2.0 * s * (z * p);  // 2 atanh(s)
   const double ed = (double)e;
   return ed * 0.69314718055994528623 + (ed * 2.3190468138462995584e-17 + lm);  // ln 2 = hi + lo
@@ -236,7 +300,7 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
   T dx = f.mx - sx, dy = f.my - sy;
   // :871 world frame: the heading is NOT subtracted here.  A caller that already holds
   // atan2(dy, dx) for this very state passes it in (one float64 atan2 saved).
-  T zhat0 = zhat0_known ? *zhat0_known : atan2(dy, dx);
+  T zhat0 = zhat0_known ? *zhat0_known : pk_atan2(dy, dx);
   T q = dx * dx + dy * dy;  // :785
   T h0, h1;                 // :789/:795 -- (dy/q, dx/q): the reference's signs, not the textbook's
   if (q == T(0)) {          // ZeroDivisionError branch :790,:796

@@ -141,10 +141,9 @@ def test_pub_big_sampled_particles_against_the_oracle_at_5000_landmarks(lib):
     f.close()
 
 
-@pytest.mark.parametrize("L,P", [(5000, 2), (5008, 2), (6144, 2)])
+@pytest.mark.parametrize("L,P", [(5000, 2), (5008, 2)])
 def test_two_pass_instance_against_the_oracle_at_5000_landmarks(lib, L, P):
-    """tests/test_gpu_pub.py holds k_step_pub_big to the oracle up to 3 000 landmarks; here the map of configs[4] and the
-    instance's limits, look-alikes and immutable landmarks included (prkt_core_v2.py:353-381, :909, :926)."""
+    """tests/test_gpu_pub.py holds k_step_pub_big to the oracle up to 3 000 landmarks; here the map of configs[4], look-alikes and immutable landmarks included (prkt_core_v2.py:353-381, :909, :926)."""
     from oracle.fastslam_oracle import synthetic_scan, synthetic_world
 
     rs = np.random.RandomState(1300 + L)
@@ -152,7 +151,7 @@ def test_two_pass_instance_against_the_oracle_at_5000_landmarks(lib, L, P):
     n = len(means[3::7])
     means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))
     imm = (rs.uniform(size=L) < 0.1).astype(np.uint8)
-    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))[rs.permutation(L)][:5200]  # (the scan tables of 6 144 blobs do not fit the route)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))[rs.permutation(L)]
     poses = np.zeros((P, 4))
     poses[:, 0] = rs.normal(0, 0.05, P)
     poses[:, 1] = rs.normal(0, 0.05, P)
