@@ -70,6 +70,45 @@ def measured_traffic(P, L, variant):
     return best
 
 
+CLOCK_GHZ = 2.4   # MI355X_MICROARCH.md: peak engine clock
+N_SIMD = 1024     # 256 CUs x 4 SIMDs
+SQ_KERNEL_KEY = {"ml_regs_pub": "k_step_pub<2, 512>", "ml_fused": "k_step_fused", "ml_fused_pub": "k_step_pub<1, 256>", "ml_pub_big": "k_step_pub_big",
+                 "ml_regs": "k_step_regs", "known_ids": "k_observe"}
+
+
+def measured_issue(P, L, route):
+    """Instruction-issue time of the route's dominant kernel for one launch over P particles, from the committed SQ counter pass
+    (profiles/*/pmc_sq_*.json, scripts/gpu_pmc_sq.sh) taken at THIS map size: (VALU + SALU wave-instructions per particle) x P x
+    4 cycles / (1 024 SIMDs x clock).  The counts per particle do not depend on P (persistent grid, one particle per workgroup
+    at a time).  The newest round wins; None when no pass exists for this size / kernel."""
+    import re
+
+    key = SQ_KERNEL_KEY.get(route)
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if (key and os.path.isdir(pdir)) else []:
+        rdir = os.path.join(pdir, rnd)
+        for name in sorted(os.listdir(rdir)) if os.path.isdir(rdir) else []:
+            if not (name.startswith("pmc_sq") and name.endswith(".json")):
+                continue
+            try:
+                d = json.load(open(os.path.join(rdir, name)))
+                cfg = d["config"]
+                mp, ml = re.search(r"--particles (\d+)", cfg), re.search(r"--landmarks (\d+)", cfg)
+                if not (mp and ml) or int(ml.group(1)) != L:
+                    continue
+                for k, c in d["counters"].items():
+                    if key in k and c.get("SQ_INSTS_VALU", 0) > 0:
+                        per_particle = (c["SQ_INSTS_VALU"] + c.get("SQ_INSTS_SALU", 0.0)) / float(mp.group(1))
+                        best = {"ms": per_particle * P * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3,
+                                "valu_per_particle": c["SQ_INSTS_VALU"] / float(mp.group(1)),
+                                "salu_per_particle": c.get("SQ_INSTS_SALU", 0.0) / float(mp.group(1)),
+                                "source": "profiles/%s/%s (git %s)" % (rnd, name, d.get("git", "?"))}
+            except (ValueError, KeyError, OSError):
+                continue
+    return best
+
+
 ROUTE_KERNEL = {
     "known_ids": "k_observe<known ids> (fused EKF update + log-weight)",
     "ml_fused": "k_step_fused (association gates + settling of contested blobs + EKF update + log-weight in ONE kernel)",
@@ -268,8 +307,11 @@ def self_launch(args, argv):
         sys.stderr.write("bench.py --gpus %d: the %d-rank launch failed (exit code %d, %s)\n"
                          % (args.gpus, args.gpus, proc.returncode, "no result line" if line is None else "result line seen"))
         raise SystemExit(proc.returncode or 4)
-    if json.loads(line).get("n_gpus") != args.gpus:
-        sys.stderr.write("bench.py --gpus %d: the ranks report n_gpus = %r\n" % (args.gpus, json.loads(line).get("n_gpus")))
+    rec = json.loads(line)
+    # a rehearsal (PK_BENCH_SAME_GPU: every rank on ONE device, gloo) says so and counts DEVICES, not ranks, in n_gpus
+    if rec.get("world_size") != args.gpus or (rec.get("n_gpus") != args.gpus and not (same_gpu and rec.get("rehearsal"))):
+        sys.stderr.write("bench.py --gpus %d: the ranks report n_gpus = %r, world_size = %r\n"
+                         % (args.gpus, rec.get("n_gpus"), rec.get("world_size")))
         raise SystemExit(5)
     sys.stdout.write(line + "\n")
     sys.stdout.flush()
@@ -335,10 +377,27 @@ def roofline_object(P, L, route, obs_ms, obs_n, stride, K, copy_gbs):
     obs_avg_s = (obs_ms / max(obs_n, 1)) * 1e-3
     alg_bytes = float(P) * L * BYTES_PER_UPDATE
     achieved = alg_bytes / obs_avg_s / 1e9 if obs_avg_s > 0 else 0.0
+    hbm_frac = achieved / HBM_PEAK_GBS
+    issue = measured_issue(P, L, route)
+    issue_obj = None
+    if issue is not None and obs_avg_s > 0:
+        issue_obj = {
+            "frac": issue["ms"] / (obs_avg_s * 1e3),
+            "issue_ms": issue["ms"],
+            "valu_wave_instructions_per_particle": issue["valu_per_particle"],
+            "salu_wave_instructions_per_particle": issue["salu_per_particle"],
+            "what": "replayed: (VALU + SALU wave-instructions per launch from the committed SQ counter pass) x 4 cycles / (%d SIMDs x "
+                    "%.1f GHz) / this run's kernel time -- the share of the launch during which every SIMD would be issuing if the "
+                    "instructions were spread evenly; float64 vector instructions take 4 cycles of a wave64 SIMD" % (N_SIMD, CLOCK_GHZ),
+            "source": issue["source"],
+        }
     return {
         "kernel": ROUTE_KERNEL.get(route, route),
         "route": route,
-        "bound": "hbm",
+        # the maximum-likelihood kernels are bounded by BOTH the pass over the map and float64 instruction issue: `bound` names the
+        # larger share; `frac` / `achieved` stay the HBM figures SURVEY 8(d) defines (ekf_stage is the pure-HBM kernel)
+        "bound": "issue" if (issue_obj is not None and issue_obj["frac"] > hbm_frac) else "hbm",
+        "issue": issue_obj,
         "achieved": achieved,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
@@ -370,6 +429,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] object")
     ap.add_argument("--no-probes", action="store_true", help="skip the untimed probes behind the timed region")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] shard object (125 000 x 5 000 on this GPU)")
+    ap.add_argument("--no-refscene", action="store_true", help="skip the facade latency object (the reference's own scene sizes)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (collectives included) even with one rank")
@@ -601,6 +662,43 @@ def main():
         f2.close()
         del f2
 
+    # One whole shard of BASELINE.json configs[4] (1 000 000 x 5 000 over 8 GPUs = 125 000 x 5 000 per GPU) on this GPU: the two-pass
+    # kernel k_step_pub_big, timed by the driver's run and not only in profiles/ (N = 1, default workload only)
+    shard4 = None
+    if world == 1 and not args.force_sharded and not args.no_configs4 and (P, L) == (DEFAULT_P, DEFAULT_L) and args.assoc == "ml":
+        P4, L4, K4, W4 = 125000, 5000, 6, 2
+        try:
+            m4, c4, s4 = synthetic_inputs(L4, K4 + W4)
+            f4 = _lib.DeviceFilter(P4, L4, device=local_rank)
+            f4.upload_map(m4, c4.reshape(L4, 25))
+            rnd4 = random.Random(7)
+            e4, tm4, route4, _ = timed_steps(f4, _lib, P4, L4, K4, W4, s4, synthetic_controls(K4 + W4),
+                                              [rnd4.random() for _ in range(K4 + W4)], None, barrier2(torch, f4), 1)
+            fl4 = f4.observe_flagged()
+            shard4 = {
+                "workload": workload_name(P4, L4, "ml"),
+                "value": float(P4) * L4 * K4 / e4,
+                "unit": "updates/s",
+                "steps": K4,
+                "warmup": W4,
+                "ms_per_step": e4 / K4 * 1e3,
+                "filter_steps_per_sec": K4 / e4,
+                "device_bytes": f4.device_bytes(),
+                "particles_sent_to_fallback_kernels_last_step": fl4[0],
+                "roofline": roofline_object(P4, L4, route4, tm4["observe"][0], tm4["observe"][1], 1, K4, None),
+            }
+            f4.close()
+            del f4
+        except Exception as e:  # (a GPU with less free memory than 170 GB: say so instead of failing the headline)
+            shard4 = {"workload": workload_name(P4, L4, "ml"), "error": repr(e)}
+
+    # The reference's own scene sizes through the FACADE (FastSLAM.cam_cb wall time, Python included): prkt_ros.py's node --
+    # 50 particles x 4 landmarks (prkt_ros.py:33-52; mutable, as BASELINE.md section 2 measured them) -- and BASELINE configs[0],
+    # 100 x 50.  BASELINE.md section 2 holds the reference's own figures for the same sizes (build container, one CPU core).
+    refscene = None
+    if world == 1 and not args.force_sharded and not args.no_refscene and (P, L) == (DEFAULT_P, DEFAULT_L) and args.assoc == "ml":
+        refscene = facade_latency(local_rank)
+
     # what a plain device-to-device copy reaches on THIS box (read + write bytes / time), outside the
     # timed region: the practical ceiling next to the 8 TB/s vendor figure
     copy_gbs = None
@@ -627,10 +725,23 @@ def main():
         elapsed = float(tt.item())
 
     backend_name = "none"
+    rank_devices = None
     if sharded:
         import torch.distributed as dist
 
         backend_name = "%s%s" % (dist.get_backend(), " (= RCCL over xGMI)" if dist.get_backend() == "nccl" else "")
+        # which physical device every rank really ran on (so that a SCALE record can be checked for "N ranks on N GPUs")
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "device_index": local_rank, "name": prop.name,
+                "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None)}
+        if world > 1:
+            rank_devices = [None] * world
+            dist.all_gather_object(rank_devices, mine)
+        else:
+            rank_devices = [mine]
+    n_devices = world
+    if rank_devices is not None:
+        n_devices = len(set((d["uuid"], d["pci_bus_id"], d["device_index"]) for d in rank_devices))
     if rank == 0:
         total_updates = float(P) * world * L * K
         obs_ms, obs_n = tm["observe"]
@@ -664,7 +775,7 @@ def main():
             "metric": "particle*landmark EKF updates/sec (whole filter step)",
             "value": total_updates / elapsed,
             "unit": "updates/s",
-            "n_gpus": world,
+            "n_gpus": n_devices,
             "steps": K,
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
@@ -694,11 +805,21 @@ def main():
             out["per_step"] = replay
             if replay.get("slow_window"):
                 out["slow_window_ms_per_step"] = replay["slow_window"]["ms_mean"]
+        if sharded:
+            out["world_size"] = world  # dist.get_world_size(): the ranks the process group really formed
+            out["rank_devices"] = rank_devices
+            if same_gpu or n_devices != world:
+                out["rehearsal"] = True  # several ranks share a device: control flow only, NOT a scaling measurement
+                out["rehearsal_note"] = "%d ranks on %d device(s) over %s: the value is not a multi-GPU throughput" % (world, n_devices, backend_name)
         if migrated is not None:
             out["migrated_particles_per_step"] = migrated  # all ranks together: each one is a pose + a whole map slot on the wire
             out["migrated_bytes_per_step"] = migrated_bytes
         if second is not None:
             out["configs1"] = second
+        if shard4 is not None:
+            out["configs4_shard"] = shard4
+        if refscene is not None:
+            out["refscene"] = refscene
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()
@@ -708,6 +829,71 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def facade_latency(device):
+    """cam_cb through parakeet_slam_amd.FastSLAM at the reference's own sizes: seconds per filter step, host side included."""
+    import parakeet_slam_amd as pk
+
+    class Scan(object):
+        pass
+
+    class Node(object):
+        pass
+
+    out = {"what": "wall time of FastSLAM.cam_cb (facade + C ABI + kernels, one synchronising summary() per step as prkt_ros.py:84-85 "
+                   "does), rng='global', weights 'linear' -- the reference's semantics",
+           "reference_note": "BASELINE.md section 2: the unmodified reference takes 0.135 s per step at 50 x 4 (author's profile) and "
+                             "7.86 s per step at 100 x 50 (measured in the build container, 1 core)"}
+    for tag, P, L, immutable, steps, ref_s in (("prkt_ros_size_50x4", 50, 4, False, 200, 0.135), ("configs0_100x50", 100, 50, False, 100, 7.86)):
+        means, covs, scans = synthetic_inputs(L, steps + 5)
+        feats = []
+        for l in range(L):
+            f = pk.Feature(mean=means[l], covar=covs[l])
+            f.__immutable__ = immutable
+            feats.append(f)
+        pk.msgs.Time.set_now(0.0)
+        np.random.seed(7)
+        random.seed(7)
+        fs = pk.FastSLAM(feats, num_particles=P, device=device)
+        tw = pk.msgs.Twist()
+        tw.linear.x, tw.angular.z = 0.2, 0.1
+        fs.last_control = tw
+        node = Node()
+        node.last_sensor_reading = Scan()
+        t = 0.0
+
+        def blobs_of(sc):
+            obs = []
+            for b in sc:
+                o = pk.msgs.Blob()
+                o.bearing = float(b[0])
+                o.color.r, o.color.g, o.color.b = float(b[1]), float(b[2]), float(b[3])
+                obs.append(o)
+            return obs
+
+        views = [blobs_of(sc) for sc in scans]
+        for s_ in range(5):
+            t += 0.1
+            pk.msgs.Time.set_now(t)
+            node.last_sensor_reading.observes = views[s_]
+            fs.cam_cb(node)
+            fs.summary()
+        t0 = time.perf_counter()
+        for s_ in range(5, 5 + steps):
+            t += 0.1
+            pk.msgs.Time.set_now(t)
+            node.last_sensor_reading.observes = views[s_]
+            fs.cam_cb(node)
+            fs.summary()
+        dt = (time.perf_counter() - t0) / steps
+        fs.close()
+        out[tag] = {"particles": P, "landmarks": L, "blobs": L, "immutable_landmarks": immutable, "steps": steps,
+                    "seconds_per_step": dt, "steps_per_sec": 1.0 / dt, "reference_seconds_per_step": ref_s,
+                    "reference_source": "BASELINE.md section 2 (measured in the build container / the author's profile; not on this box)",
+                    "speedup_vs_reference": ref_s / dt}
+    pk.msgs.Time.set_now(None)
+    return out
 
 
 def barrier2(torch, filt):

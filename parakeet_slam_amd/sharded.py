@@ -395,6 +395,14 @@ class ShardedFilter(object):
     def observe_route(self):
         return self.f.observe_route() if hasattr(self.f, "observe_route") else "none"
 
+    def observe_published(self):
+        """Which instance of the register route worked on this shard's last scan (pk_observe_published)."""
+        return bool(self.f.observe_published()) if hasattr(self.f, "observe_published") else False
+
+    def observe_flagged(self):
+        """(particles of THIS shard the one-pass kernel handed on, candidate-list overflows) -- pk_observe_flagged."""
+        return self.f.observe_flagged() if hasattr(self.f, "observe_flagged") else (0, 0)
+
     def close(self):
         self._pending = None
         self.f.close()

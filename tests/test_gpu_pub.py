@@ -320,7 +320,7 @@ def test_lanes_beyond_the_map_do_not_repeat_the_last_pair(lib, L, opts):
     gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
     assert pub["published"] and pub["flagged"] == 0  # the production kernel itself did the work
     assert pub["route"] == ("ml_pub_big" if L > 2048 else "ml_fused" if L <= 512 else "ml_regs")
-    assert (gen["ids"] == L).sum(axis=1).min() == 3  # the last landmark really takes its three blobs
+    assert (gen["ids"] == L).sum(axis=1).max() == 3  # the last landmark really takes its three blobs (a particle on the other side of atan2's branch cut takes none: unwrapped bearings, :408-423)
     same_state(pub, gen, 1e-11)
     if L <= 2048:  # (the big maps against the oracle: test_gpu_audit.py, particle by particle)
         against_oracle(pub, means, covs, poses, blobs)
