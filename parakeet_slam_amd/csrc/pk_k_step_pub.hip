@@ -278,9 +278,13 @@ struct PubGateIn {
   bool has;
 };
 // N: landmarks worked on side by side; W4: uint4 words per list (1: eight candidates, 2: sixteen)
-template <int N, int W4 = 1, int SL = kPubSlots>
+// OVF: a landmark may pass MORE blobs than it has slots without the particle being flagged: pmask_out says which of its
+// candidates passed, and pub_keysN looks at the ones the slots no longer hold (round 4: what flagged up to 13 % of the
+// particles on some stretches of the bench's trajectory and sent them through the second-chance kernels).
+template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false>
 __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
-                                           double* pub, unsigned dump, int* flag, double sx, double sy, double sh) {
+                                           double* pub, unsigned dump, int* flag, double sx, double sy, double sh,
+                                           unsigned (*pmask_out)[N] = nullptr) {
   constexpr int NW = 4 * W4;  // 32-bit words per list, two candidates each
   double eb[N];
   bool inside[N];
@@ -288,6 +292,7 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
   unsigned sl[N][SL];
   float dmin[N];  // colour distance of the blob in slot 0: the best colour match stands in front (pub_keys)
   int npass[N];
+  unsigned pmask[N];  // OVF: bit k = candidate k of the list passed both gates
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const double pse = pk_atan2(in[j].my - sy, in[j].mx - sx);
@@ -317,6 +322,7 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
     for (int k = 0; k < SL; ++k) sl[j][k] = 0xFFFFFFFFu;
     dmin[j] = 3.0e38f;
     npass[j] = 0;
+    pmask[j] = 0u;
   }
 #pragma unroll  // (written out: the list words are addressed statically -- shifted through the registers every round they cost 1.3 %)
   for (int k = 0; k < NW; ++k) {
@@ -362,12 +368,20 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
         sl[j][0] = front ? wb : sl[j][0];
         dmin[j] = front ? d : dmin[j];
       }
-      npass[j] += (pa ? 1 : 0) + (pb ? 1 : 0);
+      if constexpr (OVF)
+        pmask[j] |= (pa ? (1u << (2 * kk)) : 0u) | (pb ? (2u << (2 * kk)) : 0u);
+      else
+        npass[j] += (pa ? 1 : 0) + (pb ? 1 : 0);
     }
   }
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    if (in[j].has && (!inside[j] || npass[j] > SL)) *flag = 1;
+    if constexpr (OVF) {
+      if (in[j].has && !inside[j]) *flag = 1;
+      (*pmask_out)[j] = pmask[j];
+    } else {
+      if (in[j].has && (!inside[j] || npass[j] > SL)) *flag = 1;
+    }
 #pragma unroll
     for (int k = 0; k < SL; ++k) q[j].s[k] = sl[j][k];
     q[j].st = 0u;
@@ -408,10 +422,13 @@ __device__ __forceinline__ double pub_log(double x) {
   const double lm = 2.0 * s + 2.0 * s * (z * p);  // 2 atanh(s); the series' remainder: 2 s z^8 / 17 < 3e-14
   return (double)e * 0.69314718055994530942 + lm;
 }
+// pmask / cand_row / erec_row (OVF instances, see pub_gatesN): the candidates that passed the gates, and where the landmarks'
+// list words can be read again.
 template <int N, int SL = kPubSlots>
 __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
-                                          unsigned anydump, int* flag, double sx, double sy) {
+                                          unsigned anydump, int* flag, double sx, double sy, const unsigned (*pmask)[N] = nullptr,
+                                          const uint4* cand_row = nullptr, const uint4* erec_row = nullptr) {
   {
     unsigned sall = q[0].s[0];
 #pragma unroll
@@ -452,6 +469,15 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
                                        lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
                      : 0.0;
   }
+  // Landmarks that passed MORE blobs than they have slots (OVF instances; a few landmarks of some particles, at some poses):
+  // the slots hold the last SL blobs that passed, the others are worked on in a SECOND turn of the same rounds -- one copy of
+  // the code, no register beyond the first turn's -- after they have taken the places of slots whose blob turned out to have
+  // probability 0 (a look-alike's, beyond the underflow edge once the landmark's colour block has tightened: nearly always all
+  // but one).  A lane whose landmark has no such case repeats its rounds on the same slots and publishes the same values.  If
+  // the blobs left over outnumber the free slots the particle goes to the fall-back kernels, as it did for any fifth blob
+  // before round 4.
+#pragma unroll 1
+  for (int turn = 0;; ++turn) {
   int done = 0;
 #pragma unroll 1
   for (; done < SL; ++done) {
@@ -541,6 +567,39 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
   for (; done < SL; ++done) {  // wave-uniform trip count: back to the original order
 #pragma unroll
     for (int j = 0; j < N; ++j) pub_rotate(q[j]);
+  }
+  if constexpr (SL != kPubSlots) break;
+  if (pmask == nullptr || turn == 1) break;
+  {
+    bool anyovf = false;
+#pragma unroll
+    for (int j = 0; j < N; ++j) anyovf |= __popc((*pmask)[j]) > SL;
+    if (__ballot(anyovf) == 0ull) break;  // wave-uniform: the usual case
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const bool ovf = __popc((*pmask)[j]) > SL;
+    if (__ballot(ovf) == 0ull) continue;  // wave-uniform
+    const uint4 cw4 = cand_row[2 * j + 1], ew4 = erec_row[j];  // this landmark's list words once more (L2)
+    const unsigned cw[4] = {cw4.x, cw4.y, cw4.z, cw4.w}, ew[4] = {ew4.x, ew4.y, ew4.z, ew4.w};
+    const unsigned id0 = q[j].s[0] & 0xFFFFu, id1 = q[j].s[1] & 0xFFFFu, id2 = q[j].s[2] & 0xFFFFu, id3 = q[j].s[3] & 0xFFFFu;
+    unsigned open = ~q[j].st & 0x1111u;  // slots whose blob has probability 0: its verdict is out, the place is free
+#pragma unroll
+    for (int k = 0; k < kCandSlots; ++k) {
+      const unsigned t = (cw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, e = (ew[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+      const bool extra = ovf && (((*pmask)[j] >> k) & 1u) != 0u && t != id0 && t != id1 && t != id2 && t != id3;
+      if (extra && open == 0u) *flag = 1;
+      const unsigned w = t | (e << 16);
+      bool placed = !extra;
+#pragma unroll
+      for (int sidx = 0; sidx < SL; ++sidx) {
+        const bool here = !placed && ((open >> (4 * sidx)) & 1u) != 0u;
+        q[j].s[sidx] = here ? w : q[j].s[sidx];
+        open &= here ? ~(1u << (4 * sidx)) : ~0u;
+        placed |= here;
+      }
+    }
+  }
   }
   if (weird) *flag = 1;
 }
@@ -947,9 +1006,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       }                                                                                                                            \
     } else {                                                                                                                       \
       const Landmark<double>* const l2[2] = {&S[2 * (q)], &S[2 * (q) + 1]};                                                        \
-      if (PK_PUB_ABLATE < 4) pub_gatesN<2>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);                                  \
+      unsigned pm_[2] = {0u, 0u};                                                                                                  \
+      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, true>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh, &pm_);        \
       PK_STAMP(sk0_)                                                                                                               \
-      if (PK_PUB_ABLATE < 3) pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                        \
+      if (PK_PUB_ABLATE < 3) {                                                                                                     \
+        PubArgsPtr R9 = pub_args_now(rp);                                                                                          \
+        const int lc9 = min(l0, Lp);                                                                                               \
+        pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, &pm_, R9->cand + 2 * (size_t)lc9,            \
+                     R9->erec + lc9);                                                                                              \
+      }                                                                                                                            \
       PK_STAMP(sk1_)                                                                                                               \
       PK_PSTAMP(2, sk0_, sk1_) /* keys: part of the gates-and-verdicts slot */                                                     \
     }                                                                                                                              \

@@ -141,7 +141,8 @@ def test_config2_routes_agree_at_full_size(lib, config2_default, name, opts):
 
 def test_config2_second_chance_route_at_the_poses_that_need_it(lib):
     """Around steps 44-62 of the bench's trajectory up to 9 % of the particles have a landmark that passes more than four
-    blobs (k_step_regs' register slots).  With "regs_retry" they are settled by the eight-slot hand-off + k_observe_sweep,
+    blobs (k_step_regs' register slots; k_step_pub settles such landmarks itself since round 4, so this test runs the
+    stand-by kernel, "pub_step" = 0).  With "regs_retry" they are settled by the eight-slot hand-off + k_observe_sweep,
     without it by the general kernels: same ancestors, same maps, weights to rounding -- at full size."""
     import bench
 
@@ -152,6 +153,7 @@ def test_config2_second_chance_route_at_the_poses_that_need_it(lib):
     for retry in (1, 0):
         f = lib.DeviceFilter(P2, L2)
         f.set_option("regs_retry", retry)
+        f.set_option("pub_step", 0)
         f.upload_map(means, covs.reshape(L2, 25))
         rnd = random.Random(7)
         flagged, ancs = [], []

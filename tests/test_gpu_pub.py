@@ -68,7 +68,9 @@ def test_pub_is_the_default_instance_and_agrees_with_regs_and_the_general_kernel
     gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0}, immutable=imm)
     assert pub["route"] == "ml_regs" and (pub["published"] or L == 2048)  # (2 048 blobs with look-alikes: the table does not fit LDS)
     assert regs["route"] == "ml_regs" and not regs["published"]
-    assert pub["flagged"] == regs["flagged"]  # both keep four gate-passing blobs per landmark; some landmarks here pass 5-7
+    # k_step_regs flags a particle for any landmark that passes more than four blobs (some here pass 5-7); k_step_pub since round 4
+    # only when more than four of them have a positive probability
+    assert pub["flagged"] <= regs["flagged"]
     same_state(pub, regs)
     same_state(pub, gen, 1e-11)
     against_oracle(pub, means, covs, poses, blobs, imm)
@@ -324,3 +326,53 @@ def test_lanes_beyond_the_map_do_not_repeat_the_last_pair(lib, L, opts):
     same_state(pub, gen, 1e-11)
     if L <= 2048:  # (the big maps against the oracle: test_gpu_audit.py, particle by particle)
         against_oracle(pub, means, covs, poses, blobs)
+
+
+def crowded_landmark_scene(L, rs, n_lookalike, n_sightings, tight=True):
+    """Landmark 40 with n_lookalike near-copies a few bearings away (their blobs pass its gates, and its blob theirs) and
+    n_sightings blobs of its own.  tight: colour blocks of 0.01 I, under which a look-alike's blob -- 2-4 colour units off -- has
+    probability 0; else the initial 0.25 I, under which every gate-passing blob has a positive one."""
+    means, covs = synthetic_world(L)
+    lm = 40
+    for i in range(n_lookalike):
+        means[lm + 3 * (i + 1), 2:] = means[lm, 2:] + rs.uniform(2.0, 4.0, 3) * rs.choice([-1.0, 1.0], 3)
+    if tight:
+        covs[:, 2:, 2:] = 0.01 * np.identity(3)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    extra = np.repeat(blobs[lm:lm + 1], n_sightings - 1, axis=0)
+    extra[:, 0] += 0.003 * (1 + np.arange(n_sightings - 1))
+    extra[:, 1:] += rs.uniform(-0.05, 0.05, (n_sightings - 1, 3))
+    blobs = np.vstack([blobs, extra])[rs.permutation(L + n_sightings - 1)]
+    return means, covs, blobs
+
+
+@pytest.mark.parametrize("L,n_lookalike,n_sightings", [(1500, 4, 1), (2000, 5, 2), (1024, 3, 3), (2000, 6, 2), (700, 2, 4)])
+def test_a_landmark_that_passes_more_blobs_than_it_has_slots_is_settled_in_the_kernel(lib, L, n_lookalike, n_sightings):
+    """Round 4: five to eight blobs inside a landmark's gates no longer send the particle to the second-chance kernels as long
+    as at most four of them have a positive probability (match_one's argmax ignores the others, prkt_core_v2.py:369-379): the
+    blobs the four slots no longer hold get their verdicts in a second turn of the key rounds."""
+    rs = np.random.RandomState(70 + L + n_lookalike)
+    means, covs, blobs = crowded_landmark_scene(L, rs, n_lookalike, n_sightings)
+    poses = poses_around(rs, 4, 0.05)
+    pub = run(lib, means, covs, poses, blobs)
+    regs = run(lib, means, covs, poses, blobs, {"pub_step": 0})
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["published"] and pub["route"] == "ml_regs"
+    assert regs["flagged"] == 4  # landmark 40 passes n_lookalike + n_sightings > 4 blobs: k_step_regs hands every particle on
+    assert pub["flagged"] == 0   # ... k_step_pub settles them itself
+    assert ((gen["ids"] == 41).sum(axis=1) == n_sightings).all()
+    same_state(pub, regs)
+    same_state(pub, gen, 1e-11)
+    against_oracle(pub, means, covs, poses, blobs)
+
+
+def test_more_than_four_blobs_with_a_positive_probability_still_go_to_the_fallback_kernels(lib):
+    rs = np.random.RandomState(99)
+    L = 1200
+    means, covs, blobs = crowded_landmark_scene(L, rs, 1, 5, tight=False)  # six gate-passing blobs, all with a positive probability
+    poses = poses_around(rs, 3, 0.05)
+    pub = run(lib, means, covs, poses, blobs)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert pub["published"] and pub["flagged"] == 3
+    same_state(pub, gen, 1e-11)
+    against_oracle(pub, means, covs, poses, blobs)
