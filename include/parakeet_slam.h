@@ -271,6 +271,13 @@ int pk_shard_block_totals_dev(pk_filter* f, const double* dev_gmax, int32_t weig
 int pk_shard_plan_dev(pk_filter* f, const double* dev_global_totals, int64_t n_global_blocks,
                       int64_t first_block, int64_t global_particles, double u, int32_t last_shard,
                       int32_t world, int64_t* dev_ranges);
+/* Debug / test entry (round 4; nothing in the reference: the exchange belongs to the multi-GPU resample of prkt_core_v2.py:210-252):
+ * pack the local particles [j0, j1) of the planned resample as exchange records whose slot ranges are clipped to the GLOBAL slots
+ * [slot_lo, slot_hi) -- what pk_shard_pack_dev does per destination rank, for an arbitrary slot interval.  With the options
+ * "split_loopback_lo" / "split_loopback_hi" (local slot bounds; pk_set_option) a single rank can send records of its OWN
+ * particles through the all-to-all to itself and adopt them with pk_shard_adopt_remote_dev: pack -> all_to_all_single(async) ->
+ * wait -> adopt with records that really travelled, on one device (tests/test_gpu_sharded.py). */
+int pk_shard_pack_slots_dev(pk_filter* f, int64_t j0, int64_t j1, int64_t slot_lo, int64_t slot_hi, void* dev_buf);
 /* The same plan for shards of ANY size (the block-total plan above reproduces the 1-GPU ancestors only when shards are
  * multiples of the 1024-particle scan block): the ranks all-gather their log-weights (pk_shard_logw_dev copies the shard's
  * into a caller buffer), and every rank runs the 1-GPU scan kernels on the whole array -- same blocks, same additions,

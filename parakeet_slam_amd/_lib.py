@@ -76,6 +76,7 @@ SIGNATURES = {
                                            C.c_void_p]),
     "pk_shard_download_offspring": (C.c_int, [_h, _lp]),
     "pk_shard_pack_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p]),
+    "pk_shard_pack_slots_dev": (C.c_int, [_h, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "pk_shard_adopt_dev": (C.c_int, [_h, C.c_int32, C.c_void_p, C.c_int64]),
     "pk_shard_local_span_dev": (C.c_int, [_h, C.c_void_p]),
     "pk_shard_adopt_local_dev": (C.c_int, [_h, C.c_int32]),
@@ -347,6 +348,9 @@ class DeviceFilter(object):
     def shard_pack_dev(self, ranges, world, rank, buf_ptr):
         r = np.ascontiguousarray(ranges, dtype=np.int64)
         check(self._lib.pk_shard_pack_dev(self._h, lptr(r), int(world), int(rank), C.c_void_p(buf_ptr)))
+
+    def shard_pack_slots_dev(self, j0, j1, slot_lo, slot_hi, buf_ptr):
+        check(self._lib.pk_shard_pack_slots_dev(self._h, int(j0), int(j1), int(slot_lo), int(slot_hi), C.c_void_p(buf_ptr)))
 
     def shard_adopt_dev(self, rank, recv_ptr, n_received):
         check(self._lib.pk_shard_adopt_dev(self._h, int(rank), C.c_void_p(recv_ptr), int(n_received)))

@@ -139,6 +139,7 @@ struct pk_filter {
   uint4* brec_dev = nullptr;     // [bcand_cap] the lists
   int64_t bcand_cap = 0;
   int cand_lists = 1;    // k_step_regs: gates against the reference particle's candidate lists (k_candidates) instead of the grid walk
+  int64_t loop_lo = INT64_MIN, loop_hi = INT64_MAX;  // "split_loopback_lo/hi" (debug): local slots outside come from records
   uint4* cand_dev = nullptr;  // [Lp + kCandSpare][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
@@ -1717,6 +1718,14 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     f->regs_step = value != 0;
     return PK_OK;
   }
+  if (!strcmp(name, "split_loopback_lo") || !strcmp(name, "split_loopback_hi")) {
+    // debug (one-rank tests of the exchange): the next split adoption fills only the LOCAL slots [lo, hi) of this shard with its
+    // own particles directly; the slots outside are filled from records -- which the caller packs with pk_shard_pack_slots_dev
+    // and sends through the all-to-all to itself.  Cleared by pk_shard_adopt_remote_dev.
+    if (value < 0 || value > f->d.P) return fail(PK_ERR_INVALID, "%s: 0..P", name);
+    (name[15] == 'l' ? f->loop_lo : f->loop_hi) = value;
+    return PK_OK;
+  }
   if (!strcmp(name, "split_reserve_cus")) {
     if (value < 0 || value > 128) return fail(PK_ERR_INVALID, "split_reserve_cus: 0..128");
     f->split_reserve_cus = (int)value;
@@ -2094,6 +2103,18 @@ int pk_shard_pack_dev(pk_filter* f, const int64_t* ranges, int32_t world, int32_
   return PK_OK;
 }
 
+int pk_shard_pack_slots_dev(pk_filter* f, int64_t j0, int64_t j1, int64_t slot_lo, int64_t slot_hi, void* dev_buf) {
+  if (!f || j0 < 0 || j1 < j0 || j1 > f->d.P || slot_hi < slot_lo) return fail(PK_ERR_INVALID, "pk_shard_pack_slots_dev: bad argument");
+  if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_pack_slots_dev: call pk_shard_plan_dev first");
+  if (j1 > j0 && !dev_buf) return fail(PK_ERR_INVALID, "pk_shard_pack_slots_dev: NULL buffer");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  Span t(f, PK_T_RESAMPLE);
+  launch_pack_range(f->stream, f->d, f->hi_dev, j0, j1 - j0, slot_lo, slot_hi, static_cast<unsigned char*>(dev_buf));
+  PK_LAUNCH_CHECK("pk_shard_pack_slots_dev");
+  return PK_OK;
+}
+
 int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
   if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: call pk_shard_plan_dev first");
@@ -2129,7 +2150,9 @@ int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
     if ((rc = materialise(f))) return rc;
   }
   Span t(f, PK_T_RESAMPLE);
-  launch_adopt_dev(f->stream, f->d, f->hi_dev, (int64_t)rank * f->d.P, nullptr, 0, nullptr, 1);
+  const int64_t base = (int64_t)rank * f->d.P;
+  launch_adopt_dev(f->stream, f->d, f->hi_dev, base, nullptr, 0, nullptr, 1, f->loop_lo == INT64_MIN ? INT64_MIN : base + f->loop_lo,
+                   f->loop_hi == INT64_MAX ? INT64_MAX : base + f->loop_hi);
   f->src_identity = false;
   f->gmax_fused = false;
   f->adopt_local_done = true;
@@ -2153,8 +2176,11 @@ int pk_shard_adopt_remote_dev(pk_filter* f, int32_t rank, const void* dev_recv, 
     f->rlohi_cap = n_received + n_received / 4;
   }
   Span t(f, PK_T_RESAMPLE);
-  launch_adopt_dev(f->stream, f->d, f->hi_dev, (int64_t)rank * f->d.P, static_cast<const unsigned char*>(dev_recv), n_received,
-                   f->rlohi_dev, 2);
+  const int64_t base = (int64_t)rank * f->d.P;
+  launch_adopt_dev(f->stream, f->d, f->hi_dev, base, static_cast<const unsigned char*>(dev_recv), n_received, f->rlohi_dev, 2,
+                   f->loop_lo == INT64_MIN ? INT64_MIN : base + f->loop_lo, f->loop_hi == INT64_MAX ? INT64_MAX : base + f->loop_hi);
+  f->loop_lo = INT64_MIN;
+  f->loop_hi = INT64_MAX;
   return PK_OK;
 }
 

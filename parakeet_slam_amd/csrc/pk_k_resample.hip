@@ -532,12 +532,15 @@ __global__ void __launch_bounds__(256) k_adopt_dev(const double* __restrict__ x,
                                                    double* __restrict__ lw2, int32_t* __restrict__ src2,
                                                    const int64_t* __restrict__ hi, int64_t slot_start,
                                                    const unsigned char* __restrict__ buf, size_t stride,
-                                                   const int64_t* __restrict__ rlohi, int64_t n_recv, int64_t P, int mode) {
+                                                   const int64_t* __restrict__ rlohi, int64_t n_recv, int64_t P, int mode,
+                                                   int64_t span_lo, int64_t span_hi) {
   // mode 0: every slot; 1: only the slots filled by this shard's own particles; 2: only those filled by received records
+  // [span_lo, span_hi): the "split_loopback" debug option narrows what counts as filled locally, so that the slots at either
+  // end are filled from records of this shard's OWN particles that went through the exchange (one-rank RCCL tests)
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   const int64_t K = slot_start + k;
-  const bool local = K >= hi[0] && K < hi[P];
+  const bool local = K >= hi[0] && K < hi[P] && K >= span_lo && K < span_hi;
   if ((mode == 1 && !local) || (mode == 2 && local)) return;
   if (local) {
     int64_t lo = 0, up = P - 1;  // first j with hi[j + 1] > K
@@ -571,7 +574,7 @@ __global__ void __launch_bounds__(256) k_adopt_dev(const double* __restrict__ x,
   }
 }
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
-                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode) {
+                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode, int64_t span_lo, int64_t span_hi) {
   if (d.P == 0) return;
   // mode 2 (the received part of a split adoption) writes into the generation mode 1 has already made current
   const int n = mode == 2 ? d.cur : d.cur ^ 1, c = n ^ 1;
@@ -581,7 +584,7 @@ void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int6
                        rlohi_dev);
   hipLaunchKernelGGL(k_adopt_dev, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c],
                      d.logw[c], d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], hi_dev, slot_start, buf_dev,
-                     stride, rlohi_dev, n_recv, d.P, mode);
+                     stride, rlohi_dev, n_recv, d.P, mode, span_lo, span_hi);
   d.cur = n;
   if (mode != 1) {
     d.alt = n_recv > 0 ? buf_dev : nullptr;

@@ -258,10 +258,12 @@ __device__ __forceinline__ void pub_rotate(PubSlotsT<SL>& q) {  // slot 0 goes t
 #pragma unroll
   for (int k = 0; k + 1 < SL; ++k) q.s[k] = q.s[k + 1];
   q.s[SL - 1] = w;
-  if constexpr (SL == 8)
+  if constexpr (SL == 8) {
     q.st = (q.st >> 4) | (q.st << 28);
-  else
-    q.st = ((q.st >> 4) | (q.st << (4 * SL - 4))) & ((1u << (4 * SL)) - 1u);
+  } else {  // (the bits above the slots' stay where they are: pub_gatesN<OVF> keeps the landmark's pass mask there)
+    const unsigned lowmask = (1u << (4 * SL)) - 1u;
+    q.st = (((q.st >> 4) | (q.st << (4 * SL - 4))) & lowmask) | (q.st & ~lowmask);
+  }
 }
 
 __device__ __forceinline__ double pub_inf() { return __longlong_as_double(0x7FF0000000000000ll); }
@@ -278,13 +280,12 @@ struct PubGateIn {
   bool has;
 };
 // N: landmarks worked on side by side; W4: uint4 words per list (1: eight candidates, 2: sixteen)
-// OVF: a landmark may pass MORE blobs than it has slots without the particle being flagged: pmask_out says which of its
-// candidates passed, and pub_keysN looks at the ones the slots no longer hold (round 4: what flagged up to 13 % of the
+// OVF: a landmark may pass MORE blobs than it has slots without the particle being flagged: bits 16.. of its slots' state word
+// say which of its candidates passed, and pub_refill_slots brings in the ones the slots no longer hold (round 4: what flagged up to 13 % of the
 // particles on some stretches of the bench's trajectory and sent them through the second-chance kernels).
 template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false>
 __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
-                                           double* pub, unsigned dump, int* flag, double sx, double sy, double sh,
-                                           unsigned (*pmask_out)[N] = nullptr) {
+                                           double* pub, unsigned dump, int* flag, double sx, double sy, double sh) {
   constexpr int NW = 4 * W4;  // 32-bit words per list, two candidates each
   double eb[N];
   bool inside[N];
@@ -378,13 +379,12 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
   for (int j = 0; j < N; ++j) {
     if constexpr (OVF) {
       if (in[j].has && !inside[j]) *flag = 1;
-      (*pmask_out)[j] = pmask[j];
     } else {
       if (in[j].has && (!inside[j] || npass[j] > SL)) *flag = 1;
     }
 #pragma unroll
     for (int k = 0; k < SL; ++k) q[j].s[k] = sl[j][k];
-    q[j].st = 0u;
+    q[j].st = OVF ? (pmask[j] << 16) : 0u;  // (OVF: the pass mask rides above the slots' state bits until pub_refill_slots)
   }
 }
 
@@ -422,13 +422,10 @@ __device__ __forceinline__ double pub_log(double x) {
   const double lm = 2.0 * s + 2.0 * s * (z * p);  // 2 atanh(s); the series' remainder: 2 s z^8 / 17 < 3e-14
   return (double)e * 0.69314718055994530942 + lm;
 }
-// pmask / cand_row / erec_row (OVF instances, see pub_gatesN): the candidates that passed the gates, and where the landmarks'
-// list words can be read again.
 template <int N, int SL = kPubSlots>
 __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
-                                          unsigned anydump, int* flag, double sx, double sy, const unsigned (*pmask)[N] = nullptr,
-                                          const uint4* cand_row = nullptr, const uint4* erec_row = nullptr) {
+                                          unsigned anydump, int* flag, double sx, double sy) {
   {
     unsigned sall = q[0].s[0];
 #pragma unroll
@@ -469,15 +466,6 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
                                        lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
                      : 0.0;
   }
-  // Landmarks that passed MORE blobs than they have slots (OVF instances; a few landmarks of some particles, at some poses):
-  // the slots hold the last SL blobs that passed, the others are worked on in a SECOND turn of the same rounds -- one copy of
-  // the code, no register beyond the first turn's -- after they have taken the places of slots whose blob turned out to have
-  // probability 0 (a look-alike's, beyond the underflow edge once the landmark's colour block has tightened: nearly always all
-  // but one).  A lane whose landmark has no such case repeats its rounds on the same slots and publishes the same values.  If
-  // the blobs left over outnumber the free slots the particle goes to the fall-back kernels, as it did for any fifth blob
-  // before round 4.
-#pragma unroll 1
-  for (int turn = 0;; ++turn) {
   int done = 0;
 #pragma unroll 1
   for (; done < SL; ++done) {
@@ -568,40 +556,55 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
 #pragma unroll
     for (int j = 0; j < N; ++j) pub_rotate(q[j]);
   }
-  if constexpr (SL != kPubSlots) break;
-  if (pmask == nullptr || turn == 1) break;
-  {
-    bool anyovf = false;
+  if (weird) *flag = 1;
+}
+
+// Landmarks that passed MORE blobs than they have slots (pub_gatesN<OVF>; a few landmarks of some particles, at some poses).
+// The slots hold the last kPubSlots blobs that passed and pub_keysN has given those their verdicts; the blobs the slots no
+// longer hold take the places of slots whose blob turned out to have probability 0 (a look-alike's, beyond the underflow edge
+// once the landmark's colour block has tightened: nearly always all but one), and the caller runs pub_keysN ONCE MORE on the
+// refilled slots -- the same code in a loop, so the usual case pays nothing for this and no register is held for it; a slot
+// that keeps its blob publishes the same values again.  Blobs left over when the free slots run out: the particle goes to the
+// fall-back kernels, as it did for any fifth blob before round 4.  Returns false when no lane of the wave has such a landmark
+// (wave-uniform).
+template <int N>
+__device__ __forceinline__ bool pub_refill_slots(PubSlots (&q)[N], const uint4* cand_row, const uint4* erec_row, int* flag) {
+  bool anyovf = false;
 #pragma unroll
-    for (int j = 0; j < N; ++j) anyovf |= __popc((*pmask)[j]) > SL;
-    if (__ballot(anyovf) == 0ull) break;  // wave-uniform: the usual case
-  }
+  for (int j = 0; j < N; ++j) anyovf |= __popc(q[j].st >> 16) > kPubSlots;
+  if (__ballot(anyovf) == 0ull) return false;  // wave-uniform: the usual case
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    const bool ovf = __popc((*pmask)[j]) > SL;
+    const unsigned pmask = q[j].st >> 16;
+    const bool ovf = __popc(pmask) > kPubSlots;
     if (__ballot(ovf) == 0ull) continue;  // wave-uniform
-    const uint4 cw4 = cand_row[2 * j + 1], ew4 = erec_row[j];  // this landmark's list words once more (L2)
-    const unsigned cw[4] = {cw4.x, cw4.y, cw4.z, cw4.w}, ew[4] = {ew4.x, ew4.y, ew4.z, ew4.w};
+    // this landmark's list words once more (L2), one word -- two candidates -- at a time
+    const unsigned* cwp = reinterpret_cast<const unsigned*>(cand_row + 2 * j + 1);
+    const unsigned* ewp = reinterpret_cast<const unsigned*>(erec_row + j);
     const unsigned id0 = q[j].s[0] & 0xFFFFu, id1 = q[j].s[1] & 0xFFFFu, id2 = q[j].s[2] & 0xFFFFu, id3 = q[j].s[3] & 0xFFFFu;
     unsigned open = ~q[j].st & 0x1111u;  // slots whose blob has probability 0: its verdict is out, the place is free
+#pragma unroll 1
+    for (int w = 0; w < kCandSlots / 2; ++w) {
+      const unsigned cw = cwp[w], ew = ewp[w];
 #pragma unroll
-    for (int k = 0; k < kCandSlots; ++k) {
-      const unsigned t = (cw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, e = (ew[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-      const bool extra = ovf && (((*pmask)[j] >> k) & 1u) != 0u && t != id0 && t != id1 && t != id2 && t != id3;
-      if (extra && open == 0u) *flag = 1;
-      const unsigned w = t | (e << 16);
-      bool placed = !extra;
+      for (int half = 0; half < 2; ++half) {
+        const unsigned t = (cw >> (16 * half)) & 0xFFFFu, e = (ew >> (16 * half)) & 0xFFFFu;
+        const bool extra = ovf && ((pmask >> (2 * w + half)) & 1u) != 0u && t != id0 && t != id1 && t != id2 && t != id3;
+        if (extra && open == 0u) *flag = 1;
+        const unsigned word = t | (e << 16);
+        bool placed = !extra;
 #pragma unroll
-      for (int sidx = 0; sidx < SL; ++sidx) {
-        const bool here = !placed && ((open >> (4 * sidx)) & 1u) != 0u;
-        q[j].s[sidx] = here ? w : q[j].s[sidx];
-        open &= here ? ~(1u << (4 * sidx)) : ~0u;
-        placed |= here;
+        for (int sidx = 0; sidx < kPubSlots; ++sidx) {
+          const bool here = !placed && ((open >> (4 * sidx)) & 1u) != 0u;
+          q[j].s[sidx] = here ? word : q[j].s[sidx];
+          open &= here ? ~(1u << (4 * sidx)) : ~0u;
+          placed |= here;
+        }
       }
     }
+    q[j].st &= 0xFFFFu;  // the mask has done its work: a second refill finds nothing
   }
-  }
-  if (weird) *flag = 1;
+  return true;
 }
 
 // Settling, BLOB-parallel: one lane per blob that several landmarks list (a few per lane, their entries one contiguous
@@ -1006,14 +1009,16 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       }                                                                                                                            \
     } else {                                                                                                                       \
       const Landmark<double>* const l2[2] = {&S[2 * (q)], &S[2 * (q) + 1]};                                                        \
-      unsigned pm_[2] = {0u, 0u};                                                                                                  \
-      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, true>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh, &pm_);        \
+      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, true>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);              \
       PK_STAMP(sk0_)                                                                                                               \
       if (PK_PUB_ABLATE < 3) {                                                                                                     \
-        PubArgsPtr R9 = pub_args_now(rp);                                                                                          \
-        const int lc9 = min(l0, Lp);                                                                                               \
-        pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, &pm_, R9->cand + 2 * (size_t)lc9,            \
-                     R9->erec + lc9);                                                                                              \
+        pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                                             \
+        { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */                           \
+          PubArgsPtr R9 = pub_args_now(rp);                                                                                        \
+          const int lc9 = min(l0, Lp);                                                                                             \
+          if (pub_refill_slots<2>(qq, R9->cand + 2 * (size_t)lc9, R9->erec + lc9, &wg_flag[cur]))                                  \
+            pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                                         \
+        }                                                                                                                          \
       }                                                                                                                            \
       PK_STAMP(sk1_)                                                                                                               \
       PK_PSTAMP(2, sk0_, sk1_) /* keys: part of the gates-and-verdicts slot */                                                     \

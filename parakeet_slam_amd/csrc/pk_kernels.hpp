@@ -302,7 +302,7 @@ void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int
 // mode 0: the whole new generation; 1: only the slots this shard's own particles fill (the generation becomes current);
 // 2: only the slots filled by received records (into the generation mode 1 made current)
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
-                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode = 0);
+                      const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode = 0, int64_t span_lo = INT64_MIN, int64_t span_hi = INT64_MAX);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
 // scan block: pinned (device-mapped) host memory -> HBM by a kernel, in stream order
 void launch_upload(hipStream_t s, void* dst_dev, const void* src_host_mapped, size_t bytes);

@@ -299,7 +299,8 @@ class ShardedFilter(object):
     """One shard of a FastSLAM filter: same methods as ``_lib.DeviceFilter`` for what bench.py
     and the tests use, with the resample made global across ranks."""
 
-    def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None, global_scan=None, split_step=None):
+    def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None, global_scan=None, split_step=None,
+                 loopback=None):
         self.comm = comm if comm is not None else TorchComm()
         self.rank, self.world = self.comm.rank, self.comm.world
         self.P = int(particles_per_rank)
@@ -325,6 +326,12 @@ class ShardedFilter(object):
         self._all_ranges = f.new_i64(self._row * self.world)
         self.split_step = (self.world > 1) if split_step is None else bool(split_step)
         self.split_steps_done = 0
+        # debug (one-rank tests): (n_front, n_back) -- the split step treats that many slots at either end of the shard as
+        # "remote": the particles that fill them are packed, sent through the asynchronous all-to-all TO THIS RANK ITSELF and
+        # adopted from the received records, so pack -> all_to_all_single(async_op) -> wait -> adopt_remote runs with records
+        # that really travelled even where only one device exists
+        self.loopback = tuple(int(v) for v in loopback) if loopback is not None else None
+        self.loopback_records = 0
         self._sums = f.new_f64(4)
         self._recv_keepalive = None
         self._pending = None  # a resample whose exchange has been planned on the GPU but not carried out yet
@@ -510,6 +517,26 @@ class ShardedFilter(object):
                 if n_send:
                     f.pack_into(allr[R].reshape(-1), W, R, send)  # from the OLD generation: before the adoption below
                 recv, work = comm.all_to_all_records_async(send, send_counts, recv_counts, f.particle_bytes())
+            elif W == 1 and self.loopback is not None and sum(self.loopback) > 0:
+                # one rank, slots [0, n_front) and [P - n_back, P) through the exchange (see __init__)
+                nf, nb = self.loopback
+                lo_s, hi_s = min(nf, self.P), max(self.P - nb, min(nf, self.P))
+                hi = np.maximum.accumulate(f.shard_download_offspring())
+                jf0, jf1 = int(np.searchsorted(hi[1:], 0, side="right")), int(np.searchsorted(hi[:-1], lo_s, side="left"))
+                jb0, jb1 = int(np.searchsorted(hi[1:], hi_s, side="right")), int(np.searchsorted(hi[:-1], self.P, side="left"))
+                jf1, jb1 = max(jf1, jf0), max(jb1, jb0)
+                n_recv = (jf1 - jf0) + (jb1 - jb0)
+                send = f.alloc_records(n_recv)
+                stride = f.particle_bytes()
+                if jf1 > jf0:
+                    f.shard_pack_slots_dev(jf0, jf1, 0, lo_s, send.data_ptr())
+                if jb1 > jb0:
+                    f.shard_pack_slots_dev(jb0, jb1, hi_s, self.P, send.data_ptr() + (jf1 - jf0) * stride)
+                recv, work = comm.all_to_all_records_async(send, [n_recv], [n_recv], stride)
+                f.set_option("split_loopback_lo", lo_s)
+                f.set_option("split_loopback_hi", hi_s)
+                a, b = lo_s, hi_s
+                self.loopback_records += n_recv
             f.adopt_local(R)
             if recv is None:  # nobody changes rank this time: every slot is filled locally, one launch over all of them
                 f.adopt_remote(R, None, 0)

@@ -346,7 +346,7 @@ def crowded_landmark_scene(L, rs, n_lookalike, n_sightings, tight=True):
     return means, covs, blobs
 
 
-@pytest.mark.parametrize("L,n_lookalike,n_sightings", [(1500, 4, 1), (2000, 5, 2), (1024, 3, 3), (2000, 6, 2), (700, 2, 4)])
+@pytest.mark.parametrize("L,n_lookalike,n_sightings", [(1500, 4, 1), (1800, 5, 2), (1024, 3, 3), (1600, 6, 2), (700, 2, 4)])
 def test_a_landmark_that_passes_more_blobs_than_it_has_slots_is_settled_in_the_kernel(lib, L, n_lookalike, n_sightings):
     """Round 4: five to eight blobs inside a landmark's gates no longer send the particle to the second-chance kernels as long
     as at most four of them have a positive probability (match_one's argmax ignores the others, prkt_core_v2.py:369-379): the

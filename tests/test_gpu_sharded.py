@@ -149,6 +149,26 @@ def _nccl_single(q):
         assert np.array_equal(s1.download_poses(), p1.download_poses())
         for xa, xb in zip(s1.download_landmarks(), p1.download_landmarks()):
             assert np.array_equal(xa, xb)
+        # ... and with records that REALLY travel (round 4, "loopback"): the slots at either end of the shard are declared remote,
+        # the particles that fill them are packed, sent through all_to_all_single(async_op=True) over RCCL to this rank itself,
+        # waited for on the stream and adopted from the received buffer (pk_shard_adopt_remote_dev) while the motion + observe of
+        # the slots in between already run -- the exchange branch of _complete_and_step_split, which a world of one never takes
+        # otherwise.  Bit-identical to the plain filter.
+        for nf, nb, Pl in ((200, 130, 1500), (0, 257, 1500), (1024, 1024, 2048), (1, 0, 1500)):
+            sl = ShardedFilter(Pl, Ls, device=0, comm=comm, split_step=True, loopback=(nf, nb))
+            sl.upload_map(ms, cs.reshape(Ls, 25))
+            pl = _lib_mod.DeviceFilter(Pl, Ls)
+            pl.upload_map(ms, cs.reshape(Ls, 25))
+            for st in range(3):
+                sl.step(_V, _W, 0.1, scs[st], 0.37 + 0.2 * st, seed=4, draw=st, domain=1)
+                pl.step(_V, _W, 0.1, scs[st], 0.37 + 0.2 * st, seed=4, draw=st, domain=1)
+            assert sl.split_steps_done == 2 and sl.loopback_records >= 2 * max(1, (nf > 0) + (nb > 0)), (sl.split_steps_done, sl.loopback_records)
+            assert np.array_equal(sl.download_poses(), pl.download_poses()), ("loopback poses", nf, nb)
+            for xa, xb in zip(sl.download_landmarks(), pl.download_landmarks()):
+                assert np.array_equal(xa, xb), ("loopback maps", nf, nb)
+            assert np.allclose(sl.summary(), pl.summary(), rtol=1e-13, atol=1e-14)
+            sl.close()
+            pl.close()
         # the global-scan plan (shards that end inside a scan block; bench.py's 100 000 particles per rank) through the same
         # communicator: ancestors against the plain filter on the same weights
         from parakeet_slam_amd import _lib
