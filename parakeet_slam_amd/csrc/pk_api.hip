@@ -533,10 +533,16 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
   *n9_out = n9;
 }
 
-int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true) {
-  const int64_t need_l = lists ? f->d.P * (int64_t)f->d.lay.Lp * (slots == kSweepSlots ? 2 : 1) : 0;
-  const int64_t need_b = lists ? f->d.P * (int64_t)std::max(B, 1) : 0;
+// rows: particles the lists have room for -- all of them (the hand-off routes), or the capped number of second-chance rows
+// (ADVICE round 2 / VERDICT round 3: the second chance used to allocate lists for ALL P particles with the route, 6.4 GB at
+// 100 000 x 2 000, for the few percent a scan flags at worst)
+int64_t retry_rows(const pk_filter* f) { return std::min<int64_t>(f->d.P, std::max<int64_t>(1024, f->d.P / 16)); }
+int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true, bool retry_only = false) {
+  const int64_t rows = retry_only ? retry_rows(f) : f->d.P;
+  const int64_t need_l = lists ? rows * (int64_t)f->d.lay.Lp * (slots == kSweepSlots ? 2 : 1) : 0;
+  const int64_t need_b = lists ? rows * (int64_t)std::max(B, 1) : 0;
   int rc;
+  if (retry_only && !f->fh.row_of && (rc = dev_alloc(f, &f->fh.row_of, (size_t)f->d.P))) return rc;
   if (need_l > f->fh_cap_l) {
     PK_HIP(hipStreamSynchronize(f->stream));
     if (f->fh.lmpass) (void)hipFree(f->fh.lmpass);
@@ -565,6 +571,8 @@ inline unsigned* ctl_n_stray(pk_filter* f) { return reinterpret_cast<unsigned*>(
 inline unsigned* ctl_skip_pub(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 12); }
 // != 0 -> the candidate-list instance of k_step_regs stands back (k_step_pub runs, or the grid walk does)
 inline unsigned* ctl_skip_cand(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 16); }
+// rows of the second-chance hand-off lists dealt out so far (FastHandoff::row_next)
+inline unsigned* ctl_retry_rows(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 20); }
 
 // Host half of the ML scan upload: blobs, ray directions, exact records and the association tables
 // are laid out in a pinned staging slot (no device work; may synchronise only to grow buffers).
@@ -670,7 +678,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       // the flags, and -- when the two-sweep kernel can take this scan -- eight-slot hand-off lists for the second chance of
       // the particles k_step_regs flags (allocated here, not at the first flagged particle in the middle of a run)
       out->retry = f->regs_retry && observe_sweep_plan(f->d, B).grid > 0;
-      if ((rc = ensure_handoff(f, B, out->retry ? kSweepSlots : kFastSlots, out->retry))) return rc;
+      if ((rc = ensure_handoff(f, B, out->retry ? kSweepSlots : kFastSlots, out->retry, true))) return rc;
       out->regs = true;
       out->grid = g;
       out->n9 = n9;
@@ -685,7 +693,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       // maps beyond the register route: publish / subscribe in two passes (k_step_pub_big); what it flags -- or the whole scan,
       // when a sixteen-entry list overflows or the publish table does not fit LDS -- goes through the eight-slot hand-off
       // and k_observe_sweep, then the general kernels
-      if ((rc = ensure_handoff(f, B, kSweepSlots, true))) return rc;
+      if ((rc = ensure_handoff(f, B, kSweepSlots, true, true))) return rc;
       out->big = true;
       out->retry = true;
       out->grid = g;
@@ -951,7 +959,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1415,6 +1423,8 @@ static int onepass_finish(pk_filter* f, const AssocLaunch& al, int B, const Obse
     fr.slots = kSweepSlots;
     fr.retry = true;
     fr.n_flagged = ctl_n_flagged(f);
+    fr.row_next = ctl_retry_rows(f);
+    fr.row_cap = retry_rows(f);
     launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fr, cand);
     ObserveExtras e3 = ex;
     e3.flip = false;

@@ -169,6 +169,9 @@ struct AssocGridArgs {
   const unsigned* cand_over;
   int cand_slots;  // kCandSlots (records of two uint4) or 2 kCandSlots (three)
   int retry;       // hand-off instance: only the particles whose flag is 1; leaves 2 (handed off) or 1 (general kernels)
+  int32_t* row_of;     // retry: hand-off row of each particle (FastHandoff)
+  unsigned* row_next;  //        rows dealt out so far
+  int64_t row_cap;     //        rows there are
 };
 
 // tables: start u16[ncell+1] (16-byte padded) | rec32 float4[B] | idx9 u16[n9] (DUP only) | order u16[B]
@@ -203,6 +206,7 @@ template <int THREADS, bool DUP, bool GENERAL, int SLOTS>
 __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int n_few, n_many, wg_flag;
+  __shared__ long long s_row;
   __shared__ unsigned long long s3_best[THREADS / 4];
   __shared__ int s3_win[THREADS / 4];
   const AssocArgs& a = ga.a;
@@ -231,6 +235,15 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
   for (int64_t p = blockIdx.x; p < ga.P; p += gridDim.x) {
     if (GENERAL && ga.only_flagged && ga.only_flagged[p] != 1) continue;  // workgroup-uniform
     if (!GENERAL && ga.retry && ga.pflag[p] != 1) continue;
+    int64_t row = p;  // where this particle's hand-off entries go
+    if (!GENERAL && ga.retry) {  // second chance: the next free row, if there is one (workgroup-uniform)
+      __syncthreads();
+      if (threadIdx.x == 0) s_row = (long long)atomicAdd(ga.row_next, 1u);
+      __syncthreads();
+      row = s_row;
+      if (row >= ga.row_cap) continue;  // none left: the flag stays 1, the general kernels take the particle
+      if (threadIdx.x == 0) ga.row_of[p] = (int32_t)row;
+    }
     const unsigned char* slot = a.ss.at(a.src[p]);
     const double* f = reinterpret_cast<const double*>(slot);
     const double sx = a.x[p], sy = a.y[p], sh = a.h[p];
@@ -459,9 +472,9 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
       if (!GENERAL) {
         const unsigned long long pb = (unsigned long long)__double_as_longlong(pse);
         if (SLOTS == 4) {
-          ga.lmpass[(size_t)p * a.Lp + l] = make_uint4(pass[0], pass[1], (unsigned)pb, (unsigned)(pb >> 32));
+          ga.lmpass[(size_t)row * a.Lp + l] = make_uint4(pass[0], pass[1], (unsigned)pb, (unsigned)(pb >> 32));
         } else {
-          uint4* e = ga.lmpass + 2 * ((size_t)p * a.Lp + l);
+          uint4* e = ga.lmpass + 2 * ((size_t)row * a.Lp + l);
           e[0] = make_uint4(pass[0], pass[1], pass[SLOTS / 2 - 2], pass[SLOTS / 2 - 1]);
           e[1] = make_uint4((unsigned)pb, (unsigned)(pb >> 32), 0u, 0u);
         }
@@ -476,7 +489,7 @@ __global__ void __launch_bounds__(THREADS) k_assoc_grid(AssocGridArgs ga) {
     if (!GENERAL) {
       for (int t = threadIdx.x; t < B; t += THREADS) {
         const int n = ccount[t];
-        ga.bcount[(size_t)p * B + t] = (unsigned char)(n > 255 ? 255 : n);
+        ga.bcount[(size_t)row * B + t] = (unsigned char)(n > 255 ? 255 : n);
       }
       if (threadIdx.x == 0) {
         if (ga.retry) {  // (already counted by the kernel that flagged it)
@@ -652,6 +665,9 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
   ga.cand_over = cand.rec ? cand.over : nullptr;
   ga.cand_slots = cand.slots;
   ga.retry = fh.retry ? 1 : 0;
+  ga.row_of = fh.row_of;
+  ga.row_next = fh.row_next;
+  ga.row_cap = fh.row_cap;
   auto go = [&](auto general, auto slots) {
     constexpr bool G = decltype(general)::value;
     constexpr int S = decltype(slots)::value;

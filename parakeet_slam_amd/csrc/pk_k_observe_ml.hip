@@ -809,6 +809,7 @@ struct SweepArgs {
   Noise<double> qt;
   int only_value;               // 0: the particles whose flag is 0; else only the particles with this flag (second chance, 2)
   const unsigned* n_flagged;    // with only_value: nothing to do when 0
+  const int32_t* row_of;        // with only_value: the particle's hand-off row (FastHandoff::row_of)
 };
 
 __host__ __device__ inline size_t sweep_lds_bytes(int B, int qcap) {
@@ -870,7 +871,8 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
     const int* sc = reinterpret_cast<const int*>(sslot + a.count_off);
     int* dc = reinterpret_cast<int*>(dslot + a.count_off);
     const double sx = a.x[p], sy = a.y[p];
-    const uint4* lmp = a.lmpass + (SLOTS == 4 ? 1 : 2) * (size_t)p * Lp;  // entries as written by k_assoc_grid
+    const int64_t row = a.only_value ? (int64_t)a.row_of[p] : p;  // (second chance: the row k_assoc_grid dealt this particle)
+    const uint4* lmp = a.lmpass + (SLOTS == 4 ? 1 : 2) * (size_t)row * Lp;  // entries as written by k_assoc_grid
     // blob fields of landmark l (unused words all ones) and its atan2(my - sy, mx - sx)
     auto entry_blobs = [&](int l) {
       if (SLOTS == 4) {
@@ -887,7 +889,7 @@ __global__ void __launch_bounds__(kSweepThreads, 3) k_observe_sweep(SweepArgs a)
     for (int t = tid; t < B; t += kSweepThreads) {
       best[t] = 0ull;
       win[t] = INT_MAX;
-      bc[t] = a.bcount[(size_t)p * B + t];
+      bc[t] = a.bcount[(size_t)row * B + t];
     }
     if (tid < 3) q_n[tid] = 0;
     __syncthreads();
@@ -1122,6 +1124,7 @@ void launch_observe_sweep(hipStream_t s, DeviceState& d, int B, const double* ex
   a.lmpass = fh.lmpass;
   a.bcount = fh.bcount;
   a.pflag = fh.pflag;
+  a.row_of = fh.row_of;
   a.immutable = d.immutable;
   a.results = results_dev;
   a.P = d.P;

@@ -45,6 +45,9 @@ namespace pk {
 #ifndef PK_PUB_ABLATE
 #define PK_PUB_ABLATE 0
 #endif
+#ifndef PK_PUB_OVF  // 1: landmarks that pass more blobs than they have slots are settled in the kernel (round 4); 0: the particle is flagged
+#define PK_PUB_OVF 1
+#endif
 #ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
 #define PK_PUB_ILV 0
 #endif
@@ -261,8 +264,8 @@ __device__ __forceinline__ void pub_rotate(PubSlotsT<SL>& q) {  // slot 0 goes t
   if constexpr (SL == 8) {
     q.st = (q.st >> 4) | (q.st << 28);
   } else {  // (the bits above the slots' stay where they are: pub_gatesN<OVF> keeps the landmark's pass mask there)
-    const unsigned lowmask = (1u << (4 * SL)) - 1u;
-    q.st = (((q.st >> 4) | (q.st << (4 * SL - 4))) & lowmask) | (q.st & ~lowmask);
+    const unsigned lowmask = (1u << (4 * SL)) - 1u, low = q.st & lowmask;
+    q.st = (((low >> 4) | (low << (4 * SL - 4))) & lowmask) | (q.st & ~lowmask);
   }
 }
 
@@ -1009,11 +1012,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       }                                                                                                                            \
     } else {                                                                                                                       \
       const Landmark<double>* const l2[2] = {&S[2 * (q)], &S[2 * (q) + 1]};                                                        \
-      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, true>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);              \
+      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, PK_PUB_OVF != 0>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);   \
       PK_STAMP(sk0_)                                                                                                               \
       if (PK_PUB_ABLATE < 3) {                                                                                                     \
         pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                                             \
-        { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */                           \
+        if constexpr (PK_PUB_OVF != 0) { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */ \
           PubArgsPtr R9 = pub_args_now(rp);                                                                                        \
           const int lc9 = min(l0, Lp);                                                                                             \
           if (pub_refill_slots<2>(qq, R9->cand + 2 * (size_t)lc9, R9->erec + lc9, &wg_flag[cur]))                                  \

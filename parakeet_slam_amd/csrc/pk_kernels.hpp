@@ -111,12 +111,19 @@ inline int device_cu_count() {
 }
 // Hand-off from the association kernel to k_observe_fast (all three NULL = not used).
 struct FastHandoff {
-  uint4* lmpass = nullptr;          // [P][Lp] (slots = 4) or [P][Lp][2] (slots = 8): see k_assoc_grid
+  uint4* lmpass = nullptr;          // [rows][Lp] (slots = 4) or [rows][Lp][2] (slots = 8): see k_assoc_grid; rows = P, or with
+                                    // `retry` the capped number of second-chance rows (row_of / row_next / row_cap below)
   int slots = 4;                    // gate-passing blobs a landmark can hand over: kFastSlots or kSweepSlots
   bool flags_only = false;          // pflag / n_flagged come from k_step_fused: run the general instance on the flagged only
   unsigned char* bcount = nullptr;  // [P][B]
   unsigned char* pflag = nullptr;   // [P] 0: done by the fast kernel, 1: for the general kernels, 2: handed off on the second chance
   unsigned* n_flagged = nullptr;    // number of flagged particles of this scan
+  // second chance only: the hand-off rows are dealt out in order of arrival, row_cap of them (a fraction of P: what a scan
+  // flags is a few percent at worst) -- row_of[p] = the row of particle p, *row_next = rows dealt so far (zeroed by the scan
+  // upload); a particle that finds none left keeps flag 1 and goes to the general kernels
+  int32_t* row_of = nullptr;
+  unsigned* row_next = nullptr;
+  int64_t row_cap = 0;
   // Second chance for the particles a one-pass kernel flagged (a landmark passing more than its four register slots): the
   // hand-off instance with eight slots works on the particles whose flag is 1 only and leaves 2 where it succeeded (for
   // k_observe_sweep, ObserveExtras::sweep_only_value) and 1 where not even eight slots do (general kernels).
