@@ -346,8 +346,11 @@ def crowded_landmark_scene(L, rs, n_lookalike, n_sightings, tight=True):
     return means, covs, blobs
 
 
-@pytest.mark.parametrize("L,n_lookalike,n_sightings", [(1500, 4, 1), (1800, 5, 2), (1024, 3, 3), (1600, 6, 2), (700, 2, 4)])
-def test_a_landmark_that_passes_more_blobs_than_it_has_slots_is_settled_in_the_kernel(lib, L, n_lookalike, n_sightings):
+# (the blobs left over -- n_lookalike + n_sightings - 4 -- must find room in the slots that the first turn frees, at least
+# 4 - n_sightings: the last case has one too many, and the particles go to the fall-back kernels as before)
+@pytest.mark.parametrize("L,n_lookalike,n_sightings,settled", [(1500, 4, 1, True), (1800, 5, 1, True), (1024, 3, 2, True), (1600, 6, 1, True),
+                                                               (700, 2, 3, True), (1800, 5, 2, False)])
+def test_a_landmark_that_passes_more_blobs_than_it_has_slots_is_settled_in_the_kernel(lib, L, n_lookalike, n_sightings, settled):
     """Round 4: five to eight blobs inside a landmark's gates no longer send the particle to the second-chance kernels as long
     as at most four of them have a positive probability (match_one's argmax ignores the others, prkt_core_v2.py:369-379): the
     blobs the four slots no longer hold get their verdicts in a second turn of the key rounds."""
@@ -359,7 +362,7 @@ def test_a_landmark_that_passes_more_blobs_than_it_has_slots_is_settled_in_the_k
     gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
     assert pub["published"] and pub["route"] == "ml_regs"
     assert regs["flagged"] == 4  # landmark 40 passes n_lookalike + n_sightings > 4 blobs: k_step_regs hands every particle on
-    assert pub["flagged"] == 0   # ... k_step_pub settles them itself
+    assert pub["flagged"] == (0 if settled else 4)   # ... k_step_pub settles them itself
     assert ((gen["ids"] == 41).sum(axis=1) == n_sightings).all()
     same_state(pub, regs)
     same_state(pub, gen, 1e-11)
