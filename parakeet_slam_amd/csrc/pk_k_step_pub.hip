@@ -48,6 +48,35 @@ namespace pk {
 #ifndef PK_PUB_OVF  // 1: landmarks that pass more blobs than they have slots are settled in the kernel (round 4); 0: the particle is flagged
 #define PK_PUB_OVF 1
 #endif
+// Diagnostic builds only: PK_PUB_PAD_<phase> = n extra float64 instructions per lane in one phase of k_step_pub<2, 512> (G0 / K0:
+// gates / keys of the first pair, G1 / K1: of the second, U0 / U1: in front of the first / second pair's updates) -- which
+// phases are on the critical path of a particle?  (an instruction added to a phase that waits for memory costs nothing)
+#ifndef PK_PUB_PAD_G0
+#define PK_PUB_PAD_G0 0
+#endif
+#ifndef PK_PUB_PAD_K0
+#define PK_PUB_PAD_K0 0
+#endif
+#ifndef PK_PUB_PAD_G1
+#define PK_PUB_PAD_G1 0
+#endif
+#ifndef PK_PUB_PAD_K1
+#define PK_PUB_PAD_K1 0
+#endif
+#ifndef PK_PUB_PAD_U0
+#define PK_PUB_PAD_U0 0
+#endif
+#ifndef PK_PUB_PAD_U1
+#define PK_PUB_PAD_U1 0
+#endif
+template <int NPAD>
+__device__ __forceinline__ void pub_pad() {
+  if constexpr (NPAD > 0) {
+    double a = 1.0, b = 2.0;
+#pragma unroll
+    for (int i = 0; i < NPAD / 2; ++i) asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1" : "+v"(a), "+v"(b));
+  }
+}
 #ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
 #define PK_PUB_ILV 0
 #endif
@@ -1012,8 +1041,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       }                                                                                                                            \
     } else {                                                                                                                       \
       const Landmark<double>* const l2[2] = {&S[2 * (q)], &S[2 * (q) + 1]};                                                        \
+      if ((q) == 0) pub_pad<PK_PUB_PAD_G0>(); else pub_pad<PK_PUB_PAD_G1>();                                                       \
       if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, PK_PUB_OVF != 0>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);   \
       PK_STAMP(sk0_)                                                                                                               \
+      if ((q) == 0) pub_pad<PK_PUB_PAD_K0>(); else pub_pad<PK_PUB_PAD_K1>();                                                       \
       if (PK_PUB_ABLATE < 3) {                                                                                                     \
         pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                                             \
         if constexpr (PK_PUB_OVF != 0) { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */ \
@@ -1204,6 +1235,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         const int l0 = 2 * kPubThreads * q + 2 * tid;
+        if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int i = 2 * q + j;

@@ -348,7 +348,7 @@ def crowded_landmark_scene(L, rs, n_lookalike, n_sightings, tight=True):
 
 # (the blobs left over -- n_lookalike + n_sightings - 4 -- must find room in the slots that the first turn frees, at least
 # 4 - n_sightings: the last case has one too many, and the particles go to the fall-back kernels as before)
-@pytest.mark.parametrize("L,n_lookalike,n_sightings,settled", [(1500, 4, 1, True), (1800, 5, 1, True), (1024, 3, 2, True), (1600, 6, 1, True),
+@pytest.mark.parametrize("L,n_lookalike,n_sightings,settled", [(1500, 4, 1, True), (1800, 5, 1, True), (1024, 3, 2, True), (1300, 4, 2, True),
                                                                (700, 2, 3, True), (1800, 5, 2, False)])
 def test_a_landmark_that_passes_more_blobs_than_it_has_slots_is_settled_in_the_kernel(lib, L, n_lookalike, n_sightings, settled):
     """Round 4: five to eight blobs inside a landmark's gates no longer send the particle to the second-chance kernels as long
