@@ -25,7 +25,7 @@ int pk_upload_landmarks(pk_filter* f, int64_t p0, int64_t p1, const double* mean
 }
 
 #ifdef PK_STAMPS
-namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); void debug_read_fused_stamps(unsigned long long* out, bool reset); void debug_read_regs_stamps(unsigned long long* out, bool reset); void debug_read_pub_stamps(unsigned long long* out, bool reset); }
+namespace pk { void debug_read_stamps(unsigned long long* out, bool reset); void debug_read_fused_stamps(unsigned long long* out, bool reset); void debug_read_regs_stamps(unsigned long long* out, bool reset); void debug_read_pub_stamps(unsigned long long* out, bool reset); void debug_read_pub_wave_stamps(unsigned long long* out, bool reset); }
 #endif
 
 namespace {
@@ -2249,6 +2249,10 @@ int pk_probe(int32_t device, const double pose[3], const double mean[5], const d
 }
 
 #ifdef PK_STAMPS
+__attribute__((visibility("default"))) int pk_debug_pub_wave_stamps(unsigned long long* out, int reset) {
+  pk::debug_read_pub_wave_stamps(out, reset != 0);  // out[8][12]: k_step_pub's sums per wave of the workgroup
+  return PK_OK;
+}
 __attribute__((visibility("default"))) int pk_debug_stamps(unsigned long long* out, int reset) {
   pk::debug_read_stamps(out, reset != 0);            // out[0..15]: k_assoc_grid
   pk::debug_read_fused_stamps(out + 16, reset != 0);  // out[16..31]: k_step_fused

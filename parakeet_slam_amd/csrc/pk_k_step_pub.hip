@@ -655,24 +655,46 @@ __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist,
     const bool on = g < G;
     const unsigned gi = glist[on ? g : 0u];
     const unsigned offs = gi & 0xFFFFu, n = on ? (gi >> 16) : 0u;
+    // (most contested blobs are listed by two or three landmarks: the first four entries in one batch, the rest -- wave-uniform --
+    // only where some lane's blob has more; round 4: the settling read and compared all SLOTS entries of every blob)
+    constexpr int kHead = SLOTS < 4 ? SLOTS : 4;
     double v[SLOTS];
 #pragma unroll
-    for (int r = 0; r < SLOTS; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
+    for (int r = 0; r < kHead; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
     double best = pub_inf();
     unsigned wr = 0u;
 #pragma unroll
-    for (int r = 0; r < SLOTS; ++r) {
+    for (int r = 0; r < kHead; ++r) {
       v[r] = (unsigned)r < n ? v[r] : pub_inf();
       const bool better = v[r] < best;  // strict: on equal keys the earlier rank stays (:377)
       wr = better ? (unsigned)r : wr;
       best = better ? v[r] : best;
     }
+    const bool more = SLOTS > kHead && __ballot(n > (unsigned)kHead) != 0ull;  // wave-uniform
+    if (more) {
+#pragma unroll
+      for (int r = kHead; r < SLOTS; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
+#pragma unroll
+      for (int r = kHead; r < SLOTS; ++r) {
+        v[r] = (unsigned)r < n ? v[r] : pub_inf();
+        const bool better = v[r] < best;
+        wr = better ? (unsigned)r : wr;
+        best = better ? v[r] : best;
+      }
+    }
     int contenders = 0;
     bool close = false;
 #pragma unroll
-    for (int r = 0; r < SLOTS; ++r) {
+    for (int r = 0; r < kHead; ++r) {
       contenders += v[r] < pub_inf() ? 1 : 0;
       close |= v[r] != best && v[r] - best < 1e-7;  // within 1e-7 of the winner without being identical to it
+    }
+    if (more) {
+#pragma unroll
+      for (int r = kHead; r < SLOTS; ++r) {
+        contenders += v[r] < pub_inf() ? 1 : 0;
+        close |= v[r] != best && v[r] - best < 1e-7;
+      }
     }
     doubt |= close || (contenders >= 2 && best > 1350.0);
     if (best < pub_inf()) pub[offs + wr] = pub_marker();
@@ -801,9 +823,18 @@ __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double
 // Diagnostic build only (-DPK_STAMPS): per-phase cycle sums of k_step_pub (slots 48.. of pk_debug_stamps).
 #ifdef PK_STAMPS
 __device__ unsigned long long pk_pstamp_acc[16];
+__device__ unsigned long long pk_pstamp_wave[8][12];  // the same sums per wave of the workgroup (which waves wait at the barriers?)
 // (summed in scalar registers, one atomic per wave and slot at the very end: an atomic per stamp put 2 048 waves in a
 // queue for sixteen addresses and, the vector memory counter being one in-order counter, every row behind them)
 #define PK_PSTAMP(slot, a, b) pst[slot] += (b) - (a);
+void debug_read_pub_wave_stamps(unsigned long long* out, bool reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_pstamp_wave), sizeof(unsigned long long) * 96);
+  if (reset) {
+    unsigned long long z[96] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pk_pstamp_wave), z, sizeof(z));
+  }
+}
 void debug_read_pub_stamps(unsigned long long* out, bool reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_pstamp_acc), sizeof(unsigned long long) * 16);
@@ -1308,7 +1339,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   }
 #ifdef PK_STAMPS
   if ((tid0 & 63) == 0)
-    for (int k = 0; k < 12; ++k) atomicAdd(&pk_pstamp_acc[k], pst[k]);
+    for (int k = 0; k < 12; ++k) {
+      atomicAdd(&pk_pstamp_acc[k], pst[k]);
+      if (THREADS == 512) atomicAdd(&pk_pstamp_wave[tid0 >> 6][k], pst[k]);
+    }
 #endif
 }
 

@@ -30,6 +30,10 @@ buf = (ctypes.c_ulonglong * 64)()
 for s in range(3):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
+wbuf = (ctypes.c_ulonglong * 96)()
+if hasattr(so, "pk_debug_pub_wave_stamps"):
+    so.pk_debug_pub_wave_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    so.pk_debug_pub_wave_stamps(wbuf, 1)
 for s in range(3, 6):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
@@ -43,6 +47,13 @@ if v[48 + 8] > 0:  # k_step_pub ran (512 < L <= 2048, publish table in LDS)
         print("pub %-44s %12.4g  %5.1f%%" % (n, v[48 + i], 100 * v[48 + i] / life))
     print("pub %-44s %12.4g  %5.1f%%" % ("  of the updates: stores + next rows issued", v[48 + 10], 100 * v[48 + 10] / life))
     print("pub cycles per particle and wave: %.0f" % (life / max(v[48 + 9], 1.0)))
+    if hasattr(so, "pk_debug_pub_wave_stamps"):
+        so.pk_debug_pub_wave_stamps(wbuf, 1)
+        w = np.array(list(wbuf), dtype=np.float64).reshape(8, 12)
+        print("per wave of the workgroup, cycles per particle: requests | gates + keys (of which keys) | wait at barrier A | settling | B..C | updates + stores (of which stores + next rows issued)")
+        for i in range(8):
+            n = max(w[i, 9], 1.0)
+            print("  wave %d  %6.0f | %6.0f (%6.0f) | %6.0f | %6.0f | %6.0f | %6.0f (%6.0f)" % (i, w[i, 0] / n, w[i, 1] / n, w[i, 2] / n, w[i, 3] / n, w[i, 4] / n, w[i, 5] / n, w[i, 6] / n, w[i, 10] / n))
     sys.exit(0)
 if v[32 + 14] > 0:  # k_step_regs ran (512 < L <= 2048)
     rn = ["scalars, requests, zeroing", "barrier", "gate arguments (scalar loads)", "gates 1st landmark (waits for means)",
