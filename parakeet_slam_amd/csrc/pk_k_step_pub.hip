@@ -77,6 +77,15 @@ __device__ __forceinline__ void pub_pad() {
     for (int i = 0; i < NPAD / 2; ++i) asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1" : "+v"(a), "+v"(b));
   }
 }
+// Diagnostic / tuning: wave priorities (s_setprio) by phase.  The per-wave stamps of round 4 show the workgroup's second four
+// waves (the second wave of every SIMD) issuing their thirty row stores / requests behind the first four's -- 10 500 cycles
+// in the queue against 5 300 -- and the first four then waiting 12 000 cycles at barrier A for them.
+//   1: the second four waves at priority 3 from barrier C to the end of the update phase
+//   2: ... for the whole particle
+//   3: as 1, and the first four at priority 3 in the gates / keys phase
+#ifndef PK_PUB_PRIO
+#define PK_PUB_PRIO 0
+#endif
 #ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
 #define PK_PUB_ILV 0
 #endif
@@ -1147,6 +1156,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     for (int i = 0; i < 2 * NP; ++i)
       if (PK_PUB_ABLATE < 2) pub_take(Q[i], pub, dump);
     lds_barrier();  // C: every marker has been read -- the table is the next particle's
+    if constexpr (PK_PUB_PRIO != 0 && THREADS == 512) {
+      if (tid0 >= 256) __builtin_amdgcn_s_setprio(3);
+      else if (PK_PUB_PRIO == 3) __builtin_amdgcn_s_setprio(0);
+    }
     PK_STAMP(s6)
     PK_PSTAMP(5, s5, s6)  // barrier B, markers, barrier C
     if (wg_flag[cur] && PK_PUB_ABLATE == 0) {  // workgroup-uniform: nothing has been written; the general kernels take the particle
@@ -1322,6 +1335,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         PK_STAMP(su1_)
         PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
       }
+    }
+    if constexpr ((PK_PUB_PRIO == 1 || PK_PUB_PRIO == 3) && THREADS == 512) {
+      if (tid0 >= 256) __builtin_amdgcn_s_setprio(0);
+      else if (PK_PUB_PRIO == 3) __builtin_amdgcn_s_setprio(3);
     }
     PK_STAMP(s7)
     PK_PSTAMP(6, s6, s7)  // updates, stores issued
