@@ -163,7 +163,12 @@ def _nccl_single(q):
                 sl.step(_V, _W, 0.1, scs[st], 0.37 + 0.2 * st, seed=4, draw=st, domain=1)
                 pl.step(_V, _W, 0.1, scs[st], 0.37 + 0.2 * st, seed=4, draw=st, domain=1)
             assert sl.split_steps_done == 2 and sl.loopback_records >= 2 * max(1, (nf > 0) + (nb > 0)), (sl.split_steps_done, sl.loopback_records)
-            assert np.array_equal(sl.download_poses(), pl.download_poses()), ("loopback poses", nf, nb)
+            # (the candidate lists of a split step are made before the slots at either end are filled, from another reference
+            # pose: a particle or two may go through the fall-back kernels here and not in the plain filter -- the same
+            # associations and maps, log-weights summed in another order)
+            pa, pb = sl.download_poses(), pl.download_poses()
+            assert np.array_equal(pa[:, :3], pb[:, :3]), ("loopback poses", nf, nb)
+            assert np.allclose(pa[:, 3], pb[:, 3], rtol=1e-11, atol=0.0), ("loopback weights", nf, nb)
             for xa, xb in zip(sl.download_landmarks(), pl.download_landmarks()):
                 assert np.array_equal(xa, xb), ("loopback maps", nf, nb)
             assert np.allclose(sl.summary(), pl.summary(), rtol=1e-13, atol=1e-14)
