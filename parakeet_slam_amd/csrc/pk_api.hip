@@ -1320,7 +1320,9 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
   }
   return PK_OK;
 }
-static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand) {
+// ref: the particle whose MAP the candidate lists are made from -- particle 0, or in a split step the first particle of the range
+// that has been filled already (the slots at either end still hold the old generation then)
+static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand, int64_t ref = 0) {
   int rc;
   f->pub_ecap = 0;
   // the register route; with "pub_small" (off: measured) also the L <= 512 route through the publish /
@@ -1334,7 +1336,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     Span t(f, PK_T_ASSOC);
     launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
-    launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
+    launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
                       2 * kCandSlots, f->out4);
     launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
                         ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots);
@@ -1357,14 +1359,14 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     cand->rec = f->cand_dev;
     cand->over = ctl_cand_over(f);
     if (ecap > 0) {  // candidate lists both ways, and the publish table's layout
-      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
+      launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
                         kCandSlots, f->out4);
       launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
                           ctl_skip_pub(f), ctl_skip_cand(f), ecap);
       cand->skip_cand = ctl_skip_cand(f);
       f->pub_ecap = ecap;
     } else {
-      launch_candidates(f->stream, f->d, B, al.exact, 0, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
+      launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
     }
   }
   return PK_OK;
@@ -1628,7 +1630,7 @@ int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1,
     if (!sp.al.regs) return fail(PK_ERR_STATE, "pk_observe_staged_range: the scan did not take the register route");
     f->route = PK_ROUTE_ML_REGS;
     sp.cand = CandTable();
-    if ((rc = onepass_prepare(f, sp.al, sp.B, &sp.cand))) return rc;
+    if ((rc = onepass_prepare(f, sp.al, sp.B, &sp.cand, p1 > p0 ? p0 : 0))) return rc;
     sp.active = true;
   } else if (!sp.active) {
     return fail(PK_ERR_STATE, "pk_observe_staged_range: no split observe in progress (first = 1)");
