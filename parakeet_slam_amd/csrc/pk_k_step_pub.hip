@@ -86,6 +86,9 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_PRIO
 #define PK_PUB_PRIO 0
 #endif
+#ifndef PK_PUB_BIG_OVF  // k_step_pub_big: 1 = four gate slots + refill turn (round 4), 0 = eight gate slots, positives kept (round 3)
+#define PK_PUB_BIG_OVF 1
+#endif
 #ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
 #define PK_PUB_ILV 0
 #endif
@@ -608,7 +611,8 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
 // that keeps its blob publishes the same values again.  Blobs left over when the free slots run out: the particle goes to the
 // fall-back kernels, as it did for any fifth blob before round 4.  Returns false when no lane of the wave has such a landmark
 // (wave-uniform).
-template <int N>
+// W4: uint4 words per list (1: eight candidates, records [ref | list] and one entry word; 2: sixteen, [ref | list | list] and two)
+template <int N, int W4 = 1>
 __device__ __forceinline__ bool pub_refill_slots(PubSlots (&q)[N], const uint4* cand_row, const uint4* erec_row, int* flag) {
   bool anyovf = false;
 #pragma unroll
@@ -620,12 +624,12 @@ __device__ __forceinline__ bool pub_refill_slots(PubSlots (&q)[N], const uint4* 
     const bool ovf = __popc(pmask) > kPubSlots;
     if (__ballot(ovf) == 0ull) continue;  // wave-uniform
     // this landmark's list words once more (L2), one word -- two candidates -- at a time
-    const unsigned* cwp = reinterpret_cast<const unsigned*>(cand_row + 2 * j + 1);
-    const unsigned* ewp = reinterpret_cast<const unsigned*>(erec_row + j);
+    const unsigned* cwp = reinterpret_cast<const unsigned*>(cand_row + (1 + W4) * j + 1);
+    const unsigned* ewp = reinterpret_cast<const unsigned*>(erec_row + W4 * j);
     const unsigned id0 = q[j].s[0] & 0xFFFFu, id1 = q[j].s[1] & 0xFFFFu, id2 = q[j].s[2] & 0xFFFFu, id3 = q[j].s[3] & 0xFFFFu;
     unsigned open = ~q[j].st & 0x1111u;  // slots whose blob has probability 0: its verdict is out, the place is free
 #pragma unroll 1
-    for (int w = 0; w < kCandSlots / 2; ++w) {
+    for (int w = 0; w < W4 * kCandSlots / 2; ++w) {
       const unsigned cw = cwp[w], ew = ewp[w];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -1564,13 +1568,31 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[1].mg = SB.mg;
           gi[1].mb = SB.mb;
           gi[1].has = l0 + 1 < L;
-          PubSlotsT<kPubBigGateSlots> qq[2];
           double pp[2] = {0.0, 0.0};
           const Landmark<double>* const l2[2] = {&SA, &SB};
+#if PK_PUB_BIG_OVF
+          // (round 4: FOUR gate slots and the refill turn of k_step_pub instead of eight slots of which the positive ones were
+          // kept -- a landmark of nearly every particle passes five to seven blobs at 5 000 random colours, but in a given
+          // WAVE that is rare, and four-deep slot insertion and key rounds are what every wave pays)
+          PubSlots qq[2];
+          pub_gatesN<2, 2, kPubSlots, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
+          pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+          {
+            PubArgsPtr R9 = pub_args_now(rp);
+            if (pub_refill_slots<2, 2>(qq, R9->cand + 3 * (size_t)lc, R9->erec + 2 * (size_t)lc, &wg_flag[cur]))
+              pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+          }
+          qa = qq[0];
+          qb = qq[1];
+          qa.st &= 0xFFFFu;
+          qb.st &= 0xFFFFu;
+#else
+          PubSlotsT<kPubBigGateSlots> qq[2];
           pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
           pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
+#endif
           pa = pp[0];
           pb = pp[1];
           {  // the next pair of this pass, or the first one of pass 2
