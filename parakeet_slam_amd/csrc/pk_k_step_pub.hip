@@ -86,8 +86,12 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_PRIO
 #define PK_PUB_PRIO 0
 #endif
-#ifndef PK_PUB_BIG_OVF  // k_step_pub_big: 1 = four gate slots + refill turn (round 4), 0 = eight gate slots, positives kept (round 3)
-#define PK_PUB_BIG_OVF 1
+// k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
+// turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
+// with five to seven gate-passing blobs is in nearly every WAVE's 128, not just in every particle, so the second turn is the
+// rule and the left-over blobs flag particles by the thousand.  Kept as a switch for maps with sparser colours.
+#ifndef PK_PUB_BIG_OVF
+#define PK_PUB_BIG_OVF 0
 #endif
 #ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
 #define PK_PUB_ILV 0
@@ -1571,9 +1575,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           double pp[2] = {0.0, 0.0};
           const Landmark<double>* const l2[2] = {&SA, &SB};
 #if PK_PUB_BIG_OVF
-          // (round 4: FOUR gate slots and the refill turn of k_step_pub instead of eight slots of which the positive ones were
-          // kept -- a landmark of nearly every particle passes five to seven blobs at 5 000 random colours, but in a given
-          // WAVE that is rare, and four-deep slot insertion and key rounds are what every wave pays)
+          // (diagnostic / sparse-colour variant, see PK_PUB_BIG_OVF)
           PubSlots qq[2];
           pub_gatesN<2, 2, kPubSlots, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
           pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
