@@ -792,8 +792,8 @@ def main():
                 "blobs": L,
                 "assoc": args.assoc,
                 "global_particles": P * world,
-                "parallelism": "particles sharded over %d GPU(s), one process per GPU; backend %s: all-reduce(max) + "
-                "all-gather(block weight totals) + all-to-all(migrating particles) per resample" % (world, backend_name) if sharded
+                "parallelism": "particles sharded over %d rank(s) on %d GPU(s), one process per GPU; backend %s: all-reduce(max) + "
+                "all-gather(block weight totals) + all-to-all(migrating particles) per resample" % (world, n_devices, backend_name) if sharded
                 else "single GPU",
             },
             "roofline": roof,
