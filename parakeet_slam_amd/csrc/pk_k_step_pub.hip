@@ -86,6 +86,9 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_PRIO
 #define PK_PUB_PRIO 0
 #endif
+#ifndef PK_PUB_HALVES  // 1: the update of a pair in halves, its position rows stored in between (round 4); 0: round 3's order only
+#define PK_PUB_HALVES 1
+#endif
 // k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
 // turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
 // with five to seven gate-passing blobs is in nearly every WAVE's 128, not just in every particle, so the second turn is the
@@ -1284,64 +1287,172 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #undef PK_ILV_STORE
       } else
 #endif
+      if constexpr (THREADS != kPubSmallThreads && PK_PUB_ABLATE < 1 && PK_PUB_HALVES != 0) {
+        // The update of a pair runs in HALVES -- position blocks of both landmarks, their five rows out, colour blocks of both, the
+        // other nine rows out -- so that the first stores of a pair leave after two fifths of its arithmetic instead of after all
+        // of it: everything between barrier C and the first store is on the critical path of a particle (the NEXT particle's rows
+        // can only be asked for into the registers those stores free; padding experiment).  A landmark that
+        // takes several blobs gets them one turn of the pair's loop each, in scan order (:88: sequential updates); the rows leave
+        // in the last turn.  ONE copy of the update code per landmark of the pair, and one `log` per lane for all the importance
+        // factors (EkfWeightSum).
+        EkfWeightSum wsum;
+#define PK_PUB_HSTORE(q_, l0_, field, F)                                                              \
+  {                                                                                                   \
+    const Double2 v_ = {S[2 * (q_)].field, S[2 * (q_) + 1].field};                                    \
+    __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + (l0_)));        \
+  }
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const int l0 = 2 * kPubThreads * q + 2 * tid;
-        if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
+        for (int q = 0; q < NP; ++q) {
+          const int l0 = 2 * kPubThreads * q + 2 * tid;
+          if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
+          const bool imm0 = immutable[min(l0, Lp - 1)] != 0, imm1 = immutable[min(l0 + 1, Lp - 1)] != 0;
+          unsigned tk0 = Q[2 * q].st & 0x4444u, tk1 = Q[2 * q + 1].st & 0x4444u;  // blobs still to be applied
+#pragma unroll 1
+          for (int turn = 0;; ++turn) {
+            // the blob of this turn: the landmark's only one (the usual case, wave-uniform), else the earliest in the scan
+            unsigned w0, w1, bit0 = tk0, bit1 = tk1;
+            if (__ballot(((tk0 & (tk0 - 1u)) | (tk1 & (tk1 - 1u))) != 0u) == 0ull) {
+              w0 = (tk0 & 0x0004u) ? Q[2 * q].s[0] : (tk0 & 0x0040u) ? Q[2 * q].s[1] : (tk0 & 0x0400u) ? Q[2 * q].s[2] : Q[2 * q].s[3];
+              w1 = (tk1 & 0x0004u) ? Q[2 * q + 1].s[0] : (tk1 & 0x0040u) ? Q[2 * q + 1].s[1] : (tk1 & 0x0400u) ? Q[2 * q + 1].s[2] : Q[2 * q + 1].s[3];
+            } else {
+              unsigned best0 = 0xFFFFFFFFu, best1 = 0xFFFFFFFFu;
+              w0 = w1 = 0u;
+              bit0 = bit1 = 0u;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int i = 2 * q + j;
-          const bool imm = immutable[min(l0 + j, Lp - 1)] != 0;
-          if (PK_PUB_ABLATE < 1)
-            acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i])
-                                               : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
+              for (int sidx = 0; sidx < kPubSlots; ++sidx) {
+                const bool a0 = ((tk0 >> (4 * sidx)) & 4u) != 0u, a1 = ((tk1 >> (4 * sidx)) & 4u) != 0u;
+                const unsigned o0 = order[a0 ? (Q[2 * q].s[sidx] & 0xFFFFu) : 0u], o1 = order[a1 ? (Q[2 * q + 1].s[sidx] & 0xFFFFu) : 0u];
+                const bool f0 = a0 && o0 < best0, f1 = a1 && o1 < best1;
+                best0 = f0 ? o0 : best0;
+                best1 = f1 ? o1 : best1;
+                w0 = f0 ? Q[2 * q].s[sidx] : w0;
+                w1 = f1 ? Q[2 * q + 1].s[sidx] : w1;
+                bit0 = f0 ? (4u << (4 * sidx)) : bit0;
+                bit1 = f1 ? (4u << (4 * sidx)) : bit1;
+              }
+            }
+            const bool on0 = tk0 != 0u, on1 = tk1 != 0u;
+            tk0 &= ~bit0;
+            tk1 &= ~bit1;
+            const bool last = __ballot((tk0 | tk1) != 0u) == 0ull;  // wave-uniform: nothing left for this pair
+            const double* r0 = ex + 6 * (on0 ? (w0 & 0xFFFFu) : 0u);
+            const double* r1 = ex + 6 * (on1 ? (w1 & 0xFFFFu) : 0u);
+            const bool pot0 = (S[2 * q].count & kPotentialBit) != 0, pot1 = (S[2 * q + 1].count & kPotentialBit) != 0;
+            // the expected bearing: the gates' for the first blob (and for an immutable landmark, whose mean does not move)
+            double zh0 = pse[2 * q], zh1 = pse[2 * q + 1];
+            if (turn > 0) {  // wave-uniform, rare
+              zh0 = imm0 ? zh0 : pk_atan2(S[2 * q].my - sy, S[2 * q].mx - sx);
+              zh1 = imm1 ? zh1 : pk_atan2(S[2 * q + 1].my - sy, S[2 * q + 1].mx - sx);
+            }
+            EkfPosHalf<double> ph0{0.0, 0.0}, ph1{0.0, 0.0};
+            if (on0) ph0 = ekf_update_position(S[2 * q], sx, sy, r0[0], qt, imm0, zh0);
+            if (on1) ph1 = ekf_update_position(S[2 * q + 1], sx, sy, r1[0], qt, imm1, zh1);
+            if (last && l0 < Lp) {
+              PK_PUB_HSTORE(q, l0, mx, F_MX)
+              PK_PUB_HSTORE(q, l0, my, F_MY)
+              PK_PUB_HSTORE(q, l0, pxx, F_PXX)
+              PK_PUB_HSTORE(q, l0, pxy, F_PXY)
+              PK_PUB_HSTORE(q, l0, pyy, F_PYY)
+            }
+            asm volatile("" ::: "memory");  // (the blobs' colours are read from LDS here, not carried across the stores)
+            if (on0) {
+              const double2 z23 = *reinterpret_cast<const double2*>(r0 + 2);
+              double fro2, maha;
+              ekf_update_colour(S[2 * q], r0[1], z23.x, z23.y, qt, imm0, ph0, fro2, maha);
+              wsum.add(fro2, maha, pot0);
+            }
+            if (on1) {
+              const double2 z23 = *reinterpret_cast<const double2*>(r1 + 2);
+              double fro2, maha;
+              ekf_update_colour(S[2 * q + 1], r1[1], z23.x, z23.y, qt, imm1, ph1, fro2, maha);
+              wsum.add(fro2, maha, pot1);
+            }
+            if (last) break;
+          }
+          PK_STAMP(su0_)
+          if (l0 < Lp) {
+            PK_PUB_HSTORE(q, l0, mr, F_MR)
+            PK_PUB_HSTORE(q, l0, mg, F_MG)
+            PK_PUB_HSTORE(q, l0, mb, F_MB)
+            PK_PUB_HSTORE(q, l0, crr, F_CRR)
+            PK_PUB_HSTORE(q, l0, crg, F_CRG)
+            PK_PUB_HSTORE(q, l0, crb, F_CRB)
+            PK_PUB_HSTORE(q, l0, cgg, F_CGG)
+            PK_PUB_HSTORE(q, l0, cgb, F_CGB)
+            PK_PUB_HSTORE(q, l0, cbb, F_CBB)
+            const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
+            __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
+          }
+          if (q < kPipe) {  // the next particle's pair, into the registers just stored
+            PubArgsPtr R6 = pub_args_now(rp);
+            const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+            PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
+          }
+          PK_STAMP(su1_)
+          PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
         }
-        PK_STAMP(su0_)
-        if (l0 < Lp) {
+#undef PK_PUB_HSTORE
+        acc += wsum.finish();
+      } else {  // the 256-lane instance (and diagnostic builds): round 3's order, a pair's rows out behind both its updates
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int l0 = 2 * kPubThreads * q + 2 * tid;
+          if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int i = 2 * q + j;
+            const bool imm = immutable[min(l0 + j, Lp - 1)] != 0;
+            if (PK_PUB_ABLATE < 1)
+              acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i])
+                                                 : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
+          }
+          PK_STAMP(su0_)
+          if (l0 < Lp) {
 #if defined(PK_PUB_STORE_FLAVOUR)  // diagnostic variants: -DPK_PUB_STORE_FLAVOUR='"sc1"' ...
 #define PK_PUB_STORE(field, F)                                                                                         \
-  {                                                                                                                    \
-    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                                            \
-    asm volatile("global_store_dwordx4 %0, %1, off " PK_PUB_STORE_FLAVOUR ::"v"(df + (size_t)F * Lp + l0), "v"(v) : "memory"); \
-  }
+    {                                                                                                                    \
+      const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                                            \
+      asm volatile("global_store_dwordx4 %0, %1, off " PK_PUB_STORE_FLAVOUR ::"v"(df + (size_t)F * Lp + l0), "v"(v) : "memory"); \
+    }
 #elif defined(PK_PUB_PLAIN_STORES)  // diagnostic variant
 #define PK_PUB_STORE(field, F)                                               \
-  {                                                                          \
-    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                  \
-    *reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0) = v;               \
-  }
+    {                                                                          \
+      const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                  \
+      *reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0) = v;               \
+    }
 #else
 #define PK_PUB_STORE(field, F)                                                             \
-  {                                                                                        \
-    const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                \
-    __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
-  }
+    {                                                                                        \
+      const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                \
+      __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
+    }
 #endif
-          PK_PUB_STORE(mx, F_MX)
-          PK_PUB_STORE(my, F_MY)
-          PK_PUB_STORE(mr, F_MR)
-          PK_PUB_STORE(mg, F_MG)
-          PK_PUB_STORE(mb, F_MB)
-          PK_PUB_STORE(pxx, F_PXX)
-          PK_PUB_STORE(pxy, F_PXY)
-          PK_PUB_STORE(pyy, F_PYY)
-          PK_PUB_STORE(crr, F_CRR)
-          PK_PUB_STORE(crg, F_CRG)
-          PK_PUB_STORE(crb, F_CRB)
-          PK_PUB_STORE(cgg, F_CGG)
-          PK_PUB_STORE(cgb, F_CGB)
-          PK_PUB_STORE(cbb, F_CBB)
+            PK_PUB_STORE(mx, F_MX)
+            PK_PUB_STORE(my, F_MY)
+            PK_PUB_STORE(mr, F_MR)
+            PK_PUB_STORE(mg, F_MG)
+            PK_PUB_STORE(mb, F_MB)
+            PK_PUB_STORE(pxx, F_PXX)
+            PK_PUB_STORE(pxy, F_PXY)
+            PK_PUB_STORE(pyy, F_PYY)
+            PK_PUB_STORE(crr, F_CRR)
+            PK_PUB_STORE(crg, F_CRG)
+            PK_PUB_STORE(crb, F_CRB)
+            PK_PUB_STORE(cgg, F_CGG)
+            PK_PUB_STORE(cgb, F_CGB)
+            PK_PUB_STORE(cbb, F_CBB)
 #undef PK_PUB_STORE
-          const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
-          __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
+            const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
+            __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
+          }
+          if (q < kPipe) {  // the next particle's pair, into the registers just stored
+            PubArgsPtr R6 = pub_args_now(rp);
+            const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+            PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
+          }
+          PK_STAMP(su1_)
+          PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
         }
-        if (q < kPipe) {  // the next particle's pair, into the registers just stored
-          PubArgsPtr R6 = pub_args_now(rp);
-          const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-          PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
-        }
-        PK_STAMP(su1_)
-        PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
       }
     }
     if constexpr ((PK_PUB_PRIO == 1 || PK_PUB_PRIO == 3) && THREADS == 512) {
