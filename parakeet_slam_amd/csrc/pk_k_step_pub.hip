@@ -86,8 +86,13 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_PRIO
 #define PK_PUB_PRIO 0
 #endif
-#ifndef PK_PUB_HALVES  // 1: the update of a pair in halves, its position rows stored in between (round 4); 0: round 3's order only
-#define PK_PUB_HALVES 1
+// 1: the update of a pair in halves -- position blocks of both landmarks, their five rows out, colour blocks, nine rows out; one
+// copy of the update code per landmark, a turn loop for landmarks with several blobs, one log per lane -- 0 (default): round 3's
+// order, a pair's rows out behind both its updates.  Measured (round 4, three interleaved repetitions on one box): 9.965-9.989 ms
+// per step with the halves against 9.925-9.933 without: the earlier stores buy nothing, because the requests that reuse the
+// pair's registers still leave behind its last store.  Exact either way (the -m gpu suite passes with the switch on).
+#ifndef PK_PUB_HALVES
+#define PK_PUB_HALVES 0
 #endif
 // k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
 // turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
