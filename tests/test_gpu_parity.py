@@ -301,3 +301,32 @@ def test_upload_kernel_and_copy_engine_give_the_same_step(lib):
         for a, b in zip(out[0][1], other[1]):
             assert np.array_equal(a, b)
     assert out[0][2] == 6 and out[2][2] == 2  # launches bracketed: every step / every third
+
+
+def test_expected_bearing_atan2_within_a_few_ulp_of_numpy(lib):
+    """pk_math.hpp::pk_atan2 (round 4: one division, degree-10 polynomial, scalar-register coefficients) is what every observe
+    kernel takes its expected bearings from (generate_measurement, prkt_core_v2.py:871; :408; :473).  Through pk_probe on 400
+    random (pose, landmark) pairs in all octants and over six decades of distance, plus the axes, the diagonals and the point
+    itself: within 4 ulp of numpy.arctan2, exact where the reference's own tests are (test_generate_measurement: pi / 4)."""
+    rs = np.random.RandomState(77)
+    cov = 0.25 * np.identity(5)
+    cases = []
+    for _ in range(400):
+        ang = rs.uniform(-np.pi, np.pi)
+        rad = 10.0 ** rs.uniform(-3, 3)
+        pose = np.array([rs.uniform(-5, 5), rs.uniform(-5, 5), 0.0])
+        cases.append((pose, pose[0] + rad * np.cos(ang), pose[1] + rad * np.sin(ang)))
+    for dx, dy in ((1, 0), (0, 1), (-1, 0), (0, -1), (1, 1), (-1, 1), (-1, -1), (1, -1), (0, 0), (3, 1.2426406871192852), (1e-300, 1e-300)):
+        cases.append((np.zeros(3), float(dx), float(dy)))
+    worst = 0.0
+    for pose, fx, fy in cases:
+        mean = np.array([fx, fy, 10.0, 20.0, 30.0])
+        got = lib.probe(pose, mean, cov, np.array([0.1, 10.0, 20.0, 30.0]))["zhat"][0]
+        ref = np.arctan2(fy - pose[1], fx - pose[0])
+        if ref == 0.0:
+            assert got == 0.0
+            continue
+        worst = max(worst, abs(got - ref) / np.spacing(abs(ref)))
+    assert worst <= 4.0, worst
+    z = lib.probe(np.array([-1.0, -1.0, 0.0]), np.array([0.0, 0.0, 73.0, 165.0, 255.0]), cov, np.array([0.1, 73.0, 165.0, 255.0]))["zhat"][0]
+    assert z == np.pi / 4  # test_prkt_ros2.py:403-423
