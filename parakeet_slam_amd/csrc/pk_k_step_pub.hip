@@ -94,6 +94,11 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_HALVES
 #define PK_PUB_HALVES 0
 #endif
+// Diagnostic: where the SECOND pair's rows of a particle are asked for -- 0: at the top, behind the first pair's candidate records
+// (default); 1: behind the first pair's gates; 2: behind the first pair's keys.
+#ifndef PK_PUB_LATE_P1
+#define PK_PUB_LATE_P1 0
+#endif
 // k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
 // turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
 // with five to seven gate-passing blobs is in nearly every WAVE's 128, not just in every particle, so the second turn is the
@@ -1057,7 +1062,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         asm volatile("" ::: "memory");
         // (pair by pair, means before covariance rows: the first pair's gates and verdicts are worked out while the second
         // pair's rows are still on their way -- the vector memory counter retires in order)
-        {
+        if constexpr (PK_PUB_LATE_P1 == 0) {
           const int coff = R->count_off;
 #pragma unroll
           for (int q = kPipe; q < NP; ++q) PK_PUB_LOAD_PAIR(q, sslot, coff, lbase[q])
@@ -1100,6 +1105,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       if ((q) == 0) pub_pad<PK_PUB_PAD_G0>(); else pub_pad<PK_PUB_PAD_G1>();                                                       \
       if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, PK_PUB_OVF != 0>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);   \
       PK_STAMP(sk0_)                                                                                                               \
+      if constexpr (PK_PUB_LATE_P1 == 1 && NP > 1) {                                                                               \
+        if ((q) == 0) { /* the second pair's rows asked for behind the first pair's GATES (diagnostic variant) */                  \
+          PubArgsPtr R7 = pub_args_now(rp);                                                                                        \
+          PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])                                                                      \
+        }                                                                                                                          \
+      }                                                                                                                            \
       if ((q) == 0) pub_pad<PK_PUB_PAD_K0>(); else pub_pad<PK_PUB_PAD_K1>();                                                       \
       if (PK_PUB_ABLATE < 3) {                                                                                                     \
         pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                                             \
@@ -1121,6 +1132,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         if (!done) {  // workgroup-uniform
           PK_PUB_PAIR(0)
           if constexpr (NP > 1) {
+            if constexpr (PK_PUB_LATE_P1 == 2) {  // (diagnostic variant: the second pair's rows behind the first pair's keys)
+              PubArgsPtr R7 = pub_args_now(rp);
+              PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
+            }
             request_cand(NP - 1);
             PK_PUB_PAIR(1)
           }
