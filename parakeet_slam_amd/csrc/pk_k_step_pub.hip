@@ -94,10 +94,15 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_HALVES
 #define PK_PUB_HALVES 0
 #endif
-// Diagnostic: where the SECOND pair's rows of a particle are asked for -- 0: at the top, behind the first pair's candidate records
-// (default); 1: behind the first pair's gates; 2: behind the first pair's keys.
+// Where the SECOND pair's rows of a particle are asked for -- 0: at the top, behind the first pair's candidate records (round 3);
+// 1: behind the first pair's gates; 2: behind the first pair's keys; 4 (default, round 4): behind the first pair's keys AND
+// behind the second pair's candidate records.  The texture addresser takes a CU's vector-memory instructions in order, ~16 cycles
+// per 1 KB: at the top of a particle the fifteen row requests of each of the eight waves stood in its queue between the last
+// row stores and what the gates need at once -- the candidate records, 96 bytes per lane.  Asked for where nothing urgent is
+// behind them, the rows still arrive long before the second pair's gates are through their atan2.  Measured at 100 000 x 2 000,
+// three interleaved repetitions on one box: 9.96 (0) -> 9.83 (1) -> 9.71 (2) -> 9.465 ms per step (4), kernel 9.80 -> 9.30 ms.
 #ifndef PK_PUB_LATE_P1
-#define PK_PUB_LATE_P1 0
+#define PK_PUB_LATE_P1 4
 #endif
 // k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
 // turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
@@ -1132,11 +1137,16 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         if (!done) {  // workgroup-uniform
           PK_PUB_PAIR(0)
           if constexpr (NP > 1) {
-            if constexpr (PK_PUB_LATE_P1 == 2) {  // (diagnostic variant: the second pair's rows behind the first pair's keys)
+            if constexpr (PK_PUB_LATE_P1 == 2) {  // (the second pair's rows behind the first pair's keys)
               PubArgsPtr R7 = pub_args_now(rp);
               PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
             }
             request_cand(NP - 1);
+            if constexpr (PK_PUB_LATE_P1 == 4) {  // (... and behind the second pair's candidate records)
+              asm volatile("" ::: "memory");
+              PubArgsPtr R7 = pub_args_now(rp);
+              PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
+            }
             PK_PUB_PAIR(1)
           }
         }
