@@ -104,9 +104,6 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_LATE_P1
 #define PK_PUB_LATE_P1 4
 #endif
-#ifndef PK_PUB_DEFER_LAST  // see k_step_pub: the last pair's row stores behind the next particle's first candidate records
-#define PK_PUB_DEFER_LAST 1
-#endif
 // k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
 // turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
 // with five to seven gate-passing blobs is in nearly every WAVE's 128, not just in every particle, so the second turn is the
@@ -1011,11 +1008,6 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #pragma unroll
     for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(2 * kPubThreads * q + 2 * tid0, Lp - 2))
   }
-  // PK_PUB_DEFER_LAST (two-pair instance): the row stores of a particle's LAST pair wait until the next particle's first candidate
-  // records have been asked for -- 96 bytes per lane that the gates need at once, and that stood in the texture addresser's
-  // queue behind 8 x 15 store instructions when they were asked for after them.  pend: the particle whose last pair is still
-  // in the registers (-1: none).
-  int64_t pend = -1;
   for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
     // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
     // occupy registers for the whole kernel)
@@ -1073,41 +1065,6 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         };
         request_cand(0);
         asm volatile("" ::: "memory");
-        if constexpr (PK_PUB_DEFER_LAST != 0 && NP == 2 && THREADS != kPubSmallThreads) {
-          if (pend >= 0) {  // workgroup-uniform: the previous particle's second pair goes out now
-            PubArgsPtr R5 = pub_args_now(rp);
-            unsigned char* pslot = R5->map_dst + (size_t)pend * R5->ss.slot_bytes;
-            double* pf = reinterpret_cast<double*>(pslot);
-            int* pc = reinterpret_cast<int*>(pslot + R5->count_off);
-            const int l1 = 2 * kPubThreads + 2 * tid;
-            if (l1 < Lp) {
-#define PK_PUB_PSTORE(field, F)                                                               \
-  {                                                                                           \
-    const Double2 v_ = {S[2].field, S[3].field};                                              \
-    __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(pf + (size_t)F * Lp + l1));   \
-  }
-              PK_PUB_PSTORE(mx, F_MX)
-              PK_PUB_PSTORE(my, F_MY)
-              PK_PUB_PSTORE(mr, F_MR)
-              PK_PUB_PSTORE(mg, F_MG)
-              PK_PUB_PSTORE(mb, F_MB)
-              PK_PUB_PSTORE(pxx, F_PXX)
-              PK_PUB_PSTORE(pxy, F_PXY)
-              PK_PUB_PSTORE(pyy, F_PYY)
-              PK_PUB_PSTORE(crr, F_CRR)
-              PK_PUB_PSTORE(crg, F_CRG)
-              PK_PUB_PSTORE(crb, F_CRB)
-              PK_PUB_PSTORE(cgg, F_CGG)
-              PK_PUB_PSTORE(cgb, F_CGB)
-              PK_PUB_PSTORE(cbb, F_CBB)
-#undef PK_PUB_PSTORE
-              const Int2 c_ = {S[2].count, S[3].count};
-              __builtin_nontemporal_store(c_, reinterpret_cast<Int2*>(pc + l1));
-            }
-            pend = -1;
-          }
-          asm volatile("" ::: "memory");
-        }
         // (pair by pair, means before covariance rows: the first pair's gates and verdicts are worked out while the second
         // pair's rows are still on their way -- the vector memory counter retires in order)
         if constexpr (PK_PUB_LATE_P1 == 0) {
@@ -1480,9 +1437,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
                                                  : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
           }
           PK_STAMP(su0_)
-          if (PK_PUB_DEFER_LAST != 0 && NP == 2 && THREADS != kPubSmallThreads && q == NP - 1) {
-            pend = p;  // (its rows leave at the top of the next particle, or of the turn that finds no particle left)
-          } else if (l0 < Lp) {
+          if (l0 < Lp) {
 #if defined(PK_PUB_STORE_FLAVOUR)  // diagnostic variants: -DPK_PUB_STORE_FLAVOUR='"sc1"' ...
 #define PK_PUB_STORE(field, F)                                                                                         \
     {                                                                                                                    \
