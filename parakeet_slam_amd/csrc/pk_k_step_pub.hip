@@ -104,6 +104,9 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_LATE_P1
 #define PK_PUB_LATE_P1 4
 #endif
+#ifndef PK_PUB_P0_WHERE  // diagnostic: where the NEXT particle's first pair is asked for (0: behind the first pair's stores)
+#define PK_PUB_P0_WHERE 0
+#endif
 // k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
 // turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
 // with five to seven gate-passing blobs is in nearly every WAVE's 128, not just in every particle, so the second turn is the
@@ -972,6 +975,36 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     S[2 * (q_)].field = v_.x;                                                                     \
     S[2 * (q_) + 1].field = v_.y;                                                                 \
   }
+#define PK_PUB_LOAD_MEANS(q_, sslot_, lb_)                                                        \
+  {                                                                                               \
+    const double* sf_ = reinterpret_cast<const double*>(sslot_);                                  \
+    const int lbq_ = (lb_);                                                                       \
+    PK_PUB_ROW(q_, mx, F_MX)                                                                      \
+    PK_PUB_ROW(q_, my, F_MY)                                                                      \
+    PK_PUB_ROW(q_, mr, F_MR)                                                                      \
+    PK_PUB_ROW(q_, mg, F_MG)                                                                      \
+    PK_PUB_ROW(q_, mb, F_MB)                                                                      \
+    asm volatile("" ::: "memory");                                                                \
+  }
+#define PK_PUB_LOAD_COVS(q_, sslot_, coff_, lb_)                                                  \
+  {                                                                                               \
+    const double* sf_ = reinterpret_cast<const double*>(sslot_);                                  \
+    const int* sc_ = reinterpret_cast<const int*>((sslot_) + (coff_));                            \
+    const int lbq_ = (lb_);                                                                       \
+    PK_PUB_ROW(q_, pxx, F_PXX)                                                                    \
+    PK_PUB_ROW(q_, pxy, F_PXY)                                                                    \
+    PK_PUB_ROW(q_, pyy, F_PYY)                                                                    \
+    PK_PUB_ROW(q_, crr, F_CRR)                                                                    \
+    PK_PUB_ROW(q_, crg, F_CRG)                                                                    \
+    PK_PUB_ROW(q_, crb, F_CRB)                                                                    \
+    PK_PUB_ROW(q_, cgg, F_CGG)                                                                    \
+    PK_PUB_ROW(q_, cgb, F_CGB)                                                                    \
+    PK_PUB_ROW(q_, cbb, F_CBB)                                                                    \
+    const Int2 c_ = *reinterpret_cast<const Int2*>(sc_ + lbq_);                                   \
+    S[2 * (q_)].count = c_.x;                                                                     \
+    S[2 * (q_) + 1].count = c_.y;                                                                 \
+    asm volatile("" ::: "memory");                                                                \
+  }
 #define PK_PUB_LOAD_PAIR(q_, sslot_, coff_, lb_)                                                  \
   {                                                                                               \
     const double* sf_ = reinterpret_cast<const double*>(sslot_);                                  \
@@ -1110,6 +1143,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       if ((q) == 0) pub_pad<PK_PUB_PAD_G0>(); else pub_pad<PK_PUB_PAD_G1>();                                                       \
       if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, PK_PUB_OVF != 0>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);   \
       PK_STAMP(sk0_)                                                                                                               \
+      if constexpr (PK_PUB_LATE_P1 == 5 && NP > 1) {                                                                               \
+        if ((q) == 1) { /* diagnostic: the second pair's covariance rows behind its own gates */                                   \
+          PubArgsPtr R7 = pub_args_now(rp);                                                                                        \
+          PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])                                                                      \
+        }                                                                                                                          \
+      }                                                                                                                            \
       if constexpr (PK_PUB_LATE_P1 == 1 && NP > 1) {                                                                               \
         if ((q) == 0) { /* the second pair's rows asked for behind the first pair's GATES (diagnostic variant) */                  \
           PubArgsPtr R7 = pub_args_now(rp);                                                                                        \
@@ -1146,6 +1185,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
               asm volatile("" ::: "memory");
               PubArgsPtr R7 = pub_args_now(rp);
               PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
+            }
+            if constexpr (PK_PUB_LATE_P1 == 5) {  // (diagnostic: the means there, the covariance rows behind the second pair's gates)
+              asm volatile("" ::: "memory");
+              PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
             }
             PK_PUB_PAIR(1)
           }
@@ -1437,6 +1480,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
                                                  : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
           }
           PK_STAMP(su0_)
+          if (PK_PUB_P0_WHERE == 1 && NP == 2 && q == 1) {  // (diagnostic: the next first pair in front of the second pair's stores)
+            PubArgsPtr R6 = pub_args_now(rp);
+            const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
+          }
           if (l0 < Lp) {
 #if defined(PK_PUB_STORE_FLAVOUR)  // diagnostic variants: -DPK_PUB_STORE_FLAVOUR='"sc1"' ...
 #define PK_PUB_STORE(field, F)                                                                                         \
@@ -1475,10 +1523,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
             const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
             __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
           }
-          if (q < kPipe) {  // the next particle's pair, into the registers just stored
+          if (q < kPipe && (PK_PUB_P0_WHERE == 0 || NP == 1)) {  // the next particle's pair, into the registers just stored
             PubArgsPtr R6 = pub_args_now(rp);
             const unsigned char* ns = pub_slot_source(R6).at(nsrc);
             PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
+          }
+          if (PK_PUB_P0_WHERE == 2 && NP == 2 && q == 1) {  // (diagnostic: ... behind the second pair's stores)
+            PubArgsPtr R6 = pub_args_now(rp);
+            const unsigned char* ns = pub_slot_source(R6).at(nsrc);
+            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
           }
           PK_STAMP(su1_)
           PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
