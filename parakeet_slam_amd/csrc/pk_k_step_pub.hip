@@ -95,14 +95,15 @@ __device__ __forceinline__ void pub_pad() {
 #define PK_PUB_HALVES 0
 #endif
 // Where the SECOND pair's rows of a particle are asked for -- 0: at the top, behind the first pair's candidate records (round 3);
-// 1: behind the first pair's gates; 2: behind the first pair's keys; 4 (default, round 4): behind the first pair's keys AND
-// behind the second pair's candidate records.  The texture addresser takes a CU's vector-memory instructions in order, ~16 cycles
+// 1: behind the first pair's gates; 2: behind the first pair's keys; 4: behind the first pair's keys AND behind the second pair's
+// candidate records; 7 (default, round 4): as 4, but the second pair's five MEAN rows in front of its candidate records (its gates
+// need both at once; -0.3 % against 4); 5, 6: means / covariance rows at other places (measured: worse).  The texture addresser takes a CU's vector-memory instructions in order, ~16 cycles
 // per 1 KB: at the top of a particle the fifteen row requests of each of the eight waves stood in its queue between the last
 // row stores and what the gates need at once -- the candidate records, 96 bytes per lane.  Asked for where nothing urgent is
 // behind them, the rows still arrive long before the second pair's gates are through their atan2.  Measured at 100 000 x 2 000,
 // three interleaved repetitions on one box: 9.96 (0) -> 9.83 (1) -> 9.71 (2) -> 9.465 ms per step (4), kernel 9.80 -> 9.30 ms.
 #ifndef PK_PUB_LATE_P1
-#define PK_PUB_LATE_P1 4
+#define PK_PUB_LATE_P1 7
 #endif
 #ifndef PK_PUB_P0_WHERE  // diagnostic: where the NEXT particle's first pair is asked for (0: behind the first pair's stores)
 #define PK_PUB_P0_WHERE 0
@@ -1149,6 +1150,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])                                                                      \
         }                                                                                                                          \
       }                                                                                                                            \
+      if constexpr (PK_PUB_LATE_P1 == 6 && NP > 1) {                                                                               \
+        if ((q) == 0) { /* diagnostic: the second pair's MEANS behind the first pair's gates, its other rows as in 4 */            \
+          PK_PUB_LOAD_MEANS(1, sslot, lbase[1])                                                                                    \
+        }                                                                                                                          \
+      }                                                                                                                            \
       if constexpr (PK_PUB_LATE_P1 == 1 && NP > 1) {                                                                               \
         if ((q) == 0) { /* the second pair's rows asked for behind the first pair's GATES (diagnostic variant) */                  \
           PubArgsPtr R7 = pub_args_now(rp);                                                                                        \
@@ -1176,6 +1182,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         if (!done) {  // workgroup-uniform
           PK_PUB_PAIR(0)
           if constexpr (NP > 1) {
+            if constexpr (PK_PUB_LATE_P1 == 7) {  // (diagnostic: means in front of the candidate records, the other rows behind)
+              PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
+            }
             if constexpr (PK_PUB_LATE_P1 == 2) {  // (the second pair's rows behind the first pair's keys)
               PubArgsPtr R7 = pub_args_now(rp);
               PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
@@ -1185,6 +1194,16 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
               asm volatile("" ::: "memory");
               PubArgsPtr R7 = pub_args_now(rp);
               PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
+            }
+            if constexpr (PK_PUB_LATE_P1 == 7) {
+              asm volatile("" ::: "memory");
+              PubArgsPtr R7 = pub_args_now(rp);
+              PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])
+            }
+            if constexpr (PK_PUB_LATE_P1 == 6) {  // (diagnostic: see above)
+              asm volatile("" ::: "memory");
+              PubArgsPtr R7 = pub_args_now(rp);
+              PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])
             }
             if constexpr (PK_PUB_LATE_P1 == 5) {  // (diagnostic: the means there, the covariance rows behind the second pair's gates)
               asm volatile("" ::: "memory");
