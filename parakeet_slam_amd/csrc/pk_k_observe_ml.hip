@@ -6,6 +6,14 @@
 // section 4.  No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
 #include "pk_device.hpp"
 
+// k_step_fused: where the lane's covariance rows are asked for -- 0: with the means, right behind the table words' requests
+// (rounds 1-3); 1 (default, round 4): when this wave's table words have ARRIVED (the rows of the early waves no longer stand in the
+// texture addresser's queue in front of the late waves' table words, which the whole workgroup waits for: 0.2423 -> 0.2406 ms at
+// 10 000 x 500, three interleaved repetitions); 3: behind the gates (0.277 ms: the settling waits for them).
+#ifndef PK_FUSED_LATE_COV
+#define PK_FUSED_LATE_COV 1
+#endif
+
 namespace pk {
 
 // ------------------------------------------------------------------ K3 (fast ML variant, L <= 512)
@@ -504,7 +512,21 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
     }
     // unconditional too (lanes beyond the map read its last landmark and never use or store it):
     // straight-line code, so that the wait below is vmcnt(15) -- table words only
+#if PK_FUSED_LATE_COV
+    // (round 4, as in k_step_pub: the covariance rows -- not needed before the settling -- are asked for only when
+    // this wave's table words have arrived, so that they do not stand in the texture addresser's queue in front of the OTHER
+    // waves' table words, which the whole workgroup waits for at the barrier below)
+    {
+      const int lq = min(l, Lp - 1);
+      A.mx = sf[F_MX * Lp + lq];
+      A.my = sf[F_MY * Lp + lq];
+      A.mr = sf[F_MR * Lp + lq];
+      A.mg = sf[F_MG * Lp + lq];
+      A.mb = sf[F_MB * Lp + lq];
+    }
+#else
     A = load_landmark_means_first(sf, sc, Lp, min(l, Lp - 1));
+#endif
     immA = a.immutable[min(l, a.L - 1)];
     if (!a.reset) lw0 = a.logw[p];  // requested with the state: read at the very end it would wait for every store of the wave
     // the table words are needed HERE (keeps the compiler from sinking each load into its
@@ -513,6 +535,22 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
     for (int j = 0; j < kTabBatch; ++j) asm volatile("" : "+v"(tw[j].x), "+v"(tw[j].y), "+v"(tw[j].z), "+v"(tw[j].w)::"memory");
     PK_STAMP(h1)
     PK_FSTAMP_ADD(15, h0, h1)  // table words arrived
+#if PK_FUSED_LATE_COV == 1
+    {
+      const int lq = min(l, Lp - 1);
+      A.pxx = sf[F_PXX * Lp + lq];
+      A.pxy = sf[F_PXY * Lp + lq];
+      A.pyy = sf[F_PYY * Lp + lq];
+      A.crr = sf[F_CRR * Lp + lq];
+      A.crg = sf[F_CRG * Lp + lq];
+      A.crb = sf[F_CRB * Lp + lq];
+      A.cgg = sf[F_CGG * Lp + lq];
+      A.cgb = sf[F_CGB * Lp + lq];
+      A.cbb = sf[F_CBB * Lp + lq];
+      A.count = sc[lq];
+      asm volatile("" ::: "memory");
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < kTabBatch; ++j) {
       const unsigned i = (unsigned)tid + (unsigned)j * kFastThreads;
@@ -643,6 +681,22 @@ __global__ void __launch_bounds__(kFastThreads) __attribute__((amdgpu_waves_per_
     PK_STAMP(g2)
     PK_FSTAMP_ADD(3, g1, g2)  // exact gates
   }
+#if PK_FUSED_LATE_COV == 3  // (experiment: the covariance rows behind the gates)
+  {
+    const int lq = min(l, Lp - 1);
+    A.pxx = sf[F_PXX * Lp + lq];
+    A.pxy = sf[F_PXY * Lp + lq];
+    A.pyy = sf[F_PYY * Lp + lq];
+    A.crr = sf[F_CRR * Lp + lq];
+    A.crg = sf[F_CRG * Lp + lq];
+    A.crb = sf[F_CRB * Lp + lq];
+    A.cgg = sf[F_CGG * Lp + lq];
+    A.cgb = sf[F_CGB * Lp + lq];
+    A.cbb = sf[F_CBB * Lp + lq];
+    A.count = sc[lq];
+    asm volatile("" ::: "memory");
+  }
+#endif
   PK_STAMP(f2)
   lds_barrier();
   PK_STAMP(f3)

@@ -115,6 +115,11 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_BIG_OVF
 #define PK_PUB_BIG_OVF 0
 #endif
+// k_step_pub_big, pass 1: a chunk's covariance rows with its means (0, default) or behind its candidate records (1: measured at
+// 20 000 x 5 000, 8.33 against 8.08 ms per launch -- here the keys follow the gates too closely for the rows to come later).
+#ifndef PK_BIG_LATE_COV
+#define PK_BIG_LATE_COV 0
+#endif
 #ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
 #define PK_PUB_ILV 0
 #endif
@@ -1693,6 +1698,39 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     SB.count = c_.y;                                                                                  \
     asm volatile("" ::: "memory");                                                                    \
   }
+#define PK_BIG_MEANS(SA, SB, lb_, src_)                                                               \
+  {                                                                                                   \
+    PubArgsPtr R2 = pub_args_now(rp);                                                                 \
+    const SlotSource ss_ = pub_slot_source(R2);                                                       \
+    const double* sf_ = reinterpret_cast<const double*>(ss_.at(src_));                                \
+    PK_BIG_LOAD(SA, SB, mx, F_MX, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, my, F_MY, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, mr, F_MR, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, mg, F_MG, lb_)                                                                \
+    PK_BIG_LOAD(SA, SB, mb, F_MB, lb_)                                                                \
+    asm volatile("" ::: "memory");                                                                    \
+  }
+#define PK_BIG_COVS(SA, SB, lb_, src_)                                                                \
+  {                                                                                                   \
+    PubArgsPtr R2 = pub_args_now(rp);                                                                 \
+    const SlotSource ss_ = pub_slot_source(R2);                                                       \
+    const unsigned char* sslot_ = ss_.at(src_);                                                       \
+    const double* sf_ = reinterpret_cast<const double*>(sslot_);                                      \
+    const int* sc_ = reinterpret_cast<const int*>(sslot_ + R2->count_off);                            \
+    PK_BIG_LOAD(SA, SB, pxx, F_PXX, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, pxy, F_PXY, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, pyy, F_PYY, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, crr, F_CRR, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, crg, F_CRG, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, crb, F_CRB, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, cgg, F_CGG, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, cgb, F_CGB, lb_)                                                              \
+    PK_BIG_LOAD(SA, SB, cbb, F_CBB, lb_)                                                              \
+    const Int2 c_ = *reinterpret_cast<const Int2*>(sc_ + (lb_));                                      \
+    SA.count = c_.x;                                                                                  \
+    SB.count = c_.y;                                                                                  \
+    asm volatile("" ::: "memory");                                                                    \
+  }
 #define PK_BIG_LOAD(SA, SB, field, F, lb_)                                                            \
   {                                                                                                   \
     const Double2 v_ = *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_));               \
@@ -1767,6 +1805,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[1].ew[0] = er[2];
           gi[1].ew[1] = er[3];
           asm volatile("" ::: "memory");
+#if PK_BIG_LATE_COV
+          // (round 4: this chunk's covariance rows behind its candidate records -- the gates need the records and the means at
+          // once, the other rows not before the keys)
+          if (q > 0) PK_BIG_COVS(SA, SB, min(l0, Lp - 2), csrc)
+#endif
           if (q == 0) {  // the next particle's source slot (as in k_step_pub)
             PubArgsPtr R4 = pub_args_now(rp);
             const int64_t pn = p + gridDim.x;
@@ -1813,7 +1856,15 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           {  // the next pair of this pass, or the first one of pass 2
             const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
             const int ln = min((more ? 2 * kPubThreads * (q + 1) : 0) + 2 * tid, Lp - 2);
+#if PK_BIG_LATE_COV
+            if (more) {
+              PK_BIG_MEANS(SA, SB, ln, csrc)
+            } else {
+              PK_BIG_ROWS(SA, SB, ln, csrc)
+            }
+#else
             PK_BIG_ROWS(SA, SB, ln, csrc)
+#endif
           }
         }
 #pragma unroll
@@ -1930,6 +1981,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     }
 #undef PK_BIG_STORE
 #undef PK_BIG_ROWS
+#undef PK_BIG_MEANS
+#undef PK_BIG_COVS
 #undef PK_BIG_LOAD
     {
       const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier A
