@@ -26,7 +26,7 @@ bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -2; cp gpurun_out/pmc_traffic_10000
 PMC_P=20000 PMC_L=5000 bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_20000x5000.json gpurun_out/r04/
 fi
 if [[ $PARTS == *d* ]]; then
-for cfg in "51200 2000 200" "20480 5000 80"; do
+for cfg in "51200 2000 200" "20480 5000 80" "10240 500 40"; do
 set -- $cfg
 PMC_P=$1 PMC_L=$2 bash scripts/gpu_pmc_sq.sh > /dev/null 2>&1; PP=$1 LL=$2 PER=$3 python3 - <<'PY'
 import json, os
