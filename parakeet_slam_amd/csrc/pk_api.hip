@@ -148,7 +148,7 @@ struct pk_filter {
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
-  unsigned* glist_dev = nullptr; // [bcand_cap + 1] the same for the blobs several landmarks list, compacted; then their number
+  unsigned* glist_dev = nullptr; // [bcand_cap + 1 + 64] the same for the blobs several landmarks list, compacted; then their number; then k_step_pub's octet order (128 u16)
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
   struct Split {
     bool active = false;
@@ -1315,7 +1315,7 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
     if ((rc = dev_alloc(f, &f->bcnt_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->binfo_dev, (size_t)cap))) return rc;
-    if ((rc = dev_alloc(f, &f->glist_dev, (size_t)cap + 1))) return rc;
+    if ((rc = dev_alloc(f, &f->glist_dev, (size_t)cap + 1 + 64))) return rc;
     f->bcand_cap = cap;
   }
   return PK_OK;

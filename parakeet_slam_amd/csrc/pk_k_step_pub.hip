@@ -102,6 +102,14 @@ __device__ __forceinline__ void pub_pad() {
 // row stores and what the gates need at once -- the candidate records, 96 bytes per lane.  Asked for where nothing urgent is
 // behind them, the rows still arrive long before the second pair's gates are through their atan2.  Measured at 100 000 x 2 000,
 // three interleaved repetitions on one box: 9.96 (0) -> 9.83 (1) -> 9.71 (2) -> 9.465 ms per step (4), kernel 9.80 -> 9.30 ms.
+// 1: the lanes of k_step_pub<2, 512> take their landmarks through the scan's octet order (k_cand_entries): long candidate lists
+// to waves 0-3, short ones to waves 4-7.  0: lane t has landmarks 2 t, 2 t + 1, 1024 + 2 t, 1025 + 2 t
+#ifndef PK_PUB_PERM
+#define PK_PUB_PERM 3
+#endif
+#ifndef PK_PUB_PERM_MECH
+#define PK_PUB_PERM_MECH 0
+#endif
 #ifndef PK_PUB_LATE_P1
 #define PK_PUB_LATE_P1 7
 #endif
@@ -125,6 +133,7 @@ __device__ __forceinline__ void pub_pad() {
 #endif
 constexpr int kPubThreads = 512;        // the large instances' workgroup
 constexpr int kPubSmallThreads = 256;   // ... the L <= 512 instance's
+constexpr int kPubOctets = 64;  // groups of eight lanes in a 512-lane workgroup: sixteen adjacent landmarks per pair each
 constexpr int kPubSlots = 4;  // gate-passing blobs a landmark keeps; more: the particle is flagged
 
 typedef double Double2 __attribute__((ext_vector_type(2)));
@@ -286,6 +295,52 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
         }
       }
       e[k] = (unsigned short)ev;
+    }
+  }
+  // The lane order of k_step_pub<2, 512>: 128 places of eight lanes -- sixteen landmarks, an "octet" -- each, place 8 w + k of
+  // pair q being lanes 8 k ... 8 k + 7 of wave w.  The octets are ranked by their longest candidate list (then by the sum of
+  // their lists) and dealt out eight at a time: the sixteen (wave, pair) groups get octets of like cost -- a wave's gate and
+  // verdict loops run as long as its longest list --, the eight costliest groups go to waves 0-3, the others to waves 4-7.
+  if constexpr (SLOTS == kCandSlots) {
+    __shared__ int s_cost[2 * kPubOctets];
+    unsigned short* perm = reinterpret_cast<unsigned short*>(a.glist + a.B + 1);
+    const int n_oct = a.Lp / 16;
+    if (n_oct <= 2 * kPubOctets) {  // (uniform)
+      if (tid < 2 * kPubOctets) {
+        int c = -1;
+        if (tid < n_oct) {
+          int longest = 0, sum = 0;
+          for (int i = 0; i < 16; ++i) {
+            const int l = 16 * tid + i;
+            if (l >= a.L) break;
+            const unsigned* cws = reinterpret_cast<const unsigned*>(a.cand + RW * (size_t)l + 1);
+            int n = 0;
+#pragma unroll
+            for (int k = 0; k < SLOTS; ++k) n += ((cws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0xFFFFu ? 1 : 0;
+            longest = max(longest, n);
+            sum += n;
+          }
+          c = longest * 256 + sum;
+        }
+        s_cost[tid] = c;
+        perm[tid] = 0xFFFFu;  // a place without an octet: its lanes are beyond the map
+      }
+      __syncthreads();
+      if (tid < n_oct) {
+        const int c = s_cost[tid];
+        int r = 0;
+        for (int o = 0; o < 2 * kPubOctets; ++o) r += (s_cost[o] > c || (s_cost[o] == c && o < tid)) ? 1 : 0;
+        const int g = r >> 3, k = r & 7;
+        int wave = g < 8 ? (g >> 1) : 4 + ((g - 8) >> 1), pair = g & 1;
+        if (PK_PUB_PERM == 2) wave = 7 - wave;                 // (diagnostic: the costly octets to waves 4-7)
+        if (PK_PUB_PERM == 3) wave = g & 7, pair = g >> 3;     // (diagnostic: every wave one costly and one cheap group)
+        if (PK_PUB_PERM == 5) {  // the four SIMDs (waves s and s + 4) get like sums: groups s, 7 - s, 8 + s, 15 - s of the ranking
+          wave = g < 4 ? g : g < 8 ? 11 - g : g < 12 ? g - 4 : 15 - g;
+          pair = g >> 3;
+        }
+        if (PK_PUB_PERM == 4) wave = (tid >> 3) & 7, pair = tid >> 6;  // (diagnostic: the identity, through the table)
+        perm[kPubOctets * pair + 8 * wave + (PK_PUB_PERM == 4 ? (tid & 7) : k)] = (unsigned short)tid;
+      }
     }
   }
 }
@@ -916,6 +971,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[2][kPubWaves];
   __shared__ int wg_flag[2];
+  // Which sixteen landmarks each group of eight lanes works on (<2, 512> only; k_cand_entries, once per scan): the octets with
+  // the LONGEST candidate lists go to waves 0-3, the shortest to waves 4-7 -- the waves that come second in the CU's vector
+  // memory queue all particle long, and that the others wait for at every barrier
+  constexpr bool kPerm = PK_PUB_PERM != 0 && NP == 2 && THREADS == 512;
+  __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets : 1];
+#define PK_PUB_L0(q_, t_) (kPerm ? (int)(((lw >> (kOctShift + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7) : 2 * kPubThreads * (q_) + 2 * (t_))
+  // (PK_PUB_PERM_MECH: where the two octet numbers live -- 0: above the lane index in one register, 1: in a register of their
+  // own, 2: below the lane index)
+  constexpr int kOctShift = PK_PUB_PERM_MECH == 0 ? 16 : 0;
   PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid0 = threadIdx.x;
   int B, Lp, L, ecap;
@@ -954,6 +1018,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     // and row request in flight (one in-order vector memory counter)
     const unsigned char* gi = R->immutable;
     for (int i = tid; i < Lp; i += kPubThreads) smem[o_imm + (unsigned)i] = i < L ? gi[i] : (unsigned char)0;
+    if constexpr (kPerm) {
+      if (tid < 2 * kPubOctets) s_perm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[tid];
+    }
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -1040,18 +1107,35 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   // the registers that store has just freed -- so its rows fly while the second pair is updated and stored.
   Landmark<double> S[2 * NP];
   constexpr int kPipe = 1;  // pairs asked for ahead (both: 58 registers spilled)
+  // the lane's index and (kPerm) the octets of its two pairs in one register: tid | octet of pair 0 << 16 | of pair 1 << 24
+  // (0xFF: none, the lane is beyond the map) -- read from LDS at every use the table cost 1.3 % of the kernel's time
+  unsigned lane_word = (unsigned)tid0;
+  if constexpr (kPerm) {
+    const unsigned octs = (unsigned)(s_perm[tid0 >> 3] & 0xFFu) | ((unsigned)(s_perm[kPubOctets + (tid0 >> 3)] & 0xFFu) << 8);
+    lane_word = PK_PUB_PERM_MECH == 0 ? ((unsigned)tid0 | (octs << 16)) : PK_PUB_PERM_MECH == 1 ? octs : (((unsigned)tid0 << 16) | octs);
+  }
   {
+    const unsigned lw = lane_word;
     PubArgsPtr R = pub_args_now(rp);
     const unsigned char* ns = pub_slot_source(R).at(nsrc);
     const int coff = R->count_off;
 #pragma unroll
-    for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(2 * kPubThreads * q + 2 * tid0, Lp - 2))
+    for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(PK_PUB_L0(q, tid0), Lp - 2))
   }
   for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
     // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
     // occupy registers for the whole kernel)
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
+    unsigned lw = lane_word;
+    asm volatile("" : "+v"(lw));
+    int tid;
+    if constexpr (!kPerm) {
+      tid = (int)lw;
+    } else if constexpr (PK_PUB_PERM_MECH == 1) {
+      tid = tid0;
+      asm volatile("" : "+v"(tid));
+    } else {
+      tid = PK_PUB_PERM_MECH == 0 ? (int)(lw & 0xFFFFu) : (int)(lw >> 16);
+    }
     double* ex = reinterpret_cast<double*>(smem);
     double* pub = reinterpret_cast<double*>(smem + o_pub);
     const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_binfo);
@@ -1079,7 +1163,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         // never use or store it)
         int lbase[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) lbase[q] = min(2 * kPubThreads * q + 2 * tid, Lp - 2);
+        for (int q = 0; q < NP; ++q) lbase[q] = min(PK_PUB_L0(q, tid), Lp - 2);
         // ---- 1. requests: candidate records (L2), the means of all four landmarks, then the covariance rows
         // (the first pair's now, in front of the rows; the second pair's behind the first pair's verdicts -- by then every row has
         // arrived, and twelve registers fewer are live while the verdicts are worked out)
@@ -1091,7 +1175,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #ifdef PK_DIAG_TAIL_LISTS  // diagnostic build only: round 3's indexing, to show that the regression test bites
           const int lc = lbase[q];
 #else
-          const int lc = min(2 * kPubThreads * q + 2 * tid, Lp);
+          const int lc = min(PK_PUB_L0(q, tid), Lp);
 #endif
           const uint4* cr = R2->cand + 2 * (size_t)lc;
           const uint4* er = R2->erec + lc;
@@ -1124,7 +1208,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         // (written out per pair: as nested unrolled loops the slot words were not promoted to registers)
 #define PK_PUB_PAIR(q)                                                                                                           \
   {                                                                                                                              \
-    const int l0 = 2 * kPubThreads * (q) + 2 * tid;                                                                              \
+    const int l0 = PK_PUB_L0((q), tid);                                                                              \
     const PubGateIn gi[2] = {{cref[2 * (q)], {ccw[2 * (q)], ccw[2 * (q)]}, {cew[2 * (q)], cew[2 * (q)]}, S[2 * (q)].mx, S[2 * (q)].my,    \
                               S[2 * (q)].mr, S[2 * (q)].mg, S[2 * (q)].mb, l0 < L},                                               \
                              {cref[2 * (q) + 1], {ccw[2 * (q) + 1], ccw[2 * (q) + 1]}, {cew[2 * (q) + 1], cew[2 * (q) + 1]},       \
@@ -1281,7 +1365,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         const unsigned char* ns = pub_slot_source(R6).at(nsrc);
         const int coff = R6->count_off;
 #pragma unroll
-        for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
+        for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(PK_PUB_L0(q, tid), Lp - 2))
       }
       continue;
     }
@@ -1302,7 +1386,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         // eight waves reach that burst together, the CU's one texture-addresser path takes ~16 cycles per 1 KB instruction,
         // and a wave that stands in that queue issues no arithmetic (12.7 % of a particle's time by the stamps, round 3).
         // In thirds the queue has drained by the time the wave comes back with the next one.
-        const int l00 = 2 * tid, l01 = 2 * kPubThreads + 2 * tid;
+        const int l00 = PK_PUB_L0(0, tid), l01 = PK_PUB_L0(1, tid);
 #define PK_ILV_APPLY(i, l)                                                                                    \
   if (PK_PUB_ABLATE < 1) acc += pub_apply(Q[i], ex, order, qt, S[i], immutable[min((l), Lp - 1)] != 0, sx, sy, pse[i]);
 #define PK_ILV_STORE(q, l0_, field, F)                                                                        \
@@ -1349,7 +1433,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         {  // the next particle's first pair, into the registers just stored
           PubArgsPtr R6 = pub_args_now(rp);
           const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
+          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
         }
         PK_ILV_APPLY(3, l01 + 1)
 #else
@@ -1358,7 +1442,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         {  // the next particle's first pair, into the registers just stored
           PubArgsPtr R6 = pub_args_now(rp);
           const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
+          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
         }
 #endif
         asm volatile("" ::: "memory");
@@ -1400,7 +1484,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          const int l0 = 2 * kPubThreads * q + 2 * tid;
+          const int l0 = PK_PUB_L0(q, tid);
           if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
           const bool imm0 = immutable[min(l0, Lp - 1)] != 0, imm1 = immutable[min(l0 + 1, Lp - 1)] != 0;
           unsigned tk0 = Q[2 * q].st & 0x4444u, tk1 = Q[2 * q + 1].st & 0x4444u;  // blobs still to be applied
@@ -1483,7 +1567,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           if (q < kPipe) {  // the next particle's pair, into the registers just stored
             PubArgsPtr R6 = pub_args_now(rp);
             const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-            PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
+            PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(PK_PUB_L0(q, tid), Lp - 2))
           }
           PK_STAMP(su1_)
           PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
@@ -1493,7 +1577,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       } else {  // the 256-lane instance (and diagnostic builds): round 3's order, a pair's rows out behind both its updates
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-          const int l0 = 2 * kPubThreads * q + 2 * tid;
+          const int l0 = PK_PUB_L0(q, tid);
           if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
@@ -1507,7 +1591,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           if (PK_PUB_P0_WHERE == 1 && NP == 2 && q == 1) {  // (diagnostic: the next first pair in front of the second pair's stores)
             PubArgsPtr R6 = pub_args_now(rp);
             const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
+            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
           }
           if (l0 < Lp) {
 #if defined(PK_PUB_STORE_FLAVOUR)  // diagnostic variants: -DPK_PUB_STORE_FLAVOUR='"sc1"' ...
@@ -1550,12 +1634,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           if (q < kPipe && (PK_PUB_P0_WHERE == 0 || NP == 1)) {  // the next particle's pair, into the registers just stored
             PubArgsPtr R6 = pub_args_now(rp);
             const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-            PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(2 * kPubThreads * q + 2 * tid, Lp - 2))
+            PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(PK_PUB_L0(q, tid), Lp - 2))
           }
           if (PK_PUB_P0_WHERE == 2 && NP == 2 && q == 1) {  // (diagnostic: ... behind the second pair's stores)
             PubArgsPtr R6 = pub_args_now(rp);
             const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(2 * tid, Lp - 2))
+            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
           }
           PK_STAMP(su1_)
           PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
