@@ -148,6 +148,7 @@ struct pk_filter {
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
+  float4* gate4_dev = nullptr;   // [bcand_cap] every blob's bearing and colour as float: k_step_pub_big's first look (k_cand_entries)
   unsigned* glist_dev = nullptr; // [bcand_cap + 1 + 64] the same for the blobs several landmarks list, compacted; then their number; then k_step_pub's octet order (128 u16)
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
   struct Split {
@@ -959,7 +960,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1304,8 +1305,9 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
   B = B * (slots / kCandSlots);  // (capacity in units of eight-entry lists: sixteen-entry lists take two)
   if (B > f->bcand_cap) {
     PK_HIP(hipStreamSynchronize(f->stream));
-    for (void* q : {(void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->binfo_dev, (void*)f->glist_dev})
+    for (void* q : {(void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev})
       if (q) (void)hipFree(q);
+    f->gate4_dev = nullptr;
     f->bcnt_dev = nullptr;
     f->brec_dev = nullptr;
     f->binfo_dev = nullptr;
@@ -1316,6 +1318,7 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
     if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->binfo_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->glist_dev, (size_t)cap + 1 + 64))) return rc;
+    if ((rc = dev_alloc(f, &f->gate4_dev, (size_t)cap))) return rc;
     f->bcand_cap = cap;
   }
   return PK_OK;
@@ -1339,7 +1342,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
                       2 * kCandSlots, f->out4);
     launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots);
+                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev);
     cand->rec = f->cand_dev;
     cand->over = ctl_cand_over(f);
     cand->slots = 2 * kCandSlots;
@@ -1381,7 +1384,7 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
   ObserveExtras e1 = ex;
   e1.flip = false;
   if (al.big) {
-    launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_pub(f), f->pub_ecap);
+    launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_pub(f), f->pub_ecap, f->gate4_dev);
     // a scan the kernel stood back from (a list overflowed, the table did not fit): every particle to the fall-back kernels
     launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, 0, f->d.P);
   } else if (al.regs) {

@@ -107,6 +107,10 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_PERM
 #define PK_PUB_PERM 3
 #endif
+// k_step_pub_big: 1 = the gates look at a candidate's float copy first (one gather of 16 bytes), 0 = at its exact record (two)
+#ifndef PK_BIG_GATE4
+#define PK_BIG_GATE4 1
+#endif
 #ifndef PK_PUB_PERM_MECH
 #define PK_PUB_PERM_MECH 0
 #endif
@@ -163,6 +167,7 @@ struct PubArgs {
   const uint4* erec;            // [Lp]: 8 x u16 publish entries of those blobs (0xFFFF: nobody else lists the blob)
   const unsigned* glist;        // [B + 1]: the blobs at least two landmarks list: first entry | contenders << 16; [B]: how many
   const unsigned* skip;         // != 0: this scan is not ours (a list overflowed, or the table does not fit)
+  const float4* gate4;          // [B] k_step_pub_big: bearing, r, g, b as float (NaN: out of the range the margins cover), else null
   unsigned char* pflag_out;     // [P] 1 = general route
   unsigned* n_flagged;
   int64_t P, p_begin;
@@ -207,6 +212,8 @@ struct CandEntriesArgs {
   unsigned* binfo;        // [B] per blob: first entry | contenders << 16 (scratch of this kernel)
   unsigned* glist;        // [B] the blobs at least two landmarks list, compacted: first entry | contenders << 16; [B] = their number
   const unsigned* over;   // candidate-list overflow
+  const double* exact;    // [B][6] the scan's records (for gate4), or null
+  float4* gate4;          // [B] out: the gate quantities of every blob as float (k_step_pub_big's first look), or null
   unsigned* skip_pub;
   unsigned* skip_cand;
   int L, Lp, B, ecap;
@@ -297,6 +304,18 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       e[k] = (unsigned short)ev;
     }
   }
+  // k_step_pub_big's first look at a candidate: bearing and colour as FLOAT, 16 bytes in one gather instead of 32 in two (the
+  // kernel is bound by the texture addresser's gathers, one cache line a cycle: DESIGN.md section 4).  The margins of that
+  // look (pub_gatesN<GT>) hold for |bearing| <= 8 and |colour| <= 1000; any other blob -- NaN and infinities included -- gets
+  // NaN here and is always looked at exactly.
+  if (a.gate4) {
+    for (int t = tid; t < a.B; t += 1024) {
+      const double z0 = a.exact[6 * (size_t)t], z1 = a.exact[6 * (size_t)t + 1], z2 = a.exact[6 * (size_t)t + 2], z3 = a.exact[6 * (size_t)t + 3];
+      const bool ok = fabs(z0) <= 8.0 && fabs(z1) <= 1000.0 && fabs(z2) <= 1000.0 && fabs(z3) <= 1000.0;  // NaN: false
+      const float nanf_ = __uint_as_float(0x7FC00000u);
+      a.gate4[t] = ok ? make_float4((float)z0, (float)z1, (float)z2, (float)z3) : make_float4(nanf_, nanf_, nanf_, nanf_);
+    }
+  }
   // The lane order of k_step_pub<2, 512>: 128 places of eight lanes -- sixteen landmarks, an "octet" -- each, place 8 w + k of
   // pair q being lanes 8 k ... 8 k + 7 of wave w.  The octets are ranked by their longest candidate list (then by the sum of
   // their lists) and dealt out eight at a time: the sixteen (wave, pair) groups get octets of like cost -- a wave's gate and
@@ -347,8 +366,10 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
 
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
-                         unsigned* skip_cand_dev, int ecap, int slots) {
+                         unsigned* skip_cand_dev, int ecap, int slots, const double* exact_dev, float4* gate4_dev) {
   CandEntriesArgs a;
+  a.exact = exact_dev;
+  a.gate4 = exact_dev ? gate4_dev : nullptr;
   a.cand = cand_dev;
   a.erec = reinterpret_cast<unsigned short*>(erec_dev);
   a.bcnt = bcnt_dev;
@@ -413,9 +434,12 @@ struct PubGateIn {
 // OVF: a landmark may pass MORE blobs than it has slots without the particle being flagged: bits 16.. of its slots' state word
 // say which of its candidates passed, and pub_refill_slots brings in the ones the slots no longer hold (round 4: what flagged up to 13 % of the
 // particles on some stretches of the bench's trajectory and sent them through the second-chance kernels).
-template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false>
+// GT: the first look at a candidate goes to the float table gt (see k_cand_entries): certain either way for all but a candidate in
+// a million, and only a wave with an uncertain one reads exact records (ex is global memory then, k_step_pub_big)
+template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false, bool GT = false>
 __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
-                                           double* pub, unsigned dump, int* flag, double sx, double sy, double sh) {
+                                           double* pub, unsigned dump, int* flag, double sx, double sy, double sh,
+                                           const float4* gt = nullptr) {
   constexpr int NW = 4 * W4;  // 32-bit words per list, two candidates each
   double eb[N];
   bool inside[N];
@@ -467,16 +491,45 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
       const unsigned ta = c[j][kk] & 0xFFFFu, tb = c[j][kk] >> 16;
       const unsigned ea = e[j][kk] & 0xFFFFu, eb2 = e[j][kk] >> 16;  // (0xFFFF where the blob is: k_cand_entries)
       const bool va = ta != 0xFFFFu, vb = tb != 0xFFFFu;
-      const double* ra = ex + 6 * (va ? ta : 0u);
-      const double* rb = ex + 6 * (vb ? tb : 0u);
-      const double2 a01 = *reinterpret_cast<const double2*>(ra);
-      const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
-      const double2 b01 = *reinterpret_cast<const double2*>(rb);
-      const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
-      const double cda = color_distance2(in[j].mr, in[j].mg, in[j].mb, a01.y, a23.x, a23.y);
-      const double cdb = color_distance2(in[j].mr, in[j].mg, in[j].mb, b01.y, b23.x, b23.y);
-      const bool pa = va && !(fabs(a01.x - eb[j]) > 0.5) && !(fabs(cda) > 300.0);
-      const bool pb = vb && !(fabs(b01.x - eb[j]) > 0.5) && !(fabs(cdb) > 300.0);
+      double cda, cdb;
+      bool pa, pb;
+      if constexpr (GT) {
+        // float values within 2^-24 relative of the record's: the bearing within 4.8e-7, a colour within 6e-5, the squared colour
+        // distance -- components below 17.4 where it matters -- within 6.3e-3; beyond 300.01 the error grows more slowly than
+        // the distance.  (The order of the slots follows the float distances: it decides nothing.)
+        const float4 fa = gt[va ? ta : 0u], fb = gt[vb ? tb : 0u];
+        cda = color_distance2(in[j].mr, in[j].mg, in[j].mb, (double)fa.y, (double)fa.z, (double)fa.w);
+        cdb = color_distance2(in[j].mr, in[j].mg, in[j].mb, (double)fb.y, (double)fb.z, (double)fb.w);
+        const double dba = fabs((double)fa.x - eb[j]), dbb = fabs((double)fb.x - eb[j]);
+        const bool out_a = dba > 0.5 + 1e-6 || cda > 300.01, in_a = dba < 0.5 - 1e-6 && cda < 299.99;  // NaN: neither
+        const bool out_b = dbb > 0.5 + 1e-6 || cdb > 300.01, in_b = dbb < 0.5 - 1e-6 && cdb < 299.99;
+        pa = va && in_a;
+        pb = vb && in_b;
+        const bool ua = va && !out_a && !in_a, ub = vb && !out_b && !in_b;
+        if (__ballot(ua || ub) != 0ull) {  // wave-uniform, rare: the exact records of the uncertain ones
+          const double* ra = ex + 6 * (ua ? ta : 0u);
+          const double* rb = ex + 6 * (ub ? tb : 0u);
+          const double2 a01 = *reinterpret_cast<const double2*>(ra);
+          const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
+          const double2 b01 = *reinterpret_cast<const double2*>(rb);
+          const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
+          const double xa = color_distance2(in[j].mr, in[j].mg, in[j].mb, a01.y, a23.x, a23.y);
+          const double xb = color_distance2(in[j].mr, in[j].mg, in[j].mb, b01.y, b23.x, b23.y);
+          pa = ua ? (!(fabs(a01.x - eb[j]) > 0.5) && !(fabs(xa) > 300.0)) : pa;
+          pb = ub ? (!(fabs(b01.x - eb[j]) > 0.5) && !(fabs(xb) > 300.0)) : pb;
+        }
+      } else {
+        const double* ra = ex + 6 * (va ? ta : 0u);
+        const double* rb = ex + 6 * (vb ? tb : 0u);
+        const double2 a01 = *reinterpret_cast<const double2*>(ra);
+        const double2 a23 = *reinterpret_cast<const double2*>(ra + 2);
+        const double2 b01 = *reinterpret_cast<const double2*>(rb);
+        const double2 b23 = *reinterpret_cast<const double2*>(rb + 2);
+        cda = color_distance2(in[j].mr, in[j].mg, in[j].mb, a01.y, a23.x, a23.y);
+        cdb = color_distance2(in[j].mr, in[j].mg, in[j].mb, b01.y, b23.x, b23.y);
+        pa = va && !(fabs(a01.x - eb[j]) > 0.5) && !(fabs(cda) > 300.0);
+        pb = vb && !(fabs(b01.x - eb[j]) > 0.5) && !(fabs(cdb) > 300.0);
+      }
       pub[(pa || ea == 0xFFFFu) ? dump : ea] = pub_inf();
       pub[(pb || eb2 == 0xFFFFu) ? dump : eb2] = pub_inf();
       const unsigned wa = ta | (ea << 16), wb = tb | (eb2 << 16);
@@ -1930,7 +1983,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           qb.st &= 0xFFFFu;
 #else
           PubSlotsT<kPubBigGateSlots> qq[2];
-          pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
+          if constexpr (PK_BIG_GATE4 != 0)
+            pub_gatesN<2, 2, kPubBigGateSlots, false, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4);
+          else
+            pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
           pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
@@ -2078,7 +2134,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
 
 void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                          const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
-                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap) {
+                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev) {
   if (d.P == 0) return;
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
@@ -2102,6 +2158,7 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
   a.erec = erec_dev;
   a.glist = glist_dev;
   a.skip = skip_dev;
+  a.gate4 = gate4_dev;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
   a.P = d.P;
@@ -2153,6 +2210,7 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   a.erec = erec_dev;
   a.glist = glist_dev;
   a.skip = skip_dev;
+  a.gate4 = nullptr;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
   a.P = p1;

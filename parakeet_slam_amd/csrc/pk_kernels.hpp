@@ -237,7 +237,8 @@ int step_pub_entry_capacity_small(int B);  // ... with three 256-lane workgroups
 size_t step_pub_lds_bytes(int B, int ecap);
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
-                         unsigned* skip_cand_dev, int ecap, int slots = kCandSlots);
+                         unsigned* skip_cand_dev, int ecap, int slots = kCandSlots, const double* exact_dev = nullptr,
+                         float4* gate4_dev = nullptr);
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                      const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
@@ -251,7 +252,7 @@ int step_pub_big_entry_capacity(int B);
 size_t step_pub_big_lds_bytes(int B, int ecap);
 void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                          const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
-                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap);
+                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev = nullptr);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued
