@@ -149,7 +149,7 @@ struct pk_filter {
   uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
   float4* gate4_dev = nullptr;   // [bcand_cap] every blob's bearing and colour as float: k_step_pub_big's first look (k_cand_entries)
-  unsigned* glist_dev = nullptr; // [bcand_cap + 1 + 64] the same for the blobs several landmarks list, compacted; then their number; then k_step_pub's octet order (128 u16)
+  unsigned* glist_dev = nullptr; // [bcand_cap + 1 + 256] the same for the blobs several landmarks list, compacted; then their number; then the octet orders of k_step_pub (128 u16) and k_step_pub_big (384 u16)
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
   struct Split {
     bool active = false;
@@ -1317,7 +1317,7 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
     if ((rc = dev_alloc(f, &f->bcnt_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->binfo_dev, (size_t)cap))) return rc;
-    if ((rc = dev_alloc(f, &f->glist_dev, (size_t)cap + 1 + 64))) return rc;
+    if ((rc = dev_alloc(f, &f->glist_dev, (size_t)cap + 1 + 64 + 192))) return rc;
     if ((rc = dev_alloc(f, &f->gate4_dev, (size_t)cap))) return rc;
     f->bcand_cap = cap;
   }

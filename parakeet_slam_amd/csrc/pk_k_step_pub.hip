@@ -108,6 +108,16 @@ __device__ __forceinline__ void pub_pad() {
 #define PK_PUB_PERM 3
 #endif
 // k_step_pub_big: 1 = the gates look at a candidate's float copy first (one gather of 16 bytes), 0 = at its exact record (two)
+// k_step_pub_big: 1 = the lanes take their landmarks through the scan's octet order (as PK_PUB_PERM), 0 = lane t of chunk q has
+// landmarks 1024 q + 2 t, + 1
+#ifndef PK_BIG_PERM
+#define PK_BIG_PERM 1
+#endif
+// k_step_pub_big: 1 = gate-passing blobs whose key is certainly beyond the underflow edge take no slot (decided in the gates, from
+// the float table), 0 = the verdicts find that out, one round of gathers per slot
+#ifndef PK_BIG_GATE_FAR
+#define PK_BIG_GATE_FAR 1
+#endif
 #ifndef PK_BIG_GATE4
 #define PK_BIG_GATE4 1
 #endif
@@ -137,6 +147,7 @@ __device__ __forceinline__ void pub_pad() {
 #endif
 constexpr int kPubThreads = 512;        // the large instances' workgroup
 constexpr int kPubSmallThreads = 256;   // ... the L <= 512 instance's
+constexpr int kPubBigPlaces = 384;  // k_step_pub_big: six chunks of 64 octets (kPubBigMaxL / 16)
 constexpr int kPubOctets = 64;  // groups of eight lanes in a 512-lane workgroup: sixteen adjacent landmarks per pair each
 constexpr int kPubSlots = 4;  // gate-passing blobs a landmark keeps; more: the particle is flagged
 
@@ -320,12 +331,16 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   // pair q being lanes 8 k ... 8 k + 7 of wave w.  The octets are ranked by their longest candidate list (then by the sum of
   // their lists) and dealt out eight at a time: the sixteen (wave, pair) groups get octets of like cost -- a wave's gate and
   // verdict loops run as long as its longest list --, the eight costliest groups go to waves 0-3, the others to waves 4-7.
-  if constexpr (SLOTS == kCandSlots) {
-    __shared__ int s_cost[2 * kPubOctets];
-    unsigned short* perm = reinterpret_cast<unsigned short*>(a.glist + a.B + 1);
+  {
+    // (k_step_pub_big, SLOTS = 16: up to six chunks of 64 places -- the same ranking, chunk c takes ranks 512 c ... 512 c + 511 and
+    // wave w of it the ranks 64 w ... : all eight waves work through lists of like length at the same time)
+    constexpr bool kBig = SLOTS != kCandSlots;
+    constexpr int kPlaces = kBig ? kPubBigPlaces : 2 * kPubOctets;
+    __shared__ int s_cost[kPlaces];
+    unsigned short* perm = reinterpret_cast<unsigned short*>(a.glist + a.B + 1) + (kBig ? 2 * kPubOctets : 0);
     const int n_oct = a.Lp / 16;
-    if (n_oct <= 2 * kPubOctets) {  // (uniform)
-      if (tid < 2 * kPubOctets) {
+    if (n_oct <= kPlaces) {  // (uniform)
+      if (tid < kPlaces) {
         int c = -1;
         if (tid < n_oct) {
           int longest = 0, sum = 0;
@@ -348,17 +363,21 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       if (tid < n_oct) {
         const int c = s_cost[tid];
         int r = 0;
-        for (int o = 0; o < 2 * kPubOctets; ++o) r += (s_cost[o] > c || (s_cost[o] == c && o < tid)) ? 1 : 0;
-        const int g = r >> 3, k = r & 7;
-        int wave = g < 8 ? (g >> 1) : 4 + ((g - 8) >> 1), pair = g & 1;
-        if (PK_PUB_PERM == 2) wave = 7 - wave;                 // (diagnostic: the costly octets to waves 4-7)
-        if (PK_PUB_PERM == 3) wave = g & 7, pair = g >> 3;     // (diagnostic: every wave one costly and one cheap group)
-        if (PK_PUB_PERM == 5) {  // the four SIMDs (waves s and s + 4) get like sums: groups s, 7 - s, 8 + s, 15 - s of the ranking
-          wave = g < 4 ? g : g < 8 ? 11 - g : g < 12 ? g - 4 : 15 - g;
-          pair = g >> 3;
+        for (int o = 0; o < kPlaces; ++o) r += (s_cost[o] > c || (s_cost[o] == c && o < tid)) ? 1 : 0;
+        if constexpr (kBig) {
+          perm[PK_BIG_PERM != 0 ? r : tid] = (unsigned short)tid;  // place = chunk 64 + wave 8 + k = the rank itself
+        } else {
+          const int g = r >> 3, k = r & 7;
+          int wave = g < 8 ? (g >> 1) : 4 + ((g - 8) >> 1), pair = g & 1;
+          if (PK_PUB_PERM == 2) wave = 7 - wave;                 // (diagnostic: the costly octets to waves 4-7)
+          if (PK_PUB_PERM == 3) wave = g & 7, pair = g >> 3;     // (the default: every wave one costly and one cheap group)
+          if (PK_PUB_PERM == 5) {  // the four SIMDs (waves s and s + 4) get like sums: groups s, 7 - s, 8 + s, 15 - s of the ranking
+            wave = g < 4 ? g : g < 8 ? 11 - g : g < 12 ? g - 4 : 15 - g;
+            pair = g >> 3;
+          }
+          if (PK_PUB_PERM == 4) wave = (tid >> 3) & 7, pair = tid >> 6;  // (diagnostic: the identity, through the table)
+          perm[kPubOctets * pair + 8 * wave + (PK_PUB_PERM == 4 ? (tid & 7) : k)] = (unsigned short)tid;
         }
-        if (PK_PUB_PERM == 4) wave = (tid >> 3) & 7, pair = tid >> 6;  // (diagnostic: the identity, through the table)
-        perm[kPubOctets * pair + 8 * wave + (PK_PUB_PERM == 4 ? (tid & 7) : k)] = (unsigned short)tid;
       }
     }
   }
@@ -429,7 +448,22 @@ struct PubGateIn {
   uint4 cw[2], ew[2];  // the candidate blobs and their publish entries, 16 bits each ([1] only with sixteen-entry lists)
   double mx, my, mr, mg, mb;
   bool has;
+  double fk, fi;  // GT only: the landmark's key is at least fk + fi |colour difference|^2 (pub_far_bound; -inf, 0: no bound)
 };
+// The lower bound of a landmark's keys that pub_keysN calls "far" (see there): key >= kbase + |d|^2 / rowmax for a colour block
+// that is certainly positive definite.  The same expressions as in pub_keysN -- the same values.
+__device__ __forceinline__ double pub_recip(double x);
+__device__ __forceinline__ double pub_log(double x);
+__device__ __forceinline__ void pub_far_bound(const Landmark<double>& lm, double& fk, double& fi) {
+  const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
+  double det3;
+  const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
+  const bool sane = det2 > 1e-20 && det2 < 1e60 && det3 > 1e-20 && det3 < 1e60;  // NaN: false
+  const bool pd3 = sane && lm.crr > 0.0 && adj3.f > 0.0 && lm.pxx > 0.0;
+  const double rowmax = fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))), lm.cbb + (fabs(lm.crb) + fabs(lm.cgb)));
+  fk = pd3 ? 5.0 * Consts<double>::log_two_pi + pub_log(det2 * det3) : -pub_inf();
+  fi = pd3 ? pub_recip(rowmax) : 0.0;
+}
 // N: landmarks worked on side by side; W4: uint4 words per list (1: eight candidates, 2: sixteen)
 // OVF: a landmark may pass MORE blobs than it has slots without the particle being flagged: bits 16.. of its slots' state word
 // say which of its candidates passed, and pub_refill_slots brings in the ones the slots no longer hold (round 4: what flagged up to 13 % of the
@@ -503,8 +537,14 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
         const double dba = fabs((double)fa.x - eb[j]), dbb = fabs((double)fb.x - eb[j]);
         const bool out_a = dba > 0.5 + 1e-6 || cda > 300.01, in_a = dba < 0.5 - 1e-6 && cda < 299.99;  // NaN: neither
         const bool out_b = dbb > 0.5 + 1e-6 || cdb > 300.01, in_b = dbb < 0.5 - 1e-6 && cdb < 299.99;
-        pa = va && in_a;
-        pb = vb && in_b;
+        // A blob that passes the gates but whose key is CERTAINLY beyond the underflow edge (probability 0: what pub_keysN calls
+        // far -- once a landmark's colour block has tightened, every look-alike's) is no contender and takes no slot: at several
+        // thousand blobs each landmark passes a handful of those, and each cost the verdicts a round of gathers from L2
+        // (27 % of the kernel's time, profiles/r04/stamps_k_step_pub_big_*).  The float distance is within 6.3e-3 of the exact one.
+        const bool far_a = PK_BIG_GATE_FAR != 0 && in[j].fk + (cda - 0.01) * in[j].fi > 1492.0;  // NaN: false
+        const bool far_b = PK_BIG_GATE_FAR != 0 && in[j].fk + (cdb - 0.01) * in[j].fi > 1492.0;
+        pa = va && in_a && !far_a;
+        pb = vb && in_b && !far_b;
         const bool ua = va && !out_a && !in_a, ub = vb && !out_b && !in_b;
         if (__ballot(ua || ub) != 0ull) {  // wave-uniform, rare: the exact records of the uncertain ones
           const double* ra = ex + 6 * (ua ? ta : 0u);
@@ -1775,6 +1815,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[2][kPubThreads / kWave];
   __shared__ int wg_flag[2];
+  // which sixteen landmarks the eight lanes of place 64 q + tid / 8 work on in chunk q (k_cand_entries: the octets ranked by
+  // their longest candidate list, so that a wave's -- and a chunk's -- lists are of like length)
+  __shared__ unsigned short s_bperm[kPubBigPlaces];
+#define PK_BIG_L0(q_, t_) ((int)(16u * (unsigned)s_bperm[kPubOctets * (q_) + ((t_) >> 3)]) + 2 * ((t_)&7))
   constexpr int kPubWaves = kPubThreads / kWave;
   PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid0 = threadIdx.x;
@@ -1800,6 +1844,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     G = gb[B];
     for (int i = tid; i < B; i += kPubThreads) glist[i] = (unsigned)i < G ? gb[i] : 0u;
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
+    if (tid < kPubBigPlaces) s_bperm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[2 * kPubOctets + tid];
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -1876,6 +1921,14 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   }
   int64_t prev = -1;
   int cur = 0;
+#ifdef PK_STAMPS
+  // (diagnostic build: 0 pass 1 waits for records and rows | 1 gates | 2 verdicts | 3 next rows asked for | 4 barrier A | 5 settling, B |
+  //  6 take, C | 7 pass 2 waits for rows | 8 updates | 9 particles | 10 stores, next rows asked for | 11 particle)
+  unsigned long long pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PK_BIG_WAIT_ALL asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+#define PK_BIG_WAIT_ALL
+#endif
   int32_t nsrc;  // the next particle's source slot, asked for a whole particle ahead (as in k_step_pub)
   {
     PubArgsPtr R = pub_args_now(rp);
@@ -1888,7 +1941,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   // last stores.
   Landmark<double> SA, SB;
   {
-    const int lb0 = min(2 * tid0, Lp - 2);
+    const int lb0 = min(PK_BIG_L0(0, tid0), Lp - 2);
     PK_BIG_ROWS(SA, SB, lb0, nsrc)
   }
   for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
@@ -1910,6 +1963,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
       PubArgsPtr R = pub_args_now(rp);
       done = p >= R->P;
     }
+    PK_STAMP(b0)
     // ---- pass 1: gates and verdicts, pair by pair
     // (ONE copy of the pair's code in a loop that is not unrolled -- written out per pair the kernel was 143 KB of
     // instructions, more than twice the instruction cache two CUs share -- with the carried words ROTATING through the
@@ -1920,8 +1974,9 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         PubSlots qa = kPubNoSlots, qb = kPubNoSlots;
         double pa = 0.0, pb = 0.0;
         if (2 * kPubThreads * q < Lp) {  // workgroup-uniform
-          const int l0 = 2 * kPubThreads * q + 2 * tid;
+          const int l0 = PK_BIG_L0(q, tid);
           PubArgsPtr R = pub_args_now(rp);
+          PK_STAMP(c0)
           const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
 #ifdef PK_DIAG_TAIL_LISTS
           const int lc = min(l0, Lp - 2);
@@ -1953,6 +2008,9 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
             nsrc = regs_source_pub(R4->src, pn < R4->P ? pn : R4->P - 1);
             asm volatile("" : "+s"(nsrc));
           }
+          PK_BIG_WAIT_ALL
+          PK_STAMP(c1)
+          PK_PSTAMP(0, c0, c1)
           gi[0].mx = SA.mx;
           gi[0].my = SA.my;
           gi[0].mr = SA.mr;
@@ -1965,6 +2023,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[1].mg = SB.mg;
           gi[1].mb = SB.mb;
           gi[1].has = l0 + 1 < L;
+          if constexpr (PK_BIG_GATE4 != 0 && PK_BIG_GATE_FAR != 0) {
+            pub_far_bound(SA, gi[0].fk, gi[0].fi);
+            pub_far_bound(SB, gi[1].fk, gi[1].fi);
+          }
           double pp[2] = {0.0, 0.0};
           const Landmark<double>* const l2[2] = {&SA, &SB};
 #if PK_PUB_BIG_OVF
@@ -1987,15 +2049,19 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
             pub_gatesN<2, 2, kPubBigGateSlots, false, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4);
           else
             pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
+          PK_STAMP(c2)
+          PK_PSTAMP(1, c1, c2)
           pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
+          PK_STAMP(c3)
+          PK_PSTAMP(2, c2, c3)
 #endif
           pa = pp[0];
           pb = pp[1];
           {  // the next pair of this pass, or the first one of pass 2
             const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
-            const int ln = min((more ? 2 * kPubThreads * (q + 1) : 0) + 2 * tid, Lp - 2);
+            const int ln = min(PK_BIG_L0(more ? q + 1 : 0, tid), Lp - 2);
 #if PK_BIG_LATE_COV
             if (more) {
               PK_BIG_MEANS(SA, SB, ln, csrc)
@@ -2006,6 +2072,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
             PK_BIG_ROWS(SA, SB, ln, csrc)
 #endif
           }
+#if defined(PK_STAMPS) && !PK_PUB_BIG_OVF
+          PK_STAMP(c4)
+          PK_PSTAMP(3, c3, c4)
+#endif
         }
 #pragma unroll
         for (int i = 0; i + 2 < 2 * NCH; ++i) {
@@ -2018,7 +2088,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         pse[2 * NCH - 1] = pb;
       }
     }
+    PK_STAMP(b1)
     lds_barrier();  // A: every verdict of this particle is in the table
+    PK_STAMP(b2)
+    PK_PSTAMP(4, b1, b2)
     if (prev >= 0 && tid == 0) {  // the previous particle's log-weight (its partial sums were written before A)
       PubArgsPtr R = pub_args_now(rp);
       double tot = red[cur ^ 1][0];
@@ -2048,9 +2121,13 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     }
     pub_settle_blobs<kPubThreads, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur]);
     lds_barrier();  // B: every winner is marked, every flag is set
+    PK_STAMP(b3)
+    PK_PSTAMP(5, b2, b3)
 #pragma unroll
     for (int i = 0; i < 2 * NCH; ++i) pub_take(Q[i], pub, dump);
     lds_barrier();  // C: every marker has been read -- the table is the next particle's
+    PK_STAMP(b4)
+    PK_PSTAMP(6, b3, b4)
     if (wg_flag[cur]) {  // workgroup-uniform: nothing has been written; the fall-back kernels take the particle
       if (tid == 0) {
         PubArgsPtr R = pub_args_now(rp);
@@ -2058,7 +2135,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         atomicAdd(R->n_flagged, 1u);
       }
       {  // (the registers hold this particle's first pair: the next particle's instead)
-        const int lb0 = min(2 * tid, Lp - 2);
+        const int lb0 = min(PK_BIG_L0(0, tid), Lp - 2);
         PK_BIG_ROWS(SA, SB, lb0, nsrc)
       }
       continue;
@@ -2073,8 +2150,12 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
 #pragma unroll 1
     for (int q = 0; q < NCH; ++q) {
       if (2 * kPubThreads * q < Lp) {  // workgroup-uniform
-        const int l0 = 2 * kPubThreads * q + 2 * tid;
+        const int l0 = PK_BIG_L0(q, tid);
         PubArgsPtr R = pub_args_now(rp);
+        PK_STAMP(d0)
+        PK_BIG_WAIT_ALL
+        PK_STAMP(d1)
+        PK_PSTAMP(7, d0, d1)
         const Noise<double> qt = pub_noise(R);
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
         const unsigned char* immutable = R->immutable;
@@ -2084,6 +2165,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           PubArgsPtr R8 = pub_args_now(rp);
           acc += pub_apply_loop(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1]);
         }
+        PK_STAMP(d2)
+        PK_PSTAMP(8, d1, d2)
         if (l0 < Lp) {
           PubArgsPtr R3 = pub_args_now(rp);
           unsigned char* dslot = R3->map_dst + (size_t)p * R3->ss.slot_bytes;
@@ -2108,10 +2191,12 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         }
         {  // the next pair, or the next particle's first one
           const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
-          const int ln = min((more ? 2 * kPubThreads * (q + 1) : 0) + 2 * tid, Lp - 2);
+          const int ln = min(PK_BIG_L0(more ? q + 1 : 0, tid), Lp - 2);
           const int32_t sn = more ? csrc : nsrc;
           PK_BIG_ROWS(SA, SB, ln, sn)
         }
+        PK_STAMP(d3)
+        PK_PSTAMP(10, d2, d3)
       }
 #pragma unroll
       for (int i = 0; i + 2 < 2 * NCH; ++i) {  // the next pair's words to the front
@@ -2129,7 +2214,19 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
       if ((tid & (kWave - 1)) == 0) red[cur][tid / kWave] = ws;
       prev = p;
     }
+#ifdef PK_STAMPS
+    {
+      PK_STAMP(b5)
+      PK_PSTAMP(11, b0, b5)
+      pst[9] += 1ull;
+    }
+#endif
   }
+#ifdef PK_STAMPS
+  if ((tid0 & 63) == 0)
+    for (int k = 0; k < 12; ++k) atomicAdd(&pk_pstamp_wave[tid0 >> 6][k], pst[k]);
+#endif
+#undef PK_BIG_WAIT_ALL
 }
 
 void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,

@@ -39,6 +39,23 @@ for s in range(3, 6):
 f.synchronize(); so.pk_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
 print("git", os.environ.get("PK_GIT_SHA") or os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "unknown", "P", P, "L", L)
+if L > 2048 and hasattr(so, "pk_debug_pub_wave_stamps"):  # k_step_pub_big ran (its stamps are kept per wave only)
+    so.pk_debug_pub_wave_stamps(wbuf, 1)
+    w = np.array(list(wbuf), dtype=np.float64).reshape(8, 12)
+    if w[:, 9].sum() > 0:
+        bn = ["pass 1: waits for records and rows", "pass 1: gates", "pass 1: verdicts", "pass 1: next rows asked for", "barrier A",
+              "settling, barrier B", "take, barrier C", "pass 2: waits for rows", "pass 2: updates", None,
+              "pass 2: stores, next rows asked for", "particle"]
+        tot = w.sum(axis=0)
+        for i, n in enumerate(bn):
+            if n:
+                print("big %-40s %12.4g  %5.1f%%" % (n, tot[i], 100 * tot[i] / tot[11]))
+        print("big cycles per particle and wave: %.0f" % (tot[11] / max(tot[9], 1.0)))
+        print("per wave, cycles per particle: p1 wait | gates | verdicts | ask | A | settle+B | take+C | p2 wait | updates | stores+ask")
+        for i in range(8):
+            n = max(w[i, 9], 1.0)
+            print("  wave %d  " % i + " | ".join("%6.0f" % (w[i, k] / n) for k in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10)))
+        sys.exit(0)
 if v[48 + 8] > 0:  # k_step_pub ran (512 < L <= 2048, publish table in LDS)
     pn = ["scalars, requests", "gates (waits for candidate records, means)", "  of which: keys of the gate-passing blobs", "barrier A",
           "unseen blobs, subscribe", "barrier B", "updates, stores issued", "wave sum", "particle (wave lifetime)"]
