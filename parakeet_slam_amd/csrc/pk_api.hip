@@ -148,6 +148,7 @@ struct pk_filter {
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
+  unsigned char* npass_dev = nullptr; // [Lp + kCandSpare] per landmark: blobs inside the reference particle's own gates (k_candidates)
   float4* gate4_dev = nullptr;   // [bcand_cap] every blob's bearing and colour as float: k_step_pub_big's first look (k_cand_entries)
   unsigned* glist_dev = nullptr; // [bcand_cap + 1 + 256] the same for the blobs several landmarks list, compacted; then their number; then the octet orders of k_step_pub (128 u16) and k_step_pub_big (384 u16)
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
@@ -960,7 +961,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1333,6 +1334,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
   const bool small_pub = al.fused && f->pub_small && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
   if (al.big) {  // sixteen-entry lists both ways and the publish table's layout
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
+    if (!f->npass_dev && (rc = dev_alloc(f, &f->npass_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
     if (!f->erec_dev2 && (rc = dev_alloc(f, &f->erec_dev2, ((size_t)f->d.lay.Lp + kCandSpare) * 2))) return rc;
     if ((rc = ensure_inverse_lists(f, B, 2 * kCandSlots))) return rc;
     int ecap = step_pub_big_entry_capacity(B);
@@ -1340,9 +1342,9 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     Span t(f, PK_T_ASSOC);
     launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
     launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
-                      2 * kCandSlots, f->out4);
+                      2 * kCandSlots, f->out4, f->npass_dev);
     launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev);
+                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev, f->npass_dev);
     cand->rec = f->cand_dev;
     cand->over = ctl_cand_over(f);
     cand->slots = 2 * kCandSlots;
@@ -1355,6 +1357,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     if (ecap > 0) {
       if (!f->erec_dev && (rc = dev_alloc(f, &f->erec_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
+      if (!f->npass_dev && (rc = dev_alloc(f, &f->npass_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
       if ((rc = ensure_inverse_lists(f, B))) return rc;
     }
     Span t(f, PK_T_ASSOC);
@@ -1363,9 +1366,9 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     cand->over = ctl_cand_over(f);
     if (ecap > 0) {  // candidate lists both ways, and the publish table's layout
       launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
-                        kCandSlots, f->out4);
+                        kCandSlots, f->out4, f->npass_dev);
       launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                          ctl_skip_pub(f), ctl_skip_cand(f), ecap);
+                          ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev);
       cand->skip_cand = ctl_skip_cand(f);
       f->pub_ecap = ecap;
     } else {

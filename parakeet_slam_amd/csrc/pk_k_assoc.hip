@@ -733,6 +733,8 @@ struct CandArgs {
   int L, Lp, B;
   const double* pose4;  // sums of x, y, sin h, cos h over the P particles (k_summary_*): the reference POSE is their mean, or NULL
   int64_t P;
+  unsigned char* npass;  // [Lp + kCandSpare] out: blobs inside the reference's OWN gates (:433, :441) -- what a particle's verdict rounds
+                         // will be about; k_cand_entries orders the lanes of k_step_pub by it.  Or NULL
 };
 
 constexpr int kCandThreads = 1024;  // 64 landmarks x 16 waves that share the scan's blobs
@@ -740,7 +742,7 @@ template <int SLOTS>
 __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   static_assert(SLOTS == kCandSlots || SLOTS == 2 * kCandSlots, "records of two or three uint4");
   __shared__ unsigned short s_c[64][SLOTS];
-  __shared__ int s_n[64];
+  __shared__ int s_n[64], s_pass[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int l = blockIdx.x * 64 + lane;
   const unsigned char* slot = a.ss.at(a.src[a.ref]);
@@ -769,7 +771,10 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   const double tb = 0.5 + kCandBearing + 1e-9;
   const double rad = 17.320508075688775 + 1.7320508075688773 * kCandColour + 1e-6;  // sqrt(300) + sqrt(3) margin
   const double tc = rad * rad;
-  if (w == 0) s_n[lane] = 0;
+  if (w == 0) {
+    s_n[lane] = 0;
+    s_pass[lane] = 0;
+  }
   __syncthreads();
   const int chunk = (a.B + kCandThreads / 64 - 1) / (kCandThreads / 64);
   const int t1 = min(a.B, (w + 1) * chunk);
@@ -787,6 +792,7 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
     if (has && near && dr * dr + dg * dg + dc * dc <= tc) {
       const int n = atomicAdd(&s_n[lane], 1);
       if (n < SLOTS) s_c[lane][n] = (unsigned short)t;
+      if (fabs(db) <= 0.5 && dr * dr + dg * dg + dc * dc <= 300.0) atomicAdd(&s_pass[lane], 1);
     }
   }
   __syncthreads();
@@ -802,6 +808,7 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
       out[1 + j] = make_uint4((unsigned)c[8 * j + 0] | ((unsigned)c[8 * j + 1] << 16), (unsigned)c[8 * j + 2] | ((unsigned)c[8 * j + 3] << 16),
                               (unsigned)c[8 * j + 4] | ((unsigned)c[8 * j + 5] << 16), (unsigned)c[8 * j + 6] | ((unsigned)c[8 * j + 7] << 16));
     if (n > SLOTS) atomicAdd(a.over, 1u);
+    if (a.npass) a.npass[l] = (unsigned char)min(has ? s_pass[lane] : 0, 255);
     if (a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
       for (int k = 0; k < min(n, SLOTS); ++k) {
         const unsigned t = s_c[lane][k];
@@ -825,7 +832,7 @@ __global__ void __launch_bounds__(256) k_cand_strays(const unsigned* bcnt, int B
 
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev, int slots,
-                       const double* pose_sums4_dev) {
+                       const double* pose_sums4_dev, unsigned char* npass_dev) {
   if (d.P == 0 || d.lay.Lp == 0) return;
   // (inverse lists as wide as the lists themselves: brec_dev holds B x slots u16)
   if (bcnt_dev && brec_dev) {
@@ -846,6 +853,7 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.over = over_dev;
   a.ref = ref_particle;
   a.pose4 = pose_sums4_dev;
+  a.npass = npass_dev;
   a.P = d.P;
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;

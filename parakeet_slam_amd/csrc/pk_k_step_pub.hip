@@ -118,8 +118,25 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_BIG_GATE_FAR
 #define PK_BIG_GATE_FAR 1
 #endif
+// k_step_pub_big: 1 = the float records of a gate round are asked for a round ahead (measured: 7.40 against 7.27 ms, six registers
+// spilled; the six-chunk instance would spill 44 and never does it)
+#ifndef PK_BIG_GATE_AHEAD
+#define PK_BIG_GATE_AHEAD 0
+#endif
+// k_step_pub_big: 1 = the verdicts take the key's constant term and the colour bound from the gates (0: worked out twice)
+#ifndef PK_BIG_KEYS_PRE
+#define PK_BIG_KEYS_PRE 1
+#endif
 #ifndef PK_BIG_GATE4
 #define PK_BIG_GATE4 1
+#endif
+// k_step_pub: 1 = look-alikes that are certainly beyond the underflow edge are taken out of the slots before the verdict rounds
+#ifndef PK_PUB_PRUNE
+#define PK_PUB_PRUNE 0
+#endif
+// the octet order's first criterion: 1 = blobs inside the reference particle's own gates, 0 = the longest candidate list alone
+#ifndef PK_PUB_PERM_COST
+#define PK_PUB_PERM_COST 1
 #endif
 #ifndef PK_PUB_PERM_MECH
 #define PK_PUB_PERM_MECH 0
@@ -225,6 +242,7 @@ struct CandEntriesArgs {
   const unsigned* over;   // candidate-list overflow
   const double* exact;    // [B][6] the scan's records (for gate4), or null
   float4* gate4;          // [B] out: the gate quantities of every blob as float (k_step_pub_big's first look), or null
+  const unsigned char* npass;  // [Lp] blobs inside the reference's own gates (k_candidates), or null
   unsigned* skip_pub;
   unsigned* skip_cand;
   int L, Lp, B, ecap;
@@ -343,7 +361,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       if (tid < kPlaces) {
         int c = -1;
         if (tid < n_oct) {
-          int longest = 0, sum = 0;
+          int longest = 0, sum = 0, passes = 0;
           for (int i = 0; i < 16; ++i) {
             const int l = 16 * tid + i;
             if (l >= a.L) break;
@@ -353,8 +371,11 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
             for (int k = 0; k < SLOTS; ++k) n += ((cws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0xFFFFu ? 1 : 0;
             longest = max(longest, n);
             sum += n;
+            if (a.npass && PK_PUB_PERM_COST != 0) passes = max(passes, (int)a.npass[l]);
           }
-          c = longest * 256 + sum;
+          // (first by the blobs inside the reference's own gates -- a verdict round each, and a round costs the whole wave its
+          // arithmetic --, then by the longest list -- two candidates a gate round)
+          c = min(passes, 15) * 4096 + longest * 256 + sum;
         }
         s_cost[tid] = c;
         perm[tid] = 0xFFFFu;  // a place without an octet: its lanes are beyond the map
@@ -385,8 +406,10 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
 
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
-                         unsigned* skip_cand_dev, int ecap, int slots, const double* exact_dev, float4* gate4_dev) {
+                         unsigned* skip_cand_dev, int ecap, int slots, const double* exact_dev, float4* gate4_dev,
+                         const unsigned char* npass_dev) {
   CandEntriesArgs a;
+  a.npass = npass_dev;
   a.exact = exact_dev;
   a.gate4 = exact_dev ? gate4_dev : nullptr;
   a.cand = cand_dev;
@@ -448,7 +471,7 @@ struct PubGateIn {
   uint4 cw[2], ew[2];  // the candidate blobs and their publish entries, 16 bits each ([1] only with sixteen-entry lists)
   double mx, my, mr, mg, mb;
   bool has;
-  double fk, fi;  // GT only: the landmark's key is at least fk + fi |colour difference|^2 (pub_far_bound; -inf, 0: no bound)
+  double fk, fi;  // GT only: where fi > 0 the landmark's keys are at least fk + fi |colour difference|^2 (pub_far_bound)
 };
 // The lower bound of a landmark's keys that pub_keysN calls "far" (see there): key >= kbase + |d|^2 / rowmax for a colour block
 // that is certainly positive definite.  The same expressions as in pub_keysN -- the same values.
@@ -461,8 +484,8 @@ __device__ __forceinline__ void pub_far_bound(const Landmark<double>& lm, double
   const bool sane = det2 > 1e-20 && det2 < 1e60 && det3 > 1e-20 && det3 < 1e60;  // NaN: false
   const bool pd3 = sane && lm.crr > 0.0 && adj3.f > 0.0 && lm.pxx > 0.0;
   const double rowmax = fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))), lm.cbb + (fabs(lm.crb) + fabs(lm.cgb)));
-  fk = pd3 ? 5.0 * Consts<double>::log_two_pi + pub_log(det2 * det3) : -pub_inf();
-  fi = pd3 ? pub_recip(rowmax) : 0.0;
+  fk = 5.0 * Consts<double>::log_two_pi + pub_log(det2 * det3);  // (pub_keysN's kbase, whatever the blocks are like)
+  fi = pd3 ? pub_recip(rowmax) : 0.0;                            // (0: no bound)
 }
 // N: landmarks worked on side by side; W4: uint4 words per list (1: eight candidates, 2: sixteen)
 // OVF: a landmark may pass MORE blobs than it has slots without the particle being flagged: bits 16.. of its slots' state word
@@ -470,7 +493,7 @@ __device__ __forceinline__ void pub_far_bound(const Landmark<double>& lm, double
 // particles on some stretches of the bench's trajectory and sent them through the second-chance kernels).
 // GT: the first look at a candidate goes to the float table gt (see k_cand_entries): certain either way for all but a candidate in
 // a million, and only a wave with an uncertain one reads exact records (ex is global memory then, k_step_pub_big)
-template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false, bool GT = false>
+template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false, bool GT = false, bool AHEAD = false>
 __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
                                            double* pub, unsigned dump, int* flag, double sx, double sy, double sh,
                                            const float4* gt = nullptr) {
@@ -513,6 +536,20 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
     npass[j] = 0;
     pmask[j] = 0u;
   }
+  // GT: the float records of a round's candidates are asked for a round ahead (a gather from L2 takes as long as a round's
+  // arithmetic; a list that has ended reads record 0)
+  float4 nfa[GT ? N : 1], nfb[GT ? N : 1];
+  auto gate_request = [&](int kk) {
+    if constexpr (GT) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const unsigned ta = c[j][kk] & 0xFFFFu, tb = c[j][kk] >> 16;
+        nfa[j] = gt[ta != 0xFFFFu ? ta : 0u];
+        nfb[j] = gt[tb != 0xFFFFu ? tb : 0u];
+      }
+    }
+  };
+  if constexpr (GT && AHEAD) gate_request(0);
 #pragma unroll  // (written out: the list words are addressed statically -- shifted through the registers every round they cost 1.3 %)
   for (int k = 0; k < NW; ++k) {
     const int kk = k;
@@ -520,6 +557,19 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
 #pragma unroll
     for (int j = 1; j < N; ++j) call &= c[j][kk];
     if (__ballot((call & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: every list is through
+    float4 cfa[GT ? N : 1], cfb[GT ? N : 1];
+    if constexpr (GT) {
+      if constexpr (!AHEAD) gate_request(kk);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        cfa[j] = nfa[j];
+        cfb[j] = nfb[j];
+      }
+      if constexpr (AHEAD) {
+        asm volatile("" ::: "memory");
+        if (k + 1 < NW) gate_request(kk + 1);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       const unsigned ta = c[j][kk] & 0xFFFFu, tb = c[j][kk] >> 16;
@@ -531,7 +581,7 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
         // float values within 2^-24 relative of the record's: the bearing within 4.8e-7, a colour within 6e-5, the squared colour
         // distance -- components below 17.4 where it matters -- within 6.3e-3; beyond 300.01 the error grows more slowly than
         // the distance.  (The order of the slots follows the float distances: it decides nothing.)
-        const float4 fa = gt[va ? ta : 0u], fb = gt[vb ? tb : 0u];
+        const float4 fa = cfa[j], fb = cfb[j];
         cda = color_distance2(in[j].mr, in[j].mg, in[j].mb, (double)fa.y, (double)fa.z, (double)fa.w);
         cdb = color_distance2(in[j].mr, in[j].mg, in[j].mb, (double)fb.y, (double)fb.z, (double)fb.w);
         const double dba = fabs((double)fa.x - eb[j]), dbb = fabs((double)fb.x - eb[j]);
@@ -541,8 +591,8 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
         // far -- once a landmark's colour block has tightened, every look-alike's) is no contender and takes no slot: at several
         // thousand blobs each landmark passes a handful of those, and each cost the verdicts a round of gathers from L2
         // (27 % of the kernel's time, profiles/r04/stamps_k_step_pub_big_*).  The float distance is within 6.3e-3 of the exact one.
-        const bool far_a = PK_BIG_GATE_FAR != 0 && in[j].fk + (cda - 0.01) * in[j].fi > 1492.0;  // NaN: false
-        const bool far_b = PK_BIG_GATE_FAR != 0 && in[j].fk + (cdb - 0.01) * in[j].fi > 1492.0;
+        const bool far_a = PK_BIG_GATE_FAR != 0 && in[j].fi > 0.0 && in[j].fk + (cda - 0.01) * in[j].fi > 1492.0;  // NaN: false
+        const bool far_b = PK_BIG_GATE_FAR != 0 && in[j].fi > 0.0 && in[j].fk + (cdb - 0.01) * in[j].fi > 1492.0;
         pa = va && in_a && !far_a;
         pb = vb && in_b && !far_b;
         const bool ua = va && !out_a && !in_a, ub = vb && !out_b && !in_b;
@@ -645,10 +695,15 @@ __device__ __forceinline__ double pub_log(double x) {
   const double lm = 2.0 * s + 2.0 * s * (z * p);  // 2 atanh(s); the series' remainder: 2 s z^8 / 17 < 3e-14
   return (double)e * 0.69314718055994530942 + lm;
 }
-template <int N, int SL = kPubSlots>
+// PRE: kbase and 1 / rowmax come from the caller (pub_far_bound, k_step_pub_big: its gates needed them already)
+// PRUNE: before the rounds, the blobs in slots 1.. whose key is certainly beyond the underflow edge ("far", below) are published
+// as no contenders and taken out, the others close ranks: a round costs the whole wave its arithmetic when ONE lane has a blob
+// that is not far, and the rounds behind the first were nearly all about look-alikes (10 % of k_step_pub's time)
+template <int N, int SL = kPubSlots, bool PRE = false, bool PRUNE = false>
 __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
-                                          unsigned anydump, int* flag, double sx, double sy) {
+                                          unsigned anydump, int* flag, double sx, double sy, const double* pre_kbase = nullptr,
+                                          const double* pre_itr3 = nullptr) {
   {
     unsigned sall = q[0].s[0];
 #pragma unroll
@@ -677,7 +732,10 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
     (void)frexp(det3[j], &e3i);
     a2base[j] = 2.0 * Consts<double>::log_two_pi + (double)e2i * ln2;  // >= 2 log 2pi + log det2
     a3base[j] = 3.0 * Consts<double>::log_two_pi + (double)e3i * ln2;
-    kbase[j] = 5.0 * Consts<double>::log_two_pi + pub_log(det2[j] * det3[j]);
+    if constexpr (PRE)
+      kbase[j] = pre_kbase[j];
+    else
+      kbase[j] = 5.0 * Consts<double>::log_two_pi + pub_log(det2[j] * det3[j]);
     // A colour block that is certainly positive definite (Sylvester) has d' C^-1 d >= |d|^2 / lmax(C), and lmax(C) is at
     // most the largest absolute row sum (Gershgorin): with the position term >= 0 that bounds the key from below by
     // kbase + |d|^2 / rowmax, and a blob whose bound lies beyond the underflow edge has probability 0 whatever the rest
@@ -685,9 +743,57 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
     // when that holds for all lanes of the wave the round's arithmetic is skipped
     // (both blocks positive definite: adj3.f = crr cgg - crg^2, the determinants > 0 are part of sane)
     pd3[j] = sane[j] && lm.crr > 0.0 && adj3[j].f > 0.0 && lm.pxx > 0.0;
-    itr3[j] = pd3[j] ? pub_recip(fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))),
-                                       lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
-                     : 0.0;
+    if constexpr (PRE)
+      itr3[j] = pre_itr3[j];
+    else
+      itr3[j] = pd3[j] ? pub_recip(fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))),
+                                         lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
+                       : 0.0;
+  }
+  if constexpr (PRUNE && SL == 4) {
+    unsigned s1 = q[0].s[1];
+#pragma unroll
+    for (int j = 1; j < N; ++j) s1 &= q[j].s[1];
+    if (__ballot((s1 & 0xFFFFu) != 0xFFFFu) != 0ull) {  // wave-uniform: some landmark has passed a second blob
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const Landmark<double>& lm = *lmp[j];
+        unsigned w[3] = {q[j].s[1], q[j].s[2], q[j].s[3]};
+        bool keep[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const unsigned t = w[s] & 0xFFFFu, e = w[s] >> 16;
+          const bool valid = t != 0xFFFFu;
+          const double* rec = ex + 6 * (valid ? t : 0u);
+          const double2 z01 = *reinterpret_cast<const double2*>(rec);
+          const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+          const double d1 = z01.y - lm.mr, d2c = z23.x - lm.mg, d3c = z23.y - lm.mb;
+          const bool far = pd3[j] && kbase[j] + (d1 * d1 + d2c * d2c + d3c * d3c) * itr3[j] > 1492.0;  // (as in the rounds)
+          pub[(valid && far && e != 0xFFFFu) ? e : dump] = pub_inf();
+          keep[s] = valid && !far;
+          w[s] = keep[s] ? w[s] : 0xFFFFFFFFu;
+        }
+        // the kept ones to the front, in their order
+#pragma unroll
+        for (int turn = 0; turn < 2; ++turn) {
+          const bool sh = !keep[0];
+          w[0] = sh ? w[1] : w[0];
+          keep[0] = sh ? keep[1] : keep[0];
+          w[1] = sh ? w[2] : w[1];
+          keep[1] = sh ? keep[2] : keep[1];
+          w[2] = sh ? 0xFFFFFFFFu : w[2];
+          keep[2] = sh ? false : keep[2];
+        }
+        {
+          const bool sh = !keep[1];
+          w[1] = sh ? w[2] : w[1];
+          w[2] = sh ? 0xFFFFFFFFu : w[2];
+        }
+        q[j].s[1] = w[0];
+        q[j].s[2] = w[1];
+        q[j].s[3] = w[2];
+      }
+    }
   }
   int done = 0;
 #pragma unroll 1
@@ -1345,7 +1451,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       }                                                                                                                            \
       if ((q) == 0) pub_pad<PK_PUB_PAD_K0>(); else pub_pad<PK_PUB_PAD_K1>();                                                       \
       if (PK_PUB_ABLATE < 3) {                                                                                                     \
-        pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                                             \
+        pub_keysN<2, kPubSlots, false, PK_PUB_PRUNE != 0>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);        \
         if constexpr (PK_PUB_OVF != 0) { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */ \
           PubArgsPtr R9 = pub_args_now(rp);                                                                                        \
           const int lc9 = min(l0, Lp);                                                                                             \
@@ -2046,12 +2152,17 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
 #else
           PubSlotsT<kPubBigGateSlots> qq[2];
           if constexpr (PK_BIG_GATE4 != 0)
-            pub_gatesN<2, 2, kPubBigGateSlots, false, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4);
+            pub_gatesN<2, 2, kPubBigGateSlots, false, true, (PK_BIG_GATE_AHEAD != 0 && NCH <= 5)>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4);
           else
             pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
           PK_STAMP(c2)
           PK_PSTAMP(1, c1, c2)
-          pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+          if constexpr (PK_BIG_GATE4 != 0 && PK_BIG_GATE_FAR != 0 && PK_BIG_KEYS_PRE != 0) {
+            const double kb_[2] = {gi[0].fk, gi[1].fk}, it_[2] = {gi[0].fi, gi[1].fi};
+            pub_keysN<2, kPubBigGateSlots, true>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, kb_, it_);
+          } else {
+            pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+          }
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
           PK_STAMP(c3)

@@ -213,7 +213,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 // bcnt_dev / brec_dev: NULL, or u32[B] / u16[B][slots] (cleared / filled with 0xFF by this call); stray_dev: their count
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr,
-                       int slots = kCandSlots, const double* pose_sums4_dev = nullptr);
+                       int slots = kCandSlots, const double* pose_sums4_dev = nullptr, unsigned char* npass_dev = nullptr);
 // K2 + K3 in one pass (pk_k_observe_ml.hip, pk_k_step_pub.hip).  (k_step_owner, a barrier-free variant in which every
 // landmark settled its blobs against the rivals named by the two-way lists, was measured at 56 ms against 13 and removed
 // in round 3: DESIGN.md section 4.)
@@ -238,7 +238,7 @@ size_t step_pub_lds_bytes(int B, int ecap);
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap, int slots = kCandSlots, const double* exact_dev = nullptr,
-                         float4* gate4_dev = nullptr);
+                         float4* gate4_dev = nullptr, const unsigned char* npass_dev = nullptr);
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                      const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
