@@ -13,3 +13,4 @@ for k in ('configs1', 'configs4_shard'):
 print('refscene', json.dumps(d.get('refscene'))[:700])
 PY
 )
+exit $rc
