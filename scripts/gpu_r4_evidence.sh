@@ -1,5 +1,5 @@
 # round-4 evidence at one commit (PK_GIT_SHA is passed in: the snapshot on the box carries no .git).  Parts (EV_PARTS, default all):
-#   a  stamps: k_step_pub per phase and per wave (51 200 x 2 000), k_step_fused (10 000 x 500)
+#   a  stamps: k_step_pub per phase and per wave (51 200 x 2 000), k_step_fused (10 000 x 500), k_step_pub_big per wave (20 480 x 5 000)
 #   b  rocprofv3 --kernel-trace --stats of ONLY the timed filter (driver's window), at configs[2] and at 20 000 x 5 000
 #   c  PMC traffic (FETCH / WRITE passes) at 100 000 x 2 000 and 20 000 x 5 000
 #   d  SQ counters at 51 200 x 2 000 and 20 480 x 5 000
@@ -10,6 +10,7 @@ PARTS=${EV_PARTS:-abcde}
 if [[ $PARTS == *a* ]]; then
 ST_P=51200 ST_L=2000 timeout -k 10 300 python scripts/gpu_stamps.py > gpurun_out/r04/stamps_k_step_pub_51200x2000.txt 2>&1; echo "stamps pub rc=$?"
 ST_P=10000 ST_L=500 timeout -k 10 300 python scripts/gpu_stamps.py > gpurun_out/r04/stamps_k_step_fused_10000x500.txt 2>&1; echo "stamps fused rc=$?"
+ST_P=20480 ST_L=5000 timeout -k 10 300 python scripts/gpu_stamps.py > gpurun_out/r04/stamps_k_step_pub_big_20480x5000.txt 2>&1; echo "stamps big rc=$?"
 fi
 if [[ $PARTS == *b* ]]; then
 for cfg in "default:" "20000x5000:--particles 20000 --landmarks 5000"; do
