@@ -596,7 +596,11 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
         pa = va && in_a && !far_a;
         pb = vb && in_b && !far_b;
         const bool ua = va && !out_a && !in_a, ub = vb && !out_b && !in_b;
+#ifdef PK_DIAG_BIG_NO_EXACT  // diagnostic build only: the uncertain ones count as outside -- to show that the edge test bites
+        if (false) {
+#else
         if (__ballot(ua || ub) != 0ull) {  // wave-uniform, rare: the exact records of the uncertain ones
+#endif
           const double* ra = ex + 6 * (ua ? ta : 0u);
           const double* rb = ex + 6 * (ub ? tb : 0u);
           const double2 a01 = *reinterpret_cast<const double2*>(ra);

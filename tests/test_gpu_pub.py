@@ -260,6 +260,47 @@ def test_two_pass_instance_for_maps_beyond_2048_landmarks(lib, L, P):
         against_oracle(big, means, covs, poses, blobs, imm)
 
 
+def test_two_pass_gates_first_look_at_the_edges_of_its_margins(lib):
+    """k_step_pub_big's gates look at a FLOAT copy of a candidate's bearing and colour first (one 16-byte gather) and read the exact
+    record only where that look cannot decide: blobs a hair inside and a hair outside the bearing gate (0.5 rad, :433) and the colour
+    gate (300, :441) -- closer to the edge than the float copy resolves --, a blob whose colours are beyond the range the margins
+    were derived for (NaN in the table: always looked at exactly), and blobs just inside / outside the margins themselves."""
+    L, P = 2300, 2
+    rs = np.random.RandomState(77)
+    means, covs = synthetic_world(L)
+    means[1400, 2:] = [1500.0, 20.0, 30.0]  # beyond |colour| <= 1 000
+    pose = (0.0, 0.0, 0.0)
+    base = synthetic_scan(means, pose)
+    extra, expect_pass = [], []
+    edge = math.sqrt(300.0)
+    for i, (l, kind, delta) in enumerate([(100, "b", -2e-7), (230, "b", +2e-7), (360, "b", -5e-6), (490, "b", +5e-6), (620, "b", -3e-8), (750, "b", +3e-8),
+                                          (880, "c", -1e-4), (1010, "c", +1e-4), (1140, "c", -2e-3), (1270, "c", +2e-3), (1400, "c", -1e-4), (1530, "c", -1e-7),
+                                          (1660, "c", +1e-7), (1790, "bneg", -2e-7), (1920, "bneg", +2e-7)]):
+        z = base[l].copy()
+        if kind == "b":
+            z[0] = base[l, 0] + (0.5 + delta)
+        elif kind == "bneg":
+            z[0] = base[l, 0] - (0.5 + delta)
+        else:
+            z[1] = means[l, 2] + (edge + delta)
+        extra.append(z)
+        expect_pass.append(delta < 0)
+    blobs = np.vstack([base, np.array(extra)])
+    blobs = blobs[rs.permutation(len(blobs))]
+    poses = np.zeros((P, 4))
+    poses[:, 3] = 1.0
+    big = run(lib, means, covs, poses, blobs)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert big["route"] == "ml_pub_big" and big["published"] and gen["route"] == "ml_general"
+    assert big["flagged"] == 0  # the kernel itself decided: nobody went to the fall-back kernels
+    same_state(big, gen, 1e-11)
+    against_oracle(big, means, covs, poses, blobs)
+    # the scene does what it says: a landmark whose extra blob is inside its gates was updated twice (count 2 + 2), the others once
+    counts = big["maps"][2][0]
+    for (l, want) in zip([100, 230, 360, 490, 620, 750, 880, 1010, 1140, 1270, 1400, 1530, 1660, 1790, 1920], expect_pass):
+        assert counts[l] == (4 if want else 2), (l, counts[l], want)
+
+
 def test_two_pass_instance_whole_steps_against_the_sweep_route(lib):
     L, P = 2600, 256
     means, covs = synthetic_world(L)
