@@ -124,20 +124,29 @@ def test_keys_too_close_to_call_send_the_particle_to_the_general_kernels(lib):
     against_oracle(pub, means, covs, poses, blobs)
 
 
-@pytest.mark.parametrize("target", [1470.0, 1488.5, 1489.6, 1490.2, 1490.4, 1491.0, 1492.5, 1520.0])
-def test_probabilities_around_the_float64_underflow_edge(lib, target):
+@pytest.mark.parametrize("L", [640, 2300])
+@pytest.mark.parametrize("target", [1470.0, 1488.5, 1489.6, 1490.2, 1490.4, 1491.0, 1492.03, 1492.5, 1520.0])
+def test_probabilities_around_the_float64_underflow_edge(lib, target, L):
     # one landmark whose own blob is so far off in colour (inside the gate) that its probability lands around the smallest
     # subnormal: -2 log pr = target.  Positive below 1490.27, zero above; between 1489 and 1491.5 the kernel evaluates the
     # probability as the reference does.  Matched or not must agree with the general kernels and the oracle.
+    # (L = 2 300: k_step_pub_big, whose GATES already leave out a blob that is certainly beyond the edge -- from the float copy of
+    # its colour, less a margin: 1 492.03 is beyond the edge but inside that margin, 1 492.5 beyond both)
     rs = np.random.RandomState(int(target * 10))
-    L = 640
     means, covs = synthetic_world(L)
     blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
     P = 4
     poses = np.zeros((P, 4))
     poses[:, 3] = 1.0  # on the spot: the position term is 0 for every landmark
+    d2 = 200.0  # squared colour distance of the landmark's own blob (gate: 300)
     lm = 17
-    d2 = 200.0  # squared colour distance of landmark 17's blob (gate: 300)
+    if L > 640:  # (a denser ring: a landmark whose shifted blob no OTHER landmark has inside its colour gate -- a second contender
+        # next to a subnormal winner rightly sends the particle to the general kernels, which is another test's subject)
+        for lm in range(17, L):
+            shifted = means[lm, 2:] + np.array([math.sqrt(d2), 0.0, 0.0])
+            others = np.delete(np.arange(L), lm)
+            if np.min(np.sum((means[others, 2:] - shifted) ** 2, axis=1)) > 500.0:
+                break
     # key = 5 log 2pi + log det2 + log det3 + d2 / c with covariances 0.25 I_2 and c I_3
     kconst = 5.0 * math.log(2.0 * math.pi) + math.log(0.25 * 0.25)
     lo, hi = 1e-3, 0.25
@@ -239,21 +248,32 @@ def test_the_256_lane_instance_for_small_maps_is_exact_too(lib, L, P):
     against_oracle(pub, means, covs, poses, blobs)
 
 
-@pytest.mark.parametrize("L,P", [(2049, 3), (3000, 3), (4096, 2), (5000, 4)])
-def test_two_pass_instance_for_maps_beyond_2048_landmarks(lib, L, P):
+@pytest.mark.parametrize("L,P,tight", [(2049, 3, False), (3000, 3, False), (4096, 2, False), (5000, 4, False), (2300, 3, True), (3000, 3, True), (5000, 4, True),
+                                       (5200, 2, True), (5632, 2, True)])
+def test_two_pass_instance_for_maps_beyond_2048_landmarks(lib, L, P, tight):
     """k_step_pub_big (2 048 < L <= 6 144): sixteen-entry candidate lists both ways, verdicts published in a first pass over
-    the map, updates in a second -- against the two-sweep route it replaces as the default, the general kernels and the oracle."""
+    the map, updates in a second -- against the two-sweep route it replaces as the default, the general kernels and the oracle.
+    With the fresh map's loose colour blocks (0.25 I) some landmark of a ring of several thousand has five blobs with a positive
+    probability inside its gates and the kernel hands every particle to the fall-back kernels (a landmark keeps four): those cases
+    hold the hand-over; the TIGHT ones (0.01 I: a look-alike four colour units away is beyond the underflow edge, and the gates
+    leave it out) hold the kernel itself -- nobody may be flagged there."""
     rs = np.random.RandomState(1200 + L)
     means, covs = synthetic_world(L)
+    if tight:
+        covs[:, 2:, 2:] = 0.01 * np.identity(3)
     n = len(means[3::7])
     means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))  # look-alikes: contested blobs
     imm = (rs.uniform(size=L) < 0.1).astype(np.uint8)
     blobs = synthetic_scan(means, (0.02, -0.01, 0.01))[rs.permutation(L)]
+    if L > 5120:  # (the six-chunk instance: the fall-back sweep's tables hold no more than some 5 000 blobs, so a part of the scan)
+        blobs = blobs[:3500]
     poses = poses_around(rs, P, 0.05)
     big = run(lib, means, covs, poses, blobs, immutable=imm)
     sweep = run(lib, means, covs, poses, blobs, {"pub_step": 0}, immutable=imm)
     gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0}, immutable=imm)
     assert big["route"] == "ml_pub_big" and sweep["route"] == "ml_sweep" and gen["route"] == "ml_general"
+    if tight:
+        assert big["published"] and big["flagged"] == 0
     same_state(big, sweep, 1e-11)
     same_state(big, gen, 1e-11)
     if L <= 3000:  # (the NumPy oracle takes a while at 5 000 x 5 000)
