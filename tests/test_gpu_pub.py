@@ -54,10 +54,13 @@ def against_oracle(got, means, covs, poses, blobs, immutable=None):
     assert np.allclose(m, o.mean, rtol=1e-10, atol=1e-12) and np.allclose(c, o.cov, rtol=1e-9, atol=1e-13) and np.array_equal(k, o.count)
 
 
-@pytest.mark.parametrize("L,P", [(700, 6), (1024, 4), (1026, 4), (2000, 3), (2048, 3)])
-def test_pub_is_the_default_instance_and_agrees_with_regs_and_the_general_kernels(lib, L, P):
+@pytest.mark.parametrize("L,P,tight", [(700, 6, False), (1024, 4, False), (1026, 4, False), (2000, 3, False), (2048, 3, False), (700, 6, True), (1500, 4, True),
+                                       (2000, 3, True)])
+def test_pub_is_the_default_instance_and_agrees_with_regs_and_the_general_kernels(lib, L, P, tight):
     rs = np.random.RandomState(900 + L)
     means, covs = synthetic_world(L)
+    if tight:  # (colour blocks of a map that has been seen a few times: nobody may be flagged -- the kernel itself is held to the others)
+        covs[:, 2:, 2:] = 0.01 * np.identity(3)
     n = len(means[3::7])
     means[0:7 * n:7, 2:] = means[3::7, 2:] + rs.uniform(-4, 4, (n, 3))  # look-alikes three bearings apart: contested blobs
     imm = (rs.uniform(size=L) < 0.1).astype(np.uint8)
@@ -71,6 +74,8 @@ def test_pub_is_the_default_instance_and_agrees_with_regs_and_the_general_kernel
     # k_step_regs flags a particle for any landmark that passes more than four blobs (some here pass 5-7); k_step_pub since round 4
     # only when more than four of them have a positive probability
     assert pub["flagged"] <= regs["flagged"]
+    if tight:
+        assert pub["published"] and pub["flagged"] == 0
     same_state(pub, regs)
     same_state(pub, gen, 1e-11)
     against_oracle(pub, means, covs, poses, blobs, imm)
