@@ -127,6 +127,10 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_BIG_KEYS_PRE
 #define PK_BIG_KEYS_PRE 1
 #endif
+// k_step_pub_big, diagnostic: wave priorities in pass 2 (1: the second four waves raised, 3: the first four; measured)
+#ifndef PK_BIG_PRIO
+#define PK_BIG_PRIO 0
+#endif
 #ifndef PK_BIG_GATE4
 #define PK_BIG_GATE4 1
 #endif
@@ -137,6 +141,11 @@ __device__ __forceinline__ void pub_pad() {
 // the octet order's first criterion: 1 = blobs inside the reference particle's own gates, 0 = the longest candidate list alone
 #ifndef PK_PUB_PERM_COST
 #define PK_PUB_PERM_COST 1
+#endif
+// 1 = the publish table of k_step_pub_big rank-major (see k_cand_entries), 0 = blob-major as k_step_pub's (where rank-major measured
+// +0.6 %: three or four entries per blob, little to gain, and the rank bases are table reads)
+#ifndef PK_PUB_RANKMAJOR
+#define PK_PUB_RANKMAJOR 1
 #endif
 #ifndef PK_PUB_PERM_MECH
 #define PK_PUB_PERM_MECH 0
@@ -164,6 +173,7 @@ __device__ __forceinline__ void pub_pad() {
 #endif
 constexpr int kPubThreads = 512;        // the large instances' workgroup
 constexpr int kPubSmallThreads = 256;   // ... the L <= 512 instance's
+constexpr int kPubTailWords = 256;  // words behind glist[B]: the octet orders of k_step_pub (128 u16) and k_step_pub_big (384 u16); then rbase[16]
 constexpr int kPubBigPlaces = 384;  // k_step_pub_big: six chunks of 64 octets (kPubBigMaxL / 16)
 constexpr int kPubOctets = 64;  // groups of eight lanes in a 512-lane workgroup: sixteen adjacent landmarks per pair each
 constexpr int kPubSlots = 4;  // gate-passing blobs a landmark keeps; more: the particle is flagged
@@ -251,12 +261,18 @@ struct CandEntriesArgs {
 // SLOTS: entries per candidate list and per inverse list (kCandSlots, or twice that for the scans of several thousand blobs)
 template <int SLOTS>
 __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
-  __shared__ unsigned s_part[1024], s_gpart[1024];
+  constexpr bool kRankMajor = PK_PUB_RANKMAJOR != 0 && SLOTS > kCandSlots;  // (sixteen-entry lists: k_step_pub_big)
+  __shared__ unsigned s_part[kRankMajor ? 1 : 1024], s_gpart[kRankMajor ? 1 : 1024];
+  __shared__ unsigned short s_cls[kRankMajor ? SLOTS + 1 : 1][1024];  // per class (number of contenders) and chunk: blobs, then their scan
+  __shared__ unsigned s_tot[SLOTS + 1], s_cbase[SLOTS + 1], s_rbase[SLOTS];
   __shared__ unsigned s_total;
   const int tid = threadIdx.x;
   const int chunk = (a.B + 1023) / 1024;
   const int t0 = tid * chunk, t1 = min(a.B, t0 + chunk);
   unsigned mine = 0, gmine = 0;
+  int ncls[SLOTS + 1];
+#pragma unroll
+  for (int c = 0; c <= SLOTS; ++c) ncls[c] = 0;
   for (int t = t0; t < t1; ++t) {
     const unsigned n = min(a.bcnt[t], (unsigned)SLOTS);
     unsigned short* row = a.brec + (size_t)t * SLOTS;
@@ -277,7 +293,65 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     for (int i = 0; i < SLOTS; ++i) row[i] = v[i];
     mine += n >= 2u ? n : 0u;
     gmine += n >= 2u ? 1u : 0u;
+    if constexpr (kRankMajor) {
+#pragma unroll
+      for (int c = 2; c <= SLOTS; ++c) ncls[c] += n == (unsigned)c ? 1 : 0;
+    }
   }
+  if constexpr (kRankMajor) {
+    // RANK-MAJOR table: the contested blobs ordered by their number of contenders, most first (g = a blob's place in that order),
+    // entry of (blob g, rank r) = rbase[r] + g with rbase[r] = how many entries of lower rank there are.  The settling's lane g
+    // then reads rank r of ITS blob next to lane g + 1's: consecutive 8-byte words, no bank conflict -- blob-major (a blob's
+    // entries side by side) the lanes read at a stride of three to six entries, an 8-way conflict on every read: the settling
+    // loop was 8 % of k_step_pub_big's time and LDS-bound -- and a wave reads no further than its longest list.
+#pragma unroll
+    for (int c = 2; c <= SLOTS; ++c) s_cls[c][tid] = (unsigned short)ncls[c];
+    __syncthreads();
+    if (tid >= 2 && tid <= SLOTS) {  // one thread per class: exclusive scan over the 1 024 chunks
+      unsigned run = 0;
+      for (int i = 0; i < 1024; ++i) {
+        const unsigned v = s_cls[tid][i];
+        s_cls[tid][i] = (unsigned short)run;
+        run += v;
+      }
+      s_tot[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned base = 0, entries = 0;
+      for (int c = SLOTS; c >= 2; --c) {  // most contenders first
+        s_cbase[c] = base;
+        base += s_tot[c];
+        entries += (unsigned)c * s_tot[c];
+      }
+      s_total = entries;
+      a.glist[a.B] = base;  // G
+      unsigned rb = 0;
+      unsigned* rbg = a.glist + a.B + 1 + kPubTailWords;
+      for (int r = 0; r < SLOTS; ++r) {  // rank r exists for the blobs with more than r contenders
+        s_rbase[r] = rb;
+        rbg[r] = rb;
+        unsigned more = 0;
+        for (int c = max(r + 1, 2); c <= SLOTS; ++c) more += s_tot[c];
+        rb += more;
+      }
+    }
+    __syncthreads();
+    {
+      int k[SLOTS + 1];
+#pragma unroll
+      for (int c = 0; c <= SLOTS; ++c) k[c] = 0;
+      for (int t = t0; t < t1; ++t) {
+        const unsigned n = min(a.bcnt[t], (unsigned)SLOTS);
+        unsigned g = 0;
+#pragma unroll
+        for (int c = 2; c <= SLOTS; ++c)
+          if (n == (unsigned)c) g = s_cbase[c] + s_cls[c][tid] + (unsigned)(k[c]++);
+        a.binfo[t] = (g & 0xFFFFu) | (n << 16);
+        if (n >= 2u) a.glist[g] = (g & 0xFFFFu) | (n << 16);
+      }
+    }
+  } else {
   s_part[tid] = mine;
   s_gpart[tid] = gmine;
   __syncthreads();
@@ -304,6 +378,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       run += c;
     }
   }
+  }
   const bool fits = *a.over == 0u && s_total <= (unsigned)a.ecap && s_total < 0xFFFFu;
   if (tid == 0) {
     *a.skip_pub = fits ? 0u : 1u;
@@ -327,7 +402,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
           unsigned rank = 0;
 #pragma unroll
           for (int j = 0; j < SLOTS; ++j) rank += (unsigned)row[j] < (unsigned)l ? 1u : 0u;
-          ev = (bi & 0xFFFFu) + rank;
+          ev = kRankMajor ? s_rbase[rank] + (bi & 0xFFFFu) : (bi & 0xFFFFu) + rank;
         }
       }
       e[k] = (unsigned short)ev;
@@ -950,19 +1025,26 @@ __device__ __forceinline__ bool pub_refill_slots(PubSlots (&q)[N], const uint4* 
 // entries one after the other: 40 % of the kernel's time went into those dependent LDS round trips.)
 __device__ __forceinline__ double pub_marker() { return __longlong_as_double((long long)0xFFF0000000000000ull); }
 template <int THREADS, int SLOTS = kCandSlots>
-__device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist, unsigned G, double* pub, unsigned dump, int* flag) {
+__device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist, unsigned G, double* pub, unsigned dump, int* flag,
+                                                 const unsigned* rb) {
+  constexpr bool kRankMajor = PK_PUB_RANKMAJOR != 0 && SLOTS > kCandSlots;
   bool doubt = false;
 #pragma unroll 1
   for (unsigned g = (unsigned)tid; __ballot(g < G) != 0ull; g += THREADS) {  // wave-uniform
     const bool on = g < G;
     const unsigned gi = glist[on ? g : 0u];
-    const unsigned offs = gi & 0xFFFFu, n = on ? (gi >> 16) : 0u;
+    const unsigned n = on ? (gi >> 16) : 0u;
+    // entry of (this blob, rank r): rank-major rb[r] + g (the lanes of a wave read consecutive words), blob-major offs + r
+    const unsigned offs = gi & 0xFFFFu;
+    // (every contested blob has ranks 0 and 1: their bases are 0 and G)
+    auto entry = [&](int r) -> unsigned { return kRankMajor ? (r == 0 ? g : r == 1 ? G + g : rb[r] + g) : offs + (unsigned)r; };
     // (most contested blobs are listed by two or three landmarks: the first four entries in one batch, the rest -- wave-uniform --
     // only where some lane's blob has more; round 4: the settling read and compared all SLOTS entries of every blob)
     constexpr int kHead = SLOTS < 4 ? SLOTS : 4;
+    constexpr int kMid = SLOTS > 8 ? 8 : SLOTS;
     double v[SLOTS];
 #pragma unroll
-    for (int r = 0; r < kHead; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
+    for (int r = 0; r < kHead; ++r) v[r] = pub[(unsigned)r < n ? entry(r) : dump];
     double best = pub_inf();
     unsigned wr = 0u;
 #pragma unroll
@@ -973,11 +1055,23 @@ __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist,
       best = better ? v[r] : best;
     }
     const bool more = SLOTS > kHead && __ballot(n > (unsigned)kHead) != 0ull;  // wave-uniform
+    const bool most = SLOTS > kMid && __ballot(n > (unsigned)kMid) != 0ull;
     if (more) {
 #pragma unroll
-      for (int r = kHead; r < SLOTS; ++r) v[r] = pub[(unsigned)r < n ? offs + r : dump];
+      for (int r = kHead; r < kMid; ++r) v[r] = pub[(unsigned)r < n ? entry(r) : dump];
 #pragma unroll
-      for (int r = kHead; r < SLOTS; ++r) {
+      for (int r = kHead; r < kMid; ++r) {
+        v[r] = (unsigned)r < n ? v[r] : pub_inf();
+        const bool better = v[r] < best;
+        wr = better ? (unsigned)r : wr;
+        best = better ? v[r] : best;
+      }
+    }
+    if (most) {
+#pragma unroll
+      for (int r = kMid; r < SLOTS; ++r) v[r] = pub[(unsigned)r < n ? entry(r) : dump];
+#pragma unroll
+      for (int r = kMid; r < SLOTS; ++r) {
         v[r] = (unsigned)r < n ? v[r] : pub_inf();
         const bool better = v[r] < best;
         wr = better ? (unsigned)r : wr;
@@ -993,13 +1087,24 @@ __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist,
     }
     if (more) {
 #pragma unroll
-      for (int r = kHead; r < SLOTS; ++r) {
+      for (int r = kHead; r < kMid; ++r) {
+        contenders += v[r] < pub_inf() ? 1 : 0;
+        close |= v[r] != best && v[r] - best < 1e-7;
+      }
+    }
+    if (most) {
+#pragma unroll
+      for (int r = kMid; r < SLOTS; ++r) {
         contenders += v[r] < pub_inf() ? 1 : 0;
         close |= v[r] != best && v[r] - best < 1e-7;
       }
     }
     doubt |= close || (contenders >= 2 && best > 1350.0);
-    if (best < pub_inf()) pub[offs + wr] = pub_marker();
+    if (best < pub_inf()) {
+      unsigned we = kRankMajor ? g : offs + wr;
+      if constexpr (kRankMajor) we += rb[wr];
+      pub[we] = pub_marker();
+    }
   }
   if (doubt) *flag = 1;
 }
@@ -1179,6 +1284,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   // memory queue all particle long, and that the others wait for at every barrier
   constexpr bool kPerm = PK_PUB_PERM != 0 && NP == 2 && THREADS == 512;
   __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets : 1];
+  __shared__ unsigned s_rb[kCandSlots];  // the publish table's rank bases (k_cand_entries: entry of (blob g, rank r) = s_rb[r] + g)
 #define PK_PUB_L0(q_, t_) (kPerm ? (int)(((lw >> (kOctShift + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7) : 2 * kPubThreads * (q_) + 2 * (t_))
   // (PK_PUB_PERM_MECH: where the two octet numbers live -- 0: above the lane index in one register, 1: in a register of their
   // own, 2: below the lane index)
@@ -1224,6 +1330,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     if constexpr (kPerm) {
       if (tid < 2 * kPubOctets) s_perm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[tid];
     }
+    if (tid < kCandSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -1543,7 +1650,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
-    if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur]);
+    if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     PK_STAMP(s5)
     PK_PSTAMP(4, s4, s5)  // unseen blobs, settling
     lds_barrier();  // B: every winner is marked, every flag is set
@@ -1928,6 +2035,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   // which sixteen landmarks the eight lanes of place 64 q + tid / 8 work on in chunk q (k_cand_entries: the octets ranked by
   // their longest candidate list, so that a wave's -- and a chunk's -- lists are of like length)
   __shared__ unsigned short s_bperm[kPubBigPlaces];
+  __shared__ unsigned s_rb[kPubBigSlots];  // the publish table's rank bases (k_cand_entries)
 #define PK_BIG_L0(q_, t_) ((int)(16u * (unsigned)s_bperm[kPubOctets * (q_) + ((t_) >> 3)]) + 2 * ((t_)&7))
   constexpr int kPubWaves = kPubThreads / kWave;
   PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1955,6 +2063,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     for (int i = tid; i < B; i += kPubThreads) glist[i] = (unsigned)i < G ? gb[i] : 0u;
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
     if (tid < kPubBigPlaces) s_bperm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[2 * kPubOctets + tid];
+    if (tid < kPubBigSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -2234,7 +2343,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
-    pub_settle_blobs<kPubThreads, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur]);
+    pub_settle_blobs<kPubThreads, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     lds_barrier();  // B: every winner is marked, every flag is set
     PK_STAMP(b3)
     PK_PSTAMP(5, b2, b3)
@@ -2257,6 +2366,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     }
     if (tid == 0) pub_args_now(rp)->pflag_out[p] = 0;
     // ---- pass 2: rows in again, updates in scan order, rows out
+    if (PK_BIG_PRIO == 1 && tid0 >= 256) __builtin_amdgcn_s_setprio(3);  // (diagnostic: the second four waves first in pass 2)
+    if (PK_BIG_PRIO == 3 && tid0 < 256) __builtin_amdgcn_s_setprio(3);   // (diagnostic: the first four)
 #define PK_BIG_STORE(field, F)                                                             \
   {                                                                                        \
     const Double2 v_ = {SA.field, SB.field};                                               \
@@ -2319,6 +2430,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         pse[i] = pse[i + 2];
       }
     }
+    if (PK_BIG_PRIO == 1 || PK_BIG_PRIO == 3) __builtin_amdgcn_s_setprio(0);
 #undef PK_BIG_STORE
 #undef PK_BIG_ROWS
 #undef PK_BIG_MEANS
