@@ -131,6 +131,19 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_BIG_PRIO
 #define PK_BIG_PRIO 0
 #endif
+// k_step_pub_big, pass 2: 1 = the record of a landmark's blob is asked for behind the pair's rows, a pair ahead of the update (measured:
+// 6.88 against 6.82 ms -- the other wave of the SIMD covers that round trip already)
+#ifndef PK_BIG_APPLY_AHEAD
+#define PK_BIG_APPLY_AHEAD 0
+#endif
+// k_step_pub_big: 1 = the rows go out as non-temporal stores (0: plain ones; diagnostic)
+#ifndef PK_BIG_NT_STORES
+#define PK_BIG_NT_STORES 1
+#endif
+// k_step_pub_big: 1 = pass 2 reads the rows with non-temporal loads (their last use; diagnostic)
+#ifndef PK_BIG_NT_LOADS
+#define PK_BIG_NT_LOADS 0
+#endif
 #ifndef PK_BIG_GATE4
 #define PK_BIG_GATE4 1
 #endif
@@ -1187,8 +1200,17 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
 
 // The same with ONE copy of the update code, in a loop that nearly always turns once (the 256-lane instance: 145 VGPRs
 // instead of 181; on the large instance 0.7 % slower than the two-path form above).
+// (PRE: the record of the landmark's ONLY blob -- the usual case -- has been asked for ahead, pub_apply_request: k_step_pub_big reads
+// the records from L2, and a gather issued where the update needs it costs the wave a round trip per landmark)
+__device__ __forceinline__ unsigned pub_apply_only_blob(const PubSlots& q) {
+  const unsigned tk = q.st & 0x4444u;
+  const unsigned w = (tk & 0x0004u) ? q.s[0] : (tk & 0x0040u) ? q.s[1] : (tk & 0x0400u) ? q.s[2] : q.s[3];
+  return (tk != 0u && (tk & (tk - 1u)) == 0u) ? (w & 0xFFFFu) : 0u;  // (no blob, or several: record 0, not used)
+}
+template <bool PRE = false>
 __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
-                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
+                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse,
+                                            double2 pre01 = double2{0.0, 0.0}, double2 pre23 = double2{0.0, 0.0}) {
   double acc = 0.0;
   unsigned tk = q.st & 0x4444u;
   bool fresh = true;
@@ -1215,9 +1237,16 @@ __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double
       }
     }
     if (tk != 0u) {
-      const double* rec = ex + 6 * (w & 0xFFFFu);
-      const double2 z01 = *reinterpret_cast<const double2*>(rec);
-      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+      double2 z01, z23;
+      // (the first turn of a landmark with one blob: pub_apply_only_blob picked the same slot)
+      if (PRE && it == 0 && (tk & (tk - 1u)) == 0u) {
+        z01 = pre01;
+        z23 = pre23;
+      } else {
+        const double* rec = ex + 6 * (w & 0xFFFFu);
+        z01 = *reinterpret_cast<const double2*>(rec);
+        z23 = *reinterpret_cast<const double2*>(rec + 2);
+      }
       BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
       acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
       fresh = imm;
@@ -2134,10 +2163,12 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   }
 #define PK_BIG_LOAD(SA, SB, field, F, lb_)                                                            \
   {                                                                                                   \
-    const Double2 v_ = *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_));               \
+    const Double2 v_ = big_last_read ? __builtin_nontemporal_load(reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_))) \
+                                     : *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_)); \
     SA.field = v_.x;                                                                                  \
     SB.field = v_.y;                                                                                  \
   }
+  constexpr bool big_last_read = false;  // (shadowed where a request is pass 2's: PK_BIG_NT_LOADS)
   int64_t prev = -1;
   int cur = 0;
 #ifdef PK_STAMPS
@@ -2293,7 +2324,12 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
               PK_BIG_ROWS(SA, SB, ln, csrc)
             }
 #else
-            PK_BIG_ROWS(SA, SB, ln, csrc)
+            if (PK_BIG_NT_LOADS != 0 && !more) {  // pass 2's first pair: the LAST read of these rows
+              constexpr bool big_last_read = true;
+              PK_BIG_ROWS(SA, SB, ln, csrc)
+            } else {
+              PK_BIG_ROWS(SA, SB, ln, csrc)
+            }
 #endif
           }
 #if defined(PK_STAMPS) && !PK_PUB_BIG_OVF
@@ -2366,12 +2402,25 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     }
     if (tid == 0) pub_args_now(rp)->pflag_out[p] = 0;
     // ---- pass 2: rows in again, updates in scan order, rows out
+    double2 za01 = {0.0, 0.0}, za23 = {0.0, 0.0}, zb01 = {0.0, 0.0}, zb23 = {0.0, 0.0};
+    if constexpr (PK_BIG_APPLY_AHEAD != 0) {  // the records of the first pair's blobs (its rows have been on their way since pass 1 ended)
+      const double* exn = pub_args_now(rp)->exact;
+      const double* ra = exn + 6 * pub_apply_only_blob(Q[0]);
+      const double* rb_ = exn + 6 * pub_apply_only_blob(Q[1]);
+      za01 = *reinterpret_cast<const double2*>(ra);
+      za23 = *reinterpret_cast<const double2*>(ra + 2);
+      zb01 = *reinterpret_cast<const double2*>(rb_);
+      zb23 = *reinterpret_cast<const double2*>(rb_ + 2);
+    }
     if (PK_BIG_PRIO == 1 && tid0 >= 256) __builtin_amdgcn_s_setprio(3);  // (diagnostic: the second four waves first in pass 2)
     if (PK_BIG_PRIO == 3 && tid0 < 256) __builtin_amdgcn_s_setprio(3);   // (diagnostic: the first four)
 #define PK_BIG_STORE(field, F)                                                             \
   {                                                                                        \
     const Double2 v_ = {SA.field, SB.field};                                               \
-    __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
+    if (PK_BIG_NT_STORES != 0)                                                             \
+      __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
+    else                                                                                   \
+      *reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0) = v_;                           \
   }
 #pragma unroll 1
     for (int q = 0; q < NCH; ++q) {
@@ -2386,10 +2435,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
         const unsigned char* immutable = R->immutable;
         // (the scan-order table in global memory: see pub_big_fixed_lds_bytes)
-        acc += pub_apply_loop(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0]);
+        acc += pub_apply_loop<PK_BIG_APPLY_AHEAD != 0>(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0], za01, za23);
         {
           PubArgsPtr R8 = pub_args_now(rp);
-          acc += pub_apply_loop(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1]);
+          acc += pub_apply_loop<PK_BIG_APPLY_AHEAD != 0>(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1], zb01, zb23);
         }
         PK_STAMP(d2)
         PK_PSTAMP(8, d1, d2)
@@ -2419,7 +2468,23 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
           const int ln = min(PK_BIG_L0(more ? q + 1 : 0, tid), Lp - 2);
           const int32_t sn = more ? csrc : nsrc;
-          PK_BIG_ROWS(SA, SB, ln, sn)
+          if (PK_BIG_NT_LOADS != 0 && more) {
+            constexpr bool big_last_read = true;
+            PK_BIG_ROWS(SA, SB, ln, sn)
+          } else {
+            PK_BIG_ROWS(SA, SB, ln, sn)
+          }
+          if constexpr (PK_BIG_APPLY_AHEAD != 0) {  // the records of the next pair's blobs, right behind its rows
+            if (more) {
+              const double* exn = pub_args_now(rp)->exact;
+              const double* ra = exn + 6 * pub_apply_only_blob(Q[2]);
+              const double* rb_ = exn + 6 * pub_apply_only_blob(Q[3]);
+              za01 = *reinterpret_cast<const double2*>(ra);
+              za23 = *reinterpret_cast<const double2*>(ra + 2);
+              zb01 = *reinterpret_cast<const double2*>(rb_);
+              zb23 = *reinterpret_cast<const double2*>(rb_ + 2);
+            }
+          }
         }
         PK_STAMP(d3)
         PK_PSTAMP(10, d2, d3)
