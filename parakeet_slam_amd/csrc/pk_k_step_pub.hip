@@ -160,6 +160,10 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_RANKMAJOR
 #define PK_PUB_RANKMAJOR 1
 #endif
+// lanes per group of the octet order of k_step_pub: 8 (sixteen landmarks, 128 bytes of a row) or 4 (eight landmarks, 64 bytes)
+#ifndef PK_PUB_GRAIN
+#define PK_PUB_GRAIN 8
+#endif
 #ifndef PK_PUB_PERM_MECH
 #define PK_PUB_PERM_MECH 0
 #endif
@@ -441,17 +445,20 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     // (k_step_pub_big, SLOTS = 16: up to six chunks of 64 places -- the same ranking, chunk c takes ranks 512 c ... 512 c + 511 and
     // wave w of it the ranks 64 w ... : all eight waves work through lists of like length at the same time)
     constexpr bool kBig = SLOTS != kCandSlots;
-    constexpr int kPlaces = kBig ? kPubBigPlaces : 2 * kPubOctets;
+    // (PK_PUB_GRAIN = 4, k_step_pub only: groups of FOUR lanes -- eight landmarks, 64 bytes of a row -- 256 places, sixteen to
+    // a (wave, pair))
+    constexpr int kGrain = kBig ? 8 : PK_PUB_GRAIN, kLm = 2 * kGrain;  // lanes and landmarks per group
+    constexpr int kPlaces = kBig ? kPubBigPlaces : 2 * kPubOctets * (8 / kGrain);
     __shared__ int s_cost[kPlaces];
     unsigned short* perm = reinterpret_cast<unsigned short*>(a.glist + a.B + 1) + (kBig ? 2 * kPubOctets : 0);
-    const int n_oct = a.Lp / 16;
+    const int n_oct = a.Lp / kLm;
     if (n_oct <= kPlaces) {  // (uniform)
       if (tid < kPlaces) {
         int c = -1;
         if (tid < n_oct) {
           int longest = 0, sum = 0, passes = 0;
-          for (int i = 0; i < 16; ++i) {
-            const int l = 16 * tid + i;
+          for (int i = 0; i < kLm; ++i) {
+            const int l = kLm * tid + i;
             if (l >= a.L) break;
             const unsigned* cws = reinterpret_cast<const unsigned*>(a.cand + RW * (size_t)l + 1);
             int n = 0;
@@ -475,6 +482,9 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
         for (int o = 0; o < kPlaces; ++o) r += (s_cost[o] > c || (s_cost[o] == c && o < tid)) ? 1 : 0;
         if constexpr (kBig) {
           perm[PK_BIG_PERM != 0 ? r : tid] = (unsigned short)tid;  // place = chunk 64 + wave 8 + k = the rank itself
+        } else if constexpr (kGrain == 4) {
+          const int g = r >> 4, k = r & 15;  // sixteen groups of four lanes to a (wave, pair); every wave one costly and one cheap set
+          perm[2 * kPubOctets * (g >> 3) + 16 * (g & 7) + k] = (unsigned short)tid;
         } else {
           const int g = r >> 3, k = r & 7;
           int wave = g < 8 ? (g >> 1) : 4 + ((g - 8) >> 1), pair = g & 1;
@@ -1312,9 +1322,14 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   // the LONGEST candidate lists go to waves 0-3, the shortest to waves 4-7 -- the waves that come second in the CU's vector
   // memory queue all particle long, and that the others wait for at every barrier
   constexpr bool kPerm = PK_PUB_PERM != 0 && NP == 2 && THREADS == 512;
-  __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets : 1];
+  constexpr int kGrain = PK_PUB_GRAIN;  // lanes per group of the order: 8 (sixteen landmarks, 128 bytes of a row) or 4
+  static_assert(kGrain == 8 || (kGrain == 4 && PK_PUB_PERM_MECH == 0), "four-lane groups: lane word tid | group << 10 | group << 19");
+  __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets * (8 / kGrain) : 1];
   __shared__ unsigned s_rb[kCandSlots];  // the publish table's rank bases (k_cand_entries: entry of (blob g, rank r) = s_rb[r] + g)
-#define PK_PUB_L0(q_, t_) (kPerm ? (int)(((lw >> (kOctShift + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7) : 2 * kPubThreads * (q_) + 2 * (t_))
+#define PK_PUB_L0(q_, t_)                                                                                         \
+  (!kPerm ? 2 * kPubThreads * (q_) + 2 * (t_)                                                                     \
+          : kGrain == 8 ? (int)(((lw >> (kOctShift + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7)                     \
+                        : (int)(((lw >> (10 + 9 * (q_))) & 0x1FFu) << 3) + 2 * ((t_)&3))
   // (PK_PUB_PERM_MECH: where the two octet numbers live -- 0: above the lane index in one register, 1: in a register of their
   // own, 2: below the lane index)
   constexpr int kOctShift = PK_PUB_PERM_MECH == 0 ? 16 : 0;
@@ -1357,7 +1372,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     const unsigned char* gi = R->immutable;
     for (int i = tid; i < Lp; i += kPubThreads) smem[o_imm + (unsigned)i] = i < L ? gi[i] : (unsigned char)0;
     if constexpr (kPerm) {
-      if (tid < 2 * kPubOctets) s_perm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[tid];
+      if (tid < 2 * kPubOctets * (8 / kGrain)) s_perm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[tid];
     }
     if (tid < kCandSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
     if (tid == 0) {
@@ -1450,8 +1465,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   // (0xFF: none, the lane is beyond the map) -- read from LDS at every use the table cost 1.3 % of the kernel's time
   unsigned lane_word = (unsigned)tid0;
   if constexpr (kPerm) {
-    const unsigned octs = (unsigned)(s_perm[tid0 >> 3] & 0xFFu) | ((unsigned)(s_perm[kPubOctets + (tid0 >> 3)] & 0xFFu) << 8);
-    lane_word = PK_PUB_PERM_MECH == 0 ? ((unsigned)tid0 | (octs << 16)) : PK_PUB_PERM_MECH == 1 ? octs : (((unsigned)tid0 << 16) | octs);
+    if constexpr (kGrain == 8) {
+      const unsigned octs = (unsigned)(s_perm[tid0 >> 3] & 0xFFu) | ((unsigned)(s_perm[kPubOctets + (tid0 >> 3)] & 0xFFu) << 8);
+      lane_word = PK_PUB_PERM_MECH == 0 ? ((unsigned)tid0 | (octs << 16)) : PK_PUB_PERM_MECH == 1 ? octs : (((unsigned)tid0 << 16) | octs);
+    } else {  // (0x1FF: no group)
+      lane_word = (unsigned)tid0 | ((unsigned)(s_perm[tid0 >> 2] & 0x1FFu) << 10) | ((unsigned)(s_perm[2 * kPubOctets + (tid0 >> 2)] & 0x1FFu) << 19);
+    }
   }
   {
     const unsigned lw = lane_word;
@@ -1473,7 +1492,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       tid = tid0;
       asm volatile("" : "+v"(tid));
     } else {
-      tid = PK_PUB_PERM_MECH == 0 ? (int)(lw & 0xFFFFu) : (int)(lw >> 16);
+      tid = kGrain == 4 ? (int)(lw & 0x3FFu) : PK_PUB_PERM_MECH == 0 ? (int)(lw & 0xFFFFu) : (int)(lw >> 16);
     }
     double* ex = reinterpret_cast<double*>(smem);
     double* pub = reinterpret_cast<double*>(smem + o_pub);
