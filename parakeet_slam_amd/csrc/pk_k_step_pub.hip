@@ -164,6 +164,10 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_GRAIN
 #define PK_PUB_GRAIN 8
 #endif
+// k_step_pub's settling: 1 = two blobs per lane and turn (measured: +1.1 %)
+#ifndef PK_PUB_SETTLE_TWO
+#define PK_PUB_SETTLE_TWO 0
+#endif
 #ifndef PK_PUB_PERM_MECH
 #define PK_PUB_PERM_MECH 0
 #endif
@@ -1051,82 +1055,112 @@ template <int THREADS, int SLOTS = kCandSlots>
 __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist, unsigned G, double* pub, unsigned dump, int* flag,
                                                  const unsigned* rb) {
   constexpr bool kRankMajor = PK_PUB_RANKMAJOR != 0 && SLOTS > kCandSlots;
+  // TWO: two blobs per lane and turn, side by side -- reads of both, then compares, then both markers (k_step_pub, eight-entry
+  // lists: a turn is a chain of dependent LDS round trips -- list word, entries, marker -- with two waves per SIMD to cover it)
+  constexpr int TWO = (PK_PUB_SETTLE_TWO != 0 && SLOTS == kCandSlots && THREADS == 512) ? 2 : 1;
+  // (most contested blobs are listed by two or three landmarks: the first four entries in one batch, the rest -- wave-uniform --
+  // only where some lane's blob has more; round 4: the settling read and compared all SLOTS entries of every blob)
+  constexpr int kHead = SLOTS < 4 ? SLOTS : 4;
+  constexpr int kMid = SLOTS > 8 ? 8 : SLOTS;
   bool doubt = false;
 #pragma unroll 1
-  for (unsigned g = (unsigned)tid; __ballot(g < G) != 0ull; g += THREADS) {  // wave-uniform
-    const bool on = g < G;
-    const unsigned gi = glist[on ? g : 0u];
-    const unsigned n = on ? (gi >> 16) : 0u;
-    // entry of (this blob, rank r): rank-major rb[r] + g (the lanes of a wave read consecutive words), blob-major offs + r
-    const unsigned offs = gi & 0xFFFFu;
-    // (every contested blob has ranks 0 and 1: their bases are 0 and G)
-    auto entry = [&](int r) -> unsigned { return kRankMajor ? (r == 0 ? g : r == 1 ? G + g : rb[r] + g) : offs + (unsigned)r; };
-    // (most contested blobs are listed by two or three landmarks: the first four entries in one batch, the rest -- wave-uniform --
-    // only where some lane's blob has more; round 4: the settling read and compared all SLOTS entries of every blob)
-    constexpr int kHead = SLOTS < 4 ? SLOTS : 4;
-    constexpr int kMid = SLOTS > 8 ? 8 : SLOTS;
-    double v[SLOTS];
+  for (unsigned g0 = (unsigned)tid; __ballot(g0 < G) != 0ull; g0 += TWO * THREADS) {  // wave-uniform
+    unsigned g[TWO], n[TWO], offs[TWO], wr[TWO];
+    double v[TWO][SLOTS], best[TWO];
+    // entry of (blob, rank r): rank-major rb[r] + g (the lanes of a wave read consecutive words; every contested blob has ranks 0
+    // and 1: their bases are 0 and G), blob-major offs + r
+    auto entry = [&](int h, int r) -> unsigned {
+      return kRankMajor ? (r == 0 ? g[h] : r == 1 ? G + g[h] : rb[r] + g[h]) : offs[h] + (unsigned)r;
+    };
 #pragma unroll
-    for (int r = 0; r < kHead; ++r) v[r] = pub[(unsigned)r < n ? entry(r) : dump];
-    double best = pub_inf();
-    unsigned wr = 0u;
-#pragma unroll
-    for (int r = 0; r < kHead; ++r) {
-      v[r] = (unsigned)r < n ? v[r] : pub_inf();
-      const bool better = v[r] < best;  // strict: on equal keys the earlier rank stays (:377)
-      wr = better ? (unsigned)r : wr;
-      best = better ? v[r] : best;
+    for (int h = 0; h < TWO; ++h) {
+      g[h] = g0 + (unsigned)h * THREADS;
+      const bool on = g[h] < G;
+      const unsigned gi = glist[on ? g[h] : 0u];
+      offs[h] = gi & 0xFFFFu;
+      n[h] = on ? (gi >> 16) : 0u;
     }
-    const bool more = SLOTS > kHead && __ballot(n > (unsigned)kHead) != 0ull;  // wave-uniform
-    const bool most = SLOTS > kMid && __ballot(n > (unsigned)kMid) != 0ull;
+#pragma unroll
+    for (int h = 0; h < TWO; ++h)
+#pragma unroll
+      for (int r = 0; r < kHead; ++r) v[h][r] = pub[(unsigned)r < n[h] ? entry(h, r) : dump];
+    bool anymore = false, anymost = false;
+#pragma unroll
+    for (int h = 0; h < TWO; ++h) {
+      best[h] = pub_inf();
+      wr[h] = 0u;
+#pragma unroll
+      for (int r = 0; r < kHead; ++r) {
+        v[h][r] = (unsigned)r < n[h] ? v[h][r] : pub_inf();
+        const bool better = v[h][r] < best[h];  // strict: on equal keys the earlier rank stays (:377)
+        wr[h] = better ? (unsigned)r : wr[h];
+        best[h] = better ? v[h][r] : best[h];
+      }
+      anymore |= n[h] > (unsigned)kHead;
+      anymost |= n[h] > (unsigned)kMid;
+    }
+    const bool more = SLOTS > kHead && __ballot(anymore) != 0ull;  // wave-uniform
+    const bool most = SLOTS > kMid && __ballot(anymost) != 0ull;
     if (more) {
 #pragma unroll
-      for (int r = kHead; r < kMid; ++r) v[r] = pub[(unsigned)r < n ? entry(r) : dump];
+      for (int h = 0; h < TWO; ++h)
 #pragma unroll
-      for (int r = kHead; r < kMid; ++r) {
-        v[r] = (unsigned)r < n ? v[r] : pub_inf();
-        const bool better = v[r] < best;
-        wr = better ? (unsigned)r : wr;
-        best = better ? v[r] : best;
-      }
+        for (int r = kHead; r < kMid; ++r) v[h][r] = pub[(unsigned)r < n[h] ? entry(h, r) : dump];
+#pragma unroll
+      for (int h = 0; h < TWO; ++h)
+#pragma unroll
+        for (int r = kHead; r < kMid; ++r) {
+          v[h][r] = (unsigned)r < n[h] ? v[h][r] : pub_inf();
+          const bool better = v[h][r] < best[h];
+          wr[h] = better ? (unsigned)r : wr[h];
+          best[h] = better ? v[h][r] : best[h];
+        }
     }
     if (most) {
 #pragma unroll
-      for (int r = kMid; r < SLOTS; ++r) v[r] = pub[(unsigned)r < n ? entry(r) : dump];
+      for (int h = 0; h < TWO; ++h)
 #pragma unroll
-      for (int r = kMid; r < SLOTS; ++r) {
-        v[r] = (unsigned)r < n ? v[r] : pub_inf();
-        const bool better = v[r] < best;
-        wr = better ? (unsigned)r : wr;
-        best = better ? v[r] : best;
+        for (int r = kMid; r < SLOTS; ++r) v[h][r] = pub[(unsigned)r < n[h] ? entry(h, r) : dump];
+#pragma unroll
+      for (int h = 0; h < TWO; ++h)
+#pragma unroll
+        for (int r = kMid; r < SLOTS; ++r) {
+          v[h][r] = (unsigned)r < n[h] ? v[h][r] : pub_inf();
+          const bool better = v[h][r] < best[h];
+          wr[h] = better ? (unsigned)r : wr[h];
+          best[h] = better ? v[h][r] : best[h];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < TWO; ++h) {
+      int contenders = 0;
+      bool close = false;
+#pragma unroll
+      for (int r = 0; r < kHead; ++r) {
+        contenders += v[h][r] < pub_inf() ? 1 : 0;
+        close |= v[h][r] != best[h] && v[h][r] - best[h] < 1e-7;  // within 1e-7 of the winner without being identical to it
       }
-    }
-    int contenders = 0;
-    bool close = false;
+      if (more) {
 #pragma unroll
-    for (int r = 0; r < kHead; ++r) {
-      contenders += v[r] < pub_inf() ? 1 : 0;
-      close |= v[r] != best && v[r] - best < 1e-7;  // within 1e-7 of the winner without being identical to it
-    }
-    if (more) {
-#pragma unroll
-      for (int r = kHead; r < kMid; ++r) {
-        contenders += v[r] < pub_inf() ? 1 : 0;
-        close |= v[r] != best && v[r] - best < 1e-7;
+        for (int r = kHead; r < kMid; ++r) {
+          contenders += v[h][r] < pub_inf() ? 1 : 0;
+          close |= v[h][r] != best[h] && v[h][r] - best[h] < 1e-7;
+        }
       }
-    }
-    if (most) {
+      if (most) {
 #pragma unroll
-      for (int r = kMid; r < SLOTS; ++r) {
-        contenders += v[r] < pub_inf() ? 1 : 0;
-        close |= v[r] != best && v[r] - best < 1e-7;
+        for (int r = kMid; r < SLOTS; ++r) {
+          contenders += v[h][r] < pub_inf() ? 1 : 0;
+          close |= v[h][r] != best[h] && v[h][r] - best[h] < 1e-7;
+        }
       }
+      doubt |= close || (contenders >= 2 && best[h] > 1350.0);
     }
-    doubt |= close || (contenders >= 2 && best > 1350.0);
-    if (best < pub_inf()) {
-      unsigned we = kRankMajor ? g : offs + wr;
-      if constexpr (kRankMajor) we += rb[wr];
-      pub[we] = pub_marker();
+#pragma unroll
+    for (int h = 0; h < TWO; ++h) {  // (the two blobs' entries are disjoint: the markers go out behind every read of the turn)
+      unsigned we = kRankMajor ? g[h] : offs[h] + wr[h];
+      if constexpr (kRankMajor) we += wr[h] == 0u ? 0u : wr[h] == 1u ? G : rb[wr[h]];
+      pub[best[h] < pub_inf() ? we : dump] = best[h] < pub_inf() ? pub_marker() : pub_inf();
     }
   }
   if (doubt) *flag = 1;
