@@ -35,6 +35,8 @@
 // the particle's whole map in registers from its single coalesced load to its single coalesced store; 8 waves x 256
 // VGPRs are the CU's register file, and 256 registers hold a lane's four landmarks (116) plus the update's working set
 // without parking anything in LDS.
+#include <type_traits>
+
 #include "pk_device.hpp"
 
 namespace pk {
@@ -167,6 +169,10 @@ __device__ __forceinline__ void pub_pad() {
 // k_step_pub's settling: 1 = two blobs per lane and turn (measured: +1.1 %)
 #ifndef PK_PUB_SETTLE_TWO
 #define PK_PUB_SETTLE_TWO 0
+#endif
+// k_step_pub<2, 512>: 1 = the first four waves update both pairs before they store the first (0: every wave stores a pair behind its updates)
+#ifndef PK_PUB_STAGGER
+#define PK_PUB_STAGGER 0
 #endif
 #ifndef PK_PUB_PERM_MECH
 #define PK_PUB_PERM_MECH 0
@@ -1967,8 +1973,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #undef PK_PUB_HSTORE
         acc += wsum.finish();
       } else {  // the 256-lane instance (and diagnostic builds): round 3's order, a pair's rows out behind both its updates
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
+        // do_apply(q): the pair's two updates; do_store(q): its rows out and -- q < kPipe -- the next particle's pair asked for into
+        // the registers just stored
+        auto do_apply = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
           const int l0 = PK_PUB_L0(q, tid);
           if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
 #pragma unroll
@@ -1979,6 +1987,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
               acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i])
                                                  : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
           }
+        };
+        auto do_store = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const int l0 = PK_PUB_L0(q, tid);
           PK_STAMP(su0_)
           if (PK_PUB_P0_WHERE == 1 && NP == 2 && q == 1) {  // (diagnostic: the next first pair in front of the second pair's stores)
             PubArgsPtr R6 = pub_args_now(rp);
@@ -2035,6 +2047,27 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           }
           PK_STAMP(su1_)
           PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
+        };
+        using Q0 = std::integral_constant<int, 0>;
+        using Q1 = std::integral_constant<int, 1>;
+        if constexpr (NP == 2 && THREADS == 512 && PK_PUB_STAGGER != 0) {
+          // The two halves of the workgroup out of step: all eight waves leave barrier C together and met again at the first pair's
+          // thirty row stores / requests, the second four standing behind the first four in the texture addresser's queue (and being
+          // what barrier A then waits for).  The first four waves -- the ones with time to spare -- now do BOTH updates first:
+          // their memory burst comes while the second four are in their second update, and the other way round.
+          const bool spare = PK_PUB_STAGGER == 1 ? tid0 < 256 : tid0 >= 256;  // wave-uniform
+          do_apply(Q0{});
+          if (!spare) do_store(Q0{});
+          do_apply(Q1{});
+          if (spare) do_store(Q0{});
+          do_store(Q1{});
+        } else {
+          do_apply(Q0{});
+          do_store(Q0{});
+          if constexpr (NP == 2) {
+            do_apply(Q1{});
+            do_store(Q1{});
+          }
         }
       }
     }
