@@ -1604,70 +1604,74 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         // ---- 2. per pair: gates of its two landmarks (means only; failing candidates published at once), then their verdicts
         // on the gate-passing blobs (first use of the covariance rows)
         // (written out per pair: as nested unrolled loops the slot words were not promoted to registers)
-#define PK_PUB_PAIR(q)                                                                                                           \
-  {                                                                                                                              \
-    const int l0 = PK_PUB_L0((q), tid);                                                                              \
-    const PubGateIn gi[2] = {{cref[2 * (q)], {ccw[2 * (q)], ccw[2 * (q)]}, {cew[2 * (q)], cew[2 * (q)]}, S[2 * (q)].mx, S[2 * (q)].my,    \
-                              S[2 * (q)].mr, S[2 * (q)].mg, S[2 * (q)].mb, l0 < L},                                               \
-                             {cref[2 * (q) + 1], {ccw[2 * (q) + 1], ccw[2 * (q) + 1]}, {cew[2 * (q) + 1], cew[2 * (q) + 1]},       \
-                              S[2 * (q) + 1].mx, S[2 * (q) + 1].my, S[2 * (q) + 1].mr, S[2 * (q) + 1].mg, S[2 * (q) + 1].mb,       \
-                              l0 + 1 < L}};                                                                                      \
-    PubSlots qq[2] = {kPubNoSlots,                                            \
-                      kPubNoSlots};                                           \
-    double pp[2] = {0.0, 0.0};                                                                                                   \
-    if constexpr (THREADS == kPubSmallThreads) { /* three workgroups per CU: one landmark at a time (168 VGPRs) */                 \
-      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                                           \
-        const PubGateIn g1[1] = {gi[j_]};                                                                                          \
-        PubSlots q1[1] = {qq[j_]};                                                                                                 \
-        double p1[1] = {0.0};                                                                                                      \
-        const Landmark<double>* const l1[1] = {&S[2 * (q) + j_]};                                                                   \
-        if (PK_PUB_ABLATE < 4) pub_gatesN<1>(q1, p1, g1, ex, pub, dump, &wg_flag[cur], sx, sy, sh);                                \
-        if (PK_PUB_ABLATE < 3) pub_keysN<1>(q1, l1, p1, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                      \
-        qq[j_] = q1[0];                                                                                                            \
-        pp[j_] = p1[0];                                                                                                            \
-      }                                                                                                                            \
-    } else {                                                                                                                       \
-      const Landmark<double>* const l2[2] = {&S[2 * (q)], &S[2 * (q) + 1]};                                                        \
-      if ((q) == 0) pub_pad<PK_PUB_PAD_G0>(); else pub_pad<PK_PUB_PAD_G1>();                                                       \
-      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, PK_PUB_OVF != 0>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);   \
-      PK_STAMP(sk0_)                                                                                                               \
-      if constexpr (PK_PUB_LATE_P1 == 5 && NP > 1) {                                                                               \
-        if ((q) == 1) { /* diagnostic: the second pair's covariance rows behind its own gates */                                   \
-          PubArgsPtr R7 = pub_args_now(rp);                                                                                        \
-          PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])                                                                      \
-        }                                                                                                                          \
-      }                                                                                                                            \
-      if constexpr (PK_PUB_LATE_P1 == 6 && NP > 1) {                                                                               \
-        if ((q) == 0) { /* diagnostic: the second pair's MEANS behind the first pair's gates, its other rows as in 4 */            \
-          PK_PUB_LOAD_MEANS(1, sslot, lbase[1])                                                                                    \
-        }                                                                                                                          \
-      }                                                                                                                            \
-      if constexpr (PK_PUB_LATE_P1 == 1 && NP > 1) {                                                                               \
-        if ((q) == 0) { /* the second pair's rows asked for behind the first pair's GATES (diagnostic variant) */                  \
-          PubArgsPtr R7 = pub_args_now(rp);                                                                                        \
-          PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])                                                                      \
-        }                                                                                                                          \
-      }                                                                                                                            \
-      if ((q) == 0) pub_pad<PK_PUB_PAD_K0>(); else pub_pad<PK_PUB_PAD_K1>();                                                       \
-      if (PK_PUB_ABLATE < 3) {                                                                                                     \
-        pub_keysN<2, kPubSlots, false, PK_PUB_PRUNE != 0>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);        \
-        if constexpr (PK_PUB_OVF != 0) { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */ \
-          PubArgsPtr R9 = pub_args_now(rp);                                                                                        \
-          const int lc9 = min(l0, Lp);                                                                                             \
-          if (pub_refill_slots<2>(qq, R9->cand + 2 * (size_t)lc9, R9->erec + lc9, &wg_flag[cur]))                                  \
-            pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);                                         \
-        }                                                                                                                          \
-      }                                                                                                                            \
-      PK_STAMP(sk1_)                                                                                                               \
-      PK_PSTAMP(2, sk0_, sk1_) /* keys: part of the gates-and-verdicts slot */                                                     \
-    }                                                                                                                              \
-    Q[2 * (q)] = qq[0];                                                                                                          \
-    Q[2 * (q) + 1] = qq[1];                                                                                                      \
-    pse[2 * (q)] = pp[0];                                                                                                        \
-    pse[2 * (q) + 1] = pp[1];                                                                                                    \
-  }
+        auto do_pair = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+
+    const int l0 = PK_PUB_L0(q, tid);
+    const PubGateIn gi[2] = {{cref[2 * q], {ccw[2 * q], ccw[2 * q]}, {cew[2 * q], cew[2 * q]}, S[2 * q].mx, S[2 * q].my,
+                              S[2 * q].mr, S[2 * q].mg, S[2 * q].mb, l0 < L},
+                             {cref[2 * q + 1], {ccw[2 * q + 1], ccw[2 * q + 1]}, {cew[2 * q + 1], cew[2 * q + 1]},
+                              S[2 * q + 1].mx, S[2 * q + 1].my, S[2 * q + 1].mr, S[2 * q + 1].mg, S[2 * q + 1].mb,
+                              l0 + 1 < L}};
+    PubSlots qq[2] = {kPubNoSlots,
+                      kPubNoSlots};
+    double pp[2] = {0.0, 0.0};
+    if constexpr (THREADS == kPubSmallThreads) { /* three workgroups per CU: one landmark at a time (168 VGPRs) */
+      
+#pragma unroll
+      for (int j_ = 0; j_ < 2; ++j_) {
+        const PubGateIn g1[1] = {gi[j_]};
+        PubSlots q1[1] = {qq[j_]};
+        double p1[1] = {0.0};
+        const Landmark<double>* const l1[1] = {&S[2 * q + j_]};
+        if (PK_PUB_ABLATE < 4) pub_gatesN<1>(q1, p1, g1, ex, pub, dump, &wg_flag[cur], sx, sy, sh);
+        if (PK_PUB_ABLATE < 3) pub_keysN<1>(q1, l1, p1, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        qq[j_] = q1[0];
+        pp[j_] = p1[0];
+      }
+    } else {
+      const Landmark<double>* const l2[2] = {&S[2 * q], &S[2 * q + 1]};
+      if (q == 0) pub_pad<PK_PUB_PAD_G0>(); else pub_pad<PK_PUB_PAD_G1>();
+      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, PK_PUB_OVF != 0>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);
+      PK_STAMP(sk0_)
+      if constexpr (PK_PUB_LATE_P1 == 5 && NP > 1) {
+        if (q == 1) { /* diagnostic: the second pair's covariance rows behind its own gates */
+          PubArgsPtr R7 = pub_args_now(rp);
+          PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])
+        }
+      }
+      if constexpr (PK_PUB_LATE_P1 == 6 && NP > 1) {
+        if (q == 0) { /* diagnostic: the second pair's MEANS behind the first pair's gates, its other rows as in 4 */
+          PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
+        }
+      }
+      if constexpr (PK_PUB_LATE_P1 == 1 && NP > 1) {
+        if (q == 0) { /* the second pair's rows asked for behind the first pair's GATES (diagnostic variant) */
+          PubArgsPtr R7 = pub_args_now(rp);
+          PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
+        }
+      }
+      if (q == 0) pub_pad<PK_PUB_PAD_K0>(); else pub_pad<PK_PUB_PAD_K1>();
+      if (PK_PUB_ABLATE < 3) {
+        pub_keysN<2, kPubSlots, false, PK_PUB_PRUNE != 0>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        if constexpr (PK_PUB_OVF != 0) { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */
+          PubArgsPtr R9 = pub_args_now(rp);
+          const int lc9 = min(l0, Lp);
+          if (pub_refill_slots<2>(qq, R9->cand + 2 * (size_t)lc9, R9->erec + lc9, &wg_flag[cur]))
+            pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        }
+      }
+      PK_STAMP(sk1_)
+      PK_PSTAMP(2, sk0_, sk1_) /* keys: part of the gates-and-verdicts slot */
+    }
+    Q[2 * q] = qq[0];
+    Q[2 * q + 1] = qq[1];
+    pse[2 * q] = pp[0];
+    pse[2 * q + 1] = pp[1];
+  
+        };
         if (!done) {  // workgroup-uniform
-          PK_PUB_PAIR(0)
+          do_pair(std::integral_constant<int, 0>{});
           if constexpr (NP > 1) {
             if constexpr (PK_PUB_LATE_P1 == 7) {  // (diagnostic: means in front of the candidate records, the other rows behind)
               PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
@@ -1696,10 +1700,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
               asm volatile("" ::: "memory");
               PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
             }
-            PK_PUB_PAIR(1)
+            do_pair(std::integral_constant<int, 1>{});
           }
         }
-#undef PK_PUB_PAIR
         PK_STAMP(s2)
         PK_PSTAMP(1, s1, s2)  // gates and verdicts
 #ifdef PK_STAMPS
