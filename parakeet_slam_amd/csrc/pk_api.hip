@@ -1318,7 +1318,7 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
     if ((rc = dev_alloc(f, &f->bcnt_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->brec_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->binfo_dev, (size_t)cap))) return rc;
-    if ((rc = dev_alloc(f, &f->glist_dev, (size_t)cap + 1 + 256 + 16))) return rc;
+    if ((rc = dev_alloc(f, &f->glist_dev, 2 * (size_t)cap + 1 + 256 + 16))) return rc;
     if ((rc = dev_alloc(f, &f->gate4_dev, (size_t)cap))) return rc;
     f->bcand_cap = cap;
   }

@@ -174,6 +174,11 @@ __device__ __forceinline__ void pub_pad() {
 #ifndef PK_PUB_STAGGER
 #define PK_PUB_STAGGER 0
 #endif
+// k_step_pub<2, 512>: 1 = the counted protocol (pub_settle_counted: only the blobs two or more landmarks want are settled; measured: suite
+// and fuzz green, +0.6 %)
+#ifndef PK_PUB_COUNTED
+#define PK_PUB_COUNTED 0
+#endif
 #ifndef PK_PUB_PERM_MECH
 #define PK_PUB_PERM_MECH 0
 #endif
@@ -401,6 +406,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       const unsigned n = min(a.bcnt[t], (unsigned)SLOTS);
       const unsigned c = n >= 2u ? n : 0u;
       a.binfo[t] = (run & 0xFFFFu) | (n << 16);
+      a.glist[a.B + 1 + kPubTailWords + 16 + t] = (run & 0xFFFFu) | (n << 16);  // (for the counted protocol of k_step_pub<2, 512>)
       if (n >= 2u) a.glist[grun++] = (run & 0xFFFFu) | (n << 16);
       run += c;
     }
@@ -811,7 +817,9 @@ __device__ __forceinline__ double pub_log(double x) {
 // PRUNE: before the rounds, the blobs in slots 1.. whose key is certainly beyond the underflow edge ("far", below) are published
 // as no contenders and taken out, the others close ranks: a round costs the whole wave its arithmetic when ONE lane has a blob
 // that is not far, and the rounds behind the first were nearly all about look-alikes (10 % of k_step_pub's time)
-template <int N, int SL = kPubSlots, bool PRE = false, bool PRUNE = false>
+// COUNTED: any[t] COUNTS the landmarks that want blob t with a positive probability (a packed ds_add_u32 instead of a byte store):
+// a blob with one taker needs no settling (pub_settle_counted)
+template <int N, int SL = kPubSlots, bool PRE = false, bool PRUNE = false, bool COUNTED = false>
 __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
                                           unsigned anydump, int* flag, double sx, double sy, const double* pre_kbase = nullptr,
@@ -988,7 +996,13 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      any[positive[j] ? t[j] : anydump] = 1;
+      if constexpr (COUNTED) {
+        const unsigned tt = positive[j] ? t[j] : anydump;
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(any) + (tt >> 2), positive[j] ? 1u << (8u * (tt & 3u)) : 0u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        any[positive[j] ? t[j] : anydump] = 1;
+      }
       q[j].st |= positive[j] ? 1u : 0u;
       pub_rotate(q[j]);
     }
@@ -1190,6 +1204,108 @@ __device__ __forceinline__ void pub_take(PubSlots& q, const double* pub, unsigne
   }
 }
 
+// COUNTED protocol (k_step_pub<2, 512>): lane `tid` owns word `tid` of the any[] counters -- four blobs.  The blobs that two or more
+// landmarks want with a positive probability (and that several list at all) are compacted into a list of the lane's WAVE, which the
+// wave then settles as pub_settle_blobs would, one lane per blob -- one turn of the loop where the blob-parallel settling over
+// every contested blob took three or four; a blob with one taker is taken without a verdict (pub_take_counted).  binfo[t]:
+// first entry | listing landmarks << 16 of EVERY blob (blob-major table).  Returns the number of blobs nobody wants.
+constexpr int kPubWaveList = 224;  // (a wave's 256 blobs nearly never have more such; more: the particle is flagged)
+template <int SLOTS = kCandSlots>
+__device__ __forceinline__ int pub_settle_counted(int tid, const unsigned char* anyc, const unsigned* binfo, int B, unsigned Bp, double* pub,
+                                                  unsigned dump, int* flag, unsigned short* wl) {
+  const bool hasw = (unsigned)tid < Bp / 4u;
+  const unsigned v = hasw ? reinterpret_cast<const unsigned*>(anyc)[tid] : 0u;
+  int nun = 0;
+  unsigned base = 0u;
+  bool doubt = false;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int t = 4 * tid + b;
+    const unsigned c = (v >> (8 * b)) & 0xFFu;
+    const bool valid = hasw && t < B;
+    nun += (valid && c == 0u) ? 1 : 0;
+    const bool want = valid && c >= 2u;
+    const unsigned long long mask = __ballot(want);
+    const unsigned idx = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    if (want) {
+      if (idx < (unsigned)kPubWaveList) wl[idx] = (unsigned short)t;
+      else doubt = true;
+    }
+    base += (unsigned)__popcll(mask);
+  }
+  const unsigned cnt = min(base, (unsigned)kPubWaveList);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own list: written above, read below by other lanes of the wave
+  constexpr int kHead = SLOTS < 4 ? SLOTS : 4;
+#pragma unroll 1
+  for (unsigned i = (unsigned)(tid & 63); __ballot(i < cnt) != 0ull; i += 64u) {  // wave-uniform
+    const bool on = i < cnt;
+    const unsigned t = wl[on ? i : 0u];
+    const unsigned bi = binfo[on ? t : 0u];
+    const unsigned offs = bi & 0xFFFFu, n = (on && (bi >> 16) >= 2u) ? (bi >> 16) : 0u;  // (listed by one landmark: nothing to settle)
+    double vv[SLOTS];
+#pragma unroll
+    for (int r = 0; r < kHead; ++r) vv[r] = pub[(unsigned)r < n ? offs + r : dump];
+    double best = pub_inf();
+    unsigned wr = 0u;
+#pragma unroll
+    for (int r = 0; r < kHead; ++r) {
+      vv[r] = (unsigned)r < n ? vv[r] : pub_inf();
+      const bool better = vv[r] < best;  // strict: on equal keys the earlier rank stays (:377)
+      wr = better ? (unsigned)r : wr;
+      best = better ? vv[r] : best;
+    }
+    const bool more = SLOTS > kHead && __ballot(n > (unsigned)kHead) != 0ull;  // wave-uniform
+    if (more) {
+#pragma unroll
+      for (int r = kHead; r < SLOTS; ++r) vv[r] = pub[(unsigned)r < n ? offs + r : dump];
+#pragma unroll
+      for (int r = kHead; r < SLOTS; ++r) {
+        vv[r] = (unsigned)r < n ? vv[r] : pub_inf();
+        const bool better = vv[r] < best;
+        wr = better ? (unsigned)r : wr;
+        best = better ? vv[r] : best;
+      }
+    }
+    int contenders = 0;
+    bool close = false;
+#pragma unroll
+    for (int r = 0; r < kHead; ++r) {
+      contenders += vv[r] < pub_inf() ? 1 : 0;
+      close |= vv[r] != best && vv[r] - best < 1e-7;  // within 1e-7 of the winner without being identical to it
+    }
+    if (more) {
+#pragma unroll
+      for (int r = kHead; r < SLOTS; ++r) {
+        contenders += vv[r] < pub_inf() ? 1 : 0;
+        close |= vv[r] != best && vv[r] - best < 1e-7;
+      }
+    }
+    doubt |= close || (contenders >= 2 && best > 1350.0);
+    if (best < pub_inf()) pub[offs + wr] = pub_marker();
+  }
+  if (doubt) *flag = 1;
+  return nun;
+}
+// ... and the take: a positive blob nobody else lists, or nobody else wants (count 1: this landmark's own), or whose entry carries
+// the winner's marker
+__device__ __forceinline__ void pub_take_counted(PubSlots& q, const double* pub, unsigned dump, const unsigned char* anyc, unsigned anydump) {
+  const unsigned sw[kPubSlots] = {q.s[0], q.s[1], q.s[2], q.s[3]};
+  double m[kPubSlots];
+  unsigned c[kPubSlots];
+#pragma unroll
+  for (int s = 0; s < kPubSlots; ++s) {
+    const unsigned e = sw[s] >> 16, t = sw[s] & 0xFFFFu;
+    m[s] = pub[e == 0xFFFFu ? dump : e];
+    c[s] = anyc[t == 0xFFFFu ? anydump : t];
+  }
+#pragma unroll
+  for (int s = 0; s < kPubSlots; ++s) {
+    const unsigned e = sw[s] >> 16;
+    const bool pos = ((q.st >> (4 * s)) & 1u) != 0u;
+    if (pos && (e == 0xFFFFu || c[s] == 1u || m[s] == pub_marker())) q.st |= 4u << (4 * s);
+  }
+}
+
 // The blobs taken, applied in scan order (:88): regs_apply with the take bits.
 __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
                                             Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
@@ -1366,6 +1482,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   static_assert(kGrain == 8 || (kGrain == 4 && PK_PUB_PERM_MECH == 0), "four-lane groups: lane word tid | group << 10 | group << 19");
   __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets * (8 / kGrain) : 1];
   __shared__ unsigned s_rb[kCandSlots];  // the publish table's rank bases (k_cand_entries: entry of (blob g, rank r) = s_rb[r] + g)
+  constexpr bool kCounted = PK_PUB_COUNTED != 0 && NP == 2 && THREADS == 512;  // (Bp <= 2 048: lane tid owns word tid of any[])
+  __shared__ unsigned short s_wl[kCounted ? kPubWaves : 1][kCounted ? kPubWaveList : 1];
 #define PK_PUB_L0(q_, t_)                                                                                         \
   (!kPerm ? 2 * kPubThreads * (q_) + 2 * (t_)                                                                     \
           : kGrain == 8 ? (int)(((lw >> (kOctShift + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7)                     \
@@ -1403,7 +1521,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     const unsigned short* go = R->order;
     G = gb[B];
     for (int i = tid; i < B; i += kPubThreads) {
-      glist[i] = (unsigned)i < G ? gb[i] : 0u;
+      if constexpr (kCounted)
+        glist[i] = gb[B + 1 + kPubTailWords + 16 + i];  // binfo of EVERY blob: first entry | listing landmarks << 16
+      else
+        glist[i] = (unsigned)i < G ? gb[i] : 0u;
       order[i] = go[i];
     }
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
@@ -1653,12 +1774,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       }
       if (q == 0) pub_pad<PK_PUB_PAD_K0>(); else pub_pad<PK_PUB_PAD_K1>();
       if (PK_PUB_ABLATE < 3) {
-        pub_keysN<2, kPubSlots, false, PK_PUB_PRUNE != 0>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        pub_keysN<2, kPubSlots, false, PK_PUB_PRUNE != 0, kCounted>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
         if constexpr (PK_PUB_OVF != 0) { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */
           PubArgsPtr R9 = pub_args_now(rp);
           const int lc9 = min(l0, Lp);
           if (pub_refill_slots<2>(qq, R9->cand + 2 * (size_t)lc9, R9->erec + lc9, &wg_flag[cur]))
-            pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+            pub_keysN<2, kPubSlots, false, false, kCounted>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
         }
       }
       PK_STAMP(sk1_)
@@ -1731,23 +1852,31 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     double acc;
     {
       int nun = 0;
-      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) {
-        const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
+      if constexpr (kCounted) {
+        nun = pub_settle_counted(tid, anyc, glist, B, Bp, pub, dump, &wg_flag[cur], s_wl[tid >> 6]);
+      } else {
+        for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) {
+          const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
+          for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
+        }
       }
       acc = (double)nun * Consts<double>::log_no_match;  // unseen features: weight *= 0.1 each (:94-95)
       unsigned* anyn = reinterpret_cast<unsigned*>(smem + o_any + (unsigned)(cur ^ 1) * (Bp + 16u));
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
-    if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
+    if constexpr (!kCounted)
+      if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     PK_STAMP(s5)
     PK_PSTAMP(4, s4, s5)  // unseen blobs, settling
     lds_barrier();  // B: every winner is marked, every flag is set
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i)
-      if (PK_PUB_ABLATE < 2) pub_take(Q[i], pub, dump);
+      if (PK_PUB_ABLATE < 2) {
+        if constexpr (kCounted) pub_take_counted(Q[i], pub, dump, anyc, anydump);
+        else pub_take(Q[i], pub, dump);
+      }
     lds_barrier();  // C: every marker has been read -- the table is the next particle's
     if constexpr (PK_PUB_PRIO != 0 && THREADS == 512) {
       if (tid0 >= 256) __builtin_amdgcn_s_setprio(3);
