@@ -35,6 +35,13 @@
 // the particle's whole map in registers from its single coalesced load to its single coalesced store; 8 waves x 256
 // VGPRs are the CU's register file, and 256 registers hold a lane's four landmarks (116) plus the update's working set
 // without parking anything in LDS.
+//
+// Round 4: the lanes take their landmarks through a per-scan ORDER of sixteen-landmark groups (k_cand_entries
+// ranks them by the blobs inside the reference particle's gates and by list length: a round of gates or verdicts costs the whole
+// wave its arithmetic when one lane needs it); memory requests are issued in the order of their urgency (the texture addresser
+// serves a CU's vector-memory instructions in order); landmarks that pass more blobs than they have slots are settled in the
+// kernel.  k_step_pub_big (2 048 < L <= 6 144, two passes over the map, scan records in L2): the gates' first look goes to a float
+// copy of a candidate's bearing and colour, look-alikes beyond the underflow edge take no slot, the publish table is rank-major.
 #include <type_traits>
 
 #include "pk_device.hpp"
