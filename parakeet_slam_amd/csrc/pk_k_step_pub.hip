@@ -504,7 +504,16 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
         int r = 0;
         for (int o = 0; o < kPlaces; ++o) r += (s_cost[o] > c || (s_cost[o] == c && o < tid)) ? 1 : 0;
         if constexpr (kBig) {
-          perm[PK_BIG_PERM != 0 ? r : tid] = (unsigned short)tid;  // place = chunk 64 + wave 8 + k = the rank itself
+          int place = PK_BIG_PERM != 0 ? r : tid;  // place = chunk 64 + wave 8 + k = the rank itself
+          if (PK_BIG_PERM == 2 && r >= (n_oct / 64) * 64) {  // (diagnostic: the last, partial chunk dealt out evenly over the waves)
+            const int j = r - (n_oct / 64) * 64;
+            place = (n_oct / 64) * 64 + 8 * (j % 8) + j / 8;
+          }
+          if (PK_BIG_PERM == 3 && r >= (n_oct / 64) * 64) {  // (diagnostic: the last, partial chunk to the LAST waves instead of the first)
+            const int j = r - (n_oct / 64) * 64;
+            place = (n_oct / 64) * 64 + 8 * (7 - j / 8) + j % 8;
+          }
+          perm[place] = (unsigned short)tid;
         } else if constexpr (kGrain == 4) {
           const int g = r >> 4, k = r & 15;  // sixteen groups of four lanes to a (wave, pair); every wave one costly and one cheap set
           perm[2 * kPubOctets * (g >> 3) + 16 * (g & 7) + k] = (unsigned short)tid;
