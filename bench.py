@@ -829,6 +829,11 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+    elif args.force_sharded:  # (the single-rank group of --force-sharded)
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def facade_latency(device):
