@@ -33,7 +33,7 @@ def pk():
     return parakeet_slam_amd
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_devices_keyword_runs_the_reference_trajectory_on_sharded_ranks(pk, world):
     g = load_golden("step_small")
     P, L = int(g["P"]), int(g["L"])

@@ -64,7 +64,7 @@ def worker(rank, world, store, P_local, L, steps, skew, q):
 
 
 @pytest.mark.parametrize("world,P_local,skew", [(2, 1024, 0.0), (2, 1024, 6.0), (4, 1024, 3.0), (2, 300, 2.0), (4, 300, 3.0),
-                                                (3, 1500, 6.0)])
+                                                (3, 1500, 6.0), (8, 1024, 3.0), (8, 300, 3.0), (8, 300, 12.0)])
 def test_shards_reproduce_single_filter(world, P_local, skew):
     L, steps = 6, 3
     ctx = mp.get_context("spawn")
