@@ -306,6 +306,41 @@ int pk_motion_range(pk_filter* f, double v, double w, double dt, uint64_t seed, 
 int pk_staged_takes_regs(pk_filter* f); /* 1: the staged scan will take k_step_regs, 0: not (or nothing staged) */
 int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1, int32_t first, int32_t last);
 
+/* ---- balanced placement of the sharded filter: minimum migration (round 5) ----------------------
+ * The exchange above gives rank r the output slots [r P, (r + 1) P) of prkt_core_v2.py:233-250's ordered walk, so every rank
+ * boundary moves by the cumulative imbalance of the ranks below it, and it packs every particle of a contiguous index
+ * range, with or without children.  Here the ORDER of that walk is decoupled from where a particle lives: every physical
+ * slot carries the LOGICAL index of its particle -- its index in one filter holding all of them; the Philox counters of
+ * pk_motion and the weight scan are keyed by it, so the results stay those of one filter, bit for bit -- a rank keeps its
+ * own children (in its slots [0, m)), and only a rank's EXCESS children travel, to whichever rank has free slots; only
+ * particles that HAVE children there are packed.
+ *   pk_shard_state_dev          this rank's row for the ONE all-gather of a resample: [logw(P) | logical(P) as int64 bits]
+ *   pk_shard_plan_balanced_dev  from all ranks' rows (rank-major, 2 P words each): the 1-GPU weight scan in logical order, the
+ *                               offspring table, and the whole plan -- every rank derives it by itself.  dev_table: world rows
+ *                               of 2 world + 4 int64: per destination the range [a0, a1) of the row's rank's particles WITH
+ *                               children that it sends there, then n (children), m = min(n, P), ebase, dbase (running sums of
+ *                               the excess n - m and of the free slots P - m).  The caller reads the table on the host (it
+ *                               sizes the all-to-all) and hands it back to the two calls below.
+ *   pk_shard_pack_balanced_dev  the records for every other rank, destination-major; header = x, y, h, logw, lo, up, klo:
+ *                               the copy fills the destination's slots [lo, up), the child in slot k is logical klo + k - lo
+ *   pk_shard_adopt_balanced_dev mode 0: the whole new generation; 1: the slots [0, m) from this rank's own particles (the
+ *                               generation becomes current); 2: the slots [m, P) from the received records (after mode 1:
+ *                               the split step works on [0, m) while the records travel)
+ *   pk_shard_download_logical / pk_shard_reset_placement (slot j <- logical pk_set_shard's offset + j) /
+ *   pk_shard_download_balanced_offspring (the plan's table H[P_global + 1], tests) / pk_shard_balanced_errors (kernel-side
+ *   consistency failures: must stay 0).
+ * Once pk_shard_state_dev has run on a filter, pk_resample and the contiguous adoptions refuse it (PK_ERR_STATE). */
+int pk_shard_state_dev(pk_filter* f, double* dev_out);
+int pk_shard_plan_balanced_dev(pk_filter* f, const double* dev_global_state, int64_t global_particles, const double* dev_gmax,
+                               int32_t weight_domain, double u, int32_t world, int32_t rank, int64_t* dev_table);
+int pk_shard_pack_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, void* dev_buf);
+int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, const void* dev_recv,
+                                int64_t n_received, int32_t mode);
+int pk_shard_download_logical(pk_filter* f, int64_t* logical);
+int pk_shard_reset_placement(pk_filter* f);
+int pk_shard_download_balanced_offspring(pk_filter* f, int64_t global_particles, int64_t* H);
+int pk_shard_balanced_errors(pk_filter* f, int64_t* count);
+
 /* ---- single-triple probe ------------------------------------------------------
  * Runs the device functions the kernels are built from on ONE (pose, landmark, blob):
  * the scalar methods of FilterParticle the reference's unit tests call.

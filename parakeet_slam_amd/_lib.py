@@ -81,6 +81,15 @@ SIGNATURES = {
     "pk_shard_local_span_dev": (C.c_int, [_h, C.c_void_p]),
     "pk_shard_adopt_local_dev": (C.c_int, [_h, C.c_int32]),
     "pk_shard_adopt_remote_dev": (C.c_int, [_h, C.c_int32, C.c_void_p, C.c_int64]),
+    "pk_shard_state_dev": (C.c_int, [_h, C.c_void_p]),
+    "pk_shard_plan_balanced_dev": (C.c_int, [_h, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                             C.c_void_p]),
+    "pk_shard_pack_balanced_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p]),
+    "pk_shard_adopt_balanced_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
+    "pk_shard_download_logical": (C.c_int, [_h, _lp]),
+    "pk_shard_reset_placement": (C.c_int, [_h]),
+    "pk_shard_download_balanced_offspring": (C.c_int, [_h, C.c_int64, _lp]),
+    "pk_shard_balanced_errors": (C.c_int, [_h, _lp]),
     "pk_motion_range": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64]),
     "pk_staged_takes_regs": (C.c_int, [_h]),
     "pk_observe_staged_range": (C.c_int, [_h, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
@@ -364,6 +373,41 @@ class DeviceFilter(object):
 
     def shard_adopt_remote_dev(self, rank, recv_ptr, n_received):
         check(self._lib.pk_shard_adopt_remote_dev(self._h, int(rank), C.c_void_p(recv_ptr), int(n_received)))
+
+    # -- balanced placement (minimum migration) --
+    def shard_state_dev(self, out_ptr):
+        check(self._lib.pk_shard_state_dev(self._h, C.c_void_p(out_ptr)))
+
+    def shard_plan_balanced_dev(self, gstate_ptr, global_particles, gmax_ptr, domain, u, world, rank, table_ptr):
+        check(self._lib.pk_shard_plan_balanced_dev(self._h, C.c_void_p(gstate_ptr), int(global_particles), C.c_void_p(gmax_ptr),
+                                                   int(domain), float(u), int(world), int(rank), C.c_void_p(table_ptr)))
+
+    def shard_pack_balanced_dev(self, table, world, rank, buf_ptr):
+        t = np.ascontiguousarray(table, dtype=np.int64)
+        check(self._lib.pk_shard_pack_balanced_dev(self._h, lptr(t), int(world), int(rank), C.c_void_p(buf_ptr)))
+
+    def shard_adopt_balanced_dev(self, table, world, rank, recv_ptr, n_received, mode):
+        t = np.ascontiguousarray(table, dtype=np.int64)
+        check(self._lib.pk_shard_adopt_balanced_dev(self._h, lptr(t), int(world), int(rank), C.c_void_p(recv_ptr), int(n_received),
+                                                    int(mode)))
+
+    def download_logical(self):
+        out = np.empty(self.P, dtype=np.int64)
+        check(self._lib.pk_shard_download_logical(self._h, lptr(out)))
+        return out
+
+    def reset_placement(self):
+        check(self._lib.pk_shard_reset_placement(self._h))
+
+    def shard_download_balanced_offspring(self, global_particles):
+        out = np.empty(int(global_particles) + 1, dtype=np.int64)
+        check(self._lib.pk_shard_download_balanced_offspring(self._h, int(global_particles), lptr(out)))
+        return out
+
+    def shard_balanced_errors(self):
+        out = np.zeros(1, dtype=np.int64)
+        check(self._lib.pk_shard_balanced_errors(self._h, lptr(out)))
+        return int(out[0])
 
     def motion_range(self, v, w, dt, seed, draw, p0, p1):
         check(self._lib.pk_motion_range(self._h, float(v), float(w), float(dt), int(seed), int(draw), int(p0), int(p1)))

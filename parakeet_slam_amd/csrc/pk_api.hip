@@ -118,6 +118,8 @@ struct pk_filter {
   int64_t* srcs_dev = nullptr;  // P
   int64_t* rlohi_dev = nullptr; // (lo, hi) of the received records
   int64_t rlohi_cap = 0;
+  BalancedBuffers bal{};        // balanced placement of the sharded filter: the plan's tables (every rank holds the whole plan)
+  int64_t bal_m = -1;           // slots this rank's own children fill in the plan that is being carried out (-1: none)
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
   // host half of an ML scan upload done ahead of time (pk_stage_scan): tables built in a staging slot
@@ -625,9 +627,13 @@ int stage_ml_scan(pk_filter* f, const double* blobs, int B) {
 }
 
 // Will a production observe of a scan with these tables take the register route (k_step_regs)?
+// ... or, for maps beyond it, the two-pass publish / subscribe route (k_step_pub_big)?  Both run on particle ranges, which is
+// what the split step of the sharded filter needs (the conditions are enqueue_association's).
 static bool regs_route_taken(pk_filter* f, const BlobGrid& g, int B, int n9) {
   if (f->fast_observe != 1 || B <= 0 || f->d.lay.L >= 65535) return false;
-  return f->regs_step && f->d.lay.L > kFastMaxL && f->d.lay.L <= kRegsMaxL && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds;
+  if (f->regs_step && f->d.lay.L > kFastMaxL && f->d.lay.L <= kRegsMaxL && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds) return true;
+  return f->pub_step && f->cand_lists && f->d.lay.L > kRegsMaxL && f->d.lay.L <= kPubBigMaxL && step_pub_big_entry_capacity(B) > 0 &&
+         observe_sweep_plan(f->d, B).grid > 0;
 }
 
 // Upload one scan for maximum-likelihood association (one block) and enqueue the association.
@@ -964,6 +970,10 @@ int pk_destroy(pk_filter* f) {
   for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
+    if (q) (void)hipFree(q);
+  for (void* q : {(void*)d.logical[0], (void*)d.logical[1], (void*)f->bal.glogw, (void*)f->bal.clocal, (void*)f->bal.totals, (void*)f->bal.offsets,
+                  (void*)f->bal.sum, (void*)f->bal.H, (void*)f->bal.cloc, (void*)f->bal.ctot, (void*)f->bal.coff, (void*)f->bal.rel, (void*)f->bal.Hl,
+                  (void*)f->bal.alive, (void*)f->bal.bad})
     if (q) (void)hipFree(q);
   void* rest[] = {d.immutable, f->z_dev,  f->ids_dev,
                   f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
@@ -1387,9 +1397,10 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
   ObserveExtras e1 = ex;
   e1.flip = false;
   if (al.big) {
-    launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_pub(f), f->pub_ecap, f->gate4_dev);
+    launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_pub(f), f->pub_ecap, f->gate4_dev,
+                        p0, p1, reserve_cus);
     // a scan the kernel stood back from (a list overflowed, the table did not fit): every particle to the fall-back kernels
-    launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, 0, f->d.P);
+    launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
   } else if (al.regs) {
     if (f->pub_ecap > 0 && cand.rec)
       launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
@@ -1633,8 +1644,8 @@ int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1,
     sp.reset = fresh != 0;
     sp.al = AssocLaunch();
     if ((rc = enqueue_association(f, blobs, sp.B, false, true, &sp.al))) return rc;
-    if (!sp.al.regs) return fail(PK_ERR_STATE, "pk_observe_staged_range: the scan did not take the register route");
-    f->route = PK_ROUTE_ML_REGS;
+    if (!sp.al.regs && !sp.al.big) return fail(PK_ERR_STATE, "pk_observe_staged_range: the scan did not take the register route");
+    f->route = sp.al.big ? PK_ROUTE_ML_PUB_BIG : PK_ROUTE_ML_REGS;
     sp.cand = CandTable();
     if ((rc = onepass_prepare(f, sp.al, sp.B, &sp.cand, p1 > p0 ? p0 : 0))) return rc;
     sp.active = true;
@@ -1777,6 +1788,7 @@ int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestor
   if (weight_domain != PK_WEIGHTS_LINEAR && weight_domain != PK_WEIGHTS_LOG)
     return fail(PK_ERR_INVALID, "pk_resample: weight_domain %d", weight_domain);
   if (f->split.active) return fail(PK_ERR_STATE, "pk_resample: a split observe is in progress (half the particles observed)");
+  if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_resample: the balanced placement is active on this filter (its slots carry logical indices): resample through pk_shard_plan_balanced_dev / pk_shard_adopt_balanced_dev");
   int rc;
   if ((rc = use_device(f))) return rc;
   DeviceState& d = f->d;
@@ -1962,6 +1974,7 @@ int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, in
   const int64_t P = f->d.P;
   for (int64_t k = 0; k < P; ++k)
     if (src[k] >= P || src[k] < -n_received) return fail(PK_ERR_INVALID, "pk_adopt_particles: src[%lld] = %lld out of range", (long long)k, (long long)src[k]);
+  if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_adopt_particles: the balanced placement is active on this filter (its slots carry logical indices): resample through pk_shard_plan_balanced_dev / pk_shard_adopt_balanced_dev");
   int rc;
   if ((rc = use_device(f))) return rc;
   if (f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first
@@ -2136,6 +2149,7 @@ int pk_shard_pack_slots_dev(pk_filter* f, int64_t j0, int64_t j1, int64_t slot_l
 int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
   if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: call pk_shard_plan_dev first");
+  if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: the balanced placement is active on this filter (its slots carry logical indices): resample through pk_shard_plan_balanced_dev / pk_shard_adopt_balanced_dev");
   int rc;
   if ((rc = use_device(f))) return rc;
   if (f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first
@@ -2161,6 +2175,7 @@ int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t
 int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
   if (!f || rank < 0) return fail(PK_ERR_INVALID, "pk_shard_adopt_local_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_local_dev: call pk_shard_plan_dev first");
+  if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_adopt_local_dev: the balanced placement is active on this filter (its slots carry logical indices): resample through pk_shard_plan_balanced_dev / pk_shard_adopt_balanced_dev");
   int rc;
   if ((rc = use_device(f))) return rc;
   if (f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first
@@ -2209,6 +2224,219 @@ int pk_shard_local_span_dev(pk_filter* f, int64_t* dev_out2) {
   if ((rc = use_device(f))) return rc;
   PK_HIP(hipMemcpyAsync(dev_out2, f->hi_dev, sizeof(int64_t), hipMemcpyDeviceToDevice, f->stream));
   PK_HIP(hipMemcpyAsync(dev_out2 + 1, f->hi_dev + f->d.P, sizeof(int64_t), hipMemcpyDeviceToDevice, f->stream));
+  return PK_OK;
+}
+
+// ---- balanced placement: minimum migration (sharded.py::plan_balanced is the readable reference) ----
+static int ensure_logical(pk_filter* f) {
+  DeviceState& d = f->d;
+  if (d.logical[0]) return PK_OK;
+  int rc;
+  int64_t *a = nullptr, *b = nullptr;
+  if ((rc = dev_alloc(f, &a, (size_t)d.P))) return rc;
+  if ((rc = dev_alloc(f, &b, (size_t)d.P))) {
+    (void)hipFree(a);
+    return rc;
+  }
+  launch_iota64(f->stream, a, d.P, d.global_offset);
+  launch_iota64(f->stream, b, d.P, d.global_offset);
+  d.logical[0] = a;
+  d.logical[1] = b;
+  return PK_OK;
+}
+
+int pk_shard_reset_placement(pk_filter* f) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_shard_reset_placement: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (f->d.logical[0]) launch_iota64(f->stream, f->d.logical[f->d.cur], f->d.P, f->d.global_offset);
+  return PK_OK;
+}
+
+int pk_shard_download_logical(pk_filter* f, int64_t* logical) {
+  if (!f || !logical) return fail(PK_ERR_INVALID, "pk_shard_download_logical: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if (!f->d.logical[0]) {
+    for (int64_t j = 0; j < f->d.P; ++j) logical[j] = f->d.global_offset + j;
+    return PK_OK;
+  }
+  PK_HIP(hipMemcpyAsync(logical, f->d.logical[f->d.cur], (size_t)f->d.P * sizeof(int64_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+int pk_shard_state_dev(pk_filter* f, double* dev_out) {
+  if (!f || !dev_out) return fail(PK_ERR_INVALID, "pk_shard_state_dev: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = ensure_logical(f))) return rc;
+  launch_bal_state(f->stream, f->d, dev_out);
+  PK_LAUNCH_CHECK("pk_shard_state_dev");
+  return PK_OK;
+}
+
+int pk_shard_plan_balanced_dev(pk_filter* f, const double* dev_global_state, int64_t global_particles, const double* dev_gmax,
+                               int32_t weight_domain, double u, int32_t world, int32_t rank, int64_t* dev_table) {
+  if (!f || !dev_global_state || !dev_table || world < 1 || world > 64 || rank < 0 || rank >= world)
+    return fail(PK_ERR_INVALID, "pk_shard_plan_balanced_dev: bad argument (world 1 .. 64)");
+  if (weight_domain != PK_WEIGHTS_LINEAR && weight_domain != PK_WEIGHTS_LOG)
+    return fail(PK_ERR_INVALID, "pk_shard_plan_balanced_dev: weight_domain %d", weight_domain);
+  if (weight_domain == PK_WEIGHTS_LOG && !dev_gmax) return fail(PK_ERR_INVALID, "pk_shard_plan_balanced_dev: NULL maximum");
+  if (!(u >= 0.0 && u < 1.0)) return fail(PK_ERR_INVALID, "pk_shard_plan_balanced_dev: u = %g outside [0,1)", u);
+  const int64_t P = f->d.P, Pg = global_particles;
+  if (Pg != (int64_t)world * P || Pg >= ((int64_t)1 << 31))
+    return fail(PK_ERR_INVALID, "pk_shard_plan_balanced_dev: %lld particles are not %d shards of %lld (or more than 2^31)", (long long)Pg, world, (long long)P);
+  if (f->split.active) return fail(PK_ERR_STATE, "pk_shard_plan_balanced_dev: a split observe is in progress");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = ensure_logical(f))) return rc;
+  BalancedBuffers& b = f->bal;
+  const int64_t nbg = (Pg + kScanBlock - 1) / kScanBlock;
+  if (Pg > b.cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    for (void* q : {(void*)b.glogw, (void*)b.clocal, (void*)b.totals, (void*)b.offsets, (void*)b.H, (void*)b.cloc, (void*)b.ctot, (void*)b.coff})
+      if (q) (void)hipFree(q);
+    b.glogw = b.clocal = b.totals = b.offsets = nullptr;
+    b.H = nullptr;
+    b.cloc = b.ctot = b.coff = nullptr;
+    b.cap = 0;
+    if ((rc = dev_alloc(f, &b.glogw, (size_t)Pg))) return rc;
+    if ((rc = dev_alloc(f, &b.clocal, (size_t)Pg))) return rc;
+    if ((rc = dev_alloc(f, &b.totals, (size_t)nbg))) return rc;
+    if ((rc = dev_alloc(f, &b.offsets, (size_t)nbg + 1))) return rc;
+    if ((rc = dev_alloc(f, &b.H, (size_t)Pg + 1))) return rc;
+    if ((rc = dev_alloc(f, &b.cloc, (size_t)Pg))) return rc;
+    if ((rc = dev_alloc(f, &b.ctot, (size_t)nbg))) return rc;
+    if ((rc = dev_alloc(f, &b.coff, (size_t)nbg + 1))) return rc;
+    if (!b.sum && (rc = dev_alloc(f, &b.sum, (size_t)1))) return rc;
+    if (!b.rel && (rc = dev_alloc(f, &b.rel, (size_t)P + 1))) return rc;
+    if (!b.Hl && (rc = dev_alloc(f, &b.Hl, (size_t)P))) return rc;
+    if (!b.alive && (rc = dev_alloc(f, &b.alive, (size_t)P))) return rc;
+    if (!b.bad) {
+      if ((rc = dev_alloc(f, &b.bad, (size_t)1))) return rc;
+      PK_HIP(hipMemsetAsync(b.bad, 0, sizeof(int), f->stream));
+    }
+    b.cap = Pg;
+  }
+  Span t(f, PK_T_WEIGHTS);
+  launch_bal_plan(f->stream, f->d, dev_global_state, Pg, world, rank, dev_gmax ? dev_gmax : f->gmax, weight_domain, u, b, dev_table);
+  PK_LAUNCH_CHECK("pk_shard_plan_balanced_dev");
+  f->bal_m = -1;
+  return PK_OK;
+}
+
+int pk_shard_download_balanced_offspring(pk_filter* f, int64_t global_particles, int64_t* H) {
+  if (!f || !H) return fail(PK_ERR_INVALID, "pk_shard_download_balanced_offspring: NULL argument");
+  if (!f->bal.H || global_particles != f->bal.cap) return fail(PK_ERR_STATE, "pk_shard_download_balanced_offspring: no balanced plan of %lld particles yet", (long long)global_particles);
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipMemcpyAsync(H, f->bal.H, ((size_t)global_particles + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+// the plan's table as the host read it: world rows of (a0, a1) x world, n, m, ebase, dbase
+static int balanced_row_check(const int64_t* table, int world, int64_t P, const char* who) {
+  const int row = 2 * world + 4;
+  int64_t e_sum = 0, d_sum = 0;
+  for (int r = 0; r < world; ++r) {
+    const int64_t n = table[(size_t)r * row + 2 * world], m = table[(size_t)r * row + 2 * world + 1];
+    if (n < 0 || m != (n < P ? n : P) || table[(size_t)r * row + 2 * world + 2] != e_sum || table[(size_t)r * row + 2 * world + 3] != d_sum)
+      return fail(PK_ERR_INVALID, "%s: the plan table is not one pk_shard_plan_balanced_dev wrote (rank %d)", who, r);
+    e_sum += n - m;
+    d_sum += P - m;
+    for (int d = 0; d < world; ++d) {
+      const int64_t a0 = table[(size_t)r * row + 2 * d], a1 = table[(size_t)r * row + 2 * d + 1];
+      if (a0 < 0 || a1 < a0 || a1 > P) return fail(PK_ERR_INVALID, "%s: range [%lld, %lld) from rank %d to rank %d", who, (long long)a0, (long long)a1, r, d);
+    }
+  }
+  if (e_sum != d_sum) return fail(PK_ERR_INVALID, "%s: excess %lld and free slots %lld differ", who, (long long)e_sum, (long long)d_sum);
+  return PK_OK;
+}
+
+int pk_shard_pack_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, void* dev_buf) {
+  if (!f || !table || world < 1 || world > 64 || rank < 0 || rank >= world) return fail(PK_ERR_INVALID, "pk_shard_pack_balanced_dev: bad argument");
+  if (!f->bal.rel || !f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_pack_balanced_dev: call pk_shard_plan_balanced_dev first");
+  int rc;
+  const int64_t P = f->d.P;
+  if ((rc = balanced_row_check(table, world, P, "pk_shard_pack_balanced_dev"))) return rc;
+  if ((rc = use_device(f))) return rc;
+  const int row = 2 * world + 4;
+  const size_t stride = kPoseRecordBytes + f->d.lay.slot_bytes;
+  const int64_t ebase_s = table[(size_t)rank * row + 2 * world + 2];
+  int64_t rec = 0;
+  Span t(f, PK_T_RESAMPLE);
+  for (int d = 0; d < world; ++d) {
+    if (d == rank) continue;
+    const int64_t a0 = table[(size_t)rank * row + 2 * d], a1 = table[(size_t)rank * row + 2 * d + 1];
+    if (a1 <= a0) continue;
+    if (!dev_buf) return fail(PK_ERR_INVALID, "pk_shard_pack_balanced_dev: NULL buffer");
+    const int64_t m_d = table[(size_t)d * row + 2 * world + 1], dbase_d = table[(size_t)d * row + 2 * world + 3];
+    launch_bal_pack(f->stream, f->d, f->bal, a0, a1 - a0, ebase_s, dbase_d, P - m_d, m_d,
+                    static_cast<unsigned char*>(dev_buf) + (size_t)rec * stride);
+    rec += a1 - a0;
+  }
+  PK_LAUNCH_CHECK("pk_shard_pack_balanced_dev");
+  return PK_OK;
+}
+
+int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, const void* dev_recv,
+                                int64_t n_received, int32_t mode) {
+  if (!f || !table || world < 1 || world > 64 || rank < 0 || rank >= world || n_received < 0 || mode < 0 || mode > 2 ||
+      (n_received > 0 && !dev_recv))
+    return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: bad argument");
+  if (!f->bal.rel || !f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_adopt_balanced_dev: call pk_shard_plan_balanced_dev first");
+  int rc;
+  const int64_t P = f->d.P;
+  if ((rc = balanced_row_check(table, world, P, "pk_shard_adopt_balanced_dev"))) return rc;
+  const int row = 2 * world + 4;
+  const int64_t m = table[(size_t)rank * row + 2 * world + 1];
+  if (mode == 2) {
+    if (!f->adopt_local_done) return fail(PK_ERR_STATE, "pk_shard_adopt_balanced_dev: mode 1 first (it makes the new generation current)");
+    f->adopt_local_done = false;
+  }
+  if (mode != 1) {
+    int64_t expect = 0;
+    for (int s = 0; s < world; ++s)
+      if (s != rank) expect += table[(size_t)s * row + 2 * rank + 1] - table[(size_t)s * row + 2 * rank];
+    if (expect != n_received) return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: %lld records received, the plan sends %lld", (long long)n_received, (long long)expect);
+    if (m < P && n_received == 0) return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: %lld free slots and no records", (long long)(P - m));
+  }
+  if ((rc = use_device(f))) return rc;
+  if (mode != 2 && f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first
+    f->src_identity = false;
+    if ((rc = materialise(f))) return rc;
+  }
+  if (3 * n_received > 2 * f->rlohi_cap) {
+    PK_HIP(hipStreamSynchronize(f->stream));
+    if (f->rlohi_dev) (void)hipFree(f->rlohi_dev);
+    f->rlohi_dev = nullptr;
+    f->rlohi_cap = 0;
+    if ((rc = dev_alloc(f, &f->rlohi_dev, (size_t)(3 * n_received + 3 * n_received / 4 + 16)))) return rc;
+    f->rlohi_cap = (3 * n_received + 3 * n_received / 4) / 2;
+  }
+  Span t(f, PK_T_RESAMPLE);
+  launch_bal_adopt(f->stream, f->d, f->bal, m, static_cast<const unsigned char*>(dev_recv), n_received, f->rlohi_dev, mode);
+  PK_LAUNCH_CHECK("pk_shard_adopt_balanced_dev");
+  f->src_identity = false;
+  f->gmax_fused = false;
+  if (mode == 1) f->adopt_local_done = true;
+  return PK_OK;
+}
+
+/* consistency failures the balanced kernels counted since the filter was made (a logical index out of range, received
+ * records that do not tile the free slots): 0 unless the plan and the exchange disagree */
+int pk_shard_balanced_errors(pk_filter* f, int64_t* count) {
+  if (!f || !count) return fail(PK_ERR_INVALID, "pk_shard_balanced_errors: NULL argument");
+  *count = 0;
+  if (!f->bal.bad) return PK_OK;
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  int v = 0;
+  PK_HIP(hipMemcpyAsync(&v, f->bal.bad, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  *count = v;
   return PK_OK;
 }
 

@@ -14,7 +14,7 @@ __global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* 
                                                 const double* __restrict__ z, uint64_t seed,
                                                 uint64_t draw, int64_t goff, int motion_blocks,
                                                 uint4* __restrict__ up_dst, const uint4* __restrict__ up_src,
-                                                int64_t up_n16) {
+                                                int64_t up_n16, const int64_t* __restrict__ logical) {
   if ((int)blockIdx.x >= motion_blocks) {
     // the extra workgroups of a combined launch: the per-scan upload (see k_upload)
     const int64_t nb = (int64_t)gridDim.x - motion_blocks;
@@ -30,7 +30,9 @@ __global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* 
     z1 = z[3 * i + 1];
     z2 = z[3 * i + 2];
   } else {
-    uint64_t g = (uint64_t)(i + goff);
+    // the counter is the particle's index in the WHOLE filter: its slot plus the shard's offset, or -- balanced placement of
+    // the sharded filter -- the logical index its slot carries
+    uint64_t g = logical ? (uint64_t)logical[i] : (uint64_t)(i + goff);
     Philox4 a = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw,
                               (uint32_t)(draw >> 32) & 0x7fffffffu, (uint32_t)seed, (uint32_t)(seed >> 32));
     Philox4 b = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), (uint32_t)draw,
@@ -67,7 +69,8 @@ void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt,
   if (ub > 256) ub = 256;
   hipLaunchKernelGGL(k_motion, dim3((unsigned)(blocks + ub)), dim3(256), 0, s, d.x[d.cur], d.y[d.cur], d.h[d.cur], d.P,
                      v, w, dt, sd, sh, z_dev, seed, draw, global_offset + d.global_offset, blocks,
-                     static_cast<uint4*>(up_dst_dev), static_cast<const uint4*>(up_src_host_mapped), n16);
+                     static_cast<uint4*>(up_dst_dev), static_cast<const uint4*>(up_src_host_mapped), n16,
+                     (const int64_t*)d.logical[d.cur]);
 }
 
 // The same for the particles [p0, p1) only (device noise; the Philox counters use the global particle index, so the draws
@@ -81,7 +84,7 @@ void launch_motion_range(hipStream_t s, DeviceState& d, double v, double w, doub
   int blocks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(k_motion, dim3((unsigned)blocks), dim3(256), 0, s, d.x[d.cur] + p0, d.y[d.cur] + p0, d.h[d.cur] + p0, n, v, w,
                      dt, sd, sh, (const double*)nullptr, seed, draw, d.global_offset + p0, blocks, (uint4*)nullptr,
-                     (const uint4*)nullptr, (int64_t)0);
+                     (const uint4*)nullptr, (int64_t)0, d.logical[d.cur] ? (const int64_t*)(d.logical[d.cur] + p0) : (const int64_t*)nullptr);
 }
 
 __global__ void k_fill(double* p, int64_t n, double v) {

@@ -593,4 +593,328 @@ void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int6
   }
 }
 
+// ---- balanced placement (minimum migration; DESIGN.md section 6, sharded.py::plan_balanced is the readable reference) ----
+// Every physical slot g = rank * P + j carries the LOGICAL index of its particle (its index in one filter holding all of
+// them: what keys the Philox streams and orders the weight scan of prkt_core_v2.py:216-250).  Every rank holds the
+// all-gathered state rows [logw(P) | logical(P)] of all ranks and derives the whole plan by itself.
+__device__ __forceinline__ int64_t bal_logical(const double* __restrict__ gstate, int64_t P, int64_t g) {
+  const int64_t r = g / P, j = g - r * P;
+  return __double_as_longlong(gstate[(size_t)r * 2 * P + P + j]);
+}
+// the log-weights put into the single filter's order
+__global__ void __launch_bounds__(256) k_bal_scatter(const double* __restrict__ gstate, int64_t P, int64_t Pg,
+                                                     double* __restrict__ glogw, int* __restrict__ bad) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= Pg) return;
+  const int64_t r = g / P, j = g - r * P;
+  const int64_t l = __double_as_longlong(gstate[(size_t)r * 2 * P + P + j]);
+  if (l < 0 || l >= Pg) {  // a corrupted placement must not become an out-of-bounds store
+    atomicAdd(bad, 1);
+    return;
+  }
+  glogw[l] = gstate[(size_t)r * 2 * P + j];
+}
+// Children count of the particle in physical place g, c = H[l + 1] - H[l], as the packed scan element (c << 32) | (c > 0);
+// block-local inclusive scan over kScanBlock places (integers: any association gives the same sums).
+__global__ void __launch_bounds__(256) k_bal_counts(const double* __restrict__ gstate, const int64_t* __restrict__ H, int64_t P,
+                                                    int64_t Pg, long long* __restrict__ cloc, long long* __restrict__ ctot) {
+  __shared__ long long wtot[4];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * tid;
+  long long e[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    e[i] = 0;
+    if (base + i < Pg) {
+      int64_t l = bal_logical(gstate, P, base + i);
+      if (l < 0 || l >= Pg) l = 0;  // (reported by k_bal_scatter)
+      const long long c = H[l + 1] - H[l];
+      e[i] = (c << 32) | (c > 0 ? 1 : 0);
+    }
+  }
+  const long long s0 = e[0], s1 = s0 + e[1], s2 = s1 + e[2], s3 = s2 + e[3];
+  long long val = s3;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const long long t = __shfl_up(val, off, kWave);
+    if (lane >= off) val += t;
+  }
+  if (lane == kWave - 1) wtot[wave] = val;
+  long long prev = __shfl_up(val, 1, kWave);
+  if (lane == 0) prev = 0;
+  __syncthreads();
+  long long woff = 0;
+  for (int i = 0; i < wave; ++i) woff += wtot[i];
+  const long long excl = woff + prev;
+  if (base < Pg) cloc[base] = excl + s0;
+  if (base + 1 < Pg) cloc[base + 1] = excl + s1;
+  if (base + 2 < Pg) cloc[base + 2] = excl + s2;
+  if (base + 3 < Pg) cloc[base + 3] = excl + s3;
+  if (tid == 255) ctot[blockIdx.x] = excl + s3;
+}
+// exclusive packed prefix (children << 32 | particles with children) of the physical places [0, g)
+__device__ __forceinline__ long long bal_prefix(const long long* __restrict__ cloc, const long long* __restrict__ coff, int64_t g) {
+  return g == 0 ? 0 : coff[(g - 1) / kScanBlock] + cloc[g - 1];
+}
+constexpr int kBalMaxWorld = 64;
+// One workgroup: the block offsets, the per-rank tables (n, m, ebase, dbase) and who sends which of its particles to whom.
+// table: world rows of 2 world + 4 words -- (a0, a1) per destination (indices into the sender's list of particles WITH
+// children), then n, m, ebase, dbase of the row's rank.
+__global__ void __launch_bounds__(256) k_bal_plan(const long long* __restrict__ cloc, const long long* __restrict__ ctot,
+                                                  long long* __restrict__ coff, int64_t nbg, int64_t P, int world,
+                                                  int64_t* __restrict__ table) {
+  __shared__ long long s_bound[kBalMaxWorld + 1];
+  __shared__ int64_t s_n[kBalMaxWorld], s_m[kBalMaxWorld], s_eb[kBalMaxWorld], s_db[kBalMaxWorld];
+  __shared__ long long s_t[2048];
+  {
+    long long run = 0;  // (thread 0's)
+    for (int64_t c0 = 0; c0 < nbg; c0 += 2048) {
+      const int n = (int)((nbg - c0 < 2048) ? (nbg - c0) : 2048);
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) s_t[i] = ctot[c0 + i];
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int i = 0; i < n; ++i) {
+          const long long v = s_t[i];
+          s_t[i] = run;
+          run += v;
+        }
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += blockDim.x) coff[c0 + i] = s_t[i];
+    }
+    if (threadIdx.x == 0) coff[nbg] = run;
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r <= world; r += blockDim.x) s_bound[r] = bal_prefix(cloc, coff, (int64_t)r * P);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t eb = 0, db = 0;
+    for (int r = 0; r < world; ++r) {
+      const int64_t n = (s_bound[r + 1] >> 32) - (s_bound[r] >> 32);
+      const int64_t m = n < P ? n : P;
+      s_n[r] = n;
+      s_m[r] = m;
+      s_eb[r] = eb;
+      s_db[r] = db;
+      eb += n - m;
+      db += P - m;
+    }
+  }
+  __syncthreads();
+  const int row = 2 * world + 4;
+  for (int r = threadIdx.x; r < world; r += blockDim.x) {
+    table[(size_t)r * row + 2 * world + 0] = s_n[r];
+    table[(size_t)r * row + 2 * world + 1] = s_m[r];
+    table[(size_t)r * row + 2 * world + 2] = s_eb[r];
+    table[(size_t)r * row + 2 * world + 3] = s_db[r];
+  }
+  for (int pr = threadIdx.x; pr < world * world; pr += blockDim.x) {
+    const int s = pr / world, d = pr - s * world;
+    int64_t a0 = 0, a1 = 0;
+    const int64_t es = s_n[s] - s_m[s], dd = P - s_m[d];
+    const int64_t lo = s_eb[s] > s_db[d] ? s_eb[s] : s_db[d];
+    const int64_t up = (s_eb[s] + es < s_db[d] + dd) ? s_eb[s] + es : s_db[d] + dd;
+    if (s != d && up > lo) {
+      const int64_t q0 = P + lo - s_eb[s], q1 = P + up - s_eb[s];  // rank-relative child positions [q0, q1)
+      const int64_t gb = (int64_t)s * P;
+      const long long base = s_bound[s];
+      int64_t l = 0, u = P;  // first j with rel[j + 1] > q0
+      while (l < u) {
+        const int64_t mid = (l + u) >> 1;
+        if (((bal_prefix(cloc, coff, gb + mid + 1) - base) >> 32) > q0)
+          u = mid;
+        else
+          l = mid + 1;
+      }
+      const int64_t j0 = l;
+      l = 0;
+      u = P;  // first j with rel[j] >= q1
+      while (l < u) {
+        const int64_t mid = (l + u) >> 1;
+        if (((bal_prefix(cloc, coff, gb + mid) - base) >> 32) >= q1)
+          u = mid;
+        else
+          l = mid + 1;
+      }
+      const int64_t j1 = l < j0 ? j0 : l;
+      a0 = (bal_prefix(cloc, coff, gb + j0) - base) & 0xffffffffll;
+      a1 = (bal_prefix(cloc, coff, gb + j1) - base) & 0xffffffffll;
+    }
+    table[(size_t)s * row + 2 * d] = a0;
+    table[(size_t)s * row + 2 * d + 1] = a1;
+  }
+}
+// This rank's own tables: rel[j] = children of its particles [0, j) (P + 1), Hl[j] = first output slot of particle j's
+// children, alive[] = its particles with children, ascending.
+__global__ void __launch_bounds__(256) k_bal_own(const long long* __restrict__ cloc, const long long* __restrict__ coff,
+                                                 const int64_t* __restrict__ H, const int64_t* __restrict__ logical, int64_t P,
+                                                 int64_t gbase, int64_t* __restrict__ rel, int64_t* __restrict__ Hl,
+                                                 int32_t* __restrict__ alive) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > P) return;
+  const long long base = bal_prefix(cloc, coff, gbase);
+  const long long ex = bal_prefix(cloc, coff, gbase + j) - base;
+  rel[j] = ex >> 32;
+  if (j == P) return;
+  const long long in = bal_prefix(cloc, coff, gbase + j + 1) - base;
+  Hl[j] = H[logical[j]];
+  if ((in >> 32) > (ex >> 32)) alive[ex & 0xffffffffll] = (int32_t)j;
+}
+__global__ void __launch_bounds__(256) k_iota64(int64_t* p, int64_t n, int64_t off) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = off + i;
+}
+void launch_iota64(hipStream_t s, int64_t* p, int64_t n, int64_t off) {
+  if (n > 0) hipLaunchKernelGGL(k_iota64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, off);
+}
+// state row of this rank for the all-gather: [logw(P) | logical(P) as int64 bits]
+__global__ void __launch_bounds__(256) k_bal_state(const double* __restrict__ logw, const int64_t* __restrict__ logical, int64_t P,
+                                                   double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  out[j] = logw[j];
+  out[P + j] = __longlong_as_double(logical[j]);
+}
+void launch_bal_state(hipStream_t s, const DeviceState& d, double* out_dev) {
+  if (d.P > 0)
+    hipLaunchKernelGGL(k_bal_state, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.logw[d.cur], d.logical[d.cur], d.P,
+                       out_dev);
+}
+void launch_bal_plan(hipStream_t s, const DeviceState& d, const double* gstate_dev, int64_t Pg, int world, int rank,
+                     const double* gmax_dev, int domain, double u, BalancedBuffers& b, int64_t* table_dev) {
+  const int64_t P = d.P;
+  const int64_t nbg = (Pg + kScanBlock - 1) / kScanBlock;
+  hipLaunchKernelGGL(k_bal_scatter, dim3((unsigned)((Pg + 255) / 256)), dim3(256), 0, s, gstate_dev, P, Pg, b.glogw, b.bad);
+  // exactly the kernels of the 1-GPU resample on the whole filter's log-weights in logical order: same blocks, same bits
+  launch_scan_local_of(s, b.glogw, Pg, gmax_dev, domain, b.clocal, b.totals);
+  launch_scan_blocks(s, b.totals, nbg, b.offsets, b.sum);
+  launch_offspring_global(s, b.clocal, b.offsets, b.sum, 0, Pg, Pg, u, 1, b.H);
+  hipLaunchKernelGGL(k_bal_counts, dim3((unsigned)nbg), dim3(256), 0, s, gstate_dev, b.H, P, Pg, b.cloc, b.ctot);
+  hipLaunchKernelGGL(k_bal_plan, dim3(1), dim3(256), 0, s, b.cloc, b.ctot, b.coff, nbg, P, world, table_dev);
+  hipLaunchKernelGGL(k_bal_own, dim3((unsigned)((P + 1 + 255) / 256)), dim3(256), 0, s, b.cloc, b.coff, b.H, d.logical[d.cur], P,
+                     (int64_t)rank * P, b.rel, b.Hl, b.alive);
+}
+
+// Records of this rank's particles alive[a0 .. a0 + n) for one destination: header (x, y, h, logw, lo, up, klo, 0) -- the
+// free slots [lo, up) of the destination the particle's excess children fill, klo the logical index of the child in slot lo.
+__global__ void __launch_bounds__(256) k_bal_pack(SlotSource ss, const int32_t* __restrict__ src, const double* __restrict__ x,
+                                                  const double* __restrict__ y, const double* __restrict__ h,
+                                                  const double* __restrict__ lw, const int64_t* __restrict__ rel,
+                                                  const int64_t* __restrict__ Hl, const int32_t* __restrict__ alive, int64_t a0,
+                                                  int64_t P, int64_t ebase_s, int64_t dbase_d, int64_t dd_d, int64_t m_d,
+                                                  unsigned char* __restrict__ buf) {
+  const int64_t i = blockIdx.x;
+  const int64_t j = alive[a0 + i];
+  unsigned char* rec = buf + (size_t)i * (kPoseRecordBytes + ss.slot_bytes);
+  if (threadIdx.x == 0) {
+    double* hd = reinterpret_cast<double*>(rec);
+    hd[0] = x[j];
+    hd[1] = y[j];
+    hd[2] = h[j];
+    hd[3] = lw[j];
+    const int64_t r0 = rel[j] > P ? rel[j] : P, r1 = rel[j + 1] > P ? rel[j + 1] : P;
+    const int64_t e0 = ebase_s + r0 - P, e1 = ebase_s + r1 - P;
+    const int64_t elo = e0 > dbase_d ? e0 : dbase_d;
+    int64_t eup = e1 < dbase_d + dd_d ? e1 : dbase_d + dd_d;
+    if (eup < elo) eup = elo;
+    int64_t* hl = reinterpret_cast<int64_t*>(rec);
+    hl[4] = m_d + elo - dbase_d;
+    hl[5] = m_d + eup - dbase_d;
+    hl[6] = Hl[j] + (elo - ebase_s + P - rel[j]);
+    hl[7] = 0;
+  }
+  const uint4* s = reinterpret_cast<const uint4*>(ss.at(src[j]));
+  uint4* d = reinterpret_cast<uint4*>(rec + kPoseRecordBytes);
+  const size_t n = ss.slot_bytes / 16;
+  for (size_t k = threadIdx.x; k < n; k += blockDim.x) d[k] = s[k];
+}
+void launch_bal_pack(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t a0, int64_t n, int64_t ebase_s,
+                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_bal_pack, dim3((unsigned)n), dim3(256), 0, s, slot_source(d), d.src[d.cur], d.x[d.cur], d.y[d.cur],
+                     d.h[d.cur], d.logw[d.cur], b.rel, b.Hl, b.alive, a0, d.P, ebase_s, dbase_d, dd_d, m_d, buf_dev);
+}
+
+__global__ void __launch_bounds__(256) k_bal_extract(const unsigned char* __restrict__ buf, size_t stride, int64_t n,
+                                                     int64_t* __restrict__ rh) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t* hd = reinterpret_cast<const int64_t*>(buf + (size_t)r * stride);
+  rh[3 * r] = hd[4];
+  rh[3 * r + 1] = hd[5];
+  rh[3 * r + 2] = hd[6];
+}
+// New generation: slot k < m takes the child at position k of this rank's own particles, slot k >= m the received record
+// whose [lo, up) holds k (records arrive in slot order); every slot gets its logical index.
+__global__ void __launch_bounds__(256) k_bal_adopt(const double* __restrict__ x, const double* __restrict__ y,
+                                                   const double* __restrict__ h, const double* __restrict__ lw,
+                                                   const int32_t* __restrict__ src, double* __restrict__ x2,
+                                                   double* __restrict__ y2, double* __restrict__ h2, double* __restrict__ lw2,
+                                                   int32_t* __restrict__ src2, int64_t* __restrict__ logical2,
+                                                   const int64_t* __restrict__ rel, const int64_t* __restrict__ Hl, int64_t m,
+                                                   const unsigned char* __restrict__ buf, size_t stride,
+                                                   const int64_t* __restrict__ rh, int64_t n_recv, int64_t P, int mode,
+                                                   int* __restrict__ bad) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= P) return;
+  const bool local = k < m;
+  if ((mode == 1 && !local) || (mode == 2 && local)) return;
+  if (local) {
+    int64_t lo = 0, up = P - 1;  // first j with rel[j + 1] > k
+    while (lo < up) {
+      const int64_t mid = (lo + up) >> 1;
+      if (rel[mid + 1] > k)
+        up = mid;
+      else
+        lo = mid + 1;
+    }
+    x2[k] = x[lo];
+    y2[k] = y[lo];
+    h2[k] = h[lo];
+    lw2[k] = lw[lo];
+    src2[k] = src[lo];
+    logical2[k] = Hl[lo] + (k - rel[lo]);
+  } else {
+    if (n_recv <= 0) {
+      atomicAdd(bad, 1);
+      return;
+    }
+    int64_t lo = 0, up = n_recv - 1;  // first record with up_r > k
+    while (lo < up) {
+      const int64_t mid = (lo + up) >> 1;
+      if (rh[3 * mid + 1] > k)
+        up = mid;
+      else
+        lo = mid + 1;
+    }
+    if (!(rh[3 * lo] <= k && k < rh[3 * lo + 1])) atomicAdd(bad, 1);  // the records do not tile [m, P): plan and exchange disagree
+    const double* hd = reinterpret_cast<const double*>(buf + (size_t)lo * stride);
+    x2[k] = hd[0];
+    y2[k] = hd[1];
+    h2[k] = hd[2];
+    lw2[k] = hd[3];
+    src2[k] = (int32_t)(-(lo + 1));
+    logical2[k] = rh[3 * lo + 2] + (k - rh[3 * lo]);
+  }
+}
+void launch_bal_adopt(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t m, const unsigned char* buf_dev,
+                      int64_t n_recv, int64_t* rh_dev, int mode) {
+  if (d.P == 0) return;
+  // mode 2 (the received part of a split adoption) writes into the generation mode 1 has already made current
+  const int n = mode == 2 ? d.cur : d.cur ^ 1, c = n ^ 1;
+  const size_t stride = kPoseRecordBytes + d.lay.slot_bytes;
+  if (n_recv > 0 && mode != 1)
+    hipLaunchKernelGGL(k_bal_extract, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, buf_dev, stride, n_recv, rh_dev);
+  hipLaunchKernelGGL(k_bal_adopt, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c], d.logw[c],
+                     d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], d.logical[n], b.rel, b.Hl, m, buf_dev, stride, rh_dev,
+                     n_recv, d.P, mode, b.bad);
+  d.cur = n;
+  if (mode != 1) {
+    d.alt = n_recv > 0 ? buf_dev : nullptr;
+    d.alt_stride = stride;
+    d.alt_off = kPoseRecordBytes;
+  }
+}
+
 }  // namespace pk

@@ -2757,8 +2757,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
 
 void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                          const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
-                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev) {
-  if (d.P == 0) return;
+                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev, int64_t p0, int64_t p1,
+                         int reserve_cus) {
+  if (p1 < 0) p1 = d.P;
+  if (d.P == 0 || p1 <= p0) return;
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
     for (const void* fn : {reinterpret_cast<const void*>(k_step_pub_big<3>), reinterpret_cast<const void*>(k_step_pub_big<5>),
@@ -2784,8 +2786,8 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
   a.gate4 = gate4_dev;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
-  a.P = d.P;
-  a.p_begin = 0;
+  a.P = p1;
+  a.p_begin = p0;
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
@@ -2794,8 +2796,10 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
   a.gmax_key = ex.gmax_key;
   a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
   const int n_cu = device_cu_count();
-  int64_t grid_n = n_cu;
-  if (grid_n > d.P) grid_n = d.P;
+  // persistent grid, one workgroup per CU; reserve_cus as in launch_step_regs (the first part of a split step leaves CUs to
+  // the all-to-all's kernels)
+  int64_t grid_n = n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0);
+  if (grid_n > p1 - p0) grid_n = p1 - p0;
   const size_t lds = step_pub_big_lds_bytes(B, ecap);
   const int nch = (d.lay.Lp + 2 * kPubThreads - 1) / (2 * kPubThreads);
   if (nch <= 3)

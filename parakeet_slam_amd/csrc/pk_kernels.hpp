@@ -32,6 +32,10 @@ struct DeviceState {
   const unsigned char* alt = nullptr;
   size_t alt_stride = 0, alt_off = 0;
   int64_t global_offset = 0;  // index of local particle 0 in the whole filter (Philox counters)
+  // balanced placement of the sharded filter: the LOGICAL index of the particle in every physical slot
+  // (its index in one filter holding all particles -- what keys the Philox counters and orders the weight scan), double-buffered
+  // with the poses; NULL until the balanced exchange is first used (the logical index is global_offset + slot then)
+  int64_t* logical[2] = {nullptr, nullptr};
 };
 
 // Where the landmark slot of a particle lives: its own map buffer or the adoption buffer.
@@ -252,7 +256,8 @@ int step_pub_big_entry_capacity(int B);
 size_t step_pub_big_lds_bytes(int B, int ecap);
 void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                          const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
-                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev = nullptr);
+                         const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev = nullptr, int64_t p0 = 0,
+                         int64_t p1 = -1, int reserve_cus = 0);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued
@@ -290,7 +295,33 @@ void launch_probe_dense(hipStream_t s, const double* in_dev, double* out_dev);
 // sharded resample
 // record header in front of the map slot: x, y, h, logw, slot_lo, slot_hi (the last two int64:
 // the global output slots this copy fills at its destination; 0, 0 when the caller plans on the host)
-constexpr size_t kPoseRecordBytes = 6 * sizeof(double);
+// balanced placement: + klo (int64, the logical index of the child in slot_lo) + one spare word -- 64 bytes
+constexpr size_t kPoseRecordBytes = 8 * sizeof(double);
+// device tables of the balanced plan (all sized for the WHOLE filter: every rank derives the whole plan by itself)
+struct BalancedBuffers {
+  double* glogw = nullptr;    // [Pg] log-weights in logical order
+  double* clocal = nullptr;   // [Pg] block-local weight scans, [nbg] totals, [nbg + 1] offsets: the 1-GPU scan's tables
+  double* totals = nullptr;
+  double* offsets = nullptr;
+  double* sum = nullptr;
+  int64_t* H = nullptr;       // [Pg + 1] offspring table in logical order
+  long long* cloc = nullptr;  // [Pg] packed (children << 32 | has children) block-local scans in PHYSICAL order
+  long long* ctot = nullptr;  // [nbg], [nbg + 1]
+  long long* coff = nullptr;
+  int64_t* rel = nullptr;     // [P + 1] this rank's child positions
+  int64_t* Hl = nullptr;      // [P]
+  int32_t* alive = nullptr;   // [P]
+  int* bad = nullptr;         // consistency failures seen by the kernels (must stay 0)
+  int64_t cap = 0;            // Pg the tables were sized for
+};
+void launch_iota64(hipStream_t s, int64_t* p, int64_t n, int64_t off);
+void launch_bal_state(hipStream_t s, const DeviceState& d, double* out_dev);
+void launch_bal_plan(hipStream_t s, const DeviceState& d, const double* gstate_dev, int64_t Pg, int world, int rank,
+                     const double* gmax_dev, int domain, double u, BalancedBuffers& b, int64_t* table_dev);
+void launch_bal_pack(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t a0, int64_t n, int64_t ebase_s,
+                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev);
+void launch_bal_adopt(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t m, const unsigned char* buf_dev,
+                      int64_t n_recv, int64_t* rh_dev, int mode);
 void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,
                       int64_t first_block, int64_t P_local, int64_t P_global, double u, int last_shard,
                       int64_t* hi_dev);

@@ -87,8 +87,8 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
                     conn.send(("ok", None))
                 elif op == "summary":
                     conn.send(("ok", sf.summary()))
-                elif op == "poses":
-                    conn.send(("ok", sf.download_poses()))
+                elif op == "poses":  # with the logical index of every slot: the front end answers in the single filter's order
+                    conn.send(("ok", (sf.download_poses(), sf.logical_index())))
                 elif op == "landmarks":
                     conn.send(("ok", sf.download_landmarks(cmd[1], cmd[2])))
                 elif op == "set_particle":
@@ -104,6 +104,7 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
                     sf.upload_poses(poses)
                     if m is not None:
                         sf.upload_landmarks(0, P_local, m, c, k)
+                    sf.reset_placement()  # the snapshot's order: rank r holds the logical particles [r P, (r + 1) P) again
                     conn.send(("ok", None))
                 elif op == "motion_model":
                     _, pose, v, w, dt, z, seed, draw = cmd
@@ -310,8 +311,10 @@ class ShardedFastSLAM(object):
 
     def _noise(self):
         if self._rng == "global":  # numpy.random.normal(0, s, 1) x 3 per particle, particle-major (:185-193)
+            # the whole filter's normals in the reference's (= logical) particle order: every rank takes the rows of the
+            # particles it holds (ShardedFilter.motion)
             z = np.random.standard_normal((self.num_particles, 3))
-            return [z[r * self._P_local:(r + 1) * self._P_local] for r in range(len(self.devices))]
+            return [z] * len(self.devices)
         return [None] * len(self.devices)
 
     def _publish_all(self, pub, poses):
@@ -412,10 +415,25 @@ class ShardedFastSLAM(object):
 
     # ------------------------------------------------------------------ views
     def download_poses(self):
+        """(P, 4) poses and weights in the particle order of ONE filter (prkt_core_v2.py:43-44's list): the ranks answer with the
+        logical index of every slot they hold (balanced placement, sharded.py), the rows are put in that order."""
         with self._lock:
             if self._pose_cache is None:
-                self._pose_cache = np.concatenate(self._all("poses"))
+                parts = self._all("poses")
+                logical = np.concatenate([np.asarray(p[1], dtype=np.int64) for p in parts])
+                if not np.array_equal(np.sort(logical), np.arange(self.num_particles)):
+                    raise RuntimeError("the ranks' logical indices are not a permutation of the particles")
+                poses = np.empty((self.num_particles, 4))
+                poses[logical] = np.concatenate([p[0] for p in parts])
+                self._where = np.empty(self.num_particles, dtype=np.int64)  # logical index -> physical place rank * P_local + j
+                self._where[logical] = np.arange(self.num_particles)
+                self._pose_cache = poses
             return self._pose_cache
+
+    def _place(self, i):
+        """(rank, slot) that holds logical particle i now."""
+        self.download_poses()
+        return divmod(int(self._where[i]), self._P_local)
 
     def _particle_view(self, i):
         from .core import Feature, FilterParticle, _FeatureSet, _make_state
@@ -425,7 +443,7 @@ class ShardedFastSLAM(object):
             p = FilterParticle(_make_state(x, y, h))
             p.weight = float(w)
             p.Qt = self.Qt
-            r, j = divmod(i, self._P_local)
+            r, j = self._place(i)
             feats, lock, L, one = self._features, self._lock, self._L, self._one
 
             def load_all():
@@ -449,7 +467,7 @@ class ShardedFastSLAM(object):
 
         with self._lock:
             x, y, h = _state_pose(particle.state)
-            r, j = divmod(i, self._P_local)
+            r, j = self._place(i)
             L = self._L
             m = c = k = None
             ids = range(1, L + 1)
@@ -466,9 +484,9 @@ class ShardedFastSLAM(object):
         with self._lock:
             poses = self.download_poses()
             parts = self._all("landmarks", 0, self._P_local)
-            m = np.concatenate([p[0] for p in parts])
-            c = np.concatenate([p[1] for p in parts])
-            k = np.concatenate([p[2] for p in parts])
+            m = np.concatenate([p[0] for p in parts])[self._where]  # the single filter's particle order
+            c = np.concatenate([p[1] for p in parts])[self._where]
+            k = np.concatenate([p[2] for p in parts])[self._where]
             np.savez_compressed(
                 path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
                 immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),

@@ -116,6 +116,75 @@ def fill_from_received(local_src, rank, p_local, recv_ranges):
     return local_src, r0
 
 
+# --------------------------------------------------------------------------- balanced placement (minimum migration)
+def balanced_tables(n, p_local):
+    """Per-rank bookkeeping of the balanced placement, from n[r] = children of rank r's particles (sum = world * p_local).
+
+    Rank r keeps the first m[r] = min(n[r], p_local) of its children in its physical slots [0, m[r]); the other e[r] (its
+    EXCESS) leave; a rank with n[r] < p_local has dd[r] = p_local - n[r] free slots [m[r], p_local) (its DEFICIT).  All excess
+    children, numbered E = ebase[r] + (q - p_local) in (rank, child position q) order, fill all free slots, numbered
+    D = dbase[r] + (slot - m[r]) in (rank, slot) order: child E goes to free slot D = E.  Nothing else moves, and
+    sum(e) is the least number of children that can change rank with p_local slots per rank."""
+    n = np.asarray(n, dtype=np.int64)
+    m = np.minimum(n, p_local)
+    e = n - m
+    dd = p_local - m
+    ebase = np.concatenate([[0], np.cumsum(e)[:-1]]).astype(np.int64)
+    dbase = np.concatenate([[0], np.cumsum(dd)[:-1]]).astype(np.int64)
+    return m, e, dd, ebase, dbase
+
+
+def plan_balanced(H, logical_all, world, p_local):
+    """The whole balanced plan in NumPy -- the readable reference of pk_shard_plan_balanced_dev, and what the CPU tests check
+    the device tables against.
+
+    H: int64[Pg + 1], the single-filter offspring table in LOGICAL order (logical particle l fills output slots
+       [H[l], H[l + 1]) -- prkt_core_v2.py:233-250's ordered walk); logical_all: int64[Pg], the logical index of the particle
+       in physical place g = rank * p_local + j.
+
+    Returns (cq, nz, tables, pairs): cq int64[Pg + 1] the exclusive prefix of the children counts in PHYSICAL order, nz the
+    exclusive prefix of "has children" (a particle without children is never packed: after a resample three of four are
+    dead); tables = (n,) + balanced_tables(...); pairs int64[world, world, 2]: rank s sends the particles number [a0, a1)
+    of ITS LIST OF PARTICLES WITH CHILDREN to rank d."""
+    H = np.asarray(H, dtype=np.int64)
+    logical_all = np.asarray(logical_all, dtype=np.int64)
+    cnt = H[logical_all + 1] - H[logical_all]
+    cq = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    nz = np.concatenate([[0], np.cumsum(cnt > 0)]).astype(np.int64)
+    bounds = cq[np.arange(world + 1) * p_local]
+    n = np.diff(bounds)
+    m, e, dd, ebase, dbase = balanced_tables(n, p_local)
+    pairs = np.zeros((world, world, 2), dtype=np.int64)
+    for s in range(world):
+        rel = cq[s * p_local:(s + 1) * p_local + 1] - bounds[s]  # child positions of rank s's particles, rank-relative
+        nzr = nz[s * p_local:(s + 1) * p_local + 1] - nz[s * p_local]
+        for d in range(world):
+            lo, up = max(ebase[s], dbase[d]), min(ebase[s] + e[s], dbase[d] + dd[d])
+            if s == d or up <= lo:
+                continue
+            q0, q1 = p_local + lo - ebase[s], p_local + up - ebase[s]
+            j0 = np.searchsorted(rel[1:], q0, side="right")  # first j with rel[j + 1] > q0 (it has children)
+            j1 = np.searchsorted(rel[:-1], q1, side="left")  # first j with rel[j] >= q1
+            pairs[s, d] = nzr[j0], nzr[j1]
+    return cq, nz, (n, m, e, dd, ebase, dbase), pairs
+
+
+def balanced_record_ranges(rel, Hl, alive, a0, a1, p_local, ebase_s, dbase_d, dd_d, m_d):
+    """Headers of the records rank s packs for rank d: for the particles j = alive[a0 .. a1) the free slots [lo, up) of rank d
+    their excess children fill and klo, the logical index of the child in slot lo (the child in slot k is klo + k - lo).
+    rel: the rank-relative exclusive child-position prefix (p_local + 1), Hl[j] = H[logical[j]], alive: the rank's particles
+    with children, ascending.  Returns (j, lo, up, klo); every range is non-empty."""
+    j = np.asarray(alive, dtype=np.int64)[a0:a1]
+    e0 = ebase_s + np.maximum(rel[j], p_local) - p_local
+    e1 = ebase_s + np.maximum(rel[j + 1], p_local) - p_local
+    elo = np.maximum(e0, dbase_d)
+    eup = np.maximum(np.minimum(e1, dbase_d + dd_d), elo)
+    lo = m_d + elo - dbase_d
+    up = m_d + eup - dbase_d
+    klo = Hl[j] + (elo - ebase_s + p_local - rel[j])
+    return j, lo, up, klo
+
+
 # --------------------------------------------------------------------------- communicators
 class TorchComm(object):
     """torch.distributed on torch tensors, in place.  'nccl' (= RCCL over xGMI) runs on the device
@@ -262,6 +331,25 @@ class HipShard(_lib.DeviceFilter):
     def adopt_from(self, rank, recv, n_received):
         self.shard_adopt_dev(rank, recv.data_ptr() if (recv is not None and n_received) else 0, n_received)
 
+    # -- balanced placement --
+    def state_into(self, t):
+        self.shard_state_dev(t.data_ptr())
+
+    def plan_balanced_into(self, gstate_t, global_particles, gmax_t, domain, u, world, rank, table_t):
+        self._bal_pg = int(global_particles)
+        self.shard_plan_balanced_dev(gstate_t.data_ptr(), global_particles, gmax_t.data_ptr() if gmax_t is not None else 0, domain, u,
+                                     world, rank, table_t.data_ptr())
+
+    def pack_balanced_into(self, table, world, rank, buf):
+        self.shard_pack_balanced_dev(table, world, rank, buf.data_ptr())
+
+    def adopt_balanced(self, table, world, rank, recv, n_received, mode=0):
+        self.shard_adopt_balanced_dev(table, world, rank, recv.data_ptr() if (recv is not None and n_received) else 0, n_received,
+                                      mode)
+
+    def download_balanced_offspring(self):
+        return self.shard_download_balanced_offspring(self._bal_pg)
+
     # -- the split step --
     def local_span_into(self, t2):
         self.shard_local_span_dev(t2.data_ptr())
@@ -300,7 +388,7 @@ class ShardedFilter(object):
     and the tests use, with the resample made global across ranks."""
 
     def __init__(self, particles_per_rank, num_landmarks, device=0, comm=None, shard=None, global_scan=None, split_step=None,
-                 loopback=None):
+                 loopback=None, placement=None):
         self.comm = comm if comm is not None else TorchComm()
         self.rank, self.world = self.comm.rank, self.comm.world
         self.P = int(particles_per_rank)
@@ -332,6 +420,22 @@ class ShardedFilter(object):
         # that really travelled even where only one device exists
         self.loopback = tuple(int(v) for v in loopback) if loopback is not None else None
         self.loopback_records = 0
+        # "balanced" (the default between ranks): the physical slots carry their LOGICAL index (the index the particle has in
+        # one filter holding everything -- what keys the Philox streams and orders the weight scan); a rank keeps its own
+        # children and ships only its excess to whichever rank is short (balanced_tables above).  "contiguous": rank r
+        # holds the logical slots [r P, (r + 1) P), whatever that moves (rounds 1-4).
+        if placement is None:
+            placement = "balanced" if (self.world > 1 and self.loopback is None and hasattr(f, "plan_balanced_into")) else "contiguous"
+        if placement not in ("balanced", "contiguous"):
+            raise ValueError("placement must be 'balanced' or 'contiguous'")
+        if placement == "balanced" and self.loopback is not None:
+            raise ValueError("the loopback debug mode exercises the contiguous exchange")
+        self.placement = placement
+        if placement == "balanced":
+            self._state = f.new_f64(2 * self.P)  # [log-weights | logical indices (int64 bits)]
+            self._gstate = f.new_f64(2 * self.P * self.world) if self.world > 1 else self._state
+            self._brow = 2 * self.world + 4
+            self._btable = f.new_i64(self._brow * self.world)
         self._sums = f.new_f64(4)
         self._recv_keepalive = None
         self._pending = None  # a resample whose exchange has been planned on the GPU but not carried out yet
@@ -356,8 +460,31 @@ class ShardedFilter(object):
         return self.f.reset_weights()
 
     def motion(self, v, w, dt, z=None, seed=0, draw=0):
+        """z (the reference's RNG mode): the normals of THIS rank's particles in physical order (P rows), or those of the
+        whole filter in logical order (P_global rows: each rank takes the rows of the particles it holds)."""
         self._complete()
-        return self.f.motion(v, w, dt, z=z, seed=seed, draw=draw)
+        return self.f.motion(v, w, dt, z=self._my_rows(z), seed=seed, draw=draw)
+
+    def _my_rows(self, z):
+        if z is None:
+            return None
+        z = np.asarray(z, dtype=np.float64)
+        if z.shape[0] == self.P_global and self.world > 1:
+            return np.ascontiguousarray(z[self.logical_index()])
+        return z
+
+    def logical_index(self):
+        """int64[P]: the logical index (the particle's index in one filter holding everything) of every physical slot."""
+        self._complete()
+        if self.placement == "balanced":
+            return np.asarray(self.f.download_logical(), dtype=np.int64)
+        return self.rank * self.P + np.arange(self.P, dtype=np.int64)
+
+    def reset_placement(self):
+        """Physical slot j holds logical particle rank * P + j again (after a state upload in that order)."""
+        self._complete()
+        if self.placement == "balanced":
+            self.f.reset_placement()
 
     def observe(self, blobs, ids=None, return_ids=False, fresh=False):
         self._complete()
@@ -439,6 +566,16 @@ class ShardedFilter(object):
             f.max_logw_into(gmax)
             if W > 1:
                 comm.all_reduce_max_(gmax)
+        if self.placement == "balanced":
+            # ONE all-gather (16 B per particle of the whole filter); every rank then runs the 1-GPU scan on the weights in
+            # logical order and derives the whole plan -- who keeps what, who sends which particles to whom -- by itself
+            f.state_into(self._state)
+            if W > 1:
+                comm.all_gather_(self._gstate, self._state)
+            f.plan_balanced_into(self._gstate, self.P_global, gmax, domain, u, W, R, self._btable)
+            handle = f.start_host_read(self._btable) if hasattr(f, "start_host_read") else None
+            self._pending = (self._btable, handle)
+            return
         if self.global_scan:
             f.logw_into(self._logw)
             if W > 1:
@@ -470,6 +607,14 @@ class ShardedFilter(object):
         self._pending = None
         f, W, R = self.f, self.world, self.rank
         host = f.finish_host_read(handle) if handle is not None else table.cpu().numpy()
+        if self.placement == "balanced":
+            rows = np.asarray(host, dtype=np.int64).reshape(W, self._brow)
+            allr = rows[:, :2 * W].reshape(W, W, 2)
+            counts = allr[:, :, 1] - allr[:, :, 0]
+            send_counts = [int(counts[R, d]) for d in range(W)]
+            recv_counts = [int(counts[s, R]) for s in range(W)]
+            self._bhost = rows
+            return rows, send_counts, recv_counts, int(counts.sum()), 0, int(rows[R, 2 * W + 1])
         rows = np.asarray(host).reshape(W, self._row)
         allr = rows[:, :2 * W].reshape(W, W, 2)  # [source][destination] -> (j0, j1)
         counts = allr[:, :, 1] - allr[:, :, 0]
@@ -493,12 +638,19 @@ class ShardedFilter(object):
             self.last_migrated = n_send
             self.total_migrated += n_send
             recv = None
+            bal = self.placement == "balanced"
             if W > 1 and moving > 0:  # every rank takes part in the exchange, even with nothing of its own to move
                 send = f.alloc_records(n_send)
                 if n_send:
-                    f.pack_into(allr[R].reshape(-1), W, R, send)
+                    if bal:
+                        f.pack_balanced_into(allr.reshape(-1), W, R, send)
+                    else:
+                        f.pack_into(allr[R].reshape(-1), W, R, send)
                 recv = comm.all_to_all_records(send, send_counts, recv_counts, f.particle_bytes())
-            f.adopt_from(R, recv, n_recv)
+            if bal:
+                f.adopt_balanced(allr.reshape(-1), W, R, recv, n_recv, 0)
+            else:
+                f.adopt_from(R, recv, n_recv)
             self._recv_keepalive = recv if n_recv else None
 
     def _complete_and_step_split(self, v, w, dt, seed, draw):
@@ -512,10 +664,14 @@ class ShardedFilter(object):
             self.last_migrated = n_send
             self.total_migrated += n_send
             recv, work = None, None
+            bal = self.placement == "balanced"
             if W > 1 and moving > 0:
                 send = f.alloc_records(n_send)
-                if n_send:
-                    f.pack_into(allr[R].reshape(-1), W, R, send)  # from the OLD generation: before the adoption below
+                if n_send:  # from the OLD generation: before the adoption below
+                    if bal:
+                        f.pack_balanced_into(allr.reshape(-1), W, R, send)
+                    else:
+                        f.pack_into(allr[R].reshape(-1), W, R, send)
                 recv, work = comm.all_to_all_records_async(send, send_counts, recv_counts, f.particle_bytes())
             elif W == 1 and self.loopback is not None and sum(self.loopback) > 0:
                 # one rank, slots [0, n_front) and [P - n_back, P) through the exchange (see __init__)
@@ -537,9 +693,15 @@ class ShardedFilter(object):
                 f.set_option("split_loopback_hi", hi_s)
                 a, b = lo_s, hi_s
                 self.loopback_records += n_recv
-            f.adopt_local(R)
+            if bal:  # the rank's own children fill [0, m) = [a, b); what it is sent fills [m, P)
+                f.adopt_balanced(allr.reshape(-1), W, R, None, 0, 1)
+            else:
+                f.adopt_local(R)
             if recv is None:  # nobody changes rank this time: every slot is filled locally, one launch over all of them
-                f.adopt_remote(R, None, 0)
+                if bal:
+                    f.adopt_balanced(allr.reshape(-1), W, R, None, 0, 2)
+                else:
+                    f.adopt_remote(R, None, 0)
                 f.motion_range(v, w, dt, seed, draw, 0, self.P)
                 f.observe_staged_range(True, 0, self.P, True, True)
             else:
@@ -547,7 +709,10 @@ class ShardedFilter(object):
                 f.observe_staged_range(True, a, b, True, False)  # weight reset (:73) fused in; consumes the staged scan
                 if work is not None:
                     work.wait()  # the stream waits for the records, the host does not
-                f.adopt_remote(R, recv, n_recv)
+                if bal:
+                    f.adopt_balanced(allr.reshape(-1), W, R, recv, n_recv, 2)
+                else:
+                    f.adopt_remote(R, recv, n_recv)
                 f.motion_range(v, w, dt, seed, draw, 0, a)
                 f.motion_range(v, w, dt, seed, draw, b, self.P)
                 f.observe_staged_range(True, 0, a, False, False)
@@ -557,7 +722,11 @@ class ShardedFilter(object):
 
     def _global_ancestors(self, u, domain):
         """Tests only: global ancestor index of every local output slot, from the host-array
-        variant of the same plan (pk_shard_offspring)."""
+        variant of the same plan (pk_shard_offspring).  Balanced placement: the ancestors' LOGICAL indices, in the physical
+        order of this rank's slots (logical_index() says which output slot of the single filter each of them is)."""
+        if self.placement == "balanced":
+            H = np.maximum.accumulate(np.asarray(self.f.download_balanced_offspring(), dtype=np.int64))
+            return np.searchsorted(H[1:], self.logical_index(), side="right").astype(np.int64)
         if self.global_scan:
             hi = self.f.shard_download_offspring()  # the table the plan itself used
         else:
@@ -592,7 +761,7 @@ class ShardedFilter(object):
             self._complete_and_step_split(v, w, dt, seed, draw)
         else:
             self._complete()
-            self.f.motion(v, w, dt, z=z, seed=seed, draw=draw)
+            self.f.motion(v, w, dt, z=self._my_rows(z), seed=seed, draw=draw)
             if staged:
                 self.f.observe_staged(fresh=True)  # weight reset (:73) fused into the observe kernels
                 self._recv_keepalive = None

@@ -30,6 +30,7 @@ class OracleShard(object):
 
     def set_shard(self, off):
         self.off = off
+        self.logical = off + np.arange(self.P, dtype=np.int64)  # balanced placement: logical index of the particle in place j
 
     def upload_map(self, *a, **k):
         pass
@@ -39,6 +40,12 @@ class OracleShard(object):
 
     def motion(self, v, w, dt, z=None, seed=0, draw=0):
         self.o.motion(v, w, dt, z)
+
+    def download_logical(self):
+        return self.logical.copy()
+
+    def reset_placement(self):
+        self.logical = self.off + np.arange(self.P, dtype=np.int64)
 
     def observe(self, blobs, ids=None, return_ids=False, fresh=False):
         if fresh:
@@ -115,8 +122,10 @@ class OracleShard(object):
 
         return torch.zeros(int(n), dtype=torch.int64)
 
+    HEAD = 8  # words in a record's header: x, y, h, logw, lo, up, klo, spare
+
     def particle_bytes(self):
-        return 8 * (6 + self.L * 30 + self.L)
+        return 8 * (self.HEAD + self.L * 30 + self.L)
 
     def alloc_records(self, n):
         import torch
@@ -179,10 +188,10 @@ class OracleShard(object):
             ranges_t[2 * d] = j0
             ranges_t[2 * d + 1] = max(j1, j0)
 
-    def _record(self, j, lo, up):
+    def _record(self, j, lo, up, klo=0):
         o = self.o
-        head = np.array([o.x[j], o.y[j], o.h[j], o.logw[j], 0.0, 0.0])
-        head[4:6] = np.array([lo, up], dtype=np.int64).view(np.float64)
+        head = np.array([o.x[j], o.y[j], o.h[j], o.logw[j], 0.0, 0.0, 0.0, 0.0])
+        head[4:7] = np.array([lo, up, klo], dtype=np.int64).view(np.float64)
         return np.concatenate([head, o.mean[j].ravel(), o.cov[j].ravel(), o.count[j].astype(np.float64)])
 
     def pack_into(self, ranges, world, rank, buf):
@@ -216,9 +225,109 @@ class OracleShard(object):
                 lo_, up_ = rec[4:6].view(np.int64)
                 assert lo_ <= K < up_
                 o.x[k], o.y[k], o.h[k], o.logw[k] = rec[:4]
-                o.mean[k] = rec[6:6 + 5 * L].reshape(L, 5)
-                o.cov[k] = rec[6 + 5 * L:6 + 30 * L].reshape(L, 5, 5)
-                o.count[k] = rec[6 + 30 * L:].astype(np.int64)
+                self._take_record(k, rec)
+
+    def _take_record(self, k, rec):
+        o, L, H = self.o, self.L, self.HEAD
+        o.x[k], o.y[k], o.h[k], o.logw[k] = rec[:4]
+        o.mean[k] = rec[H:H + 5 * L].reshape(L, 5)
+        o.cov[k] = rec[H + 5 * L:H + 30 * L].reshape(L, 5, 5)
+        o.count[k] = rec[H + 30 * L:].astype(np.int64)
+
+    # ---- balanced placement (minimum migration): NumPy mirror of pk_shard_state_dev / pk_shard_plan_balanced_dev /
+    # pk_shard_pack_balanced_dev / pk_shard_adopt_balanced_dev ----
+    def state_into(self, t):
+        import torch
+
+        t[:self.P] = torch.from_numpy(self.o.logw.copy())
+        t[self.P:] = torch.from_numpy(self.logical.view(np.float64).copy())
+
+    def plan_balanced_into(self, gstate_t, P_global, gmax_t, domain, u, world, rank, table_t):
+        from parakeet_slam_amd.sharded import plan_balanced
+
+        P = self.P
+        g = gstate_t.numpy().reshape(world, 2 * P)
+        glogw_phys = g[:, :P].reshape(-1)
+        glog = g[:, P:].copy().view(np.int64).reshape(-1)
+        glogw = np.empty(P_global)
+        glogw[glog] = glogw_phys  # the single filter's order
+        gmax = float(gmax_t[0]) if gmax_t is not None else 0.0
+        w = np.exp(glogw - (gmax if domain == 1 and gmax > -np.inf else 0.0))
+        nb = (P_global + SCAN_BLOCK - 1) // SCAN_BLOCK
+        C = np.empty(P_global)
+        run = 0.0
+        for b in range(nb):  # the 1-GPU blocked scan
+            c = np.cumsum(w[b * SCAN_BLOCK:(b + 1) * SCAN_BLOCK])
+            C[b * SCAN_BLOCK:b * SCAN_BLOCK + len(c)] = run + c
+            run = run + c[-1]
+        r = run / float(P_global)
+        t = u * r + np.arange(P_global, dtype=np.float64) * r
+        H = np.empty(P_global + 1, dtype=np.int64)
+        H[0] = 0
+        H[1:] = np.searchsorted(t, C, side="right")
+        H[-1] = P_global
+        H = np.maximum.accumulate(H)
+        cq, _nz, (n, m, e, dd, ebase, dbase), pairs = plan_balanced(H, glog, world, P)
+        rel = cq[rank * P:(rank + 1) * P + 1] - cq[rank * P]
+        self.bal = dict(H=H, Hl=H[self.logical], rel=rel, alive=np.nonzero(np.diff(rel) > 0)[0], n=n, m=m, e=e, dd=dd,
+                        ebase=ebase, dbase=dbase)
+        row = 2 * world + 4
+        tab = np.zeros((world, row), dtype=np.int64)
+        tab[:, :2 * world] = pairs.reshape(world, 2 * world)
+        tab[:, 2 * world], tab[:, 2 * world + 1], tab[:, 2 * world + 2], tab[:, 2 * world + 3] = n, m, ebase, dbase
+        import torch
+
+        table_t.copy_(torch.from_numpy(tab.reshape(-1)))
+
+    def download_balanced_offspring(self):
+        return self.bal["H"].copy()
+
+    def pack_balanced_into(self, table, world, rank, buf):
+        from parakeet_slam_amd.sharded import balanced_record_ranges
+
+        b, rb, P = self.bal, self.particle_bytes(), self.P
+        tab = np.asarray(table).reshape(world, 2 * world + 4)
+        out = buf.numpy()
+        i = 0
+        for d in range(world):
+            a0, a1 = int(tab[rank, 2 * d]), int(tab[rank, 2 * d + 1])
+            if d == rank or a1 <= a0:
+                continue
+            js, lo, up, klo = balanced_record_ranges(b["rel"], b["Hl"], b["alive"], a0, a1, P, int(b["ebase"][rank]),
+                                                     int(b["dbase"][d]), int(b["dd"][d]), int(b["m"][d]))
+            for j, a, c, k in zip(js, lo, up, klo):
+                assert c > a  # no record travels without a child at the destination
+                out[i * rb:(i + 1) * rb] = self._record(int(j), int(a), int(c), int(k)).view(np.uint8)
+                i += 1
+
+    def adopt_balanced(self, table, world, rank, recv, n_received, mode=0):
+        """mode 0: every slot; 1: the slots [0, m) this rank fills with its own children (and the new generation becomes
+        current); 2: the slots [m, P) from the received records."""
+        o, b, P, rb = self.o, self.bal, self.P, self.particle_bytes()
+        m = int(b["m"][rank])
+        if mode != 2:
+            rel, Hl = b["rel"], b["Hl"]
+            k = np.arange(m)
+            a = np.searchsorted(rel[1:], k, side="right")  # the particle whose children hold position k
+            self._old = (o.x.copy(), o.y.copy(), o.h.copy(), o.logw.copy(), o.mean.copy(), o.cov.copy(), o.count.copy())
+            x, y, h, lw, mean, cov, cnt = self._old
+            o.x[:m], o.y[:m], o.h[:m], o.logw[:m] = x[a], y[a], h[a], lw[a]
+            o.mean[:m], o.cov[:m], o.count[:m] = mean[a], cov[a], cnt[a]
+            newlog = self.logical.copy()
+            newlog[:m] = Hl[a] + (k - rel[a])
+            anc = np.full(P, -1, dtype=np.int64)
+            anc[:m] = self.logical[a]
+            self.logical, self.anc_logical = newlog, anc
+        if mode != 1 and m < P:
+            buf = recv.numpy()
+            recs = [buf[r * rb:(r + 1) * rb].view(np.float64) for r in range(n_received)]
+            heads = np.array([r[4:7].view(np.int64) for r in recs], dtype=np.int64).reshape(-1, 3)
+            for k in range(m, P):
+                r = int(np.searchsorted(heads[:, 1], k, side="right"))
+                lo_, up_, klo = heads[r]
+                assert lo_ <= k < up_, (k, lo_, up_)
+                self._take_record(k, recs[r])
+                self.logical[k] = klo + (k - lo_)
 
 
 def scenario(L, steps, seed=5):

@@ -69,12 +69,15 @@ def _shard(rank, store, q):
         sf.upload_map(means, covs.reshape(L, 25))
         for s in range(STEPS):
             sf.step(V, W, 0.1, scans[s], US[s], seed=9, draw=s, domain=_lib.PK_WEIGHTS_LOG)
-        lo = rank * P_local
-        mine = [int(p) - lo for p in SAMPLE if lo <= p < lo + P_local]
         poses = sf.download_poses()  # (completes the last resample's exchange)
-        maps = [sf.download_landmarks(p, p + 1) for p in mine]
-        q.put((rank, dict(poses=poses, maps=maps, summary=sf.summary(), split=sf.split_steps_done, migrated=sf.total_migrated,
-                          bytes_per_particle=sf.f.particle_bytes())))
+        # balanced placement: every slot carries its logical index (its index in the one filter); the sampled particles are
+        # wherever the exchange left them
+        logical = sf.logical_index()
+        assert sf.placement == "balanced" and sf.f.shard_balanced_errors() == 0
+        where = {int(l): j for j, l in enumerate(logical)}
+        maps = {int(p): sf.download_landmarks(where[int(p)], where[int(p)] + 1) for p in SAMPLE if int(p) in where}
+        q.put((rank, dict(poses=poses, logical=logical, maps=maps, summary=sf.summary(), split=sf.split_steps_done,
+                          migrated=sf.total_migrated, bytes_per_particle=sf.f.particle_bytes())))
     except Exception:  # pragma: no cover
         import traceback
 
@@ -109,16 +112,20 @@ def test_config3_one_filter_then_four_shards_on_one_gpu():
         got[r] = res
     for pr in procs:
         pr.join(timeout=120)
-    sharded = np.concatenate([got[r]["poses"] for r in range(WORLD)])
+    logical = np.concatenate([got[r]["logical"] for r in range(WORLD)])
+    assert np.array_equal(np.sort(logical), np.arange(P_TOTAL))
+    sharded = np.empty((P_TOTAL, 4))
+    sharded[logical] = np.concatenate([got[r]["poses"] for r in range(WORLD)])
     # the poses after the last resample are the ancestors' poses: equal poses = equal ancestors at every step (the noise of
     # step s + 1 is drawn per global particle index on the poses step s left)
     assert np.array_equal(sharded[:, :3], poses[:, :3])
     assert np.allclose(np.log(sharded[:, 3]), np.log(poses[:, 3]), rtol=1e-9, atol=1e-9)
     k = 0
+    index_of = {int(p): i for i, p in enumerate(SAMPLE)}
     for r in range(WORLD):
         assert got[r]["split"] == STEPS - 1  # every step after the first overlapped its exchange
-        for m in got[r]["maps"]:
-            ref = one["maps"][k]
+        for p, m in got[r]["maps"].items():
+            ref = one["maps"][index_of[p]]
             k += 1
             for x, y in zip(m, ref):
                 assert np.array_equal(x, y)

@@ -35,7 +35,7 @@ def single_run(P, L, steps, skew, assoc_ids):
     return out
 
 
-def worker(rank, world, store, P_local, L, steps, skew, use_ml, q):
+def worker(rank, world, store, P_local, L, steps, skew, use_ml, q, placement="contiguous"):
     try:
         init_gloo(rank, world, store)
         from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
@@ -43,23 +43,25 @@ def worker(rank, world, store, P_local, L, steps, skew, use_ml, q):
         means, covs, scans = scenario(L, steps)
         P = P_local * world
         z, us = noise(P, steps, 11)
-        sf = ShardedFilter(P_local, L, device=0, comm=TorchComm())
+        sf = ShardedFilter(P_local, L, device=0, comm=TorchComm(), placement=placement)
+        assert sf.placement == placement
         sf.upload_map(means, covs.reshape(L, 25))
-        lo, hi = rank * P_local, (rank + 1) * P_local
         res = []
         for s in range(steps):
             sf.reset_weights()
-            sf.motion(0.2, 0.1, 0.1, z=z[s, lo:hi])
+            sf.motion(0.2, 0.1, 0.1, z=z[s])  # the whole filter's normals, logical order: the rank takes its particles' rows
             sf.observe(scans[s], ids=None if use_ml else np.arange(1, L + 1))
             if skew:
                 poses = sf.f.download_poses()
-                poses[:, 3] *= np.exp(np.linspace(0.0, skew, P))[lo:hi]
+                poses[:, 3] *= np.exp(np.linspace(0.0, skew, P))[sf.logical_index()]
                 sf.f.upload_poses(poses)
             anc = sf.resample(float(us[s]), domain=1, return_ancestors=True)
             mig = sf.last_migrated
             sm = sf.summary()
             m, c, k = sf.download_landmarks()
-            res.append((anc, sf.download_poses(), m, c, k, sm, mig))
+            res.append((anc, sf.download_poses(), m, c, k, sm, mig, sf.logical_index()))
+        if placement == "balanced":
+            assert sf.f.shard_balanced_errors() == 0
         q.put((rank, res))
     except Exception:  # pragma: no cover
         import traceback
@@ -67,15 +69,30 @@ def worker(rank, world, store, P_local, L, steps, skew, use_ml, q):
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
+def _in_logical_order(got, world, s, fld, logical_fld):
+    """One field of every rank's result, put into the single filter's order (balanced placement: each physical slot carries
+    its logical index; contiguous placement: the identity)."""
+    logical = np.concatenate([got[r][s][logical_fld] for r in range(world)])
+    assert np.array_equal(np.sort(logical), np.arange(logical.size)), "the logical indices are not a permutation"
+    cat = np.concatenate([got[r][s][fld] for r in range(world)])
+    out = np.empty_like(cat)
+    out[logical] = cat
+    return out
+
+
+@pytest.mark.parametrize("placement", ["balanced", "contiguous"])
 @pytest.mark.parametrize("skew,use_ml,world,P_local", [(0.0, False, 2, 1024), (5.0, False, 2, 1024), (2.0, True, 2, 1024),
                                                        # shards that end inside a scan block: the global-scan plan
-                                                       (5.0, False, 2, 300), (2.0, True, 3, 1500)])
-def test_two_shards_on_one_gpu_match_single_filter(skew, use_ml, world, P_local):
+                                                       (5.0, False, 2, 300), (2.0, True, 3, 1500),
+                                                       # five ranks on the one device (the box allows six processes on its card,
+                                                       # this one included)
+                                                       (4.0, True, 5, 500)])
+def test_two_shards_on_one_gpu_match_single_filter(skew, use_ml, world, P_local, placement):
     L, steps = 12, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     store = store_file()
-    procs = [ctx.Process(target=worker, args=(r, world, store, P_local, L, steps, skew, use_ml, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, store, P_local, L, steps, skew, use_ml, q, placement)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -88,10 +105,9 @@ def test_two_shards_on_one_gpu_match_single_filter(skew, use_ml, world, P_local)
     ref = single_run(world * P_local, L, steps, skew, None if use_ml else np.arange(1, L + 1))
     moved = 0
     for s in range(steps):
-        assert np.array_equal(np.concatenate([got[r][s][0] for r in range(world)]), ref[s][0]), "ancestors"
+        assert np.array_equal(_in_logical_order(got, world, s, 0, 7), ref[s][0]), "ancestors"
         for fld in (1, 2, 3, 4):
-            whole = np.concatenate([got[r][s][fld] for r in range(world)])
-            assert np.array_equal(whole, ref[s][fld]), (s, fld)
+            assert np.array_equal(_in_logical_order(got, world, s, fld, 7), ref[s][fld]), (s, fld)
         for r in range(world):
             assert np.allclose(got[r][s][5], ref[s][5], rtol=1e-12, atol=1e-13)
         moved += sum(got[r][s][6] for r in range(world))
@@ -281,7 +297,7 @@ def _fast_scenario(L, steps):
     return means, covs, scans
 
 
-def _step_worker(rank, world, store, P_local, L, steps, split, q, rccl=False):
+def _step_worker(rank, world, store, P_local, L, steps, split, q, rccl=False, placement=None):
     try:
         if rccl:  # one GPU per rank, RCCL between them: the asynchronous all-to-all of the split step
             import torch
@@ -295,24 +311,27 @@ def _step_worker(rank, world, store, P_local, L, steps, split, q, rccl=False):
 
         means, covs, scans = _fast_scenario(L, steps)
         _z, us = noise(P_local * world, steps, 11)
-        sf = ShardedFilter(P_local, L, device=rank if rccl else 0, comm=TorchComm(), split_step=split)
+        sf = ShardedFilter(P_local, L, device=rank if rccl else 0, comm=TorchComm(), split_step=split, placement=placement)
         sf.upload_map(means, covs.reshape(L, 25))
         for s in range(steps):
             sf.step(_V, _W, 0.1, scans[s], float(us[s]), seed=9, draw=s, domain=1)
         sm = sf.summary()
         m, c, k = sf.download_landmarks()
-        q.put((rank, (sf.download_poses(), m, c, k, sm, sf.split_steps_done, sf.total_migrated)))
+        if sf.placement == "balanced":
+            assert sf.f.shard_balanced_errors() == 0
+        q.put((rank, (sf.download_poses(), m, c, k, sm, sf.split_steps_done, sf.total_migrated, sf.logical_index(), sf.observe_route(),
+                       sf.f.download_log_weights())))
     except Exception:  # pragma: no cover
         import traceback
 
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-def _run_step_workers(world, P_local, L, steps, split, rccl=False):
+def _run_step_workers(world, P_local, L, steps, split, rccl=False, placement=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     store = store_file()
-    procs = [ctx.Process(target=_step_worker, args=(r, world, store, P_local, L, steps, split, q, rccl)) for r in range(world)]
+    procs = [ctx.Process(target=_step_worker, args=(r, world, store, P_local, L, steps, split, q, rccl, placement)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -325,13 +344,24 @@ def _run_step_workers(world, P_local, L, steps, split, rccl=False):
     return got
 
 
+def _whole(res, world, fld):
+    """Field fld of every rank's final state in the single filter's order (res[r][7] = the rank's logical indices)."""
+    logical = np.concatenate([res[r][7] for r in range(world)])
+    assert np.array_equal(np.sort(logical), np.arange(logical.size))
+    cat = np.concatenate([res[r][fld] for r in range(world)])
+    out = np.empty_like(cat)
+    out[logical] = cat
+    return out
+
+
+@pytest.mark.parametrize("placement", ["balanced", "contiguous"])
 @pytest.mark.parametrize("world,P_local", [(2, 1024), (3, 700)])
-def test_split_step_overlaps_the_exchange_and_changes_nothing(world, P_local):
+def test_split_step_overlaps_the_exchange_and_changes_nothing(world, P_local, placement):
     from parakeet_slam_amd import _lib
 
     L, steps = 600, 5
-    a = _run_step_workers(world, P_local, L, steps, True)
-    b = _run_step_workers(world, P_local, L, steps, False)
+    a = _run_step_workers(world, P_local, L, steps, True, placement=placement)
+    b = _run_step_workers(world, P_local, L, steps, False, placement=placement)
     moved = 0
     for r in range(world):
         assert a[r][5] == steps - 1 and b[r][5] == 0  # every step after the first took the split path / none did
@@ -353,13 +383,49 @@ def test_split_step_overlaps_the_exchange_and_changes_nothing(world, P_local):
     f.upload_map(means, covs.reshape(L, 25))
     for s in range(steps):
         f.step(_V, _W, 0.1, scans[s], float(us[s]), seed=9, draw=s, domain=1)
-    poses = np.concatenate([a[r][0] for r in range(world)])
+    poses = _whole(a, world, 0)
     ref = f.download_poses()
     assert np.allclose(poses[:, :3], ref[:, :3], rtol=1e-12, atol=1e-13)
     assert np.allclose(np.log(poses[:, 3]), np.log(ref[:, 3]), rtol=1e-9, atol=1e-9)
-    m = np.concatenate([a[r][1] for r in range(world)])
+    m = _whole(a, world, 1)
     rm, rc, rk = f.download_landmarks()
-    assert np.allclose(m, rm, rtol=1e-11, atol=1e-12) and np.array_equal(np.concatenate([a[r][3] for r in range(world)]), rk)
+    assert np.allclose(m, rm, rtol=1e-11, atol=1e-12) and np.array_equal(_whole(a, world, 3), rk)
+    assert np.allclose(a[0][4], f.summary(), rtol=1e-12, atol=1e-13)
+    f.close()
+
+
+def test_five_ranks_split_steps_on_the_two_pass_route_match_one_filter():
+    """The shape of BASELINE configs[4] on one device: 5 000 landmarks (k_step_pub_big, the two-pass route, on particle
+    ranges -- round 5), five ranks of 2 048 particles sharing the GPU over gloo (the box allows six processes on its card, this
+    one included; the eight-rank protocol runs on the CPU in tests/test_sharded_gloo.py and tests/test_multi_facade_gloo.py,
+    with the oracle's arithmetic in place of the HIP shards'), three steps with the exchange overlapped, balanced placement:
+    poses, maps and counts of one filter holding all 10 240 particles, bit for bit (prkt_core_v2.py:216-252 is the one
+    coupling point)."""
+    from parakeet_slam_amd import _lib
+
+    world, P_local, L, steps = 5, 2048, 5000, 3
+    a = _run_step_workers(world, P_local, L, steps, True, placement="balanced")
+    moved = sum(a[r][6] for r in range(world))
+    assert moved > 0, "no particle changed rank"
+    for r in range(world):
+        assert a[r][5] == steps - 1, "the steps after the first must take the split path"
+        assert a[r][8] == "ml_pub_big", a[r][8]
+    means, covs, scans = _fast_scenario(L, steps)
+    P = world * P_local
+    _z, us = noise(P, steps, 11)
+    f = _lib.DeviceFilter(P, L)
+    f.upload_map(means, covs.reshape(L, 25))
+    for s in range(steps):
+        f.step(_V, _W, 0.1, scans[s], float(us[s]), seed=9, draw=s, domain=1)
+    assert f.observe_route() == "ml_pub_big"
+    ref = f.download_poses()
+    poses = _whole(a, world, 0)
+    assert np.array_equal(poses[:, :3], ref[:, :3]), "poses differ from the single filter"
+    # (5 000 factors: the linear weights underflow, the log-weights are what the filter keeps)
+    assert np.allclose(_whole(a, world, 9), f.download_log_weights(), rtol=1e-9, atol=1e-9)
+    rm, rc, rk = f.download_landmarks()
+    assert np.array_equal(_whole(a, world, 1), rm) and np.array_equal(_whole(a, world, 2), rc), "maps differ from the single filter"
+    assert np.array_equal(_whole(a, world, 3), rk)
     assert np.allclose(a[0][4], f.summary(), rtol=1e-12, atol=1e-13)
     f.close()
 

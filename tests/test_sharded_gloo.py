@@ -35,7 +35,7 @@ def reference_run(P, L, steps, skew):
     return out
 
 
-def worker(rank, world, store, P_local, L, steps, skew, q):
+def worker(rank, world, store, P_local, L, steps, skew, q, placement="contiguous"):
     try:
         init_gloo(rank, world, store)
         from parakeet_slam_amd.sharded import ShardedFilter, TorchComm
@@ -43,19 +43,19 @@ def worker(rank, world, store, P_local, L, steps, skew, q):
         means, covs, scans = scenario(L, steps)
         P = P_local * world
         z, us = noise(P, steps, 11)
-        sf = ShardedFilter(P_local, L, comm=TorchComm(), shard=OracleShard(P_local, means, covs))
+        sf = ShardedFilter(P_local, L, comm=TorchComm(), shard=OracleShard(P_local, means, covs), placement=placement)
+        assert sf.placement == placement
         res = []
-        lo, hi = rank * P_local, (rank + 1) * P_local
         for s in range(steps):
             sf.reset_weights()
-            sf.motion(0.2, 0.1, 0.1, z=z[s, lo:hi])
+            sf.motion(0.2, 0.1, 0.1, z=z[s])  # the whole filter's normals in logical order: the rank takes its particles' rows
             sf.observe(scans[s], ids=np.arange(1, L + 1))
             if skew:
-                sf.f.o.logw += np.linspace(0.0, skew, P)[lo:hi]
+                sf.f.o.logw += np.linspace(0.0, skew, P)[sf.logical_index()]
             anc = sf.resample(float(us[s]), domain=1, return_ancestors=True)
             o = sf.f.o
             res.append((anc, o.x.copy(), o.y.copy(), o.h.copy(), o.logw.copy(), o.mean.copy(), o.count.copy(),
-                        sf.last_migrated, sf.summary()))
+                        sf.last_migrated, sf.summary(), sf.logical_index()))
         q.put((rank, res))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -63,14 +63,21 @@ def worker(rank, world, store, P_local, L, steps, skew, q):
         q.put((rank, "ERR " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,P_local,skew", [(2, 1024, 0.0), (2, 1024, 6.0), (4, 1024, 3.0), (2, 300, 2.0), (4, 300, 3.0),
-                                                (3, 1500, 6.0), (8, 1024, 3.0), (8, 300, 3.0), (8, 300, 12.0)])
-def test_shards_reproduce_single_filter(world, P_local, skew):
+CASES = [(2, 1024, 0.0), (2, 1024, 6.0), (4, 1024, 3.0), (2, 300, 2.0), (4, 300, 3.0), (3, 1500, 6.0), (8, 1024, 3.0), (8, 300, 3.0),
+         (8, 300, 12.0)]
+
+
+@pytest.mark.parametrize("placement", ["balanced", "contiguous"])
+@pytest.mark.parametrize("world,P_local,skew", CASES)
+def test_shards_reproduce_single_filter(world, P_local, skew, placement):
+    """G shards give the single filter's ancestors, poses, weights and maps exactly.  Contiguous placement: rank r holds
+    the logical slots [r P, (r + 1) P).  Balanced placement (the default): each physical slot carries its logical index and
+    only a rank's excess children move; the comparison is made in logical order."""
     L, steps = 6, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     store = store_file()
-    procs = [ctx.Process(target=worker, args=(r, world, store, P_local, L, steps, skew, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, store, P_local, L, steps, skew, q, placement)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -84,16 +91,26 @@ def test_shards_reproduce_single_filter(world, P_local, skew):
     ref = reference_run(P, L, steps, skew)
     migrated = 0
     for s in range(steps):
-        anc = np.concatenate([got[r][s][0] for r in range(world)])
+        logical = np.concatenate([got[r][s][9] for r in range(world)])
+        assert np.array_equal(np.sort(logical), np.arange(P)), "the logical indices must be a permutation of the filter"
+        if placement == "contiguous":
+            assert np.array_equal(logical, np.arange(P))
+
+        def whole_of(fld):  # the field of every rank, put into the single filter's order
+            cat = np.concatenate([got[r][s][fld] for r in range(world)])
+            out = np.empty_like(cat)
+            out[logical] = cat
+            return out
+
+        anc = whole_of(0)
         # any shard size: the 1024-aligned ones through the block-total plan, the others through the global scan
         assert np.array_equal(anc, ref[s][0]), "ancestors differ from the single-filter run"
         for fld in range(1, 7):
-            whole = np.concatenate([got[r][s][fld] for r in range(world)])
-            assert np.array_equal(whole, ref[s][fld]), (s, fld)
+            assert np.array_equal(whole_of(fld), ref[s][fld]), (s, fld)
         migrated += sum(got[r][s][7] for r in range(world))
         # summaries agree across ranks and with the concatenated state
-        x = np.concatenate([got[r][s][1] for r in range(world)])
-        h = np.concatenate([got[r][s][3] for r in range(world)])
+        x = whole_of(1)
+        h = whole_of(3)
         for r in range(world):
             sm = got[r][s][8]
             assert abs(sm[0] - x.mean()) < 1e-12 and abs(sm[2] - np.arctan2(np.sin(h).sum(), np.cos(h).sum())) < 1e-12
@@ -101,6 +118,14 @@ def test_shards_reproduce_single_filter(world, P_local, skew):
         assert np.all(np.diff(anc) >= 0) and anc.min() >= 0 and anc.max() < P
     if skew >= 3.0:
         assert migrated > 0, "the skewed case must actually move particles between ranks"
+    _MIGRATED[(world, P_local, skew, placement)] = migrated
+    other = _MIGRATED.get((world, P_local, skew, "contiguous" if placement == "balanced" else "balanced"))
+    if other is not None:  # the balanced placement never moves more records than the contiguous one
+        bal, con = (migrated, other) if placement == "balanced" else (other, migrated)
+        assert bal <= con, (bal, con)
+
+
+_MIGRATED = {}
 
 
 def test_plan_exchange_covers_every_slot():
