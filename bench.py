@@ -297,7 +297,30 @@ def self_launch(args, argv):
     env["PK_BENCH_CHILD"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    # The ranks run in a process group of their own, so that a launch that does not come back (a rank that never joins, a
+    # collective that never completes) can be stopped as a whole, by handle -- no retry, no re-exec: the parent reports and
+    # exits non-zero.  The ranks themselves give up on the rendezvous and on any collective after 120 s
+    # (init_process_group(timeout=)), which normally ends the launch long before this limit.
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+
+        sys.stderr.write("bench.py --gpus %d: the %d-rank launch did not finish within %.0f s; stopping it\n"
+                         % (args.gpus, args.gpus, args.launch_timeout))
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)  # the group we started, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise SystemExit(6)
+    proc = subprocess.CompletedProcess(cmd, proc.returncode, stdout)
     line = None
     for raw in proc.stdout.decode("utf-8", "replace").splitlines():
         raw = raw.strip()
@@ -432,6 +455,10 @@ def main():
     ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] shard object (125 000 x 5 000 on this GPU)")
     ap.add_argument("--no-refscene", action="store_true", help="skip the facade latency object (the reference's own scene sizes)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--placement", choices=["balanced", "contiguous"], default=None,
+                    help="N > 1: where the resample puts the particles (default: balanced = minimum migration)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PK_BENCH_LAUNCH_TIMEOUT", "1500")),
+                    help="N > 1: seconds the parent waits for the ranks before it stops them and exits non-zero")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (collectives included) even with one rank")
     args = ap.parse_args()
@@ -450,6 +477,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: one rank per GPU, no more, no fewer" % (args.gpus, world))
+    if os.environ.get("PK_BENCH_SABOTAGE_RANK") in (str(rank), "all"):  # tests: a rank that never joins the process group
+        time.sleep(3600)
 
     import torch
 
@@ -472,7 +501,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(os.environ.get("PK_BENCH_BACKEND", "gloo" if same_gpu else "nccl"))  # "nccl" = RCCL over xGMI (RCCL refuses two ranks on one device)
+        import datetime
+
+        # every rank says where it runs BEFORE the first collective: a launch that hangs in the rendezvous shows who came
+        prop = torch.cuda.get_device_properties(local_rank)
+        sys.stderr.write("bench.py rank %d/%d: pid %d, device %d %s uuid %s\n"
+                         % (rank, world, os.getpid(), local_rank, prop.name, getattr(prop, "uuid", "?")))
+        sys.stderr.flush()
+        dist.init_process_group(os.environ.get("PK_BENCH_BACKEND", "gloo" if same_gpu else "nccl"),  # "nccl" = RCCL over xGMI (RCCL refuses two ranks on one device)
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("PK_BENCH_DIST_TIMEOUT", "120"))))
         if dist.get_world_size() != args.gpus:
             raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
         world = dist.get_world_size()
@@ -499,7 +536,7 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1)
         from parakeet_slam_amd.sharded import ShardedFilter
 
-        filt = ShardedFilter(P, L, device=local_rank)
+        filt = ShardedFilter(P, L, device=local_rank, placement=args.placement)
     else:
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
@@ -812,6 +849,7 @@ def main():
                 out["rehearsal"] = True  # several ranks share a device: control flow only, NOT a scaling measurement
                 out["rehearsal_note"] = "%d ranks on %d device(s) over %s: the value is not a multi-GPU throughput" % (world, n_devices, backend_name)
         if migrated is not None:
+            out["placement"] = filt.placement  # "balanced": only a rank's excess children travel, only particles that have any
             out["migrated_particles_per_step"] = migrated  # all ranks together: each one is a pose + a whole map slot on the wire
             out["migrated_bytes_per_step"] = migrated_bytes
         if second is not None:

@@ -1,0 +1,43 @@
+"""CPU: `python bench.py --gpus N` must FAIL FAST when the N-rank launch does not come together: the
+parent starts the ranks in a process group of their own, waits with a limit, stops the group by handle and exits non-zero --
+it never hangs the driver, never retries, never re-execs.  (The ranks give up on the rendezvous after 120 s on their own:
+init_process_group(timeout=); PK_BENCH_DIST_TIMEOUT shortens that for the GPU test of the same in test_gpu_config2.py.)"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(env_extra, args, limit):
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PK_BENCH_SAME_GPU"] = "1"  # (lets the parent start two ranks on a box with fewer than two devices)
+    env["PK_BENCH_BACKEND"] = "gloo"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=limit)
+    return r, time.monotonic() - t0
+
+
+def test_a_launch_that_never_comes_together_is_stopped_and_reported():
+    # every rank sleeps instead of joining: nothing ends the launch but the parent's own limit
+    r, dt = _run({"PK_BENCH_SABOTAGE_RANK": "all"}, ["--launch-timeout", "12"], limit=150)
+    assert r.returncode == 6, (r.returncode, r.stderr.decode()[-2000:])
+    assert dt < 100, dt
+    assert b"did not finish within" in r.stderr and b'"metric"' not in r.stdout
+    # the group was stopped: no rank of that launch is left (they would sleep for an hour)
+    time.sleep(0.5)
+    out = subprocess.run(["ps", "-eo", "pid,args"], stdout=subprocess.PIPE).stdout.decode()
+    left = [ln for ln in out.splitlines() if "bench.py" in ln and "--launch-timeout 12" in ln and "ps -eo" not in ln]
+    assert not left, left
+
+
+def test_one_rank_that_never_joins_fails_the_launch_inside_150_seconds():
+    # rank 1 never joins.  On a GPU box rank 0 waits in the rendezvous until its (shortened) timeout; here, without a GPU, it
+    # stops even earlier ("needs a GPU").  Either way: non-zero, no result line, well inside 150 s.
+    r, dt = _run({"PK_BENCH_SABOTAGE_RANK": "1", "PK_BENCH_DIST_TIMEOUT": "20"}, ["--launch-timeout", "120"], limit=150)
+    assert r.returncode != 0, r.stderr.decode()[-2000:]
+    assert dt < 150 and b'"metric"' not in r.stdout

@@ -244,3 +244,29 @@ def test_bench_gpus_2_launches_its_own_ranks_or_refuses(lib):
     else:
         assert r.returncode != 0
         assert b'"n_gpus"' not in r.stdout
+
+
+def test_bench_with_a_rank_that_never_joins_fails_fast_on_the_gpu_box(lib):
+    """VERDICT round 4 #7 on the device: two ranks on the one GPU (the rehearsal's gloo world), rank 1 never joins the process
+    group.  Rank 0 has initialised its device and waits in the rendezvous -- for the (shortened) timeout of
+    init_process_group, not for ever; the launch fails, the parent exits non-zero without a result line.  And the same launch
+    without the saboteur gives the rehearsal line, with the placement it used and what it moved."""
+    import time
+
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--particles", "4096", "--landmarks", "600", "--no-cpu-baseline",
+            "--no-probes", "--launch-timeout", "140"]
+    env = dict(os.environ)
+    env.update({"PK_BENCH_SAME_GPU": "1", "PK_BENCH_BACKEND": "gloo", "PK_BENCH_DIST_TIMEOUT": "20", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    bad = dict(env)
+    bad["PK_BENCH_SABOTAGE_RANK"] = "1"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=bad, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=200)
+    assert r.returncode != 0 and time.monotonic() - t0 < 150, (r.returncode, r.stderr.decode()[-1500:])
+    assert b'"metric"' not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["world_size"] == 2 and d["rehearsal"] is True and d["placement"] == "balanced"
+    assert d["migrated_particles_per_step"] >= 0 and all(math.isfinite(v) for v in d["summary"])
