@@ -579,6 +579,7 @@ def main():
                 dist.all_reduce(t)
         migrated = float(t.item()) / max(K, 1)
         migrated_bytes = migrated * filt.f.particle_bytes()
+        placement = filt.placement
     summary = filt.summary()
     flagged = filt.observe_flagged() if hasattr(filt, "observe_flagged") else None
     if route in ("ml_regs", "ml_fused") and hasattr(filt, "observe_published") and filt.observe_published():
@@ -849,7 +850,7 @@ def main():
                 out["rehearsal"] = True  # several ranks share a device: control flow only, NOT a scaling measurement
                 out["rehearsal_note"] = "%d ranks on %d device(s) over %s: the value is not a multi-GPU throughput" % (world, n_devices, backend_name)
         if migrated is not None:
-            out["placement"] = filt.placement  # "balanced": only a rank's excess children travel, only particles that have any
+            out["placement"] = placement  # "balanced": only a rank's excess children travel, only particles that have any
             out["migrated_particles_per_step"] = migrated  # all ranks together: each one is a pose + a whole map slot on the wire
             out["migrated_bytes_per_step"] = migrated_bytes
         if second is not None:
