@@ -54,162 +54,6 @@ namespace pk {
 #ifndef PK_PUB_ABLATE
 #define PK_PUB_ABLATE 0
 #endif
-#ifndef PK_PUB_OVF  // 1: landmarks that pass more blobs than they have slots are settled in the kernel (round 4); 0: the particle is flagged
-#define PK_PUB_OVF 1
-#endif
-// Diagnostic builds only: PK_PUB_PAD_<phase> = n extra float64 instructions per lane in one phase of k_step_pub<2, 512> (G0 / K0:
-// gates / keys of the first pair, G1 / K1: of the second, U0 / U1: in front of the first / second pair's updates) -- which
-// phases are on the critical path of a particle?  (an instruction added to a phase that waits for memory costs nothing)
-#ifndef PK_PUB_PAD_G0
-#define PK_PUB_PAD_G0 0
-#endif
-#ifndef PK_PUB_PAD_K0
-#define PK_PUB_PAD_K0 0
-#endif
-#ifndef PK_PUB_PAD_G1
-#define PK_PUB_PAD_G1 0
-#endif
-#ifndef PK_PUB_PAD_K1
-#define PK_PUB_PAD_K1 0
-#endif
-#ifndef PK_PUB_PAD_U0
-#define PK_PUB_PAD_U0 0
-#endif
-#ifndef PK_PUB_PAD_U1
-#define PK_PUB_PAD_U1 0
-#endif
-template <int NPAD>
-__device__ __forceinline__ void pub_pad() {
-  if constexpr (NPAD > 0) {
-    double a = 1.0, b = 2.0;
-#pragma unroll
-    for (int i = 0; i < NPAD / 2; ++i) asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1" : "+v"(a), "+v"(b));
-  }
-}
-// Diagnostic / tuning: wave priorities (s_setprio) by phase.  The per-wave stamps of round 4 show the workgroup's second four
-// waves (the second wave of every SIMD) issuing their thirty row stores / requests behind the first four's -- 10 500 cycles
-// in the queue against 5 300 -- and the first four then waiting 12 000 cycles at barrier A for them.
-//   1: the second four waves at priority 3 from barrier C to the end of the update phase
-//   2: ... for the whole particle
-//   3: as 1, and the first four at priority 3 in the gates / keys phase
-#ifndef PK_PUB_PRIO
-#define PK_PUB_PRIO 0
-#endif
-// 1: the update of a pair in halves -- position blocks of both landmarks, their five rows out, colour blocks, nine rows out; one
-// copy of the update code per landmark, a turn loop for landmarks with several blobs, one log per lane -- 0 (default): round 3's
-// order, a pair's rows out behind both its updates.  Measured (round 4, three interleaved repetitions on one box): 9.965-9.989 ms
-// per step with the halves against 9.925-9.933 without: the earlier stores buy nothing, because the requests that reuse the
-// pair's registers still leave behind its last store.  Exact either way (the -m gpu suite passes with the switch on).
-#ifndef PK_PUB_HALVES
-#define PK_PUB_HALVES 0
-#endif
-// Where the SECOND pair's rows of a particle are asked for -- 0: at the top, behind the first pair's candidate records (round 3);
-// 1: behind the first pair's gates; 2: behind the first pair's keys; 4: behind the first pair's keys AND behind the second pair's
-// candidate records; 7 (default, round 4): as 4, but the second pair's five MEAN rows in front of its candidate records (its gates
-// need both at once; -0.3 % against 4); 5, 6: means / covariance rows at other places (measured: worse).  The texture addresser takes a CU's vector-memory instructions in order, ~16 cycles
-// per 1 KB: at the top of a particle the fifteen row requests of each of the eight waves stood in its queue between the last
-// row stores and what the gates need at once -- the candidate records, 96 bytes per lane.  Asked for where nothing urgent is
-// behind them, the rows still arrive long before the second pair's gates are through their atan2.  Measured at 100 000 x 2 000,
-// three interleaved repetitions on one box: 9.96 (0) -> 9.83 (1) -> 9.71 (2) -> 9.465 ms per step (4), kernel 9.80 -> 9.30 ms.
-// 1: the lanes of k_step_pub<2, 512> take their landmarks through the scan's octet order (k_cand_entries): long candidate lists
-// to waves 0-3, short ones to waves 4-7.  0: lane t has landmarks 2 t, 2 t + 1, 1024 + 2 t, 1025 + 2 t
-#ifndef PK_PUB_PERM
-#define PK_PUB_PERM 3
-#endif
-// k_step_pub_big: 1 = the gates look at a candidate's float copy first (one gather of 16 bytes), 0 = at its exact record (two)
-// k_step_pub_big: 1 = the lanes take their landmarks through the scan's octet order (as PK_PUB_PERM), 0 = lane t of chunk q has
-// landmarks 1024 q + 2 t, + 1
-#ifndef PK_BIG_PERM
-#define PK_BIG_PERM 1
-#endif
-// k_step_pub_big: 1 = gate-passing blobs whose key is certainly beyond the underflow edge take no slot (decided in the gates, from
-// the float table), 0 = the verdicts find that out, one round of gathers per slot
-#ifndef PK_BIG_GATE_FAR
-#define PK_BIG_GATE_FAR 1
-#endif
-// k_step_pub_big: 1 = the float records of a gate round are asked for a round ahead (measured: 7.40 against 7.27 ms, six registers
-// spilled; the six-chunk instance would spill 44 and never does it)
-#ifndef PK_BIG_GATE_AHEAD
-#define PK_BIG_GATE_AHEAD 0
-#endif
-// k_step_pub_big: 1 = the verdicts take the key's constant term and the colour bound from the gates (0: worked out twice)
-#ifndef PK_BIG_KEYS_PRE
-#define PK_BIG_KEYS_PRE 1
-#endif
-// k_step_pub_big, diagnostic: wave priorities in pass 2 (1: the second four waves raised, 3: the first four; measured)
-#ifndef PK_BIG_PRIO
-#define PK_BIG_PRIO 0
-#endif
-// k_step_pub_big, pass 2: 1 = the record of a landmark's blob is asked for behind the pair's rows, a pair ahead of the update (measured:
-// 6.88 against 6.82 ms -- the other wave of the SIMD covers that round trip already)
-#ifndef PK_BIG_APPLY_AHEAD
-#define PK_BIG_APPLY_AHEAD 0
-#endif
-// k_step_pub_big: 1 = the rows go out as non-temporal stores (0: plain ones; diagnostic)
-#ifndef PK_BIG_NT_STORES
-#define PK_BIG_NT_STORES 1
-#endif
-// k_step_pub_big: 1 = pass 2 reads the rows with non-temporal loads (their last use; diagnostic)
-#ifndef PK_BIG_NT_LOADS
-#define PK_BIG_NT_LOADS 0
-#endif
-#ifndef PK_BIG_GATE4
-#define PK_BIG_GATE4 1
-#endif
-// k_step_pub: 1 = look-alikes that are certainly beyond the underflow edge are taken out of the slots before the verdict rounds
-#ifndef PK_PUB_PRUNE
-#define PK_PUB_PRUNE 0
-#endif
-// the octet order's first criterion: 1 = blobs inside the reference particle's own gates, 0 = the longest candidate list alone
-#ifndef PK_PUB_PERM_COST
-#define PK_PUB_PERM_COST 1
-#endif
-// 1 = the publish table of k_step_pub_big rank-major (see k_cand_entries), 0 = blob-major as k_step_pub's (where rank-major measured
-// +0.6 %: three or four entries per blob, little to gain, and the rank bases are table reads)
-#ifndef PK_PUB_RANKMAJOR
-#define PK_PUB_RANKMAJOR 1
-#endif
-// lanes per group of the octet order of k_step_pub: 8 (sixteen landmarks, 128 bytes of a row) or 4 (eight landmarks, 64 bytes)
-#ifndef PK_PUB_GRAIN
-#define PK_PUB_GRAIN 8
-#endif
-// k_step_pub's settling: 1 = two blobs per lane and turn (measured: +1.1 %)
-#ifndef PK_PUB_SETTLE_TWO
-#define PK_PUB_SETTLE_TWO 0
-#endif
-// k_step_pub<2, 512>: 1 = the first four waves update both pairs before they store the first (0: every wave stores a pair behind its updates)
-#ifndef PK_PUB_STAGGER
-#define PK_PUB_STAGGER 0
-#endif
-// k_step_pub<2, 512>: 1 = the counted protocol (pub_settle_counted: only the blobs two or more landmarks want are settled; measured: suite
-// and fuzz green, +0.6 %)
-#ifndef PK_PUB_COUNTED
-#define PK_PUB_COUNTED 0
-#endif
-#ifndef PK_PUB_PERM_MECH
-#define PK_PUB_PERM_MECH 0
-#endif
-#ifndef PK_PUB_LATE_P1
-#define PK_PUB_LATE_P1 7
-#endif
-#ifndef PK_PUB_P0_WHERE  // diagnostic: where the NEXT particle's first pair is asked for (0: behind the first pair's stores)
-#define PK_PUB_P0_WHERE 0
-#endif
-// k_step_pub_big: 0 = eight gate slots of which the positive ones are kept (round 3; the default), 1 = four gate slots + the refill
-// turn of k_step_pub.  Measured at 20 000 x 5 000 (round 4): 23.4 ms per step against 8.37 -- among 5 000 random colours a landmark
-// with five to seven gate-passing blobs is in nearly every WAVE's 128, not just in every particle, so the second turn is the
-// rule and the left-over blobs flag particles by the thousand.  Kept as a switch for maps with sparser colours.
-#ifndef PK_PUB_BIG_OVF
-#define PK_PUB_BIG_OVF 0
-#endif
-// k_step_pub_big, pass 1: a chunk's covariance rows with its means (0, default) or behind its candidate records (1: measured at
-// 20 000 x 5 000, 8.33 against 8.08 ms per launch -- here the keys follow the gates too closely for the rows to come later).
-#ifndef PK_BIG_LATE_COV
-#define PK_BIG_LATE_COV 0
-#endif
-#ifndef PK_PUB_ILV  // 0: rows out in one burst per pair (round 3); 1, 2: pair 0's rows out between pair 1's updates
-#define PK_PUB_ILV 0
-#endif
 constexpr int kPubThreads = 512;        // the large instances' workgroup
 constexpr int kPubSmallThreads = 256;   // ... the L <= 512 instance's
 constexpr int kPubTailWords = 256;  // words behind glist[B]: the octet orders of k_step_pub (128 u16) and k_step_pub_big (384 u16); then rbase[16]
@@ -300,7 +144,7 @@ struct CandEntriesArgs {
 // SLOTS: entries per candidate list and per inverse list (kCandSlots, or twice that for the scans of several thousand blobs)
 template <int SLOTS>
 __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
-  constexpr bool kRankMajor = PK_PUB_RANKMAJOR != 0 && SLOTS > kCandSlots;  // (sixteen-entry lists: k_step_pub_big)
+  constexpr bool kRankMajor = SLOTS > kCandSlots;  // (sixteen-entry lists: k_step_pub_big; k_step_pub keeps blob-major, +0.6 % otherwise)
   __shared__ unsigned s_part[kRankMajor ? 1 : 1024], s_gpart[kRankMajor ? 1 : 1024];
   __shared__ unsigned short s_cls[kRankMajor ? SLOTS + 1 : 1][1024];  // per class (number of contenders) and chunk: blobs, then their scan
   __shared__ unsigned s_tot[SLOTS + 1], s_cbase[SLOTS + 1], s_rbase[SLOTS];
@@ -413,7 +257,6 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       const unsigned n = min(a.bcnt[t], (unsigned)SLOTS);
       const unsigned c = n >= 2u ? n : 0u;
       a.binfo[t] = (run & 0xFFFFu) | (n << 16);
-      a.glist[a.B + 1 + kPubTailWords + 16 + t] = (run & 0xFFFFu) | (n << 16);  // (for the counted protocol of k_step_pub<2, 512>)
       if (n >= 2u) a.glist[grun++] = (run & 0xFFFFu) | (n << 16);
       run += c;
     }
@@ -468,10 +311,9 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     // (k_step_pub_big, SLOTS = 16: up to six chunks of 64 places -- the same ranking, chunk c takes ranks 512 c ... 512 c + 511 and
     // wave w of it the ranks 64 w ... : all eight waves work through lists of like length at the same time)
     constexpr bool kBig = SLOTS != kCandSlots;
-    // (PK_PUB_GRAIN = 4, k_step_pub only: groups of FOUR lanes -- eight landmarks, 64 bytes of a row -- 256 places, sixteen to
-    // a (wave, pair))
-    constexpr int kGrain = kBig ? 8 : PK_PUB_GRAIN, kLm = 2 * kGrain;  // lanes and landmarks per group
-    constexpr int kPlaces = kBig ? kPubBigPlaces : 2 * kPubOctets * (8 / kGrain);
+    // (groups of FOUR lanes -- eight landmarks, 64 bytes of a row -- measured +18 %: profiles/r04/ab_perm_groups_of_four_lanes.log)
+    constexpr int kLm = 16;  // landmarks per group: eight lanes, 128 bytes of a row
+    constexpr int kPlaces = kBig ? kPubBigPlaces : 2 * kPubOctets;
     __shared__ int s_cost[kPlaces];
     unsigned short* perm = reinterpret_cast<unsigned short*>(a.glist + a.B + 1) + (kBig ? 2 * kPubOctets : 0);
     const int n_oct = a.Lp / kLm;
@@ -489,7 +331,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
             for (int k = 0; k < SLOTS; ++k) n += ((cws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0xFFFFu ? 1 : 0;
             longest = max(longest, n);
             sum += n;
-            if (a.npass && PK_PUB_PERM_COST != 0) passes = max(passes, (int)a.npass[l]);
+            if (a.npass) passes = max(passes, (int)a.npass[l]);
           }
           // (first by the blobs inside the reference's own gates -- a verdict round each, and a round costs the whole wave its
           // arithmetic --, then by the longest list -- two candidates a gate round)
@@ -504,30 +346,15 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
         int r = 0;
         for (int o = 0; o < kPlaces; ++o) r += (s_cost[o] > c || (s_cost[o] == c && o < tid)) ? 1 : 0;
         if constexpr (kBig) {
-          int place = PK_BIG_PERM != 0 ? r : tid;  // place = chunk 64 + wave 8 + k = the rank itself
-          if (PK_BIG_PERM == 2 && r >= (n_oct / 64) * 64) {  // (diagnostic: the last, partial chunk dealt out evenly over the waves)
-            const int j = r - (n_oct / 64) * 64;
-            place = (n_oct / 64) * 64 + 8 * (j % 8) + j / 8;
-          }
-          if (PK_BIG_PERM == 3 && r >= (n_oct / 64) * 64) {  // (diagnostic: the last, partial chunk to the LAST waves instead of the first)
-            const int j = r - (n_oct / 64) * 64;
-            place = (n_oct / 64) * 64 + 8 * (7 - j / 8) + j % 8;
-          }
-          perm[place] = (unsigned short)tid;
-        } else if constexpr (kGrain == 4) {
-          const int g = r >> 4, k = r & 15;  // sixteen groups of four lanes to a (wave, pair); every wave one costly and one cheap set
-          perm[2 * kPubOctets * (g >> 3) + 16 * (g & 7) + k] = (unsigned short)tid;
+          // place = chunk 64 + wave 8 + k = the rank itself (a last, partial chunk thus goes to the first waves -- the ones
+          // with time to spare at barrier A; dealt out evenly or to the last waves: +3-4 %, profiles/r04/ab_big_last_chunk_*.log)
+          perm[r] = (unsigned short)tid;
         } else {
+          // every wave one costly and one cheap group (the costly ones all to waves 0-3: -0.3 %, to waves 4-7: +2.4 %, a snake over
+          // the SIMDs: -0.5 % -- profiles/r04/ab_perm_*.log)
           const int g = r >> 3, k = r & 7;
-          int wave = g < 8 ? (g >> 1) : 4 + ((g - 8) >> 1), pair = g & 1;
-          if (PK_PUB_PERM == 2) wave = 7 - wave;                 // (diagnostic: the costly octets to waves 4-7)
-          if (PK_PUB_PERM == 3) wave = g & 7, pair = g >> 3;     // (the default: every wave one costly and one cheap group)
-          if (PK_PUB_PERM == 5) {  // the four SIMDs (waves s and s + 4) get like sums: groups s, 7 - s, 8 + s, 15 - s of the ranking
-            wave = g < 4 ? g : g < 8 ? 11 - g : g < 12 ? g - 4 : 15 - g;
-            pair = g >> 3;
-          }
-          if (PK_PUB_PERM == 4) wave = (tid >> 3) & 7, pair = tid >> 6;  // (diagnostic: the identity, through the table)
-          perm[kPubOctets * pair + 8 * wave + (PK_PUB_PERM == 4 ? (tid & 7) : k)] = (unsigned short)tid;
+          const int wave = g & 7, pair = g >> 3;
+          perm[kPubOctets * pair + 8 * wave + k] = (unsigned short)tid;
         }
       }
     }
@@ -623,7 +450,7 @@ __device__ __forceinline__ void pub_far_bound(const Landmark<double>& lm, double
 // particles on some stretches of the bench's trajectory and sent them through the second-chance kernels).
 // GT: the first look at a candidate goes to the float table gt (see k_cand_entries): certain either way for all but a candidate in
 // a million, and only a wave with an uncertain one reads exact records (ex is global memory then, k_step_pub_big)
-template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false, bool GT = false, bool AHEAD = false>
+template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false, bool GT = false>
 __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
                                            double* pub, unsigned dump, int* flag, double sx, double sy, double sh,
                                            const float4* gt = nullptr) {
@@ -666,8 +493,8 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
     npass[j] = 0;
     pmask[j] = 0u;
   }
-  // GT: the float records of a round's candidates are asked for a round ahead (a gather from L2 takes as long as a round's
-  // arithmetic; a list that has ended reads record 0)
+  // GT: the float records of a round's candidates (a list that has ended reads record 0; asked for a round AHEAD: +1.7 %, six
+  // registers spilled -- profiles/r04/ab_big_gate_records_a_round_ahead.log)
   float4 nfa[GT ? N : 1], nfb[GT ? N : 1];
   auto gate_request = [&](int kk) {
     if constexpr (GT) {
@@ -679,7 +506,6 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
       }
     }
   };
-  if constexpr (GT && AHEAD) gate_request(0);
 #pragma unroll  // (written out: the list words are addressed statically -- shifted through the registers every round they cost 1.3 %)
   for (int k = 0; k < NW; ++k) {
     const int kk = k;
@@ -689,15 +515,11 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
     if (__ballot((call & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: every list is through
     float4 cfa[GT ? N : 1], cfb[GT ? N : 1];
     if constexpr (GT) {
-      if constexpr (!AHEAD) gate_request(kk);
+      gate_request(kk);
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         cfa[j] = nfa[j];
         cfb[j] = nfb[j];
-      }
-      if constexpr (AHEAD) {
-        asm volatile("" ::: "memory");
-        if (k + 1 < NW) gate_request(kk + 1);
       }
     }
 #pragma unroll
@@ -721,8 +543,8 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
         // far -- once a landmark's colour block has tightened, every look-alike's) is no contender and takes no slot: at several
         // thousand blobs each landmark passes a handful of those, and each cost the verdicts a round of gathers from L2
         // (27 % of the kernel's time, profiles/r04/stamps_k_step_pub_big_*).  The float distance is within 6.3e-3 of the exact one.
-        const bool far_a = PK_BIG_GATE_FAR != 0 && in[j].fi > 0.0 && in[j].fk + (cda - 0.01) * in[j].fi > 1492.0;  // NaN: false
-        const bool far_b = PK_BIG_GATE_FAR != 0 && in[j].fi > 0.0 && in[j].fk + (cdb - 0.01) * in[j].fi > 1492.0;
+        const bool far_a = in[j].fi > 0.0 && in[j].fk + (cda - 0.01) * in[j].fi > 1492.0;  // NaN: false
+        const bool far_b = in[j].fi > 0.0 && in[j].fk + (cdb - 0.01) * in[j].fi > 1492.0;
         pa = va && in_a && !far_a;
         pb = vb && in_b && !far_b;
         const bool ua = va && !out_a && !in_a, ub = vb && !out_b && !in_b;
@@ -830,12 +652,10 @@ __device__ __forceinline__ double pub_log(double x) {
   return (double)e * 0.69314718055994530942 + lm;
 }
 // PRE: kbase and 1 / rowmax come from the caller (pub_far_bound, k_step_pub_big: its gates needed them already)
-// PRUNE: before the rounds, the blobs in slots 1.. whose key is certainly beyond the underflow edge ("far", below) are published
-// as no contenders and taken out, the others close ranks: a round costs the whole wave its arithmetic when ONE lane has a blob
-// that is not far, and the rounds behind the first were nearly all about look-alikes (10 % of k_step_pub's time)
-// COUNTED: any[t] COUNTS the landmarks that want blob t with a positive probability (a packed ds_add_u32 instead of a byte store):
-// a blob with one taker needs no settling (pub_settle_counted)
-template <int N, int SL = kPubSlots, bool PRE = false, bool PRUNE = false, bool COUNTED = false>
+// (Measured and dropped, round 4: look-alikes certainly beyond the underflow edge taken out of slots 1.. before the rounds, +11 % --
+// profiles/r04/ab_pub_prune_far_slots.log; any[] as COUNTERS of the landmarks that want a blob, so that a blob with one taker
+// needs no settling, +0.6 % -- ab_counted_settling.log.)
+template <int N, int SL = kPubSlots, bool PRE = false>
 __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
                                           unsigned anydump, int* flag, double sx, double sy, const double* pre_kbase = nullptr,
@@ -885,51 +705,6 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
       itr3[j] = pd3[j] ? pub_recip(fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))),
                                          lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
                        : 0.0;
-  }
-  if constexpr (PRUNE && SL == 4) {
-    unsigned s1 = q[0].s[1];
-#pragma unroll
-    for (int j = 1; j < N; ++j) s1 &= q[j].s[1];
-    if (__ballot((s1 & 0xFFFFu) != 0xFFFFu) != 0ull) {  // wave-uniform: some landmark has passed a second blob
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const Landmark<double>& lm = *lmp[j];
-        unsigned w[3] = {q[j].s[1], q[j].s[2], q[j].s[3]};
-        bool keep[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const unsigned t = w[s] & 0xFFFFu, e = w[s] >> 16;
-          const bool valid = t != 0xFFFFu;
-          const double* rec = ex + 6 * (valid ? t : 0u);
-          const double2 z01 = *reinterpret_cast<const double2*>(rec);
-          const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
-          const double d1 = z01.y - lm.mr, d2c = z23.x - lm.mg, d3c = z23.y - lm.mb;
-          const bool far = pd3[j] && kbase[j] + (d1 * d1 + d2c * d2c + d3c * d3c) * itr3[j] > 1492.0;  // (as in the rounds)
-          pub[(valid && far && e != 0xFFFFu) ? e : dump] = pub_inf();
-          keep[s] = valid && !far;
-          w[s] = keep[s] ? w[s] : 0xFFFFFFFFu;
-        }
-        // the kept ones to the front, in their order
-#pragma unroll
-        for (int turn = 0; turn < 2; ++turn) {
-          const bool sh = !keep[0];
-          w[0] = sh ? w[1] : w[0];
-          keep[0] = sh ? keep[1] : keep[0];
-          w[1] = sh ? w[2] : w[1];
-          keep[1] = sh ? keep[2] : keep[1];
-          w[2] = sh ? 0xFFFFFFFFu : w[2];
-          keep[2] = sh ? false : keep[2];
-        }
-        {
-          const bool sh = !keep[1];
-          w[1] = sh ? w[2] : w[1];
-          w[2] = sh ? 0xFFFFFFFFu : w[2];
-        }
-        q[j].s[1] = w[0];
-        q[j].s[2] = w[1];
-        q[j].s[3] = w[2];
-      }
-    }
   }
   int done = 0;
 #pragma unroll 1
@@ -1012,13 +787,7 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      if constexpr (COUNTED) {
-        const unsigned tt = positive[j] ? t[j] : anydump;
-        __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(any) + (tt >> 2), positive[j] ? 1u << (8u * (tt & 3u)) : 0u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        any[positive[j] ? t[j] : anydump] = 1;
-      }
+      any[positive[j] ? t[j] : anydump] = 1;
       q[j].st |= positive[j] ? 1u : 0u;
       pub_rotate(q[j]);
     }
@@ -1090,10 +859,9 @@ __device__ __forceinline__ double pub_marker() { return __longlong_as_double((lo
 template <int THREADS, int SLOTS = kCandSlots>
 __device__ __forceinline__ void pub_settle_blobs(int tid, const unsigned* glist, unsigned G, double* pub, unsigned dump, int* flag,
                                                  const unsigned* rb) {
-  constexpr bool kRankMajor = PK_PUB_RANKMAJOR != 0 && SLOTS > kCandSlots;
-  // TWO: two blobs per lane and turn, side by side -- reads of both, then compares, then both markers (k_step_pub, eight-entry
-  // lists: a turn is a chain of dependent LDS round trips -- list word, entries, marker -- with two waves per SIMD to cover it)
-  constexpr int TWO = (PK_PUB_SETTLE_TWO != 0 && SLOTS == kCandSlots && THREADS == 512) ? 2 : 1;
+  constexpr bool kRankMajor = SLOTS > kCandSlots;
+  // (TWO blobs per lane and turn, side by side: +1.1 %, profiles/r04/ab_settle_two_blobs_per_turn.log)
+  constexpr int TWO = 1;
   // (most contested blobs are listed by two or three landmarks: the first four entries in one batch, the rest -- wave-uniform --
   // only where some lane's blob has more; round 4: the settling read and compared all SLOTS entries of every blob)
   constexpr int kHead = SLOTS < 4 ? SLOTS : 4;
@@ -1220,108 +988,6 @@ __device__ __forceinline__ void pub_take(PubSlots& q, const double* pub, unsigne
   }
 }
 
-// COUNTED protocol (k_step_pub<2, 512>): lane `tid` owns word `tid` of the any[] counters -- four blobs.  The blobs that two or more
-// landmarks want with a positive probability (and that several list at all) are compacted into a list of the lane's WAVE, which the
-// wave then settles as pub_settle_blobs would, one lane per blob -- one turn of the loop where the blob-parallel settling over
-// every contested blob took three or four; a blob with one taker is taken without a verdict (pub_take_counted).  binfo[t]:
-// first entry | listing landmarks << 16 of EVERY blob (blob-major table).  Returns the number of blobs nobody wants.
-constexpr int kPubWaveList = 224;  // (a wave's 256 blobs nearly never have more such; more: the particle is flagged)
-template <int SLOTS = kCandSlots>
-__device__ __forceinline__ int pub_settle_counted(int tid, const unsigned char* anyc, const unsigned* binfo, int B, unsigned Bp, double* pub,
-                                                  unsigned dump, int* flag, unsigned short* wl) {
-  const bool hasw = (unsigned)tid < Bp / 4u;
-  const unsigned v = hasw ? reinterpret_cast<const unsigned*>(anyc)[tid] : 0u;
-  int nun = 0;
-  unsigned base = 0u;
-  bool doubt = false;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int t = 4 * tid + b;
-    const unsigned c = (v >> (8 * b)) & 0xFFu;
-    const bool valid = hasw && t < B;
-    nun += (valid && c == 0u) ? 1 : 0;
-    const bool want = valid && c >= 2u;
-    const unsigned long long mask = __ballot(want);
-    const unsigned idx = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-    if (want) {
-      if (idx < (unsigned)kPubWaveList) wl[idx] = (unsigned short)t;
-      else doubt = true;
-    }
-    base += (unsigned)__popcll(mask);
-  }
-  const unsigned cnt = min(base, (unsigned)kPubWaveList);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own list: written above, read below by other lanes of the wave
-  constexpr int kHead = SLOTS < 4 ? SLOTS : 4;
-#pragma unroll 1
-  for (unsigned i = (unsigned)(tid & 63); __ballot(i < cnt) != 0ull; i += 64u) {  // wave-uniform
-    const bool on = i < cnt;
-    const unsigned t = wl[on ? i : 0u];
-    const unsigned bi = binfo[on ? t : 0u];
-    const unsigned offs = bi & 0xFFFFu, n = (on && (bi >> 16) >= 2u) ? (bi >> 16) : 0u;  // (listed by one landmark: nothing to settle)
-    double vv[SLOTS];
-#pragma unroll
-    for (int r = 0; r < kHead; ++r) vv[r] = pub[(unsigned)r < n ? offs + r : dump];
-    double best = pub_inf();
-    unsigned wr = 0u;
-#pragma unroll
-    for (int r = 0; r < kHead; ++r) {
-      vv[r] = (unsigned)r < n ? vv[r] : pub_inf();
-      const bool better = vv[r] < best;  // strict: on equal keys the earlier rank stays (:377)
-      wr = better ? (unsigned)r : wr;
-      best = better ? vv[r] : best;
-    }
-    const bool more = SLOTS > kHead && __ballot(n > (unsigned)kHead) != 0ull;  // wave-uniform
-    if (more) {
-#pragma unroll
-      for (int r = kHead; r < SLOTS; ++r) vv[r] = pub[(unsigned)r < n ? offs + r : dump];
-#pragma unroll
-      for (int r = kHead; r < SLOTS; ++r) {
-        vv[r] = (unsigned)r < n ? vv[r] : pub_inf();
-        const bool better = vv[r] < best;
-        wr = better ? (unsigned)r : wr;
-        best = better ? vv[r] : best;
-      }
-    }
-    int contenders = 0;
-    bool close = false;
-#pragma unroll
-    for (int r = 0; r < kHead; ++r) {
-      contenders += vv[r] < pub_inf() ? 1 : 0;
-      close |= vv[r] != best && vv[r] - best < 1e-7;  // within 1e-7 of the winner without being identical to it
-    }
-    if (more) {
-#pragma unroll
-      for (int r = kHead; r < SLOTS; ++r) {
-        contenders += vv[r] < pub_inf() ? 1 : 0;
-        close |= vv[r] != best && vv[r] - best < 1e-7;
-      }
-    }
-    doubt |= close || (contenders >= 2 && best > 1350.0);
-    if (best < pub_inf()) pub[offs + wr] = pub_marker();
-  }
-  if (doubt) *flag = 1;
-  return nun;
-}
-// ... and the take: a positive blob nobody else lists, or nobody else wants (count 1: this landmark's own), or whose entry carries
-// the winner's marker
-__device__ __forceinline__ void pub_take_counted(PubSlots& q, const double* pub, unsigned dump, const unsigned char* anyc, unsigned anydump) {
-  const unsigned sw[kPubSlots] = {q.s[0], q.s[1], q.s[2], q.s[3]};
-  double m[kPubSlots];
-  unsigned c[kPubSlots];
-#pragma unroll
-  for (int s = 0; s < kPubSlots; ++s) {
-    const unsigned e = sw[s] >> 16, t = sw[s] & 0xFFFFu;
-    m[s] = pub[e == 0xFFFFu ? dump : e];
-    c[s] = anyc[t == 0xFFFFu ? anydump : t];
-  }
-#pragma unroll
-  for (int s = 0; s < kPubSlots; ++s) {
-    const unsigned e = sw[s] >> 16;
-    const bool pos = ((q.st >> (4 * s)) & 1u) != 0u;
-    if (pos && (e == 0xFFFFu || c[s] == 1u || m[s] == pub_marker())) q.st |= 4u << (4 * s);
-  }
-}
-
 // The blobs taken, applied in scan order (:88): regs_apply with the take bits.
 __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
                                             Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
@@ -1382,17 +1048,8 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
 
 // The same with ONE copy of the update code, in a loop that nearly always turns once (the 256-lane instance: 145 VGPRs
 // instead of 181; on the large instance 0.7 % slower than the two-path form above).
-// (PRE: the record of the landmark's ONLY blob -- the usual case -- has been asked for ahead, pub_apply_request: k_step_pub_big reads
-// the records from L2, and a gather issued where the update needs it costs the wave a round trip per landmark)
-__device__ __forceinline__ unsigned pub_apply_only_blob(const PubSlots& q) {
-  const unsigned tk = q.st & 0x4444u;
-  const unsigned w = (tk & 0x0004u) ? q.s[0] : (tk & 0x0040u) ? q.s[1] : (tk & 0x0400u) ? q.s[2] : q.s[3];
-  return (tk != 0u && (tk & (tk - 1u)) == 0u) ? (w & 0xFFFFu) : 0u;  // (no blob, or several: record 0, not used)
-}
-template <bool PRE = false>
 __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
-                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse,
-                                            double2 pre01 = double2{0.0, 0.0}, double2 pre23 = double2{0.0, 0.0}) {
+                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
   double acc = 0.0;
   unsigned tk = q.st & 0x4444u;
   bool fresh = true;
@@ -1419,16 +1076,9 @@ __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double
       }
     }
     if (tk != 0u) {
-      double2 z01, z23;
-      // (the first turn of a landmark with one blob: pub_apply_only_blob picked the same slot)
-      if (PRE && it == 0 && (tk & (tk - 1u)) == 0u) {
-        z01 = pre01;
-        z23 = pre23;
-      } else {
-        const double* rec = ex + 6 * (w & 0xFFFFu);
-        z01 = *reinterpret_cast<const double2*>(rec);
-        z23 = *reinterpret_cast<const double2*>(rec + 2);
-      }
+      const double* rec = ex + 6 * (w & 0xFFFFu);
+      const double2 z01 = *reinterpret_cast<const double2*>(rec);
+      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
       BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
       acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
       fresh = imm;
@@ -1493,20 +1143,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   // Which sixteen landmarks each group of eight lanes works on (<2, 512> only; k_cand_entries, once per scan): the octets with
   // the LONGEST candidate lists go to waves 0-3, the shortest to waves 4-7 -- the waves that come second in the CU's vector
   // memory queue all particle long, and that the others wait for at every barrier
-  constexpr bool kPerm = PK_PUB_PERM != 0 && NP == 2 && THREADS == 512;
-  constexpr int kGrain = PK_PUB_GRAIN;  // lanes per group of the order: 8 (sixteen landmarks, 128 bytes of a row) or 4
-  static_assert(kGrain == 8 || (kGrain == 4 && PK_PUB_PERM_MECH == 0), "four-lane groups: lane word tid | group << 10 | group << 19");
-  __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets * (8 / kGrain) : 1];
+  constexpr bool kPerm = NP == 2 && THREADS == 512;
+  __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets : 1];
   __shared__ unsigned s_rb[kCandSlots];  // the publish table's rank bases (k_cand_entries: entry of (blob g, rank r) = s_rb[r] + g)
-  constexpr bool kCounted = PK_PUB_COUNTED != 0 && NP == 2 && THREADS == 512;  // (Bp <= 2 048: lane tid owns word tid of any[])
-  __shared__ unsigned short s_wl[kCounted ? kPubWaves : 1][kCounted ? kPubWaveList : 1];
-#define PK_PUB_L0(q_, t_)                                                                                         \
-  (!kPerm ? 2 * kPubThreads * (q_) + 2 * (t_)                                                                     \
-          : kGrain == 8 ? (int)(((lw >> (kOctShift + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7)                     \
-                        : (int)(((lw >> (10 + 9 * (q_))) & 0x1FFu) << 3) + 2 * ((t_)&3))
-  // (PK_PUB_PERM_MECH: where the two octet numbers live -- 0: above the lane index in one register, 1: in a register of their
-  // own, 2: below the lane index)
-  constexpr int kOctShift = PK_PUB_PERM_MECH == 0 ? 16 : 0;
+  // (the two octet numbers of a lane ride above its index in one register; in a register of their own, or below the index: no
+  // better -- profiles/r04/ab_perm_mechanisms.log)
+#define PK_PUB_L0(q_, t_) (!kPerm ? 2 * kPubThreads * (q_) + 2 * (t_) : (int)(((lw >> (16 + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7))
   PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid0 = threadIdx.x;
   int B, Lp, L, ecap;
@@ -1537,10 +1179,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     const unsigned short* go = R->order;
     G = gb[B];
     for (int i = tid; i < B; i += kPubThreads) {
-      if constexpr (kCounted)
-        glist[i] = gb[B + 1 + kPubTailWords + 16 + i];  // binfo of EVERY blob: first entry | listing landmarks << 16
-      else
-        glist[i] = (unsigned)i < G ? gb[i] : 0u;
+      glist[i] = (unsigned)i < G ? gb[i] : 0u;
       order[i] = go[i];
     }
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
@@ -1549,7 +1188,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     const unsigned char* gi = R->immutable;
     for (int i = tid; i < Lp; i += kPubThreads) smem[o_imm + (unsigned)i] = i < L ? gi[i] : (unsigned char)0;
     if constexpr (kPerm) {
-      if (tid < 2 * kPubOctets * (8 / kGrain)) s_perm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[tid];
+      if (tid < 2 * kPubOctets) s_perm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[tid];
     }
     if (tid < kCandSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
     if (tid == 0) {
@@ -1642,12 +1281,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   // (0xFF: none, the lane is beyond the map) -- read from LDS at every use the table cost 1.3 % of the kernel's time
   unsigned lane_word = (unsigned)tid0;
   if constexpr (kPerm) {
-    if constexpr (kGrain == 8) {
-      const unsigned octs = (unsigned)(s_perm[tid0 >> 3] & 0xFFu) | ((unsigned)(s_perm[kPubOctets + (tid0 >> 3)] & 0xFFu) << 8);
-      lane_word = PK_PUB_PERM_MECH == 0 ? ((unsigned)tid0 | (octs << 16)) : PK_PUB_PERM_MECH == 1 ? octs : (((unsigned)tid0 << 16) | octs);
-    } else {  // (0x1FF: no group)
-      lane_word = (unsigned)tid0 | ((unsigned)(s_perm[tid0 >> 2] & 0x1FFu) << 10) | ((unsigned)(s_perm[2 * kPubOctets + (tid0 >> 2)] & 0x1FFu) << 19);
-    }
+    const unsigned octs = (unsigned)(s_perm[tid0 >> 3] & 0xFFu) | ((unsigned)(s_perm[kPubOctets + (tid0 >> 3)] & 0xFFu) << 8);
+    lane_word = (unsigned)tid0 | (octs << 16);
   }
   {
     const unsigned lw = lane_word;
@@ -1665,11 +1300,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     int tid;
     if constexpr (!kPerm) {
       tid = (int)lw;
-    } else if constexpr (PK_PUB_PERM_MECH == 1) {
-      tid = tid0;
-      asm volatile("" : "+v"(tid));
     } else {
-      tid = kGrain == 4 ? (int)(lw & 0x3FFu) : PK_PUB_PERM_MECH == 0 ? (int)(lw & 0xFFFFu) : (int)(lw >> 16);
+      tid = (int)(lw & 0xFFFFu);
     }
     double* ex = reinterpret_cast<double*>(smem);
     double* pub = reinterpret_cast<double*>(smem + o_pub);
@@ -1725,11 +1357,6 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         asm volatile("" ::: "memory");
         // (pair by pair, means before covariance rows: the first pair's gates and verdicts are worked out while the second
         // pair's rows are still on their way -- the vector memory counter retires in order)
-        if constexpr (PK_PUB_LATE_P1 == 0) {
-          const int coff = R->count_off;
-#pragma unroll
-          for (int q = kPipe; q < NP; ++q) PK_PUB_LOAD_PAIR(q, sslot, coff, lbase[q])
-        }
         {  // the next particle's source slot (pinned here: the wait for it passes under the wait for the first rows)
           PubArgsPtr R4 = pub_args_now(rp);
           const int64_t pn = p + gridDim.x;
@@ -1768,34 +1395,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       }
     } else {
       const Landmark<double>* const l2[2] = {&S[2 * q], &S[2 * q + 1]};
-      if (q == 0) pub_pad<PK_PUB_PAD_G0>(); else pub_pad<PK_PUB_PAD_G1>();
-      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, PK_PUB_OVF != 0>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);
+      if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, true>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);
       PK_STAMP(sk0_)
-      if constexpr (PK_PUB_LATE_P1 == 5 && NP > 1) {
-        if (q == 1) { /* diagnostic: the second pair's covariance rows behind its own gates */
-          PubArgsPtr R7 = pub_args_now(rp);
-          PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])
-        }
-      }
-      if constexpr (PK_PUB_LATE_P1 == 6 && NP > 1) {
-        if (q == 0) { /* diagnostic: the second pair's MEANS behind the first pair's gates, its other rows as in 4 */
-          PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
-        }
-      }
-      if constexpr (PK_PUB_LATE_P1 == 1 && NP > 1) {
-        if (q == 0) { /* the second pair's rows asked for behind the first pair's GATES (diagnostic variant) */
-          PubArgsPtr R7 = pub_args_now(rp);
-          PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
-        }
-      }
-      if (q == 0) pub_pad<PK_PUB_PAD_K0>(); else pub_pad<PK_PUB_PAD_K1>();
       if (PK_PUB_ABLATE < 3) {
-        pub_keysN<2, kPubSlots, false, PK_PUB_PRUNE != 0, kCounted>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
-        if constexpr (PK_PUB_OVF != 0) { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */
+        pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */
           PubArgsPtr R9 = pub_args_now(rp);
           const int lc9 = min(l0, Lp);
           if (pub_refill_slots<2>(qq, R9->cand + 2 * (size_t)lc9, R9->erec + lc9, &wg_flag[cur]))
-            pub_keysN<2, kPubSlots, false, false, kCounted>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+            pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
         }
       }
       PK_STAMP(sk1_)
@@ -1810,32 +1418,18 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         if (!done) {  // workgroup-uniform
           do_pair(std::integral_constant<int, 0>{});
           if constexpr (NP > 1) {
-            if constexpr (PK_PUB_LATE_P1 == 7) {  // (diagnostic: means in front of the candidate records, the other rows behind)
-              PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
-            }
-            if constexpr (PK_PUB_LATE_P1 == 2) {  // (the second pair's rows behind the first pair's keys)
-              PubArgsPtr R7 = pub_args_now(rp);
-              PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
-            }
+            // The SECOND pair's rows are asked for HERE -- behind the first pair's keys, its five mean rows in front of its
+            // candidate records (its gates need both at once), the other rows behind them: the texture addresser takes a CU's
+            // vector-memory instructions in order, ~16 cycles per 1 KB; at the top of the particle these fifteen requests of each of
+            // the eight waves stood between the last row stores and what the first gates need at once, and the rows still arrive
+            // long before the second pair's gates are through their atan2.  At the top: 9.96 ms per step; behind the first pair's
+            // gates 9.83; behind its keys 9.71; here 9.465 (profiles/r04/ab_second_pair_rows_later.log, ab_request_order_*.log).
+            PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
             request_cand(NP - 1);
-            if constexpr (PK_PUB_LATE_P1 == 4) {  // (... and behind the second pair's candidate records)
-              asm volatile("" ::: "memory");
-              PubArgsPtr R7 = pub_args_now(rp);
-              PK_PUB_LOAD_PAIR(1, sslot, R7->count_off, lbase[1])
-            }
-            if constexpr (PK_PUB_LATE_P1 == 7) {
+            {
               asm volatile("" ::: "memory");
               PubArgsPtr R7 = pub_args_now(rp);
               PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])
-            }
-            if constexpr (PK_PUB_LATE_P1 == 6) {  // (diagnostic: see above)
-              asm volatile("" ::: "memory");
-              PubArgsPtr R7 = pub_args_now(rp);
-              PK_PUB_LOAD_COVS(1, sslot, R7->count_off, lbase[1])
-            }
-            if constexpr (PK_PUB_LATE_P1 == 5) {  // (diagnostic: the means there, the covariance rows behind the second pair's gates)
-              asm volatile("" ::: "memory");
-              PK_PUB_LOAD_MEANS(1, sslot, lbase[1])
             }
             do_pair(std::integral_constant<int, 1>{});
           }
@@ -1868,36 +1462,24 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
     double acc;
     {
       int nun = 0;
-      if constexpr (kCounted) {
-        nun = pub_settle_counted(tid, anyc, glist, B, Bp, pub, dump, &wg_flag[cur], s_wl[tid >> 6]);
-      } else {
-        for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) {
-          const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
+      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) {
+        const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
-        }
+        for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
       }
       acc = (double)nun * Consts<double>::log_no_match;  // unseen features: weight *= 0.1 each (:94-95)
       unsigned* anyn = reinterpret_cast<unsigned*>(smem + o_any + (unsigned)(cur ^ 1) * (Bp + 16u));
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
-    if constexpr (!kCounted)
-      if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
+    if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     PK_STAMP(s5)
     PK_PSTAMP(4, s4, s5)  // unseen blobs, settling
     lds_barrier();  // B: every winner is marked, every flag is set
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i)
-      if (PK_PUB_ABLATE < 2) {
-        if constexpr (kCounted) pub_take_counted(Q[i], pub, dump, anyc, anydump);
-        else pub_take(Q[i], pub, dump);
-      }
+      if (PK_PUB_ABLATE < 2) pub_take(Q[i], pub, dump);
     lds_barrier();  // C: every marker has been read -- the table is the next particle's
-    if constexpr (PK_PUB_PRIO != 0 && THREADS == 512) {
-      if (tid0 >= 256) __builtin_amdgcn_s_setprio(3);
-      else if (PK_PUB_PRIO == 3) __builtin_amdgcn_s_setprio(0);
-    }
     PK_STAMP(s6)
     PK_PSTAMP(5, s5, s6)  // barrier B, markers, barrier C
     if (wg_flag[cur] && PK_PUB_ABLATE == 0) {  // workgroup-uniform: nothing has been written; the general kernels take the particle
@@ -1925,208 +1507,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       double* df = reinterpret_cast<double*>(dslot);
       int* dc = reinterpret_cast<int*>(dslot + R->count_off);
       const unsigned char* immutable = smem + o_imm;
-#if PK_PUB_ILV
-      if constexpr (NP == 2 && THREADS == kPubThreads) {
-        // The rows of pair 0 go out -- and the next particle's pair 0 is asked for -- BETWEEN the updates of pair 1's two
-        // landmarks, a third at a time, instead of in one burst of thirty vector-memory instructions: behind barrier C all
-        // eight waves reach that burst together, the CU's one texture-addresser path takes ~16 cycles per 1 KB instruction,
-        // and a wave that stands in that queue issues no arithmetic (12.7 % of a particle's time by the stamps, round 3).
-        // In thirds the queue has drained by the time the wave comes back with the next one.
-        const int l00 = PK_PUB_L0(0, tid), l01 = PK_PUB_L0(1, tid);
-#define PK_ILV_APPLY(i, l)                                                                                    \
-  if (PK_PUB_ABLATE < 1) acc += pub_apply(Q[i], ex, order, qt, S[i], immutable[min((l), Lp - 1)] != 0, sx, sy, pse[i]);
-#define PK_ILV_STORE(q, l0_, field, F)                                                                        \
-  {                                                                                                           \
-    const Double2 v = {S[2 * (q)].field, S[2 * (q) + 1].field};                                               \
-    __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + (l0_)));                  \
-  }
-        PK_ILV_APPLY(0, l00)
-        PK_ILV_APPLY(1, l00 + 1)
-        asm volatile("" ::: "memory");
-        if (l00 < Lp) {
-          PK_ILV_STORE(0, l00, mx, F_MX)
-          PK_ILV_STORE(0, l00, my, F_MY)
-          PK_ILV_STORE(0, l00, mr, F_MR)
-          PK_ILV_STORE(0, l00, mg, F_MG)
-          PK_ILV_STORE(0, l00, mb, F_MB)
-#if PK_PUB_ILV >= 2
-        }
-        asm volatile("" ::: "memory");
-        PK_ILV_APPLY(2, l01)
-        asm volatile("" ::: "memory");
-        if (l00 < Lp) {
-#endif
-          PK_ILV_STORE(0, l00, pxx, F_PXX)
-          PK_ILV_STORE(0, l00, pxy, F_PXY)
-          PK_ILV_STORE(0, l00, pyy, F_PYY)
-          PK_ILV_STORE(0, l00, crr, F_CRR)
-          PK_ILV_STORE(0, l00, crg, F_CRG)
-#if PK_PUB_ILV == 1
-        }
-        asm volatile("" ::: "memory");
-        PK_ILV_APPLY(2, l01)
-        asm volatile("" ::: "memory");
-        if (l00 < Lp) {
-#endif
-          PK_ILV_STORE(0, l00, crb, F_CRB)
-          PK_ILV_STORE(0, l00, cgg, F_CGG)
-          PK_ILV_STORE(0, l00, cgb, F_CGB)
-          PK_ILV_STORE(0, l00, cbb, F_CBB)
-          const Int2 c = {S[0].count, S[1].count};
-          __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l00));
-        }
-#if PK_PUB_ILV == 1
-        {  // the next particle's first pair, into the registers just stored
-          PubArgsPtr R6 = pub_args_now(rp);
-          const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
-        }
-        PK_ILV_APPLY(3, l01 + 1)
-#else
-        asm volatile("" ::: "memory");
-        PK_ILV_APPLY(3, l01 + 1)
-        {  // the next particle's first pair, into the registers just stored
-          PubArgsPtr R6 = pub_args_now(rp);
-          const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-          PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
-        }
-#endif
-        asm volatile("" ::: "memory");
-        if (l01 < Lp) {
-          PK_ILV_STORE(1, l01, mx, F_MX)
-          PK_ILV_STORE(1, l01, my, F_MY)
-          PK_ILV_STORE(1, l01, mr, F_MR)
-          PK_ILV_STORE(1, l01, mg, F_MG)
-          PK_ILV_STORE(1, l01, mb, F_MB)
-          PK_ILV_STORE(1, l01, pxx, F_PXX)
-          PK_ILV_STORE(1, l01, pxy, F_PXY)
-          PK_ILV_STORE(1, l01, pyy, F_PYY)
-          PK_ILV_STORE(1, l01, crr, F_CRR)
-          PK_ILV_STORE(1, l01, crg, F_CRG)
-          PK_ILV_STORE(1, l01, crb, F_CRB)
-          PK_ILV_STORE(1, l01, cgg, F_CGG)
-          PK_ILV_STORE(1, l01, cgb, F_CGB)
-          PK_ILV_STORE(1, l01, cbb, F_CBB)
-          const Int2 c = {S[2].count, S[3].count};
-          __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l01));
-        }
-#undef PK_ILV_APPLY
-#undef PK_ILV_STORE
-      } else
-#endif
-      if constexpr (THREADS != kPubSmallThreads && PK_PUB_ABLATE < 1 && PK_PUB_HALVES != 0) {
-        // The update of a pair runs in HALVES -- position blocks of both landmarks, their five rows out, colour blocks of both, the
-        // other nine rows out -- so that the first stores of a pair leave after two fifths of its arithmetic instead of after all
-        // of it: everything between barrier C and the first store is on the critical path of a particle (the NEXT particle's rows
-        // can only be asked for into the registers those stores free; padding experiment).  A landmark that
-        // takes several blobs gets them one turn of the pair's loop each, in scan order (:88: sequential updates); the rows leave
-        // in the last turn.  ONE copy of the update code per landmark of the pair, and one `log` per lane for all the importance
-        // factors (EkfWeightSum).
-        EkfWeightSum wsum;
-#define PK_PUB_HSTORE(q_, l0_, field, F)                                                              \
-  {                                                                                                   \
-    const Double2 v_ = {S[2 * (q_)].field, S[2 * (q_) + 1].field};                                    \
-    __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + (l0_)));        \
-  }
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          const int l0 = PK_PUB_L0(q, tid);
-          if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
-          const bool imm0 = immutable[min(l0, Lp - 1)] != 0, imm1 = immutable[min(l0 + 1, Lp - 1)] != 0;
-          unsigned tk0 = Q[2 * q].st & 0x4444u, tk1 = Q[2 * q + 1].st & 0x4444u;  // blobs still to be applied
-#pragma unroll 1
-          for (int turn = 0;; ++turn) {
-            // the blob of this turn: the landmark's only one (the usual case, wave-uniform), else the earliest in the scan
-            unsigned w0, w1, bit0 = tk0, bit1 = tk1;
-            if (__ballot(((tk0 & (tk0 - 1u)) | (tk1 & (tk1 - 1u))) != 0u) == 0ull) {
-              w0 = (tk0 & 0x0004u) ? Q[2 * q].s[0] : (tk0 & 0x0040u) ? Q[2 * q].s[1] : (tk0 & 0x0400u) ? Q[2 * q].s[2] : Q[2 * q].s[3];
-              w1 = (tk1 & 0x0004u) ? Q[2 * q + 1].s[0] : (tk1 & 0x0040u) ? Q[2 * q + 1].s[1] : (tk1 & 0x0400u) ? Q[2 * q + 1].s[2] : Q[2 * q + 1].s[3];
-            } else {
-              unsigned best0 = 0xFFFFFFFFu, best1 = 0xFFFFFFFFu;
-              w0 = w1 = 0u;
-              bit0 = bit1 = 0u;
-#pragma unroll
-              for (int sidx = 0; sidx < kPubSlots; ++sidx) {
-                const bool a0 = ((tk0 >> (4 * sidx)) & 4u) != 0u, a1 = ((tk1 >> (4 * sidx)) & 4u) != 0u;
-                const unsigned o0 = order[a0 ? (Q[2 * q].s[sidx] & 0xFFFFu) : 0u], o1 = order[a1 ? (Q[2 * q + 1].s[sidx] & 0xFFFFu) : 0u];
-                const bool f0 = a0 && o0 < best0, f1 = a1 && o1 < best1;
-                best0 = f0 ? o0 : best0;
-                best1 = f1 ? o1 : best1;
-                w0 = f0 ? Q[2 * q].s[sidx] : w0;
-                w1 = f1 ? Q[2 * q + 1].s[sidx] : w1;
-                bit0 = f0 ? (4u << (4 * sidx)) : bit0;
-                bit1 = f1 ? (4u << (4 * sidx)) : bit1;
-              }
-            }
-            const bool on0 = tk0 != 0u, on1 = tk1 != 0u;
-            tk0 &= ~bit0;
-            tk1 &= ~bit1;
-            const bool last = __ballot((tk0 | tk1) != 0u) == 0ull;  // wave-uniform: nothing left for this pair
-            const double* r0 = ex + 6 * (on0 ? (w0 & 0xFFFFu) : 0u);
-            const double* r1 = ex + 6 * (on1 ? (w1 & 0xFFFFu) : 0u);
-            const bool pot0 = (S[2 * q].count & kPotentialBit) != 0, pot1 = (S[2 * q + 1].count & kPotentialBit) != 0;
-            // the expected bearing: the gates' for the first blob (and for an immutable landmark, whose mean does not move)
-            double zh0 = pse[2 * q], zh1 = pse[2 * q + 1];
-            if (turn > 0) {  // wave-uniform, rare
-              zh0 = imm0 ? zh0 : pk_atan2(S[2 * q].my - sy, S[2 * q].mx - sx);
-              zh1 = imm1 ? zh1 : pk_atan2(S[2 * q + 1].my - sy, S[2 * q + 1].mx - sx);
-            }
-            EkfPosHalf<double> ph0{0.0, 0.0}, ph1{0.0, 0.0};
-            if (on0) ph0 = ekf_update_position(S[2 * q], sx, sy, r0[0], qt, imm0, zh0);
-            if (on1) ph1 = ekf_update_position(S[2 * q + 1], sx, sy, r1[0], qt, imm1, zh1);
-            if (last && l0 < Lp) {
-              PK_PUB_HSTORE(q, l0, mx, F_MX)
-              PK_PUB_HSTORE(q, l0, my, F_MY)
-              PK_PUB_HSTORE(q, l0, pxx, F_PXX)
-              PK_PUB_HSTORE(q, l0, pxy, F_PXY)
-              PK_PUB_HSTORE(q, l0, pyy, F_PYY)
-            }
-            asm volatile("" ::: "memory");  // (the blobs' colours are read from LDS here, not carried across the stores)
-            if (on0) {
-              const double2 z23 = *reinterpret_cast<const double2*>(r0 + 2);
-              double fro2, maha;
-              ekf_update_colour(S[2 * q], r0[1], z23.x, z23.y, qt, imm0, ph0, fro2, maha);
-              wsum.add(fro2, maha, pot0);
-            }
-            if (on1) {
-              const double2 z23 = *reinterpret_cast<const double2*>(r1 + 2);
-              double fro2, maha;
-              ekf_update_colour(S[2 * q + 1], r1[1], z23.x, z23.y, qt, imm1, ph1, fro2, maha);
-              wsum.add(fro2, maha, pot1);
-            }
-            if (last) break;
-          }
-          PK_STAMP(su0_)
-          if (l0 < Lp) {
-            PK_PUB_HSTORE(q, l0, mr, F_MR)
-            PK_PUB_HSTORE(q, l0, mg, F_MG)
-            PK_PUB_HSTORE(q, l0, mb, F_MB)
-            PK_PUB_HSTORE(q, l0, crr, F_CRR)
-            PK_PUB_HSTORE(q, l0, crg, F_CRG)
-            PK_PUB_HSTORE(q, l0, crb, F_CRB)
-            PK_PUB_HSTORE(q, l0, cgg, F_CGG)
-            PK_PUB_HSTORE(q, l0, cgb, F_CGB)
-            PK_PUB_HSTORE(q, l0, cbb, F_CBB)
-            const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
-            __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
-          }
-          if (q < kPipe) {  // the next particle's pair, into the registers just stored
-            PubArgsPtr R6 = pub_args_now(rp);
-            const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-            PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(PK_PUB_L0(q, tid), Lp - 2))
-          }
-          PK_STAMP(su1_)
-          PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
-        }
-#undef PK_PUB_HSTORE
-        acc += wsum.finish();
-      } else {  // the 256-lane instance (and diagnostic builds): round 3's order, a pair's rows out behind both its updates
+      {  // a pair's rows go out behind both its updates.  (Measured and dropped, round 4: the update of a pair in halves -- position
+        // blocks, five rows out, colour blocks, nine rows out: +0.5 %, ab_update_in_halves.log; pair 0's rows out between pair 1's
+        // updates, a third or a half at a time: +3.3 % / +7.2 %, ab_atan2_fmak_interleaved_stores.log; the two halves of the workgroup
+        // out of step: +3 % / +0.5 %, ab_update_phase_as_lambdas_and_staggered_halves.log; wave priorities: ab_wave_priorities.log.)
         // do_apply(q): the pair's two updates; do_store(q): its rows out and -- q < kPipe -- the next particle's pair asked for into
         // the registers just stored
         auto do_apply = [&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const int l0 = PK_PUB_L0(q, tid);
-          if (q == 0) pub_pad<PK_PUB_PAD_U0>(); else pub_pad<PK_PUB_PAD_U1>();
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int i = 2 * q + j;
@@ -2140,31 +1529,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
           constexpr int q = decltype(qc)::value;
           const int l0 = PK_PUB_L0(q, tid);
           PK_STAMP(su0_)
-          if (PK_PUB_P0_WHERE == 1 && NP == 2 && q == 1) {  // (diagnostic: the next first pair in front of the second pair's stores)
-            PubArgsPtr R6 = pub_args_now(rp);
-            const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
-          }
           if (l0 < Lp) {
-#if defined(PK_PUB_STORE_FLAVOUR)  // diagnostic variants: -DPK_PUB_STORE_FLAVOUR='"sc1"' ...
-#define PK_PUB_STORE(field, F)                                                                                         \
-    {                                                                                                                    \
-      const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                                            \
-      asm volatile("global_store_dwordx4 %0, %1, off " PK_PUB_STORE_FLAVOUR ::"v"(df + (size_t)F * Lp + l0), "v"(v) : "memory"); \
-    }
-#elif defined(PK_PUB_PLAIN_STORES)  // diagnostic variant
-#define PK_PUB_STORE(field, F)                                               \
-    {                                                                          \
-      const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                  \
-      *reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0) = v;               \
-    }
-#else
+            // (non-temporal: nothing reads the rows before the next step; sc1 or plain stores 11.45, 11.65 against 11.05 ms, round 3)
 #define PK_PUB_STORE(field, F)                                                             \
     {                                                                                        \
       const Double2 v = {S[2 * q].field, S[2 * q + 1].field};                                \
       __builtin_nontemporal_store(v, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
     }
-#endif
             PK_PUB_STORE(mx, F_MX)
             PK_PUB_STORE(my, F_MY)
             PK_PUB_STORE(mr, F_MR)
@@ -2183,45 +1554,23 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
             const Int2 c = {S[2 * q].count, S[2 * q + 1].count};
             __builtin_nontemporal_store(c, reinterpret_cast<Int2*>(dc + l0));
           }
-          if (q < kPipe && (PK_PUB_P0_WHERE == 0 || NP == 1)) {  // the next particle's pair, into the registers just stored
+          if (q < kPipe) {  // the next particle's pair, into the registers just stored (asked for later: +9 %, ab_request_order_more.log)
             PubArgsPtr R6 = pub_args_now(rp);
             const unsigned char* ns = pub_slot_source(R6).at(nsrc);
             PK_PUB_LOAD_PAIR(q, ns, R6->count_off, min(PK_PUB_L0(q, tid), Lp - 2))
-          }
-          if (PK_PUB_P0_WHERE == 2 && NP == 2 && q == 1) {  // (diagnostic: ... behind the second pair's stores)
-            PubArgsPtr R6 = pub_args_now(rp);
-            const unsigned char* ns = pub_slot_source(R6).at(nsrc);
-            PK_PUB_LOAD_PAIR(0, ns, R6->count_off, min(PK_PUB_L0(0, tid), Lp - 2))
           }
           PK_STAMP(su1_)
           PK_PSTAMP(10, su0_, su1_)  // of the updates: rows out, the next particle's first pair asked for
         };
         using Q0 = std::integral_constant<int, 0>;
         using Q1 = std::integral_constant<int, 1>;
-        if constexpr (NP == 2 && THREADS == 512 && PK_PUB_STAGGER != 0) {
-          // The two halves of the workgroup out of step: all eight waves leave barrier C together and met again at the first pair's
-          // thirty row stores / requests, the second four standing behind the first four in the texture addresser's queue (and being
-          // what barrier A then waits for).  The first four waves -- the ones with time to spare -- now do BOTH updates first:
-          // their memory burst comes while the second four are in their second update, and the other way round.
-          const bool spare = PK_PUB_STAGGER == 1 ? tid0 < 256 : tid0 >= 256;  // wave-uniform
-          do_apply(Q0{});
-          if (!spare) do_store(Q0{});
+        do_apply(Q0{});
+        do_store(Q0{});
+        if constexpr (NP == 2) {
           do_apply(Q1{});
-          if (spare) do_store(Q0{});
           do_store(Q1{});
-        } else {
-          do_apply(Q0{});
-          do_store(Q0{});
-          if constexpr (NP == 2) {
-            do_apply(Q1{});
-            do_store(Q1{});
-          }
         }
       }
-    }
-    if constexpr ((PK_PUB_PRIO == 1 || PK_PUB_PRIO == 3) && THREADS == 512) {
-      if (tid0 >= 256) __builtin_amdgcn_s_setprio(0);
-      else if (PK_PUB_PRIO == 3) __builtin_amdgcn_s_setprio(3);
     }
     PK_STAMP(s7)
     PK_PSTAMP(6, s6, s7)  // updates, stores issued
@@ -2362,47 +1711,14 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     SB.count = c_.y;                                                                                  \
     asm volatile("" ::: "memory");                                                                    \
   }
-#define PK_BIG_MEANS(SA, SB, lb_, src_)                                                               \
-  {                                                                                                   \
-    PubArgsPtr R2 = pub_args_now(rp);                                                                 \
-    const SlotSource ss_ = pub_slot_source(R2);                                                       \
-    const double* sf_ = reinterpret_cast<const double*>(ss_.at(src_));                                \
-    PK_BIG_LOAD(SA, SB, mx, F_MX, lb_)                                                                \
-    PK_BIG_LOAD(SA, SB, my, F_MY, lb_)                                                                \
-    PK_BIG_LOAD(SA, SB, mr, F_MR, lb_)                                                                \
-    PK_BIG_LOAD(SA, SB, mg, F_MG, lb_)                                                                \
-    PK_BIG_LOAD(SA, SB, mb, F_MB, lb_)                                                                \
-    asm volatile("" ::: "memory");                                                                    \
-  }
-#define PK_BIG_COVS(SA, SB, lb_, src_)                                                                \
-  {                                                                                                   \
-    PubArgsPtr R2 = pub_args_now(rp);                                                                 \
-    const SlotSource ss_ = pub_slot_source(R2);                                                       \
-    const unsigned char* sslot_ = ss_.at(src_);                                                       \
-    const double* sf_ = reinterpret_cast<const double*>(sslot_);                                      \
-    const int* sc_ = reinterpret_cast<const int*>(sslot_ + R2->count_off);                            \
-    PK_BIG_LOAD(SA, SB, pxx, F_PXX, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, pxy, F_PXY, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, pyy, F_PYY, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, crr, F_CRR, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, crg, F_CRG, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, crb, F_CRB, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, cgg, F_CGG, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, cgb, F_CGB, lb_)                                                              \
-    PK_BIG_LOAD(SA, SB, cbb, F_CBB, lb_)                                                              \
-    const Int2 c_ = *reinterpret_cast<const Int2*>(sc_ + (lb_));                                      \
-    SA.count = c_.x;                                                                                  \
-    SB.count = c_.y;                                                                                  \
-    asm volatile("" ::: "memory");                                                                    \
-  }
+  // (plain loads: non-temporal ones for pass 2's -- last -- read of the rows +8 %: that read does come from cache,
+  // profiles/r04/ab_big_nontemporal_loads_pass2.log)
 #define PK_BIG_LOAD(SA, SB, field, F, lb_)                                                            \
   {                                                                                                   \
-    const Double2 v_ = big_last_read ? __builtin_nontemporal_load(reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_))) \
-                                     : *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_)); \
+    const Double2 v_ = *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + (lb_));              \
     SA.field = v_.x;                                                                                  \
     SB.field = v_.y;                                                                                  \
   }
-  constexpr bool big_last_read = false;  // (shadowed where a request is pass 2's: PK_BIG_NT_LOADS)
   int64_t prev = -1;
   int cur = 0;
 #ifdef PK_STAMPS
@@ -2481,11 +1797,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[1].ew[0] = er[2];
           gi[1].ew[1] = er[3];
           asm volatile("" ::: "memory");
-#if PK_BIG_LATE_COV
-          // (round 4: this chunk's covariance rows behind its candidate records -- the gates need the records and the means at
-          // once, the other rows not before the keys)
-          if (q > 0) PK_BIG_COVS(SA, SB, min(l0, Lp - 2), csrc)
-#endif
+          // (this chunk's covariance rows asked for HERE, behind its candidate records, instead of with its means: 8.33 against
+          // 8.08 ms -- the keys follow the gates too closely here; profiles/r04/ab_big_late_cov_rows.log)
           if (q == 0) {  // the next particle's source slot (as in k_step_pub)
             PubArgsPtr R4 = pub_args_now(rp);
             const int64_t pn = p + gridDim.x;
@@ -2507,66 +1820,36 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[1].mg = SB.mg;
           gi[1].mb = SB.mb;
           gi[1].has = l0 + 1 < L;
-          if constexpr (PK_BIG_GATE4 != 0 && PK_BIG_GATE_FAR != 0) {
-            pub_far_bound(SA, gi[0].fk, gi[0].fi);
-            pub_far_bound(SB, gi[1].fk, gi[1].fi);
-          }
+          pub_far_bound(SA, gi[0].fk, gi[0].fi);
+          pub_far_bound(SB, gi[1].fk, gi[1].fi);
           double pp[2] = {0.0, 0.0};
           const Landmark<double>* const l2[2] = {&SA, &SB};
-#if PK_PUB_BIG_OVF
-          // (diagnostic / sparse-colour variant, see PK_PUB_BIG_OVF)
-          PubSlots qq[2];
-          pub_gatesN<2, 2, kPubSlots, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
-          pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
-          {
-            PubArgsPtr R9 = pub_args_now(rp);
-            if (pub_refill_slots<2, 2>(qq, R9->cand + 3 * (size_t)lc, R9->erec + 2 * (size_t)lc, &wg_flag[cur]))
-              pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
-          }
-          qa = qq[0];
-          qb = qq[1];
-          qa.st &= 0xFFFFu;
-          qb.st &= 0xFFFFu;
-#else
+          // Eight gate slots of which the positive ones -- at most four -- are kept.  (Four gate slots + the refill turn of
+          // k_step_pub: 23.4 against 8.37 ms per step at 20 000 x 5 000 -- among 5 000 random colours a landmark with five to seven
+          // gate-passing blobs is in nearly every WAVE's 128; profiles/r04/ab_big_four_slots_refill.log.)
           PubSlotsT<kPubBigGateSlots> qq[2];
-          if constexpr (PK_BIG_GATE4 != 0)
-            pub_gatesN<2, 2, kPubBigGateSlots, false, true, (PK_BIG_GATE_AHEAD != 0 && NCH <= 5)>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4);
-          else
-            pub_gatesN<2, 2>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh);
+          // the gates look at a candidate's float copy first (one 16-byte gather instead of two of the 48-byte record: 8.11 -> 7.75 ms,
+          // ab_big_gate_float_table.log) and give look-alikes beyond the underflow edge no slot (-> 7.29 ms, ab_big_far_in_gates.log);
+          // the verdicts take the key's constant term and the colour bound from them
+          pub_gatesN<2, 2, kPubBigGateSlots, false, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4);
           PK_STAMP(c2)
           PK_PSTAMP(1, c1, c2)
-          if constexpr (PK_BIG_GATE4 != 0 && PK_BIG_GATE_FAR != 0 && PK_BIG_KEYS_PRE != 0) {
+          {
             const double kb_[2] = {gi[0].fk, gi[1].fk}, it_[2] = {gi[0].fi, gi[1].fi};
             pub_keysN<2, kPubBigGateSlots, true>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, kb_, it_);
-          } else {
-            pub_keysN<2>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
           }
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
           PK_STAMP(c3)
           PK_PSTAMP(2, c2, c3)
-#endif
           pa = pp[0];
           pb = pp[1];
           {  // the next pair of this pass, or the first one of pass 2
             const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
             const int ln = min(PK_BIG_L0(more ? q + 1 : 0, tid), Lp - 2);
-#if PK_BIG_LATE_COV
-            if (more) {
-              PK_BIG_MEANS(SA, SB, ln, csrc)
-            } else {
-              PK_BIG_ROWS(SA, SB, ln, csrc)
-            }
-#else
-            if (PK_BIG_NT_LOADS != 0 && !more) {  // pass 2's first pair: the LAST read of these rows
-              constexpr bool big_last_read = true;
-              PK_BIG_ROWS(SA, SB, ln, csrc)
-            } else {
-              PK_BIG_ROWS(SA, SB, ln, csrc)
-            }
-#endif
+            PK_BIG_ROWS(SA, SB, ln, csrc)
           }
-#if defined(PK_STAMPS) && !PK_PUB_BIG_OVF
+#if defined(PK_STAMPS)
           PK_STAMP(c4)
           PK_PSTAMP(3, c3, c4)
 #endif
@@ -2636,25 +1919,13 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     }
     if (tid == 0) pub_args_now(rp)->pflag_out[p] = 0;
     // ---- pass 2: rows in again, updates in scan order, rows out
-    double2 za01 = {0.0, 0.0}, za23 = {0.0, 0.0}, zb01 = {0.0, 0.0}, zb23 = {0.0, 0.0};
-    if constexpr (PK_BIG_APPLY_AHEAD != 0) {  // the records of the first pair's blobs (its rows have been on their way since pass 1 ended)
-      const double* exn = pub_args_now(rp)->exact;
-      const double* ra = exn + 6 * pub_apply_only_blob(Q[0]);
-      const double* rb_ = exn + 6 * pub_apply_only_blob(Q[1]);
-      za01 = *reinterpret_cast<const double2*>(ra);
-      za23 = *reinterpret_cast<const double2*>(ra + 2);
-      zb01 = *reinterpret_cast<const double2*>(rb_);
-      zb23 = *reinterpret_cast<const double2*>(rb_ + 2);
-    }
-    if (PK_BIG_PRIO == 1 && tid0 >= 256) __builtin_amdgcn_s_setprio(3);  // (diagnostic: the second four waves first in pass 2)
-    if (PK_BIG_PRIO == 3 && tid0 < 256) __builtin_amdgcn_s_setprio(3);   // (diagnostic: the first four)
+    // (Measured and dropped, round 4: the record of a landmark's blob asked for a pair AHEAD of its update, +0.9 % --
+    // ab_big_apply_records_a_pair_ahead.log; wave priorities in pass 2 -- ab_big_wave_priorities.log; plain stores, +8 % --
+    // ab_big_plain_stores.log.)
 #define PK_BIG_STORE(field, F)                                                             \
   {                                                                                        \
     const Double2 v_ = {SA.field, SB.field};                                               \
-    if (PK_BIG_NT_STORES != 0)                                                             \
-      __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
-    else                                                                                   \
-      *reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0) = v_;                           \
+    __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
   }
 #pragma unroll 1
     for (int q = 0; q < NCH; ++q) {
@@ -2669,10 +1940,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
         const unsigned char* immutable = R->immutable;
         // (the scan-order table in global memory: see pub_big_fixed_lds_bytes)
-        acc += pub_apply_loop<PK_BIG_APPLY_AHEAD != 0>(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0], za01, za23);
+        acc += pub_apply_loop(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0]);
         {
           PubArgsPtr R8 = pub_args_now(rp);
-          acc += pub_apply_loop<PK_BIG_APPLY_AHEAD != 0>(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1], zb01, zb23);
+          acc += pub_apply_loop(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1]);
         }
         PK_STAMP(d2)
         PK_PSTAMP(8, d1, d2)
@@ -2702,23 +1973,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
           const int ln = min(PK_BIG_L0(more ? q + 1 : 0, tid), Lp - 2);
           const int32_t sn = more ? csrc : nsrc;
-          if (PK_BIG_NT_LOADS != 0 && more) {
-            constexpr bool big_last_read = true;
-            PK_BIG_ROWS(SA, SB, ln, sn)
-          } else {
-            PK_BIG_ROWS(SA, SB, ln, sn)
-          }
-          if constexpr (PK_BIG_APPLY_AHEAD != 0) {  // the records of the next pair's blobs, right behind its rows
-            if (more) {
-              const double* exn = pub_args_now(rp)->exact;
-              const double* ra = exn + 6 * pub_apply_only_blob(Q[2]);
-              const double* rb_ = exn + 6 * pub_apply_only_blob(Q[3]);
-              za01 = *reinterpret_cast<const double2*>(ra);
-              za23 = *reinterpret_cast<const double2*>(ra + 2);
-              zb01 = *reinterpret_cast<const double2*>(rb_);
-              zb23 = *reinterpret_cast<const double2*>(rb_ + 2);
-            }
-          }
+          PK_BIG_ROWS(SA, SB, ln, sn)
         }
         PK_STAMP(d3)
         PK_PSTAMP(10, d2, d3)
@@ -2729,11 +1984,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         pse[i] = pse[i + 2];
       }
     }
-    if (PK_BIG_PRIO == 1 || PK_BIG_PRIO == 3) __builtin_amdgcn_s_setprio(0);
 #undef PK_BIG_STORE
 #undef PK_BIG_ROWS
-#undef PK_BIG_MEANS
-#undef PK_BIG_COVS
 #undef PK_BIG_LOAD
     {
       const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier A

@@ -404,126 +404,6 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
   return logw;
 }
 
-// ---- ekf_update in two halves (k_step_pub's usual case, round 4) ---------------------------------------------------------
-// The position block (x, y and their 2x2 covariance) and the colour block (r, g, b and their 3x3) of an update do not touch
-// each other's state.  The one-pass kernel runs the position halves of BOTH landmarks of a lane's pair, stores the pair's five
-// position rows, and only then the colour halves: the first stores of a pair leave after two fifths of its arithmetic.  The
-// expressions are ekf_update's own, term for term (same divisions, same association), so the state comes out bit-identical
-// to every other route; the weight goes through EkfWeightSum (one log per lane instead of one per update: its rounding differs
-// from ekf_update's by a few 1e-16).
-template <typename T>
-struct EkfPosHalf {
-  T q00;   // h' Pxy h + Qt[0][0]
-  T maha;  // d0^2 / Q00
-};
-template <typename T>
-__device__ __forceinline__ EkfPosHalf<T> ekf_update_position(Landmark<T>& f, T sx, T sy, T bearing, const Noise<T>& qt, bool immutable,
-                                                            T zhat0) {
-  T dx = f.mx - sx, dy = f.my - sy;
-  T q = dx * dx + dy * dy;  // :785
-  T h0, h1;                 // :789/:795
-  if (q == T(0)) {
-    h0 = T(0);
-    h1 = T(0);
-  } else {
-    T iq = T(1) / q;
-    h0 = dy * iq;
-    h1 = dx * iq;
-  }
-  T a0 = f.pxx * h0 + f.pxy * h1;  // Pxy h
-  T a1 = f.pxy * h0 + f.pyy * h1;
-  T q00 = h0 * a0 + h1 * a1 + qt.q00;  // :817-818
-  T iq00 = T(1) / q00;
-  T d0 = bearing - zhat0;  // :846/:911 innovation, not wrapped
-  T k0 = a0 * iq00, k1 = a1 * iq00;
-  if (!immutable) {
-    f.mx += k0 * d0;
-    f.my += k1 * d0;
-    T nxx = f.pxx - k0 * a0;
-    T nxy = f.pxy - T(0.5) * (k0 * a1 + k1 * a0);
-    T nyy = f.pyy - k1 * a1;
-    f.pxx = nxx;
-    f.pxy = nxy;
-    f.pyy = nyy;
-  }
-  return EkfPosHalf<T>{q00, d0 * d0 * iq00};
-}
-// the colour half; returns (||Q||_F^2, d' Q^-1 d) of the WHOLE update given the position half's (q00, maha)
-template <typename T>
-__device__ __forceinline__ void ekf_update_colour(Landmark<T>& f, T zr, T zg, T zb, const Noise<T>& qt, bool immutable,
-                                                  const EkfPosHalf<T>& ph, T& fro2, T& maha) {
-  Sym3<T> qc{f.crr + qt.rr, f.crg + qt.rg, f.crb + qt.rb, f.cgg + qt.gg, f.cgb + qt.gb, f.cbb + qt.bb};
-  T detc;
-  Sym3<T> qci = sym3_inverse(qc, detc);
-  T d1 = zr - f.mr, d2 = zg - f.mg, d3 = zb - f.mb;
-  fro2 = ph.q00 * ph.q00 + qc.a * qc.a + qc.d * qc.d + qc.f * qc.f + T(2) * (qc.b * qc.b + qc.c * qc.c + qc.e * qc.e);
-  T v0 = qci.a * d1 + qci.b * d2 + qci.c * d3;
-  T v1 = qci.b * d1 + qci.d * d2 + qci.e * d3;
-  T v2 = qci.c * d1 + qci.e * d2 + qci.f * d3;
-  maha = ph.maha + (d1 * v0 + d2 * v1 + d3 * v2);
-  if (!immutable) {
-    T nr = f.mr + (f.crr * v0 + f.crg * v1 + f.crb * v2);
-    T ng = f.mg + (f.crg * v0 + f.cgg * v1 + f.cgb * v2);
-    T nb = f.mb + (f.crb * v0 + f.cgb * v1 + f.cbb * v2);
-    T nrr, nrg, nrb, ngg, ngb, nbb;
-    T m00 = qci.a * f.crr + qci.b * f.crg + qci.c * f.crb;
-    T m01 = qci.a * f.crg + qci.b * f.cgg + qci.c * f.cgb;
-    T m02 = qci.a * f.crb + qci.b * f.cgb + qci.c * f.cbb;
-    T m11 = qci.b * f.crg + qci.d * f.cgg + qci.e * f.cgb;
-    T m12 = qci.b * f.crb + qci.d * f.cgb + qci.e * f.cbb;
-    T m22 = qci.c * f.crb + qci.e * f.cgb + qci.f * f.cbb;
-    if (qt.diag) {
-      nrr = qt.rr * m00;
-      nrg = qt.rr * m01;
-      nrb = qt.rr * m02;
-      ngg = qt.gg * m11;
-      ngb = qt.gg * m12;
-      nbb = qt.bb * m22;
-    } else {
-      T m10 = qci.b * f.crr + qci.d * f.crg + qci.e * f.crb;
-      T m20 = qci.c * f.crr + qci.e * f.crg + qci.f * f.crb;
-      T m21 = qci.c * f.crg + qci.e * f.cgg + qci.f * f.cgb;
-      nrr = f.crr - (f.crr * m00 + f.crg * m10 + f.crb * m20);
-      nrg = f.crg - (f.crr * m01 + f.crg * m11 + f.crb * m21);
-      nrb = f.crb - (f.crr * m02 + f.crg * m12 + f.crb * m22);
-      ngg = f.cgg - (f.crg * m01 + f.cgg * m11 + f.cgb * m21);
-      ngb = f.cgb - (f.crg * m02 + f.cgg * m12 + f.cgb * m22);
-      nbb = f.cbb - (f.crb * m02 + f.cgb * m12 + f.cbb * m22);
-    }
-    f.mr = nr;
-    f.mg = ng;
-    f.mb = nb;
-    f.crr = nrr;
-    f.crg = nrg;
-    f.crb = nrb;
-    f.cgg = ngg;
-    f.cgb = ngb;
-    f.cbb = nbb;
-    count_update(f.count);
-  }
-}
-
-// The importance factors of a lane's landmarks (:844-849, one per matched blob) with ONE log: the squared Frobenius norms as a
-// product of mantissas and a sum of exponents (frexp: no over- or underflow whatever the factors), the Mahalanobis terms and the
-// constants as a plain sum.   log w = sum_i [ -1/2 (log 2 pi + 1/2 log fro2_i) - 1/2 maha_i ]   (+ log 0.1 per potential
-// feature, :111-112).  The product of a few mantissas in [0.5, 1) is a normal number; its rounding is far inside the 1e-9 the
-// weights are held to.
-struct EkfWeightSum {
-  double mant = 1.0;
-  double lin = 0.0;
-  int expo = 0;
-  __device__ __forceinline__ void add(double fro2, double maha, bool potential) {
-    int e = 0;
-    const double m = frexp(fro2, &e);
-    mant *= potential ? 1.0 : m;
-    expo += potential ? 0 : e;
-    lin += potential ? Consts<double>::log_no_match : -0.5 * Consts<double>::log_two_pi - 0.5 * maha;
-  }
-  __device__ __forceinline__ double finish() const {
-    return lin - 0.25 * ((double)expo * 0.69314718055994528623 + log_few_ulp(mant));
-  }
-};
-
 // motion_model, prkt_core_v2.py:168-208, on one pose.  n0..n2 are the three draws
 // normal(0, sigma, 1) already scaled (:185, :190, :193).
 template <typename T>
