@@ -541,7 +541,7 @@ def main():
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
     for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_CAND_LISTS",
-                 "PK_OPT_REGS_RETRY", "PK_OPT_SPLIT_RESERVE_CUS", "PK_OPT_PUB_STEP", "PK_OPT_PUB_SMALL"):  # tuning experiments only
+                 "PK_OPT_REGS_RETRY", "PK_OPT_SPLIT_RESERVE_CUS", "PK_OPT_PUB_STEP", "PK_OPT_PUB_SMALL", "PK_OPT_FAR_PRUNE"):  # tuning experiments only
         if os.environ.get(name):
             filt.set_option(name[7:].lower(), int(os.environ[name]))
     if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only

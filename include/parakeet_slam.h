@@ -117,6 +117,10 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    there, one lane per contested blob picks the winner; two landmark pairs per lane, 512 lanes -- while
  *                    the table fits LDS and no candidate list overflows; decided per scan on the device,
  *                    pk_observe_published) or 0 (k_step_regs: per-blob counters, probability queue, bids);
+ *   "far_prune"    = 1 (default) or 0: once per scan, the look-alikes whose match probability is certainly 0 for every particle
+ *                    (a key beyond the float64 underflow edge by the reference particle's bound with margins) leave the candidate
+ *                    lists of the publish / subscribe kernels; a landmark whose own bound is weaker re-checks them itself
+ *                    (prkt_core_v2.py:369: probability 0 never matches).  0: every particle tests and judges them (round 4).
  *   "pub_small"    = 0 (default) or 1: maps of at most 512 landmarks through k_step_pub's 256-lane instance (three workgroups per
  *                    CU) instead of k_step_fused -- built, exact, and no faster (the kernel 1 % slower, the step 50 us longer
  *                    for the candidate-list launches at 10 000 x 500);

@@ -152,6 +152,8 @@ struct pk_filter {
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
   unsigned char* npass_dev = nullptr; // [Lp + kCandSpare] per landmark: blobs inside the reference particle's own gates (k_candidates)
   float4* gate4_dev = nullptr;   // [bcand_cap] every blob's bearing and colour as float: k_step_pub_big's first look (k_cand_entries)
+  uint4* far_dev = nullptr;      // [Lp + kCandSpare][3] per landmark: the bound its list was pruned with | its far list (k_candidates, pk_pub_math.hpp)
+  int far_prune = 1;             // look-alikes certainly beyond the underflow edge leave the candidate lists once per scan (0: as round 4)
   unsigned* glist_dev = nullptr; // [bcand_cap + 1 + 256] the same for the blobs several landmarks list, compacted; then their number; then the octet orders of k_step_pub (128 u16) and k_step_pub_big (384 u16)
   // a split observe in progress (pk_observe_staged_range): what the first call set up for the later ones
   struct Split {
@@ -967,7 +969,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev, (void*)f->far_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
@@ -1347,15 +1349,18 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     if (!f->npass_dev && (rc = dev_alloc(f, &f->npass_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
     if (!f->erec_dev2 && (rc = dev_alloc(f, &f->erec_dev2, ((size_t)f->d.lay.Lp + kCandSpare) * 2))) return rc;
     if ((rc = ensure_inverse_lists(f, B, 2 * kCandSlots))) return rc;
+    if (!f->far_dev && (rc = dev_alloc(f, &f->far_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
     int ecap = step_pub_big_entry_capacity(B);
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     Span t(f, PK_T_ASSOC);
+    uint4* far = f->far_prune ? f->far_dev : nullptr;
     launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
     launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
-                      2 * kCandSlots, f->out4, f->npass_dev);
+                      2 * kCandSlots, f->out4, f->npass_dev, far);
     launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev, f->npass_dev);
+                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev, f->npass_dev, far != nullptr);
     cand->rec = f->cand_dev;
+    cand->far = far;
     cand->over = ctl_cand_over(f);
     cand->slots = 2 * kCandSlots;
     f->pub_ecap = ecap;
@@ -1368,6 +1373,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     if (ecap > 0) {
       if (!f->erec_dev && (rc = dev_alloc(f, &f->erec_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
       if (!f->npass_dev && (rc = dev_alloc(f, &f->npass_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
+      if (!f->far_dev && (rc = dev_alloc(f, &f->far_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
       if ((rc = ensure_inverse_lists(f, B))) return rc;
     }
     Span t(f, PK_T_ASSOC);
@@ -1375,10 +1381,12 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     cand->rec = f->cand_dev;
     cand->over = ctl_cand_over(f);
     if (ecap > 0) {  // candidate lists both ways, and the publish table's layout
+      uint4* far = f->far_prune ? f->far_dev : nullptr;
       launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
-                        kCandSlots, f->out4, f->npass_dev);
+                        kCandSlots, f->out4, f->npass_dev, far);
       launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                          ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev);
+                          ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev, far != nullptr);
+      cand->far = far;
       cand->skip_cand = ctl_skip_cand(f);
       f->pub_ecap = ecap;
     } else {
@@ -1407,6 +1415,9 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
                       p0, p1, reserve_cus);
     launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
                      reserve_cus);
+    // pruned lists (cand.far): k_step_regs' candidate-list instance never takes them (k_cand_entries: skip_cand), so a scan the
+    // publish / subscribe kernel stood back from goes to the fall-back kernels as a whole
+    if (cand.far && f->pub_ecap > 0) launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
   } else {
     if (f->pub_ecap > 0 && cand.rec)
       launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
@@ -1444,7 +1455,8 @@ static int onepass_finish(pk_filter* f, const AssocLaunch& al, int B, const Obse
     fr.n_flagged = ctl_n_flagged(f);
     fr.row_next = ctl_retry_rows(f);
     fr.row_cap = retry_rows(f);
-    launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fr, cand);
+    // (pruned candidate lists are the publish / subscribe kernels' alone: the hand-off instance walks the colour grid then)
+    launch_assoc_grid(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, f->ids_dev, false, fr, cand.far ? CandTable{} : cand);
     ObserveExtras e3 = ex;
     e3.flip = false;
     e3.sweep_only_value = 2;
@@ -1736,6 +1748,10 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
   }
   if (!strcmp(name, "pub_small")) {
     f->pub_small = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "far_prune")) {
+    f->far_prune = value != 0;
     return PK_OK;
   }
   if (!strcmp(name, "pub_entry_limit")) {

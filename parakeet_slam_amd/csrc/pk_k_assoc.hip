@@ -3,6 +3,7 @@
 // Hand-written gfx950 (CDNA4, wave64) kernels of the FastSLAM particle update; see DESIGN.md
 // section 4.  No MFMA: the algebra is 2x2 / 3x3 and register resident (pk_math.hpp).
 #include "pk_device.hpp"
+#include "pk_pub_math.hpp"
 
 namespace pk {
 
@@ -735,14 +736,17 @@ struct CandArgs {
   int64_t P;
   unsigned char* npass;  // [Lp + kCandSpare] out: blobs inside the reference's OWN gates (:433, :441) -- what a particle's verdict rounds
                          // will be about; k_cand_entries orders the lanes of k_step_pub by it.  Or NULL
+  uint4* far;            // [Lp + kCandSpare][1 + SLOTS / 8] out, or NULL: (Kb, Ib as float, entries of the far list, 0) | the FAR list --
+                         // look-alikes whose key is certainly beyond the underflow edge for every particle whose own bound is at
+                         // least (Kb, Ib) leave the landmark's list (pk_pub_math.hpp); NULL: nothing is taken off
 };
 
 constexpr int kCandThreads = 1024;  // 64 landmarks x 16 waves that share the scan's blobs
 template <int SLOTS>
 __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   static_assert(SLOTS == kCandSlots || SLOTS == 2 * kCandSlots, "records of two or three uint4");
-  __shared__ unsigned short s_c[64][SLOTS];
-  __shared__ int s_n[64], s_pass[64];
+  __shared__ unsigned short s_c[64][SLOTS], s_f[64][SLOTS];
+  __shared__ int s_n[64], s_pass[64], s_nf[64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int l = blockIdx.x * 64 + lane;
   const unsigned char* slot = a.ss.at(a.src[a.ref]);
@@ -766,6 +770,19 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
     gf = (float)f[(size_t)F_MG * a.Lp + l];
     bf = (float)f[(size_t)F_MB * a.Lp + l];
   }
+  // the reference's far bound with its margins, ROUNDED as the particles will read it (Ib = 0: nothing is far)
+  float kbf = -3.0e38f, ibf = 0.f;
+  if (has && a.far) {
+    Landmark<double> lm = load_landmark_nocount(f, a.Lp, l);
+    double fk, fi;
+    pub_far_bound(lm, fk, fi);
+    if (fi > 0.0 && fk == fk && fabs(fk) < 1e30) {  // (fi > 0: sane determinants, a positive definite colour block)
+      kbf = pub_round_down_to_float(fk - kFarKeySlack);
+      ibf = pub_round_down_to_float(fi / kFarVarFactor);
+      if (!(ibf > 0.f)) ibf = 0.f;
+    }
+  }
+  const double Kb = (double)kbf, Ib = (double)ibf;
   // the centres are the ROUNDED values the particles will compare themselves with
   const double cb = (double)ebf, cr = (double)rf, cg = (double)gf, cc = (double)bf;
   const double tb = 0.5 + kCandBearing + 1e-9;
@@ -774,6 +791,7 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   if (w == 0) {
     s_n[lane] = 0;
     s_pass[lane] = 0;
+    s_nf[lane] = 0;
   }
   __syncthreads();
   const int chunk = (a.B + kCandThreads / 64 - 1) / (kCandThreads / 64);
@@ -790,9 +808,17 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
     const double db = zb - cb;
     const bool near = fabs(db) <= tb || fabs(db - Consts<double>::two_pi) <= tb || fabs(db + Consts<double>::two_pi) <= tb;
     if (has && near && dr * dr + dg * dg + dc * dc <= tc) {
-      const int n = atomicAdd(&s_n[lane], 1);
-      if (n < SLOTS) s_c[lane][n] = (unsigned short)t;
-      if (fabs(db) <= 0.5 && dr * dr + dg * dg + dc * dc <= 300.0) atomicAdd(&s_pass[lane], 1);
+      // certainly beyond the underflow edge for every particle inside the margins whose own bound is at least (Kb, Ib)?
+      const double er = fmax(fabs(dr) - kCandColour, 0.0), eg = fmax(fabs(dg) - kCandColour, 0.0), ec = fmax(fabs(dc) - kCandColour, 0.0);
+      const bool far = Ib > 0.0 && Kb + (er * er + eg * eg + ec * ec) * Ib > kPubFarKey + 0.5;
+      if (far) {
+        const int n = atomicAdd(&s_nf[lane], 1);
+        if (n < SLOTS) s_f[lane][n] = (unsigned short)t;
+      } else {
+        const int n = atomicAdd(&s_n[lane], 1);
+        if (n < SLOTS) s_c[lane][n] = (unsigned short)t;
+        if (fabs(db) <= 0.5 && dr * dr + dg * dg + dc * dc <= 300.0) atomicAdd(&s_pass[lane], 1);
+      }
     }
   }
   __syncthreads();
@@ -808,6 +834,19 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
       out[1 + j] = make_uint4((unsigned)c[8 * j + 0] | ((unsigned)c[8 * j + 1] << 16), (unsigned)c[8 * j + 2] | ((unsigned)c[8 * j + 3] << 16),
                               (unsigned)c[8 * j + 4] | ((unsigned)c[8 * j + 5] << 16), (unsigned)c[8 * j + 6] | ((unsigned)c[8 * j + 7] << 16));
     if (n > SLOTS) atomicAdd(a.over, 1u);
+    if (a.far) {
+      const int nf = has ? s_nf[lane] : 0;
+      unsigned short cf[SLOTS];
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) cf[k] = k < nf ? s_f[lane][k] : (unsigned short)0xFFFF;
+      uint4* fo = a.far + (1 + SLOTS / 8) * (size_t)l;
+      fo[0] = make_uint4(__float_as_uint(kbf), __float_as_uint(ibf), (unsigned)min(nf, SLOTS), 0u);
+#pragma unroll
+      for (int j = 0; j < SLOTS / 8; ++j)
+        fo[1 + j] = make_uint4((unsigned)cf[8 * j + 0] | ((unsigned)cf[8 * j + 1] << 16), (unsigned)cf[8 * j + 2] | ((unsigned)cf[8 * j + 3] << 16),
+                               (unsigned)cf[8 * j + 4] | ((unsigned)cf[8 * j + 5] << 16), (unsigned)cf[8 * j + 6] | ((unsigned)cf[8 * j + 7] << 16));
+      if (nf > SLOTS) atomicAdd(a.over, 1u);  // (a far list that does not hold its blobs: the scan goes the general way)
+    }
     if (a.npass) a.npass[l] = (unsigned char)min(has ? s_pass[lane] : 0, 255);
     if (a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
       for (int k = 0; k < min(n, SLOTS); ++k) {
@@ -832,7 +871,7 @@ __global__ void __launch_bounds__(256) k_cand_strays(const unsigned* bcnt, int B
 
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev, int slots,
-                       const double* pose_sums4_dev, unsigned char* npass_dev) {
+                       const double* pose_sums4_dev, unsigned char* npass_dev, uint4* far_dev) {
   if (d.P == 0 || d.lay.Lp == 0) return;
   // (inverse lists as wide as the lists themselves: brec_dev holds B x slots u16)
   if (bcnt_dev && brec_dev) {
@@ -854,6 +893,7 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.ref = ref_particle;
   a.pose4 = pose_sums4_dev;
   a.npass = npass_dev;
+  a.far = far_dev;
   a.P = d.P;
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;

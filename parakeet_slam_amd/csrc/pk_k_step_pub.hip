@@ -45,6 +45,7 @@
 #include <type_traits>
 
 #include "pk_device.hpp"
+#include "pk_pub_math.hpp"
 
 namespace pk {
 
@@ -89,6 +90,7 @@ struct PubArgs {
   const unsigned* glist;        // [B + 1]: the blobs at least two landmarks list: first entry | contenders << 16; [B]: how many
   const unsigned* skip;         // != 0: this scan is not ours (a list overflowed, or the table does not fit)
   const float4* gate4;          // [B] k_step_pub_big: bearing, r, g, b as float (NaN: out of the range the margins cover), else null
+  const uint4* far;             // [Lp + spare][1 + slots / 8]: (Kb, Ib, n, 0) | the far list of every landmark (k_candidates), or null
   unsigned char* pflag_out;     // [P] 1 = general route
   unsigned* n_flagged;
   int64_t P, p_begin;
@@ -102,11 +104,13 @@ struct PubArgs {
 // dynamic LDS: exact records 48 B | publish table 8 (ecap + 2: a dump entry, padding) | binfo 4 B | order 2 B |
 // any 2 x (B + 16: a dump byte) (B padded to 16) | the landmarks' immutable flags, 1 B each (kPubImmBytes)
 constexpr size_t kPubImmBytes = 2048;  // k_step_pub: maps up to 2 048 landmarks
-__host__ __device__ inline size_t pub_fixed_lds_bytes(int B) {
+// ... | the landmarks' far bounds (Kb, Ib as float, 8 B each: pk_pub_math.hpp) -- 2 048 landmarks, 512 for the 256-lane instance
+__host__ __device__ inline size_t pub_bound_lds_bytes(bool small) { return (small ? 512 : 2048) * 8; }
+__host__ __device__ inline size_t pub_fixed_lds_bytes(int B, bool small = false) {
   const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
-  return Bp * 48 + 16 + Bp * 4 + Bp * 2 + 2 * (Bp + 16) + kPubImmBytes;
+  return Bp * 48 + 16 + Bp * 4 + Bp * 2 + 2 * (Bp + 16) + kPubImmBytes + pub_bound_lds_bytes(small);
 }
-size_t step_pub_lds_bytes(int B, int ecap) { return pub_fixed_lds_bytes(B) + (size_t)ecap * 8; }  // (the 16 spare bytes: the dump entry)
+size_t step_pub_lds_bytes(int B, int ecap, bool small) { return pub_fixed_lds_bytes(B, small) + (size_t)ecap * 8; }  // (the 16 spare bytes: the dump entry)
 int step_pub_entry_capacity(int B) {
   const size_t fixed = pub_fixed_lds_bytes(B);
   if (fixed + 64 * 8 > kMaxDynLds) return 0;
@@ -115,7 +119,7 @@ int step_pub_entry_capacity(int B) {
 }
 
 int step_pub_entry_capacity_small(int B) {
-  const size_t budget = 52 * 1024, fixed = pub_fixed_lds_bytes(B);  // three workgroups per CU
+  const size_t budget = 52 * 1024, fixed = pub_fixed_lds_bytes(B, true);  // three workgroups per CU
   if (fixed + 64 * 8 > budget) return 0;
   return (int)((budget - fixed) / 8);
 }
@@ -139,6 +143,8 @@ struct CandEntriesArgs {
   unsigned* skip_pub;
   unsigned* skip_cand;
   int L, Lp, B, ecap;
+  int pruned;  // the lists have had their far look-alikes taken off (k_candidates): only the publish / subscribe kernels, which check
+               // every landmark's own bound against the scan's, may use them -- k_step_regs' candidate-list instance always stands back
 };
 
 // SLOTS: entries per candidate list and per inverse list (kCandSlots, or twice that for the scans of several thousand blobs)
@@ -265,7 +271,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   const bool fits = *a.over == 0u && s_total <= (unsigned)a.ecap && s_total < 0xFFFFu;
   if (tid == 0) {
     *a.skip_pub = fits ? 0u : 1u;
-    *a.skip_cand = (*a.over != 0u || fits) ? 1u : 0u;
+    *a.skip_cand = (*a.over != 0u || fits || a.pruned != 0) ? 1u : 0u;
   }
   __syncthreads();  // brec / binfo written above are read below by other threads of this (the only) workgroup
   __threadfence_block();
@@ -364,8 +370,9 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap, int slots, const double* exact_dev, float4* gate4_dev,
-                         const unsigned char* npass_dev) {
+                         const unsigned char* npass_dev, bool pruned) {
   CandEntriesArgs a;
+  a.pruned = pruned ? 1 : 0;
   a.npass = npass_dev;
   a.exact = exact_dev;
   a.gate4 = exact_dev ? gate4_dev : nullptr;
@@ -430,20 +437,6 @@ struct PubGateIn {
   bool has;
   double fk, fi;  // GT only: where fi > 0 the landmark's keys are at least fk + fi |colour difference|^2 (pub_far_bound)
 };
-// The lower bound of a landmark's keys that pub_keysN calls "far" (see there): key >= kbase + |d|^2 / rowmax for a colour block
-// that is certainly positive definite.  The same expressions as in pub_keysN -- the same values.
-__device__ __forceinline__ double pub_recip(double x);
-__device__ __forceinline__ double pub_log(double x);
-__device__ __forceinline__ void pub_far_bound(const Landmark<double>& lm, double& fk, double& fi) {
-  const double det2 = lm.pxx * lm.pyy - lm.pxy * lm.pxy;
-  double det3;
-  const Sym3<double> adj3 = sym3_adjugate(Sym3<double>{lm.crr, lm.crg, lm.crb, lm.cgg, lm.cgb, lm.cbb}, det3);
-  const bool sane = det2 > 1e-20 && det2 < 1e60 && det3 > 1e-20 && det3 < 1e60;  // NaN: false
-  const bool pd3 = sane && lm.crr > 0.0 && adj3.f > 0.0 && lm.pxx > 0.0;
-  const double rowmax = fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))), lm.cbb + (fabs(lm.crb) + fabs(lm.cgb)));
-  fk = 5.0 * Consts<double>::log_two_pi + pub_log(det2 * det3);  // (pub_keysN's kbase, whatever the blocks are like)
-  fi = pd3 ? pub_recip(rowmax) : 0.0;                            // (0: no bound)
-}
 // N: landmarks worked on side by side; W4: uint4 words per list (1: eight candidates, 2: sixteen)
 // OVF: a landmark may pass MORE blobs than it has slots without the particle being flagged: bits 16.. of its slots' state word
 // say which of its candidates passed, and pub_refill_slots brings in the ones the slots no longer hold (round 4: what flagged up to 13 % of the
@@ -617,54 +610,90 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
   }
 }
 
+// Look-alikes taken off the lists once per scan (pk_pub_math.hpp; k_candidates): a landmark whose OWN far bound (fk, fi) is not at
+// least the one its list was pruned with -- (Kb, Ib) -- cannot rely on "far for everybody" and looks at its FAR list itself: a
+// blob there that passes its gates (:433, :441) and is not certainly far by the landmark's own bound sends the particle to the
+// fall-back kernels.  Wave-uniform and rare (a particle that missed most of the updates the reference particle made to a landmark).
+// far_row: the pair's far records [hdr | list] x 2; ex: the scan's exact records (LDS or global); has: the landmark exists.
+template <int N, int W4 = 1, class FarRow>
+__device__ __forceinline__ void pub_far_recheck(const bool (&viol)[N], const Landmark<double>* const (&lmp)[N], const double (&pse)[N],
+                                                const double (&fk)[N], const double (&fi)[N], const FarRow& far_row_fn, const double* ex,
+                                                double sh, int* flag) {
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) any |= viol[j];
+  if (__ballot(any) == 0ull) return;  // wave-uniform: the usual case
+  const uint4* far_row = far_row_fn();
+  if (far_row == nullptr) return;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (__ballot(viol[j]) == 0ull) continue;  // wave-uniform
+    const Landmark<double>& lm = *lmp[j];
+    const double eb = pse[j] - sh;  // :408
+    const unsigned* fw = reinterpret_cast<const unsigned*>(far_row + (1 + W4) * j + 1);
+#pragma unroll 1
+    for (int w = 0; w < 4 * W4; ++w) {
+      const unsigned cw = viol[j] ? fw[w] : 0xFFFFFFFFu;
+      if (__ballot((cw & 0xFFFFu) != 0xFFFFu) == 0ull) break;  // wave-uniform: the lists are filled from the front
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned t = (cw >> (16 * half)) & 0xFFFFu;
+        const bool valid = t != 0xFFFFu;
+        const double* rec = ex + 6 * (valid ? t : 0u);
+        const double2 z01 = *reinterpret_cast<const double2*>(rec);
+        const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+        const double cd = color_distance2(lm.mr, lm.mg, lm.mb, z01.y, z23.x, z23.y);
+        const bool pass = valid && !(fabs(z01.x - eb) > 0.5) && !(fabs(cd) > 300.0);
+        const double d1 = z01.y - lm.mr, d2 = z23.x - lm.mg, d3 = z23.y - lm.mb;
+        const bool farp = fi[j] > 0.0 && fk[j] + (d1 * d1 + d2 * d2 + d3 * d3) * fi[j] > kPubFarKey;  // (as in pub_keysN's rounds; NaN: false)
+        bad |= pass && !farp;
+      }
+    }
+  }
+  if (bad) *flag = 1;
+}
+
+// What pub_keysN needs to test that the scan's pruned lists hold for its landmarks (CHK), as FUNCTIONS evaluated where the
+// values are used -- held in registers from the call on they cost k_step_pub<2, 512>, which sits at 256 VGPRs, 70-100 spills:
+// bnd(j): the bound landmark j's list was pruned with (Kb, Ib; Ib = 0: an empty far list, nothing to hold); has(j): the landmark
+// exists; far_row(): the pair's far records [hdr | list x W4] x N, or null; sh: the heading.
+struct PubNoChk {
+  __device__ __forceinline__ float2 bnd(int) const { return make_float2(-3.0e38f, 0.f); }
+  __device__ __forceinline__ bool has(int) const { return false; }
+  __device__ __forceinline__ const uint4* far_row() const { return nullptr; }
+  double sh = 0.0;
+};
 // Verdicts of the two landmarks of a pair on their gate-passing blobs: published for the blobs other landmarks list too,
 // any[t] = 1 where the probability is > 0 (the blob will be matched by somebody: no 0.1 factor, :94-95).  any[anydump]: a
 // byte nobody reads.  One slot of each landmark per round, side by side (two independent chains).
-__device__ __forceinline__ double pub_recip(double x) {
-  // 1 / x to a few ulp (v_rcp_f64 and two Newton steps: the full division sequence is twice as long; the keys are compared
-  // with each other only, all made the same way)
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  return r;
-}
-// log(x) for the keys: x a positive normal number (the product of two determinants inside 1e-20 ... 1e60 each -- anything
-// else is flagged), absolute error below 1e-12: keys are only compared with each other and with thresholds a unit wide, two
-// keys within 1e-7 relative are handed to the exact route anyway, and identical landmarks still give identical keys (same
-// function, same inputs).  log_few_ulp's form -- e ln 2 + 2 atanh((m - 1) / (m + 1)) -- with eight terms instead of eleven,
-// a Newton reciprocal instead of the division and no special cases: 35 instructions against 65.
-__device__ __forceinline__ double pub_log(double x) {
-  int e = 0;
-  double m = frexp(x, &e);  // m in [0.5, 1)
-  const bool low = m < 0.70710678118654752440;
-  m = low ? m * 2.0 : m;
-  e = low ? e - 1 : e;
-  const double s = (m - 1.0) * pub_recip(m + 1.0);
-  const double z = s * s;  // <= 0.0295
-  double p = 1.0 / 15.0;  // (fma_k: the coefficients through scalar registers, pk_math.hpp)
-  p = fma_k(p, z, 1.0 / 13.0);
-  p = fma_k(p, z, 1.0 / 11.0);
-  p = fma_k(p, z, 1.0 / 9.0);
-  p = fma_k(p, z, 1.0 / 7.0);
-  p = fma_k(p, z, 1.0 / 5.0);
-  p = fma_k(p, z, 1.0 / 3.0);
-  const double lm = 2.0 * s + 2.0 * s * (z * p);  // 2 atanh(s); the series' remainder: 2 s z^8 / 17 < 3e-14
-  return (double)e * 0.69314718055994530942 + lm;
-}
 // PRE: kbase and 1 / rowmax come from the caller (pub_far_bound, k_step_pub_big: its gates needed them already)
 // (Measured and dropped, round 4: look-alikes certainly beyond the underflow edge taken out of slots 1.. before the rounds, +11 % --
 // profiles/r04/ab_pub_prune_far_slots.log; any[] as COUNTERS of the landmarks that want a blob, so that a blob with one taker
 // needs no settling, +0.6 % -- ab_counted_settling.log.)
-template <int N, int SL = kPubSlots, bool PRE = false>
+// CHK: the lists have had their far look-alikes taken off (k_candidates): the landmarks' own bounds are held against the scan's
+// (pub_far_recheck), W4F uint4 words per far list
+template <int N, int SL = kPubSlots, bool PRE = false, bool CHK = false, int W4F = 1, class Chk = PubNoChk>
 __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
                                           unsigned anydump, int* flag, double sx, double sy, const double* pre_kbase = nullptr,
-                                          const double* pre_itr3 = nullptr) {
+                                          const double* pre_itr3 = nullptr, const Chk& chk = Chk()) {
+  bool nobody;  // wave-uniform: nobody's landmark passes a blob
   {
     unsigned sall = q[0].s[0];
 #pragma unroll
     for (int j = 1; j < N; ++j) sall &= q[j].s[0];
-    if (__ballot((sall & 0xFFFFu) != 0xFFFFu) == 0ull) return;  // wave-uniform: nobody's landmark passes a blob
+    nobody = __ballot((sall & 0xFFFFu) != 0xFFFFu) == 0ull;
+    if (nobody) {
+      // (... of its pruned list: a landmark with a far list still has to hold its own bound against the scan's -- the wave goes
+      // through the prologue for that and leaves behind the test; rare: a wave none of whose 128 landmarks sees a blob it could match)
+      bool need = false;
+      if constexpr (CHK) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) need |= chk.has(j) && chk.bnd(j).y > 0.f;
+      }
+      if (!CHK || __ballot(need) == 0ull) return;
+    }
   }
   constexpr double ln2 = 0.69314718055994530942;
   double det2[N], det3[N], r2[N], r3[N], a2base[N], a3base[N], kbase[N], itr3[N];
@@ -705,6 +734,16 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
       itr3[j] = pd3[j] ? pub_recip(fmax(fmax(lm.crr + (fabs(lm.crg) + fabs(lm.crb)), lm.cgg + (fabs(lm.crg) + fabs(lm.cgb))),
                                          lm.cbb + (fabs(lm.crb) + fabs(lm.cgb))))
                        : 0.0;
+  }
+  if constexpr (CHK) {
+    bool viol[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float2 b = chk.bnd(j);
+      viol[j] = chk.has(j) && !(itr3[j] >= (double)b.y && kbase[j] >= (double)b.x);
+    }
+    pub_far_recheck<N, W4F>(viol, lmp, pse, kbase, itr3, [&]() { return chk.far_row(); }, ex, chk.sh, flag);
+    if (nobody) return;
   }
   int done = 0;
 #pragma unroll 1
@@ -1164,12 +1203,25 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   // LDS offsets (bytes): exact | pub (ecap + 2 entries) | glist (binfo's place) | order | any[2][Bp + 16]
   const unsigned o_pub = Bp * 48u, o_binfo = o_pub + ((unsigned)ecap + 2u) * 8u, o_order = o_binfo + Bp * 4u, o_any = o_order + Bp * 2u;
   const unsigned o_imm = o_any + 2u * (Bp + 16u);
+  const unsigned o_bnd = o_imm + (unsigned)kPubImmBytes;  // float2 (Kb, Ib) per landmark
   const unsigned dump = (unsigned)ecap, anydump = Bp;
   unsigned G;  // blobs that several landmarks list
   {
     const int tid = tid0;
     PubArgsPtr R = pub_args_now(rp);
     // ---- the scan's tables: once per workgroup
+    {  // the bounds the landmarks' lists were pruned with (no far table: bounds that every landmark meets)
+      const uint4* gf = R->far;
+      float2* bnd = reinterpret_cast<float2*>(smem + o_bnd);
+      for (int i = tid; i < Lp; i += kPubThreads) {
+        float2 v = make_float2(-3.0e38f, 0.f);
+        if (gf) {
+          const uint4 hdr = gf[2 * (size_t)i];
+          if (hdr.z != 0u) v = make_float2(__uint_as_float(hdr.x), __uint_as_float(hdr.y));  // (an empty far list: nothing to hold)
+        }
+        bnd[i] = v;
+      }
+    }
     double* ex = reinterpret_cast<double*>(smem);
     const double* gex = R->exact;
     for (int i = tid; i < 6 * B; i += kPubThreads) ex[i] = gex[i];
@@ -1389,7 +1441,22 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         double p1[1] = {0.0};
         const Landmark<double>* const l1[1] = {&S[2 * q + j_]};
         if (PK_PUB_ABLATE < 4) pub_gatesN<1>(q1, p1, g1, ex, pub, dump, &wg_flag[cur], sx, sy, sh);
-        if (PK_PUB_ABLATE < 3) pub_keysN<1>(q1, l1, p1, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        if (PK_PUB_ABLATE < 3) {
+          struct Chk1 {
+            const float2* bnd_;
+            int l_, L_, Lp_;
+            PubArgsPtr rp_;
+            double sh;
+            __device__ __forceinline__ float2 bnd(int) const { return bnd_[min(l_, Lp_ - 1)]; }
+            __device__ __forceinline__ bool has(int) const { return l_ < L_; }
+            __device__ __forceinline__ const uint4* far_row() const {
+              const uint4* fr = pub_args_now(rp_)->far;
+              return fr ? fr + 2 * (size_t)min(l_, Lp_) : nullptr;
+            }
+          };
+          const Chk1 chk{reinterpret_cast<const float2*>(smem + o_bnd), l0 + j_, L, Lp, rp, sh};
+          pub_keysN<1, kPubSlots, false, true, 1, Chk1>(q1, l1, p1, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, nullptr, nullptr, chk);
+        }
         qq[j_] = q1[0];
         pp[j_] = p1[0];
       }
@@ -1398,7 +1465,23 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       if (PK_PUB_ABLATE < 4) pub_gatesN<2, 1, kPubSlots, true>(qq, pp, gi, ex, pub, dump, &wg_flag[cur], sx, sy, sh);
       PK_STAMP(sk0_)
       if (PK_PUB_ABLATE < 3) {
-        pub_keysN<2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy);
+        /* (the landmarks' own far bounds are held against the ones the scan's lists were pruned with: pub_far_recheck) */
+        struct Chk2 {
+          const float2* bnd_;
+          unsigned lw, tid_;
+          int L_, Lp_;
+          PubArgsPtr rp_;
+          double sh;
+          __device__ __forceinline__ int l0() const { const unsigned lw = this->lw; const int tid = (int)tid_; (void)tid; return PK_PUB_L0(q, tid); }
+          __device__ __forceinline__ float2 bnd(int j) const { return bnd_[min(l0() + j, Lp_ - 1)]; }
+          __device__ __forceinline__ bool has(int j) const { return l0() + j < L_; }
+          __device__ __forceinline__ const uint4* far_row() const {
+            const uint4* fr = pub_args_now(rp_)->far;
+            return fr ? fr + 2 * (size_t)min(l0(), Lp_) : nullptr;
+          }
+        };
+        const Chk2 chk{reinterpret_cast<const float2*>(smem + o_bnd), lw, (unsigned)tid, L, Lp, rp, sh};
+        pub_keysN<2, kPubSlots, false, true, 1, Chk2>(qq, l2, pp, ex, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, nullptr, nullptr, chk);
         { /* (a second turn where a landmark passed more blobs than it has slots: wave-uniform, rare) */
           PubArgsPtr R9 = pub_args_now(rp);
           const int lc9 = min(l0, Lp);
@@ -1796,6 +1879,13 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[0].ew[1] = er[1];
           gi[1].ew[0] = er[2];
           gi[1].ew[1] = er[3];
+          const uint4* frow = R->far;
+          const bool far_hdr_on = frow != nullptr;
+          uint4 fh0 = make_uint4(0u, 0u, 0u, 0u), fh1 = fh0;
+          if (far_hdr_on) {
+            fh0 = frow[3 * (size_t)lc];
+            fh1 = frow[3 * (size_t)lc + 3];
+          }
           asm volatile("" ::: "memory");
           // (this chunk's covariance rows asked for HERE, behind its candidate records, instead of with its means: 8.33 against
           // 8.08 ms -- the keys follow the gates too closely here; profiles/r04/ab_big_late_cov_rows.log)
@@ -1822,6 +1912,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           gi[1].has = l0 + 1 < L;
           pub_far_bound(SA, gi[0].fk, gi[0].fi);
           pub_far_bound(SB, gi[1].fk, gi[1].fi);
+          bool viol[2] = {false, false};
+          if (far_hdr_on) {  // (uniform) do the scan's pruned lists hold for these two landmarks?
+            viol[0] = gi[0].has && !(gi[0].fi >= (double)__uint_as_float(fh0.y) && gi[0].fk >= (double)__uint_as_float(fh0.x));
+            viol[1] = gi[1].has && !(gi[1].fi >= (double)__uint_as_float(fh1.y) && gi[1].fk >= (double)__uint_as_float(fh1.x));
+          }
           double pp[2] = {0.0, 0.0};
           const Landmark<double>* const l2[2] = {&SA, &SB};
           // Eight gate slots of which the positive ones -- at most four -- are kept.  (Four gate slots + the refill turn of
@@ -1836,6 +1931,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           PK_PSTAMP(1, c1, c2)
           {
             const double kb_[2] = {gi[0].fk, gi[1].fk}, it_[2] = {gi[0].fi, gi[1].fi};
+            {
+              PubArgsPtr R8 = pub_args_now(rp);
+              const uint4* fr8 = R8->far;
+              pub_far_recheck<2, 2>(viol, l2, pp, kb_, it_, [&]() { return fr8 ? fr8 + 3 * (size_t)lc : (const uint4*)nullptr; }, R8->exact, sh, &wg_flag[cur]);
+            }
             pub_keysN<2, kPubBigGateSlots, true>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, kb_, it_);
           }
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
@@ -2036,6 +2136,7 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
   a.glist = glist_dev;
   a.skip = skip_dev;
   a.gate4 = gate4_dev;
+  a.far = cand.far;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
   a.P = p1;
@@ -2090,6 +2191,7 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   a.glist = glist_dev;
   a.skip = skip_dev;
   a.gate4 = nullptr;
+  a.far = cand.far;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
   a.P = p1;
@@ -2104,8 +2206,8 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   const int n_cu = device_cu_count();
   // persistent grid: one workgroup per CU (512 lanes x 256 VGPRs), three of the 256-lane instance (143 VGPRs; LDS permitting);
   // reserve_cus as in launch_step_regs
-  const size_t lds = step_pub_lds_bytes(B, ecap);
   const bool small = d.lay.Lp <= 2 * kPubSmallThreads;
+  const size_t lds = step_pub_lds_bytes(B, ecap, small);
   int per_cu = 1;
   if (small) per_cu = (int)std::min<size_t>(3, std::max<size_t>(1, (160 * 1024 - 1024) / (lds + 256)));
   int64_t grid_n = (int64_t)(n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0)) * per_cu;

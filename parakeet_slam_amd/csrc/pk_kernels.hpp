@@ -208,6 +208,7 @@ struct CandTable {
   const unsigned* over = nullptr;     // != 0: some list has more entries than slots -> grid walk for this scan
   const unsigned* skip_cand = nullptr; // k_step_regs' candidate-list instance stands back when != 0 (NULL: when *over != 0)
   const unsigned* n_stray = nullptr;  // blobs on no landmark's list
+  const uint4* far = nullptr;         // [Lp][1 + slots / 8] (Kb, Ib, n, 0) | far list: look-alikes k_candidates took off the lists (pk_pub_math.hpp), or NULL
   int slots = kCandSlots;             // entries per list: kCandSlots ([Lp][2] records) or twice that ([Lp][3]; no inverse lists)
 };
 // launch_assoc_grid whose hand-off instance takes its gates from the candidate lists (while no list overflowed)
@@ -217,7 +218,8 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 // bcnt_dev / brec_dev: NULL, or u32[B] / u16[B][slots] (cleared / filled with 0xFF by this call); stray_dev: their count
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr,
-                       int slots = kCandSlots, const double* pose_sums4_dev = nullptr, unsigned char* npass_dev = nullptr);
+                       int slots = kCandSlots, const double* pose_sums4_dev = nullptr, unsigned char* npass_dev = nullptr,
+                       uint4* far_dev = nullptr);
 // K2 + K3 in one pass (pk_k_observe_ml.hip, pk_k_step_pub.hip).  (k_step_owner, a barrier-free variant in which every
 // landmark settled its blobs against the rivals named by the two-way lists, was measured at 56 ms against 13 and removed
 // in round 3: DESIGN.md section 4.)
@@ -238,11 +240,11 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
 // 512-lane persistent workgroups, four landmarks per lane, two barriers per particle.  Returns at once when *skip != 0.
 int step_pub_entry_capacity(int B);  // publish-table entries that fit LDS beside the scan's tables (0: the scan does not fit)
 int step_pub_entry_capacity_small(int B);  // ... with three 256-lane workgroups per CU (the L <= 512 instance)
-size_t step_pub_lds_bytes(int B, int ecap);
+size_t step_pub_lds_bytes(int B, int ecap, bool small = false);
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap, int slots = kCandSlots, const double* exact_dev = nullptr,
-                         float4* gate4_dev = nullptr, const unsigned char* npass_dev = nullptr);
+                         float4* gate4_dev = nullptr, const unsigned char* npass_dev = nullptr, bool pruned = false);
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                      const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
