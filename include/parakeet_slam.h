@@ -399,6 +399,10 @@ int pk_download_sources(pk_filter* f, int32_t* src);
  * cand_overflow = landmarks of the reference particle with more candidate blobs than list slots (non-zero: the
  * scan took the grid walk instead of the lists).  Synchronises the stream. */
 int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow);
+/* The second chance of flagged particles (eight-slot hand-off + k_observe_sweep) has list rows for P / 16 particles (>= 1 024);
+ * a scan that wanted more -- the one-pass kernel stood back from it as a whole -- sends the rest through the general kernels
+ * ONCE: the rows grow to what the last scan wanted.  wanted: of the last finished scan; capacity: rows the next scan will find. */
+int pk_observe_retry_rows(pk_filter* f, int64_t* wanted, int64_t* capacity);
 /* Which instance of the register route (PK_ROUTE_ML_REGS) worked on the last scan (instrumentation; the choice is made
  * on the device, per scan): *published = 1 when k_step_pub did -- contested blobs (prkt_core_v2.py:353-381) settled by
  * static publish / subscribe through LDS, three barriers per particle -- 0 when k_step_regs did (the publish table did

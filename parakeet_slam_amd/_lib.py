@@ -104,6 +104,7 @@ SIGNATURES = {
     "pk_observe_route": (C.c_int, [_h]),
     "pk_download_sources": (C.c_int, [_h, _ip]),
     "pk_observe_flagged": (C.c_int, [_h, _lp, _lp]),
+    "pk_observe_retry_rows": (C.c_int, [_h, _lp, _lp]),
     "pk_observe_published": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pk_observe_flags": (C.c_int, [_h, _bp]),
     "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
@@ -428,6 +429,12 @@ class DeviceFilter(object):
         """(particles the last ML observe handed to the general kernels, candidate-list overflows) -- pk_observe_flagged."""
         a, b = C.c_int64(), C.c_int64()
         check(self._lib.pk_observe_flagged(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def observe_retry_rows(self):
+        """(second-chance rows the last scan wanted, rows the next scan will find) -- pk_observe_retry_rows."""
+        a, b = C.c_int64(), C.c_int64()
+        check(self._lib.pk_observe_retry_rows(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     def observe_published(self):

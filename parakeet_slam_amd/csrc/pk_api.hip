@@ -171,6 +171,8 @@ struct pk_filter {
   int fast_observe = 1;  // association hand-off + k_observe_fast (L <= 512) / k_observe_sweep; 2 = always the sweep kernel
   uint4* sweep_results = nullptr;  // k_observe_sweep: per-workgroup result lists
   size_t sweep_cap = 0;
+  unsigned* retry_seen = nullptr;  // pinned host word: second-chance rows the last scan WANTED (copied behind every second chance)
+  int64_t retry_rows_min = 0;      // what retry_rows() grows to when a scan wanted more rows than there were
   FastHandoff fh{};      // device buffers of the hand-off
   int64_t fh_cap_l = 0, fh_cap_b = 0;
   // pinned host staging ring for the per-scan uploads (blobs, ray directions, chains):
@@ -542,8 +544,17 @@ void build_blob_grid(const double* blobs, const double* dir, int B, bool want_du
 // rows: particles the lists have room for -- all of them (the hand-off routes), or the capped number of second-chance rows
 // (ADVICE round 2 / VERDICT round 3: the second chance used to allocate lists for ALL P particles with the route, 6.4 GB at
 // 100 000 x 2 000, for the few percent a scan flags at worst)
-int64_t retry_rows(const pk_filter* f) { return std::min<int64_t>(f->d.P, std::max<int64_t>(1024, f->d.P / 16)); }
+// (a scan the one-pass kernel stands back from as a WHOLE -- a list overflowed, the publish table does not fit -- flags
+// all P particles; the rows grow to what the last scan wanted, so only the first such scan sends particles beyond P / 16 through
+// the general kernels)
+int64_t retry_rows(const pk_filter* f) {
+  return std::min<int64_t>(f->d.P, std::max<int64_t>(std::max<int64_t>(1024, f->d.P / 16), f->retry_rows_min));
+}
 int ensure_handoff(pk_filter* f, int B, int slots, bool lists = true, bool retry_only = false) {
+  if (retry_only && f->retry_seen) {
+    const int64_t wanted = *reinterpret_cast<volatile unsigned*>(f->retry_seen);  // (the last finished scan's, or the one before)
+    if (wanted > retry_rows(f)) f->retry_rows_min = std::min<int64_t>(f->d.P, wanted + wanted / 4);
+  }
   const int64_t rows = retry_only ? retry_rows(f) : f->d.P;
   const int64_t need_l = lists ? rows * (int64_t)f->d.lay.Lp * (slots == kSweepSlots ? 2 : 1) : 0;
   const int64_t need_b = lists ? rows * (int64_t)std::max(B, 1) : 0;
@@ -986,6 +997,7 @@ int pk_destroy(pk_filter* f) {
     if (f->stage[i]) (void)hipHostFree(f->stage[i]);
     if (f->stage_done[i]) (void)hipEventDestroy(f->stage_done[i]);
   }
+  if (f->retry_seen) (void)hipHostFree(f->retry_seen);
   if (f->own_stream) (void)hipStreamDestroy(f->own_stream);
   delete f;
   return PK_OK;
@@ -1462,6 +1474,9 @@ static int onepass_finish(pk_filter* f, const AssocLaunch& al, int B, const Obse
     e3.sweep_only_value = 2;
     e3.n_flagged = ctl_n_flagged(f);
     launch_observe_sweep(f->stream, f->d, B, al.exact, al.order, fr, f->qt, e3, plan, f->sweep_results);
+    if (!f->retry_seen && hipHostMalloc((void**)&f->retry_seen, 64, hipHostMallocDefault) == hipSuccess) *f->retry_seen = 0u;
+    if (f->retry_seen) (void)hipMemcpyAsync(f->retry_seen, ctl_retry_rows(f), sizeof(unsigned), hipMemcpyDeviceToHost, f->stream);
+    (void)hipGetLastError();
   }
   // the particles still flagged (a landmark passing more blobs than any slot count): general kernels, both timed in the
   // association slot
@@ -2558,6 +2573,16 @@ int pk_observe_flagged(pk_filter* f, int64_t* flagged, int64_t* cand_overflow) {
   }
   if (flagged) *flagged = w[0];
   if (cand_overflow) *cand_overflow = w[1];
+  return PK_OK;
+}
+/* second-chance rows: how many the last scan wanted (particles the one-pass kernel flagged) and how many there are */
+int pk_observe_retry_rows(pk_filter* f, int64_t* wanted, int64_t* capacity) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_observe_retry_rows: NULL handle");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  PK_HIP(hipStreamSynchronize(f->stream));
+  if (wanted) *wanted = f->retry_seen ? (int64_t)*f->retry_seen : 0;
+  if (capacity) *capacity = retry_rows(f);
   return PK_OK;
 }
 int pk_observe_flags(pk_filter* f, uint8_t* flags) {

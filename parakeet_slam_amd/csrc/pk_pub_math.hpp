@@ -68,11 +68,17 @@ constexpr double kPubFarKey = 1492.0;
 //   bound satisfies fk >= Kb and fi >= Ib, its key >= fk + |d|^2 fi >= Kb + dmin^2 Ib > kPubFarKey: probability 0.
 // Far candidates leave the landmark's list (and never enter the blobs' inverse lists: no publish entry, no contested blob); they
 // are kept in a FAR list beside it.  A particle's landmark whose own bound is NOT that good (it missed most of the updates the
-// reference made: a colour block kFarVarFactor times wider, or determinants e^kFarKeySlack times smaller) walks the far list as
+// reference made: a colour block kFarVarFactor times wider -- with C_n = 1 / (4 + 10 n) more than half of them --, or determinants
+// e^kFarKeySlack times smaller) walks the far list as
 // well, in a rare wave-uniform branch: a far-listed blob that passes its gates and is not certainly far by its OWN bound sends the
 // particle to the fall-back kernels (exact as ever).
+#ifndef PK_FAR_VAR_FACTOR  // (tuning builds only)
+#define PK_FAR_VAR_FACTOR 2.0
+#endif
+// (kFarVarFactor 4 / 2 / 1.5 at 100 000 x 2 000, two interleaved repetitions on one box: 8.18 / 8.04 / 8.02 ms per launch, nobody
+// flagged in any of them -- profiles/r05/ab_far_var_factor.log)
 constexpr double kFarKeySlack = 8.0;
-constexpr double kFarVarFactor = 4.0;
+constexpr double kFarVarFactor = PK_FAR_VAR_FACTOR;
 __device__ __forceinline__ float pub_round_down_to_float(double x) {
   float f = (float)x;
   if ((double)f > x) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1u : f < 0.f ? __float_as_uint(f) + 1u : 0x80000001u);

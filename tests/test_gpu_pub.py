@@ -81,7 +81,9 @@ def test_pub_is_the_default_instance_and_agrees_with_regs_and_the_general_kernel
     against_oracle(pub, means, covs, poses, blobs, imm)
 
 
-def test_a_publish_table_that_does_not_fit_leaves_the_scan_to_k_step_regs(lib):
+def test_a_publish_table_that_does_not_fit_leaves_the_scan_to_the_fall_back_kernels(lib):
+    # (round 5: the scan's candidate lists have had their far look-alikes taken off -- k_step_regs' candidate-list instance,
+    # which cannot hold a landmark's own bound against the scan's, stands back too, and every particle is flagged)
     rs = np.random.RandomState(7)
     L = 900
     means, covs = synthetic_world(L)
@@ -445,3 +447,107 @@ def test_more_than_four_blobs_with_a_positive_probability_still_go_to_the_fallba
     assert pub["published"] and pub["flagged"] == 3
     same_state(pub, gen, 1e-11)
     against_oracle(pub, means, covs, poses, blobs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 5: look-alikes that are certainly beyond the underflow edge leave the candidate lists ONCE PER SCAN (k_candidates on the
+# reference particle, with margins; pk_pub_math.hpp).  That verdict holds for a particle's landmark only while its own bound is
+# at least the scan's: a landmark with a much WIDER colour block than the reference particle's (it missed most of the updates)
+# has to look at its far list itself -- and is handed to the fall-back kernels when a blob there could match it.
+def run_stale(lib, means, covs, poses, blobs, stale, opts=None):
+    """One observe on a filter whose particles share (means, covs) except `stale` = {particle: (landmarks, covs)} overrides."""
+    L, P = means.shape[0], poses.shape[0]
+    f = lib.DeviceFilter(P, L)
+    for k, v in (opts or {}).items():
+        f.set_option(k, v)
+    f.upload_map(means, covs.reshape(L, 25))
+    for p, (ls, cv) in stale.items():
+        m, c, k = f.download_landmarks(p, p + 1)
+        c[0, ls] = cv
+        f.upload_landmarks(p, p + 1, m, c.reshape(1, L, 25), k)
+    f.upload_poses(poses)
+    f.observe(blobs)
+    out = dict(logw=f.download_log_weights(), maps=f.download_landmarks(), route=f.observe_route(), flagged=f.observe_flagged()[0],
+               flags=f.observe_flags(), published=f.observe_published())
+    f.close()
+    return out
+
+
+@pytest.mark.parametrize("L", [700, 1500, 2600, 5000])
+def test_a_landmark_with_a_weaker_bound_than_the_scans_looks_at_its_far_list_itself(lib, L):
+    rs = np.random.RandomState(50 + L)
+    means, covs = synthetic_world(L)
+    covs[:, 2:, 2:] = 0.004 * np.identity(3)  # colour blocks of a map seen some twenty-five times (C_n = 1 / (4 + 10 n))
+    covs[:, :2, :2] = 0.02 * np.identity(2)
+    # look-alikes: landmark 7 k gets the colour of landmark 7 k + 3 (three bearings on: inside the bearing gate) shifted by ten --
+    # inside the colour gate (radius 17.3), and FAR for the tight block: |d|^2 / c = 100 / 0.004
+    n = len(means[3::7])
+    shift = rs.normal(size=(n, 3))
+    means[0:7 * n:7, 2:] = means[3::7, 2:] + 10.0 * shift / np.linalg.norm(shift, axis=1, keepdims=True)
+    blobs = synthetic_scan(means, (0.01, -0.02, 0.005))[rs.permutation(L)]
+    P = 8
+    poses = poses_around(rs, P, 0.05)
+    # particles 3 and 6 hold WIDE colour blocks for some of those landmarks (and for a few others): for them the look-alike's blob has
+    # a positive probability -- it contends, may win, may be a second sighting of the landmark
+    wide = 0.25 * np.identity(5)
+    stale = {3: (np.arange(0, 7 * n, 7)[::3], wide), 6: (np.concatenate([np.arange(3, L, 7)[::4], np.arange(5, L, 50)]), wide)}
+    pruned = run_stale(lib, means, covs, poses, blobs, stale)
+    plain = run_stale(lib, means, covs, poses, blobs, stale, {"far_prune": 0})
+    gen = run_stale(lib, means, covs, poses, blobs, stale, {"fast_observe": 0})
+    assert pruned["route"] == plain["route"] == ("ml_regs" if L <= 2048 else "ml_pub_big") and pruned["published"]
+    # the stale particles, and only they, were handed on by the pruned scan (their landmarks' own bounds do not meet the scan's, and a
+    # far-listed blob passes their gates with a probability that is not certainly 0)
+    assert set(np.nonzero(pruned["flags"])[0]) == {3, 6}, np.nonzero(pruned["flags"])[0]
+    same_state(pruned, plain, 1e-11)
+    same_state(pruned, gen, 1e-11)
+    assert plain["flagged"] == 0  # (without the pruning the kernel judges every look-alike itself, for every particle)
+
+
+def test_a_weaker_bound_without_a_matching_far_blob_costs_nothing(lib):
+    # wide colour blocks on landmarks that have NO look-alike: their bounds do not meet the scan's either, but their far lists are
+    # empty or hold nothing that passes their gates -- nobody is flagged
+    rs = np.random.RandomState(77)
+    L = 1200
+    means, covs = synthetic_world(L)
+    covs[:, 2:, 2:] = 0.004 * np.identity(3)
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    poses = poses_around(rs, 6, 0.05)
+    d2 = ((means[:, None, 2:] - means[None, :, 2:]) ** 2).sum(-1) + 1e9 * np.eye(L)
+    lonely = np.nonzero(d2.min(1) > 700.0)[0][:40]  # no other landmark's colour within the (widened) colour gate
+    assert lonely.size >= 10
+    stale = {2: (lonely, 0.25 * np.identity(5))}
+    pruned = run_stale(lib, means, covs, poses, blobs, stale)
+    gen = run_stale(lib, means, covs, poses, blobs, stale, {"fast_observe": 0})
+    assert pruned["published"] and pruned["flagged"] == 0
+    same_state(pruned, gen, 1e-11)
+
+
+def test_a_whole_scan_the_kernel_stands_back_from_gets_second_chance_rows_for_every_particle(lib):
+    """a scan whose publish table does not fit flags ALL particles; the second chance has rows for P / 16 (>= 1 024)
+    and sent the rest through the general kernels, every scan.  The rows now grow to what the last scan wanted."""
+    rs = np.random.RandomState(5)
+    L, P = 2300, 3000
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.0, 0.0, 0.0))
+    f = lib.DeviceFilter(P, L)
+    f.set_option("pub_entry_limit", 8)  # no table: the two-pass kernel stands back from every scan
+    f.upload_map(means, covs.reshape(L, 25))
+    f.upload_poses(poses_around(rs, P, 0.05))
+    f.observe(blobs)
+    assert f.observe_route() == "ml_pub_big" and f.observe_flagged()[0] == P
+    wanted, cap = f.observe_retry_rows()
+    assert wanted == P and cap == 1024
+    a = (f.download_log_weights(), f.download_landmarks())
+    f.observe(blobs)  # (this scan finds rows for everybody)
+    wanted, cap = f.observe_retry_rows()
+    assert wanted == P and cap == P
+    f.close()
+    g = lib.DeviceFilter(P, L)
+    g.set_option("fast_observe", 0)
+    g.upload_map(means, covs.reshape(L, 25))
+    g.upload_poses(poses_around(np.random.RandomState(5), P, 0.05))
+    g.observe(blobs)
+    assert np.allclose(a[0], g.download_log_weights(), rtol=1e-11, atol=1e-9)
+    for x, y in zip(a[1], g.download_landmarks()):
+        assert np.array_equal(x, y)
+    g.close()
