@@ -78,9 +78,10 @@ SQ_KERNEL_KEY = {"ml_regs_pub": "k_step_pub<2, 512>", "ml_fused": "k_step_fused"
 
 def measured_issue(P, L, route):
     """Instruction-issue time of the route's dominant kernel for one launch over P particles, from the committed SQ counter pass
-    (profiles/*/pmc_sq_*.json, scripts/gpu_pmc_sq.sh) taken at THIS map size: (VALU + SALU wave-instructions per particle) x P x
-    4 cycles / (1 024 SIMDs x clock).  The counts per particle do not depend on P (persistent grid, one particle per workgroup
-    at a time).  The newest round wins; None when no pass exists for this size / kernel."""
+    (profiles/*/pmc_sq_*.json, scripts/gpu_pmc_sq.sh) taken at THIS map size: VALU wave-instructions per particle x P x 4 cycles /
+    (1 024 SIMDs x clock) -- the scalar instructions issue on a port of their own at about a cycle each and are reported beside
+    it, not added.  The counts per particle do not depend on P (persistent grid, one particle per workgroup at
+    a time).  The newest round wins; None when no pass exists for this size / kernel."""
     import re
 
     key = SQ_KERNEL_KEY.get(route)
@@ -99,8 +100,9 @@ def measured_issue(P, L, route):
                     continue
                 for k, c in d["counters"].items():
                     if key in k and c.get("SQ_INSTS_VALU", 0) > 0:
-                        per_particle = (c["SQ_INSTS_VALU"] + c.get("SQ_INSTS_SALU", 0.0)) / float(mp.group(1))
+                        per_particle = c["SQ_INSTS_VALU"] / float(mp.group(1))
                         best = {"ms": per_particle * P * 4.0 / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3,
+                                "salu_ms": c.get("SQ_INSTS_SALU", 0.0) / float(mp.group(1)) * P * 1.0 / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3,
                                 "valu_per_particle": c["SQ_INSTS_VALU"] / float(mp.group(1)),
                                 "salu_per_particle": c.get("SQ_INSTS_SALU", 0.0) / float(mp.group(1)),
                                 "source": "profiles/%s/%s (git %s)" % (rnd, name, d.get("git", "?"))}
@@ -409,9 +411,11 @@ def roofline_object(P, L, route, obs_ms, obs_n, stride, K, copy_gbs):
             "issue_ms": issue["ms"],
             "valu_wave_instructions_per_particle": issue["valu_per_particle"],
             "salu_wave_instructions_per_particle": issue["salu_per_particle"],
-            "what": "replayed: (VALU + SALU wave-instructions per launch from the committed SQ counter pass) x 4 cycles / (%d SIMDs x "
-                    "%.1f GHz) / this run's kernel time -- the share of the launch during which every SIMD would be issuing if the "
-                    "instructions were spread evenly; float64 vector instructions take 4 cycles of a wave64 SIMD" % (N_SIMD, CLOCK_GHZ),
+            "salu_issue_ms": issue.get("salu_ms"),
+            "what": "replayed: VALU wave-instructions per launch from the committed SQ counter pass x 4 cycles / (%d SIMDs x "
+                    "%.1f GHz) / this run's kernel time -- the share of the launch during which every SIMD would be issuing vector "
+                    "instructions if they were spread evenly (a wave64 instruction takes 4 cycles of a SIMD; the scalar instructions "
+                    "issue on their own port, about a cycle each: salu_issue_ms, not added)" % (N_SIMD, CLOCK_GHZ),
             "source": issue["source"],
         }
     return {
@@ -616,6 +620,25 @@ def main():
     no_dup = None
     if not sharded and not args.no_probes:
         no_dup = {}
+        if args.assoc == "ml":
+            # ... first on the map AS THE RUN LEFT IT (round 5): every particle's landmarks copied into its own slot (a download
+            # materialises the resample's indirection), then the same scan observed six times without a resample -- the steady
+            # state of the filter without the cache's help; the two probes below start from a FRESH map instead (the first
+            # updates of a landmark: wide colour blocks, every look-alike still a contender)
+            s_last = W + K + (0 if args.no_probes else 8) - 1
+            filt.download_landmarks(0, 1)
+            filt.observe(scans[s_last], fresh=True)
+            filt.enable_timing(0b0000100)
+            filt.reset_timings()
+            for _ in range(6):
+                filt.observe(scans[s_last], fresh=True)
+            ms, cnt = filt.timings()["observe"]
+            filt.enable_timing(0)
+            avg = ms / max(cnt, 1) * 1e-3
+            no_dup["ml_steady_state_map"] = {"avg_launch_ms": avg * 1e3, "launches": cnt,
+                                             "achieved": float(P) * L * BYTES_PER_UPDATE / avg / 1e9 if avg > 0 else 0.0,
+                                             "frac": float(P) * L * BYTES_PER_UPDATE / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0,
+                                             "distinct_source_slots": int(np.unique(filt.download_sources()).size)}
         for tag, pids in (("ml", None), ("supplied_ids", np.arange(1, L + 1, dtype=np.int32))):
             if tag == "ml" and args.assoc != "ml":
                 continue
@@ -704,15 +727,33 @@ def main():
     # kernel k_step_pub_big, timed by the driver's run and not only in profiles/ (N = 1, default workload only)
     shard4 = None
     if world == 1 and not args.force_sharded and not args.no_configs4 and (P, L) == (DEFAULT_P, DEFAULT_L) and args.assoc == "ml":
-        P4, L4, K4, W4 = 125000, 5000, 6, 2
+        # (round 5: the same window of the trajectory as the headline -- warm-up 5, 20 steps -- where rounds 3-4 timed steps 2-7
+        # of the fresh filter; and the steps 40-49 beside it: the map's colour blocks tighten for some twenty steps, and with
+        # them the scan-level pruning of look-alikes)
+        P4, L4, K4, W4, LATE0, LATEK = 125000, 5000, 20, 5, 40, 10
+        f4 = None
         try:
-            m4, c4, s4 = synthetic_inputs(L4, K4 + W4)
+            n4 = LATE0 + LATEK
+            m4, c4, s4 = synthetic_inputs(L4, n4)
+            ws4 = synthetic_controls(n4)
             f4 = _lib.DeviceFilter(P4, L4, device=local_rank)
             f4.upload_map(m4, c4.reshape(L4, 25))
             rnd4 = random.Random(7)
-            e4, tm4, route4, _ = timed_steps(f4, _lib, P4, L4, K4, W4, s4, synthetic_controls(K4 + W4),
-                                              [rnd4.random() for _ in range(K4 + W4)], None, barrier2(torch, f4), 1)
+            us4 = [rnd4.random() for _ in range(n4)]
+            e4, tm4, route4, step4 = timed_steps(f4, _lib, P4, L4, K4, W4, s4, ws4, us4, None, barrier2(torch, f4), 1)
             fl4 = f4.observe_flagged()
+            for s_ in range(W4 + K4, LATE0):
+                step4(s_)
+            f4.synchronize()
+            f4.enable_timing(0b0000100)
+            f4.reset_timings()
+            t_l = time.perf_counter()
+            for s_ in range(LATE0, LATE0 + LATEK):
+                step4(s_)
+            f4.synchronize()
+            e_late = time.perf_counter() - t_l
+            tl4 = f4.timings()["observe"]
+            f4.enable_timing(0)
             shard4 = {
                 "workload": workload_name(P4, L4, "ml"),
                 "value": float(P4) * L4 * K4 / e4,
@@ -723,12 +764,17 @@ def main():
                 "filter_steps_per_sec": K4 / e4,
                 "device_bytes": f4.device_bytes(),
                 "particles_sent_to_fallback_kernels_last_step": fl4[0],
+                "trajectory_steps": [W4, W4 + K4 - 1],
                 "roofline": roofline_object(P4, L4, route4, tm4["observe"][0], tm4["observe"][1], 1, K4, None),
+                "late_window": {"trajectory_steps": [LATE0, LATE0 + LATEK - 1], "ms_per_step": e_late / LATEK * 1e3,
+                                "roofline": roofline_object(P4, L4, route4, tl4[0], tl4[1], 1, LATEK, None)},
             }
-            f4.close()
-            del f4
         except Exception as e:  # (a GPU with less free memory than 170 GB: say so instead of failing the headline)
             shard4 = {"workload": workload_name(P4, L4, "ml"), "error": repr(e)}
+        finally:  # (170 GB must not stay allocated behind a failure while the rest of the line is measured)
+            if f4 is not None:
+                f4.close()
+            f4 = None
 
     # The reference's own scene sizes through the FACADE (FastSLAM.cam_cb wall time, Python included): prkt_ros.py's node --
     # 50 particles x 4 landmarks (prkt_ros.py:33-52; mutable, as BASELINE.md section 2 measured them) -- and BASELINE configs[0],
@@ -736,6 +782,10 @@ def main():
     refscene = None
     if world == 1 and not args.force_sharded and not args.no_refscene and (P, L) == (DEFAULT_P, DEFAULT_L) and args.assoc == "ml":
         refscene = facade_latency(local_rank)
+        try:  # the reference's call pattern at the headline's size
+            refscene["configs2_through_the_facade"] = facade_at_size(local_rank, DEFAULT_P, DEFAULT_L, 20, 5)
+        except Exception as e:  # noqa: BLE001
+            refscene["configs2_through_the_facade"] = {"error": repr(e)}
 
     # what a plain device-to-device copy reaches on THIS box (read + write bytes / time), outside the
     # timed region: the practical ceiling next to the 8 TB/s vendor figure
@@ -873,6 +923,63 @@ def main():
 
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+def facade_at_size(device, P, L, steps, warm):
+    """FastSLAM.cam_cb + summary() per step -- what prkt_ros.py:84-85 does: the summary synchronises every step -- at a BASELINE
+    size, through the facade (device RNG, log weights: the throughput mode; the association, the EKF and the resample are the
+    same kernels as in the headline).  Three ways of handing the scan over: message objects (the reference's interface:
+    ros_view.last_sensor_reading.observes, 4 attribute reads per blob), the same scan object again (a ROS node whose camera is
+    slower than its 10 Hz loop sees that: prkt_ros.py:109 keeps the last message), and a (B, 4) array."""
+    import parakeet_slam_amd as pk
+
+    class Scan(object):
+        pass
+
+    class Node(object):
+        pass
+
+    means, covs, scans = synthetic_inputs(L, steps + warm)
+    ws = synthetic_controls(steps + warm)
+    feats = [pk.Feature(mean=means[l], covar=covs[l]) for l in range(L)]
+    out = {"what": "wall time of FastSLAM.cam_cb + FastSLAM.summary() per step (the reference's call pattern, prkt_ros.py:84-85: one "
+                   "synchronisation per step), %d particles x %d landmarks, B = L, rng='device', weights 'log'; steps %d..%d of the "
+                   "trajectory" % (P, L, warm, warm + steps - 1)}
+
+    def blobs_of(sc):
+        obs = []
+        for b in sc:
+            o = pk.msgs.Blob()
+            o.bearing = float(b[0])
+            o.color.r, o.color.g, o.color.b = float(b[1]), float(b[2]), float(b[3])
+            obs.append(o)
+        return obs
+
+    for tag in ("message_objects", "array"):
+        views = [blobs_of(sc) for sc in scans] if tag == "message_objects" else [np.ascontiguousarray(sc) for sc in scans]
+        pk.msgs.Time.set_now(0.0)
+        random.seed(7)
+        fs = pk.FastSLAM(feats, num_particles=P, device=device, weight_domain="log", rng="device", seed=7)
+        node = Node()
+        node.last_sensor_reading = Scan()
+        t = 0.0
+        dts = []
+        for s_ in range(warm + steps):
+            tw = pk.msgs.Twist()
+            tw.linear.x, tw.angular.z = 0.2, ws[s_]
+            fs.last_control = tw
+            t += 0.1
+            pk.msgs.Time.set_now(t)
+            node.last_sensor_reading.observes = views[s_]
+            t0 = time.perf_counter()
+            fs.cam_cb(node)
+            sm = fs.summary()
+            dts.append(time.perf_counter() - t0)
+        fs.close()
+        d = np.array(dts[warm:])
+        out[tag] = {"ms_per_step": float(d.mean() * 1e3), "ms_p95": float(np.percentile(d, 95) * 1e3), "ms_max": float(d.max() * 1e3),
+                    "steps": steps, "summary": [float(v) for v in sm]}
+    return out
 
 
 def facade_latency(device):

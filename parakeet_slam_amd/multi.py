@@ -334,9 +334,9 @@ class ShardedFastSLAM(object):
             self._check_open()
             dt = msgs.now() - self.last_update  # :158, the motion update of :75-77
             v, w = float(self.last_control.linear.x), float(self.last_control.angular.z)
-            observes = list(ros_view.last_sensor_reading.observes)  # :82
-            blobs = np.array([[float(b.bearing), float(b.color.r), float(b.color.g), float(b.color.b)] for b in observes],
-                             dtype=np.float64).reshape(-1, 4)
+            from .core import _blob_matrix
+
+            blobs = _blob_matrix(ros_view.last_sensor_reading.observes)  # :82
             zs = self._noise()
             qt = np.asarray(self.Qt, dtype=np.float64).reshape(4, 4)
             if self._publish:

@@ -18,7 +18,8 @@ _lib.LIB_PATH = os.path.join(ROOT, "parakeet_slam_amd", "libparakeet_slam_stamps
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 import bench
 P = int(os.environ.get("ST_P", 10000)); L = int(os.environ.get("ST_L", 500))
-means, covs, scans = bench.synthetic_inputs(L, 6)
+WARM = int(os.environ.get("ST_WARM", 3))  # steps before the measured three (the far pruning of round 5 needs a map seen a few times)
+means, covs, scans = bench.synthetic_inputs(L, WARM + 3)
 f = _lib.DeviceFilter(P, L)
 f.upload_map(means, covs.reshape(L, 25))
 for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_PUB_STEP"):
@@ -27,17 +28,18 @@ for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK
 so = _lib.load()
 so.pk_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 buf = (ctypes.c_ulonglong * 64)()
-for s in range(3):
+for s in range(WARM):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
 wbuf = (ctypes.c_ulonglong * 96)()
 if hasattr(so, "pk_debug_pub_wave_stamps"):
     so.pk_debug_pub_wave_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     so.pk_debug_pub_wave_stamps(wbuf, 1)
-for s in range(3, 6):
+for s in range(WARM, WARM + 3):
     f.step(0.2, 0.1, 0.1, scans[s], 0.3, seed=7, draw=s, domain=1)
 f.synchronize(); so.pk_debug_stamps(buf, 1)
 v = np.array(list(buf), dtype=np.float64)
+print("steps before the measured three:", WARM)
 print("git", os.environ.get("PK_GIT_SHA") or os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or "unknown", "P", P, "L", L)
 if L > 2048 and hasattr(so, "pk_debug_pub_wave_stamps"):  # k_step_pub_big ran (its stamps are kept per wave only)
     so.pk_debug_pub_wave_stamps(wbuf, 1)
