@@ -8,7 +8,7 @@ i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_FLAT"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmcsq_$i
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmcsq_$i -- python3 $R/bench.py --steps 3 --warmup 1 --particles $P --landmarks $L --no-cpu-baseline --no-secondary --no-probes ${PMC_ARGS} > $R/gpurun_out/pmcsq_$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmcsq_$i -- python3 $R/bench.py --steps ${SQ_STEPS:-3} --warmup ${SQ_WARMUP:-1} --particles $P --landmarks $L --no-cpu-baseline --no-secondary --no-probes ${PMC_ARGS} > $R/gpurun_out/pmcsq_$i.log 2>&1
   tail -1 $R/gpurun_out/pmcsq_$i.log | cut -c1-160
 done
 cd $R
