@@ -722,6 +722,26 @@ def main():
         }
         f2.close()
         del f2
+        # ... and the same steps through the OTHER one-pass kernel for maps of at most 512 landmarks (option "pub_small"): the
+        # publish / subscribe instance on candidate lists, three 256-lane workgroups per CU.  Its kernel is the faster one since
+        # the look-alikes leave the lists once per scan (round 5), but it needs two per-scan kernels (k_candidates, k_cand_entries)
+        # that a 0.27-ms step does not amortise: the whole step stays slower, and k_step_fused stays the default
+        try:
+            f3 = _lib.DeviceFilter(P2, L2, device=local_rank)
+            f3.set_option("pub_small", 1)
+            f3.upload_map(m2, c2.reshape(L2, 25))
+            rnd3 = random.Random(7)
+            e3, tm3, route3, _ = timed_steps(f3, _lib, P2, L2, K2, W2, s2, synthetic_controls(K2 + W2),
+                                              [rnd3.random() for _ in range(K2 + W2)], None, barrier2(torch, f3), 4)
+            if route3 in ("ml_regs", "ml_fused") and f3.observe_published():
+                route3 += "_pub"
+            second["pub_small"] = {"what": "the same workload with the option pub_small = 1 (not the default)", "ms_per_step": e3 / K2 * 1e3,
+                                   "value": float(P2) * L2 * K2 / e3,
+                                   "roofline": roofline_object(P2, L2, route3, tm3["observe"][0], tm3["observe"][1], 4, K2, None)}
+            f3.close()
+            del f3
+        except Exception as e:  # noqa: BLE001
+            second["pub_small"] = {"error": repr(e)}
 
     # One whole shard of BASELINE.json configs[4] (1 000 000 x 5 000 over 8 GPUs = 125 000 x 5 000 per GPU) on this GPU: the two-pass
     # kernel k_step_pub_big, timed by the driver's run and not only in profiles/ (N = 1, default workload only)

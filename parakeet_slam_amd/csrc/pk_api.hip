@@ -195,6 +195,8 @@ struct pk_filter {
   double* offsets = nullptr;  // nblocks
   double* sum = nullptr;
   double* out4 = nullptr;
+  double* pose_part = nullptr;   // [motion_pose_blocks(P)][4]: per-block sums of x, y, sin h, cos h the last whole-filter motion launch left
+  bool pose_part_ok = false;     // ... and nothing has touched the poses since
   int32_t* anc = nullptr;           // P
   unsigned char* slot_tmp = nullptr;  // one slot
   // timing
@@ -940,6 +942,7 @@ int pk_create(int64_t P, int32_t L, int32_t device, pk_filter** out) {
   if (!rc) rc = dev_alloc(f, &f->offsets, (size_t)f->nblocks);
   if (!rc) rc = dev_alloc(f, &f->sum, 1);
   if (!rc) rc = dev_alloc(f, &f->out4, 4);
+  if (!rc) rc = dev_alloc(f, &f->pose_part, (size_t)(4 * motion_pose_blocks(P)));
   if (!rc) rc = dev_alloc(f, &f->anc, (size_t)P);
   if (!rc) rc = dev_alloc(f, &f->slot_tmp, d.lay.slot_bytes);
   if (rc) return bail(rc);
@@ -989,7 +992,7 @@ int pk_destroy(pk_filter* f) {
                   (void*)f->bal.alive, (void*)f->bal.bad})
     if (q) (void)hipFree(q);
   void* rest[] = {d.immutable, f->z_dev,  f->ids_dev,
-                  f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4,
+                  f->partial,  f->gmax,   f->clocal,    f->totals,      f->offsets,   f->sum,      f->out4, f->pose_part,
                   f->anc,      f->slot_tmp};
   for (void* p : rest)
     if (p) (void)hipFree(p);
@@ -1080,6 +1083,7 @@ int pk_upload_map(pk_filter* f, const double* means, const double* covs, const u
 }
 
 int pk_upload_poses(pk_filter* f, const double* xyhw) {
+  if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || !xyhw) return fail(PK_ERR_INVALID, "pk_upload_poses: NULL argument");
   int rc;
   if ((rc = use_device(f))) return rc;
@@ -1250,7 +1254,8 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
   if (!z && sg.valid && !sg.uploaded && f->upload_kernel) {
     void* dev_view = nullptr;
     if (hipHostGetDevicePointer(&dev_view, sg.st, 0) == hipSuccess && dev_view) {
-      launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg));
+      launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg), f->pose_part);
+      f->pose_part_ok = true;
       sg.uploaded = true;
       f->gmax_fused = false;  // the block's control words (running weight maximum) were just overwritten
       if ((rc = note_upload(f, sg.slot))) return rc;
@@ -1259,7 +1264,8 @@ int pk_motion(pk_filter* f, double v, double w, double dt, const double* z, uint
     }
     (void)hipGetLastError();
   }
-  launch_motion(f->stream, f->d, v, w, dt, zd, seed, draw, 0);
+  launch_motion(f->stream, f->d, v, w, dt, zd, seed, draw, 0, nullptr, nullptr, 0, f->pose_part);
+  f->pose_part_ok = true;
   PK_LAUNCH_CHECK("pk_motion");
   return PK_OK;
 }
@@ -1344,6 +1350,9 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
     if ((rc = dev_alloc(f, &f->binfo_dev, (size_t)cap))) return rc;
     if ((rc = dev_alloc(f, &f->glist_dev, 2 * (size_t)cap + 1 + 256 + 16))) return rc;
     if ((rc = dev_alloc(f, &f->gate4_dev, (size_t)cap))) return rc;
+    // (empty inverse lists: k_candidates appends to them, k_cand_entries empties them again behind its last read)
+    PK_HIP(hipMemsetAsync(f->bcnt_dev, 0, (size_t)cap * sizeof(unsigned), f->stream));
+    PK_HIP(hipMemsetAsync(f->brec_dev, 0xFF, (size_t)cap * sizeof(uint4), f->stream));
     f->bcand_cap = cap;
   }
   return PK_OK;
@@ -1366,9 +1375,11 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     Span t(f, PK_T_ASSOC);
     uint4* far = f->far_prune ? f->far_dev : nullptr;
-    launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
+    // the reference pose: the particles' mean -- from the sums the motion launch left, or (poses touched since) two launches
+    const double* part = f->pose_part_ok ? f->pose_part : nullptr;
+    if (!part) launch_summary_partials(f->stream, f->d, f->partial, f->out4);
     launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
-                      2 * kCandSlots, f->out4, f->npass_dev, far);
+                      2 * kCandSlots, f->out4, f->npass_dev, far, part);
     launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
                         ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev, f->npass_dev, far != nullptr);
     cand->rec = f->cand_dev;
@@ -1389,20 +1400,21 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
       if ((rc = ensure_inverse_lists(f, B))) return rc;
     }
     Span t(f, PK_T_ASSOC);
-    launch_summary_partials(f->stream, f->d, f->partial, f->out4);  // the reference pose: the particles' mean
+    const double* part = f->pose_part_ok ? f->pose_part : nullptr;  // (as above)
+    if (!part) launch_summary_partials(f->stream, f->d, f->partial, f->out4);
     cand->rec = f->cand_dev;
     cand->over = ctl_cand_over(f);
     if (ecap > 0) {  // candidate lists both ways, and the publish table's layout
       uint4* far = f->far_prune ? f->far_dev : nullptr;
       launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
-                        kCandSlots, f->out4, f->npass_dev, far);
+                        kCandSlots, f->out4, f->npass_dev, far, part);
       launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
                           ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev, far != nullptr);
       cand->far = far;
       cand->skip_cand = ctl_skip_cand(f);
       f->pub_ecap = ecap;
     } else {
-      launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4);
+      launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), nullptr, nullptr, nullptr, kCandSlots, f->out4, nullptr, nullptr, part);
     }
   }
   return PK_OK;
@@ -1699,6 +1711,7 @@ int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1,
 }
 
 int pk_motion_range(pk_filter* f, double v, double w, double dt, uint64_t seed, uint64_t draw, int64_t p0, int64_t p1) {
+  if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f) return fail(PK_ERR_INVALID, "pk_motion_range: NULL handle");
   if (!std::isfinite(v) || !std::isfinite(w) || !std::isfinite(dt)) return fail(PK_ERR_INVALID, "pk_motion_range: non-finite control");
   if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "pk_motion_range: bad particle range [%lld, %lld)", (long long)p0, (long long)p1);
@@ -1814,6 +1827,7 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
 }
 
 int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestors_out) {
+  if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f) return fail(PK_ERR_INVALID, "pk_resample: NULL handle");
   if (!(u >= 0.0 && u < 1.0)) return fail(PK_ERR_INVALID, "pk_resample: u = %g outside [0,1)", u);
   if (weight_domain != PK_WEIGHTS_LINEAR && weight_domain != PK_WEIGHTS_LOG)
@@ -1900,7 +1914,8 @@ int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64
       if (hipHostGetDevicePointer(&dev_view, sg.st, 0) == hipSuccess && dev_view) {
         {
           Span t(f, PK_T_MOTION);
-          launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg));
+          launch_motion(f->stream, f->d, v, w, dt, nullptr, seed, draw, 0, f->scan_dev, dev_view, staged_upload_bytes(sg), f->pose_part);
+      f->pose_part_ok = true;
         }
         sg.uploaded = true;
         f->gmax_fused = false;
@@ -2001,6 +2016,7 @@ int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* d
 }
 
 int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, int64_t n_received) {
+  if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || !src || n_received < 0 || (n_received > 0 && !dev_buf)) return fail(PK_ERR_INVALID, "pk_adopt_particles: bad argument");
   const int64_t P = f->d.P;
   for (int64_t k = 0; k < P; ++k)
@@ -2178,6 +2194,7 @@ int pk_shard_pack_slots_dev(pk_filter* f, int64_t j0, int64_t j1, int64_t slot_l
 }
 
 int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
+  if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: call pk_shard_plan_dev first");
   if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: the balanced placement is active on this filter (its slots carry logical indices): resample through pk_shard_plan_balanced_dev / pk_shard_adopt_balanced_dev");
@@ -2204,6 +2221,7 @@ int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t
 }
 
 int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
+  if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || rank < 0) return fail(PK_ERR_INVALID, "pk_shard_adopt_local_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_local_dev: call pk_shard_plan_dev first");
   if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_adopt_local_dev: the balanced placement is active on this filter (its slots carry logical indices): resample through pk_shard_plan_balanced_dev / pk_shard_adopt_balanced_dev");
@@ -2224,6 +2242,7 @@ int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
 }
 
 int pk_shard_adopt_remote_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
+  if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_remote_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_remote_dev: call pk_shard_plan_dev first");
   if (!f->adopt_local_done)
@@ -2414,6 +2433,7 @@ int pk_shard_pack_balanced_dev(pk_filter* f, const int64_t* table, int32_t world
 
 int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, const void* dev_recv,
                                 int64_t n_received, int32_t mode) {
+  if (f) f->pose_part_ok = false;
   if (!f || !table || world < 1 || world > 64 || rank < 0 || rank >= world || n_received < 0 || mode < 0 || mode > 2 ||
       (n_received > 0 && !dev_recv))
     return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: bad argument");

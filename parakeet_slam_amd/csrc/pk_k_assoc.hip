@@ -733,6 +733,8 @@ struct CandArgs {
   int64_t ref;
   int L, Lp, B;
   const double* pose4;  // sums of x, y, sin h, cos h over the P particles (k_summary_*): the reference POSE is their mean, or NULL
+  const double* part;   // ... or the per-block sums the motion launch left ([n_part][4]), reduced here in a fixed order
+  int64_t n_part;
   int64_t P;
   unsigned char* npass;  // [Lp + kCandSpare] out: blobs inside the reference's OWN gates (:433, :441) -- what a particle's verdict rounds
                          // will be about; k_cand_entries orders the lanes of k_step_pub by it.  Or NULL
@@ -755,7 +757,23 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
   // :254-276 takes it) -- the particles' expected bearings scatter around it with their heading spread, and a particle
   // drawn at random (particle 0 itself) sits one sigma off the middle: twice the margin for the same cloud
   double sx = a.x[a.ref], sy = a.y[a.ref], sh = a.h[a.ref];
-  if (a.pose4) {
+  if (a.part) {  // (kernel-uniform)
+    // every WAVE adds the motion launch's per-block sums up for itself, in a fixed order (lane i: blocks i, i + 64, ...; then the
+    // butterfly): no barrier, and the loads fly beside the landmark's rows and the scan's records
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = lane; i < a.n_part; i += 64) {
+      const double2 p01 = *reinterpret_cast<const double2*>(a.part + 4 * i), p23 = *reinterpret_cast<const double2*>(a.part + 4 * i + 2);
+      v[0] += p01.x;
+      v[1] += p01.y;
+      v[2] += p23.x;
+      v[3] += p23.y;
+    }
+    for (int c = 0; c < 4; ++c) v[c] = wave_sum(v[c]);
+    const double n = (double)a.P;
+    sx = v[0] / n;
+    sy = v[1] / n;
+    sh = atan2(v[2], v[3]);
+  } else if (a.pose4) {
     const double n = (double)a.P;
     sx = a.pose4[0] / n;
     sy = a.pose4[1] / n;
@@ -794,30 +812,46 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
     s_nf[lane] = 0;
   }
   __syncthreads();
-  const int chunk = (a.B + kCandThreads / 64 - 1) / (kCandThreads / 64);
-  const int t1 = min(a.B, (w + 1) * chunk);
-  for (int t = w * chunk; t < t1; ++t) {  // wave-uniform: the records come through the scalar cache
-    const double* rec = a.exact + 6 * (size_t)t;
-    const double zb = rec[0], zr = rec[1], zg = rec[2], zc = rec[3];
-    const double dr = zr - cr, dg = zg - cg, dc = zc - cc;
-    // NaN / inf in the reference's state fail both tests: no candidates, and every particle near such a state
-    // breaks the margin test (comparisons with NaN are false) and goes the general way
-    // the expected bearing is not wrapped (:416-423 are commented out in the reference): particles on the other side
-    // of atan2's branch cut for this landmark, or of the heading wrap, sit 2 pi away from the reference -- their
-    // blobs are listed as well
-    const double db = zb - cb;
-    const bool near = fabs(db) <= tb || fabs(db - Consts<double>::two_pi) <= tb || fabs(db + Consts<double>::two_pi) <= tb;
-    if (has && near && dr * dr + dg * dg + dc * dc <= tc) {
-      // certainly beyond the underflow edge for every particle inside the margins whose own bound is at least (Kb, Ib)?
-      const double er = fmax(fabs(dr) - kCandColour, 0.0), eg = fmax(fabs(dg) - kCandColour, 0.0), ec = fmax(fabs(dc) - kCandColour, 0.0);
-      const bool far = Ib > 0.0 && Kb + (er * er + eg * eg + ec * ec) * Ib > kPubFarKey + 0.5;
-      if (far) {
-        const int n = atomicAdd(&s_nf[lane], 1);
-        if (n < SLOTS) s_f[lane][n] = (unsigned short)t;
-      } else {
-        const int n = atomicAdd(&s_n[lane], 1);
-        if (n < SLOTS) s_c[lane][n] = (unsigned short)t;
-        if (fabs(db) <= 0.5 && dr * dr + dg * dg + dc * dc <= 300.0) atomicAdd(&s_pass[lane], 1);
+  // The scan's records go through LDS, 1 024 at a time (one coalesced round trip; read back at wave-uniform addresses: broadcasts).
+  // Round 4 read them through the scalar cache where they were used -- a chain of cache misses per wave, 22 us of the
+  // kernel's 25 at 500 x 500, where the work itself is a microsecond.
+  __shared__ double s_rec[1024][4];
+  for (int c0 = 0; c0 < a.B; c0 += 1024) {
+    const int nb = min(1024, a.B - c0);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+      const double2* r = reinterpret_cast<const double2*>(a.exact + 6 * (size_t)(c0 + threadIdx.x));
+      const double2 r01 = r[0], r23 = r[1];
+      s_rec[threadIdx.x][0] = r01.x;
+      s_rec[threadIdx.x][1] = r01.y;
+      s_rec[threadIdx.x][2] = r23.x;
+      s_rec[threadIdx.x][3] = r23.y;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = w; i < nb; i += kCandThreads / 64) {  // wave-uniform
+      const int t = c0 + i;
+      const double zb = s_rec[i][0], zr = s_rec[i][1], zg = s_rec[i][2], zc = s_rec[i][3];
+      const double dr = zr - cr, dg = zg - cg, dc = zc - cc;
+      // NaN / inf in the reference's state fail both tests: no candidates, and every particle near such a state
+      // breaks the margin test (comparisons with NaN are false) and goes the general way
+      // the expected bearing is not wrapped (:416-423 are commented out in the reference): particles on the other side
+      // of atan2's branch cut for this landmark, or of the heading wrap, sit 2 pi away from the reference -- their
+      // blobs are listed as well
+      const double db = zb - cb;
+      const bool near = fabs(db) <= tb || fabs(db - Consts<double>::two_pi) <= tb || fabs(db + Consts<double>::two_pi) <= tb;
+      if (has && near && dr * dr + dg * dg + dc * dc <= tc) {
+        // certainly beyond the underflow edge for every particle inside the margins whose own bound is at least (Kb, Ib)?
+        const double er = fmax(fabs(dr) - kCandColour, 0.0), eg = fmax(fabs(dg) - kCandColour, 0.0), ec = fmax(fabs(dc) - kCandColour, 0.0);
+        const bool far = Ib > 0.0 && Kb + (er * er + eg * eg + ec * ec) * Ib > kPubFarKey + 0.5;
+        if (far) {
+          const int n = atomicAdd(&s_nf[lane], 1);
+          if (n < SLOTS) s_f[lane][n] = (unsigned short)t;
+        } else {
+          const int n = atomicAdd(&s_n[lane], 1);
+          if (n < SLOTS) s_c[lane][n] = (unsigned short)t;
+          if (fabs(db) <= 0.5 && dr * dr + dg * dg + dc * dc <= 300.0) atomicAdd(&s_pass[lane], 1);
+        }
       }
     }
   }
@@ -848,36 +882,27 @@ __global__ void __launch_bounds__(kCandThreads) k_candidates(CandArgs a) {
       if (nf > SLOTS) atomicAdd(a.over, 1u);  // (a far list that does not hold its blobs: the scan goes the general way)
     }
     if (a.npass) a.npass[l] = (unsigned char)min(has ? s_pass[lane] : 0, 255);
-    if (a.bcnt) {  // the inverse lists: this landmark joins the list of each of its blobs
-      for (int k = 0; k < min(n, SLOTS); ++k) {
-        const unsigned t = s_c[lane][k];
-        const unsigned m = atomicAdd(&a.bcnt[t], 1u);
-        if (m < (unsigned)a.inv_slots)
-          a.blist[(size_t)t * a.inv_slots + m] = (unsigned short)l;
-        else
-          atomicAdd(a.over, 1u);
-      }
-    }
   }
-}
-
-// blobs on nobody's list: unmatched for every particle inside the margins (weight *= 0.1 each, :94-95)
-__global__ void __launch_bounds__(256) k_cand_strays(const unsigned* bcnt, int B, unsigned* n_stray) {
-  int n = 0;
-  for (int t = threadIdx.x; t < B; t += 256) n += bcnt[t] == 0u;
-  for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, kWave);
-  if ((threadIdx.x & 63) == 0 && n) atomicAdd(n_stray, (unsigned)n);
+  // the inverse lists: the landmark joins the list of each of its blobs -- wave w appends candidate w (sixteen waves, at most sixteen
+  // candidates: every atomic of the workgroup is in flight at once; one lane per landmark did them one round trip after the other)
+  if (a.bcnt && has && w < SLOTS && w < min(s_n[lane], SLOTS)) {
+    const unsigned t = s_c[lane][w];
+    const unsigned m = atomicAdd(&a.bcnt[t], 1u);
+    if (m < (unsigned)a.inv_slots)
+      a.blist[(size_t)t * a.inv_slots + m] = (unsigned short)l;
+    else
+      atomicAdd(a.over, 1u);
+  }
 }
 
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev, uint4* brec_dev, unsigned* stray_dev, int slots,
-                       const double* pose_sums4_dev, unsigned char* npass_dev, uint4* far_dev) {
+                       const double* pose_sums4_dev, unsigned char* npass_dev, uint4* far_dev, const double* pose_part_dev) {
   if (d.P == 0 || d.lay.Lp == 0) return;
-  // (inverse lists as wide as the lists themselves: brec_dev holds B x slots u16)
-  if (bcnt_dev && brec_dev) {
-    (void)hipMemsetAsync(bcnt_dev, 0, (size_t)B * sizeof(unsigned), s);
-    (void)hipMemsetAsync(brec_dev, 0xFF, (size_t)B * (size_t)slots * sizeof(unsigned short), s);
-  }
+  // (inverse lists as wide as the lists themselves: brec_dev holds B x slots u16.  bcnt_dev is all 0 and brec_dev all 0xFF when
+  // this is called: cleared at their allocation, and again by k_cand_entries behind its last read of them -- two memset
+  // launches per scan less.  stray_dev: unused since round 3, kept in the signature)
+  (void)stray_dev;
   CandArgs a;
   a.inv_slots = slots;
   a.bcnt = brec_dev ? bcnt_dev : nullptr;
@@ -892,6 +917,8 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
   a.over = over_dev;
   a.ref = ref_particle;
   a.pose4 = pose_sums4_dev;
+  a.part = pose_part_dev;
+  a.n_part = motion_pose_blocks(d.P);
   a.npass = npass_dev;
   a.far = far_dev;
   a.P = d.P;
@@ -902,7 +929,6 @@ void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact
     hipLaunchKernelGGL(k_candidates<2 * kCandSlots>, dim3((unsigned)((d.lay.Lp + kCandSpare + 63) / 64)), dim3(kCandThreads), 0, s, a);
   else
     hipLaunchKernelGGL(k_candidates<kCandSlots>, dim3((unsigned)((d.lay.Lp + kCandSpare + 63) / 64)), dim3(kCandThreads), 0, s, a);
-  if (a.bcnt && stray_dev) hipLaunchKernelGGL(k_cand_strays, dim3(1), dim3(256), 0, s, a.bcnt, B, stray_dev);
 }
 
 // A candidate list overflowed (a landmark with more than kCandSlots blobs inside the widened gates, or a blob listed by

@@ -14,7 +14,9 @@ __global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* 
                                                 const double* __restrict__ z, uint64_t seed,
                                                 uint64_t draw, int64_t goff, int motion_blocks,
                                                 uint4* __restrict__ up_dst, const uint4* __restrict__ up_src,
-                                                int64_t up_n16, const int64_t* __restrict__ logical) {
+                                                int64_t up_n16, const int64_t* __restrict__ logical,
+                                                double* __restrict__ pose_part) {
+  __shared__ double red[4];
   if ((int)blockIdx.x >= motion_blocks) {
     // the extra workgroups of a combined launch: the per-scan upload (see k_upload)
     const int64_t nb = (int64_t)gridDim.x - motion_blocks;
@@ -23,7 +25,9 @@ __global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* 
     return;
   }
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
+  if (i >= P && pose_part == nullptr) return;
+  double px = 0.0, py = 0.0, ps = 0.0, pc = 0.0;  // this particle's share of the block's pose sums
+  if (i < P) {
   double z0, z1, z2;
   if (z) {
     z0 = z[3 * i];
@@ -55,11 +59,31 @@ __global__ void __launch_bounds__(256) k_motion(double* __restrict__ x, double* 
   x[i] = xi;
   y[i] = yi;
   h[i] = hi;
+  if (pose_part) {
+    px = xi;
+    py = yi;
+    sincos(hi, &ps, &pc);
+  }
+  }
+  // The block's sums of x, y, sin h, cos h of the MOVED particles (fixed order): k_candidates takes the particles' mean pose from
+  // them (the reference the candidate lists are made around), which used to cost two launches of its own per scan
+  if (pose_part) {  // (kernel-uniform)
+    px = block_sum<4>(px, red);
+    py = block_sum<4>(py, red);
+    ps = block_sum<4>(ps, red);
+    pc = block_sum<4>(pc, red);
+    if (threadIdx.x == 0) {
+      pose_part[4 * blockIdx.x + 0] = px;
+      pose_part[4 * blockIdx.x + 1] = py;
+      pose_part[4 * blockIdx.x + 2] = ps;
+      pose_part[4 * blockIdx.x + 3] = pc;
+    }
+  }
 }
 
 void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt, const double* z_dev,
                    uint64_t seed, uint64_t draw, int64_t global_offset, void* up_dst_dev,
-                   const void* up_src_host_mapped, size_t up_bytes) {
+                   const void* up_src_host_mapped, size_t up_bytes, double* pose_part_dev) {
   const int64_t n16 = up_dst_dev ? (int64_t)((up_bytes + 15) / 16) : 0;
   if (d.P == 0 && n16 == 0) return;
   double sd = fabs(.05 * v) + fabs(.005 * w) + .0005;  // :185
@@ -70,7 +94,7 @@ void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt,
   hipLaunchKernelGGL(k_motion, dim3((unsigned)(blocks + ub)), dim3(256), 0, s, d.x[d.cur], d.y[d.cur], d.h[d.cur], d.P,
                      v, w, dt, sd, sh, z_dev, seed, draw, global_offset + d.global_offset, blocks,
                      static_cast<uint4*>(up_dst_dev), static_cast<const uint4*>(up_src_host_mapped), n16,
-                     (const int64_t*)d.logical[d.cur]);
+                     (const int64_t*)d.logical[d.cur], pose_part_dev);
 }
 
 // The same for the particles [p0, p1) only (device noise; the Philox counters use the global particle index, so the draws
@@ -84,7 +108,8 @@ void launch_motion_range(hipStream_t s, DeviceState& d, double v, double w, doub
   int blocks = (int)((n + 255) / 256);
   hipLaunchKernelGGL(k_motion, dim3((unsigned)blocks), dim3(256), 0, s, d.x[d.cur] + p0, d.y[d.cur] + p0, d.h[d.cur] + p0, n, v, w,
                      dt, sd, sh, (const double*)nullptr, seed, draw, d.global_offset + p0, blocks, (uint4*)nullptr,
-                     (const uint4*)nullptr, (int64_t)0, d.logical[d.cur] ? (const int64_t*)(d.logical[d.cur] + p0) : (const int64_t*)nullptr);
+                     (const uint4*)nullptr, (int64_t)0, d.logical[d.cur] ? (const int64_t*)(d.logical[d.cur] + p0) : (const int64_t*)nullptr,
+                     (double*)nullptr);
 }
 
 __global__ void k_fill(double* p, int64_t n, double v) {

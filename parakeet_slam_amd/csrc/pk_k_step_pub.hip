@@ -147,14 +147,41 @@ struct CandEntriesArgs {
                // every landmark's own bound against the scan's, may use them -- k_step_regs' candidate-list instance always stands back
 };
 
+// Exclusive scan of one value per thread over a 1 024-lane workgroup in thread order (Kogge-Stone across the wave, the sixteen wave
+// totals through LDS); returns the prefix, `total` = the sum.  sw: 16 words nobody else uses between the call's two barriers.
+__device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* sw, unsigned& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) sw[wave] = inc;
+  __syncthreads();
+  unsigned woff = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned x = sw[i];
+    woff += i < wave ? x : 0u;
+    tot += x;
+  }
+  total = tot;
+  return woff + inc - v;
+}
+
 // SLOTS: entries per candidate list and per inverse list (kCandSlots, or twice that for the scans of several thousand blobs)
+// (Round 5: the kernel's chains of dependent round trips taken apart -- the scans over the 1 024 threads' partial sums by one thread,
+// a landmark's entries looked up candidate by candidate (two round trips to L2 each), the octets' lists read landmark by landmark:
+// 27 us at 500 x 500, where it stood between the motion update and the one-pass kernel of a 270-us step.)
 template <int SLOTS>
 __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   constexpr bool kRankMajor = SLOTS > kCandSlots;  // (sixteen-entry lists: k_step_pub_big; k_step_pub keeps blob-major, +0.6 % otherwise)
-  __shared__ unsigned s_part[kRankMajor ? 1 : 1024], s_gpart[kRankMajor ? 1 : 1024];
-  __shared__ unsigned short s_cls[kRankMajor ? SLOTS + 1 : 1][1024];  // per class (number of contenders) and chunk: blobs, then their scan
   __shared__ unsigned s_tot[SLOTS + 1], s_cbase[SLOTS + 1], s_rbase[SLOTS];
-  __shared__ unsigned s_total;
+  __shared__ unsigned s_total, s_sw[16];
+  __shared__ unsigned short s_cls[kRankMajor ? SLOTS + 1 : 1][1024];  // per class (number of contenders) and thread: its blobs of the class, then their scan
+  __shared__ unsigned char s_len[kPubBigMaxL + kCandSpare + 14], s_np[kPubBigMaxL + kCandSpare + 14];  // per landmark: list length, npass
   const int tid = threadIdx.x;
   const int chunk = (a.B + 1023) / 1024;
   const int t0 = tid * chunk, t1 = min(a.B, t0 + chunk);
@@ -194,16 +221,13 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     // entries side by side) the lanes read at a stride of three to six entries, an 8-way conflict on every read: the settling
     // loop was 8 % of k_step_pub_big's time and LDS-bound -- and a wave reads no further than its longest list.
 #pragma unroll
-    for (int c = 2; c <= SLOTS; ++c) s_cls[c][tid] = (unsigned short)ncls[c];
-    __syncthreads();
-    if (tid >= 2 && tid <= SLOTS) {  // one thread per class: exclusive scan over the 1 024 chunks
-      unsigned run = 0;
-      for (int i = 0; i < 1024; ++i) {
-        const unsigned v = s_cls[tid][i];
-        s_cls[tid][i] = (unsigned short)run;
-        run += v;
-      }
-      s_tot[tid] = run;
+    for (int c = 2; c <= SLOTS; ++c) s_cls[c][tid] = (unsigned short)ncls[c];  // (through LDS: held in registers across the scans they spilled)
+#pragma unroll 1
+    for (int c = 2; c <= SLOTS; ++c) {  // per class: blobs of that class in the threads before this one
+      unsigned tot;
+      const unsigned pre = block_excl_scan_1024((unsigned)s_cls[c][tid], s_sw, tot);
+      s_cls[c][tid] = (unsigned short)pre;
+      if (tid == 0) s_tot[c] = tot;
     }
     __syncthreads();
     if (tid == 0) {
@@ -241,24 +265,16 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       }
     }
   } else {
-  s_part[tid] = mine;
-  s_gpart[tid] = gmine;
-  __syncthreads();
-  if (tid == 0) {  // sequential scan of 1024 partial sums: once per scan, a microsecond
-    unsigned run = 0, grun = 0;
-    for (int i = 0; i < 1024; ++i) {
-      const unsigned v = s_part[i], g = s_gpart[i];
-      s_part[i] = run;
-      s_gpart[i] = grun;
-      run += v;
-      grun += g;
-    }
-    s_total = run;
-    a.glist[a.B] = grun;
+  unsigned tot_e, tot_g;
+  const unsigned pre_e = block_excl_scan_1024(mine, s_sw, tot_e);
+  const unsigned pre_g = block_excl_scan_1024(gmine, s_sw, tot_g);
+  if (tid == 0) {
+    s_total = tot_e;
+    a.glist[a.B] = tot_g;
   }
   __syncthreads();
   {
-    unsigned run = s_part[tid], grun = s_gpart[tid];
+    unsigned run = pre_e, grun = pre_g;
     for (int t = t0; t < t1; ++t) {
       const unsigned n = min(a.bcnt[t], (unsigned)SLOTS);
       const unsigned c = n >= 2u ? n : 0u;
@@ -277,26 +293,60 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   __threadfence_block();
   constexpr int RW = 1 + SLOTS / 8;  // uint4 per landmark record
   for (int l = tid; l < a.Lp + kCandSpare; l += 1024) {  // (the spare records get empty entry words)
-    const unsigned* cws = reinterpret_cast<const unsigned*>(a.cand + RW * (size_t)l + 1);
-    unsigned short* e = a.erec + (size_t)l * SLOTS;
+    // the landmark's list in one go, then eight candidates at a time: their blob words in one batch, their inverse lists in one
+    // batch (clamped indices instead of branches: a branch per candidate made every lookup a round trip of its own)
+    uint4 lw[SLOTS / 8];
 #pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-      const unsigned t = (cws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-      unsigned ev = 0xFFFFu;
-      if (l < a.L && t != 0xFFFFu && fits) {
-        const unsigned bi = __hip_atomic_load(&a.binfo[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const unsigned n = bi >> 16;
-        if (n >= 2u) {
-          const unsigned short* row = a.brec + (size_t)t * SLOTS;
-          unsigned rank = 0;
+    for (int j = 0; j < SLOTS / 8; ++j) lw[j] = a.cand[RW * (size_t)l + 1 + j];
+    int len = 0;
+    constexpr int BATCH = SLOTS > 8 ? 4 : 8;  // candidates looked up side by side (sixteen-entry lists: four -- their rows are 32 bytes)
+    unsigned cw[SLOTS / 2];
 #pragma unroll
-          for (int j = 0; j < SLOTS; ++j) rank += (unsigned)row[j] < (unsigned)l ? 1u : 0u;
-          ev = kRankMajor ? s_rbase[rank] + (bi & 0xFFFFu) : (bi & 0xFFFFu) + rank;
-        }
-      }
-      e[k] = (unsigned short)ev;
+    for (int j = 0; j < SLOTS / 8; ++j) {
+      cw[4 * j + 0] = lw[j].x;
+      cw[4 * j + 1] = lw[j].y;
+      cw[4 * j + 2] = lw[j].z;
+      cw[4 * j + 3] = lw[j].w;
     }
+#pragma unroll
+    for (int h = 0; h < SLOTS / BATCH; ++h) {
+      unsigned t[BATCH], bi[BATCH];
+      bool on[BATCH];
+      uint4 rows[BATCH][SLOTS / 8];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int kk = BATCH * h + k;
+        t[k] = (cw[kk >> 1] >> (16 * (kk & 1))) & 0xFFFFu;
+        len += t[k] != 0xFFFFu ? 1 : 0;
+        on[k] = l < a.L && t[k] != 0xFFFFu && fits;
+        bi[k] = __hip_atomic_load(&a.binfo[on[k] ? t[k] : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k)
+#pragma unroll
+        for (int j = 0; j < SLOTS / 8; ++j)
+          rows[k][j] = reinterpret_cast<const uint4*>(a.brec)[(size_t)(on[k] ? t[k] : 0u) * (SLOTS / 8) + j];
+      unsigned ev[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        unsigned rank = 0;
+#pragma unroll
+        for (int j = 0; j < SLOTS / 8; ++j) {
+          const unsigned w4[4] = {rows[k][j].x, rows[k][j].y, rows[k][j].z, rows[k][j].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rank += ((w4[q] & 0xFFFFu) < (unsigned)l ? 1u : 0u) + ((w4[q] >> 16) < (unsigned)l ? 1u : 0u);
+        }
+        const unsigned n = bi[k] >> 16;
+        ev[k] = (on[k] && n >= 2u) ? (kRankMajor ? s_rbase[rank < (unsigned)SLOTS ? rank : 0u] + (bi[k] & 0xFFFFu) : (bi[k] & 0xFFFFu) + rank) : 0xFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; k += 2)
+        reinterpret_cast<unsigned*>(a.erec)[(size_t)l * (SLOTS / 2) + (BATCH * h + k) / 2] = (ev[k] & 0xFFFFu) | (ev[k + 1] << 16);
+    }
+    s_len[l] = (unsigned char)len;
+    s_np[l] = (a.npass && l < a.L) ? a.npass[l] : (unsigned char)0;
   }
+  __syncthreads();
   // k_step_pub_big's first look at a candidate: bearing and colour as FLOAT, 16 bytes in one gather instead of 32 in two (the
   // kernel is bound by the texture addresser's gathers, one cache line a cycle: DESIGN.md section 4).  The margins of that
   // look (pub_gatesN<GT>) hold for |bearing| <= 8 and |colour| <= 1000; any other blob -- NaN and infinities included -- gets
@@ -328,16 +378,13 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
         int c = -1;
         if (tid < n_oct) {
           int longest = 0, sum = 0, passes = 0;
-          for (int i = 0; i < kLm; ++i) {
-            const int l = kLm * tid + i;
-            if (l >= a.L) break;
-            const unsigned* cws = reinterpret_cast<const unsigned*>(a.cand + RW * (size_t)l + 1);
-            int n = 0;
 #pragma unroll
-            for (int k = 0; k < SLOTS; ++k) n += ((cws[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) != 0xFFFFu ? 1 : 0;
+          for (int i = 0; i < kLm; ++i) {  // (list lengths and gate passes: left in LDS by the loop above)
+            const int l = kLm * tid + i;
+            const int n = l < a.L ? (int)s_len[l] : 0;
             longest = max(longest, n);
             sum += n;
-            if (a.npass) passes = max(passes, (int)a.npass[l]);
+            passes = max(passes, l < a.L ? (int)s_np[l] : 0);
           }
           // (first by the blobs inside the reference's own gates -- a verdict round each, and a round costs the whole wave its
           // arithmetic --, then by the longest list -- two candidates a gate round)
@@ -350,6 +397,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       if (tid < n_oct) {
         const int c = s_cost[tid];
         int r = 0;
+#pragma unroll 8
         for (int o = 0; o < kPlaces; ++o) r += (s_cost[o] > c || (s_cost[o] == c && o < tid)) ? 1 : 0;
         if constexpr (kBig) {
           // place = chunk 64 + wave 8 + k = the rank itself (a last, partial chunk thus goes to the first waves -- the ones
@@ -364,6 +412,14 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
         }
       }
     }
+  }
+  // the inverse lists have done their work: back to "empty" for the next scan's k_candidates (which appends with atomics)
+  __syncthreads();
+  for (int t = tid; t < a.B; t += 1024) a.bcnt[t] = 0u;
+  {
+    unsigned* bw = reinterpret_cast<unsigned*>(a.brec);
+    const int nw = a.B * (SLOTS / 2);
+    for (int i = tid; i < nw; i += 1024) bw[i] = 0xFFFFFFFFu;
   }
 }
 

@@ -59,7 +59,10 @@ constexpr int kScanBlock = 1024;  // particles per weight-scan block (256 thread
 // device-mapped staging slot) into HBM with a few extra workgroups -- one launch less per step
 void launch_motion(hipStream_t s, DeviceState& d, double v, double w, double dt, const double* z_dev,
                    uint64_t seed, uint64_t draw, int64_t global_offset, void* up_dst_dev = nullptr,
-                   const void* up_src_host_mapped = nullptr, size_t up_bytes = 0);
+                   const void* up_src_host_mapped = nullptr, size_t up_bytes = 0, double* pose_part_dev = nullptr);
+// pose_part_dev != NULL: the launch also leaves, per block of 256 particles, the sums of x, y, sin h, cos h of the moved particles
+// ([4] doubles per block, motion_pose_blocks(P) blocks): k_candidates reduces them to the particles' mean pose
+inline int64_t motion_pose_blocks(int64_t P) { return (P + 255) / 256; }
 void launch_motion_range(hipStream_t s, DeviceState& d, double v, double w, double dt, uint64_t seed, uint64_t draw,
                          int64_t p0, int64_t p1);
 void launch_reset_weights(hipStream_t s, DeviceState& d);
@@ -219,7 +222,7 @@ void launch_assoc_grid(hipStream_t s, DeviceState& d, int B, const BlobGrid& gri
 void launch_candidates(hipStream_t s, DeviceState& d, int B, const double* exact_dev, int64_t ref_particle, uint4* rec_dev,
                        unsigned* over_dev, unsigned* bcnt_dev = nullptr, uint4* brec_dev = nullptr, unsigned* stray_dev = nullptr,
                        int slots = kCandSlots, const double* pose_sums4_dev = nullptr, unsigned char* npass_dev = nullptr,
-                       uint4* far_dev = nullptr);
+                       uint4* far_dev = nullptr, const double* pose_part_dev = nullptr);  // pose_part_dev: the motion launch's per-block sums instead of pose_sums4_dev
 // K2 + K3 in one pass (pk_k_observe_ml.hip, pk_k_step_pub.hip).  (k_step_owner, a barrier-free variant in which every
 // landmark settled its blobs against the rivals named by the two-way lists, was measured at 56 ms against 13 and removed
 // in round 3: DESIGN.md section 4.)

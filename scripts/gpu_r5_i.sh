@@ -1,0 +1,11 @@
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
+for rep in 1 2; do for ps in 0 1; do
+PK_OPT_PUB_SMALL=$ps timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --no-configs4 --no-refscene --no-probes --particles 10000 --landmarks 500 --steps 120 --warmup 10 > gpurun_out/r05/c1_ps$ps.$rep.json 2>/dev/null; echo "rc=$?"
+done; done
+python3 - <<'PY'
+import json
+for rep in (1,2):
+  for ps in (0,1):
+    d = json.load(open('gpurun_out/r05/c1_ps%d.%d.json' % (ps, rep))); r = d['roofline']
+    print('pub_small', ps, 'ms/step %.4f kernel %.4f frac %.3f route %s' % (d['ms_per_step'], r['avg_launch_ms'], r['frac'], r['route']))
+PY

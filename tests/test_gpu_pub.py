@@ -500,7 +500,9 @@ def test_a_landmark_with_a_weaker_bound_than_the_scans_looks_at_its_far_list_its
     assert set(np.nonzero(pruned["flags"])[0]) == {3, 6}, np.nonzero(pruned["flags"])[0]
     same_state(pruned, plain, 1e-11)
     same_state(pruned, gen, 1e-11)
-    assert plain["flagged"] == 0  # (without the pruning the kernel judges every look-alike itself, for every particle)
+    # (without the pruning the kernels judge every look-alike themselves, for every particle: whom they hand on is another matter --
+    # at most the stale ones, where a landmark now has more than four blobs with a positive probability)
+    assert set(np.nonzero(plain["flags"])[0]) <= {3, 6}
 
 
 def test_a_weaker_bound_without_a_matching_far_blob_costs_nothing(lib):
