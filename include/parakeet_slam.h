@@ -158,6 +158,9 @@ int pk_upload_map(pk_filter* f, const double* means, const double* covs, const u
  * (FilterParticle.weight, :288), stored on the device as its natural log. */
 int pk_upload_poses(pk_filter* f, const double* xyhw);
 int pk_download_poses(pk_filter* f, double* xyhw);
+/* One particle's pose and weight -- FastSLAM.particles[i] = p, prkt_core_v2.py:162 -- without touching the other particles'
+ * log-weights (which a download / upload of all poses sends through exp and log: every weight that underflows comes back as 0). */
+int pk_upload_pose(pk_filter* f, int64_t particle, const double xyhw[4]);
 /* The natural logarithms of the particle weights (the quantity the filter keeps: with B >~ 1000
  * blobs per scan the weights themselves underflow float64, prkt_core_v2.py:95,124). */
 int pk_download_log_weights(pk_filter* f, double* logw);

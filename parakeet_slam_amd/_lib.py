@@ -47,6 +47,7 @@ SIGNATURES = {
     "pk_upload_map": (C.c_int, [_h, _dp, _dp, _bp]),
     "pk_upload_poses": (C.c_int, [_h, _dp]),
     "pk_download_poses": (C.c_int, [_h, _dp]),
+    "pk_upload_pose": (C.c_int, [_h, C.c_int64, _dp]),
     "pk_download_landmarks": (C.c_int, [_h, C.c_int64, C.c_int64, _dp, _dp, _ip]),
     "pk_upload_landmarks": (C.c_int, [_h, C.c_int64, C.c_int64, _dp, _dp, _ip]),
     "pk_reset_weights": (C.c_int, [_h]),
@@ -225,6 +226,11 @@ class DeviceFilter(object):
     def upload_poses(self, xyhw):
         a = f64(xyhw, (self.P, 4))
         check(self._lib.pk_upload_poses(self._h, dptr(a)))
+
+    def upload_pose(self, p, xyhw):
+        """One particle's (x, y, heading, weight); the other particles keep their log-weights bit for bit."""
+        a = f64(xyhw, (4,))
+        check(self._lib.pk_upload_pose(self._h, int(p), dptr(a)))
 
     def download_poses(self):
         out = np.empty((self.P, 4), dtype=np.float64)

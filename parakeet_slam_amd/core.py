@@ -583,10 +583,8 @@ class FastSLAM(object):
         """``fs.particles[i] = particle`` (the reference does this at :162): write the pose,
         weight and landmark estimates of a host particle into slot i."""
         with self._lock:
-            poses = self._filter.download_poses()
             x, y, h = _state_pose(particle.state)
-            poses[i] = (x, y, h, float(particle.weight))
-            self._filter.upload_poses(poses)
+            self._filter.upload_pose(i, (x, y, h, float(particle.weight)))  # (the other particles' log-weights stay as they are)
             L = len(self._ids)
             if L and all(k in particle.feature_set for k in self._ids):
                 fs_ = [particle.feature_set[k] for k in self._ids]

@@ -1107,6 +1107,29 @@ int pk_upload_poses(pk_filter* f, const double* xyhw) {
   return PK_OK;
 }
 
+/* One particle's pose and weight (FastSLAM.particles[i] = p, prkt_core_v2.py:162): the other particles' log-weights are not
+ * touched -- a round trip of ALL poses through their linear weights (pk_download_poses / pk_upload_poses) loses every weight that
+ * underflows as exp(log w). */
+int pk_upload_pose(pk_filter* f, int64_t p, const double xyhw[4]) {
+  if (!f || !xyhw) return fail(PK_ERR_INVALID, "pk_upload_pose: NULL argument");
+  if (p < 0 || p >= f->d.P) return fail(PK_ERR_INVALID, "pk_upload_pose: particle %lld of %lld", (long long)p, (long long)f->d.P);
+  for (int i = 0; i < 3; ++i)
+    if (!std::isfinite(xyhw[i])) return fail(PK_ERR_INVALID, "pk_upload_pose: pose component %d is not finite", i);
+  if (!(xyhw[3] >= 0.0)) return fail(PK_ERR_INVALID, "pk_upload_pose: the weight is negative or NaN");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  f->pose_part_ok = false;
+  const double lw = std::log(xyhw[3]);
+  const int c = f->d.cur;
+  PK_HIP(hipMemcpyAsync(f->d.x[c] + p, &xyhw[0], 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->d.y[c] + p, &xyhw[1], 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->d.h[c] + p, &xyhw[2], 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipMemcpyAsync(f->d.logw[c] + p, &lw, 8, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  f->gmax_fused = false;
+  return PK_OK;
+}
+
 int pk_download_poses(pk_filter* f, double* xyhw) {
   if (!f || !xyhw) return fail(PK_ERR_INVALID, "pk_download_poses: NULL argument");
   int rc;

@@ -93,9 +93,7 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
                     conn.send(("ok", sf.download_landmarks(cmd[1], cmd[2])))
                 elif op == "set_particle":
                     _, j, pose, m, c, k = cmd
-                    poses = sf.download_poses()
-                    poses[j] = pose
-                    sf.upload_poses(poses)
+                    sf.upload_pose(j, pose)  # (one particle: the shard's other log-weights are not sent through exp and log)
                     if m is not None:
                         sf.upload_landmarks(j, j + 1, m, c, k)
                     conn.send(("ok", None))

@@ -501,6 +501,10 @@ class ShardedFilter(object):
         self._complete()
         return self.f.upload_poses(xyhw)
 
+    def upload_pose(self, p, xyhw):
+        self._complete()
+        return self.f.upload_pose(p, xyhw)
+
     def upload_landmarks(self, p0, p1, means=None, covs=None, counts=None):
         self._complete()
         out = self.f.upload_landmarks(p0, p1, means, covs, counts)

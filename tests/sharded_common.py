@@ -61,6 +61,11 @@ class OracleShard(object):
         with np.errstate(divide="ignore"):
             self.o.logw = np.log(a[:, 3])
 
+    def upload_pose(self, p, xyhw):
+        self.o.x[p], self.o.y[p], self.o.h[p] = float(xyhw[0]), float(xyhw[1]), float(xyhw[2])
+        with np.errstate(divide="ignore"):
+            self.o.logw[p] = np.log(float(xyhw[3]))
+
     def upload_landmarks(self, p0, p1, means=None, covs=None, counts=None):
         n = p1 - p0
         if means is not None:

@@ -330,3 +330,15 @@ def test_expected_bearing_atan2_within_a_few_ulp_of_numpy(lib):
     assert worst <= 4.0, worst
     z = lib.probe(np.array([-1.0, -1.0, 0.0]), np.array([0.0, 0.0, 73.0, 165.0, 255.0]), cov, np.array([0.1, 73.0, 165.0, 255.0]))["zhat"][0]
     assert z == np.pi / 4  # test_prkt_ros2.py:403-423
+    # NaN in, NaN out: the kernels rely on a NaN state failing every comparison, and v_max / v_min in pk_atan2
+    # drop NaNs -- the NaN is put back by arithmetic (0 * (x + y): not foldable without fast-math, which the build does not use)
+    for fx, fy in ((np.nan, 1.0), (1.0, np.nan), (np.nan, np.nan)):
+        try:
+            z = lib.probe(np.zeros(3), np.array([fx, fy, 10.0, 20.0, 30.0]), cov, np.array([0.1, 10.0, 20.0, 30.0]))["zhat"][0]
+        except Exception:  # (a probe that refuses non-finite input is as good)
+            continue
+        assert np.isnan(z), (fx, fy, z)
+    # signed zeros: dy = -0.0 on the positive x axis is -0.0, as the library's; dx = fx - sx is never -0.0 for finite operands
+    # (a - a is +0 in round-to-nearest), so atan2(+-0, -0) = +-pi -- where pk_atan2 gives +-0 -- cannot come up
+    z = lib.probe(np.array([0.0, 0.0, 0.0]), np.array([2.0, -0.0, 10.0, 20.0, 30.0]), cov, np.array([0.1, 10.0, 20.0, 30.0]))["zhat"][0]
+    assert z == 0.0
