@@ -158,3 +158,61 @@ def test_plan_exchange_covers_every_slot():
             for k in np.nonzero(local_src < 0)[0]:
                 glob[k] = owners[-(local_src[k] + 1)]
             assert np.array_equal(glob, anc[rank * P_local:(rank + 1) * P_local]), (trial, rank)
+
+
+def test_plan_balanced_places_every_child_exactly_once():
+    """sharded.plan_balanced (the readable reference of pk_shard_plan_balanced_dev) on random weights, random placements and world sizes
+    1-8: the new logical indices are a permutation of the filter, a rank keeps min(n, P) of its own children, every record fills free
+    slots of its destination and none travels without a child, the records reach a destination in slot order (what the adoption's
+    binary search over the received headers relies on), and what moves is exactly the ranks' excess."""
+    from parakeet_slam_amd.sharded import balanced_record_ranges, plan_balanced
+
+    rs = np.random.RandomState(1)
+    for trial in range(200):
+        W = int(rs.choice([1, 2, 3, 4, 8]))
+        P = int(rs.choice([1, 2, 5, 50, 300]))
+        Pg = W * P
+        w = np.exp(rs.normal(0, rs.uniform(0.1, 6), Pg))
+        if rs.uniform() < 0.2:  # most particles dead
+            w[rs.uniform(size=Pg) < 0.7] = 0
+            w[rs.randint(Pg)] = 1
+        c = np.cumsum(w)
+        r = c[-1] / Pg
+        t = rs.uniform() * r + np.arange(Pg) * r
+        H = np.concatenate([[0], np.searchsorted(t, c, side="right")])
+        H[-1] = Pg
+        H = np.maximum.accumulate(H)
+        logical = rs.permutation(Pg)
+        cq, nz, (n, m, e, dd, eb, db), pairs = plan_balanced(H, logical, W, P)
+        assert n.sum() == Pg and e.sum() == dd.sum() and np.array_equal(m, np.minimum(n, P))
+        newlog = np.full(Pg, -1)
+        moved = 0
+        for R in range(W):
+            rel = cq[R * P:(R + 1) * P + 1] - cq[R * P]
+            Hl = H[logical[R * P:(R + 1) * P]]
+            alive = np.nonzero(np.diff(rel) > 0)[0]
+            k = np.arange(m[R])
+            a = np.searchsorted(rel[1:], k, side="right")
+            newlog[R * P + k] = Hl[a] + (k - rel[a])
+            for d in range(W):
+                a0, a1 = pairs[R, d]
+                if a1 <= a0:
+                    continue
+                assert d != R
+                _, lo, up, klo = balanced_record_ranges(rel, Hl, alive, a0, a1, P, eb[R], db[d], dd[d], m[d])
+                assert (up > lo).all()  # no record without a child at the destination
+                for a_, b_, k_ in zip(lo, up, klo):
+                    assert m[d] <= a_ < b_ <= P and (newlog[d * P + a_:d * P + b_] == -1).all()
+                    newlog[d * P + a_:d * P + b_] = k_ + np.arange(b_ - a_)
+                    moved += b_ - a_
+        assert np.array_equal(np.sort(newlog), np.arange(Pg)), (trial, W, P)
+        assert moved == e.sum()
+        for d in range(W):  # arrival order = slot order
+            los = []
+            for s_ in range(W):
+                a0, a1 = pairs[s_, d]
+                if a1 > a0:
+                    rel = cq[s_ * P:(s_ + 1) * P + 1] - cq[s_ * P]
+                    alive = np.nonzero(np.diff(rel) > 0)[0]
+                    los += list(balanced_record_ranges(rel, H[logical[s_ * P:(s_ + 1) * P]], alive, a0, a1, P, eb[s_], db[d], dd[d], m[d])[1])
+            assert los == sorted(los)
