@@ -211,6 +211,26 @@ int pk_observe_staged(pk_filter* f, int32_t fresh);
  * No state changes. */
 int pk_associate(pk_filter* f, const double* blobs, int32_t num_blobs, int32_t* ids_out);
 
+/* ---- new landmarks: FilterParticle.add_hypothesis / find_nearest_reading / ray_intersect /
+ * color_distance / add_new_feature / cross_readings / add_orphaned_reading (prkt_core_v2.py:546-746) for every particle on the
+ * device.  The filter's landmarks beyond the first `preset_landmarks` are SPARE slots (upload them with a colour no blob can gate
+ * against).  From then on every maximum-likelihood observe (pk_observe / pk_observe_fresh / pk_step without ids) ends with one
+ * kernel that walks each particle's unmatched blobs in scan order (:92-95): a blob pairs with the particle's nearest stored reading
+ * -- rays crossing, colour distance below pair_threshold; the one change to the reference, whose find_nearest_reading (:579) walks
+ * potential_features where the readings are in hypothesis_set and so never pairs anything -- and becomes a potential feature at
+ * the crossing in the next spare slot (mean colour, identity covariance, count word PK_LANDMARK_POTENTIAL, :656-686); else it is
+ * stored as an orphaned reading (:739-746).  Each particle keeps up to reading_capacity readings (the reference's dict grows
+ * without bound; what does not fit is counted, see below).  pk_resample carries the bookkeeping along with the particles (:243).
+ * Supplied ids and the dense layout are refused while it is on (PK_ERR_STATE). */
+int pk_grow_enable(pk_filter* f, int32_t preset_landmarks, int32_t reading_capacity, double pair_threshold);
+/* The bookkeeping of particles [p0, p1) (any pointer may be NULL): counters[n][4] = readings stored, spare slots in use, next_id
+ * (:298), readings dropped because the ring was full; readings[n][reading_capacity][8] = id, x, y, heading, bearing, r, g, b of each
+ * stored reading (the rows beyond `readings stored` are undefined); slot_ids[n][spare] = the feature id of each spare slot in use
+ * (potential: the reference's -id, promoted: +id). */
+int pk_grow_download(pk_filter* f, int64_t p0, int64_t p1, int32_t* counters, double* readings, int32_t* slot_ids);
+int pk_grow_upload(pk_filter* f, int64_t p0, int64_t p1, const int32_t* counters, const double* readings, const int32_t* slot_ids);
+int pk_grow_shape(const pk_filter* f, int32_t* preset_landmarks, int32_t* spare_slots, int32_t* reading_capacity);
+
 /* FastSLAM.low_variance_resample (prkt_core_v2.py:210-252) with step = u * sum/P, u in
  * [0,1) standing for random.random() (:226).  ancestors_out: NULL or P int64. */
 int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestors_out);

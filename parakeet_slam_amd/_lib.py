@@ -106,6 +106,10 @@ SIGNATURES = {
     "pk_download_sources": (C.c_int, [_h, _ip]),
     "pk_observe_flagged": (C.c_int, [_h, _lp, _lp]),
     "pk_observe_retry_rows": (C.c_int, [_h, _lp, _lp]),
+    "pk_grow_enable": (C.c_int, [_h, C.c_int32, C.c_int32, C.c_double]),
+    "pk_grow_download": (C.c_int, [_h, C.c_int64, C.c_int64, _ip, _dp, _ip]),
+    "pk_grow_upload": (C.c_int, [_h, C.c_int64, C.c_int64, _ip, _dp, _ip]),
+    "pk_grow_shape": (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pk_observe_published": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pk_observe_flags": (C.c_int, [_h, _bp]),
     "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
@@ -436,6 +440,36 @@ class DeviceFilter(object):
         a, b = C.c_int64(), C.c_int64()
         check(self._lib.pk_observe_flagged(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    # ---- new landmarks on the device (pk_grow_enable) ----
+    def grow_enable(self, preset_landmarks, reading_capacity=64, pair_threshold=30.0):
+        check(self._lib.pk_grow_enable(self._h, int(preset_landmarks), int(reading_capacity), float(pair_threshold)))
+
+    def grow_shape(self):
+        """(preset landmarks, spare slots, reading capacity); zeros while the bookkeeping is off."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self._lib.pk_grow_shape(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def grow_download(self, p0=0, p1=None, counters=True, readings=True, slot_ids=True):
+        """(counters (n, 4) int32: readings stored / spare slots in use / next_id / readings dropped,
+        readings (n, R, 8): id, x, y, heading, bearing, r, g, b, slot_ids (n, S) int32); None for what was not asked for."""
+        p1 = self.P if p1 is None else p1
+        _, S, R = self.grow_shape()
+        n = p1 - p0
+        c = np.empty((n, 4), dtype=np.int32) if counters else None
+        r = np.empty((n, R, 8), dtype=np.float64) if readings else None
+        s = np.empty((n, S), dtype=np.int32) if slot_ids else None
+        check(self._lib.pk_grow_download(self._h, int(p0), int(p1), iptr(c), dptr(r), iptr(s)))
+        return c, r, s
+
+    def grow_upload(self, p0, p1, counters=None, readings=None, slot_ids=None):
+        _, S, R = self.grow_shape()
+        n = p1 - p0
+        c = None if counters is None else np.ascontiguousarray(counters, dtype=np.int32).reshape(n, 4)
+        r = None if readings is None else f64(readings, (n, R, 8))
+        s = None if slot_ids is None else np.ascontiguousarray(slot_ids, dtype=np.int32).reshape(n, S)
+        check(self._lib.pk_grow_upload(self._h, int(p0), int(p1), iptr(c), dptr(r), iptr(s)))
 
     def observe_retry_rows(self):
         """(second-chance rows the last scan wanted, rows the next scan will find) -- pk_observe_retry_rows."""

@@ -441,7 +441,11 @@ class FastSLAM(object):
     paired with the nearest stored reading of the particle -- rays crossing, colour distance below ``pair_threshold`` --
     and becomes a potential feature at the crossing, else it is stored as an orphaned reading.  Matching, the EKF
     update, the 0.1 weight of a potential feature and its promotion past update_count 5 run in the device kernels (a
-    flag in the landmark's count word); the per-unmatched-blob bookkeeping is host work per particle, as in the reference.
+    flag in the landmark's count word).  The per-unmatched-blob bookkeeping runs on the device too (bookkeeping="device",
+    the default: one kernel behind every observe, pk_grow_enable; each particle keeps up to ``reading_capacity`` orphaned
+    readings in HBM, ``readings_dropped()`` counts what did not fit) -- nothing per particle crosses to the host in a step;
+    bookkeeping="host" is the per-particle host loop of the reference (and the only one on the dense layout).
+    ``record_ids`` (default: only with bookkeeping="host"): keep ``last_ids`` / ``last_ancestors`` of every step.
     """
 
     EMPTY_COLOUR = 2.0 ** 100  # colour of a spare slot that holds nothing yet: fails every colour gate (:441), exact in float32
@@ -475,7 +479,8 @@ class FastSLAM(object):
         return super(FastSLAM, cls).__new__(cls)
 
     def __init__(self, preset_features=[], num_particles=50, device=0, weight_domain="linear", rng="global",
-                 seed=0, publish_debug=None, new_landmarks=False, spare_landmarks=0, pair_threshold=30.0, devices=None):
+                 seed=0, publish_debug=None, new_landmarks=False, spare_landmarks=0, pair_threshold=30.0, devices=None,
+                 bookkeeping="device", reading_capacity=64, record_ids=None):
         if devices is not None and len(list(devices)) == 1:
             device = list(devices)[0]
         self._lock = threading.RLock()
@@ -502,11 +507,21 @@ class FastSLAM(object):
             means[L:, 2:] = self.EMPTY_COLOUR
             self._filter.upload_map(means, covs, imm)
         P = self.num_particles
-        # per-particle host bookkeeping of the growing mode (follows the particles through every resample)
-        self._hyp = [[] for _ in range(P)]            # orphaned readings: (id, x, y, heading, bearing, r, g, b)  (:739-746)
-        self._next_id = [L + 1] * P                   # FilterParticle.next_id (:298)
-        self._used = [0] * P                          # spare slots in use
-        self._slot_id = [dict() for _ in range(P)]    # spare slot -> feature id
+        if bookkeeping not in ("device", "host"):
+            raise ValueError("bookkeeping must be 'device' or 'host'")
+        # the per-particle bookkeeping of the growing mode (follows the particles through every resample): on the device
+        # (pk_grow_enable; the four views below download it when asked) or in host lists
+        self._nl_device = self._grow and self._spare > 0 and bookkeeping == "device"
+        self._nl_cache = None
+        if self._nl_device:
+            self._filter.grow_enable(L, int(reading_capacity), self._pair_threshold)
+        else:
+            self._nl_host = dict(
+                hyp=[[] for _ in range(P)],          # orphaned readings: (id, x, y, heading, bearing, r, g, b)  (:739-746)
+                next_id=[L + 1] * P,                 # FilterParticle.next_id (:298)
+                used=[0] * P,                        # spare slots in use
+                slot_id=[dict() for _ in range(P)])  # spare slot -> feature id
+        self.record_ids = (not self._nl_device) if record_ids is None else bool(record_ids)
         self.Qt = _default_Qt()
         self._domain = {"linear": _lib.PK_WEIGHTS_LINEAR, "log": _lib.PK_WEIGHTS_LOG}[weight_domain]
         if rng not in ("global", "device"):
@@ -533,6 +548,61 @@ class FastSLAM(object):
     def _touch(self):
         self._gen += 1
         self._pose_cache = None
+        self._nl_cache = None
+
+    def _nl(self):
+        """The new-landmark bookkeeping of every particle as host lists (device mode: one download, kept until the next change)."""
+        if not self._nl_device:
+            return self._nl_host
+        if self._nl_cache is None:
+            cnt, rd, sid = self._filter.grow_download()
+            L0 = self._L0
+            self._nl_cache = dict(
+                hyp=[[(int(r[0]),) + tuple(float(v) for v in r[1:]) for r in rd[i, :cnt[i, 0]]] for i in range(self.num_particles)],
+                next_id=[int(v) for v in cnt[:, 2]], used=[int(v) for v in cnt[:, 1]],
+                slot_id=[{L0 + k: int(sid[i, k]) for k in range(cnt[i, 1])} for i in range(self.num_particles)],
+                dropped=int(cnt[:, 3].sum()))
+        return self._nl_cache
+
+    _hyp = property(lambda self: self._nl()["hyp"])
+    _next_id = property(lambda self: self._nl()["next_id"])
+    _used = property(lambda self: self._nl()["used"])
+    _slot_id = property(lambda self: self._nl()["slot_id"])
+
+    def _nl_particle(self, i):
+        """(next_id, readings, spare slot -> id) of particle i."""
+        if not self._nl_device:
+            h = self._nl_host
+            return h["next_id"][i], h["hyp"][i], dict(h["slot_id"][i])
+        cnt, rd, sid = self._filter.grow_download(i, i + 1)
+        return (int(cnt[0, 2]), [(int(r[0]),) + tuple(float(v) for v in r[1:]) for r in rd[0, :cnt[0, 0]]],
+                {self._L0 + k: int(sid[0, k]) for k in range(cnt[0, 1])})
+
+    def _nl_assign(self, hyp, next_id, used, slot_id):
+        """Replace the whole bookkeeping (load_state)."""
+        if not self._nl_device:
+            self._nl_host = dict(hyp=hyp, next_id=next_id, used=used, slot_id=slot_id)
+            return
+        P = self.num_particles
+        _, S, R = self._filter.grow_shape()
+        cnt = np.zeros((P, 4), dtype=np.int32)
+        rd = np.zeros((P, R, 8))
+        sid = np.zeros((P, S), dtype=np.int32)
+        for i in range(P):
+            cnt[i, :3] = (len(hyp[i]), used[i], next_id[i])
+            if hyp[i]:
+                rd[i, :len(hyp[i])] = np.asarray(hyp[i], dtype=np.float64)
+            for slot, fid in slot_id[i].items():
+                sid[i, slot - self._L0] = fid
+        self._filter.grow_upload(0, P, cnt, rd, sid)
+        self._nl_cache = None
+
+    def readings_dropped(self):
+        """Orphaned readings that found the particle's ring full (bookkeeping="device"; the reference's dict grows without
+        bound): 0 means the device bookkeeping is the reference's."""
+        if not self._nl_device:
+            return 0
+        return int(self._filter.grow_download(readings=False, slot_ids=False)[0][:, 3].sum())
 
     def _poses(self):
         if self._pose_cache is None:
@@ -546,11 +616,10 @@ class FastSLAM(object):
             p.weight = float(w)
             p.Qt = self.Qt
             p._device = self._device
-            p.next_id = self._next_id[i]
+            p.next_id, hyp_i, slot_id = self._nl_particle(i)
             filt, ids, feats, lock = self._filter, self._ids, self._features, self._lock
-            slot_id = dict(self._slot_id[i])
             if self._grow:
-                for rd in self._hyp[i]:
+                for rd in hyp_i:
                     b = Blob()
                     b.bearing = rd[4]
                     b.color.r, b.color.g, b.color.b = rd[5], rd[6], rd[7]
@@ -618,10 +687,13 @@ class FastSLAM(object):
             self._filter.set_measurement_noise(self.Qt)
             # :73 weight = 1 (the reset is fused into the observe kernels: pk_observe_fresh; the motion
             # update in between does not read the weights), :84-124 association + EKF + weights
-            if self._grow and len(blobs):
+            if self._grow and len(blobs) and not self._nl_device:
                 self.last_ids = self._filter.observe(blobs, fresh=True, return_ids=True)
                 self._touch()
                 self._new_landmarks(blobs, self.last_ids)  # :92-95 for every particle's unmatched blobs
+            elif self._nl_device and len(blobs):
+                # :92-95 on the device, behind the association and the updates (k_new_landmarks)
+                self.last_ids = self._filter.observe(blobs, fresh=True, return_ids=self.record_ids)
             else:
                 self._filter.observe(blobs, fresh=True)
             self._touch()
@@ -718,13 +790,14 @@ class FastSLAM(object):
             if self._publish:
                 self._publish_all(self.aged_particles_pub, self._poses())  # :237
             u = _pyrandom.random()  # :226
-            self.last_ancestors = self._filter.resample(u, domain=self._domain, return_ancestors=self._publish or self._grow)
-            if self._grow:
+            host_nl = self._grow and not self._nl_device
+            self.last_ancestors = self._filter.resample(u, domain=self._domain,
+                                                        return_ancestors=self._publish or host_nl or (self._grow and self.record_ids))
+            if host_nl:  # (device mode: pk_resample gathers the bookkeeping with the particles)
                 anc = [int(a) for a in self.last_ancestors]
-                self._hyp = [list(self._hyp[a]) for a in anc]
-                self._next_id = [self._next_id[a] for a in anc]
-                self._used = [self._used[a] for a in anc]
-                self._slot_id = [dict(self._slot_id[a]) for a in anc]
+                h = self._nl_host
+                self._nl_host = dict(hyp=[list(h["hyp"][a]) for a in anc], next_id=[h["next_id"][a] for a in anc],
+                                     used=[h["used"][a] for a in anc], slot_id=[dict(h["slot_id"][a]) for a in anc])
             self._touch()
             if self._publish:
                 self._publish_all(self.resampled_particles_pub, self._poses())  # :242
@@ -747,15 +820,16 @@ class FastSLAM(object):
                 # the new-landmark bookkeeping as plain numeric arrays (a snapshot never needs pickle to load): every
                 # particle's orphaned readings (8 numbers each) back to back with per-particle offsets, the id counters,
                 # and the (particle, slot, id) triples of the spare slots in use
+                nl = self._nl()
                 offs = np.zeros(self.num_particles + 1, dtype=np.int64)
-                offs[1:] = np.cumsum([len(h) for h in self._hyp])
-                flat = [rd for h in self._hyp for rd in h]
+                offs[1:] = np.cumsum([len(h) for h in nl["hyp"]])
+                flat = [rd for h in nl["hyp"] for rd in h]
                 extra = dict(
                     nl_readings=np.asarray(flat, dtype=np.float64).reshape(len(flat), 8),
                     nl_offsets=offs,
-                    nl_next_id=np.asarray(self._next_id, dtype=np.int64),
-                    nl_used=np.asarray(self._used, dtype=np.int64),
-                    nl_slot_id=np.asarray([(i, s, v) for i, d in enumerate(self._slot_id) for s, v in sorted(d.items())],
+                    nl_next_id=np.asarray(nl["next_id"], dtype=np.int64),
+                    nl_used=np.asarray(nl["used"], dtype=np.int64),
+                    nl_slot_id=np.asarray([(i, s, v) for i, d in enumerate(nl["slot_id"]) for s, v in sorted(d.items())],
                                           dtype=np.int64).reshape(-1, 3))
             np.savez_compressed(
                 path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
@@ -785,6 +859,9 @@ class FastSLAM(object):
                 if (np.any(used < 0) or np.any(used > self._spare) or np.any(slot_id[:, 0] < 0) or np.any(slot_id[:, 0] >= P)
                         or np.any(slot_id[:, 1] < self._L0) or np.any(slot_id[:, 1] >= L)):
                     raise ValueError("snapshot: new-landmark bookkeeping names particles / spare slots this filter does not have")
+                if self._nl_device and P and int(np.diff(offs).max()) > self._filter.grow_shape()[2]:
+                    raise ValueError("snapshot: a particle holds %d orphaned readings, this filter keeps %d (reading_capacity)"
+                                     % (int(np.diff(offs).max()), self._filter.grow_shape()[2]))
 
             self._filter.upload_poses(d["poses"])
             if L:
@@ -799,12 +876,11 @@ class FastSLAM(object):
                 def reading(r):  # (id, x, y, heading, bearing, r, g, b): the id is an integer
                     return (int(r[0]),) + tuple(float(v) for v in r[1:])
 
-                self._hyp = [[reading(r) for r in rd[offs[i]:offs[i + 1]]] for i in range(P)]
-                self._next_id = [int(v) for v in d["nl_next_id"]]
-                self._used = [int(v) for v in d["nl_used"]]
-                self._slot_id = [dict() for _ in range(P)]
+                slot_ids = [dict() for _ in range(P)]
                 for i, slot, fid in d["nl_slot_id"]:
-                    self._slot_id[int(i)][int(slot)] = int(fid)
+                    slot_ids[int(i)][int(slot)] = int(fid)
+                self._nl_assign([[reading(r) for r in rd[offs[i]:offs[i + 1]]] for i in range(P)],
+                                [int(v) for v in d["nl_next_id"]], [int(v) for v in d["nl_used"]], slot_ids)
             self._touch()
 
     def close(self):

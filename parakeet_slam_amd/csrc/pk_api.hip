@@ -197,6 +197,8 @@ struct pk_filter {
   double* out4 = nullptr;
   double* pose_part = nullptr;   // [motion_pose_blocks(P)][4]: per-block sums of x, y, sin h, cos h the last whole-filter motion launch left
   bool pose_part_ok = false;     // ... and nothing has touched the poses since
+  GrowState grow{};                 // section 8(f4) on the device (pk_grow_enable): per-particle new-landmark bookkeeping
+  bool grow_on = false;
   int32_t* anc = nullptr;           // P
   unsigned char* slot_tmp = nullptr;  // one slot
   // timing
@@ -985,6 +987,9 @@ int pk_destroy(pk_filter* f) {
   if (f->scan_dev) (void)hipFree(f->scan_dev);
   for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev, (void*)f->far_dev})
     if (q) (void)hipFree(q);
+  for (int i = 0; i < 2; ++i)
+    for (void* q : {(void*)f->grow.hyp[i], (void*)f->grow.cnt[i], (void*)f->grow.slot_id[i]})
+      if (q) (void)hipFree(q);
   for (void* q : {(void*)f->g_totals, (void*)f->g_offsets, (void*)f->hi_dev, (void*)f->gl_clocal, (void*)f->gl_totals, (void*)f->gl_offsets, (void*)f->plan_ticket, (void*)f->idx_dev, (void*)f->srcs_dev, (void*)f->rlohi_dev})
     if (q) (void)hipFree(q);
   for (void* q : {(void*)d.logical[0], (void*)d.logical[1], (void*)f->bal.glogw, (void*)f->bal.clocal, (void*)f->bal.totals, (void*)f->bal.offsets,
@@ -1541,6 +1546,12 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   if (ids)
     for (int b = 0; b < B; ++b)
       if (ids[b] < 0 || ids[b] > L) return fail(PK_ERR_INVALID, "pk_observe: ids[%d] = %d outside 0..%d", b, ids[b], L);
+  // section 8(f4) on the device: the unmatched blobs of every particle go through the new-landmark bookkeeping behind the observe
+  const bool grow = f->grow_on && B > 0;
+  if (grow && ids) return fail(PK_ERR_STATE, "pk_observe: the new-landmark bookkeeping (pk_grow_enable) follows the maximum-likelihood association: no ids");
+  if (grow && f->dense)
+    return fail(PK_ERR_STATE, "pk_observe: the new-landmark bookkeeping (pk_grow_enable) writes the compact landmark layout; this filter "
+                              "is on the dense one (a covariance or Qt that couples position and colour)");
   if (f->dense) return dense_observe(f, blobs, B, ids, ids_out, reset, true);
   ObserveExtras ex;
   ex.reset = reset;
@@ -1599,7 +1610,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   }
   // maximum-likelihood association on the device
   AssocLaunch al;
-  if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al))) return rc;
+  if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr && !grow, &al))) return rc;  // (ids wanted: the association kernel + k_observe)
   ex.gmax_key = ctl_gmax_key(f);
   f->route = al.big ? PK_ROUTE_ML_PUB_BIG
              : al.fused ? PK_ROUTE_ML_FUSED
@@ -1643,6 +1654,11 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   f->src_identity = true;
   f->d.alt = nullptr;  // every map slot was just rewritten from its source: the receive buffer of the last exchange is free
   f->gmax_fused = true;
+  if (grow) {  // :92-95 for every particle, on the ids the association kernel left in HBM (every particle's slot is its own now)
+    Span t(f, PK_T_OBSERVE);
+    launch_new_landmarks(f->stream, f->d, f->grow, f->ids_dev, al.blobs, B);
+    PK_LAUNCH_CHECK("pk_observe (new landmarks)");
+  }
   if (ids_out && B > 0) {
     PK_HIP(hipMemcpyAsync(ids_out, f->ids_dev, (size_t)f->d.P * B * 4, hipMemcpyDeviceToHost, f->stream));
     PK_HIP(hipStreamSynchronize(f->stream));
@@ -1694,6 +1710,7 @@ int pk_staged_takes_regs(pk_filter* f) {
 int pk_observe_staged_range(pk_filter* f, int32_t fresh, int64_t p0, int64_t p1, int32_t first, int32_t last) {
   if (!f) return fail(PK_ERR_INVALID, "pk_observe_staged_range: NULL handle");
   if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "pk_observe_staged_range: bad particle range [%lld, %lld)", (long long)p0, (long long)p1);
+  if (f->grow_on) return fail(PK_ERR_STATE, "pk_observe_staged_range: the new-landmark bookkeeping (pk_grow_enable) runs behind whole observes (pk_observe / pk_observe_staged)");
   int rc;
   if ((rc = use_device(f))) return rc;
   pk_filter::Split& sp = f->split;
@@ -1877,6 +1894,7 @@ int pk_resample(pk_filter* f, double u, int32_t weight_domain, int64_t* ancestor
       launch_ancestors(f->stream, f->clocal, f->totals, f->offsets, f->sum, f->nblocks, d.P, d.P, u, 0, d.P, f->anc, &d);
     }
   }
+  if (f->grow_on) launch_grow_gather(f->stream, f->grow, f->anc, d.P);  // the bookkeeping follows the particles (:243)
   PK_LAUNCH_CHECK("pk_resample");
   f->src_identity = false;
   f->gmax_fused = false;
@@ -1925,7 +1943,7 @@ int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64
   int rc;
   // Throughput mode with ML association: the host half of the scan upload first, then ONE launch
   // for the motion update and the upload of the scan block, then the observe kernels.
-  if (f && !f->dense && !z && !ids && B > 0 && blobs && f->map_loaded && f->upload_kernel && std::isfinite(v) && std::isfinite(w) &&
+  if (f && !f->dense && !f->grow_on && !z && !ids && B > 0 && blobs && f->map_loaded && f->upload_kernel && std::isfinite(v) && std::isfinite(w) &&
       std::isfinite(dt)) {
     bool finite = true;
     for (int i = 0; i < 4 * B && finite; ++i) finite = std::isfinite(blobs[i]);
@@ -1953,6 +1971,84 @@ int pk_step(pk_filter* f, double v, double w, double dt, const double* z, uint64
   if ((rc = pk_motion(f, v, w, dt, z, seed, draw))) return rc;              // :75-77
   if ((rc = observe_impl(f, blobs, B, ids, nullptr, true))) return rc;    // :73 (reset fused) + :82-124
   return pk_resample(f, u, weight_domain, nullptr);                         // :137
+}
+
+// ---- section 8(f4) on the device: the new-landmark bookkeeping (pk_k_grow.hip) -------
+int pk_grow_enable(pk_filter* f, int32_t preset_landmarks, int32_t reading_capacity, double pair_threshold) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_grow_enable: NULL handle");
+  const int L = f->d.lay.L;
+  if (preset_landmarks < 0 || preset_landmarks >= L)
+    return fail(PK_ERR_INVALID, "pk_grow_enable: %d preset landmarks leave no spare slot among the filter's %d", preset_landmarks, L);
+  if (reading_capacity < 1 || reading_capacity > 65536) return fail(PK_ERR_INVALID, "pk_grow_enable: reading_capacity %d outside 1..65536", reading_capacity);
+  if (!(pair_threshold >= 0.0)) return fail(PK_ERR_INVALID, "pk_grow_enable: pair_threshold %g", pair_threshold);
+  if (f->grow_on) return fail(PK_ERR_STATE, "pk_grow_enable: already enabled on this filter");
+  if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_grow_enable: the balanced placement of the sharded filter is active on this filter");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  GrowState& g = f->grow;
+  g.L0 = preset_landmarks;
+  g.S = L - preset_landmarks;
+  g.R = reading_capacity;
+  g.pair_threshold = pair_threshold;
+  g.cur = 0;
+  const size_t P = (size_t)f->d.P;
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = dev_alloc(f, &g.hyp[i], P * g.R * 8))) return rc;
+    if ((rc = dev_alloc(f, &g.cnt[i], P * 4))) return rc;
+    if ((rc = dev_alloc(f, &g.slot_id[i], P * g.S))) return rc;
+  }
+  std::vector<int32_t> c0(P * 4, 0);
+  for (size_t p = 0; p < P; ++p) c0[4 * p + 2] = preset_landmarks + 1;  // FilterParticle.next_id (:298)
+  PK_HIP(hipMemcpyAsync(g.cnt[0], c0.data(), P * 16, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  f->grow_on = true;
+  return PK_OK;
+}
+
+static int grow_range(pk_filter* f, const char* who, int64_t p0, int64_t p1) {
+  if (!f) return fail(PK_ERR_INVALID, "%s: NULL handle", who);
+  if (!f->grow_on) return fail(PK_ERR_STATE, "%s: pk_grow_enable was not called on this filter", who);
+  if (p0 < 0 || p1 < p0 || p1 > f->d.P) return fail(PK_ERR_INVALID, "%s: particles [%lld, %lld) of %lld", who, (long long)p0, (long long)p1, (long long)f->d.P);
+  return use_device(f);
+}
+
+int pk_grow_download(pk_filter* f, int64_t p0, int64_t p1, int32_t* counters, double* readings, int32_t* slot_ids) {
+  int rc;
+  if ((rc = grow_range(f, "pk_grow_download", p0, p1))) return rc;
+  const GrowState& g = f->grow;
+  const size_t n = (size_t)(p1 - p0);
+  if (n == 0) return PK_OK;
+  if (counters) PK_HIP(hipMemcpyAsync(counters, g.cnt[g.cur] + 4 * p0, n * 16, hipMemcpyDeviceToHost, f->stream));
+  if (readings) PK_HIP(hipMemcpyAsync(readings, g.hyp[g.cur] + (size_t)p0 * g.R * 8, n * g.R * 64, hipMemcpyDeviceToHost, f->stream));
+  if (slot_ids) PK_HIP(hipMemcpyAsync(slot_ids, g.slot_id[g.cur] + (size_t)p0 * g.S, n * g.S * 4, hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+int pk_grow_upload(pk_filter* f, int64_t p0, int64_t p1, const int32_t* counters, const double* readings, const int32_t* slot_ids) {
+  int rc;
+  if ((rc = grow_range(f, "pk_grow_upload", p0, p1))) return rc;
+  const GrowState& g = f->grow;
+  const size_t n = (size_t)(p1 - p0);
+  if (n == 0) return PK_OK;
+  if (counters)
+    for (size_t i = 0; i < n; ++i)
+      if (counters[4 * i] < 0 || counters[4 * i] > g.R || counters[4 * i + 1] < 0 || counters[4 * i + 1] > g.S || counters[4 * i + 3] < 0)
+        return fail(PK_ERR_INVALID, "pk_grow_upload: particle %lld: %d readings of %d, %d spare slots of %d in use", (long long)(p0 + (int64_t)i),
+                    counters[4 * i], g.R, counters[4 * i + 1], g.S);
+  if (counters) PK_HIP(hipMemcpyAsync(g.cnt[g.cur] + 4 * p0, counters, n * 16, hipMemcpyHostToDevice, f->stream));
+  if (readings) PK_HIP(hipMemcpyAsync(g.hyp[g.cur] + (size_t)p0 * g.R * 8, readings, n * g.R * 64, hipMemcpyHostToDevice, f->stream));
+  if (slot_ids) PK_HIP(hipMemcpyAsync(g.slot_id[g.cur] + (size_t)p0 * g.S, slot_ids, n * g.S * 4, hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+int pk_grow_shape(const pk_filter* f, int32_t* preset_landmarks, int32_t* spare_slots, int32_t* reading_capacity) {
+  if (!f) return fail(PK_ERR_INVALID, "pk_grow_shape: NULL handle");
+  if (preset_landmarks) *preset_landmarks = f->grow_on ? f->grow.L0 : 0;
+  if (spare_slots) *spare_slots = f->grow_on ? f->grow.S : 0;
+  if (reading_capacity) *reading_capacity = f->grow_on ? f->grow.R : 0;
+  return PK_OK;
 }
 
 // ---- sharded resampling ---------------------------------------

@@ -348,6 +348,18 @@ void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
                       const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode = 0, int64_t span_lo = INT64_MIN, int64_t span_hi = INT64_MAX);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
+// section 8(f4) on the device (pk_k_grow.hip): the per-particle bookkeeping of the new-landmark machinery, double-buffered like the
+// poses (the resample gathers it by ancestors)
+struct GrowState {
+  double* hyp[2] = {nullptr, nullptr};       // [P][R][8] stored readings: id, x, y, heading, bearing, r, g, b
+  int32_t* cnt[2] = {nullptr, nullptr};      // [P][4]: readings stored, spare slots in use, next_id, readings dropped (ring full)
+  int32_t* slot_id[2] = {nullptr, nullptr};  // [P][S] feature id of every spare slot in use
+  int cur = 0;
+  int L0 = 0, S = 0, R = 0;                  // preset landmarks, spare slots, ring capacity
+  double pair_threshold = 0.0;
+};
+void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int32_t* ids_dev, const double* blobs_dev, int B);
+void launch_grow_gather(hipStream_t s, GrowState& g, const int32_t* anc_dev, int64_t P);
 // scan block: pinned (device-mapped) host memory -> HBM by a kernel, in stream order
 void launch_upload(hipStream_t s, void* dst_dev, const void* src_host_mapped, size_t bytes);
 

@@ -1,0 +1,144 @@
+"""GPU: SURVEY section 8 row (f4) at device speed -- the new-landmark bookkeeping of prkt_core_v2.py:546-746 (add_hypothesis,
+find_nearest_reading, ray_intersect, color_distance, add_new_feature, cross_readings, add_orphaned_reading) as ONE kernel behind
+every maximum-likelihood observe (pk_grow_enable, pk_k_grow.hip), its state in HBM and carried through the resample on the device.
+The checker is oracle/fastslam_oracle.py::GrowingOracle, particle by particle."""
+import numpy as np
+import pytest
+
+from oracle.fastslam_oracle import EMPTY_COLOUR, GrowingOracle, synthetic_scan, synthetic_world, truth_step
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(L0, U, seed=123):
+    world, covs = synthetic_world(L0 + U, seed=seed)
+    return world, covs, world[:L0], covs[:L0]
+
+
+def _device_filter(lib, P, known, kcov, spare, thr, R):
+    L0 = len(known)
+    f = lib.DeviceFilter(P, L0 + spare)
+    means = np.zeros((L0 + spare, 5))
+    means[:L0] = known
+    means[L0:, 2:] = EMPTY_COLOUR
+    covs = np.tile(np.identity(5).reshape(25), (L0 + spare, 1))
+    covs[:L0] = kcov.reshape(L0, 25)
+    f.upload_map(means, covs)
+    f.grow_enable(L0, R, thr)
+    return f
+
+
+def _compare(lib, f, o, L0, step):
+    cnt, rd, sid = f.grow_download()
+    assert np.array_equal(cnt[:, 0], [len(h) for h in o.hyp]), "step %d: readings stored" % step
+    assert np.array_equal(cnt[:, 1], o.used), "step %d: spare slots in use" % step
+    assert np.array_equal(cnt[:, 2], o.next_id), "step %d: next_id" % step
+    assert not cnt[:, 3].any(), "step %d: readings dropped" % step
+    for i in range(f.P):
+        if o.hyp[i]:
+            assert np.allclose(rd[i, :len(o.hyp[i])], np.asarray(o.hyp[i]), rtol=1e-12, atol=1e-12), (step, i)
+        assert [int(v) for v in sid[i, :cnt[i, 1]]] == [o.slot_id[i][L0 + k] for k in range(cnt[i, 1])], (step, i)
+    m, c, k = f.download_landmarks()
+    assert np.array_equal((k & lib.PK_LANDMARK_POTENTIAL) != 0, o.f.potential), step
+    assert np.array_equal(k & ~lib.PK_LANDMARK_POTENTIAL, o.f.count), step
+    assert np.allclose(m, o.f.mean, rtol=1e-8, atol=1e-8), step
+    assert np.allclose(c.reshape(o.f.cov.shape), o.f.cov, rtol=1e-8, atol=1e-9), step
+
+
+def _run(lib, P, L0, U, spare, steps, seed, R=64, check_every=1, log_domain=True):
+    thr = 30.0
+    v, w, dt = 0.8, 0.35, 0.5
+    world, covs, known, kcov = _scene(L0, U)
+    f = _device_filter(lib, P, known, kcov, spare, thr, R)
+    o = GrowingOracle(P, known, kcov, spare, thr)
+    rs = np.random.RandomState(seed)
+    pose = (0.0, 0.0, 0.0)
+    created = promoted = 0
+    for s in range(steps):
+        pose = truth_step(pose, v, w, dt)
+        blobs = synthetic_scan(world, pose)
+        z = rs.standard_normal((P, 3))
+        f.motion(v, w, dt, z=z)
+        f.observe(blobs, fresh=True)  # no ids asked for: nothing per particle comes back
+        assert f.observe_route() == "ml_general"  # (the association kernel leaves the ids in HBM for k_new_landmarks)
+        o.f.reset_weights()
+        o.f.motion(v, w, dt, z)
+        o.observe(blobs)
+        assert np.allclose(f.download_log_weights(), o.f.logw, rtol=1e-9, atol=1e-9), s
+        u = float(rs.uniform())
+        anc = f.resample(u, domain=lib.PK_WEIGHTS_LOG, return_ancestors=True)
+        o.gather(anc)
+        if s % check_every == 0 or s == steps - 1:
+            _compare(lib, f, o, L0, s)
+        created = max(created, max(o.used))
+        promoted = max(promoted, int(((o.f.count[:, L0:] > 5) & ~o.f.potential[:, L0:]).sum()))
+    f.close()
+    return created, promoted
+
+
+def test_bookkeeping_kernel_matches_the_oracle_particle_by_particle(lib):
+    created, promoted = _run(lib, P=64, L0=10, U=3, spare=5, steps=9, seed=5)
+    assert created >= 2 and promoted >= 1
+
+
+def test_ten_thousand_particles_grow_their_maps_with_no_per_particle_host_traffic(lib):
+    """P = 10 000.  The step itself moves nothing per particle to the host (observe without ids, the
+    resample's gather on the device); the downloads are the test's own, every third step."""
+    created, promoted = _run(lib, P=10000, L0=12, U=4, spare=6, steps=8, seed=11, check_every=3)
+    assert created >= 3 and promoted >= 1
+
+
+def test_a_full_ring_and_full_spare_slots_are_counted_not_overrun(lib):
+    # two readings per particle and one spare slot: the third unknown landmark's readings find the ring full
+    P, L0, U, spare, thr = 32, 8, 4, 1, 30.0
+    world, covs, known, kcov = _scene(L0, U)
+    f = _device_filter(lib, P, known, kcov, spare, thr, R=2)
+    rs = np.random.RandomState(2)
+    pose = (0.0, 0.0, 0.0)
+    for s in range(4):
+        pose = truth_step(pose, 0.8, 0.35, 0.5)
+        f.motion(0.8, 0.35, 0.5, z=rs.standard_normal((P, 3)))
+        f.observe(synthetic_scan(world, pose), fresh=True)
+        f.resample(float(rs.uniform()), domain=lib.PK_WEIGHTS_LOG)
+    cnt, rd, sid = f.grow_download()
+    assert (cnt[:, 0] <= 2).all() and (cnt[:, 1] <= 1).all()
+    assert cnt[:, 3].min() > 0, "the dropped readings were not counted"
+    # every blob of every scan got an id, stored or not (:564 / :746)
+    assert (cnt[:, 2] > L0 + 1 + 2).all()
+    f.close()
+
+
+def test_refused_where_it_cannot_follow(lib):
+    world, covs, known, kcov = _scene(6, 2)
+    f = _device_filter(lib, 16, known, kcov, 3, 30.0, 8)
+    blobs = synthetic_scan(world, (0.0, 0.0, 0.0))
+    with pytest.raises(lib.PkError, match="no ids"):
+        f.observe(blobs, ids=np.arange(1, 9) % 7)
+    with pytest.raises(lib.PkError, match="already enabled"):
+        f.grow_enable(6, 8, 30.0)
+    f.close()
+    g = lib.DeviceFilter(4, 5)
+    with pytest.raises(lib.PkError, match="no spare slot"):
+        g.grow_enable(5, 8, 30.0)
+    with pytest.raises(lib.PkError, match="pk_grow_enable was not called"):
+        g.grow_download()
+    g.close()
+
+
+def test_upload_round_trip(lib):
+    world, covs, known, kcov = _scene(6, 2)
+    f = _device_filter(lib, 8, known, kcov, 3, 30.0, 4)
+    rs = np.random.RandomState(0)
+    cnt = np.stack([rs.randint(0, 5, 8), rs.randint(0, 4, 8), rs.randint(7, 30, 8), np.zeros(8, dtype=np.int64)], axis=1).astype(np.int32)
+    rd = rs.normal(size=(8, 4, 8))
+    sid = rs.randint(7, 30, size=(8, 3)).astype(np.int32)
+    f.grow_upload(0, 8, cnt, rd, sid)
+    c2, r2, s2 = f.grow_download()
+    assert np.array_equal(c2, cnt) and np.array_equal(r2, rd) and np.array_equal(s2, sid)
+    f.grow_upload(2, 5, cnt[:3], None, None)
+    assert np.array_equal(f.grow_download(2, 5)[0], cnt[:3])
+    bad = cnt.copy()
+    bad[3, 0] = 5
+    with pytest.raises(lib.PkError, match="readings of"):
+        f.grow_upload(0, 8, bad, None, None)
+    f.close()

@@ -88,7 +88,8 @@ class _View(object):
         self.last_sensor_reading.observes = obs
 
 
-def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
+@pytest.mark.parametrize("bookkeeping", ["device", "host"])
+def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib, bookkeeping):
     import random
 
     import parakeet_slam_amd as pk
@@ -102,7 +103,9 @@ def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
     random.seed(5)
     pk.msgs.Time.set_now(0.0)
     fs = pk.FastSLAM([pk.Feature(mean=m.copy(), covar=c.copy()) for m, c in zip(known, kcov)], num_particles=P,
-                     weight_domain="log", new_landmarks=True, spare_landmarks=spare, pair_threshold=thr)
+                     weight_domain="log", new_landmarks=True, spare_landmarks=spare, pair_threshold=thr, bookkeeping=bookkeeping,
+                     record_ids=True)
+    assert fs._nl_device == (bookkeeping == "device")
     tw = pk.msgs.Twist()
     tw.linear.x, tw.angular.z = v, w
     fs.last_control = tw
@@ -128,7 +131,7 @@ def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
         assert np.array_equal((k & lib.PK_LANDMARK_POTENTIAL) != 0, o.f.potential), s
         assert np.array_equal(k & ~lib.PK_LANDMARK_POTENTIAL, o.f.count), s
         assert np.allclose(m, o.f.mean, rtol=1e-9, atol=1e-9), s
-        assert fs._next_id == o.next_id and fs._used == o.used
+        assert fs._next_id == o.next_id and fs._used == o.used and fs.readings_dropped() == 0
         assert [len(h) for h in fs._hyp] == [len(h) for h in o.hyp]
         created = max(created, max(o.used))
         promoted = max(promoted, int(((o.f.count[:, L0:] > 5) & ~o.f.potential[:, L0:]).sum()))
@@ -153,7 +156,7 @@ def test_unknown_landmarks_are_triangulated_tracked_and_promoted(lib):
     with np.load(path, allow_pickle=False) as snap:  # plain numeric arrays: loading a snapshot never needs pickle
         assert all(snap[k].dtype != object for k in snap.files) and "nl_readings" in snap.files
     fs2 = pk.FastSLAM([pk.Feature(mean=m.copy(), covar=c.copy()) for m, c in zip(known, kcov)], num_particles=P,
-                      weight_domain="log", new_landmarks=True, spare_landmarks=spare, pair_threshold=thr)
+                      weight_domain="log", new_landmarks=True, spare_landmarks=spare, pair_threshold=thr, bookkeeping=bookkeeping)
     fs2.load_state(path)
     for xa, xb in zip(fs._filter.download_landmarks(), fs2._filter.download_landmarks()):
         assert np.array_equal(xa, xb)
