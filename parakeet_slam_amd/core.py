@@ -387,6 +387,78 @@ class FilterParticle(object):
         self.next_id += 1
 
 
+
+# ----------------------------------------------------------------------------- new-landmark bookkeeping: arrays <-> lists
+def _nl_unpack(cnt, rd, sid, L0):
+    """pk_grow_download's arrays of n particles as the host lists of the growing mode."""
+    n = cnt.shape[0]
+    return dict(
+        hyp=[[(int(r[0]),) + tuple(float(v) for v in r[1:]) for r in rd[i, :cnt[i, 0]]] for i in range(n)],
+        next_id=[int(v) for v in cnt[:, 2]], used=[int(v) for v in cnt[:, 1]],
+        slot_id=[{L0 + k: int(sid[i, k]) for k in range(cnt[i, 1])} for i in range(n)],
+        dropped=int(cnt[:, 3].sum()))
+
+
+def _nl_pack(hyp, next_id, used, slot_id, L0, S, R):
+    """... and back: (counters (n, 4), readings (n, R, 8), slot ids (n, S)) for pk_grow_upload."""
+    n = len(hyp)
+    cnt = np.zeros((n, 4), dtype=np.int32)
+    rd = np.zeros((n, R, 8))
+    sid = np.zeros((n, S), dtype=np.int32)
+    for i in range(n):
+        cnt[i, :3] = (len(hyp[i]), used[i], next_id[i])
+        if hyp[i]:
+            rd[i, :len(hyp[i])] = np.asarray(hyp[i], dtype=np.float64)
+        for slot, fid in slot_id[i].items():
+            sid[i, slot - L0] = fid
+    return cnt, rd, sid
+
+
+def _nl_snapshot(nl):
+    """The bookkeeping as plain numeric arrays (a snapshot never needs pickle to load): every particle's orphaned readings
+    (8 numbers each) back to back with per-particle offsets, the id counters, and the (particle, slot, id) triples of the
+    spare slots in use."""
+    offs = np.zeros(len(nl["hyp"]) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(h) for h in nl["hyp"]])
+    flat = [rd for h in nl["hyp"] for rd in h]
+    return dict(
+        nl_readings=np.asarray(flat, dtype=np.float64).reshape(len(flat), 8),
+        nl_offsets=offs,
+        nl_next_id=np.asarray(nl["next_id"], dtype=np.int64),
+        nl_used=np.asarray(nl["used"], dtype=np.int64),
+        nl_slot_id=np.asarray([(i, s, v) for i, d in enumerate(nl["slot_id"]) for s, v in sorted(d.items())],
+                              dtype=np.int64).reshape(-1, 3))
+
+
+def _nl_check_snapshot(d, P, L0, L, spare, ring=None):
+    """Raises ValueError unless d's nl_* arrays fit a filter of P particles, landmarks [L0, L) spare, rings of `ring` readings."""
+    offs, rd = d["nl_offsets"], d["nl_readings"]
+    used, slot_id = d["nl_used"], d["nl_slot_id"]
+    if (offs.shape != (P + 1,) or offs[0] != 0 or np.any(np.diff(offs) < 0) or rd.shape != (int(offs[-1]), 8)
+            or d["nl_next_id"].shape != (P,) or used.shape != (P,) or slot_id.ndim != 2 or slot_id.shape[1] != 3):
+        raise ValueError("snapshot: malformed new-landmark bookkeeping")
+    if (np.any(used < 0) or np.any(used > spare) or np.any(slot_id[:, 0] < 0) or np.any(slot_id[:, 0] >= P)
+            or np.any(slot_id[:, 1] < L0) or np.any(slot_id[:, 1] >= L)):
+        raise ValueError("snapshot: new-landmark bookkeeping names particles / spare slots this filter does not have")
+    if ring is not None and P and int(np.diff(offs).max()) > ring:
+        raise ValueError("snapshot: a particle holds %d orphaned readings, this filter keeps %d (reading_capacity)"
+                         % (int(np.diff(offs).max()), ring))
+
+
+def _nl_restore(d, P):
+    """(hyp, next_id, used, slot_id) lists from a checked snapshot."""
+    offs, rd = d["nl_offsets"], d["nl_readings"]
+
+    def reading(r):  # (id, x, y, heading, bearing, r, g, b): the id is an integer
+        return (int(r[0]),) + tuple(float(v) for v in r[1:])
+
+    slot_ids = [dict() for _ in range(P)]
+    for i, slot, fid in d["nl_slot_id"]:
+        slot_ids[int(i)][int(slot)] = int(fid)
+    return ([[reading(r) for r in rd[offs[i]:offs[i + 1]]] for i in range(P)], [int(v) for v in d["nl_next_id"]],
+            [int(v) for v in d["nl_used"]], slot_ids)
+
+
 # =============================================================================
 class _ParticleList(list):
     """``FastSLAM.particles``: list-like view of the particles held in HBM."""
@@ -466,14 +538,16 @@ class FastSLAM(object):
         if devices is not None and len(list(devices)) > 1:
             from .multi import ShardedFastSLAM
 
-            if a["new_landmarks"] or a["spare_landmarks"]:
-                raise ValueError("FastSLAM(devices=[...]): new_landmarks / spare_landmarks are not supported on several GPUs "
-                                 "(the per-particle bookkeeping of prkt_core_v2.py:546-746 lives on the single-GPU facade)")
+            if a["new_landmarks"] and a["bookkeeping"] != "device":
+                raise ValueError("FastSLAM(devices=[...]): the new-landmark bookkeeping of several GPUs lives on the devices "
+                                 "(bookkeeping='device'): host lists cannot follow a particle from one GPU to another")
             if a["device"] not in (0, list(devices)[0]):
                 raise ValueError("FastSLAM: give either device= or devices=, not both")
             return ShardedFastSLAM(a["preset_features"], num_particles=a["num_particles"], devices=list(devices),
                                    weight_domain=a["weight_domain"], rng=a["rng"], seed=a["seed"],
-                                   publish_debug=a["publish_debug"], **extra)
+                                   publish_debug=a["publish_debug"], new_landmarks=a["new_landmarks"],
+                                   spare_landmarks=a["spare_landmarks"], pair_threshold=a["pair_threshold"],
+                                   reading_capacity=a["reading_capacity"], **extra)
         if extra:
             raise TypeError("FastSLAM: %s only apply with devices=[...] naming several GPUs" % ", ".join(sorted(extra)))
         return super(FastSLAM, cls).__new__(cls)
@@ -555,13 +629,7 @@ class FastSLAM(object):
         if not self._nl_device:
             return self._nl_host
         if self._nl_cache is None:
-            cnt, rd, sid = self._filter.grow_download()
-            L0 = self._L0
-            self._nl_cache = dict(
-                hyp=[[(int(r[0]),) + tuple(float(v) for v in r[1:]) for r in rd[i, :cnt[i, 0]]] for i in range(self.num_particles)],
-                next_id=[int(v) for v in cnt[:, 2]], used=[int(v) for v in cnt[:, 1]],
-                slot_id=[{L0 + k: int(sid[i, k]) for k in range(cnt[i, 1])} for i in range(self.num_particles)],
-                dropped=int(cnt[:, 3].sum()))
+            self._nl_cache = _nl_unpack(*self._filter.grow_download(), L0=self._L0)
         return self._nl_cache
 
     _hyp = property(lambda self: self._nl()["hyp"])
@@ -574,9 +642,8 @@ class FastSLAM(object):
         if not self._nl_device:
             h = self._nl_host
             return h["next_id"][i], h["hyp"][i], dict(h["slot_id"][i])
-        cnt, rd, sid = self._filter.grow_download(i, i + 1)
-        return (int(cnt[0, 2]), [(int(r[0]),) + tuple(float(v) for v in r[1:]) for r in rd[0, :cnt[0, 0]]],
-                {self._L0 + k: int(sid[0, k]) for k in range(cnt[0, 1])})
+        one = _nl_unpack(*self._filter.grow_download(i, i + 1), L0=self._L0)
+        return one["next_id"][0], one["hyp"][0], one["slot_id"][0]
 
     def _nl_assign(self, hyp, next_id, used, slot_id):
         """Replace the whole bookkeeping (load_state)."""
@@ -585,15 +652,7 @@ class FastSLAM(object):
             return
         P = self.num_particles
         _, S, R = self._filter.grow_shape()
-        cnt = np.zeros((P, 4), dtype=np.int32)
-        rd = np.zeros((P, R, 8))
-        sid = np.zeros((P, S), dtype=np.int32)
-        for i in range(P):
-            cnt[i, :3] = (len(hyp[i]), used[i], next_id[i])
-            if hyp[i]:
-                rd[i, :len(hyp[i])] = np.asarray(hyp[i], dtype=np.float64)
-            for slot, fid in slot_id[i].items():
-                sid[i, slot - self._L0] = fid
+        cnt, rd, sid = _nl_pack(hyp, next_id, used, slot_id, self._L0, S, R)
         self._filter.grow_upload(0, P, cnt, rd, sid)
         self._nl_cache = None
 
@@ -817,20 +876,7 @@ class FastSLAM(object):
             m, c, k = self._filter.download_landmarks()
             extra = {}
             if self._grow:
-                # the new-landmark bookkeeping as plain numeric arrays (a snapshot never needs pickle to load): every
-                # particle's orphaned readings (8 numbers each) back to back with per-particle offsets, the id counters,
-                # and the (particle, slot, id) triples of the spare slots in use
-                nl = self._nl()
-                offs = np.zeros(self.num_particles + 1, dtype=np.int64)
-                offs[1:] = np.cumsum([len(h) for h in nl["hyp"]])
-                flat = [rd for h in nl["hyp"] for rd in h]
-                extra = dict(
-                    nl_readings=np.asarray(flat, dtype=np.float64).reshape(len(flat), 8),
-                    nl_offsets=offs,
-                    nl_next_id=np.asarray(nl["next_id"], dtype=np.int64),
-                    nl_used=np.asarray(nl["used"], dtype=np.int64),
-                    nl_slot_id=np.asarray([(i, s, v) for i, d in enumerate(nl["slot_id"]) for s, v in sorted(d.items())],
-                                          dtype=np.int64).reshape(-1, 3))
+                extra = _nl_snapshot(self._nl())
             np.savez_compressed(
                 path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
                 immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),
@@ -851,17 +897,7 @@ class FastSLAM(object):
                                  % ("; it was written in the old pickled format" if "new_landmarks" in d.files else ""))
             have_nl = "nl_offsets" in d.files and self._grow
             if have_nl:  # everything is checked before anything is assigned
-                offs, rd = d["nl_offsets"], d["nl_readings"]
-                used, slot_id = d["nl_used"], d["nl_slot_id"]
-                if (offs.shape != (P + 1,) or offs[0] != 0 or np.any(np.diff(offs) < 0) or rd.shape != (int(offs[-1]), 8)
-                        or d["nl_next_id"].shape != (P,) or used.shape != (P,) or slot_id.ndim != 2 or slot_id.shape[1] != 3):
-                    raise ValueError("snapshot: malformed new-landmark bookkeeping")
-                if (np.any(used < 0) or np.any(used > self._spare) or np.any(slot_id[:, 0] < 0) or np.any(slot_id[:, 0] >= P)
-                        or np.any(slot_id[:, 1] < self._L0) or np.any(slot_id[:, 1] >= L)):
-                    raise ValueError("snapshot: new-landmark bookkeeping names particles / spare slots this filter does not have")
-                if self._nl_device and P and int(np.diff(offs).max()) > self._filter.grow_shape()[2]:
-                    raise ValueError("snapshot: a particle holds %d orphaned readings, this filter keeps %d (reading_capacity)"
-                                     % (int(np.diff(offs).max()), self._filter.grow_shape()[2]))
+                _nl_check_snapshot(d, P, self._L0, L, self._spare, self._filter.grow_shape()[2] if self._nl_device else None)
 
             self._filter.upload_poses(d["poses"])
             if L:
@@ -871,16 +907,7 @@ class FastSLAM(object):
             self.last_control.angular.z = float(d["last_control"][1])
             self._draw = int(d["draw"])
             if have_nl:
-                offs, rd = d["nl_offsets"], d["nl_readings"]
-
-                def reading(r):  # (id, x, y, heading, bearing, r, g, b): the id is an integer
-                    return (int(r[0]),) + tuple(float(v) for v in r[1:])
-
-                slot_ids = [dict() for _ in range(P)]
-                for i, slot, fid in d["nl_slot_id"]:
-                    slot_ids[int(i)][int(slot)] = int(fid)
-                self._nl_assign([[reading(r) for r in rd[offs[i]:offs[i + 1]]] for i in range(P)],
-                                [int(v) for v in d["nl_next_id"]], [int(v) for v in d["nl_used"]], slot_ids)
+                self._nl_assign(*_nl_restore(d, P))
             self._touch()
 
     def close(self):

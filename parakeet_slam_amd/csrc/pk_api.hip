@@ -1703,7 +1703,7 @@ int pk_observe_staged(pk_filter* f, int32_t fresh) {
 }
 
 int pk_staged_takes_regs(pk_filter* f) {
-  if (!f || f->dense || !f->staged.valid || !f->staged.use_grid) return 0;
+  if (!f || f->dense || f->grow_on || !f->staged.valid || !f->staged.use_grid) return 0;  // (the bookkeeping wants the ids in HBM: the general route)
   return regs_route_taken(f, f->staged.g, f->staged.B, f->staged.n9) ? 1 : 0;
 }
 
@@ -1982,7 +1982,6 @@ int pk_grow_enable(pk_filter* f, int32_t preset_landmarks, int32_t reading_capac
   if (reading_capacity < 1 || reading_capacity > 65536) return fail(PK_ERR_INVALID, "pk_grow_enable: reading_capacity %d outside 1..65536", reading_capacity);
   if (!(pair_threshold >= 0.0)) return fail(PK_ERR_INVALID, "pk_grow_enable: pair_threshold %g", pair_threshold);
   if (f->grow_on) return fail(PK_ERR_STATE, "pk_grow_enable: already enabled on this filter");
-  if (f->d.logical[0]) return fail(PK_ERR_STATE, "pk_grow_enable: the balanced placement of the sharded filter is active on this filter");
   int rc;
   if ((rc = use_device(f))) return rc;
   GrowState& g = f->grow;
@@ -2114,7 +2113,9 @@ int pk_shard_offspring(pk_filter* f, const double* global_totals, int64_t n_glob
   return PK_OK;
 }
 
-int64_t pk_particle_bytes(const pk_filter* f) { return f ? (int64_t)(f->d.lay.slot_bytes + kPoseRecordBytes) : -1; }
+// one particle in the sharded exchange: header | map slot | the new-landmark bookkeeping when it is on (pk_grow_enable)
+static size_t record_stride(const pk_filter* f) { return kPoseRecordBytes + f->d.lay.slot_bytes + (f->grow_on ? grow_tail_bytes(f->grow) : 0); }
+int64_t pk_particle_bytes(const pk_filter* f) { return f ? (int64_t)record_stride(f) : -1; }
 
 int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* dev_buf) {
   if (!f || n < 0 || (n > 0 && (!local_idx || !dev_buf))) return fail(PK_ERR_INVALID, "pk_pack_particles: bad argument");
@@ -2280,6 +2281,7 @@ int pk_shard_download_offspring(pk_filter* f, int64_t* slot_hi) {
 }
 
 int pk_shard_pack_dev(pk_filter* f, const int64_t* ranges, int32_t world, int32_t rank, void* dev_buf) {
+  if (f && f->grow_on) return fail(PK_ERR_STATE, "pk_shard_pack_dev: the new-landmark bookkeeping (pk_grow_enable) travels with the balanced placement only (pk_shard_*_balanced_dev)");
   if (!f || !ranges || world < 1 || rank < 0 || rank >= world) return fail(PK_ERR_INVALID, "pk_shard_pack_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_pack_dev: call pk_shard_plan_dev first");
   int rc;
@@ -2301,6 +2303,7 @@ int pk_shard_pack_dev(pk_filter* f, const int64_t* ranges, int32_t world, int32_
 }
 
 int pk_shard_pack_slots_dev(pk_filter* f, int64_t j0, int64_t j1, int64_t slot_lo, int64_t slot_hi, void* dev_buf) {
+  if (f && f->grow_on) return fail(PK_ERR_STATE, "pk_shard_pack_slots_dev: the new-landmark bookkeeping (pk_grow_enable) travels with the balanced placement only (pk_shard_*_balanced_dev)");
   if (!f || j0 < 0 || j1 < j0 || j1 > f->d.P || slot_hi < slot_lo) return fail(PK_ERR_INVALID, "pk_shard_pack_slots_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_pack_slots_dev: call pk_shard_plan_dev first");
   if (j1 > j0 && !dev_buf) return fail(PK_ERR_INVALID, "pk_shard_pack_slots_dev: NULL buffer");
@@ -2313,6 +2316,7 @@ int pk_shard_pack_slots_dev(pk_filter* f, int64_t j0, int64_t j1, int64_t slot_l
 }
 
 int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
+  if (f && f->grow_on) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: the new-landmark bookkeeping (pk_grow_enable) travels with the balanced placement only (pk_shard_*_balanced_dev)");
   if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_dev: call pk_shard_plan_dev first");
@@ -2340,6 +2344,7 @@ int pk_shard_adopt_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t
 }
 
 int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
+  if (f && f->grow_on) return fail(PK_ERR_STATE, "pk_shard_adopt_local_dev: the new-landmark bookkeeping (pk_grow_enable) travels with the balanced placement only (pk_shard_*_balanced_dev)");
   if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || rank < 0) return fail(PK_ERR_INVALID, "pk_shard_adopt_local_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_local_dev: call pk_shard_plan_dev first");
@@ -2361,6 +2366,7 @@ int pk_shard_adopt_local_dev(pk_filter* f, int32_t rank) {
 }
 
 int pk_shard_adopt_remote_dev(pk_filter* f, int32_t rank, const void* dev_recv, int64_t n_received) {
+  if (f && f->grow_on) return fail(PK_ERR_STATE, "pk_shard_adopt_remote_dev: the new-landmark bookkeeping (pk_grow_enable) travels with the balanced placement only (pk_shard_*_balanced_dev)");
   if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || rank < 0 || n_received < 0 || (n_received > 0 && !dev_recv)) return fail(PK_ERR_INVALID, "pk_shard_adopt_remote_dev: bad argument");
   if (!f->hi_dev) return fail(PK_ERR_STATE, "pk_shard_adopt_remote_dev: call pk_shard_plan_dev first");
@@ -2532,7 +2538,7 @@ int pk_shard_pack_balanced_dev(pk_filter* f, const int64_t* table, int32_t world
   if ((rc = balanced_row_check(table, world, P, "pk_shard_pack_balanced_dev"))) return rc;
   if ((rc = use_device(f))) return rc;
   const int row = 2 * world + 4;
-  const size_t stride = kPoseRecordBytes + f->d.lay.slot_bytes;
+  const size_t stride = record_stride(f);
   const int64_t ebase_s = table[(size_t)rank * row + 2 * world + 2];
   int64_t rec = 0;
   Span t(f, PK_T_RESAMPLE);
@@ -2543,7 +2549,7 @@ int pk_shard_pack_balanced_dev(pk_filter* f, const int64_t* table, int32_t world
     if (!dev_buf) return fail(PK_ERR_INVALID, "pk_shard_pack_balanced_dev: NULL buffer");
     const int64_t m_d = table[(size_t)d * row + 2 * world + 1], dbase_d = table[(size_t)d * row + 2 * world + 3];
     launch_bal_pack(f->stream, f->d, f->bal, a0, a1 - a0, ebase_s, dbase_d, P - m_d, m_d,
-                    static_cast<unsigned char*>(dev_buf) + (size_t)rec * stride);
+                    static_cast<unsigned char*>(dev_buf) + (size_t)rec * stride, stride, f->grow_on ? &f->grow : nullptr);
     rec += a1 - a0;
   }
   PK_LAUNCH_CHECK("pk_shard_pack_balanced_dev");
@@ -2557,6 +2563,7 @@ int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t worl
       (n_received > 0 && !dev_recv))
     return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: bad argument");
   if (!f->bal.rel || !f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_adopt_balanced_dev: call pk_shard_plan_balanced_dev first");
+  if (f->grow_on && mode != 0) return fail(PK_ERR_STATE, "pk_shard_adopt_balanced_dev: the new-landmark bookkeeping (pk_grow_enable) is adopted whole (mode 0)");
   int rc;
   const int64_t P = f->d.P;
   if ((rc = balanced_row_check(table, world, P, "pk_shard_adopt_balanced_dev"))) return rc;
@@ -2587,7 +2594,11 @@ int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t worl
     f->rlohi_cap = (3 * n_received + 3 * n_received / 4) / 2;
   }
   Span t(f, PK_T_RESAMPLE);
-  launch_bal_adopt(f->stream, f->d, f->bal, m, static_cast<const unsigned char*>(dev_recv), n_received, f->rlohi_dev, mode);
+  const size_t stride = record_stride(f);
+  launch_bal_adopt(f->stream, f->d, f->bal, m, static_cast<const unsigned char*>(dev_recv), n_received, f->rlohi_dev, mode, stride,
+                   f->grow_on ? f->anc : nullptr);
+  if (f->grow_on)  // the bookkeeping follows: own children from this filter's arrays, adopted ones from their records' tails
+    launch_grow_gather(f->stream, f->grow, f->anc, P, static_cast<const unsigned char*>(dev_recv), stride, kPoseRecordBytes + f->d.lay.slot_bytes);
   PK_LAUNCH_CHECK("pk_shard_adopt_balanced_dev");
   f->src_identity = false;
   f->gmax_fused = false;

@@ -131,25 +131,39 @@ void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int
                      blobs_dev, B, d.map[d.mcur], d.lay.slot_bytes, d.lay.count_off, d.lay.Lp, d.P);
 }
 
-// the bookkeeping follows the particles through the resample (:243: the deepcopy of the whole particle): slot k takes ancestor anc[k]'s
-__global__ void __launch_bounds__(256) k_grow_gather(GrowState g, const int32_t* __restrict__ anc, int64_t P) {
+// the bookkeeping follows the particles through the resample (:243: the deepcopy of the whole particle): slot k takes ancestor
+// anc[k]'s -- a particle of this filter, or (sharded filter, anc < 0) the tail of received record -anc - 1
+__global__ void __launch_bounds__(64) k_grow_gather(GrowState g, const int32_t* __restrict__ anc, int64_t P,
+                                                    const unsigned char* __restrict__ buf, size_t stride, size_t tail_off) {
   const int64_t k = blockIdx.x;
   if (k >= P) return;
   const int c = g.cur, n = c ^ 1;
   const int64_t a = anc[k];
-  const int32_t* sc = g.cnt[c] + 4 * a;
-  const int m = sc[0], used = sc[1];
-  if (threadIdx.x < 4) g.cnt[n][4 * k + threadIdx.x] = sc[threadIdx.x];
-  const double* sr = g.hyp[c] + (size_t)a * g.R * 8;
+  const int32_t *sc, *ss;
+  const double* sr;
+  if (a >= 0) {
+    sc = g.cnt[c] + 4 * a;
+    sr = g.hyp[c] + (size_t)a * g.R * 8;
+    ss = g.slot_id[c] + (size_t)a * g.S;
+  } else {
+    const unsigned char* tail = buf + (size_t)(-(a + 1)) * stride + tail_off;
+    sc = reinterpret_cast<const int32_t*>(tail);
+    ss = sc + 4;
+    sr = reinterpret_cast<const double*>(tail + grow_tail_readings_off(g.S));
+  }
+  int m = sc[0], used = sc[1];
+  m = m < 0 ? 0 : m > g.R ? g.R : m;  // (a record is foreign data: never past the ring)
+  used = used < 0 ? 0 : used > g.S ? g.S : used;
+  if (threadIdx.x < 4) g.cnt[n][4 * k + threadIdx.x] = threadIdx.x == 0 ? m : threadIdx.x == 1 ? used : sc[threadIdx.x];
   double* dr = g.hyp[n] + (size_t)k * g.R * 8;
   for (int i = threadIdx.x; i < 8 * m; i += blockDim.x) dr[i] = sr[i];
-  const int32_t* ss = g.slot_id[c] + (size_t)a * g.S;
   int32_t* ds = g.slot_id[n] + (size_t)k * g.S;
   for (int i = threadIdx.x; i < used; i += blockDim.x) ds[i] = ss[i];
 }
-void launch_grow_gather(hipStream_t s, GrowState& g, const int32_t* anc_dev, int64_t P) {
+void launch_grow_gather(hipStream_t s, GrowState& g, const int32_t* anc_dev, int64_t P, const unsigned char* buf_dev, size_t stride,
+                        size_t tail_off) {
   if (P == 0) return;
-  hipLaunchKernelGGL(k_grow_gather, dim3((unsigned)P), dim3(64), 0, s, g, anc_dev, P);
+  hipLaunchKernelGGL(k_grow_gather, dim3((unsigned)P), dim3(64), 0, s, g, anc_dev, P, buf_dev, stride, tail_off);
   g.cur ^= 1;
 }
 

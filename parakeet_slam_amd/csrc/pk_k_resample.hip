@@ -803,10 +803,10 @@ __global__ void __launch_bounds__(256) k_bal_pack(SlotSource ss, const int32_t* 
                                                   const double* __restrict__ lw, const int64_t* __restrict__ rel,
                                                   const int64_t* __restrict__ Hl, const int32_t* __restrict__ alive, int64_t a0,
                                                   int64_t P, int64_t ebase_s, int64_t dbase_d, int64_t dd_d, int64_t m_d,
-                                                  unsigned char* __restrict__ buf) {
+                                                  unsigned char* __restrict__ buf, size_t stride, GrowState g) {
   const int64_t i = blockIdx.x;
   const int64_t j = alive[a0 + i];
-  unsigned char* rec = buf + (size_t)i * (kPoseRecordBytes + ss.slot_bytes);
+  unsigned char* rec = buf + (size_t)i * stride;
   if (threadIdx.x == 0) {
     double* hd = reinterpret_cast<double*>(rec);
     hd[0] = x[j];
@@ -828,12 +828,26 @@ __global__ void __launch_bounds__(256) k_bal_pack(SlotSource ss, const int32_t* 
   uint4* d = reinterpret_cast<uint4*>(rec + kPoseRecordBytes);
   const size_t n = ss.slot_bytes / 16;
   for (size_t k = threadIdx.x; k < n; k += blockDim.x) d[k] = s[k];
+  if (g.R > 0) {  // the particle's new-landmark bookkeeping travels behind its map (GrowState: counters | slot ids | readings)
+    unsigned char* tail = rec + kPoseRecordBytes + ss.slot_bytes;
+    const int32_t* sc = g.cnt[g.cur] + 4 * j;
+    int32_t* tc = reinterpret_cast<int32_t*>(tail);
+    if (threadIdx.x < 4) tc[threadIdx.x] = sc[threadIdx.x];
+    const int nrd = sc[0], used = sc[1];
+    const int32_t* ss_ = g.slot_id[g.cur] + (size_t)j * g.S;
+    int32_t* ts = tc + 4;
+    for (int k = threadIdx.x; k < used; k += blockDim.x) ts[k] = ss_[k];
+    const double* sr = g.hyp[g.cur] + (size_t)j * g.R * 8;
+    double* tr = reinterpret_cast<double*>(tail + grow_tail_readings_off(g.S));
+    for (int k = threadIdx.x; k < 8 * nrd; k += blockDim.x) tr[k] = sr[k];
+  }
 }
 void launch_bal_pack(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t a0, int64_t n, int64_t ebase_s,
-                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev) {
+                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev, size_t stride, const GrowState* g) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_bal_pack, dim3((unsigned)n), dim3(256), 0, s, slot_source(d), d.src[d.cur], d.x[d.cur], d.y[d.cur],
-                     d.h[d.cur], d.logw[d.cur], b.rel, b.Hl, b.alive, a0, d.P, ebase_s, dbase_d, dd_d, m_d, buf_dev);
+                     d.h[d.cur], d.logw[d.cur], b.rel, b.Hl, b.alive, a0, d.P, ebase_s, dbase_d, dd_d, m_d, buf_dev, stride,
+                     g ? *g : GrowState{});
 }
 
 __global__ void __launch_bounds__(256) k_bal_extract(const unsigned char* __restrict__ buf, size_t stride, int64_t n,
@@ -855,7 +869,7 @@ __global__ void __launch_bounds__(256) k_bal_adopt(const double* __restrict__ x,
                                                    const int64_t* __restrict__ rel, const int64_t* __restrict__ Hl, int64_t m,
                                                    const unsigned char* __restrict__ buf, size_t stride,
                                                    const int64_t* __restrict__ rh, int64_t n_recv, int64_t P, int mode,
-                                                   int* __restrict__ bad) {
+                                                   int* __restrict__ bad, int32_t* __restrict__ anc) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= P) return;
   const bool local = k < m;
@@ -875,6 +889,7 @@ __global__ void __launch_bounds__(256) k_bal_adopt(const double* __restrict__ x,
     lw2[k] = lw[lo];
     src2[k] = src[lo];
     logical2[k] = Hl[lo] + (k - rel[lo]);
+    if (anc) anc[k] = (int32_t)lo;
   } else {
     if (n_recv <= 0) {
       atomicAdd(bad, 1);
@@ -896,19 +911,20 @@ __global__ void __launch_bounds__(256) k_bal_adopt(const double* __restrict__ x,
     lw2[k] = hd[3];
     src2[k] = (int32_t)(-(lo + 1));
     logical2[k] = rh[3 * lo + 2] + (k - rh[3 * lo]);
+    if (anc) anc[k] = (int32_t)(-(lo + 1));
   }
 }
+// anc_dev (or NULL): where every slot's particle came from -- a local particle (>= 0) or received record -anc - 1
 void launch_bal_adopt(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t m, const unsigned char* buf_dev,
-                      int64_t n_recv, int64_t* rh_dev, int mode) {
+                      int64_t n_recv, int64_t* rh_dev, int mode, size_t stride, int32_t* anc_dev) {
   if (d.P == 0) return;
   // mode 2 (the received part of a split adoption) writes into the generation mode 1 has already made current
   const int n = mode == 2 ? d.cur : d.cur ^ 1, c = n ^ 1;
-  const size_t stride = kPoseRecordBytes + d.lay.slot_bytes;
   if (n_recv > 0 && mode != 1)
     hipLaunchKernelGGL(k_bal_extract, dim3((unsigned)((n_recv + 255) / 256)), dim3(256), 0, s, buf_dev, stride, n_recv, rh_dev);
   hipLaunchKernelGGL(k_bal_adopt, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, d.x[c], d.y[c], d.h[c], d.logw[c],
                      d.src[c], d.x[n], d.y[n], d.h[n], d.logw[n], d.src[n], d.logical[n], b.rel, b.Hl, m, buf_dev, stride, rh_dev,
-                     n_recv, d.P, mode, b.bad);
+                     n_recv, d.P, mode, b.bad, anc_dev);
   d.cur = n;
   if (mode != 1) {
     d.alt = n_recv > 0 ? buf_dev : nullptr;

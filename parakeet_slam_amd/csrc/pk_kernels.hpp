@@ -38,6 +38,20 @@ struct DeviceState {
   int64_t* logical[2] = {nullptr, nullptr};
 };
 
+// section 8(f4) on the device (pk_k_grow.hip): the per-particle bookkeeping of the new-landmark machinery, double-buffered like the
+// poses (the resample gathers it by ancestors)
+struct GrowState {
+  double* hyp[2] = {nullptr, nullptr};       // [P][R][8] stored readings: id, x, y, heading, bearing, r, g, b
+  int32_t* cnt[2] = {nullptr, nullptr};      // [P][4]: readings stored, spare slots in use, next_id, readings dropped (ring full)
+  int32_t* slot_id[2] = {nullptr, nullptr};  // [P][S] feature id of every spare slot in use
+  int cur = 0;
+  int L0 = 0, S = 0, R = 0;                  // preset landmarks, spare slots, ring capacity
+  double pair_threshold = 0.0;
+};
+// the bookkeeping of one particle behind its record in the sharded exchange: counters (16 B) | slot ids | readings
+__host__ __device__ inline size_t grow_tail_readings_off(int S) { return 16 + (((size_t)S * 4 + 15) & ~(size_t)15); }
+inline size_t grow_tail_bytes(const GrowState& g) { return g.R > 0 ? grow_tail_readings_off(g.S) + (size_t)g.R * 64 : 0; }
+
 // Where the landmark slot of a particle lives: its own map buffer or the adoption buffer.
 struct SlotSource {
   const unsigned char* map;
@@ -324,9 +338,9 @@ void launch_bal_state(hipStream_t s, const DeviceState& d, double* out_dev);
 void launch_bal_plan(hipStream_t s, const DeviceState& d, const double* gstate_dev, int64_t Pg, int world, int rank,
                      const double* gmax_dev, int domain, double u, BalancedBuffers& b, int64_t* table_dev);
 void launch_bal_pack(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t a0, int64_t n, int64_t ebase_s,
-                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev);
+                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev, size_t stride, const GrowState* g);
 void launch_bal_adopt(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t m, const unsigned char* buf_dev,
-                      int64_t n_recv, int64_t* rh_dev, int mode);
+                      int64_t n_recv, int64_t* rh_dev, int mode, size_t stride, int32_t* anc_dev);
 void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,
                       int64_t first_block, int64_t P_local, int64_t P_global, double u, int last_shard,
                       int64_t* hi_dev);
@@ -348,18 +362,10 @@ void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
                       const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode = 0, int64_t span_lo = INT64_MIN, int64_t span_hi = INT64_MAX);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
-// section 8(f4) on the device (pk_k_grow.hip): the per-particle bookkeeping of the new-landmark machinery, double-buffered like the
-// poses (the resample gathers it by ancestors)
-struct GrowState {
-  double* hyp[2] = {nullptr, nullptr};       // [P][R][8] stored readings: id, x, y, heading, bearing, r, g, b
-  int32_t* cnt[2] = {nullptr, nullptr};      // [P][4]: readings stored, spare slots in use, next_id, readings dropped (ring full)
-  int32_t* slot_id[2] = {nullptr, nullptr};  // [P][S] feature id of every spare slot in use
-  int cur = 0;
-  int L0 = 0, S = 0, R = 0;                  // preset landmarks, spare slots, ring capacity
-  double pair_threshold = 0.0;
-};
 void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int32_t* ids_dev, const double* blobs_dev, int B);
-void launch_grow_gather(hipStream_t s, GrowState& g, const int32_t* anc_dev, int64_t P);
+// anc >= 0: a particle of this filter; anc < 0: record -anc - 1 of buf (stride bytes apart, its bookkeeping tail_off bytes in)
+void launch_grow_gather(hipStream_t s, GrowState& g, const int32_t* anc_dev, int64_t P, const unsigned char* buf_dev = nullptr,
+                        size_t stride = 0, size_t tail_off = 0);
 // scan block: pinned (device-mapped) host memory -> HBM by a kernel, in stream order
 void launch_upload(hipStream_t s, void* dst_dev, const void* src_host_mapped, size_t bytes);
 

@@ -45,7 +45,7 @@ from . import msgs
 from .msgs import Odometry, Twist
 
 
-def _worker_main(rank, world, device, store_path, backend, P_local, L, means, covs, imm, domain, shard_factory, conn):
+def _worker_main(rank, world, device, store_path, backend, P_local, L, means, covs, imm, domain, shard_factory, conn, grow=None):
     """One rank: joins the process group, builds its shard, serves the pipe.  Runs in a freshly spawned interpreter."""
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on these hosts
@@ -61,6 +61,8 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
         sf = ShardedFilter(P_local, L, device=device, comm=TorchComm(), shard=shard)
         if L:
             sf.upload_map(means, covs.reshape(L, 25), imm)
+        if grow is not None:  # (preset landmarks, reading capacity, pair threshold): section 8(f4) on every rank's device
+            sf.grow_enable(*grow)
         probe = None  # a one-particle filter for motion_model, made on first use and kept
         conn.send(("ok", None))
         while True:
@@ -91,6 +93,11 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
                     conn.send(("ok", (sf.download_poses(), sf.logical_index())))
                 elif op == "landmarks":
                     conn.send(("ok", sf.download_landmarks(cmd[1], cmd[2])))
+                elif op == "grow":  # the new-landmark bookkeeping of local slots [j0, j1)
+                    conn.send(("ok", sf.grow_download(cmd[1], cmd[2])))
+                elif op == "set_grow":
+                    sf.grow_upload(0, P_local, *cmd[1:4])
+                    conn.send(("ok", None))
                 elif op == "set_particle":
                     _, j, pose, m, c, k = cmd
                     sf.upload_pose(j, pose)  # (one particle: the shard's other log-weights are not sent through exp and log)
@@ -180,10 +187,15 @@ class ShardedFastSLAM(object):
     :55-57 (/particle_track :126-127, /aged_particles :237, /resampled_particles :242) fed from pose downloads gathered over
     the ranks.  ``backend="gloo"`` with ``_shard_factory`` is the CPU rehearsal the tests use.
 
+    new_landmarks=True with spare_landmarks=S: the working new-landmark initialisation of ``FastSLAM`` (:546-746, core.py) on
+    every rank's device (pk_grow_enable); a particle that migrates in the resample takes its orphaned readings, id counter and
+    spare-slot ids along behind its map, so the filter grows the same maps whatever the number of GPUs.
+
     (``FastSLAM(..., devices=[...])`` arrives here with FastSLAM's OWN defaults -- weight_domain "linear", rng "global".)"""
 
     def __init__(self, preset_features=[], num_particles=50, devices=(0, 1), weight_domain="log", rng="device", seed=0,
-                 backend="nccl", publish_debug=None, _shard_factory=None):
+                 backend="nccl", publish_debug=None, _shard_factory=None, new_landmarks=False, spare_landmarks=0,
+                 pair_threshold=30.0, reading_capacity=64):
         from . import _lib  # constants only; loads nothing
 
         self._lock = threading.RLock()
@@ -200,11 +212,26 @@ class ShardedFastSLAM(object):
             raise ValueError("rng must be 'global' or 'device'")
         self._P_local = self.num_particles // world
         self._features = list(preset_features)
-        L = len(self._features)
+        L0 = len(self._features)
+        self._grow = bool(new_landmarks) and int(spare_landmarks) > 0
+        self._spare = int(spare_landmarks) if self._grow else 0
+        if self._grow and _shard_factory is not None:
+            raise ValueError("ShardedFastSLAM: new_landmarks runs on the HIP shards only (no _shard_factory)")
+        self._L0 = L0
+        L = L0 + self._spare  # every particle's map: the preset landmarks, then the spare slots
         self._L = L
-        means = np.array([np.asarray(f.mean, dtype=np.float64).reshape(5) for f in self._features]).reshape(L, 5)
-        covs = np.array([np.asarray(f.covar, dtype=np.float64).reshape(5, 5) for f in self._features]).reshape(L, 5, 5)
-        imm = np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8)
+        means = np.zeros((L, 5))
+        covs = np.tile(np.identity(5), (L, 1, 1))
+        imm = np.zeros(L, dtype=np.uint8)
+        if L0:
+            means[:L0] = np.array([np.asarray(f.mean, dtype=np.float64).reshape(5) for f in self._features])
+            covs[:L0] = np.array([np.asarray(f.covar, dtype=np.float64).reshape(5, 5) for f in self._features])
+            imm[:L0] = np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8)
+        from .core import FastSLAM as _Single
+
+        means[L0:, 2:] = _Single.EMPTY_COLOUR  # a spare slot that holds nothing yet fails every colour gate
+        self._reading_capacity = int(reading_capacity)
+        grow = (L0, int(reading_capacity), float(pair_threshold)) if self._grow else None
         self.Qt = np.identity(4) * 0.1  # prkt_core_v2.py:50-53
         self._domain = {"linear": _lib.PK_WEIGHTS_LINEAR, "log": _lib.PK_WEIGHTS_LOG}[weight_domain]
         self._rng, self._seed, self._draw = rng, int(seed), 0
@@ -228,7 +255,7 @@ class ShardedFastSLAM(object):
         for rk, dev in enumerate(self.devices):
             a, b = ctx.Pipe()
             p = ctx.Process(target=_worker_main, args=(rk, world, dev, self._store, backend, self._P_local, L, means, covs, imm,
-                                                       self._domain, _shard_factory, b), daemon=True)
+                                                       self._domain, _shard_factory, b, grow), daemon=True)
             p.start()
             self._conns.append(a)
             self._procs.append(p)
@@ -442,20 +469,45 @@ class ShardedFastSLAM(object):
             p.weight = float(w)
             p.Qt = self.Qt
             r, j = self._place(i)
-            feats, lock, L, one = self._features, self._lock, self._L, self._one
+            feats, lock, L0, one = self._features, self._lock, self._L0, self._one
+            slot_id = {}
+            if self._grow:
+                from . import _lib
+                from .core import _nl_unpack
+                from .msgs import Blob
+
+                nl = _nl_unpack(*one(r, "grow", j, j + 1), L0=L0)
+                p.next_id, slot_id = nl["next_id"][0], nl["slot_id"][0]
+                for rd in nl["hyp"][0]:
+                    b = Blob()
+                    b.bearing = rd[4]
+                    b.color.r, b.color.g, b.color.b = rd[5], rd[6], rd[7]
+                    p.hypothesis_set[rd[0]] = (_make_state(rd[1], rd[2], rd[3]), b)
+            else:
+                p.next_id = L0 + 1
+            pot_bit = 0x40000000  # PK_LANDMARK_POTENTIAL
 
             def load_all():
                 with lock:
                     m, c, k = one(r, "landmarks", j, j + 1)
-                full = {}
-                for l in range(L):
+                full, potential = {}, {}
+                for l in range(L0):
                     f = Feature(mean=m[0, l], covar=c[0, l])
-                    f.update_count = int(k[0, l])
+                    f.update_count = int(k[0, l]) & ~pot_bit
                     f.__immutable__ = bool(feats[l].__immutable__)
                     full[l + 1] = f
-                return full
+                for slot, id_ in slot_id.items():
+                    f = Feature(mean=m[0, slot], covar=c[0, slot])
+                    f.update_count = int(k[0, slot]) & ~pot_bit
+                    if int(k[0, slot]) & pot_bit:
+                        potential[-id_] = f  # :685
+                    else:
+                        full[id_] = f        # promoted (:115-116)
+                return full, potential
 
-            p.feature_set = _FeatureSet(load_all)
+            p.feature_set = _FeatureSet(lambda: load_all()[0])
+            if slot_id:
+                p.potential_features = load_all()[1]
             return p
 
     def _store_particle(self, i, particle):
@@ -466,7 +518,7 @@ class ShardedFastSLAM(object):
         with self._lock:
             x, y, h = _state_pose(particle.state)
             r, j = self._place(i)
-            L = self._L
+            L = self._L0
             m = c = k = None
             ids = range(1, L + 1)
             if L and all(q in particle.feature_set for q in ids):
@@ -474,6 +526,11 @@ class ShardedFastSLAM(object):
                 m = np.array([np.asarray(f.mean, dtype=np.float64) for f in fs_]).reshape(1, L, 5)
                 c = np.array([np.asarray(f.covar, dtype=np.float64) for f in fs_]).reshape(1, L, 25)
                 k = np.array([int(f.update_count) for f in fs_], dtype=np.int32).reshape(1, L)
+                if self._spare:  # the preset landmarks only: the spare slots keep what the filter put there
+                    m0, c0, k0 = self._one(r, "landmarks", j, j + 1)
+                    c0 = c0.reshape(1, -1, 25)
+                    m0[:, :L], c0[:, :L], k0[:, :L] = m, c, k
+                    m, c, k = m0, c0, k0
             self._one(r, "set_particle", j, (x, y, h, float(particle.weight)), m, c, k)
             self._pose_cache = None
 
@@ -485,11 +542,17 @@ class ShardedFastSLAM(object):
             m = np.concatenate([p[0] for p in parts])[self._where]  # the single filter's particle order
             c = np.concatenate([p[1] for p in parts])[self._where]
             k = np.concatenate([p[2] for p in parts])[self._where]
+            extra = {}
+            if self._grow:  # the single-GPU facade's nl_* arrays, in the single filter's particle order
+                from .core import _nl_snapshot, _nl_unpack
+
+                g = self._all("grow", 0, self._P_local)
+                extra = _nl_snapshot(_nl_unpack(*[np.concatenate([q[a] for q in g])[self._where] for a in range(3)], L0=self._L0))
             np.savez_compressed(
                 path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
                 immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),
                 last_control=np.array([float(self.last_control.linear.x), float(self.last_control.angular.z)]),
-                last_update=float(self.last_update.to_sec()), draw=self._draw)
+                last_update=float(self.last_update.to_sec()), draw=self._draw, **extra)
 
     def load_state(self, path):
         with self._lock:
@@ -499,11 +562,24 @@ class ShardedFastSLAM(object):
             if d["poses"].shape != (P, 4) or d["means"].shape != (P, L, 5):
                 raise ValueError("snapshot is for %s particles x %s landmarks, this filter has %d x %d"
                                  % (d["poses"].shape[0], d["means"].shape[1], P, L))
+            nl = None
+            if self._grow:
+                from .core import _nl_check_snapshot, _nl_pack, _nl_restore
+
+                if "nl_offsets" not in d.files:
+                    raise ValueError("snapshot: no new-landmark bookkeeping (nl_* arrays) for a filter with new_landmarks=True")
+                _nl_check_snapshot(d, P, self._L0, L, self._spare, self._reading_capacity)  # before anything is assigned
+                nl = _nl_pack(*_nl_restore(d, P), L0=self._L0, S=self._spare, R=self._reading_capacity)
             for r in range(len(self._conns)):
                 s = slice(r * Pl, (r + 1) * Pl)
                 self._post(r, ("set_state", d["poses"][s], d["means"][s] if L else None,
                            d["covs"][s].reshape(Pl, L, 25) if L else None, d["counts"][s].astype(np.int32) if L else None))
             self._collect("set_state")
+            if nl is not None:  # (set_state put rank r's slots back in the snapshot's order)
+                for r in range(len(self._conns)):
+                    s = slice(r * Pl, (r + 1) * Pl)
+                    self._post(r, ("set_grow", nl[0][s], nl[1][s], nl[2][s]))
+                self._collect("set_grow")
             self.Qt = d["Qt"].copy()
             self.last_control.linear.x = float(d["last_control"][0])
             self.last_control.angular.z = float(d["last_control"][1])

@@ -517,6 +517,22 @@ class ShardedFilter(object):
         self._recv_keepalive = None
         return out
 
+    # ---- new landmarks on the device: every particle's bookkeeping rides behind its map in the exchange ----
+    def grow_enable(self, preset_landmarks, reading_capacity=64, pair_threshold=30.0):
+        if self.placement != "balanced":
+            raise ValueError("grow_enable: the new-landmark bookkeeping travels with the balanced placement (placement='balanced')")
+        self._complete()
+        self.split_step = False  # (the bookkeeping kernel wants the ids in HBM: whole observes on the general route)
+        return self.f.grow_enable(preset_landmarks, reading_capacity, pair_threshold)
+
+    def grow_download(self, *a, **k):
+        self._complete()
+        return self.f.grow_download(*a, **k)
+
+    def grow_upload(self, *a, **k):
+        self._complete()
+        return self.f.grow_upload(*a, **k)
+
     def synchronize(self):
         self._complete()
         return self.f.synchronize()

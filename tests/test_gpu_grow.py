@@ -142,3 +142,83 @@ def test_upload_round_trip(lib):
     with pytest.raises(lib.PkError, match="readings of"):
         f.grow_upload(0, 8, bad, None, None)
     f.close()
+
+
+class _View(object):
+    def __init__(self, pk, blobs):
+        class Scan(object):
+            pass
+
+        self.last_sensor_reading = Scan()
+        obs = []
+        for b in blobs:
+            o = pk.msgs.Blob()
+            o.bearing = float(b[0])
+            o.color.r, o.color.g, o.color.b = float(b[1]), float(b[2]), float(b[3])
+            obs.append(o)
+        self.last_sensor_reading.observes = obs
+
+
+def test_three_ranks_grow_the_same_maps_as_one_filter(tmp_path):
+    """FastSLAM(..., new_landmarks=True, devices=[0, 0, 0]) (three child processes on the one device, gloo between them) against
+    FastSLAM(device=0): a particle that migrates in the resample takes its readings, id counter and spare-slot ids along behind its
+    map (the record's tail), so the snapshots -- poses, maps, flags, bookkeeping, all in the single filter's order -- are equal
+    array for array.  Then the snapshot of the one goes into the other and both take another step."""
+    import random
+
+    import parakeet_slam_amd as pk
+
+    L0, U, P, spare, steps = 10, 3, 1200, 5, 8
+    v, w, dt = 0.8, 0.35, 0.5
+    world, covs = synthetic_world(L0 + U)
+    feats = [pk.Feature(mean=world[l].copy(), covar=covs[l].copy()) for l in range(L0)]
+    snaps, views, filters = [], [], []
+    for devices in ([0, 0, 0], None):
+        random.seed(7)
+        pk.msgs.Time.set_now(0.0)
+        kw = dict(num_particles=P, weight_domain="log", rng="device", seed=3, new_landmarks=True, spare_landmarks=spare)
+        if devices:
+            fs = pk.FastSLAM(feats, devices=devices, backend="gloo", **kw)
+            assert isinstance(fs, pk.ShardedFastSLAM)
+        else:
+            fs = pk.FastSLAM(feats, device=0, **kw)
+        tw = pk.msgs.Twist()
+        tw.linear.x, tw.angular.z = v, w
+        fs.last_control = tw
+        pose = (0.0, 0.0, 0.0)
+        for s in range(steps):
+            pose = truth_step(pose, v, w, dt)
+            pk.msgs.Time.set_now(dt * (s + 1))
+            fs.cam_cb(_View(pk, synthetic_scan(world, pose)))
+        path = str(tmp_path / ("grow_%d.npz" % len(snaps)))
+        fs.save_state(path)
+        snaps.append(path)
+        p = fs.particles[P - 3]
+        views.append((p.next_id, sorted(p.hypothesis_set.keys()), sorted(p.potential_features.keys()), sorted(p.feature_set.keys())))
+        filters.append((fs, pose))
+    a, b = np.load(snaps[0]), np.load(snaps[1])
+    assert set(a.files) == set(b.files) and "nl_readings" in a.files
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert int(a["nl_used"].max()) >= 2, "nothing was triangulated"
+    assert len(set(a["nl_used"].tolist())) > 1 or len(set(np.diff(a["nl_offsets"]).tolist())) > 1, "every particle holds the same bookkeeping: the test shows nothing"
+    assert views[0] == views[1]
+    # cross-load: the single filter's snapshot into the three ranks and the other way round, then one more step on both
+    (fm, pose), (f1, _) = filters
+    fm.load_state(snaps[1])
+    f1.load_state(snaps[0])
+    random.seed(9)
+    pose = truth_step(pose, v, w, dt)
+    pk.msgs.Time.set_now(dt * (steps + 1))
+    blobs = synthetic_scan(world, pose)
+    fm.cam_cb(_View(pk, blobs))
+    random.seed(9)
+    f1.cam_cb(_View(pk, blobs))
+    pa, pb = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
+    fm.save_state(pa)
+    f1.save_state(pb)
+    a, b = np.load(pa), np.load(pb)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), ("after the cross-load", k)
+    fm.close()
+    f1.close()
