@@ -215,8 +215,9 @@ class ShardedFastSLAM(object):
         L0 = len(self._features)
         self._grow = bool(new_landmarks) and int(spare_landmarks) > 0
         self._spare = int(spare_landmarks) if self._grow else 0
-        if self._grow and _shard_factory is not None:
-            raise ValueError("ShardedFastSLAM: new_landmarks runs on the HIP shards only (no _shard_factory)")
+        if self._grow and _shard_factory is not None and not getattr(_shard_factory, "grows", False):
+            raise ValueError("ShardedFastSLAM: new_landmarks needs shards that keep the bookkeeping (the HIP shards do; this "
+                             "_shard_factory does not say it does)")
         self._L0 = L0
         L = L0 + self._spare  # every particle's map: the preset landmarks, then the spare slots
         self._L = L

@@ -366,3 +366,134 @@ def store_file():
 def make_oracle_shard(P, means, covs, immutable=None):
     """Shard factory for ShardedFastSLAM's CPU rehearsal (module-level: picklable for the spawned ranks)."""
     return OracleShard(P, means, covs, immutable)
+
+
+class GrowingOracleShard(OracleShard):
+    """OracleShard + the new-landmark bookkeeping: GrowingOracle per shard, and the bookkeeping of a migrating
+    particle behind its map in the record -- the NumPy mirror of pk_grow_enable / k_new_landmarks / k_grow_gather and of the tail
+    pk_shard_pack_balanced_dev appends (here as float64 words: counters (4) | slot ids (S) | readings (R x 8))."""
+
+    grow = None
+
+    def grow_enable(self, preset_landmarks, reading_capacity=64, pair_threshold=30.0):
+        from oracle.fastslam_oracle import GrowingOracle
+
+        g = GrowingOracle.__new__(GrowingOracle)  # around the shard's own OracleFilter (its map already holds the spare slots)
+        g.f, g.L0, g.spare, g.thr = self.o, int(preset_landmarks), self.L - int(preset_landmarks), float(pair_threshold)
+        g.hyp = [[] for _ in range(self.P)]
+        g.next_id = [g.L0 + 1] * self.P
+        g.used = [0] * self.P
+        g.slot_id = [dict() for _ in range(self.P)]
+        self.grow, self.R = g, int(reading_capacity)
+
+    def grow_shape(self):
+        return (self.grow.L0, self.grow.spare, self.R) if self.grow else (0, 0, 0)
+
+    def observe(self, blobs, ids=None, return_ids=False, fresh=False):
+        if self.grow is None or ids is not None or len(blobs) == 0:
+            return OracleShard.observe(self, blobs, ids, return_ids, fresh)
+        if fresh:
+            self.o.reset_weights()
+        return self.grow.observe(blobs)
+
+    def _tail_words(self):
+        return 4 + self.grow.spare + 8 * self.R if self.grow else 0
+
+    def particle_bytes(self):
+        return OracleShard.particle_bytes(self) + 8 * self._tail_words()
+
+    def _tail(self, j):
+        g = self.grow
+        t = np.zeros(self._tail_words())
+        assert len(g.hyp[j]) <= self.R, "the rehearsal's ring is too small for this scene"
+        t[:3] = (len(g.hyp[j]), g.used[j], g.next_id[j])
+        for k in range(g.used[j]):
+            t[4 + k] = g.slot_id[j][g.L0 + k]
+        if g.hyp[j]:
+            t[4 + g.spare:4 + g.spare + 8 * len(g.hyp[j])] = np.asarray(g.hyp[j], dtype=np.float64).ravel()
+        return t
+
+    def _set_tail(self, k, t):
+        g = self.grow
+        n, used = int(t[0]), int(t[1])
+        g.next_id[k], g.used[k] = int(t[2]), used
+        g.slot_id[k] = {g.L0 + i: int(t[4 + i]) for i in range(used)}
+        rd = t[4 + g.spare:4 + g.spare + 8 * n].reshape(n, 8)
+        g.hyp[k] = [(int(r[0]),) + tuple(float(v) for v in r[1:]) for r in rd]
+
+    POT = 0x40000000  # PK_LANDMARK_POTENTIAL: the device keeps the potential flag in the count word, so do the records here
+
+    def _record(self, j, lo, up, klo=0):
+        rec = OracleShard._record(self, j, lo, up, klo)
+        if self.grow is None:
+            return rec
+        rec[self.HEAD + 30 * self.L:] += np.where(self.o.potential[j], float(self.POT), 0.0)
+        return np.concatenate([rec, self._tail(j)])
+
+    def _take_record(self, k, rec):
+        if self.grow is None:
+            return OracleShard._take_record(self, k, rec)
+        n = self._tail_words()
+        OracleShard._take_record(self, k, rec[:-n])
+        self.o.potential[k] = (self.o.count[k] & self.POT) != 0
+        self.o.count[k] &= ~self.POT
+        self._set_tail(k, rec[-n:])
+
+    def download_landmarks(self, p0=0, p1=None):
+        m, c, k = OracleShard.download_landmarks(self, p0, p1)
+        p1 = self.P if p1 is None else p1
+        return m, c, k | np.where(self.o.potential[p0:p1], self.POT, 0)
+
+    def upload_landmarks(self, p0, p1, means=None, covs=None, counts=None):
+        OracleShard.upload_landmarks(self, p0, p1, means, covs, None)
+        if counts is not None:
+            k = np.asarray(counts).reshape(p1 - p0, self.L).astype(np.int64)
+            self.o.count[p0:p1] = k & ~self.POT
+            self.o.potential[p0:p1] = (k & self.POT) != 0
+
+    def adopt_balanced(self, table, world, rank, recv, n_received, mode=0):
+        if self.grow is not None:
+            assert mode == 0
+            g, b = self.grow, self.bal
+            m = int(b["m"][rank])
+            a = np.searchsorted(b["rel"][1:], np.arange(m), side="right")  # the particle whose children hold position k
+            old = (g.hyp, g.next_id, g.used, g.slot_id)
+            g.hyp = [list(old[0][i]) for i in a] + [[] for _ in range(self.P - m)]
+            g.next_id = [old[1][i] for i in a] + [0] * (self.P - m)
+            g.used = [old[2][i] for i in a] + [0] * (self.P - m)
+            g.slot_id = [dict(old[3][i]) for i in a] + [dict() for _ in range(self.P - m)]
+            pot = self.o.potential.copy()
+            self.o.potential[:m] = pot[a]
+        return OracleShard.adopt_balanced(self, table, world, rank, recv, n_received, mode)
+
+    def adopt_from(self, rank, recv, n_received):
+        assert self.grow is None, "the bookkeeping travels with the balanced placement only"
+        return OracleShard.adopt_from(self, rank, recv, n_received)
+
+    def grow_download(self, p0=0, p1=None, counters=True, readings=True, slot_ids=True):
+        g = self.grow
+        p1 = self.P if p1 is None else p1
+        n = p1 - p0
+        cnt = np.zeros((n, 4), dtype=np.int32)
+        rd = np.zeros((n, self.R, 8))
+        sid = np.zeros((n, g.spare), dtype=np.int32)
+        for i in range(n):
+            t = self._tail(p0 + i)
+            cnt[i] = t[:4]
+            sid[i] = t[4:4 + g.spare]
+            rd[i] = t[4 + g.spare:].reshape(self.R, 8)
+        return cnt, rd, sid
+
+    def grow_upload(self, p0, p1, counters=None, readings=None, slot_ids=None):
+        g = self.grow
+        for i in range(p1 - p0):
+            t = np.concatenate([np.asarray(counters[i], dtype=np.float64), np.asarray(slot_ids[i], dtype=np.float64),
+                                np.asarray(readings[i], dtype=np.float64).ravel()])
+            self._set_tail(p0 + i, t)
+
+
+def make_growing_oracle_shard(P, means, covs, immutable=None):
+    return GrowingOracleShard(P, means, covs, immutable)
+
+
+make_growing_oracle_shard.grows = True  # (ShardedFastSLAM(new_landmarks=True) asks the factory whether its shards can)

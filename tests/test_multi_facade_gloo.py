@@ -230,3 +230,83 @@ if __name__ == "__main__":
 ''' % (root, os.path.join(root, "tests"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "SHARDED-ROS-MODE-OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_new_landmarks_over_sharded_ranks_grow_the_same_maps_as_one_filter(pk, world, tmp_path):
+    """SURVEY 8 row (f4) over several ranks: FastSLAM(new_landmarks=True, devices=[...]).  The front end, the command pipes, the
+    balanced exchange and the record's tail are the product's protocol; the per-particle arithmetic is the test-only
+    GrowingOracleShard.  Against ONE GrowingOracle holding every particle, same numpy / random streams: the snapshot -- poses,
+    maps, potential flags, readings, id counters, slot ids, in the single filter's particle order -- must be equal."""
+    from oracle.fastslam_oracle import GrowingOracle, low_variance_ancestors, synthetic_scan, synthetic_world, truth_step
+    from sharded_common import make_growing_oracle_shard
+
+    L0, U, P, spare, steps, thr = 10, 3, 12 * world, 5, 7, 30.0
+    v, w, dt = 0.8, 0.35, 0.5
+    world_m, covs = synthetic_world(L0 + U)
+    known, kcov = world_m[:L0], covs[:L0]
+    np.random.seed(5)
+    random.seed(5)
+    pk.msgs.Time.set_now(0.0)
+    fs = pk.FastSLAM([pk.Feature(mean=m.copy(), covar=c.copy()) for m, c in zip(known, kcov)], num_particles=P,
+                     devices=list(range(world)), weight_domain="log", rng="global", backend="gloo", new_landmarks=True,
+                     spare_landmarks=spare, pair_threshold=thr, _shard_factory=make_growing_oracle_shard)
+    try:
+        tw = pk.msgs.Twist()
+        tw.linear.x, tw.angular.z = v, w
+        fs.last_control = tw
+        o = GrowingOracle(P, known, kcov, spare, thr)
+        np_rs, py_rs = np.random.RandomState(5), random.Random(5)
+        path = str(tmp_path / "grow.npz")
+
+        def same_as_the_one_filter():
+            fs.save_state(path)
+            d = np.load(path)
+            assert np.allclose(d["poses"][:, :3], np.stack([o.f.x, o.f.y, o.f.h], 1), rtol=1e-12, atol=1e-13)
+            assert np.allclose(d["means"], o.f.mean, rtol=1e-10, atol=1e-10)
+            assert np.array_equal(d["counts"] & ~0x40000000, o.f.count) and np.array_equal((d["counts"] & 0x40000000) != 0, o.f.potential)
+            assert d["nl_next_id"].tolist() == o.next_id and d["nl_used"].tolist() == o.used
+            assert np.diff(d["nl_offsets"]).tolist() == [len(h) for h in o.hyp]
+            flat = np.array([rd for h in o.hyp for rd in h]).reshape(-1, 8)
+            assert np.allclose(d["nl_readings"], flat, rtol=1e-12, atol=1e-13)
+            assert [tuple(t) for t in d["nl_slot_id"].tolist()] == [(i, sl, v_) for i, m in enumerate(o.slot_id) for sl, v_ in sorted(m.items())]
+            return len(set(zip(o.used, [len(h) for h in o.hyp], o.next_id)))
+
+        kinds = 0
+        pose = (0.0, 0.0, 0.0)
+        for s in range(steps):
+            pose = truth_step(pose, v, w, dt)
+            blobs = synthetic_scan(world_m, pose)
+            pk.msgs.Time.set_now(dt * (s + 1))
+            fs.cam_cb(View(pk, blobs))
+            o.f.reset_weights()
+            o.f.motion(v, w, dt, np_rs.standard_normal((P, 3)))
+            o.observe(blobs)
+            wts = np.exp(o.f.logw - o.f.logw.max())
+            o.gather(low_variance_ancestors(wts, py_rs.random()))
+            if s in (1, 3):
+                kinds = max(kinds, same_as_the_one_filter())
+        kinds = max(kinds, same_as_the_one_filter())
+        assert max(o.used) >= 2 and kinds > 1, "the scene shows nothing: every particle held the same bookkeeping at every check"
+        # the object view of a particle wherever it lives now (:278-292)
+        i = P - 2
+        p = fs.particles[i]
+        assert p.next_id == o.next_id[i] and len(p.hypothesis_set) == len(o.hyp[i])
+        assert len(p.potential_features) + len([k for k in p.feature_set.keys() if k > L0]) == o.used[i]
+        # the snapshot goes back in (every rank takes its rows again) and the next step still agrees
+        fs.load_state(path)
+        pose = truth_step(pose, v, w, dt)
+        blobs = synthetic_scan(world_m, pose)
+        pk.msgs.Time.set_now(dt * (steps + 1))
+        fs.cam_cb(View(pk, blobs))
+        o.f.reset_weights()
+        o.f.motion(v, w, dt, np_rs.standard_normal((P, 3)))
+        o.observe(blobs)
+        wts = np.exp(o.f.logw - o.f.logw.max())
+        o.gather(low_variance_ancestors(wts, py_rs.random()))
+        fs.save_state(path)
+        d = np.load(path)
+        assert d["nl_next_id"].tolist() == o.next_id and d["nl_used"].tolist() == o.used
+        assert np.allclose(d["means"], o.f.mean, rtol=1e-10, atol=1e-10)
+    finally:
+        fs.close()
