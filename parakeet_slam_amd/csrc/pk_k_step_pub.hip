@@ -1740,7 +1740,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 //   pass 1  rows in -> gates -> verdicts published -- the rows are dropped, what stays in registers is the seven words per
 //           landmark the second pass needs (the gate-passing blobs with their entries, the expected bearing);
 //   barriers, blob-parallel settling, markers (as in k_step_pub);
-//   pass 2  rows in again (L2 / Infinity Cache: the same workgroup read them microseconds ago) -> updates -> rows out.
+//   pass 2  back to front: the last pair's rows are still in the registers, the others come in again (L2 / Infinity Cache: the same
+//           workgroup read them microseconds ago) -> updates -> rows out.
 // HBM sees the state once on the way in (the second read is a cache hit, which the FETCH_SIZE counter still counts) and once
 // on the way out.  The scan's exact records (48 B x B: 240 KB at 5 000 blobs) do not fit LDS beside the publish table; they
 // are read from L2.  Candidate and inverse lists of sixteen entries (eight overflow somewhere in every scan of several
@@ -1789,6 +1790,11 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   __shared__ unsigned s_rb[kPubBigSlots];  // the publish table's rank bases (k_cand_entries)
 #define PK_BIG_L0(q_, t_) ((int)(16u * (unsigned)s_bperm[kPubOctets * (q_) + ((t_) >> 3)]) + 2 * ((t_)&7))
   constexpr int kPubWaves = kPubThreads / kWave;
+#ifdef PK_DIAG_BIG_FRONT_TO_BACK  // (regression build: pass 2 front to back from rows asked for again, as until round 5)
+  constexpr bool kBack = false;
+#else
+  constexpr bool kBack = NCH < 6;  // pass 2 back to front, from the pair pass 1 ended on (see below)
+#endif
   PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid0 = threadIdx.x;
   int B, Lp, L, ecap;
@@ -1906,7 +1912,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     // ---- pass 1: gates and verdicts, pair by pair
     // (ONE copy of the pair's code in a loop that is not unrolled -- written out per pair the kernel was 143 KB of
     // instructions, more than twice the instruction cache two CUs share -- with the carried words ROTATING through the
-    // register arrays: a pair's results enter at the back, after NCH turns pair 0 stands in front again)
+    // register arrays: a pair's results enter at the front, after NCH turns the LAST pair stands in front, where pass 2 begins)
     if (!done) {
 #pragma unroll 1
       for (int q = 0; q < NCH; ++q) {
@@ -2000,7 +2006,15 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           PK_PSTAMP(2, c2, c3)
           pa = pp[0];
           pb = pp[1];
-          {  // the next pair of this pass, or the first one of pass 2
+          // the next pair of this pass; the LAST pair's rows stay where they are: pass 2 starts with them (round 5: a fifth of the
+          // second read at five pairs, a third at three, never asked for)
+          // (six pairs: the registers do not stretch to it -- three of them spilled; pass 2 front to back from rows asked for again)
+          if (kBack) {
+            if (q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp) {  // workgroup-uniform
+              const int ln = min(PK_BIG_L0(q + 1, tid), Lp - 2);
+              PK_BIG_ROWS(SA, SB, ln, csrc)
+            }
+          } else {
             const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
             const int ln = min(PK_BIG_L0(more ? q + 1 : 0, tid), Lp - 2);
             PK_BIG_ROWS(SA, SB, ln, csrc)
@@ -2010,15 +2024,27 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           PK_PSTAMP(3, c3, c4)
 #endif
         }
+        if (kBack) {
 #pragma unroll
-        for (int i = 0; i + 2 < 2 * NCH; ++i) {
-          Q[i] = Q[i + 2];
-          pse[i] = pse[i + 2];
+          for (int i = 2 * NCH - 1; i >= 2; --i) {  // (a pair's results enter at the FRONT: pass 2 walks the pairs back to front)
+            Q[i] = Q[i - 2];
+            pse[i] = pse[i - 2];
+          }
+          Q[0] = qa;
+          Q[1] = qb;
+          pse[0] = pa;
+          pse[1] = pb;
+        } else {
+#pragma unroll
+          for (int i = 0; i + 2 < 2 * NCH; ++i) {
+            Q[i] = Q[i + 2];
+            pse[i] = pse[i + 2];
+          }
+          Q[2 * NCH - 2] = qa;
+          Q[2 * NCH - 1] = qb;
+          pse[2 * NCH - 2] = pa;
+          pse[2 * NCH - 1] = pb;
         }
-        Q[2 * NCH - 2] = qa;
-        Q[2 * NCH - 1] = qb;
-        pse[2 * NCH - 2] = pa;
-        pse[2 * NCH - 1] = pb;
       }
     }
     PK_STAMP(b1)
@@ -2083,8 +2109,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     const Double2 v_ = {SA.field, SB.field};                                               \
     __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
   }
+    // (back to front: the pair pass 1 ended on is still in the registers)
 #pragma unroll 1
-    for (int q = 0; q < NCH; ++q) {
+    for (int qr = 0; qr < NCH; ++qr) {
+      const int q = kBack ? NCH - 1 - qr : qr;
       if (2 * kPubThreads * q < Lp) {  // workgroup-uniform
         const int l0 = PK_BIG_L0(q, tid);
         PubArgsPtr R = pub_args_now(rp);
@@ -2125,9 +2153,9 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           const Int2 c2_ = {SA.count, SB.count};
           __builtin_nontemporal_store(c2_, reinterpret_cast<Int2*>(dc + l0));
         }
-        {  // the next pair, or the next particle's first one
-          const bool more = q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp;  // workgroup-uniform
-          const int ln = min(PK_BIG_L0(more ? q + 1 : 0, tid), Lp - 2);
+        {  // the pair before it (front to back: behind it), or the next particle's first one
+          const bool more = kBack ? q > 0 : (q + 1 < NCH && 2 * kPubThreads * (q + 1) < Lp);  // workgroup-uniform
+          const int ln = min(PK_BIG_L0(more ? (kBack ? q - 1 : q + 1) : 0, tid), Lp - 2);
           const int32_t sn = more ? csrc : nsrc;
           PK_BIG_ROWS(SA, SB, ln, sn)
         }
@@ -2135,7 +2163,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         PK_PSTAMP(10, d2, d3)
       }
 #pragma unroll
-      for (int i = 0; i + 2 < 2 * NCH; ++i) {  // the next pair's words to the front
+      for (int i = 0; i + 2 < 2 * NCH; ++i) {  // the words of the pair before it to the front
         Q[i] = Q[i + 2];
         pse[i] = pse[i + 2];
       }
