@@ -806,6 +806,10 @@ def main():
             refscene["configs2_through_the_facade"] = facade_at_size(local_rank, DEFAULT_P, DEFAULT_L, 20, 5)
         except Exception as e:  # noqa: BLE001
             refscene["configs2_through_the_facade"] = {"error": repr(e)}
+        try:  # SURVEY 8 row (f4) at device speed: maps that grow, the per-particle bookkeeping on the device
+            refscene["new_landmarks"] = facade_growing(local_rank, 10000, 40, 6, 12)
+        except Exception as e:  # noqa: BLE001
+            refscene["new_landmarks"] = {"error": repr(e)}
 
     # what a plain device-to-device copy reaches on THIS box (read + write bytes / time), outside the
     # timed region: the practical ceiling next to the 8 TB/s vendor figure
@@ -999,6 +1003,59 @@ def facade_at_size(device, P, L, steps, warm):
         d = np.array(dts[warm:])
         out[tag] = {"ms_per_step": float(d.mean() * 1e3), "ms_p95": float(np.percentile(d, 95) * 1e3), "ms_max": float(d.max() * 1e3),
                     "steps": steps, "summary": [float(v) for v in sm]}
+    return out
+
+
+def facade_growing(device, P, L0, U, steps):
+    """FastSLAM(new_landmarks=True).cam_cb + summary() per step on a scene with U landmarks the preset map does not hold
+    (prkt_core_v2.py:546-746 made to work): the unmatched blobs of every particle are paired and
+    triangulated by ONE kernel behind the observe, the readings / id counters / slot ids live in HBM and follow the resample on
+    the device.  Nothing per particle crosses to the host inside a step."""
+    import parakeet_slam_amd as pk
+
+    class Scan(object):
+        pass
+
+    class Node(object):
+        pass
+
+    means, covs, _ = synthetic_inputs(L0 + U, 1)
+    feats = [pk.Feature(mean=means[l], covar=covs[l]) for l in range(L0)]
+    pk.msgs.Time.set_now(0.0)
+    random.seed(7)
+    fs = pk.FastSLAM(feats, num_particles=P, device=device, weight_domain="log", rng="device", seed=7, new_landmarks=True,
+                     spare_landmarks=U + 2, publish_debug=False)
+    node = Node()
+    node.last_sensor_reading = Scan()
+    tw = pk.msgs.Twist()
+    tw.linear.x, tw.angular.z = 0.5, 0.2
+    fs.last_control = tw
+    pose, dts, used = (0.0, 0.0, 0.0), [], []
+    for s_ in range(steps):
+        h1 = pose[2] + 0.2 * 0.1
+        pose = (pose[0] + 0.1 * math.cos(h1), pose[1] + 0.1 * math.sin(h1), pose[2] + 0.04)  # v = 0.5, w = 0.2, dt = 0.2, no noise
+        pk.msgs.Time.set_now(0.2 * (s_ + 1))
+        b = np.empty((L0 + U, 4))
+        b[:, 0] = np.arctan2(means[:, 1] - pose[1], means[:, 0] - pose[0]) - pose[2]
+        b[:, 1:] = means[:, 2:]
+        node.last_sensor_reading.observes = b
+        t0 = time.perf_counter()
+        fs.cam_cb(node)
+        fs.summary()
+        dts.append(time.perf_counter() - t0)
+        used.append(float(fs._filter.grow_download(readings=False, slot_ids=False)[0][:, 1].mean()))  # (the bench's own look at the counters: outside the timed step)
+    k = fs._filter.download_landmarks(means=False, covs=False)[2][:, L0:]
+    u = fs._filter.grow_download(readings=False, slot_ids=False)[0][:, 1]
+    promoted = float((((k & 0x40000000) == 0) & (np.arange(k.shape[1])[None, :] < u[:, None])).sum() / float(P))
+    growing = [i for i in range(1, steps) if used[i] > used[i - 1]]
+    out = {"what": "wall time of FastSLAM(new_landmarks=True).cam_cb + summary() per step, %d particles, %d preset + %d unknown landmarks, "
+                   "bookkeeping='device' (pk_k_grow.hip); the general ML route (the bookkeeping kernel reads the association's ids in HBM)" % (P, L0, U),
+           "ms_per_step": [round(x * 1e3, 3) for x in dts],
+           "ms_per_step_while_maps_grow": round(float(np.mean([dts[i] for i in growing])) * 1e3, 3) if growing else None,
+           "ms_per_step_afterwards": round(float(np.mean(dts[max(growing) + 1:])) * 1e3, 3) if growing and max(growing) + 1 < steps else None,
+           "spare_slots_in_use_mean": used, "promoted_per_particle": promoted, "readings_dropped": fs.readings_dropped(),
+           "host_loop_note": "the same scene with bookkeeping='host' (rounds 2-4): 90-900 ms per growing step (profiles/r05/grow_speed_10000x40.json)"}
+    fs.close()
     return out
 
 
