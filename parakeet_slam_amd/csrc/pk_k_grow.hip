@@ -7,8 +7,8 @@
 // the counters (readings stored, spare slots in use, next_id :298, readings dropped because the ring was full), the feature id of
 // every spare slot in use.  They follow the particles through the resample like the poses do (k_grow_gather).
 //
-// Hand-written gfx950 (CDNA4, wave64); one lane per particle: the work is a few unmatched blobs x a few stored readings, sequential
-// by nature (:92-95: the blobs of a scan in order, each seeing what the ones before it stored).
+// Hand-written gfx950 (CDNA4, wave64); one wave per particle: the blobs of a scan are taken in order, each seeing what the ones
+// before it stored (:92-95) -- that order is sequential by nature; the search over the stored readings is not.
 #include "pk_device.hpp"
 
 namespace pk {
@@ -46,12 +46,17 @@ __device__ __forceinline__ bool grow_cross_readings(double x1, double y1, double
   return true;
 }
 
+// One WAVE per particle: the lanes read the particle's row of ids side by side (64 blobs a turn) and vote the unmatched ones out;
+// those are taken one after the other, in scan order (each sees what the ones before it stored: the loop over the vote is
+// wave-uniform); the nearest-reading search of one blob runs over the stored readings lane-parallel, the first minimum wins as in the
+// reference's loop (strict <: the smallest distance, then the smallest index); lane 0 writes.
 __global__ void __launch_bounds__(256) k_new_landmarks(GrowState g, const double* __restrict__ x, const double* __restrict__ y,
                                                        const double* __restrict__ h, const int32_t* __restrict__ ids,
                                                        const double* __restrict__ blobs, int B, unsigned char* __restrict__ map,
                                                        size_t slot_bytes, size_t count_off, int Lp, int64_t P) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  if (p >= P) return;  // wave-uniform
   const int c = g.cur;
   int32_t* cnt = g.cnt[c] + 4 * p;
   double* ring = g.hyp[c] + (size_t)p * g.R * 8;
@@ -60,74 +65,89 @@ __global__ void __launch_bounds__(256) k_new_landmarks(GrowState g, const double
   const double px = x[p], py = y[p], ph = h[p];
   double* f = reinterpret_cast<double*>(map + (size_t)p * slot_bytes);
   int32_t* fc = reinterpret_cast<int32_t*>(map + (size_t)p * slot_bytes + count_off);
-  for (int b = 0; b < B; ++b) {  // the unmatched blobs of the scan, in scan order (:88-95)
-    if (ids[(size_t)p * B + b] != 0) continue;
-    const double zb = blobs[4 * b], zr = blobs[4 * b + 1], zg = blobs[4 * b + 2], zc = blobs[4 * b + 3];
-    int best = -1;
-    double best_d = INFINITY;
-    for (int r = 0; r < n; ++r) {  // find_nearest_reading :566-590 over the stored readings
-      const double* rd = ring + 8 * r;
-      if (!grow_ray_intersect(rd[1], rd[2], rd[4] + rd[3], px, py, zb + ph)) continue;  // :592-609
-      const double d = sqrt((rd[5] - zr) * (rd[5] - zr) + (rd[6] - zg) * (rd[6] - zg) + (rd[7] - zc) * (rd[7] - zc));  // :645-654
-      if (d < best_d) {
-        best = r;
-        best_d = d;
+  const int32_t* row = ids + (size_t)p * B;
+  for (int b0 = 0; b0 < B; b0 += kWave) {  // the unmatched blobs of the scan, in scan order (:88-95)
+    const int bl = b0 + lane;
+    unsigned long long vote = __ballot(bl < B && row[bl] == 0);
+    while (vote != 0ull) {  // wave-uniform
+      const int b = b0 + __builtin_ctzll(vote);
+      vote &= vote - 1ull;
+      const double zb = blobs[4 * b], zr = blobs[4 * b + 1], zg = blobs[4 * b + 2], zc = blobs[4 * b + 3];
+      int best = -1;
+      double best_d = INFINITY;
+      for (int r = lane; r < n; r += kWave) {  // find_nearest_reading :566-590 over the stored readings
+        const double* rd = ring + 8 * r;
+        if (!grow_ray_intersect(rd[1], rd[2], rd[4] + rd[3], px, py, zb + ph)) continue;  // :592-609
+        const double d = sqrt((rd[5] - zr) * (rd[5] - zr) + (rd[6] - zg) * (rd[6] - zg) + (rd[7] - zc) * (rd[7] - zc));  // :645-654
+        if (d < best_d) {
+          best = r;
+          best_d = d;
+        }
       }
-    }
-    bool made = false;
-    if (best >= 0 && best_d < g.pair_threshold && used < g.S) {
-      const double* rd = ring + 8 * best;
-      double ox, oy;
-      if (grow_cross_readings(rd[1], rd[2], rd[3] + rd[4], px, py, ph + zb, ox, oy)) {  // add_new_feature :656-686
-        const int l = g.L0 + used;
-        f[(size_t)F_MX * Lp + l] = ox;
-        f[(size_t)F_MY * Lp + l] = oy;
-        f[(size_t)F_MR * Lp + l] = (rd[5] + zr) / 2;
-        f[(size_t)F_MG * Lp + l] = (rd[6] + zg) / 2;
-        f[(size_t)F_MB * Lp + l] = (rd[7] + zc) / 2;
-        f[(size_t)F_PXX * Lp + l] = 1.0;  // identity covariance (:676)
-        f[(size_t)F_PXY * Lp + l] = 0.0;
-        f[(size_t)F_PYY * Lp + l] = 1.0;
-        f[(size_t)F_CRR * Lp + l] = 1.0;
-        f[(size_t)F_CRG * Lp + l] = 0.0;
-        f[(size_t)F_CRB * Lp + l] = 0.0;
-        f[(size_t)F_CGG * Lp + l] = 1.0;
-        f[(size_t)F_CGB * Lp + l] = 0.0;
-        f[(size_t)F_CBB * Lp + l] = 1.0;
-        fc[l] = kPotentialBit;  // update_count 0, potential (the reference's negative id)
-        sid[used] = next_id;
-        ++used;
-        made = true;
+#pragma unroll
+      for (int off = kWave / 2; off >= 1; off >>= 1) {  // the smallest distance, then the smallest index: the reference's first minimum
+        const double od = __shfl_xor(best_d, off);
+        const int orr = __shfl_xor(best, off);
+        if (orr >= 0 && (best < 0 || od < best_d || (od == best_d && orr < best))) {
+          best = orr;
+          best_d = od;
+        }
       }
-    }
-    if (!made) {  // add_orphaned_reading :739-746
-      if (n < g.R) {
-        double* rd = ring + 8 * n;
-        rd[0] = (double)next_id;
-        rd[1] = px;
-        rd[2] = py;
-        rd[3] = ph;
-        rd[4] = zb;
-        rd[5] = zr;
-        rd[6] = zg;
-        rd[7] = zc;
-        ++n;
-      } else {
-        ++dropped;  // (the reference's list grows without bound; the ring holds g.R readings: reported, never silent)
+      bool made = false;
+      if (best >= 0 && best_d < g.pair_threshold && used < g.S) {  // wave-uniform
+        const double* rd = ring + 8 * best;
+        double ox, oy;
+        if (grow_cross_readings(rd[1], rd[2], rd[3] + rd[4], px, py, ph + zb, ox, oy)) {  // add_new_feature :656-686
+          if (lane == 0) {
+            const int l = g.L0 + used;
+            f[(size_t)F_MX * Lp + l] = ox;
+            f[(size_t)F_MY * Lp + l] = oy;
+            f[(size_t)F_MR * Lp + l] = (rd[5] + zr) / 2;
+            f[(size_t)F_MG * Lp + l] = (rd[6] + zg) / 2;
+            f[(size_t)F_MB * Lp + l] = (rd[7] + zc) / 2;
+            f[(size_t)F_PXX * Lp + l] = 1.0;  // identity covariance (:676)
+            f[(size_t)F_PXY * Lp + l] = 0.0;
+            f[(size_t)F_PYY * Lp + l] = 1.0;
+            f[(size_t)F_CRR * Lp + l] = 1.0;
+            f[(size_t)F_CRG * Lp + l] = 0.0;
+            f[(size_t)F_CRB * Lp + l] = 0.0;
+            f[(size_t)F_CGG * Lp + l] = 1.0;
+            f[(size_t)F_CGB * Lp + l] = 0.0;
+            f[(size_t)F_CBB * Lp + l] = 1.0;
+            fc[l] = kPotentialBit;  // update_count 0, potential (the reference's negative id)
+            sid[used] = next_id;
+          }
+          ++used;
+          made = true;
+        }
       }
+      if (!made) {  // add_orphaned_reading :739-746
+        if (n < g.R) {
+          if (lane < 8) {
+            const double v = lane == 0 ? (double)next_id : lane == 1 ? px : lane == 2 ? py : lane == 3 ? ph : lane == 4 ? zb : lane == 5 ? zr : lane == 6 ? zg : zc;
+            ring[8 * n + lane] = v;
+          }
+          ++n;
+          __threadfence_block();  // the next blob's search reads it (other lanes of this wave)
+        } else {
+          ++dropped;  // (the reference's dict grows without bound; the ring holds g.R readings: counted, never silent)
+        }
+      }
+      ++next_id;
     }
-    ++next_id;
   }
-  cnt[0] = n;
-  cnt[1] = used;
-  cnt[2] = next_id;
-  cnt[3] = dropped;
+  if (lane == 0) {
+    cnt[0] = n;
+    cnt[1] = used;
+    cnt[2] = next_id;
+    cnt[3] = dropped;
+  }
 }
 #pragma clang fp contract(on)
 
 void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int32_t* ids_dev, const double* blobs_dev, int B) {
   if (d.P == 0 || B == 0) return;
-  hipLaunchKernelGGL(k_new_landmarks, dim3((unsigned)((d.P + 255) / 256)), dim3(256), 0, s, g, d.x[d.cur], d.y[d.cur], d.h[d.cur], ids_dev,
+  hipLaunchKernelGGL(k_new_landmarks, dim3((unsigned)((d.P + 3) / 4)), dim3(256), 0, s, g, d.x[d.cur], d.y[d.cur], d.h[d.cur], ids_dev,
                      blobs_dev, B, d.map[d.mcur], d.lay.slot_bytes, d.lay.count_off, d.lay.Lp, d.P);
 }
 

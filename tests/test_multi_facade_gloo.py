@@ -232,7 +232,7 @@ if __name__ == "__main__":
     assert "SHARDED-ROS-MODE-OK" in out.stdout, out.stdout + out.stderr
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_new_landmarks_over_sharded_ranks_grow_the_same_maps_as_one_filter(pk, world, tmp_path):
     """SURVEY 8 row (f4) over several ranks: FastSLAM(new_landmarks=True, devices=[...]).  The front end, the command pipes, the
     balanced exchange and the record's tail are the product's protocol; the per-particle arithmetic is the test-only
