@@ -1229,6 +1229,21 @@ __device__ __forceinline__ Noise<double> pub_noise(PubArgsPtr R) {
 // NP: adjacent landmark pairs per lane, THREADS: lanes of the workgroup -- <2, 512>: maps up to 2 048 landmarks, one workgroup
 // per CU (256 VGPRs); <1, 512>: up to 1 024; <1, 256>: up to 512 landmarks, 143 VGPRs: three workgroups per CU work on three
 // particles side by side (the L <= 512 route: what k_step_fused does with a grid walk, a probability queue and seven barriers)
+// Which particle of a turn a workgroup takes.  The dispatcher deals workgroups round the eight XCDs (workgroup b runs on XCD b mod 8);
+// k_step_pub lets the workgroups of ONE XCD take CONSECUTIVE particles of a turn: after a resample the copies of one ancestor stand
+// side by side and read the same source slot -- this way they meet in one L2 (4 MB per XCD) instead of missing in eight.  A/B on one
+// box (profiles/r05/ab_xcd_runs.log): 100 000 x 2 000 8.23-8.27 -> 8.09-8.12 ms in the driver's window.  k_step_pub_big keeps the plain
+// deal: 20 000 x 5 000 gained 1 %, a configs[4] shard lost 2 % on steps 5-24 (few copies yet, and 32 neighbouring 1.16-MB slots
+// written from one XCD) and gained 2 % on steps 40-49.  PK_DIAG_NO_XCD_RUNS: the regression build.
+template <bool RUNS>
+__device__ __forceinline__ unsigned pub_block_index() {
+#ifdef PK_DIAG_NO_XCD_RUNS
+  return blockIdx.x;
+#else
+  const unsigned g = gridDim.x, b = blockIdx.x;
+  return RUNS && (g & 7u) == 0u ? (b & 7u) * (g >> 3) + (b >> 3) : b;
+#endif
+}
 template <int NP, int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(PubArgs a_unused) {
   constexpr int kPubThreads = THREADS, kPubWaves = THREADS / kWave;
@@ -1313,7 +1328,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   int32_t nsrc;
   {
     PubArgsPtr R = pub_args_now(rp);
-    const int64_t p0 = R->p_begin + blockIdx.x;
+    const int64_t p0 = R->p_begin + pub_block_index<true>();
     nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
   }
 #ifdef PK_STAMPS
@@ -1400,7 +1415,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #pragma unroll
     for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(PK_PUB_L0(q, tid0), Lp - 2))
   }
-  for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
+  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<true>();; p += gridDim.x, cur ^= 1) {
     // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
     // occupy registers for the whole kernel)
     unsigned lw = lane_word;
@@ -1877,7 +1892,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   int32_t nsrc;  // the next particle's source slot, asked for a whole particle ahead (as in k_step_pub)
   {
     PubArgsPtr R = pub_args_now(rp);
-    const int64_t p0 = R->p_begin + blockIdx.x;
+    const int64_t p0 = R->p_begin + pub_block_index<false>();
     nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
   }
   // The rows of a pair are asked for as soon as the pair before it is through (into the registers it has just let go):
@@ -1889,7 +1904,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     const int lb0 = min(PK_BIG_L0(0, tid0), Lp - 2);
     PK_BIG_ROWS(SA, SB, lb0, nsrc)
   }
-  for (int64_t p = pub_args_now(rp)->p_begin + blockIdx.x;; p += gridDim.x, cur ^= 1) {
+  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<false>();; p += gridDim.x, cur ^= 1) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int32_t csrc = nsrc;
