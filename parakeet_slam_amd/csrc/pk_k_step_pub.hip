@@ -1235,13 +1235,21 @@ __device__ __forceinline__ Noise<double> pub_noise(PubArgsPtr R) {
 // box (profiles/r05/ab_xcd_runs.log): 100 000 x 2 000 8.23-8.27 -> 8.09-8.12 ms in the driver's window.  k_step_pub_big keeps the plain
 // deal: 20 000 x 5 000 gained 1 %, a configs[4] shard lost 2 % on steps 5-24 (few copies yet, and 32 neighbouring 1.16-MB slots
 // written from one XCD) and gained 2 % on steps 40-49.  PK_DIAG_NO_XCD_RUNS: the regression build.
-template <bool RUNS>
+#ifndef PK_BIG_XCD_RUN  // (tuning builds: runs of 4 / 8 / 16 consecutive particles per XCD in k_step_pub_big)
+#define PK_BIG_XCD_RUN 0
+#endif
+// RUN: 0 the plain deal; -1 the XCD's whole share of a turn in one run; n > 0 (a power of two) runs of n
+template <int RUN>
 __device__ __forceinline__ unsigned pub_block_index() {
 #ifdef PK_DIAG_NO_XCD_RUNS
   return blockIdx.x;
 #else
   const unsigned g = gridDim.x, b = blockIdx.x;
-  return RUNS && (g & 7u) == 0u ? (b & 7u) * (g >> 3) + (b >> 3) : b;
+  if (RUN == 0 || (g & 7u) != 0u) return b;
+  const unsigned x = b & 7u, j = b >> 3;
+  if (RUN < 0) return x * (g >> 3) + j;
+  if (((g >> 3) & (unsigned)(RUN - 1)) != 0u) return b;
+  return (j / (unsigned)RUN) * 8u * (unsigned)RUN + x * (unsigned)RUN + (j & (unsigned)(RUN - 1));
 #endif
 }
 template <int NP, int THREADS>
@@ -1328,7 +1336,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   int32_t nsrc;
   {
     PubArgsPtr R = pub_args_now(rp);
-    const int64_t p0 = R->p_begin + pub_block_index<true>();
+    const int64_t p0 = R->p_begin + pub_block_index<-1>();
     nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
   }
 #ifdef PK_STAMPS
@@ -1415,7 +1423,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #pragma unroll
     for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(PK_PUB_L0(q, tid0), Lp - 2))
   }
-  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<true>();; p += gridDim.x, cur ^= 1) {
+  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<-1>();; p += gridDim.x, cur ^= 1) {
     // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
     // occupy registers for the whole kernel)
     unsigned lw = lane_word;
@@ -1892,7 +1900,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   int32_t nsrc;  // the next particle's source slot, asked for a whole particle ahead (as in k_step_pub)
   {
     PubArgsPtr R = pub_args_now(rp);
-    const int64_t p0 = R->p_begin + pub_block_index<false>();
+    const int64_t p0 = R->p_begin + pub_block_index<PK_BIG_XCD_RUN>();
     nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
   }
   // The rows of a pair are asked for as soon as the pair before it is through (into the registers it has just let go):
@@ -1904,7 +1912,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     const int lb0 = min(PK_BIG_L0(0, tid0), Lp - 2);
     PK_BIG_ROWS(SA, SB, lb0, nsrc)
   }
-  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<false>();; p += gridDim.x, cur ^= 1) {
+  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<PK_BIG_XCD_RUN>();; p += gridDim.x, cur ^= 1) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int32_t csrc = nsrc;
