@@ -430,6 +430,33 @@ def _nl_snapshot(nl):
                               dtype=np.int64).reshape(-1, 3))
 
 
+def _nl_snapshot_arrays(cnt, rd, sid, L0):
+    """_nl_snapshot straight from pk_grow_download's arrays (no per-particle Python objects: a snapshot of 10^5 particles)."""
+    n, used = cnt[:, 0].astype(np.int64), cnt[:, 1].astype(np.int64)
+    offs = np.zeros(cnt.shape[0] + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(n)
+    keep = np.arange(rd.shape[1])[None, :] < n[:, None]
+    in_use = np.arange(sid.shape[1])[None, :] < used[:, None]
+    ii, kk = np.nonzero(in_use)
+    return dict(nl_readings=np.ascontiguousarray(rd[keep], dtype=np.float64).reshape(-1, 8), nl_offsets=offs,
+                nl_next_id=cnt[:, 2].astype(np.int64), nl_used=used,
+                nl_slot_id=np.stack([ii, L0 + kk, sid[in_use].astype(np.int64)], axis=1).astype(np.int64).reshape(-1, 3))
+
+
+def _nl_arrays_from_snapshot(d, P, L0, S, R):
+    """... and back: (counters, readings, slot ids) for pk_grow_upload from a CHECKED snapshot."""
+    offs = np.asarray(d["nl_offsets"], dtype=np.int64)
+    n = np.diff(offs)
+    cnt = np.zeros((P, 4), dtype=np.int32)
+    cnt[:, 0], cnt[:, 1], cnt[:, 2] = n, d["nl_used"], d["nl_next_id"]
+    rd = np.zeros((P, R, 8))
+    rd[np.arange(R)[None, :] < n[:, None]] = np.asarray(d["nl_readings"], dtype=np.float64).reshape(-1, 8)
+    sid = np.zeros((P, S), dtype=np.int32)
+    t = np.asarray(d["nl_slot_id"], dtype=np.int64).reshape(-1, 3)
+    sid[t[:, 0], t[:, 1] - L0] = t[:, 2]
+    return cnt, rd, sid
+
+
 def _nl_check_snapshot(d, P, L0, L, spare, ring=None):
     """Raises ValueError unless d's nl_* arrays fit a filter of P particles, landmarks [L0, L) spare, rings of `ring` readings."""
     offs, rd = d["nl_offsets"], d["nl_readings"]
@@ -875,7 +902,9 @@ class FastSLAM(object):
             poses = self._filter.download_poses()
             m, c, k = self._filter.download_landmarks()
             extra = {}
-            if self._grow:
+            if self._nl_device:
+                extra = _nl_snapshot_arrays(*self._filter.grow_download(), L0=self._L0)
+            elif self._grow:
                 extra = _nl_snapshot(self._nl())
             np.savez_compressed(
                 path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
@@ -906,7 +935,10 @@ class FastSLAM(object):
             self.last_control.linear.x = float(d["last_control"][0])
             self.last_control.angular.z = float(d["last_control"][1])
             self._draw = int(d["draw"])
-            if have_nl:
+            if have_nl and self._nl_device:
+                _, S, R = self._filter.grow_shape()
+                self._filter.grow_upload(0, P, *_nl_arrays_from_snapshot(d, P, self._L0, S, R))
+            elif have_nl:
                 self._nl_assign(*_nl_restore(d, P))
             self._touch()
 

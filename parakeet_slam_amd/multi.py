@@ -545,10 +545,10 @@ class ShardedFastSLAM(object):
             k = np.concatenate([p[2] for p in parts])[self._where]
             extra = {}
             if self._grow:  # the single-GPU facade's nl_* arrays, in the single filter's particle order
-                from .core import _nl_snapshot, _nl_unpack
+                from .core import _nl_snapshot_arrays
 
                 g = self._all("grow", 0, self._P_local)
-                extra = _nl_snapshot(_nl_unpack(*[np.concatenate([q[a] for q in g])[self._where] for a in range(3)], L0=self._L0))
+                extra = _nl_snapshot_arrays(*[np.concatenate([q[a] for q in g])[self._where] for a in range(3)], L0=self._L0)
             np.savez_compressed(
                 path, poses=poses, means=m, covs=c, counts=k, Qt=np.asarray(self.Qt, dtype=np.float64),
                 immutable=np.array([bool(f.__immutable__) for f in self._features], dtype=np.uint8),
@@ -565,12 +565,12 @@ class ShardedFastSLAM(object):
                                  % (d["poses"].shape[0], d["means"].shape[1], P, L))
             nl = None
             if self._grow:
-                from .core import _nl_check_snapshot, _nl_pack, _nl_restore
+                from .core import _nl_arrays_from_snapshot, _nl_check_snapshot
 
                 if "nl_offsets" not in d.files:
                     raise ValueError("snapshot: no new-landmark bookkeeping (nl_* arrays) for a filter with new_landmarks=True")
                 _nl_check_snapshot(d, P, self._L0, L, self._spare, self._reading_capacity)  # before anything is assigned
-                nl = _nl_pack(*_nl_restore(d, P), L0=self._L0, S=self._spare, R=self._reading_capacity)
+                nl = _nl_arrays_from_snapshot(d, P, self._L0, self._spare, self._reading_capacity)
             for r in range(len(self._conns)):
                 s = slice(r * Pl, (r + 1) * Pl)
                 self._post(r, ("set_state", d["poses"][s], d["means"][s] if L else None,
