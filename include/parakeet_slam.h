@@ -272,8 +272,9 @@ int pk_shard_block_totals(pk_filter* f, double gmax, int32_t weight_domain, doub
 int pk_shard_offspring(pk_filter* f, const double* global_totals, int64_t n_global_blocks,
                        int64_t first_block, int64_t global_particles, double u, int32_t last_shard,
                        int64_t* slot_hi);
-/* Bytes of one migrating particle record: header (x, y, heading, log weight, slot_lo, slot_hi)
- * + its landmark slot. */
+/* Bytes of one migrating particle record: a 64-byte header (x, y, heading, log weight, slot_lo, slot_hi, the logical index of the
+ * child in slot_lo, 0) + its landmark slot + -- while the new-landmark bookkeeping is on (pk_grow_enable) -- the particle's
+ * counters, spare-slot ids and stored readings behind the slot. */
 int64_t pk_particle_bytes(const pk_filter* f);
 /* Pack the listed local particles into dev_buf (device pointer owned by the caller, e.g. a
  * torch tensor), n records of pk_particle_bytes. */
