@@ -222,3 +222,58 @@ def test_three_ranks_grow_the_same_maps_as_one_filter(tmp_path):
         assert np.array_equal(a[k], b[k]), ("after the cross-load", k)
     fm.close()
     f1.close()
+
+
+def test_the_first_minimum_wins_over_rings_longer_than_a_wave(lib):
+    """find_nearest_reading keeps the FIRST reading with the smallest colour distance (strict <, :566-590).  The device searches the
+    ring lane-parallel and ends with a butterfly: ties must fall to the smaller index, also when the ring is longer than the 64
+    lanes of the wave.  Rings written by hand (pk_grow_upload), one unmatched blob, the result against GrowingOracle.add_hypothesis."""
+    P, L0, spare, R, thr = 9, 1, 2, 150, 30.0
+    known = np.array([[40.0, 40.0, 250.0, 250.0, 250.0]])
+    kcov = 0.25 * np.identity(5).reshape(1, 5, 5)
+    f = _device_filter(lib, P, known, kcov, spare, thr, R)
+    o = GrowingOracle(P, known, kcov, spare, thr)
+    rs = np.random.RandomState(4)
+    poses = np.zeros((P, 4))
+    poses[:, 0] = rs.uniform(-0.5, 0.5, P)
+    poses[:, 1] = rs.uniform(-0.5, 0.5, P)
+    poses[:, 2] = rs.uniform(-0.2, 0.2, P)
+    poses[:, 3] = 1.0
+    f.upload_poses(poses)
+    o.f.x[:], o.f.y[:], o.f.h[:] = poses[:, 0], poses[:, 1], poses[:, 2]
+    target = np.array([6.0, 3.0])  # where the unknown landmark is: every stored ray and the new one point at it
+    blob_colour = np.array([100.0, 50.0, 20.0])
+    cnt = np.zeros((P, 4), dtype=np.int32)
+    rd = np.zeros((P, R, 8))
+    n_of = [0, 1, 2, 63, 64, 65, 100, 129, 150]
+    for i in range(P):
+        n = n_of[i]
+        cnt[i] = (n, 0, L0 + 1 + n, 0)
+        for r in range(n):
+            ox, oy, oh = rs.uniform(-3, -1), rs.uniform(-3, 3), rs.uniform(-0.3, 0.3)
+            bearing = np.arctan2(target[1] - oy, target[0] - ox) - oh
+            col = blob_colour + rs.uniform(5.0, 9.0, 3) * rs.choice([-1.0, 1.0], 3)
+            rd[i, r] = (L0 + 1 + r, ox, oy, oh, bearing, col[0], col[1], col[2])
+        if n >= 2:  # the nearest colour twice (and a third time beyond lane 64 where the ring is that long): the first one wins
+            best = blob_colour + np.array([1.0, -2.0, 2.0])
+            spots = [q for q in (n - 1, n // 2, 70, 3) if 0 <= q < n]
+            for q in spots:
+                rd[i, q, 5:8] = best
+        o.hyp[i] = [(int(r[0]),) + tuple(float(v) for v in r[1:]) for r in rd[i, :n]]
+        o.next_id[i] = L0 + 1 + n
+    f.grow_upload(0, P, cnt, rd, np.zeros((P, spare), dtype=np.int32))
+    blobs = np.zeros((1, 4))
+    blobs[0, 1:] = blob_colour
+    # (one scan for all particles: the bearing of the target from the mean pose -- the rays still cross near it)
+    blobs[0, 0] = np.arctan2(target[1], target[0])
+    f.observe(blobs, fresh=True)
+    o.f.reset_weights()
+    o.observe(blobs)
+    c2, r2, s2 = f.grow_download()
+    assert np.array_equal(c2[:, 0], [len(h) for h in o.hyp]) and np.array_equal(c2[:, 1], o.used) and np.array_equal(c2[:, 2], o.next_id)
+    assert o.used[0] == 0 and all(u == 1 for u in o.used[1:]), o.used  # (no reading: an orphan; else a pair)
+    m, c, k = f.download_landmarks()
+    assert np.allclose(m[:, L0:], o.f.mean[:, L0:], rtol=1e-9, atol=1e-9)  # the crossing with the FIRST of the equal readings
+    for i in range(1, P):
+        assert int(s2[i, 0]) == o.slot_id[i][L0]
+    f.close()
