@@ -1465,11 +1465,14 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
     if (f->pub_ecap > 0 && cand.rec)
       launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
                       p0, p1, reserve_cus);
-    launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
-                     reserve_cus);
-    // pruned lists (cand.far): k_step_regs' candidate-list instance never takes them (k_cand_entries: skip_cand), so a scan the
-    // publish / subscribe kernel stood back from goes to the fall-back kernels as a whole
-    if (cand.far && f->pub_ecap > 0) launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
+    // pruned lists (cand.far): k_step_regs' candidate-list instance never takes them (k_cand_entries: skip_cand) -- it is not even
+    // launched then (5 us a step for a kernel that returns at once) --, so a scan the publish / subscribe kernel stood back from goes
+    // to the fall-back kernels as a whole
+    if (cand.far && f->pub_ecap > 0)
+      launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
+    else
+      launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
+                       reserve_cus);
   } else {
     if (f->pub_ecap > 0 && cand.rec)
       launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,

@@ -35,6 +35,7 @@ struct ObserveArgs {
   int reset;                          // 1: the weight restarts from 1 (prkt_core_v2.py:73) instead of accumulating
   unsigned long long* gmax_key;       // running max of the new log-weights (double_to_key), or NULL
   int L, Lp, B;
+  int64_t P;
   Noise<double> qt;
 };
 
@@ -110,8 +111,11 @@ template <bool KNOWN, int NV>
 __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double red[kObsThreads / kWave];
-  const int64_t p = blockIdx.x;
-  if (a.only_flagged && (*a.n_flagged == 0u || a.only_flagged[p] != 1)) return;  // workgroup-uniform
+  if (a.only_flagged && *a.n_flagged == 0u) return;  // workgroup-uniform: nobody was handed on
+  // One workgroup per particle -- or, behind a one-pass kernel (only_flagged), a few thousand workgroups that walk the flags: the
+  // stand-by launch of every step then costs 2 us instead of the 22 us that 100 000 workgroups returning at once take to dispatch.
+  for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
+  if (a.only_flagged && a.only_flagged[p] != 1) continue;  // workgroup-uniform
   const int tid = threadIdx.x;
   const int32_t sp = a.src[p];
   const unsigned char* sslot = a.ss.at(sp);
@@ -229,6 +233,8 @@ __global__ void __launch_bounds__(kObsThreads) k_observe(ObserveArgs a) {
     if (a.gmax_key) atomicMax(a.gmax_key + (p & (kGmaxKeys - 1)), double_to_key(v));  // sharded: same-address atomics serialise
     a.src[p] = (int32_t)p;
   }
+  __syncthreads();  // (the LDS tables and the reduction's scratch are the next particle's)
+  }
 }
 
 
@@ -314,7 +320,10 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
   a.L = d.lay.L;
   a.Lp = d.lay.Lp;
   a.B = B;
+  a.P = d.P;
   a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
+  // (behind a one-pass kernel few particles, if any, are flagged: 4 096 workgroups walk the flags)
+  const unsigned grid = (unsigned)(ex.only_flagged && d.P > 4096 ? 4096 : d.P);
   if (ids_dev == nullptr && ex.single_sightings && !ex.only_flagged && d.lay.Lp <= 1024 && g_observe_nv == 0) {
     if (d.lay.Lp <= 256)
       hipLaunchKernelGGL((k_observe_single<256>), dim3((unsigned)d.P), dim3(256), 0, s, a);
@@ -324,9 +333,9 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
       hipLaunchKernelGGL((k_observe_single<1024>), dim3((unsigned)d.P), dim3(1024), 0, s, a);
   } else if (ids_dev == nullptr) {
     if (g_observe_nv == 1)
-      hipLaunchKernelGGL((k_observe<true, 1>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
+      hipLaunchKernelGGL((k_observe<true, 1>), dim3(grid), dim3(kObsThreads), 0, s, a);
     else
-      hipLaunchKernelGGL((k_observe<true, 2>), dim3((unsigned)d.P), dim3(kObsThreads), 0, s, a);
+      hipLaunchKernelGGL((k_observe<true, 2>), dim3(grid), dim3(kObsThreads), 0, s, a);
   } else {
     const size_t lds = observe_general_lds_bytes(d.lay.Lp, B);  // <= kMaxDynLds: checked by the caller
     static bool attr_set[kMaxDevices] = {false};
@@ -336,9 +345,9 @@ void launch_observe(hipStream_t s, DeviceState& d, const double* blobs_dev, cons
           (void)hipGetLastError();
     }
     if (g_observe_nv == 2)
-      hipLaunchKernelGGL((k_observe<false, 2>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
+      hipLaunchKernelGGL((k_observe<false, 2>), dim3(grid), dim3(kObsThreads), lds, s, a);
     else
-      hipLaunchKernelGGL((k_observe<false, 1>), dim3((unsigned)d.P), dim3(kObsThreads), lds, s, a);
+      hipLaunchKernelGGL((k_observe<false, 1>), dim3(grid), dim3(kObsThreads), lds, s, a);
   }
   if (ex.flip) {
     d.mcur ^= 1;
