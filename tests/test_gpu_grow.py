@@ -277,3 +277,12 @@ def test_the_first_minimum_wins_over_rings_longer_than_a_wave(lib):
     for i in range(1, P):
         assert int(s2[i, 0]) == o.slot_id[i][L0]
     f.close()
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_random_growing_scenes_against_the_oracle(lib, seed):
+    rs = np.random.RandomState(seed)
+    L0, U = int(rs.randint(3, 30)), int(rs.randint(1, 5))
+    spare = int(rs.randint(1, U + 3))
+    created, _ = _run(lib, P=int(rs.randint(20, 400)), L0=L0, U=U, spare=spare, steps=int(rs.randint(4, 9)), seed=seed, R=128)
+    assert created >= 1
