@@ -2025,6 +2025,22 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           }
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
+#if defined(PK_STAMPS) && defined(PK_DIAG_BIG_CERTAIN)
+          {  // (diagnostic: how many wave.pairs hold only landmarks whose gate-passing blobs nobody else lists -- DESIGN.md section 10.2)
+            bool cert = true;
+#pragma unroll
+            for (int s_ = 0; s_ < kPubSlots; ++s_) {
+              if (((qa.st >> (4 * s_)) & 1u) && (qa.s[s_] >> 16) != 0xFFFFu) cert = false;
+              if (((qb.st >> (4 * s_)) & 1u) && (qb.s[s_] >> 16) != 0xFFFFu) cert = false;
+            }
+            const unsigned long long bal = __ballot(cert);
+            if ((tid & 63) == 0) {
+              atomicAdd(&pk_pstamp_acc[12], bal == ~0ull ? 1ull : 0ull);
+              atomicAdd(&pk_pstamp_acc[13], 1ull);
+              atomicAdd(&pk_pstamp_acc[14], (unsigned long long)__popcll(bal));
+            }
+          }
+#endif
           PK_STAMP(c3)
           PK_PSTAMP(2, c2, c3)
           pa = pp[0];
