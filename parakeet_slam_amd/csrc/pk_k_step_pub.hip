@@ -1229,29 +1229,49 @@ __device__ __forceinline__ Noise<double> pub_noise(PubArgsPtr R) {
 // NP: adjacent landmark pairs per lane, THREADS: lanes of the workgroup -- <2, 512>: maps up to 2 048 landmarks, one workgroup
 // per CU (256 VGPRs); <1, 512>: up to 1 024; <1, 256>: up to 512 landmarks, 143 VGPRs: three workgroups per CU work on three
 // particles side by side (the L <= 512 route: what k_step_fused does with a grid walk, a probability queue and seven barriers)
-// Which particle of a turn a workgroup takes.  The dispatcher deals workgroups round the eight XCDs (workgroup b runs on XCD b mod 8);
-// k_step_pub lets the workgroups of ONE XCD take CONSECUTIVE particles of a turn: after a resample the copies of one ancestor stand
-// side by side and read the same source slot -- this way they meet in one L2 (4 MB per XCD) instead of missing in eight.  A/B on one
-// box (profiles/r05/ab_xcd_runs.log): 100 000 x 2 000 8.23-8.27 -> 8.09-8.12 ms in the driver's window.  k_step_pub_big keeps the plain
-// deal: 20 000 x 5 000 gained 1 %, a configs[4] shard lost 2 % on steps 5-24 (few copies yet, and 32 neighbouring 1.16-MB slots
-// written from one XCD) and gained 2 % on steps 40-49.  PK_DIAG_NO_XCD_RUNS: the regression build.
-#ifndef PK_BIG_XCD_RUN  // (tuning builds: runs of 4 / 8 / 16 consecutive particles per XCD in k_step_pub_big)
+// Which particles a workgroup takes.  The dispatcher deals workgroups round the eight XCDs (workgroup b runs on XCD b mod 8).  After a
+// resample the copies of one ancestor stand side by side in the particle order and read the SAME source slot: k_step_pub lets every
+// XCD walk a contiguous EIGHTH of the particles, its 32 workgroups on 32 consecutive particles at a time, so that the copies meet in
+// one L2 (4 MB per XCD) -- at the same time, or a turn later -- instead of missing in eight.  A/B on one box (profiles/r05/ab_xcd_*.log):
+// 100 000 x 2 000 in the driver's window 8.33-8.38 ms (dealt round the XCDs: workgroup b on particle b of every turn of 256)
+// -> 8.16-8.18 (the XCD's 32 on consecutive particles of every turn) -> 7.94-7.97 (a contiguous eighth).  k_step_pub_big keeps the
+// plain deal: 20 000 x 5 000 gained 1 %, a configs[4] shard lost 1-2 % on steps 5-24 with runs of 4, 8 or 32 and gained 2 % on steps
+// 40-49 (PK_BIG_XCD_RUN is that tuning build).  PK_DIAG_NO_XCD_RUNS: the regression build, the plain deal everywhere.
+#ifndef PK_BIG_XCD_RUN
 #define PK_BIG_XCD_RUN 0
 #endif
-// RUN: 0 the plain deal; -1 the XCD's whole share of a turn in one run; n > 0 (a power of two) runs of n
+// RUN: 0 the plain deal; n > 0 (a power of two) runs of n consecutive particles of a turn per XCD
 template <int RUN>
 __device__ __forceinline__ unsigned pub_block_index() {
 #ifdef PK_DIAG_NO_XCD_RUNS
   return blockIdx.x;
 #else
   const unsigned g = gridDim.x, b = blockIdx.x;
-  if (RUN == 0 || (g & 7u) != 0u) return b;
+  if (RUN <= 0 || (g & 7u) != 0u || ((g >> 3) & (unsigned)(RUN - 1)) != 0u) return b;
   const unsigned x = b & 7u, j = b >> 3;
-  if (RUN < 0) return x * (g >> 3) + j;
-  if (((g >> 3) & (unsigned)(RUN - 1)) != 0u) return b;
   return (j / (unsigned)RUN) * 8u * (unsigned)RUN + x * (unsigned)RUN + (j & (unsigned)(RUN - 1));
 #endif
 }
+// k_step_pub's walk over the particles [p_begin, p_end): first particle, stride, and where this workgroup's share ends
+#ifdef PK_DIAG_NO_XCD_RUNS
+__device__ __forceinline__ int64_t pub_walk_first(int64_t p_begin, int64_t) { return p_begin + blockIdx.x; }
+__device__ __forceinline__ int64_t pub_walk_stride() { return (int64_t)gridDim.x; }
+__device__ __forceinline__ int64_t pub_walk_limit(int64_t, int64_t p_end) { return p_end; }
+#else
+__device__ __forceinline__ int64_t pub_walk_first(int64_t p_begin, int64_t p_end) {
+  const unsigned g = gridDim.x, b = blockIdx.x;
+  if ((g & 7u) != 0u) return p_begin + b;
+  const int64_t chunk = (p_end - p_begin + 7) / 8;
+  return p_begin + (int64_t)(b & 7u) * chunk + (int64_t)(b >> 3);
+}
+__device__ __forceinline__ int64_t pub_walk_stride() { return (gridDim.x & 7u) != 0u ? (int64_t)gridDim.x : (int64_t)(gridDim.x >> 3); }
+__device__ __forceinline__ int64_t pub_walk_limit(int64_t p_begin, int64_t p_end) {
+  const unsigned g = gridDim.x, b = blockIdx.x;
+  if ((g & 7u) != 0u) return p_end;
+  const int64_t chunk = (p_end - p_begin + 7) / 8, e = p_begin + (int64_t)((b & 7u) + 1u) * chunk;
+  return e < p_end ? e : p_end;
+}
+#endif
 template <int NP, int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(PubArgs a_unused) {
   constexpr int kPubThreads = THREADS, kPubWaves = THREADS / kWave;
@@ -1336,8 +1356,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   int32_t nsrc;
   {
     PubArgsPtr R = pub_args_now(rp);
-    const int64_t p0 = R->p_begin + pub_block_index<-1>();
-    nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
+    const int64_t p0 = pub_walk_first(R->p_begin, R->P), pl = pub_walk_limit(R->p_begin, R->P);
+    nsrc = regs_source_pub(R->src, p0 < pl ? p0 : pl - 1);
   }
 #ifdef PK_STAMPS
   unsigned long long pst[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1423,7 +1443,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
 #pragma unroll
     for (int q = 0; q < kPipe; ++q) PK_PUB_LOAD_PAIR(q, ns, coff, min(PK_PUB_L0(q, tid0), Lp - 2))
   }
-  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<-1>();; p += gridDim.x, cur ^= 1) {
+  for (int64_t p = pub_walk_first(pub_args_now(rp)->p_begin, pub_args_now(rp)->P);; p += pub_walk_stride(), cur ^= 1) {
     // everything derived from the lane index is derived afresh for every particle (hoisted out of the loop those values
     // occupy registers for the whole kernel)
     unsigned lw = lane_word;
@@ -1450,7 +1470,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       // (no branch on `done` in front of the requests: every kernel argument they need comes in one batch; a workgroup
       // that has run out of particles asks for the last particle's rows once more and drops them)
       PubArgsPtr R = pub_args_now(rp);
-      const int64_t Pn = R->P;
+      const int64_t Pn = pub_walk_limit(R->p_begin, R->P);
       done = p >= Pn;
       const int64_t pc = done ? Pn - 1 : p;
       {
@@ -1490,8 +1510,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         // pair's rows are still on their way -- the vector memory counter retires in order)
         {  // the next particle's source slot (pinned here: the wait for it passes under the wait for the first rows)
           PubArgsPtr R4 = pub_args_now(rp);
-          const int64_t pn = p + gridDim.x;
-          nsrc = regs_source_pub(R4->src, pn < R4->P ? pn : R4->P - 1);
+          const int64_t pn = p + pub_walk_stride(), pl = pub_walk_limit(R4->p_begin, R4->P);
+          nsrc = regs_source_pub(R4->src, pn < pl ? pn : pl - 1);
           asm volatile("" : "+s"(nsrc));
         }
         PK_STAMP(s1)
