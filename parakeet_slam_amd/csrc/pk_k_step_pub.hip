@@ -1230,28 +1230,14 @@ __device__ __forceinline__ Noise<double> pub_noise(PubArgsPtr R) {
 // per CU (256 VGPRs); <1, 512>: up to 1 024; <1, 256>: up to 512 landmarks, 143 VGPRs: three workgroups per CU work on three
 // particles side by side (the L <= 512 route: what k_step_fused does with a grid walk, a probability queue and seven barriers)
 // Which particles a workgroup takes.  The dispatcher deals workgroups round the eight XCDs (workgroup b runs on XCD b mod 8).  After a
-// resample the copies of one ancestor stand side by side in the particle order and read the SAME source slot: k_step_pub lets every
-// XCD walk a contiguous EIGHTH of the particles, its 32 workgroups on 32 consecutive particles at a time, so that the copies meet in
-// one L2 (4 MB per XCD) -- at the same time, or a turn later -- instead of missing in eight.  A/B on one box (profiles/r05/ab_xcd_*.log):
-// 100 000 x 2 000 in the driver's window 8.33-8.38 ms (dealt round the XCDs: workgroup b on particle b of every turn of 256)
-// -> 8.16-8.18 (the XCD's 32 on consecutive particles of every turn) -> 7.94-7.97 (a contiguous eighth).  k_step_pub_big keeps the
-// plain deal: 20 000 x 5 000 gained 1 %, a configs[4] shard lost 1-2 % on steps 5-24 with runs of 4, 8 or 32 and gained 2 % on steps
-// 40-49 (PK_BIG_XCD_RUN is that tuning build).  PK_DIAG_NO_XCD_RUNS: the regression build, the plain deal everywhere.
-#ifndef PK_BIG_XCD_RUN
-#define PK_BIG_XCD_RUN 0
-#endif
-// RUN: 0 the plain deal; n > 0 (a power of two) runs of n consecutive particles of a turn per XCD
-template <int RUN>
-__device__ __forceinline__ unsigned pub_block_index() {
-#ifdef PK_DIAG_NO_XCD_RUNS
-  return blockIdx.x;
-#else
-  const unsigned g = gridDim.x, b = blockIdx.x;
-  if (RUN <= 0 || (g & 7u) != 0u || ((g >> 3) & (unsigned)(RUN - 1)) != 0u) return b;
-  const unsigned x = b & 7u, j = b >> 3;
-  return (j / (unsigned)RUN) * 8u * (unsigned)RUN + x * (unsigned)RUN + (j & (unsigned)(RUN - 1));
-#endif
-}
+// resample the copies of one ancestor stand side by side in the particle order and read the SAME source slot: the publish / subscribe
+// kernels let every XCD walk a contiguous EIGHTH of the particles, its 32 workgroups on 32 consecutive particles at a time, so that
+// the copies meet in one L2 (4 MB per XCD) -- at the same time, or a turn later -- instead of missing in eight.  A/B on one box
+// (profiles/r05/ab_xcd_*.log): k_step_pub, 100 000 x 2 000 in the driver's window: 8.33-8.38 ms (dealt round the XCDs: workgroup b on
+// particle b of every turn of 256) -> 8.16-8.18 (the XCD's 32 on consecutive particles of every turn) -> 7.94-7.97 (a contiguous
+// eighth).  k_step_pub_big: 20 000 x 5 000 6.18 -> 6.10 ms, a configs[4] shard 40.8 -> 40.8 ms on steps 5-24 and 29.2 -> 28.7 on steps
+// 40-49 (runs of 4, 8 or 32 particles of every turn had lost 1-2 % on steps 5-24: ab_big_xcd_runs_4_8.log).
+// PK_DIAG_NO_XCD_RUNS: the regression build, the plain deal.
 // k_step_pub's walk over the particles [p_begin, p_end): first particle, stride, and where this workgroup's share ends
 #ifdef PK_DIAG_NO_XCD_RUNS
 __device__ __forceinline__ int64_t pub_walk_first(int64_t p_begin, int64_t) { return p_begin + blockIdx.x; }
@@ -1822,6 +1808,10 @@ int step_pub_big_entry_capacity(int B) {
 }
 size_t step_pub_big_lds_bytes(int B, int ecap) { return pub_big_fixed_lds_bytes(B) + (size_t)ecap * 8; }
 
+// (k_step_pub's walk: a contiguous eighth of the particles per XCD)
+#define PK_BIG_FIRST(R_) pub_walk_first((R_)->p_begin, (R_)->P)
+#define PK_BIG_STRIDE() pub_walk_stride()
+#define PK_BIG_LIMIT(R_) pub_walk_limit((R_)->p_begin, (R_)->P)
 template <int NCH>
 __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1920,8 +1910,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   int32_t nsrc;  // the next particle's source slot, asked for a whole particle ahead (as in k_step_pub)
   {
     PubArgsPtr R = pub_args_now(rp);
-    const int64_t p0 = R->p_begin + pub_block_index<PK_BIG_XCD_RUN>();
-    nsrc = regs_source_pub(R->src, p0 < R->P ? p0 : R->P - 1);
+    const int64_t p0 = PK_BIG_FIRST(R), pl = PK_BIG_LIMIT(R);
+    nsrc = regs_source_pub(R->src, p0 < pl ? p0 : pl - 1);
   }
   // The rows of a pair are asked for as soon as the pair before it is through (into the registers it has just let go):
   // pair q + 1 behind pair q's verdicts in pass 1, pass 2's first pair behind the last verdicts (its rows fly during the
@@ -1932,7 +1922,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     const int lb0 = min(PK_BIG_L0(0, tid0), Lp - 2);
     PK_BIG_ROWS(SA, SB, lb0, nsrc)
   }
-  for (int64_t p = pub_args_now(rp)->p_begin + pub_block_index<PK_BIG_XCD_RUN>();; p += gridDim.x, cur ^= 1) {
+  for (int64_t p = PK_BIG_FIRST(pub_args_now(rp));; p += PK_BIG_STRIDE(), cur ^= 1) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int32_t csrc = nsrc;
@@ -1949,7 +1939,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     bool done;
     {
       PubArgsPtr R = pub_args_now(rp);
-      done = p >= R->P;
+      done = p >= PK_BIG_LIMIT(R);
     }
     PK_STAMP(b0)
     // ---- pass 1: gates and verdicts, pair by pair
@@ -1996,8 +1986,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           // 8.08 ms -- the keys follow the gates too closely here; profiles/r04/ab_big_late_cov_rows.log)
           if (q == 0) {  // the next particle's source slot (as in k_step_pub)
             PubArgsPtr R4 = pub_args_now(rp);
-            const int64_t pn = p + gridDim.x;
-            nsrc = regs_source_pub(R4->src, pn < R4->P ? pn : R4->P - 1);
+            const int64_t pn = p + PK_BIG_STRIDE(), pl = PK_BIG_LIMIT(R4);
+            nsrc = regs_source_pub(R4->src, pn < pl ? pn : pl - 1);
             asm volatile("" : "+s"(nsrc));
           }
           PK_BIG_WAIT_ALL
