@@ -1985,6 +1985,9 @@ int pk_grow_enable(pk_filter* f, int32_t preset_landmarks, int32_t reading_capac
   if (reading_capacity < 1 || reading_capacity > 65536) return fail(PK_ERR_INVALID, "pk_grow_enable: reading_capacity %d outside 1..65536", reading_capacity);
   if (!(pair_threshold >= 0.0)) return fail(PK_ERR_INVALID, "pk_grow_enable: pair_threshold %g", pair_threshold);
   if (f->grow_on) return fail(PK_ERR_STATE, "pk_grow_enable: already enabled on this filter");
+  if (f->dense)
+    return fail(PK_ERR_STATE, "pk_grow_enable: the bookkeeping kernel writes the compact landmark layout; this filter is on the dense one "
+                              "(a covariance or Qt that couples position and colour)");
   int rc;
   if ((rc = use_device(f))) return rc;
   GrowState& g = f->grow;
