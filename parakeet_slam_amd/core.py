@@ -615,7 +615,13 @@ class FastSLAM(object):
         self._nl_device = self._grow and self._spare > 0 and bookkeeping == "device"
         self._nl_cache = None
         if self._nl_device:
-            self._filter.grow_enable(L, int(reading_capacity), self._pair_threshold)
+            try:
+                self._filter.grow_enable(L, int(reading_capacity), self._pair_threshold)
+            except _lib.PkError as e:
+                if e.status != _lib.PK_ERR_STATE:
+                    raise
+                self._filter.close()
+                raise ValueError("%s -- FastSLAM(..., bookkeeping='host') keeps the new-landmark bookkeeping on the host, on any layout" % e)
         else:
             self._nl_host = dict(
                 hyp=[[] for _ in range(P)],          # orphaned readings: (id, x, y, heading, bearing, r, g, b)  (:739-746)

@@ -286,3 +286,23 @@ def test_random_growing_scenes_against_the_oracle(lib, seed):
     spare = int(rs.randint(1, U + 3))
     created, _ = _run(lib, P=int(rs.randint(20, 400)), L0=L0, U=U, spare=spare, steps=int(rs.randint(4, 9)), seed=seed, R=128)
     assert created >= 1
+
+
+def test_the_dense_layout_takes_the_host_bookkeeping(lib):
+    """A preset covariance that couples position and colour puts the filter on the dense layout: the device
+    bookkeeping says so at construction, and bookkeeping='host' works there as in rounds 2-4."""
+    import parakeet_slam_amd as pk
+
+    world, covs = synthetic_world(6)
+    covs = covs.copy()
+    covs[:, 0, 2] = covs[:, 2, 0] = 0.01
+    feats = [pk.Feature(mean=world[l].copy(), covar=covs[l].copy()) for l in range(4)]
+    pk.msgs.Time.set_now(0.0)
+    with pytest.raises(ValueError, match="bookkeeping='host'"):
+        pk.FastSLAM(feats, num_particles=8, new_landmarks=True, spare_landmarks=2)
+    fs = pk.FastSLAM(feats, num_particles=8, new_landmarks=True, spare_landmarks=2, bookkeeping="host", weight_domain="log")
+    pk.msgs.Time.set_now(0.1)
+    fs.cam_cb(_View(pk, synthetic_scan(world, (0.0, 0.0, 0.0))))
+    # (six blobs, two of them of landmarks the preset map does not hold: an id each, two stored readings)
+    assert fs._filter.observe_route() == "dense" and all(n >= 4 + 1 + 2 for n in fs._next_id) and all(len(h) >= 2 for h in fs._hyp)
+    fs.close()
