@@ -553,3 +553,39 @@ def test_a_whole_scan_the_kernel_stands_back_from_gets_second_chance_rows_for_ev
     for x, y in zip(a[1], g.download_landmarks()):
         assert np.array_equal(x, y)
     g.close()
+
+
+@pytest.mark.parametrize("L,reserve", [(600, 16), (600, 10), (600, 3), (2600, 16), (2600, 5)])
+def test_the_xcd_walk_covers_every_particle_of_odd_ranges_and_grids(lib, L, reserve):
+    """Round 5: the publish / subscribe kernels let every XCD walk a contiguous eighth of the launch's particles (pub_walk_*).  An
+    observe in pieces -- ranges that are no multiple of anything, a first piece launched on a grid that is (reserve 16 -> 240
+    workgroups) or is not (10 -> 246, 3 -> 253: the plain deal) a multiple of eight -- must leave exactly the state of the observe
+    in one piece: every particle taken once, none twice."""
+    from oracle.fastslam_oracle import synthetic_scan, synthetic_world, truth_step
+
+    P = 1237
+    means, covs = synthetic_world(L)
+    rs = np.random.RandomState(3)
+    z = rs.standard_normal((P, 3))
+    pose = truth_step((0.0, 0.0, 0.0), 0.2, 0.1, 0.1)
+    blobs = synthetic_scan(means, pose)
+    out = []
+    for pieces in (None, [(0, 1), (1, 8), (8, 13), (13, 700), (700, 1236), (1236, 1237)], [(0, 1237)], [(0, 530), (530, 1237)]):
+        f = lib.DeviceFilter(P, L)
+        f.set_option("split_reserve_cus", reserve)
+        f.upload_map(means, covs.reshape(L, 25))
+        f.motion(0.2, 0.1, 0.1, z=z)
+        f.stage_scan(blobs)
+        if pieces is None:
+            f.observe_staged(fresh=True)
+        else:
+            assert f.staged_takes_regs()
+            for i, (p0, p1) in enumerate(pieces):
+                f.observe_staged_range(True, p0, p1, i == 0, i == len(pieces) - 1)
+        route = f.observe_route()
+        out.append((f.download_log_weights(), f.download_landmarks(), f.observe_flagged()))
+        f.close()
+    assert route in ("ml_regs", "ml_pub_big")
+    for lw, (m, c, k), fl in out[1:]:
+        assert np.array_equal(k, out[0][1][2]) and np.array_equal(m, out[0][1][0]) and np.array_equal(c, out[0][1][1])
+        assert np.allclose(lw, out[0][0], rtol=1e-12, atol=1e-12)
