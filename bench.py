@@ -70,6 +70,28 @@ def measured_traffic(P, L, variant):
     return best
 
 
+def measured_traffic_window(P, L, route):
+    """The same counters over the DRIVER'S WINDOW (scripts/gpu_pmc_window.sh: the mean over the 25 launches of bench.py --steps 20
+    --warmup 5 at this size, profiles/*/pmc_traffic_window_*.json), or None.  The newest round wins."""
+    key = SQ_KERNEL_KEY.get(route)
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if (key and os.path.isdir(pdir)) else []:
+        rdir = os.path.join(pdir, rnd)
+        for name in sorted(os.listdir(rdir)) if os.path.isdir(rdir) else []:
+            if not (name.startswith("pmc_traffic_window") and name.endswith(".json")):
+                continue
+            try:
+                d = json.load(open(os.path.join(rdir, name)))
+            except ValueError:
+                continue
+            if d["config"]["particles"] == P and d["config"]["landmarks"] == L:
+                for k, v in d["bytes_per_launch"].items():
+                    if k.startswith(key):
+                        best = v
+    return best
+
+
 CLOCK_GHZ = 2.4   # MI355X_MICROARCH.md: peak engine clock
 N_SIMD = 1024     # 256 CUs x 4 SIMDs
 SQ_KERNEL_KEY = {"ml_regs_pub": "k_step_pub<2, 512>", "ml_fused": "k_step_fused", "ml_fused_pub": "k_step_pub<1, 256>", "ml_pub_big": "k_step_pub_big",
@@ -433,6 +455,10 @@ def roofline_object(P, L, route, obs_ms, obs_n, stride, K, copy_gbs):
         "traffic_source": "builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this configuration (separate "
         "passes, bytes = (2*FETCH + WRITE)*1024; FETCH counts Infinity-Cache hits too), replayed from "
         "profiles/*/pmc_traffic*.json -- not collected by this run; null when no pass exists for this size",
+        "traffic_window": measured_traffic_window(P, L, route),
+        "traffic_window_source": "the same two counters over bench.py --steps 20 --warmup 5 at this size (the driver's window and its warm-up: "
+        "mean of the 25 launches), scripts/gpu_pmc_window.sh, replayed from profiles/*/pmc_traffic_window_*.json; `traffic` above is the "
+        "pass over three EARLY steps of a fresh filter, where few particles are copies of one ancestor yet; null when no pass exists",
         "copy_measured": copy_gbs,
         "frac_of_copy": achieved / copy_gbs if copy_gbs else None,
         "avg_launch_ms": obs_avg_s * 1e3,
