@@ -3,7 +3,8 @@
 #   a  stamps per phase and per wave, 15 steps before the measured three (the scan-level pruning needs a map seen a few times):
 #      k_step_pub 51 200 x 2 000, k_step_fused 10 000 x 500, k_step_pub_big 20 480 x 5 000 (also 45 steps in: the steady state)
 #   b  rocprofv3 --kernel-trace --stats of ONLY the timed filter (the driver's window), configs[2] and 20 000 x 5 000
-#   c  PMC traffic (FETCH / WRITE passes) at 100 000 x 2 000, 20 000 x 5 000 and at the size the driver times configs[4]'s shard, 125 000 x 5 000
+#   c  PMC traffic (FETCH / WRITE passes) at 100 000 x 2 000, 20 000 x 5 000 and at the size the driver times configs[4]'s shard, 125 000 x 5 000:
+#      three early steps of a fresh filter (gpu_pmc_traffic2.sh) and the driver's window (gpu_pmc_window.sh)
 #   d  SQ counters over the driver's window (warm-up 5, 20 steps) at 51 200 x 2 000, 20 480 x 5 000, 10 240 x 500
 #   e  bench lines: the driver's own command, the default 50 steps, 20 000 x 5 000
 #   f  N > 1 rehearsals on the one GPU (gloo): 4 ranks x 20 000 x 2 000 with both placements, 5 ranks x 20 000 x 5 000
@@ -33,6 +34,10 @@ if [[ $PARTS == *c* ]]; then
 bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -2; cp gpurun_out/pmc_traffic_100000x2000.json $O/
 PMC_P=20000 PMC_L=5000 bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_20000x5000.json $O/
 PMC_P=125000 PMC_L=5000 bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_125000x5000.json $O/
+# ... and over the driver's window (bench.py's own 25 launches)
+bash scripts/gpu_pmc_window.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_window_100000x2000.json $O/
+PMC_P=20000 PMC_L=5000 bash scripts/gpu_pmc_window.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_window_20000x5000.json $O/
+PMC_P=125000 PMC_L=5000 bash scripts/gpu_pmc_window.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_window_125000x5000.json $O/
 fi
 if [[ $PARTS == *d* ]]; then
 for cfg in "51200 2000 200" "20480 5000 80" "10240 500 40"; do
