@@ -19,17 +19,17 @@ import sys
 # k_step_fused: 121 against 99; k_assoc_grid<768, ...>: 168 + 44-52 B of scratch against 137-141 / none, and its 512-lane
 # instances 207 against 121).
 _NO_LICM = ["-mllvm", "-disable-machine-licm"]
-EXTRA_FLAGS = {"pk_k_observe_ml.hip": _NO_LICM, "pk_k_step_pub.hip": _NO_LICM, "pk_k_assoc.hip": _NO_LICM}
+EXTRA_FLAGS = {"pk_k_observe_ml.hip": _NO_LICM, "pk_k_step_pub.hip": _NO_LICM, "pk_k_cand_entries.hip": _NO_LICM, "pk_k_assoc.hip": _NO_LICM}
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libparakeet_slam.so")
 OBJDIR = os.path.join(HERE, "csrc", "_obj")
 
-HIP_SOURCES = ["pk_k_motion.hip", "pk_k_assoc.hip", "pk_k_observe.hip", "pk_k_observe_ml.hip", "pk_k_step_pub.hip", "pk_k_dense.hip", "pk_k_resample.hip", "pk_k_grow.hip", "pk_api.hip"]
+HIP_SOURCES = ["pk_k_motion.hip", "pk_k_assoc.hip", "pk_k_observe.hip", "pk_k_observe_ml.hip", "pk_k_step_pub.hip", "pk_k_cand_entries.hip", "pk_k_dense.hip", "pk_k_resample.hip", "pk_k_grow.hip", "pk_api.hip"]
 CXX_SOURCES = ["pk_rng.cpp"]  # host-only, no FMA contraction: must match NumPy/CPython bit for bit
 HEADERS = [
-    "pk_math.hpp", "pk_layout.hpp", "pk_kernels.hpp", "pk_philox.hpp", "pk_device.hpp",
+    "pk_math.hpp", "pk_layout.hpp", "pk_kernels.hpp", "pk_philox.hpp", "pk_device.hpp", "pk_pub_math.hpp", "pk_pub_layout.hpp",
     os.path.join("..", "..", "include", "parakeet_slam.h"),
 ]
 
