@@ -535,6 +535,14 @@ class ShardedFastSLAM(object):
             self._one(r, "set_particle", j, (x, y, h, float(particle.weight)), m, c, k)
             self._pose_cache = None
 
+    def readings_dropped(self):
+        """As ``FastSLAM.readings_dropped``: orphaned readings that found a particle's ring full, over all ranks (0 = the device
+        bookkeeping is the reference's)."""
+        if not self._grow:
+            return 0
+        with self._lock:
+            return int(sum(int(np.asarray(g[0])[:, 3].sum()) for g in self._all("grow", 0, self._P_local)))
+
     # ------------------------------------------------------------------ snapshot / restore (the single-GPU facade's format)
     def save_state(self, path):
         with self._lock:

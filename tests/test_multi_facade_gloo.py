@@ -288,6 +288,7 @@ def test_new_landmarks_over_sharded_ranks_grow_the_same_maps_as_one_filter(pk, w
                 kinds = max(kinds, same_as_the_one_filter())
         kinds = max(kinds, same_as_the_one_filter())
         assert max(o.used) >= 2 and kinds > 1, "the scene shows nothing: every particle held the same bookkeeping at every check"
+        assert fs.readings_dropped() == 0
         # the object view of a particle wherever it lives now (:278-292)
         i = P - 2
         p = fs.particles[i]
