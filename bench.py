@@ -294,6 +294,17 @@ def cpu_baseline(L, budget_s=20.0):
     return out
 
 
+def env_options(filt):
+    """Tuning experiments only: PK_OPT_<NAME>=<int> in the environment sets the library option <name> on a filter of this run
+    (scripts/gpu_ab_env.sh); the line says so in `env_options`."""
+    done = {}
+    for name, val in sorted(os.environ.items()):
+        if name.startswith("PK_OPT_") and val != "":
+            filt.set_option(name[7:].lower(), int(val))
+            done[name[7:].lower()] = int(val)
+    return done
+
+
 def workload_name(P, L, assoc):
     tag = CONFIGS.get((P, L))
     head = "BASELINE.json %s" % tag if tag else "custom size (not a BASELINE.json config)"
@@ -325,14 +336,11 @@ def self_launch(args, argv):
     # collective that never completes) can be stopped as a whole, by handle -- no retry, no re-exec: the parent reports and
     # exits non-zero.  The ranks themselves give up on the rendezvous and on any collective after 120 s
     # (init_process_group(timeout=)), which normally ends the launch long before this limit.
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
-    try:
-        stdout, _ = proc.communicate(timeout=args.launch_timeout)
-    except subprocess.TimeoutExpired:
-        import signal
+    import signal
 
-        sys.stderr.write("bench.py --gpus %d: the %d-rank launch did not finish within %.0f s; stopping it\n"
-                         % (args.gpus, args.gpus, args.launch_timeout))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+
+    def stop_ranks():
         for sig in (signal.SIGTERM, signal.SIGKILL):
             try:
                 os.killpg(proc.pid, sig)  # the group we started, nothing else
@@ -343,7 +351,25 @@ def self_launch(args, argv):
                 break
             except subprocess.TimeoutExpired:
                 continue
+
+    # (the ranks' own session no longer hears a SIGTERM / SIGINT sent to this process -- an outer `timeout` would
+    # leave them running on the GPU beside whatever starts next.  The parent passes the signal on to the group it started and exits.)
+    def on_signal(signum, _frame):
+        sys.stderr.write("bench.py --gpus %d: signal %d; stopping the %d ranks\n" % (args.gpus, signum, args.gpus))
+        stop_ranks()
+        raise SystemExit(128 + signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        stdout, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py --gpus %d: the %d-rank launch did not finish within %.0f s; stopping it\n"
+                         % (args.gpus, args.gpus, args.launch_timeout))
+        stop_ranks()
         raise SystemExit(6)
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
     proc = subprocess.CompletedProcess(cmd, proc.returncode, stdout)
     line = None
     for raw in proc.stdout.decode("utf-8", "replace").splitlines():
@@ -570,10 +596,7 @@ def main():
     else:
         filt = _lib.DeviceFilter(P, L, device=local_rank)
     filt.upload_map(means, covs.reshape(L, 25))
-    for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_CAND_LISTS",
-                 "PK_OPT_REGS_RETRY", "PK_OPT_SPLIT_RESERVE_CUS", "PK_OPT_PUB_STEP", "PK_OPT_PUB_SMALL", "PK_OPT_FAR_PRUNE"):  # tuning experiments only
-        if os.environ.get(name):
-            filt.set_option(name[7:].lower(), int(os.environ[name]))
+    env_options(filt)
     if os.environ.get("PK_OBSERVE_NV"):  # tuning experiments only
         filt.set_option("observe_landmarks_per_lane", int(os.environ["PK_OBSERVE_NV"]))
     rnd = random.Random(7)
@@ -783,6 +806,7 @@ def main():
             m4, c4, s4 = synthetic_inputs(L4, n4)
             ws4 = synthetic_controls(n4)
             f4 = _lib.DeviceFilter(P4, L4, device=local_rank)
+            env_options(f4)
             f4.upload_map(m4, c4.reshape(L4, 25))
             rnd4 = random.Random(7)
             us4 = [rnd4.random() for _ in range(n4)]

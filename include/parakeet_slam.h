@@ -117,6 +117,11 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    there, one lane per contested blob picks the winner; two landmark pairs per lane, 512 lanes -- while
  *                    the table fits LDS and no candidate list overflows; decided per scan on the device,
  *                    pk_observe_published) or 0 (k_step_regs: per-blob counters, probability queue, bids);
+ *   "pub_duo"      = 1 (default) or 0: maps of 2 049 .. 6 144 landmarks: a scan whose publish table fits HALF a CU's LDS is worked
+ *                    on by k_step_pub_duo -- the two-pass kernel k_step_pub_big with one landmark per lane and turn, at most 128
+ *                    VGPRs, so that TWO workgroups share a CU and one's memory waits are the other's arithmetic; decided per scan
+ *                    on the device (pk_observe_pub_stats); "pub_duo_park_limit" >= 0 (tests) treats its overflow area -- where a
+ *                    landmark with several blobs of probability > 0 parks its slots between the passes -- as that many places;
  *   "far_prune"    = 1 (default) or 0: once per scan, the look-alikes whose match probability is certainly 0 for every particle
  *                    (a key beyond the float64 underflow edge by the reference particle's bound with margins) leave the candidate
  *                    lists of the publish / subscribe kernels; a landmark whose own bound is weaker re-checks them itself
@@ -432,6 +437,14 @@ int pk_observe_retry_rows(pk_filter* f, int64_t* wanted, int64_t* capacity);
  * static publish / subscribe through LDS, three barriers per particle -- 0 when k_step_regs did (the publish table did
  * not fit LDS, a candidate list overflowed, or "pub_step" is off).  Synchronises the stream. */
 int pk_observe_published(pk_filter* f, int32_t* published);
+/* What the last scan's publish table came to (instrumentation; written by k_cand_entries on the device, once per scan):
+ * stats[0] entries of the table (every (landmark, blob) pair several landmarks contend for, prkt_core_v2.py:353-381),
+ * [1] contested blobs, [2] landmarks of the reference particle with two or more blobs inside their own gates (:433, :441),
+ * [3] the longest candidate list, [4] entries the LDS table was given, [5] which instance worked on the scan: 0 none of the
+ * publish / subscribe kernels (the table did not fit, a list overflowed), 1 the one-workgroup-per-CU instance, 2 the
+ * two-workgroups-per-CU instance of the two-pass kernel (k_step_pub_duo, option "pub_duo").  All zero when the last observe
+ * took another route.  Synchronises the stream. */
+int pk_observe_pub_stats(pk_filter* f, int64_t stats[6]);
 /* Per particle, how the last one-pass maximum-likelihood observe (k_step_fused / k_step_pub / k_step_pub_big / k_step_regs)
  * dealt with it (instrumentation; what the full-size oracle audits of tests/test_gpu_audit.py pick their samples by):
  * flags[P], 0 = settled by the one-pass kernel itself, 2 = redone by the second-chance route (eight-slot hand-off +

@@ -112,6 +112,7 @@ SIGNATURES = {
     "pk_grow_shape": (C.c_int, [_h, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pk_observe_published": (C.c_int, [_h, C.POINTER(C.c_int32)]),
     "pk_observe_flags": (C.c_int, [_h, _bp]),
+    "pk_observe_pub_stats": (C.c_int, [_h, _lp]),
     "pk_rng_create_numpy": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_create_python": (C.c_int, [C.c_uint32, C.POINTER(_h)]),
     "pk_rng_destroy": (C.c_int, [_h]),
@@ -440,6 +441,14 @@ class DeviceFilter(object):
         a, b = C.c_int64(), C.c_int64()
         check(self._lib.pk_observe_flagged(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def observe_pub_stats(self):
+        """The last scan's publish table (pk_observe_pub_stats): dict of entries, contested blobs, landmarks of the reference
+        particle with several blobs inside their gates, longest candidate list, entry capacity, instance (0 none, 1 one
+        workgroup per CU, 2 k_step_pub_duo)."""
+        a = np.zeros(6, dtype=np.int64)
+        check(self._lib.pk_observe_pub_stats(self._h, lptr(a)))
+        return dict(zip(("entries", "contested_blobs", "multi_landmarks", "longest_list", "entry_capacity", "instance"), (int(v) for v in a)))
 
     # ---- new landmarks on the device (SURVEY 8 row f4; pk_grow_enable) ----
     def grow_enable(self, preset_landmarks, reading_capacity=64, pair_threshold=30.0):

@@ -29,7 +29,7 @@ OBJDIR = os.path.join(HERE, "csrc", "_obj")
 HIP_SOURCES = ["pk_k_motion.hip", "pk_k_assoc.hip", "pk_k_observe.hip", "pk_k_observe_ml.hip", "pk_k_step_pub.hip", "pk_k_cand_entries.hip", "pk_k_dense.hip", "pk_k_resample.hip", "pk_k_grow.hip", "pk_api.hip"]
 CXX_SOURCES = ["pk_rng.cpp"]  # host-only, no FMA contraction: must match NumPy/CPython bit for bit
 HEADERS = [
-    "pk_math.hpp", "pk_layout.hpp", "pk_kernels.hpp", "pk_philox.hpp", "pk_device.hpp", "pk_pub_math.hpp", "pk_pub_layout.hpp",
+    "pk_math.hpp", "pk_layout.hpp", "pk_kernels.hpp", "pk_philox.hpp", "pk_device.hpp", "pk_pub_math.hpp", "pk_pub_layout.hpp", "pk_k_step_duo.inl",
     os.path.join("..", "..", "include", "parakeet_slam.h"),
 ]
 

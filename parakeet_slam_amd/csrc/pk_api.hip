@@ -146,11 +146,14 @@ struct pk_filter {
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
   int pub_small = 0;     // L <= 512: k_step_pub<256 lanes> instead of k_step_fused (measured: the kernel 1 % slower, the step 50 us longer)
+  int duo_park_limit = -1;  // >= 0: k_step_pub_duo's overflow area is treated as this small (tests: particles that need more go to the fall-back kernels)
+  int duo_on = 1;        // 2 048 < L <= 6 144: scans whose publish table fits HALF a CU's LDS go to k_step_pub_duo (two workgroups per CU, <= 128 VGPRs), the others to k_step_pub_big
   int pub_entry_limit = 0;  // > 0: the publish table is treated as this small (tests: scans whose table "does not fit" fall back to k_step_regs)
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
   unsigned char* npass_dev = nullptr; // [Lp + kCandSpare] per landmark: blobs inside the reference particle's own gates (k_candidates)
+  uint4* prim_dev = nullptr;     // the two-pass kernels' primary-blob table: every landmark's first candidate in landmark order (prim_table_uint4; k_cand_entries)
   float4* gate4_dev = nullptr;   // [bcand_cap] every blob's bearing and colour as float: k_step_pub_big's first look (k_cand_entries)
   uint4* far_dev = nullptr;      // [Lp + kCandSpare][3] per landmark: the bound its list was pruned with | its far list (k_candidates, pk_pub_math.hpp)
   int far_prune = 1;             // look-alikes certainly beyond the underflow edge leave the candidate lists once per scan (0: as round 4)
@@ -280,7 +283,7 @@ int use_device(pk_filter* f) {
 //   known ids:  [first Lp i32] [next B i32]
 //   ML:         [dir 2B f64] [exact 6B f64] [association tables]
 // The copy also zeroes ctl, which is how every observe starts with a fresh max / count.
-constexpr size_t kCtlBytes = 8 * kGmaxKeys + 32;  // running-max keys, then the flagged-particle count and the route control words
+constexpr size_t kCtlBytes = 8 * kGmaxKeys + 64;  // running-max keys, then the flagged-particle count, the route control words and the publish table's figures
 int ensure_scan_capacity(pk_filter* f, size_t bytes) {
   if (bytes <= f->scan_cap) return PK_OK;
   PK_HIP(hipStreamSynchronize(f->stream));
@@ -594,6 +597,14 @@ inline unsigned* ctl_skip_pub(pk_filter* f) { return reinterpret_cast<unsigned*>
 inline unsigned* ctl_skip_cand(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 16); }
 // rows of the second-chance hand-off lists dealt out so far (FastHandoff::row_next)
 inline unsigned* ctl_retry_rows(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 20); }
+// written by k_cand_entries: != 0 -> the two-workgroups-per-CU instance of the two-pass kernel (k_step_pub_duo) stands back and
+// k_step_pub_big takes the scan (the publish table, the contested blobs or the landmarks with several blobs exceed its share of LDS)
+inline unsigned* ctl_skip_duo(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 24); }
+// ... != 0 -> k_step_pub_big stands back (no publish / subscribe kernel takes the scan, or k_step_pub_duo does)
+inline unsigned* ctl_skip_big(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 28); }
+// what the scan's publish table came to (k_cand_entries; pk_observe_pub_stats): entries, contested blobs, landmarks of the reference
+// particle with two or more blobs inside their gates, the longest candidate list
+inline unsigned* ctl_pub_stats(pk_filter* f) { return reinterpret_cast<unsigned*>(f->scan_dev + 8 * kGmaxKeys + 32); }
 
 // Host half of the ML scan upload: blobs, ray directions, exact records and the association tables
 // are laid out in a pinned staging slot (no device work; may synchronise only to grow buffers).
@@ -985,7 +996,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev, (void*)f->far_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev, (void*)f->far_dev, (void*)f->prim_dev})
     if (q) (void)hipFree(q);
   for (int i = 0; i < 2; ++i)
     for (void* q : {(void*)f->grow.hyp[i], (void*)f->grow.cnt[i], (void*)f->grow.slot_id[i]})
@@ -1099,7 +1110,7 @@ int pk_upload_poses(pk_filter* f, const double* xyhw) {
     soa[P + i] = xyhw[4 * i + 1];
     soa[2 * P + i] = xyhw[4 * i + 2];
     double w = xyhw[4 * i + 3];
-    if (!(w >= 0.0)) return fail(PK_ERR_INVALID, "pk_upload_poses: weight of particle %lld is negative or NaN", (long long)i);
+    if (!(w >= 0.0) || !std::isfinite(w)) return fail(PK_ERR_INVALID, "pk_upload_poses: weight of particle %lld is negative, infinite or NaN", (long long)i);
     soa[3 * P + i] = std::log(w);
   }
   const int c = f->d.cur;
@@ -1120,16 +1131,15 @@ int pk_upload_pose(pk_filter* f, int64_t p, const double xyhw[4]) {
   if (p < 0 || p >= f->d.P) return fail(PK_ERR_INVALID, "pk_upload_pose: particle %lld of %lld", (long long)p, (long long)f->d.P);
   for (int i = 0; i < 3; ++i)
     if (!std::isfinite(xyhw[i])) return fail(PK_ERR_INVALID, "pk_upload_pose: pose component %d is not finite", i);
-  if (!(xyhw[3] >= 0.0)) return fail(PK_ERR_INVALID, "pk_upload_pose: the weight is negative or NaN");
+  // (+inf passed "w >= 0", and log(inf) turns the log-domain scan into NaN / all-zero weights)
+  if (!(xyhw[3] >= 0.0) || !std::isfinite(xyhw[3])) return fail(PK_ERR_INVALID, "pk_upload_pose: the weight is negative, infinite or NaN");
   int rc;
   if ((rc = use_device(f))) return rc;
   f->pose_part_ok = false;
-  const double lw = std::log(xyhw[3]);
+  const double v4[4] = {xyhw[0], xyhw[1], xyhw[2], std::log(xyhw[3])};
   const int c = f->d.cur;
-  PK_HIP(hipMemcpyAsync(f->d.x[c] + p, &xyhw[0], 8, hipMemcpyHostToDevice, f->stream));
-  PK_HIP(hipMemcpyAsync(f->d.y[c] + p, &xyhw[1], 8, hipMemcpyHostToDevice, f->stream));
-  PK_HIP(hipMemcpyAsync(f->d.h[c] + p, &xyhw[2], 8, hipMemcpyHostToDevice, f->stream));
-  PK_HIP(hipMemcpyAsync(f->d.logw[c] + p, &lw, 8, hipMemcpyHostToDevice, f->stream));
+  double* const dst[4] = {f->d.x[c] + p, f->d.y[c] + p, f->d.h[c] + p, f->d.logw[c] + p};
+  for (int i = 0; i < 4; ++i) PK_HIP(hipMemcpyAsync(dst[i], &v4[i], 8, hipMemcpyHostToDevice, f->stream));
   PK_HIP(hipStreamSynchronize(f->stream));
   f->gmax_fused = false;
   return PK_OK;
@@ -1385,6 +1395,15 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
   }
   return PK_OK;
 }
+// what k_step_pub_duo has room for at this scan size (all zero: the instance is off, k_step_pub_big takes every scan)
+static DuoLimits duo_limits(const pk_filter* f, int B) {
+  DuoLimits d;
+  if (!f->duo_on) return d;
+  step_pub_duo_limits(B, f->d.lay.Lp, &d);
+  if (f->pub_entry_limit > 0 && d.ecap > f->pub_entry_limit) d.ecap = f->pub_entry_limit;
+  d.park_limit = f->duo_park_limit;
+  return d;
+}
 // ref: the particle whose MAP the candidate lists are made from -- particle 0, or in a split step the first particle of the range
 // that has been filled already (the slots at either end still hold the old generation then)
 static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand, int64_t ref = 0) {
@@ -1399,6 +1418,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     if (!f->erec_dev2 && (rc = dev_alloc(f, &f->erec_dev2, ((size_t)f->d.lay.Lp + kCandSpare) * 2))) return rc;
     if ((rc = ensure_inverse_lists(f, B, 2 * kCandSlots))) return rc;
     if (!f->far_dev && (rc = dev_alloc(f, &f->far_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
+    if (!f->prim_dev && (rc = dev_alloc(f, &f->prim_dev, prim_table_uint4(f->d.lay.Lp)))) return rc;
     int ecap = step_pub_big_entry_capacity(B);
     if (f->pub_entry_limit > 0 && ecap > f->pub_entry_limit) ecap = f->pub_entry_limit;
     Span t(f, PK_T_ASSOC);
@@ -1409,7 +1429,8 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
     launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
                       2 * kCandSlots, f->out4, f->npass_dev, far, part);
     launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev, f->npass_dev, far != nullptr);
+                        ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev, f->npass_dev, far != nullptr,
+                        ctl_pub_stats(f), ctl_skip_duo(f), ctl_skip_big(f), duo_limits(f, B), f->prim_dev);
     cand->rec = f->cand_dev;
     cand->far = far;
     cand->over = ctl_cand_over(f);
@@ -1437,7 +1458,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
       launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
                         kCandSlots, f->out4, f->npass_dev, far, part);
       launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                          ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev, far != nullptr);
+                          ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev, far != nullptr, ctl_pub_stats(f));
       cand->far = far;
       cand->skip_cand = ctl_skip_cand(f);
       f->pub_ecap = ecap;
@@ -1457,8 +1478,14 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
   ObserveExtras e1 = ex;
   e1.flip = false;
   if (al.big) {
-    launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_pub(f), f->pub_ecap, f->gate4_dev,
-                        p0, p1, reserve_cus);
+    // the scan goes to ONE of the two instances (k_cand_entries decided which: the two-workgroups-per-CU instance when its share of
+    // LDS holds the scan's publish table); both are launched, one returns at once
+    const DuoLimits duo = duo_limits(f, B);
+    if (duo.tbytes > 0)
+      launch_step_pub_duo(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_duo(f), ctl_pub_stats(f), duo,
+                          f->gate4_dev, f->prim_dev, p0, p1, reserve_cus);
+    launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_big(f), f->pub_ecap, f->gate4_dev,
+                        p0, p1, reserve_cus, f->prim_dev, ctl_pub_stats(f));
     // a scan the kernel stood back from (a list overflowed, the table did not fit): every particle to the fall-back kernels
     launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
   } else if (al.regs) {
@@ -1825,6 +1852,15 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     f->far_prune = value != 0;
     return PK_OK;
   }
+  if (!strcmp(name, "pub_duo")) {
+    f->duo_on = value != 0;
+    return PK_OK;
+  }
+  if (!strcmp(name, "pub_duo_park_limit")) {
+    if (value < -1 || value > 65535) return fail(PK_ERR_INVALID, "pub_duo_park_limit: -1 (what LDS holds) .. 65535");
+    f->duo_park_limit = (int)value;
+    return PK_OK;
+  }
   if (!strcmp(name, "pub_entry_limit")) {
     if (value < 0 || value > 65534) return fail(PK_ERR_INVALID, "pub_entry_limit: 0 (what LDS holds) .. 65534");
     f->pub_entry_limit = (int)value;
@@ -2125,6 +2161,9 @@ int64_t pk_particle_bytes(const pk_filter* f) { return f ? (int64_t)record_strid
 
 int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* dev_buf) {
   if (!f || n < 0 || (n > 0 && (!local_idx || !dev_buf))) return fail(PK_ERR_INVALID, "pk_pack_particles: bad argument");
+  // (pk_particle_bytes() counts the bookkeeping's tail, k_pack writes records without one -- and pk_adopt_particles
+  // would leave readings and id counters on the wrong particles)
+  if (f->grow_on) return fail(PK_ERR_STATE, "pk_pack_particles: the new-landmark bookkeeping (pk_grow_enable) travels with the balanced placement only (pk_shard_*_balanced_dev)");
   if (n > f->d.P) return fail(PK_ERR_INVALID, "pk_pack_particles: %lld records from %lld particles", (long long)n, (long long)f->d.P);
   for (int64_t i = 0; i < n; ++i)
     if (local_idx[i] < 0 || local_idx[i] >= f->d.P) return fail(PK_ERR_INVALID, "pk_pack_particles: index %lld out of range", (long long)local_idx[i]);
@@ -2144,6 +2183,7 @@ int pk_pack_particles(pk_filter* f, const int64_t* local_idx, int64_t n, void* d
 int pk_adopt_particles(pk_filter* f, const int64_t* src, const void* dev_buf, int64_t n_received) {
   if (f) f->pose_part_ok = false;  // (the poses change: the motion launch's pose sums are no longer theirs)
   if (!f || !src || n_received < 0 || (n_received > 0 && !dev_buf)) return fail(PK_ERR_INVALID, "pk_adopt_particles: bad argument");
+  if (f->grow_on) return fail(PK_ERR_STATE, "pk_adopt_particles: the new-landmark bookkeeping (pk_grow_enable) travels with the balanced placement only (pk_shard_*_balanced_dev)");
   const int64_t P = f->d.P;
   for (int64_t k = 0; k < P; ++k)
     if (src[k] >= P || src[k] < -n_received) return fail(PK_ERR_INVALID, "pk_adopt_particles: src[%lld] = %lld out of range", (long long)k, (long long)src[k]);
@@ -2764,6 +2804,24 @@ int pk_observe_published(pk_filter* f, int32_t* published) {
     PK_HIP(hipMemcpyAsync(&w, ctl_skip_pub(f), sizeof(w), hipMemcpyDeviceToHost, f->stream));
     PK_HIP(hipStreamSynchronize(f->stream));
     *published = w == 0u ? 1 : 0;
+  }
+  return PK_OK;
+}
+int pk_observe_pub_stats(pk_filter* f, int64_t stats[6]) {
+  if (!f || !stats) return fail(PK_ERR_INVALID, "pk_observe_pub_stats: NULL argument");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  for (int i = 0; i < 6; ++i) stats[i] = 0;
+  if (f->scan_dev && (f->route == PK_ROUTE_ML_REGS || f->route == PK_ROUTE_ML_FUSED || f->route == PK_ROUTE_ML_PUB_BIG) && f->pub_ecap > 0) {
+    unsigned w[4] = {0u, 0u, 0u, 0u}, sk[2] = {1u, 1u};
+    PK_HIP(hipMemcpyAsync(w, ctl_pub_stats(f), sizeof(w), hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipMemcpyAsync(&sk[0], ctl_skip_pub(f), sizeof(unsigned), hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipMemcpyAsync(&sk[1], ctl_skip_duo(f), sizeof(unsigned), hipMemcpyDeviceToHost, f->stream));
+    PK_HIP(hipStreamSynchronize(f->stream));
+    for (int i = 0; i < 4; ++i) stats[i] = w[i];
+    stats[4] = f->pub_ecap;
+    // which instance worked on the scan: 0 none of the publish / subscribe kernels, 1 the one-workgroup-per-CU instance, 2 k_step_pub_duo
+    stats[5] = sk[0] != 0u ? 0 : (f->route == PK_ROUTE_ML_PUB_BIG && f->duo_on && sk[1] == 0u) ? 2 : 1;
   }
   return PK_OK;
 }

@@ -27,6 +27,14 @@ struct CandEntriesArgs {
   const unsigned char* npass;  // [Lp] blobs inside the reference's own gates (k_candidates), or null
   unsigned* skip_pub;
   unsigned* skip_cand;
+  unsigned* skip_duo;  // k_step_pub_duo (two workgroups per CU: half the LDS each) stands back when != 0, or null
+  unsigned* skip_big;  // k_step_pub_big stands back when != 0 (nobody's scan, or k_step_pub_duo's), or null
+  unsigned* stats;     // [4] out, or null: entries of the publish table, contested blobs, landmarks of the reference particle with two
+                       // or more blobs inside their own gates, the longest candidate list
+  DuoLimits duo;
+  uint4* prim;  // out, or null: the PRIMARY blob of every landmark -- of its candidates the closest in colour -- moved to the front of its
+                // list, and that blob's records in LANDMARK order (pk_pub_layout.hpp: prim_*), so that the two-pass kernels read them
+                // side by side instead of gathering them blob by blob
   int L, Lp, B, ecap;
   int pruned;  // the lists have had their far look-alikes taken off (k_candidates): only the publish / subscribe kernels, which check
                // every landmark's own bound against the scan's, may use them -- k_step_regs' candidate-list instance always stands back
@@ -65,6 +73,11 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   constexpr bool kRankMajor = SLOTS > kCandSlots;  // (sixteen-entry lists: k_step_pub_big; k_step_pub keeps blob-major, +0.6 % otherwise)
   __shared__ unsigned s_tot[SLOTS + 1], s_cbase[SLOTS + 1], s_rbase[SLOTS];
   __shared__ unsigned s_total, s_sw[16];
+  __shared__ unsigned s_multi, s_longest;
+  if (threadIdx.x == 0) {
+    s_multi = 0u;
+    s_longest = 0u;
+  }
   __shared__ unsigned short s_cls[kRankMajor ? SLOTS + 1 : 1][1024];  // per class (number of contenders) and thread: its blobs of the class, then their scan
   __shared__ unsigned char s_len[kPubBigMaxL + kCandSpare + 14], s_np[kPubBigMaxL + kCandSpare + 14];  // per landmark: list length, npass
   const int tid = threadIdx.x;
@@ -174,6 +187,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     *a.skip_pub = fits ? 0u : 1u;
     *a.skip_cand = (*a.over != 0u || fits || a.pruned != 0) ? 1u : 0u;
   }
+  unsigned my_multi = 0u, my_longest = 0u;
   __syncthreads();  // brec / binfo written above are read below by other threads of this (the only) workgroup
   __threadfence_block();
   constexpr int RW = 1 + SLOTS / 8;  // uint4 per landmark record
@@ -192,6 +206,61 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
       cw[4 * j + 1] = lw[j].y;
       cw[4 * j + 2] = lw[j].z;
       cw[4 * j + 3] = lw[j].w;
+    }
+    if (a.prim) {  // (kernel-uniform)
+      // The landmark's PRIMARY blob to the front of its list: of its candidates the one closest in colour to the reference particle's
+      // landmark -- its own blob wherever one is in sight.  (The order of a list decides nothing: k_candidates fills it in the order
+      // its atomics arrive in.)  The gates' first candidate, the verdicts' first slot and the blob the update applies are then nearly
+      // always THIS blob, whose records the kernels read in landmark order -- sixteen lanes a cache line -- instead of blob by blob, a
+      // line per lane: those gathers were 70 % of the two-pass kernels' accesses to the vector cache (profiles/r06/pmc_ta_*.json).
+      const uint4 ref = a.cand[RW * (size_t)l];
+      const double rr = (double)__uint_as_float(ref.y), rg = (double)__uint_as_float(ref.z), rb = (double)__uint_as_float(ref.w);
+      int best = 0;
+      double bd = 1e300;
+#pragma unroll
+      for (int k = 0; k < SLOTS; ++k) {
+        const unsigned t = (cw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        if (t != 0xFFFFu && l < a.L) {
+          const double* e = a.exact + 6 * (size_t)t;
+          const double d1 = e[1] - rr, d2 = e[2] - rg, d3 = e[3] - rb;
+          const double d = d1 * d1 + d2 * d2 + d3 * d3;
+          if (d < bd) {  // (NaN: never the best)
+            bd = d;
+            best = k;
+          }
+        }
+      }
+      if (best != 0) {  // swap the entries 0 and best
+        unsigned tb = 0xFFFFu;
+        const unsigned t0 = cw[0] & 0xFFFFu;
+#pragma unroll
+        for (int k = 1; k < SLOTS; ++k)
+          if (k == best) tb = (cw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+#pragma unroll
+        for (int k = 1; k < SLOTS; ++k)
+          if (k == best) cw[k >> 1] = (cw[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | (t0 << (16 * (k & 1)));
+        cw[0] = (cw[0] & 0xFFFF0000u) | tb;
+        uint4* cand_rw = const_cast<uint4*>(a.cand);
+#pragma unroll
+        for (int j = 0; j < SLOTS / 8; ++j) cand_rw[RW * (size_t)l + 1 + j] = make_uint4(cw[4 * j + 0], cw[4 * j + 1], cw[4 * j + 2], cw[4 * j + 3]);
+      }
+      const unsigned t0 = l < a.L ? (cw[0] & 0xFFFFu) : 0xFFFFu;
+      const size_t Lpp = (size_t)a.Lp + kCandSpare;
+      double z[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (t0 != 0xFFFFu) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) z[c] = a.exact[6 * (size_t)t0 + c];
+      }
+      // (the float record exactly as gate4[t0] below has it)
+      const bool ok = fabs(z[0]) <= 8.0 && fabs(z[1]) <= 1000.0 && fabs(z[2]) <= 1000.0 && fabs(z[3]) <= 1000.0;  // NaN: false
+      const unsigned nanw = 0x7FC00000u;
+      a.prim[l] = ok ? make_uint4(__float_as_uint((float)z[0]), __float_as_uint((float)z[1]), __float_as_uint((float)z[2]), __float_as_uint((float)z[3]))
+                     : make_uint4(nanw, nanw, nanw, nanw);
+      double2* pz = reinterpret_cast<double2*>(a.prim);
+      pz[Lpp + l] = make_double2(z[0], z[1]);
+      pz[2 * Lpp + l] = make_double2(z[2], z[3]);
+      pz[3 * Lpp + l] = make_double2(z[4], z[5]);
+      reinterpret_cast<unsigned*>(a.prim + 4 * Lpp)[l] = t0;
     }
 #pragma unroll
     for (int h = 0; h < SLOTS / BATCH; ++h) {
@@ -230,8 +299,29 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     }
     s_len[l] = (unsigned char)len;
     s_np[l] = (a.npass && l < a.L) ? a.npass[l] : (unsigned char)0;
+    my_multi += (l < a.L && s_np[l] >= 2) ? 1u : 0u;
+    my_longest = max(my_longest, l < a.L ? (unsigned)len : 0u);
   }
+  if (my_multi) atomicAdd(&s_multi, my_multi);
+  if (my_longest) atomicMax(&s_longest, my_longest);
   __syncthreads();
+  if (tid == 0) {
+    // The two-workgroups-per-CU instance (k_step_pub_duo) has half a CU's LDS: it takes the scan when the list of contested blobs
+    // fits its place and the publish table leaves room for the landmarks that will park their slots -- estimated from the reference
+    // particle: the landmarks with two or more blobs inside their own gates, a quarter and 64 to spare (a particle that needs more
+    // goes to the fall-back kernels, as exact as ever); k_step_pub_big takes every other scan that a publish / subscribe kernel can.
+    const unsigned G_ = a.glist[a.B];
+    const unsigned tab = ((s_total + 1u) & ~1u) * 8u + 16u, park = 16u * (s_multi + s_multi / 4u + 64u);
+    const bool duo_ok = fits && a.duo.tbytes > 0 && s_total <= (unsigned)a.duo.ecap && G_ <= (unsigned)a.duo.gcap && tab + park <= (unsigned)a.duo.tbytes;
+    if (a.skip_duo) *a.skip_duo = duo_ok ? 0u : 1u;
+    if (a.skip_big) *a.skip_big = (fits && !duo_ok) ? 0u : 1u;
+    if (a.stats) {
+      a.stats[0] = s_total;
+      a.stats[1] = G_;
+      a.stats[2] = s_multi;
+      a.stats[3] = s_longest;
+    }
+  }
   // k_step_pub_big's first look at a candidate: bearing and colour as FLOAT, 16 bytes in one gather instead of 32 in two (the
   // kernel is bound by the texture addresser's gathers, one cache line a cycle: DESIGN.md section 4).  The margins of that
   // look (pub_gatesN<GT>) hold for |bearing| <= 8 and |colour| <= 1000; any other blob -- NaN and infinities included -- gets
@@ -311,8 +401,14 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap, int slots, const double* exact_dev, float4* gate4_dev,
-                         const unsigned char* npass_dev, bool pruned) {
+                         const unsigned char* npass_dev, bool pruned, unsigned* stats_dev, unsigned* skip_duo_dev, unsigned* skip_big_dev,
+                         const DuoLimits& duo, uint4* prim_dev) {
   CandEntriesArgs a;
+  a.prim = (exact_dev && slots > kCandSlots) ? prim_dev : nullptr;
+  a.stats = stats_dev;
+  a.skip_duo = skip_duo_dev;
+  a.skip_big = skip_big_dev;
+  a.duo = duo;
   a.pruned = pruned ? 1 : 0;
   a.npass = npass_dev;
   a.exact = exact_dev;

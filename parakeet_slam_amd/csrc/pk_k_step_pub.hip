@@ -94,6 +94,26 @@ struct PubArgs {
   int reset;
   unsigned long long* gmax_key;
   Noise<double> qt;
+  // (k_step_pub_duo only; behind everything the other kernels read)
+  const unsigned* stats;        // [4] k_cand_entries' figures of this scan: [0] the entries of its publish table, [3] its longest list
+  int tbytes;                   // bytes of LDS the publish table and the overflow area share
+  const uint4* prim;            // the two-pass kernels: every landmark's primary blob in landmark order (prim_table_uint4), or null
+};
+
+// The PRIMARY blob of a landmark -- the front of its candidate list: k_cand_entries puts the candidate closest in colour there -- has
+// its records in a table in LANDMARK order (pk_kernels.hpp: prim_table_uint4).  Wherever every lane of a wave wants exactly that blob
+// (the gates' first candidate: always; the verdicts' first slot, the blob the update applies: nearly always) the two-pass kernels
+// read the table -- neighbouring lanes, neighbouring addresses -- instead of gathering the scan's records blob by blob, a cache line
+// a lane.  Same bytes either way (k_cand_entries copies them), so the same results bit for bit.
+struct PubPrim {
+  const uint4* tab;  // the table (uniform)
+  size_t Lpp;        // landmarks + spare records: the planes' stride (uniform)
+  int lc;            // the lane's first landmark (landmark j of the lane: lc + j)
+  // (addresses are made where they are used: held as three per-lane pointers from the gates to the verdicts they cost six VGPRs)
+  __device__ __forceinline__ double2 z01(int j) const { return reinterpret_cast<const double2*>(tab + Lpp)[lc + j]; }      // exact bearing, r
+  __device__ __forceinline__ double2 z23(int j) const { return reinterpret_cast<const double2*>(tab + 2 * Lpp)[lc + j]; }  // exact g, b
+  __device__ __forceinline__ double2 dir(int j) const { return reinterpret_cast<const double2*>(tab + 3 * Lpp)[lc + j]; }  // ray direction
+  __device__ __forceinline__ unsigned t0(int j) const { return reinterpret_cast<const unsigned*>(tab + 4 * Lpp)[lc + j]; }  // the blob (0xFFFF: none)
 };
 
 // dynamic LDS: exact records 48 B | publish table 8 (ecap + 2: a dump entry, padding) | binfo 4 B | order 2 B |
@@ -167,10 +187,12 @@ struct PubGateIn {
 // particles on some stretches of the bench's trajectory and sent them through the second-chance kernels).
 // GT: the first look at a candidate goes to the float table gt (see k_cand_entries): certain either way for all but a candidate in
 // a million, and only a wave with an uncertain one reads exact records (ex is global memory then, k_step_pub_big)
-template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false, bool GT = false>
+// PRIM (with GT): pga[pgi + j] = the float record of landmark j's FIRST candidate in the primary-blob table (plane 0, uniform base and
+// the lane's first landmark: read where the gather it replaces stood, so that no register is held longer than before)
+template <int N, int W4 = 1, int SL = kPubSlots, bool OVF = false, bool GT = false, bool PRIM = false>
 __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_out)[N], const PubGateIn (&in)[N], const double* ex,
                                            double* pub, unsigned dump, int* flag, double sx, double sy, double sh,
-                                           const float4* gt = nullptr) {
+                                           const float4* gt = nullptr, const float4* pga = nullptr, int pgi = 0) {
   constexpr int NW = 4 * W4;  // 32-bit words per list, two candidates each
   double eb[N];
   bool inside[N];
@@ -218,7 +240,10 @@ __device__ __forceinline__ void pub_gatesN(PubSlotsT<SL> (&q)[N], double (&pse_o
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         const unsigned ta = c[j][kk] & 0xFFFFu, tb = c[j][kk] >> 16;
-        nfa[j] = gt[ta != 0xFFFFu ? ta : 0u];
+        if (PRIM && kk == 0)  // (the front of the list: its record came side by side with the neighbours')
+          nfa[j] = pga[pgi + j];
+        else
+          nfa[j] = gt[ta != 0xFFFFu ? ta : 0u];
         nfb[j] = gt[tb != 0xFFFFu ? tb : 0u];
       }
     }
@@ -397,11 +422,12 @@ struct PubNoChk {
 // needs no settling, +0.6 % -- ab_counted_settling.log.)
 // CHK: the lists have had their far look-alikes taken off (k_candidates): the landmarks' own bounds are held against the scan's
 // (pub_far_recheck), W4F uint4 words per far list
-template <int N, int SL = kPubSlots, bool PRE = false, bool CHK = false, int W4F = 1, class Chk = PubNoChk>
+// PRIM: a round in which every lane's blob is its landmark's primary one reads the records from the primary-blob table (prim)
+template <int N, int SL = kPubSlots, bool PRE = false, bool CHK = false, int W4F = 1, class Chk = PubNoChk, bool PRIM = false>
 __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<double>* const (&lmp)[N],
                                           const double (&pse)[N], const double* ex, double* pub, unsigned dump, unsigned char* any,
                                           unsigned anydump, int* flag, double sx, double sy, const double* pre_kbase = nullptr,
-                                          const double* pre_itr3 = nullptr, const Chk& chk = Chk()) {
+                                          const double* pre_itr3 = nullptr, const Chk& chk = Chk(), const PubPrim* prim = nullptr) {
   bool nobody;  // wave-uniform: nobody's landmark passes a blob
   {
     unsigned sall = q[0].s[0];
@@ -481,15 +507,40 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
     double2 z01[N], z23[N];
     double d1[N], d2c[N], d3c[N];
     const double* rec[N];
+    // PRIM: the blob's three 16-byte words stand at rb0 + roff, + rks, + 2 rks -- in the scan's records (48-byte records, blob by blob:
+    // a gather) or, in a round in which EVERY lane's blob is its landmark's primary one (wave-uniform: the first round, nearly always),
+    // in the primary-blob table (planes in landmark order: neighbouring lanes, neighbouring addresses).  One code path, a uniform base
+    // and a 32-bit offset per landmark: no register more than the gather took.
+    unsigned roff[N];
+    const char* rb0 = nullptr;
+    size_t rks = 0;
+    if constexpr (PRIM) {
+      bool offp = false;
+#pragma unroll
+      for (int j = 0; j < N; ++j) offp |= (q[j].s[0] & 0xFFFFu) != 0xFFFFu && (q[j].s[0] & 0xFFFFu) != prim->t0(j);
+      const bool onp = __ballot(offp) == 0ull;
+      rb0 = onp ? reinterpret_cast<const char*>(prim->tab + prim->Lpp) : reinterpret_cast<const char*>(ex);
+      rks = onp ? prim->Lpp * 16 : (size_t)16;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const unsigned tj = q[j].s[0] & 0xFFFFu;
+        roff[j] = onp ? (unsigned)(prim->lc + j) * 16u : (tj != 0xFFFFu ? tj : 0u) * 48u;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       const Landmark<double>& lm = *lmp[j];
       t[j] = q[j].s[0] & 0xFFFFu;
       e[j] = q[j].s[0] >> 16;
       valid[j] = t[j] != 0xFFFFu;
-      rec[j] = ex + 6 * (valid[j] ? t[j] : 0u);
-      z01[j] = *reinterpret_cast<const double2*>(rec[j]);
-      z23[j] = *reinterpret_cast<const double2*>(rec[j] + 2);
+      if constexpr (PRIM) {
+        z01[j] = *reinterpret_cast<const double2*>(rb0 + roff[j]);
+        z23[j] = *reinterpret_cast<const double2*>(rb0 + rks + roff[j]);
+      } else {
+        rec[j] = ex + 6 * (valid[j] ? t[j] : 0u);
+        z01[j] = *reinterpret_cast<const double2*>(rec[j]);
+        z23[j] = *reinterpret_cast<const double2*>(rec[j] + 2);
+      }
       d1[j] = z01[j].y - lm.mr;
       d2c[j] = z23[j].x - lm.mg;
       d3c[j] = z23[j].y - lm.mb;
@@ -505,7 +556,11 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
 #pragma unroll
       for (int j = 0; j < N; ++j) {
         const Landmark<double>& lm = *lmp[j];
-        const double2 dir = *reinterpret_cast<const double2*>(rec[j] + 4);
+        double2 dir;
+        if constexpr (PRIM)
+          dir = *reinterpret_cast<const double2*>(rb0 + 2 * rks + roff[j]);
+        else
+          dir = *reinterpret_cast<const double2*>(rec[j] + 4);
         // prob_position_match :457-494, prob_color_match :524-544
         const bool angle_ok = !(fabs(pse[j] - z01[j].x) > Consts<double>::half_pi);  // :473-475
         double nx, ny;
@@ -811,8 +866,12 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
 
 // The same with ONE copy of the update code, in a loop that nearly always turns once (the 256-lane instance: 145 VGPRs
 // instead of 181; on the large instance 0.7 % slower than the two-path form above).
+// PRIM: a turn in which every lane applies its landmark's primary blob (t0; nearly always) reads that blob's exact record from the
+// primary-blob table -- ptab its plane 1 (uniform), pstride the planes' stride in bytes, pidx the landmark -- instead of gathering
+template <bool PRIM = false>
 __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
-                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
+                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse,
+                                            const char* ptab = nullptr, size_t pstride = 0, int pidx = 0, unsigned t0 = 0xFFFFu) {
   double acc = 0.0;
   unsigned tk = q.st & 0x4444u;
   bool fresh = true;
@@ -838,10 +897,18 @@ __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double
         bit = first ? (4u << (4 * s)) : bit;
       }
     }
+    const char* rb0 = reinterpret_cast<const char*>(ex);
+    size_t rks = 16;
+    bool onp = false;  // wave-uniform
+    if constexpr (PRIM) {
+      onp = __ballot(tk != 0u && (w & 0xFFFFu) != t0) == 0ull;
+      rb0 = onp ? ptab : rb0;
+      rks = onp ? pstride : rks;
+    }
     if (tk != 0u) {
-      const double* rec = ex + 6 * (w & 0xFFFFu);
-      const double2 z01 = *reinterpret_cast<const double2*>(rec);
-      const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
+      const unsigned roff = (PRIM && onp) ? (unsigned)pidx * 16u : (w & 0xFFFFu) * 48u;
+      const double2 z01 = *reinterpret_cast<const double2*>(rb0 + roff);
+      const double2 z23 = *reinterpret_cast<const double2*>(rb0 + rks + roff);
       BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
       acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
       fresh = imm;
@@ -1634,14 +1701,22 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           PubGateIn gi[2];
           gi[0].ref = cr[0];
           gi[0].cw[0] = cr[1];
-          gi[0].cw[1] = cr[2];
           gi[1].ref = cr[3];
           gi[1].cw[0] = cr[4];
-          gi[1].cw[1] = cr[5];
           gi[0].ew[0] = er[0];
-          gi[0].ew[1] = er[1];
           gi[1].ew[0] = er[2];
-          gi[1].ew[1] = er[3];
+          gi[0].cw[1] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+          gi[1].cw[1] = gi[0].cw[1];
+          gi[0].ew[1] = gi[0].cw[1];
+          gi[1].ew[1] = gi[0].cw[1];
+          // (some landmark lists more than eight candidates: the second list word is read at all -- k_cand_entries' figure of the scan,
+          // read here with the turn's other scalars: held across the particle loop it was one scalar register too many)
+          if (R->stats[3] > (unsigned)kCandSlots) {  // kernel-uniform: once the lists are pruned, hardly ever (round 6: a third of the records' cache lines)
+            gi[0].cw[1] = cr[2];
+            gi[1].cw[1] = cr[5];
+            gi[0].ew[1] = er[1];
+            gi[1].ew[1] = er[3];
+          }
           const uint4* frow = R->far;
           const bool far_hdr_on = frow != nullptr;
           uint4 fh0 = make_uint4(0u, 0u, 0u, 0u), fh1 = fh0;
@@ -1689,7 +1764,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
           // the gates look at a candidate's float copy first (one 16-byte gather instead of two of the 48-byte record: 8.11 -> 7.75 ms,
           // ab_big_gate_float_table.log) and give look-alikes beyond the underflow edge no slot (-> 7.29 ms, ab_big_far_in_gates.log);
           // the verdicts take the key's constant term and the colour bound from them
-          pub_gatesN<2, 2, kPubBigGateSlots, false, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4);
+          // (round 6) the two landmarks' primary blobs -- the fronts of their lists -- come from the table in landmark order: the float
+          // records in the gates' first round, the exact ones where the verdicts want them
+          pub_gatesN<2, 2, kPubBigGateSlots, false, true, true>(qq, pp, gi, R->exact, pub, dump, &wg_flag[cur], sx, sy, sh, R->gate4,
+                                                                reinterpret_cast<const float4*>(R->prim), lc);
           PK_STAMP(c2)
           PK_PSTAMP(1, c1, c2)
           {
@@ -1699,7 +1777,15 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
               const uint4* fr8 = R8->far;
               pub_far_recheck<2, 2>(viol, l2, pp, kb_, it_, [&]() { return fr8 ? fr8 + 3 * (size_t)lc : (const uint4*)nullptr; }, R8->exact, sh, &wg_flag[cur]);
             }
-            pub_keysN<2, kPubBigGateSlots, true>(qq, l2, pp, pub_args_now(rp)->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, kb_, it_);
+            {
+              PubArgsPtr R9 = pub_args_now(rp);
+              PubPrim prim;
+              prim.tab = R9->prim;
+              prim.Lpp = (size_t)R9->Lp + kCandSpare;
+              prim.lc = lc;
+              pub_keysN<2, kPubBigGateSlots, true, false, 1, PubNoChk, true>(qq, l2, pp, R9->exact, pub, dump, anyc, anydump, &wg_flag[cur], sx, sy, kb_, it_,
+                                                                             PubNoChk(), &prim);
+            }
           }
           qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           qb = pub_keep_positive(qq[1], &wg_flag[cur]);
@@ -1841,10 +1927,16 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
         const unsigned char* immutable = R->immutable;
         // (the scan-order table in global memory: see pub_big_fixed_lds_bytes)
-        acc += pub_apply_loop(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0]);
+        // (the blob a landmark applies is nearly always its primary one: its exact record from the table in landmark order)
+        const int lc2 = min(l0, Lp);
+        const size_t Lpp = (size_t)Lp + kCandSpare;
+        const uint2 tt = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(R->prim + 4 * Lpp) + lc2);
+        acc += pub_apply_loop<true>(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0],
+                                    reinterpret_cast<const char*>(R->prim + Lpp), Lpp * 16, lc2, tt.x);
         {
           PubArgsPtr R8 = pub_args_now(rp);
-          acc += pub_apply_loop(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1]);
+          acc += pub_apply_loop<true>(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1],
+                                      reinterpret_cast<const char*>(R8->prim + Lpp), Lpp * 16, lc2 + 1, tt.y);
         }
         PK_STAMP(d2)
         PK_PSTAMP(8, d1, d2)
@@ -1911,9 +2003,9 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
 void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                          const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                          const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev, int64_t p0, int64_t p1,
-                         int reserve_cus) {
+                         int reserve_cus, const uint4* prim_dev, const unsigned* stats_dev) {
   if (p1 < 0) p1 = d.P;
-  if (d.P == 0 || p1 <= p0) return;
+  if (d.P == 0 || p1 <= p0 || !prim_dev || !stats_dev) return;  // (the scan's primary-blob table and figures: onepass_prepare makes them)
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
     for (const void* fn : {reinterpret_cast<const void*>(k_step_pub_big<3>), reinterpret_cast<const void*>(k_step_pub_big<5>),
@@ -1938,6 +2030,9 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
   a.skip = skip_dev;
   a.gate4 = gate4_dev;
   a.far = cand.far;
+  a.prim = prim_dev;
+  a.stats = stats_dev;
+  a.tbytes = 0;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
   a.P = p1;
@@ -1992,6 +2087,9 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   a.glist = glist_dev;
   a.skip = skip_dev;
   a.gate4 = nullptr;
+  a.prim = nullptr;
+  a.stats = nullptr;
+  a.tbytes = 0;
   a.far = cand.far;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
@@ -2020,5 +2118,7 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   else
     hipLaunchKernelGGL((k_step_pub<2, kPubThreads>), dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
 }
+
+#include "pk_k_step_duo.inl"
 
 }  // namespace pk

@@ -258,10 +258,25 @@ void launch_step_regs(hipStream_t s, DeviceState& d, int B, const BlobGrid& grid
 int step_pub_entry_capacity(int B);  // publish-table entries that fit LDS beside the scan's tables (0: the scan does not fit)
 int step_pub_entry_capacity_small(int B);  // ... with three 256-lane workgroups per CU (the L <= 512 instance)
 size_t step_pub_lds_bytes(int B, int ecap, bool small = false);
+// What k_step_pub_duo (the two-workgroups-per-CU instance of the two-pass kernel) has room for: entries of the publish table,
+// contested blobs, landmarks with several gate-passing blobs (ecap = 0: the instance is not in use)
+struct DuoLimits {
+  int tbytes = 0;  // bytes of LDS the publish table (8 per entry) and the overflow area (16 per landmark with several blobs) share; 0: off
+  int ecap = 0;    // entries at most (the option "pub_entry_limit")
+  int gcap = 0;    // contested blobs at most
+  int park_limit = -1;  // >= 0 (tests, option "pub_duo_park_limit"): the kernel treats its overflow area as this many places
+};
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap, int slots = kCandSlots, const double* exact_dev = nullptr,
-                         float4* gate4_dev = nullptr, const unsigned char* npass_dev = nullptr, bool pruned = false);
+                         float4* gate4_dev = nullptr, const unsigned char* npass_dev = nullptr, bool pruned = false,
+                         unsigned* stats_dev = nullptr, unsigned* skip_duo_dev = nullptr, unsigned* skip_big_dev = nullptr,
+                         const DuoLimits& duo = DuoLimits(), uint4* prim_dev = nullptr);
+// The primary-blob table of the two-pass kernels (k_cand_entries writes it, once per scan): for every landmark l (and the kCandSpare
+// spare records) the records of the FIRST blob of its candidate list, in landmark order -- four planes of Lp + kCandSpare uint4
+// (bearing, r, g, b as float | exact bearing, r | exact g, b | ray direction ux, uy), then the blob's index per landmark (u32;
+// 0xFFFF: the list is empty)
+inline size_t prim_table_uint4(int Lp) { const size_t Lpp = (size_t)Lp + kCandSpare; return 4 * Lpp + (Lpp + 3) / 4; }
 void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                      const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                      const unsigned* glist_dev, const unsigned* skip_dev, int ecap, int64_t p0 = 0, int64_t p1 = -1,
@@ -276,7 +291,17 @@ size_t step_pub_big_lds_bytes(int B, int ecap);
 void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                          const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
                          const unsigned* glist_dev, const unsigned* skip_dev, int ecap, const float4* gate4_dev = nullptr, int64_t p0 = 0,
-                         int64_t p1 = -1, int reserve_cus = 0);
+                         int64_t p1 = -1, int reserve_cus = 0, const uint4* prim_dev = nullptr, const unsigned* stats_dev = nullptr);
+// The two-workgroups-per-CU instance of the two-pass kernel (pk_k_step_duo.hip): ONE landmark per lane and turn, one carried word
+// per landmark, the expected bearing worked out again in pass 2 -- at most 128 VGPRs, so that two 512-lane workgroups share a CU
+// (four waves per SIMD) and one's row latency is the other's float64 issue.  Each has half the CU's LDS: k_cand_entries decides per
+// scan whether the publish table fits (step_pub_duo_limits -> DuoLimits; *skip_duo), k_step_pub_big takes the scans that do not.
+void step_pub_duo_limits(int B, int Lp, DuoLimits* out);
+size_t step_pub_duo_lds_bytes(int B, const DuoLimits& lim);
+void launch_step_pub_duo(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
+                         const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,
+                         const unsigned* glist_dev, const unsigned* skip_duo_dev, const unsigned* stats_dev, const DuoLimits& lim,
+                         const float4* gate4_dev, const uint4* prim_dev, int64_t p0 = 0, int64_t p1 = -1, int reserve_cus = 0);
 extern int g_observe_nv;
 // dynamic LDS of the general ML instance of k_observe (per-particle chains first[Lp], next[B], ids[B]) and of
 // k_assoc_brute (best[B] u64 + bid[B]): callers check them against kMaxDynLds BEFORE anything is enqueued

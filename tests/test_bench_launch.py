@@ -30,7 +30,7 @@ def test_a_launch_that_never_comes_together_is_stopped_and_reported():
     assert b"did not finish within" in r.stderr and b'"metric"' not in r.stdout
     # the group was stopped: no rank of that launch is left (they would sleep for an hour)
     time.sleep(0.5)
-    out = subprocess.run(["ps", "-eo", "pid,args"], stdout=subprocess.PIPE).stdout.decode()
+    out = subprocess.run(["ps", "-ww", "-eo", "pid,args"], stdout=subprocess.PIPE).stdout.decode()
     left = [ln for ln in out.splitlines() if "bench.py" in ln and "--launch-timeout 12" in ln and "ps -eo" not in ln]
     assert not left, left
 
@@ -41,3 +41,36 @@ def test_one_rank_that_never_joins_fails_the_launch_inside_150_seconds():
     r, dt = _run({"PK_BENCH_SABOTAGE_RANK": "1", "PK_BENCH_DIST_TIMEOUT": "20"}, ["--launch-timeout", "120"], limit=150)
     assert r.returncode != 0, r.stderr.decode()[-2000:]
     assert dt < 150 and b'"metric"' not in r.stdout
+
+
+def test_a_signal_to_the_parent_stops_the_ranks_too():
+    #  an outer `timeout` sends SIGTERM to the parent only: the ranks run in a session of their own and used to be
+    # left behind on the GPU.  The parent now passes the signal on to the group it started and exits 128 + signum.
+    import signal
+
+    env = dict(os.environ)
+    env.update({"PK_BENCH_SABOTAGE_RANK": "all", "PK_BENCH_SAME_GPU": "1", "PK_BENCH_BACKEND": "gloo"})
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--launch-timeout", "777"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+
+    def ranks():
+        out = subprocess.run(["ps", "-ww", "-eo", "pid,args"], stdout=subprocess.PIPE).stdout.decode()
+        return [ln for ln in out.splitlines() if "bench.py" in ln and "--launch-timeout 777" in ln and "ps -eo" not in ln and str(p.pid) != ln.split()[0]]
+
+    try:
+        t0 = time.monotonic()
+        while len(ranks()) < 3 and time.monotonic() - t0 < 90:  # (the launcher and its two ranks; the first `import torch` takes a while)
+            time.sleep(0.5)
+        assert len(ranks()) >= 3, "the ranks never started"
+        p.send_signal(signal.SIGTERM)
+        _, err = p.communicate(timeout=60)
+        assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err.decode()[-1500:])
+        time.sleep(0.5)
+        assert not ranks(), ranks()
+    finally:
+        if p.poll() is None:  # (a failed assertion must not leave the launch behind: the parent stops its own group on SIGTERM)
+            p.send_signal(signal.SIGTERM)
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()

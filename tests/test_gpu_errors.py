@@ -38,6 +38,15 @@ def test_call_order_and_argument_errors(lib):
     poses[3, 3] = -1.0
     with pytest.raises(lib.PkError):
         f.upload_poses(poses)
+    # an infinite weight passes "w >= 0" and would turn the log-domain scan into NaN
+    poses[3, 3] = np.inf
+    with pytest.raises(lib.PkError) as e:
+        f.upload_poses(poses)
+    assert e.value.status == lib.PK_ERR_INVALID
+    for bad_w in (np.inf, np.nan, -0.5):
+        with pytest.raises(lib.PkError) as e:
+            f.upload_pose(2, (0.0, 0.0, 0.0, bad_w))
+        assert e.value.status == lib.PK_ERR_INVALID
     # the handle is still usable after every refused call
     f.observe(blobs)
     assert np.isfinite(f.download_poses()).all()

@@ -116,6 +116,17 @@ def test_refused_where_it_cannot_follow(lib):
         f.observe(blobs, ids=np.arange(1, 9) % 7)
     with pytest.raises(lib.PkError, match="already enabled"):
         f.grow_enable(6, 8, 30.0)
+    # the host-index exchange packs records WITHOUT the bookkeeping's tail (pk_particle_bytes counts it) and would leave readings and
+    # id counters on the wrong particles: refused like its *_dev variants
+    import torch
+
+    buf = torch.zeros(4 * f.particle_bytes(), dtype=torch.uint8, device="cuda")
+    with pytest.raises(lib.PkError, match="balanced placement only") as e:
+        f.pack_particles([0, 1, 2, 3], buf.data_ptr())
+    assert e.value.status == lib.PK_ERR_STATE
+    with pytest.raises(lib.PkError, match="balanced placement only") as e:
+        f.adopt_particles(np.arange(16), buf.data_ptr(), 0)
+    assert e.value.status == lib.PK_ERR_STATE
     f.close()
     g = lib.DeviceFilter(4, 5)
     with pytest.raises(lib.PkError, match="no spare slot"):

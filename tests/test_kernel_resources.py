@@ -44,7 +44,7 @@ def code_object_kernels(so):
             if not m:
                 continue
             k, v = m.group(1), m.group(2).strip()
-            if k in ("private_segment_fixed_size", "sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "symbol"):
+            if k in ("private_segment_fixed_size", "sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "symbol", "group_segment_fixed_size"):
                 cur[k] = v
             if k == "wavefront_size":  # the last key of a kernel's record
                 if "symbol" in cur:
@@ -96,3 +96,15 @@ def test_the_register_resident_kernels_keep_their_occupancy(kernels):
     for sym, v in by.items():
         if "k_step_fused" in sym:
             assert v <= 128, (sym, v)
+
+
+def test_the_two_workgroups_per_cu_instance_of_the_two_pass_kernel_fits_128_registers(kernels):
+    """k_step_pub_duo (round 6): 512 lanes x <= 128 VGPRs = four waves per SIMD, TWO workgroups per CU -- by construction (one landmark
+    per lane and turn, one carried word per landmark), not by a cap the allocator answers with spills: no scratch, nothing spilled;
+    and its static LDS beside 78 KB of dynamic LDS leaves room for the second workgroup (160 KB per CU)."""
+    duo = [k for k in kernels if "k_step_pub_duo" in k["symbol"]]
+    assert len(duo) >= 2, [k["symbol"] for k in kernels if "duo" in k["symbol"]]
+    for k in duo:
+        assert int(k["vgpr_count"]) <= 128, k
+        assert int(k["private_segment_fixed_size"]) == 0 and int(k["vgpr_spill_count"]) == 0, k
+        assert int(k.get("group_segment_fixed_size", 0)) + 78 * 1024 <= 80 * 1024, k
