@@ -369,7 +369,17 @@ int pk_shard_plan_balanced_dev(pk_filter* f, const double* dev_global_state, int
 int pk_shard_pack_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, void* dev_buf);
 int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, const void* dev_recv,
                                 int64_t n_received, int32_t mode);
+/* debug (one-rank tests of the balanced exchange over RCCL): with the option "balanced_loopback_keep" = keep set, the next balanced
+ * adoption fills only the slots [0, keep) with the rank's own children; its children from position keep on travel as records -- packed
+ * here for the particles alive[a0, a1) with the same 64-byte header (and bookkeeping tail) another rank would get -- through the
+ * all-to-all to the rank itself and are adopted into [keep, P) from the receive buffer. */
+int pk_shard_pack_balanced_loop_dev(pk_filter* f, int64_t keep, int64_t a0, int64_t a1, void* dev_buf);
 int pk_shard_download_logical(pk_filter* f, int64_t* logical);
+/* tests of the planner in isolation (tests/test_gpu_sharded.py): the placement set from the host -- slot j holds logical particle
+ * logical[j] --, and this rank's tables of the last plan: rel[P + 1] (children of its particles [0, j)), Hl[P] (first output slot of
+ * particle j's children), alive[P] (its particles with children, ascending; -1 behind the last) */
+int pk_shard_upload_logical(pk_filter* f, const int64_t* logical);
+int pk_shard_download_balanced_plan(pk_filter* f, int64_t* rel, int64_t* Hl, int32_t* alive);
 int pk_shard_reset_placement(pk_filter* f);
 int pk_shard_download_balanced_offspring(pk_filter* f, int64_t global_particles, int64_t* H);
 int pk_shard_balanced_errors(pk_filter* f, int64_t* count);

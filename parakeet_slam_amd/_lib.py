@@ -87,8 +87,11 @@ SIGNATURES = {
                                              C.c_void_p]),
     "pk_shard_pack_balanced_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p]),
     "pk_shard_adopt_balanced_dev": (C.c_int, [_h, _lp, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32]),
+    "pk_shard_pack_balanced_loop_dev": (C.c_int, [_h, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "pk_shard_download_logical": (C.c_int, [_h, _lp]),
     "pk_shard_reset_placement": (C.c_int, [_h]),
+    "pk_shard_upload_logical": (C.c_int, [_h, _lp]),
+    "pk_shard_download_balanced_plan": (C.c_int, [_h, _lp, _lp, _ip]),
     "pk_shard_download_balanced_offspring": (C.c_int, [_h, C.c_int64, _lp]),
     "pk_shard_balanced_errors": (C.c_int, [_h, _lp]),
     "pk_motion_range": (C.c_int, [_h, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64, C.c_int64, C.c_int64]),
@@ -403,10 +406,23 @@ class DeviceFilter(object):
         check(self._lib.pk_shard_adopt_balanced_dev(self._h, lptr(t), int(world), int(rank), C.c_void_p(recv_ptr), int(n_received),
                                                     int(mode)))
 
+    def shard_pack_balanced_loop_dev(self, keep, a0, a1, buf_ptr):
+        check(self._lib.pk_shard_pack_balanced_loop_dev(self._h, int(keep), int(a0), int(a1), C.c_void_p(buf_ptr)))
+
     def download_logical(self):
         out = np.empty(self.P, dtype=np.int64)
         check(self._lib.pk_shard_download_logical(self._h, lptr(out)))
         return out
+
+    def upload_logical(self, logical):
+        a = np.ascontiguousarray(logical, dtype=np.int64).reshape(self.P)
+        check(self._lib.pk_shard_upload_logical(self._h, lptr(a)))
+
+    def shard_download_balanced_plan(self):
+        """(rel int64[P + 1], Hl int64[P], alive int32[n_alive]) of the last balanced plan (tests)."""
+        rel, Hl, alive = np.empty(self.P + 1, dtype=np.int64), np.empty(self.P, dtype=np.int64), np.empty(self.P, dtype=np.int32)
+        check(self._lib.pk_shard_download_balanced_plan(self._h, lptr(rel), lptr(Hl), iptr(alive)))
+        return rel, Hl, alive[alive >= 0]
 
     def reset_placement(self):
         check(self._lib.pk_shard_reset_placement(self._h))

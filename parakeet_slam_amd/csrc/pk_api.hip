@@ -120,6 +120,9 @@ struct pk_filter {
   int64_t rlohi_cap = 0;
   BalancedBuffers bal{};        // balanced placement of the sharded filter: the plan's tables (every rank holds the whole plan)
   int64_t bal_m = -1;           // slots this rank's own children fill in the plan that is being carried out (-1: none)
+  int64_t bal_loop_keep = -1;   // "balanced_loopback_keep" (debug, one-rank tests of the exchange): the next balanced adoption fills only the
+                                // slots [0, keep) with this rank's own children; the slots [keep, P) come from records -- which the caller
+                                // packs with pk_shard_pack_balanced_loop_dev and sends through the all-to-all to itself
   int assoc_kernel = 0;  // 0 = colour-grid kernel, 1 = brute-force reference kernel
   int assoc_dup = 1;     // grid kernel: use the 9x column-duplicated index list when it fits in LDS
   // host half of an ML scan upload done ahead of time (pk_stage_scan): tables built in a staging slot
@@ -1878,6 +1881,11 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     (name[15] == 'l' ? f->loop_lo : f->loop_hi) = value;
     return PK_OK;
   }
+  if (!strcmp(name, "balanced_loopback_keep")) {
+    if (value < -1 || value > f->d.P) return fail(PK_ERR_INVALID, "balanced_loopback_keep: -1 (off) .. P");
+    f->bal_loop_keep = value;
+    return PK_OK;
+  }
   if (!strcmp(name, "split_reserve_cus")) {
     if (value < 0 || value > 128) return fail(PK_ERR_INVALID, "split_reserve_cus: 0..128");
     f->split_reserve_cus = (int)value;
@@ -2487,6 +2495,40 @@ int pk_shard_download_logical(pk_filter* f, int64_t* logical) {
   return PK_OK;
 }
 
+/* The placement set from the host (tests of the planner in isolation; restoring a snapshot taken in physical order): slot j holds
+ * logical particle logical[j].  Every index must lie in [0, 2^31). */
+int pk_shard_upload_logical(pk_filter* f, const int64_t* logical) {
+  if (!f || !logical) return fail(PK_ERR_INVALID, "pk_shard_upload_logical: NULL argument");
+  for (int64_t j = 0; j < f->d.P; ++j)
+    if (logical[j] < 0 || logical[j] >= ((int64_t)1 << 31)) return fail(PK_ERR_INVALID, "pk_shard_upload_logical: logical[%lld] = %lld", (long long)j, (long long)logical[j]);
+  if (f->split.active) return fail(PK_ERR_STATE, "pk_shard_upload_logical: a split observe is in progress");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  if ((rc = ensure_logical(f))) return rc;
+  PK_HIP(hipMemcpyAsync(f->d.logical[f->d.cur], logical, (size_t)f->d.P * sizeof(int64_t), hipMemcpyHostToDevice, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  return PK_OK;
+}
+
+/* This rank's tables of the last balanced plan (tests): rel[P + 1] the children of its particles [0, j), Hl[P] the first output slot
+ * of every particle's children, alive[P] its particles with children, ascending -- the first rel-derived count of them is valid,
+ * the rest is -1. */
+int pk_shard_download_balanced_plan(pk_filter* f, int64_t* rel, int64_t* Hl, int32_t* alive) {
+  if (!f || !rel || !Hl || !alive) return fail(PK_ERR_INVALID, "pk_shard_download_balanced_plan: NULL argument");
+  if (!f->bal.rel || !f->bal.Hl || !f->bal.alive) return fail(PK_ERR_STATE, "pk_shard_download_balanced_plan: no balanced plan yet (pk_shard_plan_balanced_dev)");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  const int64_t P = f->d.P;
+  PK_HIP(hipMemcpyAsync(rel, f->bal.rel, ((size_t)P + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipMemcpyAsync(Hl, f->bal.Hl, (size_t)P * sizeof(int64_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipMemcpyAsync(alive, f->bal.alive, (size_t)P * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
+  PK_HIP(hipStreamSynchronize(f->stream));
+  int64_t n = 0;  // particles with children: what k_bal_own wrote of alive[]
+  for (int64_t j = 0; j < P; ++j) n += rel[j + 1] > rel[j] ? 1 : 0;
+  for (int64_t j = n; j < P; ++j) alive[j] = -1;
+  return PK_OK;
+}
+
 int pk_shard_state_dev(pk_filter* f, double* dev_out) {
   if (!f || !dev_out) return fail(PK_ERR_INVALID, "pk_shard_state_dev: NULL argument");
   int rc;
@@ -2602,6 +2644,24 @@ int pk_shard_pack_balanced_dev(pk_filter* f, const int64_t* table, int32_t world
   return PK_OK;
 }
 
+/* debug (one-rank tests of the balanced exchange, option "balanced_loopback_keep"): records of this rank's particles alive[a0, a1) for
+ * ITSELF -- the children from position `keep` on, destined for its own slots [keep, P): what k_bal_pack writes for another rank whose
+ * free slots are [keep, P), with the 64-byte balanced header (and the new-landmark bookkeeping behind the map while that is on). */
+int pk_shard_pack_balanced_loop_dev(pk_filter* f, int64_t keep, int64_t a0, int64_t a1, void* dev_buf) {
+  if (!f || keep < 0 || keep > f->d.P || a0 < 0 || a1 < a0 || a1 > f->d.P || (a1 > a0 && !dev_buf))
+    return fail(PK_ERR_INVALID, "pk_shard_pack_balanced_loop_dev: bad argument");
+  if (!f->bal.rel || !f->d.logical[0]) return fail(PK_ERR_STATE, "pk_shard_pack_balanced_loop_dev: call pk_shard_plan_balanced_dev first");
+  int rc;
+  if ((rc = use_device(f))) return rc;
+  Span t(f, PK_T_RESAMPLE);
+  // (k_bal_pack's "P" is the number of children a rank keeps: here keep; excess positions count from 0, the destination's free slots
+  // are [keep, P): ebase = dbase = 0, dd = P - keep, m_d = keep)
+  launch_bal_pack(f->stream, f->d, f->bal, a0, a1 - a0, 0, 0, f->d.P - keep, keep, static_cast<unsigned char*>(dev_buf), record_stride(f),
+                  f->grow_on ? &f->grow : nullptr, keep);
+  PK_LAUNCH_CHECK("pk_shard_pack_balanced_loop_dev");
+  return PK_OK;
+}
+
 int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t world, int32_t rank, const void* dev_recv,
                                 int64_t n_received, int32_t mode) {
   if (f) f->pose_part_ok = false;
@@ -2614,7 +2674,10 @@ int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t worl
   const int64_t P = f->d.P;
   if ((rc = balanced_row_check(table, world, P, "pk_shard_adopt_balanced_dev"))) return rc;
   const int row = 2 * world + 4;
-  const int64_t m = table[(size_t)rank * row + 2 * world + 1];
+  int64_t m = table[(size_t)rank * row + 2 * world + 1];
+  // debug loopback (one rank): the rank's own children fill [0, keep) only, its children from position keep on arrive as records
+  const bool loop = f->bal_loop_keep >= 0 && world == 1;
+  if (loop) m = f->bal_loop_keep < m ? f->bal_loop_keep : m;
   if (mode == 2) {
     if (!f->adopt_local_done) return fail(PK_ERR_STATE, "pk_shard_adopt_balanced_dev: mode 1 first (it makes the new generation current)");
     f->adopt_local_done = false;
@@ -2623,8 +2686,9 @@ int pk_shard_adopt_balanced_dev(pk_filter* f, const int64_t* table, int32_t worl
     int64_t expect = 0;
     for (int s = 0; s < world; ++s)
       if (s != rank) expect += table[(size_t)s * row + 2 * rank + 1] - table[(size_t)s * row + 2 * rank];
-    if (expect != n_received) return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: %lld records received, the plan sends %lld", (long long)n_received, (long long)expect);
+    if (!loop && expect != n_received) return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: %lld records received, the plan sends %lld", (long long)n_received, (long long)expect);
     if (m < P && n_received == 0) return fail(PK_ERR_INVALID, "pk_shard_adopt_balanced_dev: %lld free slots and no records", (long long)(P - m));
+    f->bal_loop_keep = -1;  // (one adoption: cleared behind mode 0 or mode 2)
   }
   if ((rc = use_device(f))) return rc;
   if (mode != 2 && f->d.alt) {  // an earlier adoption is still referenced: fold it into the map buffer first

@@ -842,11 +842,12 @@ __global__ void __launch_bounds__(256) k_bal_pack(SlotSource ss, const int32_t* 
     for (int k = threadIdx.x; k < 8 * nrd; k += blockDim.x) tr[k] = sr[k];
   }
 }
+// keep: the children a rank keeps for itself (its own slots) -- P, or less in the one-rank loopback of the tests
 void launch_bal_pack(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t a0, int64_t n, int64_t ebase_s,
-                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev, size_t stride, const GrowState* g) {
+                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev, size_t stride, const GrowState* g, int64_t keep) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_bal_pack, dim3((unsigned)n), dim3(256), 0, s, slot_source(d), d.src[d.cur], d.x[d.cur], d.y[d.cur],
-                     d.h[d.cur], d.logw[d.cur], b.rel, b.Hl, b.alive, a0, d.P, ebase_s, dbase_d, dd_d, m_d, buf_dev, stride,
+                     d.h[d.cur], d.logw[d.cur], b.rel, b.Hl, b.alive, a0, keep < 0 ? d.P : keep, ebase_s, dbase_d, dd_d, m_d, buf_dev, stride,
                      g ? *g : GrowState{});
 }
 

@@ -363,7 +363,8 @@ void launch_bal_state(hipStream_t s, const DeviceState& d, double* out_dev);
 void launch_bal_plan(hipStream_t s, const DeviceState& d, const double* gstate_dev, int64_t Pg, int world, int rank,
                      const double* gmax_dev, int domain, double u, BalancedBuffers& b, int64_t* table_dev);
 void launch_bal_pack(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t a0, int64_t n, int64_t ebase_s,
-                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev, size_t stride, const GrowState* g);
+                     int64_t dbase_d, int64_t dd_d, int64_t m_d, unsigned char* buf_dev, size_t stride, const GrowState* g,
+                     int64_t keep = -1);
 void launch_bal_adopt(hipStream_t s, DeviceState& d, const BalancedBuffers& b, int64_t m, const unsigned char* buf_dev,
                       int64_t n_recv, int64_t* rh_dev, int mode, size_t stride, int32_t* anc_dev);
 void launch_offspring(hipStream_t s, const double* clocal_dev, const double* offsets_dev, const double* sum_dev,

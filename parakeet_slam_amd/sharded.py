@@ -428,12 +428,17 @@ class ShardedFilter(object):
             placement = "balanced" if (self.world > 1 and self.loopback is None and hasattr(f, "plan_balanced_into")) else "contiguous"
         if placement not in ("balanced", "contiguous"):
             raise ValueError("placement must be 'balanced' or 'contiguous'")
-        if placement == "balanced" and self.loopback is not None:
-            raise ValueError("the loopback debug mode exercises the contiguous exchange")
+        # The balanced loopback (round 6; one rank, debug): (0, n_back) -- the rank keeps its children [0, P - n_back) and sends the
+        # rest, as records with the balanced protocol's 64-byte header (and the bookkeeping's tail), through the all-to-all TO ITSELF;
+        # the state all-gather runs through the communicator as well.  Everything the default placement does between ranks then runs
+        # over RCCL where only one device exists.
+        if placement == "balanced" and self.loopback is not None and (self.world != 1 or self.loopback[0] != 0):
+            raise ValueError("the balanced loopback is (0, n_back) on a world of one")
         self.placement = placement
+        self._bal_loop = placement == "balanced" and self.loopback is not None
         if placement == "balanced":
             self._state = f.new_f64(2 * self.P)  # [log-weights | logical indices (int64 bits)]
-            self._gstate = f.new_f64(2 * self.P * self.world) if self.world > 1 else self._state
+            self._gstate = f.new_f64(2 * self.P * self.world) if (self.world > 1 or self._bal_loop) else self._state
             self._brow = 2 * self.world + 4
             self._btable = f.new_i64(self._brow * self.world)
         self._sums = f.new_f64(4)
@@ -590,7 +595,7 @@ class ShardedFilter(object):
             # ONE all-gather (16 B per particle of the whole filter); every rank then runs the 1-GPU scan on the weights in
             # logical order and derives the whole plan -- who keeps what, who sends which particles to whom -- by itself
             f.state_into(self._state)
-            if W > 1:
+            if W > 1 or self._bal_loop:
                 comm.all_gather_(self._gstate, self._state)
             f.plan_balanced_into(self._gstate, self.P_global, gmax, domain, u, W, R, self._btable)
             handle = f.start_host_read(self._btable) if hasattr(f, "start_host_read") else None
@@ -667,6 +672,10 @@ class ShardedFilter(object):
                     else:
                         f.pack_into(allr[R].reshape(-1), W, R, send)
                 recv = comm.all_to_all_records(send, send_counts, recv_counts, f.particle_bytes())
+            elif self._bal_loop:
+                send, n_recv, _keep = self._pack_balanced_loop()
+                recv = comm.all_to_all_records(send, [n_recv], [n_recv], f.particle_bytes())
+                self.loopback_records += n_recv
             if bal:
                 f.adopt_balanced(allr.reshape(-1), W, R, recv, n_recv, 0)
             else:
@@ -693,6 +702,12 @@ class ShardedFilter(object):
                     else:
                         f.pack_into(allr[R].reshape(-1), W, R, send)
                 recv, work = comm.all_to_all_records_async(send, send_counts, recv_counts, f.particle_bytes())
+            elif self._bal_loop:
+                # one rank, balanced placement: its children from position keep on through the exchange, to itself (see __init__)
+                send, n_recv, keep = self._pack_balanced_loop()
+                recv, work = comm.all_to_all_records_async(send, [n_recv], [n_recv], f.particle_bytes())
+                a, b = 0, keep
+                self.loopback_records += n_recv
             elif W == 1 and self.loopback is not None and sum(self.loopback) > 0:
                 # one rank, slots [0, n_front) and [P - n_back, P) through the exchange (see __init__)
                 nf, nb = self.loopback
@@ -739,6 +754,24 @@ class ShardedFilter(object):
                 f.observe_staged_range(True, b, self.P, False, True)
             self._recv_keepalive = recv if n_recv else None  # read by the launches above: freed in stream order later
             self.split_steps_done += 1
+
+    def _pack_balanced_loop(self):
+        """The balanced loopback's records (debug, one rank): the particles whose children reach beyond position keep = P - n_back,
+        packed for this rank's own slots [keep, P).  Returns (send buffer, number of records, keep).  Reads the plan's tables on the
+        host: a debug path."""
+        f = self.f
+        keep = max(self.P - self.loopback[1], 0)
+        rel, _Hl, alive = f.shard_download_balanced_plan()
+        first = np.searchsorted(rel[alive + 1], keep, side="right") if len(alive) else 0  # first alive particle with a child at position >= keep
+        a0, a1 = int(first), int(len(alive))
+        if keep >= self.P:
+            a0 = a1
+        n = a1 - a0
+        send = f.alloc_records(n)
+        if n:
+            f.shard_pack_balanced_loop_dev(keep, a0, a1, send.data_ptr())
+        f.set_option("balanced_loopback_keep", keep)
+        return send, n, keep
 
     def _global_ancestors(self, u, domain):
         """Tests only: global ancestor index of every local output slot, from the host-array

@@ -22,9 +22,7 @@ WARM = int(os.environ.get("ST_WARM", 3))  # steps before the measured three (the
 means, covs, scans = bench.synthetic_inputs(L, WARM + 3)
 f = _lib.DeviceFilter(P, L)
 f.upload_map(means, covs.reshape(L, 25))
-for name in ("PK_OPT_FAST_OBSERVE", "PK_OPT_FUSED_STEP", "PK_OPT_REGS_STEP", "PK_OPT_REGS_WARM", "PK_OPT_PUB_STEP"):
-    if os.environ.get(name):
-        f.set_option(name[7:].lower(), int(os.environ[name]))
+print("options from the environment:", bench.env_options(f))
 so = _lib.load()
 so.pk_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 buf = (ctypes.c_ulonglong * 64)()

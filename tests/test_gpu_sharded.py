@@ -190,6 +190,73 @@ def _nccl_single(q):
             assert np.allclose(sl.summary(), pl.summary(), rtol=1e-13, atol=1e-14)
             sl.close()
             pl.close()
+        # The DEFAULT placement between ranks -- balanced -- over RCCL on this one device (missing #1 / next #2): the
+        # all-gather of the 16-byte state and the all-to-all run through the communicator although the world is one; (0, 0): zero
+        # records, adoption modes 0 (whole) and 1 / 2 (split); (0, n_back): the rank's children from position P - n_back on are
+        # packed with the balanced protocol's 64-byte header, travel through all_to_all_single (async in the split step) to this
+        # rank itself and are adopted from the receive buffer into the slots [P - n_back, P).  Three steps each, whole and split:
+        # the plain filter's poses and maps bit for bit (compared in logical order).
+        for nb, Pl, split in ((0, 1500, True), (0, 1500, False), (257, 1500, True), (1024, 2048, True), (1, 1500, True), (700, 1500, False), (1499, 1500, True)):
+            sl = ShardedFilter(Pl, Ls, device=0, comm=comm, split_step=split, loopback=(0, nb), placement="balanced")
+            assert sl.placement == "balanced"
+            sl.upload_map(ms, cs.reshape(Ls, 25))
+            pl = _lib_mod.DeviceFilter(Pl, Ls)
+            pl.upload_map(ms, cs.reshape(Ls, 25))
+            for st in range(3):
+                sl.step(_V, _W, 0.1, scs[st], 0.37 + 0.2 * st, seed=4, draw=st, domain=1)
+                pl.step(_V, _W, 0.1, scs[st], 0.37 + 0.2 * st, seed=4, draw=st, domain=1)
+            assert sl.split_steps_done == (2 if split else 0), (nb, split, sl.split_steps_done)
+            assert sl.loopback_records >= (2 if nb else 0) and (nb or sl.loopback_records == 0), (nb, sl.loopback_records)
+            assert sl.f.shard_balanced_errors() == 0
+            lg = sl.logical_index()
+            assert np.array_equal(np.sort(lg), np.arange(Pl))
+            pa, pb = sl.download_poses(), pl.download_poses()[lg]
+            assert np.array_equal(pa[:, :3], pb[:, :3]), ("balanced loopback poses", nb, split)
+            assert np.allclose(pa[:, 3], pb[:, 3], rtol=1e-11, atol=0.0), ("balanced loopback weights", nb, split)
+            for xa, xb in zip(sl.download_landmarks(), pl.download_landmarks()):
+                assert np.array_equal(xa, xb[lg]), ("balanced loopback maps", nb, split)
+            assert np.allclose(sl.summary(), pl.summary(), rtol=1e-13, atol=1e-14)
+            sl.close()
+            pl.close()
+        # ... and with the new-landmark bookkeeping riding behind every record's map (section 8(f4): counters, spare-slot ids, stored
+        # readings; whole adoptions only -- the bookkeeping refuses split steps): a growing map whose records travelled equals the
+        # plain filter's, bookkeeping included
+        from oracle.fastslam_oracle import synthetic_scan as _sscan, synthetic_world as _sworld, truth_step as _tstep
+
+        wm, wc = _sworld(9)
+        known, kcov = wm[:6], wc[:6]
+        spare = 4
+        mm = np.vstack([known, np.zeros((spare, 5))])
+        mm[6:, 2:] = 2.0 ** 100  # an empty spare slot fails every colour gate (core.py: EMPTY_COLOUR)
+        cc = np.concatenate([kcov, np.tile(np.identity(5), (spare, 1, 1))])
+        outs = []
+        for loop in (True, False):
+            if loop:
+                g = ShardedFilter(640, 6 + spare, device=0, comm=comm, split_step=False, loopback=(0, 200), placement="balanced")
+                g.upload_map(mm, cc.reshape(-1, 25))
+                g.grow_enable(6, 16, 30.0)
+                gf = g.f
+            else:
+                g = _lib_mod.DeviceFilter(640, 6 + spare)
+                g.upload_map(mm, cc.reshape(-1, 25))
+                g.grow_enable(6, 16, 30.0)
+                gf = g
+            pose = (0.0, 0.0, 0.0)
+            for st in range(5):
+                pose = _tstep(pose, 0.6, 0.3, 0.1)
+                g.step(0.6, 0.3, 0.1, _sscan(wm, pose), 0.21 + 0.13 * st, seed=6, draw=st, domain=1)
+            if loop:
+                assert g.loopback_records >= 4
+                lgi = g.logical_index()
+            outs.append((g.download_poses(), g.download_landmarks(), gf.grow_download()))
+            g.close()
+        (pa, ma, ga), (pb, mb, gb) = outs
+        assert np.array_equal(pa[:, :3], pb[lgi][:, :3]) and np.allclose(pa[:, 3], pb[lgi][:, 3], rtol=1e-11)
+        for xa, xb in zip(ma, mb):
+            assert np.array_equal(xa, xb[lgi])
+        for xa, xb in zip(ga, gb):
+            assert np.array_equal(xa, xb[lgi])
+        assert ga[0][:, 1].max() > 0, "no particle grew a landmark: the scene does not do what it says"
         # the global-scan plan (shards that end inside a scan block; bench.py's 100 000 particles per rank) through the same
         # communicator: ancestors against the plain filter on the same weights
         from parakeet_slam_amd import _lib
@@ -277,6 +344,110 @@ def test_one_launch_shard_plan_matches_the_host_variant(lib, P, world, rank, oth
         f.synchronize()
         assert np.array_equal(ranges.cpu().numpy(), want), (ranges.cpu().numpy(), want)
     f.close()
+
+
+@pytest.mark.parametrize("P,world", [(10000, 2), (10000, 4), (10000, 8), (125000, 4), (125000, 8)])
+def test_balanced_plan_kernels_in_isolation_at_every_rank_of_worlds_up_to_eight(lib, P, world):
+    """VERDICT round 5, missing #1: the DEFAULT placement's device planner (pk_shard_plan_balanced_dev -> k_bal_scatter / counts / plan /
+    own, the coupling point prkt_core_v2.py:216-252) had run at world <= 5 only, and only inside whole filters.  Here, on one GPU and in
+    one process: a synthetic gathered state [log-weights | logical indices] of a filter of `world` ranks -- the logical indices shuffled
+    over ALL ranks (what twenty balanced resamples leave), the weights skewed (a few heavy particles, a tail of dead ones) -- is
+    planned as EVERY rank r in turn; the plan's table (who sends which of its particles with children to whom; n, m, ebase, dbase), the
+    rank's child positions rel, first output slots Hl and particles with children `alive`, and the headers of the records it would
+    send (free slots [lo, up) at the destination, logical index of the first child) must equal sharded.plan_balanced /
+    balanced_record_ranges on the offspring table H -- which in turn is the single filter's ordered walk on the weights in logical
+    order.  P = 125 000 with world 8 is BASELINE configs[4]'s million particles."""
+    import torch
+
+    from parakeet_slam_amd.sharded import balanced_record_ranges, plan_balanced
+
+    Pg, L = P * world, 2
+    rs = np.random.RandomState(P // 1000 + world)
+    logical_all = rs.permutation(Pg).astype(np.int64)
+    logw_logical = rs.normal(0.0, 2.0, Pg)
+    logw_logical[rs.choice(Pg, Pg // 40, replace=False)] += 7.0    # heavy particles: many children each
+    logw_logical[rs.choice(Pg, Pg // 3, replace=False)] -= 60.0    # dead ones: never packed
+    logw_logical[: Pg // (2 * world)] += 3.0                       # the first logical particles heavier: rank boundaries shift
+    logw_phys = logw_logical[logical_all]
+    gstate = np.concatenate([np.concatenate([logw_phys[r * P:(r + 1) * P], logical_all[r * P:(r + 1) * P].view(np.float64)]) for r in range(world)])
+    g_dev = torch.from_numpy(gstate).cuda()
+    gmax_dev = torch.tensor([logw_logical.max()], dtype=torch.float64, device="cuda")
+    u = 0.6180339887
+    row = 2 * world + 4
+    means = np.array([[5.0, 0.0, 10, 20, 30], [0.0, 5.0, 200, 100, 50]])
+    H_first, want = None, None
+    for r in range(world):
+        f = lib.DeviceFilter(P, L)
+        f.upload_map(means, np.tile(0.25 * np.identity(5), (L, 1, 1)).reshape(L, 25))
+        poses = np.zeros((P, 4))
+        poses[:, 0] = r * P + np.arange(P)  # (x names the physical particle: the records' headers are checked against it)
+        poses[:, 3] = 1.0
+        f.upload_poses(poses)
+        f.set_shard(r * P)
+        f.upload_logical(logical_all[r * P:(r + 1) * P])
+        table = torch.full((row * world,), -7, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        f.shard_plan_balanced_dev(g_dev.data_ptr(), Pg, gmax_dev.data_ptr(), lib.PK_WEIGHTS_LOG, u, world, r, table.data_ptr())
+        f.synchronize()
+        assert f.shard_balanced_errors() == 0
+        H = np.asarray(f.shard_download_balanced_offspring(Pg), dtype=np.int64)
+        if H_first is None:
+            H_first = H
+            # the single filter's ordered walk (:233-250) on the weights in logical order, 1 024-particle blocks as one GPU scans them
+            w = np.exp(logw_logical - logw_logical.max())
+            C, run = np.empty(Pg), 0.0
+            for b in range((Pg + 1023) // 1024):
+                c = np.cumsum(w[b * 1024:(b + 1) * 1024])
+                C[b * 1024:b * 1024 + len(c)] = run + c
+                run = run + c[-1]
+            rr = run / float(Pg)
+            Hn = np.empty(Pg + 1, dtype=np.int64)
+            Hn[0] = 0
+            Hn[1:] = np.searchsorted(u * rr + np.arange(Pg, dtype=np.float64) * rr, C, side="right")
+            Hn[-1] = Pg
+            Hn = np.maximum.accumulate(Hn)
+            # (a comb point within rounding of a cumulative sum may fall on either side: expected never, DESIGN.md section 5)
+            assert (H != Hn).sum() <= 2, (H != Hn).sum()
+            assert H[0] == 0 and H[-1] == Pg and (np.diff(H) >= 0).all()
+            want = plan_balanced(H, logical_all, world, P)
+        else:
+            assert np.array_equal(H, H_first)  # every rank derives the same table
+        cq, nz, (n, m, e, dd, ebase, dbase), pairs = want
+        tab = table.cpu().numpy().reshape(world, row)
+        assert np.array_equal(tab[:, :2 * world].reshape(world, world, 2), pairs), r
+        assert np.array_equal(tab[:, 2 * world], n) and np.array_equal(tab[:, 2 * world + 1], m)
+        assert np.array_equal(tab[:, 2 * world + 2], ebase) and np.array_equal(tab[:, 2 * world + 3], dbase)
+        assert n.sum() == Pg and (m == np.minimum(n, P)).all() and e.sum() == dd.sum()
+        rel, Hl, alive = f.shard_download_balanced_plan()
+        rel_want = cq[r * P:(r + 1) * P + 1] - cq[r * P]
+        assert np.array_equal(rel, rel_want)
+        assert np.array_equal(Hl, H[logical_all[r * P:(r + 1) * P]])
+        assert np.array_equal(alive, np.nonzero(np.diff(rel_want) > 0)[0])
+        # the records this rank would send: headers against balanced_record_ranges, destination by destination
+        n_send = int((pairs[r, :, 1] - pairs[r, :, 0]).sum())
+        if n_send:
+            stride = f.particle_bytes()
+            buf = torch.zeros(n_send * stride, dtype=torch.uint8, device="cuda")
+            f.shard_pack_balanced_dev(tab.reshape(-1), world, r, buf.data_ptr())
+            f.synchronize()
+            recs = buf.cpu().numpy().reshape(n_send, stride)
+            hd_f = recs[:, :32].copy().view(np.float64).reshape(n_send, 4)
+            hd_i = recs[:, 32:64].copy().view(np.int64).reshape(n_send, 4)
+            i = 0
+            for d in range(world):
+                a0, a1 = int(pairs[r, d, 0]), int(pairs[r, d, 1])
+                if d == r or a1 <= a0:
+                    continue
+                j, lo, up, klo = balanced_record_ranges(rel_want, H[logical_all[r * P:(r + 1) * P]], alive, a0, a1, P, ebase[r], dbase[d], dd[d], m[d])
+                k = a1 - a0
+                assert np.array_equal(hd_f[i:i + k, 0], (r * P + j).astype(np.float64))  # the particles named by the plan
+                assert np.array_equal(hd_i[i:i + k, 0], lo) and np.array_equal(hd_i[i:i + k, 1], up) and np.array_equal(hd_i[i:i + k, 2], klo)
+                assert (up > lo).all() and lo.min() >= m[d] and up.max() <= P
+                i += k
+            assert i == n_send
+        f.close()
+    # what the exchange as a whole does: every free slot of every rank is filled exactly once
+    assert e.sum() == dd.sum() and (pairs[:, :, 1] - pairs[:, :, 0]).sum() > 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
