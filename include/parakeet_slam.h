@@ -117,11 +117,15 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    there, one lane per contested blob picks the winner; two landmark pairs per lane, 512 lanes -- while
  *                    the table fits LDS and no candidate list overflows; decided per scan on the device,
  *                    pk_observe_published) or 0 (k_step_regs: per-blob counters, probability queue, bids);
- *   "pub_duo"      = 1 (default) or 0: maps of 2 049 .. 6 144 landmarks: a scan whose publish table fits HALF a CU's LDS is worked
- *                    on by k_step_pub_duo -- the two-pass kernel k_step_pub_big with one landmark per lane and turn, at most 128
- *                    VGPRs, so that TWO workgroups share a CU and one's memory waits are the other's arithmetic; decided per scan
- *                    on the device (pk_observe_pub_stats); "pub_duo_park_limit" >= 0 (tests) treats its overflow area -- where a
- *                    landmark with several blobs of probability > 0 parks its slots between the passes -- as that many places;
+ *   "pub_duo"      = 0 (default), 1 or 2: maps of 2 049 .. 5 120 landmarks: a scan whose publish table fits its share of a CU's LDS is
+ *                    worked on by k_step_pub_duo -- the two-pass kernel k_step_pub_big with ONE landmark at a time and one carried
+ *                    word per landmark: 1 = 512 lanes, at most 128 VGPRs, TWO workgroups per CU; 2 = 256 lanes with a pair of
+ *                    landmarks each, at most 168 VGPRs, THREE workgroups per CU -- so that one workgroup's memory waits are the
+ *                    others' arithmetic; decided per scan on the device (pk_observe_pub_stats).  Measured slower than one
+ *                    workgroup per CU (twice / three times the particles in flight no longer find their second read of the
+ *                    map in the Infinity Cache: DESIGN.md section 4), hence off.  "pub_duo_park_limit" >= 0 (tests) treats its
+ *                    overflow area -- where a landmark with several blobs of probability > 0 parks its slots between the
+ *                    passes -- as that many places;
  *   "far_prune"    = 1 (default) or 0: once per scan, the look-alikes whose match probability is certainly 0 for every particle
  *                    (a key beyond the float64 underflow edge by the reference particle's bound with margins) leave the candidate
  *                    lists of the publish / subscribe kernels; a landmark whose own bound is weaker re-checks them itself
@@ -451,9 +455,9 @@ int pk_observe_published(pk_filter* f, int32_t* published);
  * stats[0] entries of the table (every (landmark, blob) pair several landmarks contend for, prkt_core_v2.py:353-381),
  * [1] contested blobs, [2] landmarks of the reference particle with two or more blobs inside their own gates (:433, :441),
  * [3] the longest candidate list, [4] entries the LDS table was given, [5] which instance worked on the scan: 0 none of the
- * publish / subscribe kernels (the table did not fit, a list overflowed), 1 the one-workgroup-per-CU instance, 2 the
- * two-workgroups-per-CU instance of the two-pass kernel (k_step_pub_duo, option "pub_duo").  All zero when the last observe
- * took another route.  Synchronises the stream. */
+ * publish / subscribe kernels (the table did not fit, a list overflowed), 1 the one-workgroup-per-CU instance, 2 / 3 the
+ * two- / three-workgroups-per-CU instance of the two-pass kernel (k_step_pub_duo, option "pub_duo" = 1 / 2).  All zero when the
+ * last observe took another route.  Synchronises the stream. */
 int pk_observe_pub_stats(pk_filter* f, int64_t stats[6]);
 /* Per particle, how the last one-pass maximum-likelihood observe (k_step_fused / k_step_pub / k_step_pub_big / k_step_regs)
  * dealt with it (instrumentation; what the full-size oracle audits of tests/test_gpu_audit.py pick their samples by):

@@ -150,7 +150,8 @@ struct pk_filter {
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
   int pub_small = 0;     // L <= 512: k_step_pub<256 lanes> instead of k_step_fused (measured: the kernel 1 % slower, the step 50 us longer)
   int duo_park_limit = -1;  // >= 0: k_step_pub_duo's overflow area is treated as this small (tests: particles that need more go to the fall-back kernels)
-  int duo_on = 1;        // 2 048 < L <= 6 144: scans whose publish table fits HALF a CU's LDS go to k_step_pub_duo (two workgroups per CU, <= 128 VGPRs), the others to k_step_pub_big
+  int duo_on = 0;        // "pub_duo" (measured, off: DESIGN.md section 4): 2 048 < L <= 5 120, scans whose publish table fits its share of a CU's LDS go to
+                         // k_step_pub_duo -- 1: two 512-lane workgroups per CU (<= 128 VGPRs), 2: three 256-lane workgroups (<= 168) -- the others to k_step_pub_big
   int pub_entry_limit = 0;  // > 0: the publish table is treated as this small (tests: scans whose table "does not fit" fall back to k_step_regs)
   uint4* erec_dev = nullptr;     // [Lp] publish entries of every landmark's candidates (k_cand_entries)
   uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
@@ -1402,7 +1403,7 @@ static int ensure_inverse_lists(pk_filter* f, int B, int slots = kCandSlots) {
 static DuoLimits duo_limits(const pk_filter* f, int B) {
   DuoLimits d;
   if (!f->duo_on) return d;
-  step_pub_duo_limits(B, f->d.lay.Lp, &d);
+  step_pub_duo_limits(B, f->d.lay.Lp, f->duo_on, &d);
   if (f->pub_entry_limit > 0 && d.ecap > f->pub_entry_limit) d.ecap = f->pub_entry_limit;
   d.park_limit = f->duo_park_limit;
   return d;
@@ -1856,7 +1857,8 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     return PK_OK;
   }
   if (!strcmp(name, "pub_duo")) {
-    f->duo_on = value != 0;
+    if (value < 0 || value > 2) return fail(PK_ERR_INVALID, "pub_duo: 0 (off), 1 (two 512-lane workgroups per CU) or 2 (three 256-lane workgroups per CU)");
+    f->duo_on = (int)value;
     return PK_OK;
   }
   if (!strcmp(name, "pub_duo_park_limit")) {
@@ -2885,7 +2887,7 @@ int pk_observe_pub_stats(pk_filter* f, int64_t stats[6]) {
     for (int i = 0; i < 4; ++i) stats[i] = w[i];
     stats[4] = f->pub_ecap;
     // which instance worked on the scan: 0 none of the publish / subscribe kernels, 1 the one-workgroup-per-CU instance, 2 k_step_pub_duo
-    stats[5] = sk[0] != 0u ? 0 : (f->route == PK_ROUTE_ML_PUB_BIG && f->duo_on && sk[1] == 0u) ? 2 : 1;
+    stats[5] = sk[0] != 0u ? 0 : (f->route == PK_ROUTE_ML_PUB_BIG && f->duo_on && sk[1] == 0u) ? 1 + f->duo_on : 1;
   }
   return PK_OK;
 }

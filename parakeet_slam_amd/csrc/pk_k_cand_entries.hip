@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     // particle: the landmarks with two or more blobs inside their own gates, a quarter and 64 to spare (a particle that needs more
     // goes to the fall-back kernels, as exact as ever); k_step_pub_big takes every other scan that a publish / subscribe kernel can.
     const unsigned G_ = a.glist[a.B];
-    const unsigned tab = ((s_total + 1u) & ~1u) * 8u + 16u, park = 16u * (s_multi + s_multi / 4u + 64u);
+    const unsigned tab = ((G_ + 3u) & ~3u) * 4u + ((s_total + 1u) & ~1u) * 8u + 16u, park = 16u * (s_multi + s_multi / 4u + 64u);
     const bool duo_ok = fits && a.duo.tbytes > 0 && s_total <= (unsigned)a.duo.ecap && G_ <= (unsigned)a.duo.gcap && tab + park <= (unsigned)a.duo.tbytes;
     if (a.skip_duo) *a.skip_duo = duo_ok ? 0u : 1u;
     if (a.skip_big) *a.skip_big = (fits && !duo_ok) ? 0u : 1u;

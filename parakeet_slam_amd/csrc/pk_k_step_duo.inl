@@ -26,27 +26,30 @@
 // Lanes and landmarks: turn q, lanes 16 k .. 16 k + 15 of the workgroup take the sixteen landmarks of octet s_bperm[32 q + k] --
 // k_cand_entries' ranking of the octets by the length of their lists (the table k_step_pub_big reads with eight lanes per octet), so
 // a wave's 64 landmarks have lists of like length and a row access of sixteen lanes is one 128-byte line.
-constexpr int kDuoGcap = 2048;  // contested blobs whose (first entry | contenders) words are staged in LDS
 constexpr int kDuoHeld = 64;    // landmarks of ONE particle that TAKE two or more blobs (their slots are kept for pass 2)
-constexpr size_t kDuoMaxDynLds = 78 * 1024;  // two workgroups per CU (160 KB less the kernels' static __shared__)
+constexpr size_t kDuoMaxDynLds = 78 * 1024;   // two 512-lane workgroups per CU (160 KB less the kernels' static __shared__)
+constexpr size_t kTrioMaxDynLds = 51 * 1024;  // three 256-lane workgroups per CU (the pair instance, NL = 2)
+constexpr int kDuoTurn = 512;   // landmarks a workgroup works on per turn: 512 lanes x 1, or 256 lanes x 2
 constexpr int kDuoMaxTurns = 10;  // turns of 512 landmarks: maps up to 5 120 (twelve carried words and the update no longer fit 128 VGPRs: two spilled)
 
-// dynamic LDS: any 2 x (Bp + 16) | glist 4 kDuoGcap | held [2][kDuoHeld] uint4 | publish table 8 (E + 2) | overflow area, 16 B a place
-// The last two share what is left (DuoLimits::tbytes): the table takes what THIS scan's entries need -- the kernel reads their number
-// from k_cand_entries' figures --, the overflow area the rest; k_cand_entries gives the scan to this kernel when that rest holds the
-// reference particle's landmarks with two or more blobs inside their gates, with a quarter to spare.
+// dynamic LDS: any 2 x (Bp + 16) | held [2][kDuoHeld] uint4 | glist 4 G | publish table 8 (E + 2) | overflow area, 16 B a place
+// The last three share what is left (DuoLimits::tbytes): the list of contested blobs and the table take what THIS scan needs -- the
+// kernel reads the numbers from k_cand_entries' figures --, the overflow area the rest; k_cand_entries gives the scan to this kernel
+// when that rest holds the reference particle's landmarks with two or more blobs inside their gates, with a quarter to spare.
 __host__ __device__ inline size_t pub_duo_fixed_lds_bytes(int B) {
   const size_t Bp = ((size_t)B + 15) & ~(size_t)15;
-  return 2 * (Bp + 16) + (size_t)kDuoGcap * 4 + 2 * (size_t)kDuoHeld * 16;
+  return 2 * (Bp + 16) + 2 * (size_t)kDuoHeld * 16;
 }
-void step_pub_duo_limits(int B, int Lp, DuoLimits* out) {
+// nl: landmarks per lane and turn -- 1: 512-lane workgroups, two per CU, <= 128 VGPRs; 2: 256-lane workgroups, three per CU, <= 168
+void step_pub_duo_limits(int B, int Lp, int nl, DuoLimits* out) {
   *out = DuoLimits();
-  if (Lp <= kRegsMaxL || Lp > kDuoMaxTurns * kPubThreads || B <= 0) return;
-  const size_t fixed = pub_duo_fixed_lds_bytes(B);
-  if (fixed + 4096 > kDuoMaxDynLds) return;
-  out->tbytes = (int)((kDuoMaxDynLds - fixed) & ~(size_t)15);
+  if (Lp <= kRegsMaxL || Lp > kDuoMaxTurns * kDuoTurn || B <= 0 || (nl != 1 && nl != 2)) return;
+  const size_t fixed = pub_duo_fixed_lds_bytes(B), total = nl == 1 ? kDuoMaxDynLds : kTrioMaxDynLds;
+  if (fixed + 4096 > total) return;
+  out->tbytes = (int)((total - fixed) & ~(size_t)15);
   out->ecap = 65534;
-  out->gcap = kDuoGcap;
+  out->gcap = 65535;
+  out->nl = nl;
 }
 size_t step_pub_duo_lds_bytes(int B, const DuoLimits& lim) { return pub_duo_fixed_lds_bytes(B) + (size_t)lim.tbytes; }
 
@@ -54,17 +57,23 @@ constexpr unsigned kDuoNone = 0xFFFFFFFFu;   // carried word: the landmark takes
 constexpr unsigned kDuoMulti = 0xFFFEu;      // ... entry field of a landmark whose slots are parked: pass 1 -> take: place | kDuoMulti << 16
                                              // (the overflow area); take -> pass 2: place | take bits << 8 | kDuoMulti << 16 (the held area)
 
-template <int NT>
-__global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unused) {
+// NL: landmarks per lane and turn.  1: 512 lanes, <= 128 VGPRs, two workgroups per CU, 8-byte row accesses; 2: an adjacent PAIR per lane
+// (16-byte row accesses, as k_step_pub_big's) worked on one landmark after the other, 256 lanes, <= 168 VGPRs, THREE workgroups per CU.
+template <int NT, int NL>
+__global__ void __launch_bounds__(NL == 1 ? 512 : 256, NL == 1 ? 4 : 3) k_step_pub_duo(PubArgs a_unused) {
+  constexpr int TH = NL == 1 ? 512 : 256;  // lanes of the workgroup
+  constexpr int NW = NT * NL;              // carried words of a lane
   extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ double red[2][kPubThreads / kWave];
+  __shared__ double red[2][TH / kWave];
   __shared__ int wg_flag[2];
   __shared__ unsigned s_novf;      // places of the overflow area dealt out to the particle in pass 1 (read again before barrier C only)
   __shared__ unsigned s_nheld[2];  // places of the held area dealt out to the particle of either parity (read in its pass 2)
   __shared__ unsigned short s_bperm[kPubBigPlaces];
   __shared__ unsigned s_rb[kPubBigSlots];
-#define PK_DUO_L(q_, t_) ((int)(16u * (unsigned)s_bperm[32 * (q_) + ((t_) >> 4)]) + ((t_)&15))
-  constexpr int kPubWaves = kPubThreads / kWave;
+  // the lane's (first) landmark of turn q_: sixteen lanes an octet of sixteen landmarks (NL = 1), or eight lanes with a pair each
+#define PK_DUO_L(q_, t_) (NL == 1 ? (int)(16u * (unsigned)s_bperm[32 * (q_) + ((t_) >> 4)]) + ((t_)&15) \
+                                  : (int)(16u * (unsigned)s_bperm[32 * (q_) + ((t_) >> 3)]) + 2 * ((t_)&7))
+  constexpr int kPubWaves = TH / kWave;
   PubArgsPtr rp = (PubArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid0 = threadIdx.x;
   int B, Lp, L;
@@ -83,23 +92,26 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
     long_lists = R->stats[3] > (unsigned)kCandSlots;
   }
   const unsigned Bp = ((unsigned)B + 15u) & ~15u;
-  // LDS offsets (bytes): any[2][Bp + 16] | glist | held[2][kDuoHeld] | pub (ecap + 2 entries) | overflow area (what is left)
-  const unsigned o_any = 0u, o_glist = 2u * (Bp + 16u), o_held = o_glist + (unsigned)kDuoGcap * 4u, o_pub = o_held + 2u * (unsigned)kDuoHeld * 16u;
+  unsigned G;
+  {
+    PubArgsPtr R = pub_args_now(rp);
+    G = R->glist[B];
+  }
+  // LDS offsets (bytes): any[2][Bp + 16] | held[2][kDuoHeld] | glist (G words) | pub (ecap + 2 entries) | overflow area (what is left)
+  const unsigned o_any = 0u, o_held = 2u * (Bp + 16u), o_glist = o_held + 2u * (unsigned)kDuoHeld * 16u, o_pub = o_glist + ((G + 3u) & ~3u) * 4u;
   const unsigned o_ovf = o_pub + (ecap + 2u) * 8u;
-  unsigned n_places = o_pub + tbytes > o_ovf ? (o_pub + tbytes - o_ovf) / 16u : 0u;  // (>= what k_cand_entries asked for when it gave the scan to this kernel)
+  unsigned n_places = o_glist + tbytes > o_ovf ? (o_glist + tbytes - o_ovf) / 16u : 0u;  // (>= what k_cand_entries asked for when it gave the scan to this kernel)
   if (n_places > 0xFFFFu) n_places = 0xFFFFu;
   if (park_limit >= 0 && n_places > (unsigned)park_limit) n_places = (unsigned)park_limit;
   const unsigned dump = ecap, anydump = Bp;
-  unsigned G;
   {
     const int tid = tid0;
     PubArgsPtr R = pub_args_now(rp);
     unsigned* glist = reinterpret_cast<unsigned*>(smem + o_glist);
     const unsigned* gb = R->glist;
-    G = gb[B];  // (<= kDuoGcap: k_cand_entries)
-    for (int i = tid; i < kDuoGcap; i += kPubThreads) glist[i] = (unsigned)i < G ? gb[i] : 0u;
-    for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
-    if (tid < kPubBigPlaces) s_bperm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[2 * kPubOctets + tid];
+    for (unsigned i = (unsigned)tid; i < G; i += TH) glist[i] = gb[i];
+    for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += TH) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
+    for (int i = tid; i < kPubBigPlaces; i += TH) s_bperm[i] = reinterpret_cast<const unsigned short*>(gb + B + 1)[2 * kPubOctets + i];
     if (tid < kPubBigSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
     if (tid == 0) {
       wg_flag[0] = 0;
@@ -112,7 +124,14 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
   __syncthreads();
 
   // the rows of landmark lb_ of the slot at source src_: the five mean rows first (the gates need nothing else)
-#define PK_DUO_LOAD(field, F) S.field = sf_[(size_t)F * Lp + lb_];
+#define PK_DUO_LOAD(field, F)                                                                         \
+  if constexpr (NL == 1) {                                                                            \
+    S[0].field = sf_[(size_t)F * Lp + lb_];                                                           \
+  } else {                                                                                            \
+    const Double2 v_ = *reinterpret_cast<const Double2*>(sf_ + (size_t)F * Lp + lb_);                 \
+    S[0].field = v_.x;                                                                                \
+    S[NL - 1].field = v_.y;                                                                           \
+  }
 #define PK_DUO_ROWS(lbv_, src_)                                                                       \
   {                                                                                                   \
     PubArgsPtr R2 = pub_args_now(rp);                                                                 \
@@ -136,7 +155,13 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
     PK_DUO_LOAD(cgg, F_CGG)                                                                           \
     PK_DUO_LOAD(cgb, F_CGB)                                                                           \
     PK_DUO_LOAD(cbb, F_CBB)                                                                           \
-    S.count = sc_[lb_];                                                                               \
+    if constexpr (NL == 1) {                                                                          \
+      S[0].count = sc_[lb_];                                                                          \
+    } else {                                                                                          \
+      const Int2 c_ = *reinterpret_cast<const Int2*>(sc_ + lb_);                                      \
+      S[0].count = c_.x;                                                                              \
+      S[NL - 1].count = c_.y;                                                                         \
+    }                                                                                                 \
     asm volatile("" ::: "memory");                                                                    \
   }
   int64_t prev = -1;
@@ -157,9 +182,9 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
   }
   // The rows of a turn are asked for as soon as the turn before it is through, into the registers it has just let go; pass 2 walks
   // back to front from the turn pass 1 ended on (its rows are still there), and asks for the NEXT particle's first turn at its end.
-  Landmark<double> S;
+  Landmark<double> S[NL];
   {
-    const int lb0 = min(PK_DUO_L(0, tid0), Lp - 1);
+    const int lb0 = min(PK_DUO_L(0, tid0), Lp - NL);
     PK_DUO_ROWS(lb0, nsrc)
   }
   for (int64_t p = PK_BIG_FIRST(pub_args_now(rp));; p += PK_BIG_STRIDE(), cur ^= 1) {
@@ -171,9 +196,9 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
     uint4* held = reinterpret_cast<uint4*>(smem + o_held) + (unsigned)cur * (unsigned)kDuoHeld;
     const unsigned* glist = reinterpret_cast<const unsigned*>(smem + o_glist);
     unsigned char* anyc = smem + o_any + (unsigned)cur * (Bp + 16u);
-    unsigned W[NT];  // the carried words: W[0] the turn worked on last
+    unsigned W[NW];  // the carried words: W[0 .. NL) the turn worked on last
 #pragma unroll
-    for (int i = 0; i < NT; ++i) W[i] = kDuoNone;
+    for (int i = 0; i < NW; ++i) W[i] = kDuoNone;
     bool done;
     {
       PubArgsPtr R = pub_args_now(rp);
@@ -184,13 +209,17 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
     if (!done) {
 #pragma unroll 1
       for (int q = 0; q < NT; ++q) {
-        unsigned wq = kDuoNone;
-        if (kPubThreads * q < Lp) {  // workgroup-uniform
+        unsigned wq[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) wq[j] = kDuoNone;
+        if (kDuoTurn * q < Lp) {  // workgroup-uniform
           const int l0 = PK_DUO_L(q, tid);
+#pragma unroll
+          for (int j = 0; j < NL; ++j) {  // (NL = 2: the pair's landmarks one after the other -- one chain of gate / verdict arithmetic at a time)
           PubArgsPtr R = pub_args_now(rp);
           PK_STAMP(c0)
           const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p), sh = pose_scalar(R->h, p);
-          const int lc = min(l0, Lp);  // (lanes beyond the map: the spare records, empty lists -- see k_step_pub)
+          const int lc = min(l0, Lp) + j;  // (lanes beyond the map: the spare records, empty lists -- see k_step_pub)
           const uint4* cr = R->cand + 3 * (size_t)lc;
           const uint4* er = R->erec + 2 * (size_t)lc;
           PubGateIn gi[1];
@@ -208,7 +237,7 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
           uint4 fh0 = make_uint4(0u, 0u, 0u, 0u);
           if (far_hdr_on) fh0 = frow[3 * (size_t)lc];
           asm volatile("" ::: "memory");
-          if (q == 0) {  // the next particle's source slot (as in k_step_pub)
+          if (q == 0 && j == 0) {  // the next particle's source slot (as in k_step_pub)
             PubArgsPtr R4 = pub_args_now(rp);
             const int64_t pn = p + PK_BIG_STRIDE(), pl = PK_BIG_LIMIT(R4);
             nsrc = regs_source_pub(R4->src, pn < pl ? pn : pl - 1);
@@ -217,18 +246,18 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
           PK_DUO_WAIT_ALL
           PK_STAMP(c1)
           PK_PSTAMP(0, c0, c1)
-          gi[0].mx = S.mx;
-          gi[0].my = S.my;
-          gi[0].mr = S.mr;
-          gi[0].mg = S.mg;
-          gi[0].mb = S.mb;
-          gi[0].has = l0 < L;
-          pub_far_bound(S, gi[0].fk, gi[0].fi);
+          gi[0].mx = S[j].mx;
+          gi[0].my = S[j].my;
+          gi[0].mr = S[j].mr;
+          gi[0].mg = S[j].mg;
+          gi[0].mb = S[j].mb;
+          gi[0].has = l0 + j < L;
+          pub_far_bound(S[j], gi[0].fk, gi[0].fi);
           bool viol[1] = {false};
           if (far_hdr_on)  // (uniform) do the scan's pruned lists hold for this landmark?
             viol[0] = gi[0].has && !(gi[0].fi >= (double)__uint_as_float(fh0.y) && gi[0].fk >= (double)__uint_as_float(fh0.x));
           double pp[1] = {0.0};
-          const Landmark<double>* const l1[1] = {&S};
+          const Landmark<double>* const l1[1] = {&S[j]};
           PubSlotsT<kPubBigGateSlots> qq[1];
           // the landmark's primary blob -- the front of its list -- comes from the table in landmark order: its float record in the gates'
           // first round, its exact records where the verdicts want them
@@ -256,34 +285,39 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
           const PubSlots qa = pub_keep_positive(qq[0], &wg_flag[cur]);
           // the carried word: the one blob of probability > 0 (pub_keep_positive puts it in front), or the place of the parked slots
           const int npos = __popc(qa.st & 0x1111u);
-          wq = npos == 0 ? kDuoNone : qa.s[0];
+          wq[j] = npos == 0 ? kDuoNone : qa.s[0];
           if (__ballot(npos >= 2) != 0ull) {  // wave-uniform
             if (npos >= 2) {
               const unsigned place = atomicAdd(&s_novf, 1u);
               if (place < n_places) {
                 ovf[place] = make_uint4(qa.s[0], qa.s[1], qa.s[2], qa.s[3]);
-                wq = place | (kDuoMulti << 16);
+                wq[j] = place | (kDuoMulti << 16);
               } else {  // more such landmarks than the area holds: the fall-back kernels take the particle
                 wg_flag[cur] = 1;
-                wq = kDuoNone;
+                wq[j] = kDuoNone;
               }
             }
           }
           PK_STAMP(c3)
           PK_PSTAMP(2, c2, c3)
-          // the next turn of this pass; the LAST turn's rows stay where they are: pass 2 starts with them
-          if (q + 1 < NT && kPubThreads * (q + 1) < Lp) {  // workgroup-uniform
-            const int ln = min(PK_DUO_L(q + 1, tid), Lp - 1);
-            PK_DUO_ROWS(ln, csrc)
           }
+          // the next turn of this pass; the LAST turn's rows stay where they are: pass 2 starts with them
+          if (q + 1 < NT && kDuoTurn * (q + 1) < Lp) {  // workgroup-uniform
 #if defined(PK_STAMPS)
-          PK_STAMP(c4)
-          PK_PSTAMP(3, c3, c4)
+            PK_STAMP(c3b)
 #endif
+            const int ln = min(PK_DUO_L(q + 1, tid), Lp - NL);
+            PK_DUO_ROWS(ln, csrc)
+#if defined(PK_STAMPS)
+            PK_STAMP(c4)
+            PK_PSTAMP(3, c3b, c4)
+#endif
+          }
         }
 #pragma unroll
-        for (int i = NT - 1; i >= 1; --i) W[i] = W[i - 1];  // (a turn's word enters at the FRONT: pass 2 walks back to front)
-        W[0] = wq;
+        for (int i = NW - 1; i >= NL; --i) W[i] = W[i - NL];  // (a turn's words enter at the FRONT: pass 2 walks back to front)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) W[j] = wq[j];
       }
     }
     PK_STAMP(b1)
@@ -307,43 +341,43 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
     double acc;
     {
       int nun = 0;
-      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) {
+      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += TH) {
         const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
 #pragma unroll
         for (int b = 0; b < 4; ++b) nun += ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) ? 1 : 0;
       }
       acc = (double)nun * Consts<double>::log_no_match;  // unseen features: weight *= 0.1 each (:94-95)
       unsigned* anyn = reinterpret_cast<unsigned*>(smem + o_any + (unsigned)(cur ^ 1) * (Bp + 16u));
-      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
+      for (unsigned w = (unsigned)tid; w < Bp / 4u; w += TH) anyn[w] = 0u;
       if (tid == 0) {  // (the other parity's flag and held places: its particle's pass 2 ended before barrier A, the next one's
                        // pass 1 starts behind barrier C)
         wg_flag[cur ^ 1] = 0;
         s_nheld[cur ^ 1] = 0u;
       }
     }
-    pub_settle_blobs<kPubThreads, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
+    pub_settle_blobs<TH, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     lds_barrier();  // B: every winner is marked, every flag is set
     PK_STAMP(b3)
     PK_PSTAMP(5, b2, b3)
     // which of its blobs every landmark takes (pub_take): a blob nobody else lists, or the entry that carries the winner's marker
     {
-      double m[NT];
+      double m[NW];
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
+      for (int i = 0; i < NW; ++i) {
         const unsigned e = W[i] >> 16;
         m[i] = pub[e < kDuoMulti ? e : dump];
       }
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
+      for (int i = 0; i < NW; ++i) {
         const unsigned e = W[i] >> 16;
         W[i] = (e < kDuoMulti && m[i] != pub_marker()) ? kDuoNone : W[i];  // somebody else's
       }
       bool anymulti = false;
 #pragma unroll
-      for (int i = 0; i < NT; ++i) anymulti |= (W[i] >> 16) == kDuoMulti;
+      for (int i = 0; i < NW; ++i) anymulti |= (W[i] >> 16) == kDuoMulti;
       if (__ballot(anymulti) != 0ull) {  // wave-uniform: some landmark of the wave has its slots parked
 #pragma unroll 1
-        for (int r = 0; r < NT; ++r) {  // (one copy of the code; the words rotate once round)
+        for (int r = 0; r < NW; ++r) {  // (one copy of the code; the words rotate once round)
           const unsigned w0 = W[0];
           const bool multi = (w0 >> 16) == kDuoMulti;
           unsigned wn = w0;
@@ -382,8 +416,8 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
             }
           }
 #pragma unroll
-          for (int i = 0; i + 1 < NT; ++i) W[i] = W[i + 1];
-          W[NT - 1] = wn;
+          for (int i = 0; i + 1 < NW; ++i) W[i] = W[i + 1];
+          W[NW - 1] = wn;
         }
       }
     }
@@ -398,7 +432,7 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
         atomicAdd(R->n_flagged, 1u);
       }
       {  // (the registers hold this particle's last turn: the next particle's first instead)
-        const int lb0 = min(PK_DUO_L(0, tid), Lp - 1);
+        const int lb0 = min(PK_DUO_L(0, tid), Lp - NL);
         PK_DUO_ROWS(lb0, nsrc)
       }
       continue;
@@ -408,23 +442,25 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
 #pragma unroll 1
     for (int qr = 0; qr < NT; ++qr) {
       const int q = NT - 1 - qr;
-      if (kPubThreads * q < Lp) {  // workgroup-uniform
+      if (kDuoTurn * q < Lp) {  // workgroup-uniform
         const int l0 = PK_DUO_L(q, tid);
-        PubArgsPtr R = pub_args_now(rp);
         PK_STAMP(d0)
         PK_DUO_WAIT_ALL
         PK_STAMP(d1)
         PK_PSTAMP(7, d0, d1)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+        PubArgsPtr R = pub_args_now(rp);
         const Noise<double> qt = pub_noise(R);
         const double sx = pose_scalar(R->x, p), sy = pose_scalar(R->y, p);
         const unsigned char* immutable = R->immutable;
         // the landmark's primary blob again (the blob it applies, nearly always): which one it is, and where its exact record stands
-        const int lc2 = min(l0, Lp);
+        const int lc2 = min(l0, Lp) + j;
         const uint4* ptab = R->prim;
         const size_t Lpp = (size_t)Lp + kCandSpare;
         const unsigned t0 = reinterpret_cast<const unsigned*>(ptab + 4 * Lpp)[lc2];
         // the landmark's slots again: its one blob, or what it parked
-        const unsigned w0 = W[0];
+        const unsigned w0 = W[j];
         const bool multi = (w0 >> 16) == kDuoMulti;
         PubSlots qs = kPubNoSlots;
         qs.s[0] = multi ? 0xFFFFFFFFu : w0;
@@ -441,9 +477,10 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
           }
         }
         // the expected bearing (:871), as pass 1 worked it out: the same expression on the same bits
-        const double pse = pk_atan2(S.my - sy, S.mx - sx);
-        acc += pub_apply_loop<true>(qs, R->exact, R->order, qt, S, immutable[min(l0, L - 1)] != 0, sx, sy, pse,
+        const double pse = pk_atan2(S[j].my - sy, S[j].mx - sx);
+        acc += pub_apply_loop<true>(qs, R->exact, R->order, qt, S[j], immutable[min(l0 + j, L - 1)] != 0, sx, sy, pse,
                                     reinterpret_cast<const char*>(ptab + Lpp), Lpp * 16, lc2, t0);
+        }
         PK_STAMP(d2)
         PK_PSTAMP(8, d1, d2)
         if (l0 < Lp) {
@@ -451,7 +488,13 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
           unsigned char* dslot = R3->map_dst + (size_t)p * R3->ss.slot_bytes;
           double* df = reinterpret_cast<double*>(dslot);
           int* dc = reinterpret_cast<int*>(dslot + R3->count_off);
-#define PK_DUO_STORE(field, F) __builtin_nontemporal_store(S.field, df + (size_t)F * Lp + l0);
+#define PK_DUO_STORE(field, F)                                                                  \
+  if constexpr (NL == 1) {                                                                      \
+    __builtin_nontemporal_store(S[0].field, df + (size_t)F * Lp + l0);                          \
+  } else {                                                                                      \
+    const Double2 v_ = {S[0].field, S[NL - 1].field};                                           \
+    __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0));     \
+  }
           PK_DUO_STORE(mx, F_MX)
           PK_DUO_STORE(my, F_MY)
           PK_DUO_STORE(mr, F_MR)
@@ -467,11 +510,16 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
           PK_DUO_STORE(cgb, F_CGB)
           PK_DUO_STORE(cbb, F_CBB)
 #undef PK_DUO_STORE
-          __builtin_nontemporal_store(S.count, dc + l0);
+          if constexpr (NL == 1) {
+            __builtin_nontemporal_store(S[0].count, dc + l0);
+          } else {
+            const Int2 c2_ = {S[0].count, S[NL - 1].count};
+            __builtin_nontemporal_store(c2_, reinterpret_cast<Int2*>(dc + l0));
+          }
         }
         {  // the turn before it, or the next particle's first one
           const bool more = q > 0;  // workgroup-uniform
-          const int ln = min(PK_DUO_L(more ? q - 1 : 0, tid), Lp - 1);
+          const int ln = min(PK_DUO_L(more ? q - 1 : 0, tid), Lp - NL);
           const int32_t sn = more ? csrc : nsrc;
           PK_DUO_ROWS(ln, sn)
         }
@@ -479,7 +527,7 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
         PK_PSTAMP(10, d2, d3)
       }
 #pragma unroll
-      for (int i = 0; i + 1 < NT; ++i) W[i] = W[i + 1];  // the word of the turn before it to the front
+      for (int i = 0; i + NL < NW; ++i) W[i] = W[i + NL];  // the words of the turn before it to the front
     }
     {
       const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier A
@@ -496,7 +544,7 @@ __global__ void __launch_bounds__(kPubThreads, 4) k_step_pub_duo(PubArgs a_unuse
   }
 #ifdef PK_STAMPS
   if ((tid0 & 63) == 0)
-    for (int k = 0; k < 12; ++k) atomicAdd(&pk_pstamp_wave[tid0 >> 6][k], pst[k]);
+    for (int k = 0; k < 12; ++k) atomicAdd(&pk_pstamp_wave[(tid0 >> 6) + (NL == 2 ? 4 * (int)(blockIdx.x & 1u) : 0)][k], pst[k]);
 #endif
 #undef PK_DUO_WAIT_ALL
 #undef PK_DUO_ROWS
@@ -512,8 +560,10 @@ void launch_step_pub_duo(hipStream_t s, DeviceState& d, int B, const double* exa
   if (d.P == 0 || p1 <= p0 || lim.tbytes <= 0 || !prim_dev || !stats_dev) return;
   static bool attr_set[kMaxDevices] = {false};
   if (first_time_on_this_device(attr_set)) {
-    for (const void* fn : {reinterpret_cast<const void*>(k_step_pub_duo<6>), reinterpret_cast<const void*>(k_step_pub_duo<10>)})
+    for (const void* fn : {reinterpret_cast<const void*>(k_step_pub_duo<6, 1>), reinterpret_cast<const void*>(k_step_pub_duo<10, 1>)})
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDuoMaxDynLds) != hipSuccess) (void)hipGetLastError();
+    for (const void* fn : {reinterpret_cast<const void*>(k_step_pub_duo<6, 2>), reinterpret_cast<const void*>(k_step_pub_duo<10, 2>)})
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTrioMaxDynLds) != hipSuccess) (void)hipGetLastError();
   }
   PubArgs a;
   a.ss = slot_source(d);
@@ -548,13 +598,21 @@ void launch_step_pub_duo(hipStream_t s, DeviceState& d, int B, const double* exa
   a.gmax_key = ex.gmax_key;
   a.qt = make_noise(qt.q00, qt.rr, qt.rg, qt.rb, qt.gg, qt.gb, qt.bb);
   const int n_cu = device_cu_count();
-  // persistent grid, TWO workgroups per CU; reserve_cus as in launch_step_regs
-  int64_t grid_n = 2 * (int64_t)(n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0));
+  // persistent grid, TWO 512-lane (or THREE 256-lane) workgroups per CU; reserve_cus as in launch_step_regs
+  const int per_cu = lim.nl == 2 ? 3 : 2, th = lim.nl == 2 ? 256 : 512;
+  int64_t grid_n = per_cu * (int64_t)(n_cu - (reserve_cus > 0 && reserve_cus < n_cu ? reserve_cus : 0));
   if (grid_n > p1 - p0) grid_n = p1 - p0;
   const size_t lds = step_pub_duo_lds_bytes(B, lim);
-  const int nt = (d.lay.Lp + kPubThreads - 1) / kPubThreads;
-  if (nt <= 6)
-    hipLaunchKernelGGL(k_step_pub_duo<6>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
-  else
-    hipLaunchKernelGGL(k_step_pub_duo<10>, dim3((unsigned)grid_n), dim3(kPubThreads), lds, s, a);
+  const int nt = (d.lay.Lp + kDuoTurn - 1) / kDuoTurn;
+  if (lim.nl == 2) {
+    if (nt <= 6)
+      hipLaunchKernelGGL((k_step_pub_duo<6, 2>), dim3((unsigned)grid_n), dim3(th), lds, s, a);
+    else
+      hipLaunchKernelGGL((k_step_pub_duo<10, 2>), dim3((unsigned)grid_n), dim3(th), lds, s, a);
+  } else {
+    if (nt <= 6)
+      hipLaunchKernelGGL((k_step_pub_duo<6, 1>), dim3((unsigned)grid_n), dim3(th), lds, s, a);
+    else
+      hipLaunchKernelGGL((k_step_pub_duo<10, 1>), dim3((unsigned)grid_n), dim3(th), lds, s, a);
+  }
 }

@@ -1526,8 +1526,74 @@ __device__ __forceinline__ PubSlots pub_keep_positive(const PubSlotsT<kPubBigGat
     o.s[0] = pos ? g.s[k] : o.s[0];
     o.st = pos ? ((o.st << 4) | 1u) : o.st;
   }
-  if (__popc(g.st & 0x11111111u) > kPubSlots) *flag = 1;
+  if (flag && __popc(g.st & 0x11111111u) > kPubSlots) *flag = 1;
+  o.st &= 0xFFFFu;  // (a state nibble per blob of probability > 0 was shifted in: only the four kept ones' stay -- the upper half is
+                    // where pub_park_beyond_four puts the place of the others)
   return o;
+}
+// Round 6: a landmark with MORE than four blobs of probability > 0 -- on the first scan of a fresh map of several thousand landmarks
+// (0.25 I colour blocks: every look-alike inside the gates counts) a hundred landmarks of EVERY particle, so that every particle of
+// step 0 was handed to the fall-back kernels: 115 ms where the steps behind it take 7 (20 000 x 5 000), 0.7 s at a configs[4] shard --
+// keeps its first four in the slots as before and parks the fifth to eighth in LDS: the entries of the publish table this scan does
+// not use (k_cand_entries' figure says how many it does) are the overflow area, 16 bytes a place, dealt out by a counter.  Behind
+// the settling the landmark looks at the parked blobs' markers too; a parked blob it TAKES moves into a slot it did not take (there
+// nearly always is one: a landmark takes one blob, rarely two); only a landmark that takes more than four sends the particle on.
+__device__ __forceinline__ uint4 pub_positive_beyond_four(const PubSlotsT<kPubBigGateSlots>& g) {
+  unsigned x[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kPubBigGateSlots; ++k) {
+    const bool pos = ((g.st >> (4 * k)) & 1u) != 0u;
+    x[0] = (pos && c == 4) ? g.s[k] : x[0];
+    x[1] = (pos && c == 5) ? g.s[k] : x[1];
+    x[2] = (pos && c == 6) ? g.s[k] : x[2];
+    x[3] = (pos && c == 7) ? g.s[k] : x[3];
+    c += pos ? 1 : 0;
+  }
+  return make_uint4(x[0], x[1], x[2], x[3]);
+}
+// ... in pass 1: the place goes into the upper half of the slots' state word (place + 1; 0: nothing parked)
+__device__ __forceinline__ void pub_park_beyond_four(PubSlots& q, const PubSlotsT<kPubBigGateSlots>& g, uint4* ovf, unsigned n_places, unsigned* counter,
+                                                     int* flag) {
+  if (__popc(g.st & 0x11111111u) > kPubSlots) {
+    const unsigned place = atomicAdd(counter, 1u);
+    if (place < n_places) {
+      ovf[place] = pub_positive_beyond_four(g);
+      q.st |= (place + 1u) << 16;
+    } else {
+      *flag = 1;
+    }
+  }
+}
+// ... behind the settling (after pub_take): the parked blobs this landmark takes move into slots it did not take
+__device__ __forceinline__ void pub_take_parked(PubSlots& q, const uint4* ovf, const double* pub, unsigned dump, int* flag) {
+  const unsigned pl = q.st >> 16;
+  if (__ballot(pl != 0u) == 0ull) return;  // wave-uniform: the usual case
+  if (pl != 0u) {
+    const uint4 s4 = ovf[pl - 1u];
+    const unsigned xw[4] = {s4.x, s4.y, s4.z, s4.w};
+    double m[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const unsigned e = xw[x] >> 16;
+      m[x] = pub[e == 0xFFFFu ? dump : e];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const unsigned e = xw[x] >> 16;
+      const bool take = (xw[x] & 0xFFFFu) != 0xFFFFu && (e == 0xFFFFu || m[x] == pub_marker());  // (every parked blob has probability > 0)
+      bool placed = !take;
+#pragma unroll
+      for (int sidx = 0; sidx < kPubSlots; ++sidx) {
+        const bool here = !placed && ((q.st >> (4 * sidx)) & 4u) == 0u;
+        q.s[sidx] = here ? xw[x] : q.s[sidx];
+        q.st = here ? ((q.st & ~(0xFu << (4 * sidx))) | (5u << (4 * sidx))) : q.st;
+        placed |= here;
+      }
+      if (!placed) *flag = 1;  // more than four blobs taken: the fall-back kernels
+    }
+  }
+  q.st &= 0xFFFFu;
 }
 // (at B = 5 000 the publish table needs some 15 000 entries: the scan-order table -- read only where a landmark takes two
 // blobs -- stays in global memory, and there is no room for the immutable flags either)
@@ -1556,6 +1622,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   // their longest candidate list, so that a wave's -- and a chunk's -- lists are of like length)
   __shared__ unsigned short s_bperm[kPubBigPlaces];
   __shared__ unsigned s_rb[kPubBigSlots];  // the publish table's rank bases (k_cand_entries)
+  __shared__ unsigned s_novf[2];           // places of the overflow area dealt out in pass 1 to the particle of either parity (pub_park_beyond_four)
 #define PK_BIG_L0(q_, t_) ((int)(16u * (unsigned)s_bperm[kPubOctets * (q_) + ((t_) >> 3)]) + 2 * ((t_)&7))
   constexpr int kPubWaves = kPubThreads / kWave;
 #ifdef PK_DIAG_BIG_FRONT_TO_BACK  // (regression build: pass 2 front to back from rows asked for again, as until round 5)
@@ -1579,12 +1646,17 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   const unsigned o_glist = ((unsigned)ecap + 2u) * 8u, o_any = o_glist + Bp * 4u;
   const unsigned dump = (unsigned)ecap, anydump = Bp;
   unsigned G;
+  unsigned ovf0, n_places;  // the overflow area: the table's entries this scan does not use (pub_park_beyond_four)
   {
     const int tid = tid0;
     PubArgsPtr R = pub_args_now(rp);
     unsigned* glist = reinterpret_cast<unsigned*>(smem + o_glist);
     const unsigned* gb = R->glist;
     G = gb[B];
+    const unsigned E = R->stats[0];
+    ovf0 = (E + 1u) & ~1u;  // (an even entry: 16 bytes a place)
+    n_places = (unsigned)ecap > ovf0 ? ((unsigned)ecap - ovf0) / 2u : 0u;
+    if (n_places > 0xFFFEu) n_places = 0xFFFEu;
     for (int i = tid; i < B; i += kPubThreads) glist[i] = (unsigned)i < G ? gb[i] : 0u;
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
     if (tid < kPubBigPlaces) s_bperm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[2 * kPubOctets + tid];
@@ -1592,6 +1664,8 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
+      s_novf[0] = 0u;
+      s_novf[1] = 0u;
     }
   }
   __syncthreads();
@@ -1787,8 +1861,13 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
                                                                              PubNoChk(), &prim);
             }
           }
-          qa = pub_keep_positive(qq[0], &wg_flag[cur]);
-          qb = pub_keep_positive(qq[1], &wg_flag[cur]);
+          qa = pub_keep_positive(qq[0], nullptr);
+          qb = pub_keep_positive(qq[1], nullptr);
+          if (__ballot(__popc(qq[0].st & 0x11111111u) > kPubSlots || __popc(qq[1].st & 0x11111111u) > kPubSlots) != 0ull) {  // wave-uniform, rare
+            uint4* ovf = reinterpret_cast<uint4*>(smem) + ovf0 / 2u;
+            pub_park_beyond_four(qa, qq[0], ovf, n_places, &s_novf[cur], &wg_flag[cur]);
+            pub_park_beyond_four(qb, qq[1], ovf, n_places, &s_novf[cur], &wg_flag[cur]);
+          }
 #if defined(PK_STAMPS) && defined(PK_DIAG_BIG_CERTAIN)
           {  // (diagnostic: how many wave.pairs hold only landmarks whose gate-passing blobs nobody else lists -- DESIGN.md section 10.2)
             bool cert = true;
@@ -1879,7 +1958,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
       acc = (double)nun * Consts<double>::log_no_match;  // unseen features: weight *= 0.1 each (:94-95)
       unsigned* anyn = reinterpret_cast<unsigned*>(smem + o_any + (unsigned)(cur ^ 1) * (Bp + 16u));
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
-      if (tid == 0) wg_flag[cur ^ 1] = 0;
+      if (tid == 0) {  // (the other parity's: its particle's markers were read before its barrier C, the next one's pass 1 starts behind this one's C)
+        wg_flag[cur ^ 1] = 0;
+        s_novf[cur ^ 1] = 0u;
+      }
     }
     pub_settle_blobs<kPubThreads, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     lds_barrier();  // B: every winner is marked, every flag is set
@@ -1887,6 +1969,10 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     PK_PSTAMP(5, b2, b3)
 #pragma unroll
     for (int i = 0; i < 2 * NCH; ++i) pub_take(Q[i], pub, dump);
+    if (s_novf[cur] != 0u) {  // workgroup-uniform (written before barrier A; the other parity's is reset between A and B): some landmark parked blobs
+#pragma unroll
+      for (int i = 0; i < 2 * NCH; ++i) pub_take_parked(Q[i], reinterpret_cast<const uint4*>(smem) + ovf0 / 2u, pub, dump, &wg_flag[cur]);
+    }
     lds_barrier();  // C: every marker has been read -- the table is the next particle's
     PK_STAMP(b4)
     PK_PSTAMP(6, b3, b4)

@@ -264,6 +264,7 @@ struct DuoLimits {
   int tbytes = 0;  // bytes of LDS the publish table (8 per entry) and the overflow area (16 per landmark with several blobs) share; 0: off
   int ecap = 0;    // entries at most (the option "pub_entry_limit")
   int gcap = 0;    // contested blobs at most
+  int nl = 1;      // landmarks per lane and turn: 1 (512 lanes, two workgroups per CU) or 2 (256 lanes with a pair each, three per CU)
   int park_limit = -1;  // >= 0 (tests, option "pub_duo_park_limit"): the kernel treats its overflow area as this many places
 };
 void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4* cand_dev, uint4* erec_dev, unsigned* bcnt_dev,
@@ -296,7 +297,7 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
 // per landmark, the expected bearing worked out again in pass 2 -- at most 128 VGPRs, so that two 512-lane workgroups share a CU
 // (four waves per SIMD) and one's row latency is the other's float64 issue.  Each has half the CU's LDS: k_cand_entries decides per
 // scan whether the publish table fits (step_pub_duo_limits -> DuoLimits; *skip_duo), k_step_pub_big takes the scans that do not.
-void step_pub_duo_limits(int B, int Lp, DuoLimits* out);
+void step_pub_duo_limits(int B, int Lp, int nl, DuoLimits* out);
 size_t step_pub_duo_lds_bytes(int B, const DuoLimits& lim);
 void launch_step_pub_duo(hipStream_t s, DeviceState& d, int B, const double* exact_dev, const unsigned short* order_dev,
                          const FastHandoff& fh, const NoiseD& qt, const ObserveExtras& ex, const CandTable& cand, const uint4* erec_dev,

@@ -437,6 +437,24 @@ def test_a_landmark_that_passes_more_blobs_than_it_has_slots_is_settled_in_the_k
     against_oracle(pub, means, covs, poses, blobs)
 
 
+@pytest.mark.parametrize("L,n_lookalike,n_sightings", [(2600, 4, 1), (2600, 6, 1), (3000, 5, 2), (5000, 7, 1), (4096, 3, 3)])
+def test_the_two_pass_kernel_parks_the_fifth_to_eighth_blob_of_positive_probability(lib, L, n_lookalike, n_sightings):
+    """Round 6 (missing #4: the 99-ms step in the warm-up).  On the first scan of a fresh map of several thousand
+    landmarks (0.25 I colour blocks) every blob inside a landmark's gates has a probability > 0, a hundred landmarks of every particle
+    have five or more, and k_step_pub_big -- four slots a landmark -- handed EVERY particle of that step to the fall-back kernels.
+    Now the fifth to eighth wait in the publish table's unused entries and move into a slot the landmark did not take behind the
+    settling: nobody is flagged, and the state is the general kernels' bit for bit (match_one's argmax :353-381 over all of them)."""
+    rs = np.random.RandomState(700 + L + n_lookalike)
+    means, covs, blobs = crowded_landmark_scene(L, rs, n_lookalike, n_sightings, tight=False)
+    poses = poses_around(rs, 3, 0.05)
+    big = run(lib, means, covs, poses, blobs, {"pub_duo": 0})
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert big["route"] == "ml_pub_big" and big["published"]
+    assert (gen["ids"] == 41).sum(axis=1).min() >= n_sightings  # landmark 40 takes its own sightings, whoever else wanted them
+    assert big["flagged"] == 0, big["flagged"]
+    same_state(big, gen, 1e-11)
+
+
 def test_more_than_four_blobs_with_a_positive_probability_still_go_to_the_fallback_kernels(lib):
     rs = np.random.RandomState(99)
     L = 1200
