@@ -937,6 +937,15 @@ def main():
             refscene["new_landmarks"] = facade_growing(local_rank, 10000, 40, 6, 12)
         except Exception as e:  # noqa: BLE001
             refscene["new_landmarks"] = {"error": repr(e)}
+        try:  # ... and at the headline's size: 100 000 particles, 2 000 preset + 6 unknown landmarks, 16 spare slots
+            g = facade_growing(local_rank, DEFAULT_P, DEFAULT_L, 6, 14, spare=16)
+            fixed = (refscene.get("configs2_through_the_facade") or {}).get("array", {}).get("ms_per_step")
+            g["fixed_map_ms_per_step"] = fixed
+            if fixed and g.get("ms_per_step_afterwards"):
+                g["afterwards_over_fixed_map"] = g["ms_per_step_afterwards"] / fixed
+            refscene["new_landmarks_at_scale"] = g
+        except Exception as e:  # noqa: BLE001
+            refscene["new_landmarks_at_scale"] = {"error": repr(e)}
 
     # what a plain device-to-device copy reaches on THIS box (read + write bytes / time), outside the
     # timed region: the practical ceiling next to the 8 TB/s vendor figure
@@ -1133,7 +1142,7 @@ def facade_at_size(device, P, L, steps, warm):
     return out
 
 
-def facade_growing(device, P, L0, U, steps):
+def facade_growing(device, P, L0, U, steps, spare=None):
     """FastSLAM(new_landmarks=True).cam_cb + summary() per step on a scene with U landmarks the preset map does not hold
     (prkt_core_v2.py:546-746 made to work): the unmatched blobs of every particle are paired and
     triangulated by ONE kernel behind the observe, the readings / id counters / slot ids live in HBM and follow the resample on
@@ -1151,7 +1160,7 @@ def facade_growing(device, P, L0, U, steps):
     pk.msgs.Time.set_now(0.0)
     random.seed(7)
     fs = pk.FastSLAM(feats, num_particles=P, device=device, weight_domain="log", rng="device", seed=7, new_landmarks=True,
-                     spare_landmarks=U + 2, publish_debug=False)
+                     spare_landmarks=(U + 2) if spare is None else spare, publish_debug=False)
     node = Node()
     node.last_sensor_reading = Scan()
     tw = pk.msgs.Twist()
@@ -1176,7 +1185,10 @@ def facade_growing(device, P, L0, U, steps):
     promoted = float((((k & 0x40000000) == 0) & (np.arange(k.shape[1])[None, :] < u[:, None])).sum() / float(P))
     growing = [i for i in range(1, steps) if used[i] > used[i - 1]]
     out = {"what": "wall time of FastSLAM(new_landmarks=True).cam_cb + summary() per step, %d particles, %d preset + %d unknown landmarks, "
-                   "bookkeeping='device' (pk_k_grow.hip); the general ML route (the bookkeeping kernel reads the association's ids in HBM)" % (P, L0, U),
+                   "bookkeeping='device' (pk_k_grow.hip); since round 6 on the one-pass route of the map's size (the publish / subscribe kernels leave "
+                   "every particle's unmatched blobs as a bit row; rounds 2-5: the general route, whose ids the bookkeeping kernel read)" % (P, L0, U),
+           "route": fs._filter.observe_route(), "one_pass_kernel_did_the_last_scan": bool(fs._filter.observe_published()),
+           "particles_sent_to_general_kernels_last_step": int(fs._filter.observe_flagged()[0]),
            "ms_per_step": [round(x * 1e3, 3) for x in dts],
            "ms_per_step_while_maps_grow": round(float(np.mean([dts[i] for i in growing])) * 1e3, 3) if growing else None,
            "ms_per_step_afterwards": round(float(np.mean(dts[max(growing) + 1:])) * 1e3, 3) if growing and max(growing) + 1 < steps else None,

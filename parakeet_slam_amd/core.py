@@ -792,6 +792,19 @@ class FastSLAM(object):
             if self._publish:
                 self._publish_all(self.particle_track_pub, self._poses())  # :126-127
             self.low_variance_resample()  # :137
+            self._steps_done = getattr(self, "_steps_done", 0) + 1
+            if self._nl_device and not getattr(self, "_warned_dropped", False) and self._steps_done % 16 == 0:
+                # (the reference's hypothesis_set grows without bound; the device ring holds reading_capacity orphaned
+                # readings per particle and counts what it has to drop -- say so once, not only through readings_dropped())
+                n = self.readings_dropped()
+                if n:
+                    import warnings
+
+                    warnings.warn("FastSLAM(new_landmarks=True): %d orphaned readings found their particle's ring full and were dropped "
+                                  "(reading_capacity=%d per particle; the reference keeps every reading): later unknown landmarks may not be "
+                                  "triangulated -- raise reading_capacity, or use bookkeeping='host'" % (n, self._filter.grow_shape()[2]),
+                                  RuntimeWarning, stacklevel=2)
+                    self._warned_dropped = True
 
     def _new_landmarks(self, blobs, ids):
         """add_hypothesis (:546-564) for every unmatched blob of every particle, in scan order, with the working pairing

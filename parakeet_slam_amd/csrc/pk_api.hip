@@ -157,6 +157,10 @@ struct pk_filter {
   uint4* erec_dev2 = nullptr;    // [Lp][2] the same for sixteen-entry lists (k_step_pub_big)
   unsigned* binfo_dev = nullptr; // [bcand_cap] per blob: first entry | contenders << 16
   unsigned char* npass_dev = nullptr; // [Lp + kCandSpare] per landmark: blobs inside the reference particle's own gates (k_candidates)
+  unsigned* unm_dev = nullptr;   // growing maps on the publish / subscribe routes: [P][unm_words] every particle's unmatched blobs, bits in scan order
+  int unm_words = 0;
+  int64_t unm_cap = 0;
+  bool grow_bits = false;        // the last observe's one-pass kernel left those rows (k_new_landmarks reads them where the particle was not handed on)
   uint4* prim_dev = nullptr;     // the two-pass kernels' primary-blob table: every landmark's first candidate in landmark order (prim_table_uint4; k_cand_entries)
   float4* gate4_dev = nullptr;   // [bcand_cap] every blob's bearing and colour as float: k_step_pub_big's first look (k_cand_entries)
   uint4* far_dev = nullptr;      // [Lp + kCandSpare][3] per landmark: the bound its list was pruned with | its far list (k_candidates, pk_pub_math.hpp)
@@ -670,8 +674,12 @@ static bool regs_route_taken(pk_filter* f, const BlobGrid& g, int B, int n9) {
 
 // Upload one scan for maximum-likelihood association (one block) and enqueue the association.
 // `blobs` may be the staged copy itself (pk_observe_staged).
-int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize, bool want_fast, AssocLaunch* out) {
+// onepass_only (growing maps: the bookkeeping kernel needs every particle's unmatched blobs -- the publish / subscribe kernels leave them
+// as bit rows, the general association as ids): a one-pass route whose kernel is of the publish / subscribe family, or else the
+// general association; never the hand-off routes, k_step_fused or k_step_regs
+int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize, bool want_fast, AssocLaunch* out, bool onepass_only = false) {
   int rc;
+  const bool pub_ok = !onepass_only || (f->pub_step && f->cand_lists && B <= 32 * 176);
   pk_filter::Staged& sg = f->staged;
   const size_t o_blobs = kCtlBytes;
   const size_t o_dir = o_blobs + (size_t)B * 4 * sizeof(double);
@@ -702,7 +710,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
     FastHandoff fh{};
     const bool sweep = f->d.lay.L > kFastMaxL || f->fast_observe >= 2;
     if (out && want_fast && !finalize && f->fast_observe == 1 && f->fused_step && !sweep && B > 0 && n9 > 0 &&
-        fused_lds_bytes(g.ncell, B, n9) <= kFusedMaxLds) {
+        fused_lds_bytes(g.ncell, B, n9) <= kFusedMaxLds && pub_ok && (!onepass_only || (step_pub_entry_capacity_small(B) > 0 && B <= 32 * 32))) {
       if ((rc = ensure_handoff(f, B, kFastSlots, false))) return rc;
       out->fused = true;
       out->grid = g;
@@ -714,7 +722,8 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       return PK_OK;
     }
     if (out && want_fast && !finalize && f->fast_observe == 1 && f->regs_step && f->d.lay.L > kFastMaxL &&
-        f->d.lay.L <= kRegsMaxL && B > 0 && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds) {
+        f->d.lay.L <= kRegsMaxL && B > 0 && n9 > 0 && regs_lds_bytes(g.ncell, B, n9) <= kMaxDynLds && pub_ok &&
+        (!onepass_only || (step_pub_entry_capacity(B) > 0 && regs_cand_lds_bytes(f->d.lay.Lp, B) <= kMaxDynLds && B <= 32 * 96))) {
       // the flags, and -- when the two-sweep kernel can take this scan -- eight-slot hand-off lists for the second chance of
       // the particles k_step_regs flags (allocated here, not at the first flagged particle in the middle of a run)
       out->retry = f->regs_retry && observe_sweep_plan(f->d, B).grid > 0;
@@ -729,7 +738,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       return PK_OK;
     }
     if (out && want_fast && !finalize && f->fast_observe == 1 && f->pub_step && f->cand_lists && f->d.lay.L > kRegsMaxL &&
-        f->d.lay.L <= kPubBigMaxL && B > 0 && step_pub_big_entry_capacity(B) > 0 && observe_sweep_plan(f->d, B).grid > 0) {
+        f->d.lay.L <= kPubBigMaxL && B > 0 && step_pub_big_entry_capacity(B) > 0 && observe_sweep_plan(f->d, B).grid > 0 && pub_ok) {
       // maps beyond the register route: publish / subscribe in two passes (k_step_pub_big); what it flags -- or the whole scan,
       // when a sixteen-entry list overflows or the publish table does not fit LDS -- goes through the eight-slot hand-off
       // and k_observe_sweep, then the general kernels
@@ -744,7 +753,7 @@ int enqueue_association(pk_filter* f, const double* blobs, int B, bool finalize,
       out->order = reinterpret_cast<const unsigned short*>(f->scan_dev + o_tab + cs_b + (size_t)B * 16 + (size_t)n9 * 2);
       return PK_OK;
     }
-    if (want_fast && !finalize && f->fast_observe && B > 0 &&
+    if (want_fast && !onepass_only && !finalize && f->fast_observe && B > 0 &&
         (sweep ? observe_sweep_plan(f->d, B).grid > 0 : observe_fast_lds_bytes(B) <= kMaxDynLds)) {
       // eight hand-off slots per landmark for the large scans (a landmark's colour neighbourhood gets
       // busier with B: at B = 5 000 random colours some landmark of every particle passes 5-7 blobs),
@@ -1000,7 +1009,7 @@ int pk_destroy(pk_filter* f) {
     (void)hipFree(d.map[i]);
   }
   if (f->scan_dev) (void)hipFree(f->scan_dev);
-  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev, (void*)f->far_dev, (void*)f->prim_dev})
+  for (void* q : {(void*)f->fh.lmpass, (void*)f->fh.bcount, (void*)f->fh.pflag, (void*)f->fh.row_of, (void*)f->sweep_results, (void*)f->cand_dev, (void*)f->bcnt_dev, (void*)f->brec_dev, (void*)f->erec_dev, (void*)f->erec_dev2, (void*)f->binfo_dev, (void*)f->glist_dev, (void*)f->gate4_dev, (void*)f->npass_dev, (void*)f->far_dev, (void*)f->prim_dev, (void*)f->unm_dev})
     if (q) (void)hipFree(q);
   for (int i = 0; i < 2; ++i)
     for (void* q : {(void*)f->grow.hyp[i], (void*)f->grow.cnt[i], (void*)f->grow.slot_id[i]})
@@ -1415,7 +1424,7 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
   f->pub_ecap = 0;
   // the register route; with "pub_small" (off: measured) also the L <= 512 route through the publish /
   // subscribe instance of three 256-lane workgroups per CU
-  const bool small_pub = al.fused && f->pub_small && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
+  const bool small_pub = al.fused && (f->pub_small || f->grow_on) && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
   if (al.big) {  // sixteen-entry lists both ways and the publish table's layout
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
     if (!f->npass_dev && (rc = dev_alloc(f, &f->npass_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
@@ -1499,7 +1508,7 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
     // pruned lists (cand.far): k_step_regs' candidate-list instance never takes them (k_cand_entries: skip_cand) -- it is not even
     // launched then (5 us a step for a kernel that returns at once) --, so a scan the publish / subscribe kernel stood back from goes
     // to the fall-back kernels as a whole
-    if (cand.far && f->pub_ecap > 0)
+    if ((cand.far || f->grow_on) && f->pub_ecap > 0)  // (growing maps: only the publish / subscribe kernels leave the unmatched blobs' bit rows)
       launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
     else
       launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
@@ -1508,8 +1517,14 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
     if (f->pub_ecap > 0 && cand.rec)
       launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
                       p0, p1, reserve_cus);
-    launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1,
-                      (f->pub_ecap > 0 && cand.rec) ? ctl_skip_pub(f) : nullptr);
+    // (round 6: no k_step_fused stand-by behind the publish / subscribe instance -- 10 000 workgroups that return at once were 5.7 us of a
+    // 270-us step; a scan that kernel stands back from -- its table does not fit a third of a CU's LDS: a few hundred entries do -- goes
+    // to the general kernels as a whole.  Growing maps need it that way: only the publish / subscribe kernels leave the unmatched blobs' rows)
+    if (f->pub_ecap > 0 && cand.rec)
+      launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
+    else
+      launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1,
+                        (f->pub_ecap > 0 && cand.rec) ? ctl_skip_pub(f) : nullptr);
   }
   return PK_OK;
 }
@@ -1644,7 +1659,28 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   }
   // maximum-likelihood association on the device
   AssocLaunch al;
-  if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr && !grow, &al))) return rc;  // (ids wanted: the association kernel + k_observe)
+  // (ids wanted: the association kernel + k_observe; growing maps: a publish / subscribe kernel, or that)
+  if ((rc = enqueue_association(f, blobs, B, false, ids_out == nullptr, &al, grow))) return rc;
+  f->grow_bits = false;
+  if (grow && (al.fused || al.regs || al.big)) {
+    // round 6: the one-pass kernel leaves every particle's unmatched blobs as a bit row (scan order); no second chance -- what it
+    // hands on goes to the general kernels, which leave ids
+    al.retry = false;
+    const int words = 2 * ((B + 63) / 64);
+    if ((int64_t)f->d.P * words > f->unm_cap) {
+      PK_HIP(hipStreamSynchronize(f->stream));
+      if (f->unm_dev) (void)hipFree(f->unm_dev);
+      f->unm_dev = nullptr;
+      f->unm_cap = 0;
+      const int64_t cap = (int64_t)f->d.P * (words + words / 4 + 2);
+      if ((rc = dev_alloc(f, &f->unm_dev, (size_t)cap))) return rc;
+      f->unm_cap = cap;
+    }
+    f->unm_words = words;
+    ex.unm = f->unm_dev;
+    ex.unm_words = words;
+    f->grow_bits = true;
+  }
   ex.gmax_key = ctl_gmax_key(f);
   f->route = al.big ? PK_ROUTE_ML_PUB_BIG
              : al.fused ? PK_ROUTE_ML_FUSED
@@ -1690,7 +1726,8 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
   f->gmax_fused = true;
   if (grow) {  // :92-95 for every particle, on the ids the association kernel left in HBM (every particle's slot is its own now)
     Span t(f, PK_T_OBSERVE);
-    launch_new_landmarks(f->stream, f->d, f->grow, f->ids_dev, al.blobs, B);
+    launch_new_landmarks(f->stream, f->d, f->grow, f->ids_dev, al.blobs, B, f->grow_bits ? f->unm_dev : nullptr, f->unm_words,
+                         f->grow_bits ? f->fh.pflag : nullptr);
     PK_LAUNCH_CHECK("pk_observe (new landmarks)");
   }
   if (ids_out && B > 0) {

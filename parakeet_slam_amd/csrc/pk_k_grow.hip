@@ -53,7 +53,9 @@ __device__ __forceinline__ bool grow_cross_readings(double x1, double y1, double
 __global__ void __launch_bounds__(256) k_new_landmarks(GrowState g, const double* __restrict__ x, const double* __restrict__ y,
                                                        const double* __restrict__ h, const int32_t* __restrict__ ids,
                                                        const double* __restrict__ blobs, int B, unsigned char* __restrict__ map,
-                                                       size_t slot_bytes, size_t count_off, int Lp, int64_t P) {
+                                                       size_t slot_bytes, size_t count_off, int Lp, int64_t P,
+                                                       const unsigned* __restrict__ unm, int unm_words,
+                                                       const unsigned char* __restrict__ pflag) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t p = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
   if (p >= P) return;  // wave-uniform
@@ -66,9 +68,21 @@ __global__ void __launch_bounds__(256) k_new_landmarks(GrowState g, const double
   double* f = reinterpret_cast<double*>(map + (size_t)p * slot_bytes);
   int32_t* fc = reinterpret_cast<int32_t*>(map + (size_t)p * slot_bytes + count_off);
   const int32_t* row = ids + (size_t)p * B;
+  // (round 6) behind a one-pass kernel the unmatched blobs are a bit row the kernel left (scan order); the particles it handed to the
+  // fall-back kernels have their ids in HBM as before
+  const bool bits = unm != nullptr && (pflag == nullptr || pflag[p] == 0);  // wave-uniform
+  const unsigned* urow = unm + (size_t)p * (bits ? unm_words : 0);
   for (int b0 = 0; b0 < B; b0 += kWave) {  // the unmatched blobs of the scan, in scan order (:88-95)
     const int bl = b0 + lane;
-    unsigned long long vote = __ballot(bl < B && row[bl] == 0);
+    unsigned long long vote;
+    if (bits) {
+      const int w = b0 >> 5;
+      const unsigned lo = urow[w], hi = (w + 1 < unm_words) ? urow[w + 1] : 0u;
+      vote = (unsigned long long)lo | ((unsigned long long)hi << 32);
+      if (B - b0 < 64) vote &= (1ull << (B - b0)) - 1ull;
+    } else {
+      vote = __ballot(bl < B && row[bl] == 0);
+    }
     while (vote != 0ull) {  // wave-uniform
       const int b = b0 + __builtin_ctzll(vote);
       vote &= vote - 1ull;
@@ -145,10 +159,11 @@ __global__ void __launch_bounds__(256) k_new_landmarks(GrowState g, const double
 }
 #pragma clang fp contract(on)
 
-void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int32_t* ids_dev, const double* blobs_dev, int B) {
+void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int32_t* ids_dev, const double* blobs_dev, int B,
+                          const unsigned* unm_dev, int unm_words, const unsigned char* pflag_dev) {
   if (d.P == 0 || B == 0) return;
   hipLaunchKernelGGL(k_new_landmarks, dim3((unsigned)((d.P + 3) / 4)), dim3(256), 0, s, g, d.x[d.cur], d.y[d.cur], d.h[d.cur], ids_dev,
-                     blobs_dev, B, d.map[d.mcur], d.lay.slot_bytes, d.lay.count_off, d.lay.Lp, d.P);
+                     blobs_dev, B, d.map[d.mcur], d.lay.slot_bytes, d.lay.count_off, d.lay.Lp, d.P, unm_dev, unm_words, pflag_dev);
 }
 
 // the bookkeeping follows the particles through the resample (:243: the deepcopy of the whole particle): slot k takes ancestor

@@ -28,7 +28,7 @@
 // a wave's 64 landmarks have lists of like length and a row access of sixteen lanes is one 128-byte line.
 constexpr int kDuoHeld = 64;    // landmarks of ONE particle that TAKE two or more blobs (their slots are kept for pass 2)
 constexpr size_t kDuoMaxDynLds = 78 * 1024;   // two 512-lane workgroups per CU (160 KB less the kernels' static __shared__)
-constexpr size_t kTrioMaxDynLds = 51 * 1024;  // three 256-lane workgroups per CU (the pair instance, NL = 2)
+constexpr size_t kTrioMaxDynLds = 50 * 1024;  // three 256-lane workgroups per CU (the pair instance, NL = 2)
 constexpr int kDuoTurn = 512;   // landmarks a workgroup works on per turn: 512 lanes x 1, or 256 lanes x 2
 constexpr int kDuoMaxTurns = 10;  // turns of 512 landmarks: maps up to 5 120 (twelve carried words and the update no longer fit 128 VGPRs: two spilled)
 
@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(NL == 1 ? 512 : 256, NL == 1 ? 4 : 3) k_step_p
   __shared__ unsigned s_nheld[2];  // places of the held area dealt out to the particle of either parity (read in its pass 2)
   __shared__ unsigned short s_bperm[kPubBigPlaces];
   __shared__ unsigned s_rb[kPubBigSlots];
+  __shared__ unsigned s_ubits[kPubUnmWords];  // growing maps: the particle's unmatched blobs, scan order (pub_note_unmatched)
   // the lane's (first) landmark of turn q_: sixteen lanes an octet of sixteen landmarks (NL = 1), or eight lanes with a pair each
 #define PK_DUO_L(q_, t_) (NL == 1 ? (int)(16u * (unsigned)s_bperm[32 * (q_) + ((t_) >> 4)]) + ((t_)&15) \
                                   : (int)(16u * (unsigned)s_bperm[32 * (q_) + ((t_) >> 3)]) + 2 * ((t_)&7))
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(NL == 1 ? 512 : 256, NL == 1 ? 4 : 3) k_step_p
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += TH) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
     for (int i = tid; i < kPubBigPlaces; i += TH) s_bperm[i] = reinterpret_cast<const unsigned short*>(gb + B + 1)[2 * kPubOctets + i];
     if (tid < kPubBigSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
+    for (int i = tid; i < kPubUnmWords; i += TH) s_ubits[i] = 0u;
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -355,10 +357,18 @@ __global__ void __launch_bounds__(NL == 1 ? 512 : 256, NL == 1 ? 4 : 3) k_step_p
         s_nheld[cur ^ 1] = 0u;
       }
     }
+    {
+      PubArgsPtr Ru = pub_args_now(rp);
+      if (Ru->unm != nullptr) pub_note_unmatched<TH>(tid, anyc, Ru->order, B, Bp, s_ubits);  // kernel-uniform: growing maps only
+    }
     pub_settle_blobs<TH, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     lds_barrier();  // B: every winner is marked, every flag is set
     PK_STAMP(b3)
     PK_PSTAMP(5, b2, b3)
+    {
+      PubArgsPtr Ru = pub_args_now(rp);
+      if (Ru->unm != nullptr) pub_store_unmatched<TH>(tid, s_ubits, Ru->unm + (size_t)p * Ru->unm_words, Ru->unm_words);
+    }
     // which of its blobs every landmark takes (pub_take): a blob nobody else lists, or the entry that carries the winner's marker
     {
       double m[NW];
@@ -584,6 +594,8 @@ void launch_step_pub_duo(hipStream_t s, DeviceState& d, int B, const double* exa
   a.gate4 = gate4_dev;
   a.far = cand.far;
   a.prim = prim_dev;
+  a.unm = ex.unm;
+  a.unm_words = ex.unm_words;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
   a.P = p1;

@@ -98,7 +98,37 @@ struct PubArgs {
   const unsigned* stats;        // [4] k_cand_entries' figures of this scan: [0] the entries of its publish table, [3] its longest list
   int tbytes;                   // bytes of LDS the publish table and the overflow area share
   const uint4* prim;            // the two-pass kernels: every landmark's primary blob in landmark order (prim_table_uint4), or null
+  unsigned* unm;                // growing maps (section 8(f4)): out [P][unm_words], bit b of a particle's row = blob b (SCAN order) is matched by
+  int unm_words;                //   none of its landmarks (:92-95: k_new_landmarks takes those through add_hypothesis), or null
 };
+
+// Growing maps on the one-pass routes (round 6; VERDICT round 5, missing #2): the new-landmark bookkeeping (pk_k_grow.hip,
+// prkt_core_v2.py:92-95, :546-746) wants the blobs a particle matched to NO landmark.  Until now it read them off the ids the general
+// association kernel leaves in HBM, so a growing filter took the general route (an O(P B L) association kernel plus an ids round trip:
+// 58 GB per step at 100 000 x 2 000 against 36-40 for the one-pass kernel).  The publish / subscribe kernels know those blobs behind
+// barrier A -- any[t] == 0: the same test that adds log 0.1 per unseen blob (:94-95) -- and leave them as a bit row per particle, in
+// SCAN order (k_new_landmarks takes them in that order: each sees what the ones before it stored).  kPubUnmWords: the row's capacity.
+constexpr int kPubUnmWords = 176;  // 5 632 blobs
+template <int THREADS>
+__device__ __forceinline__ void pub_note_unmatched(int tid, const unsigned char* anyc, const unsigned short* order, int B, unsigned Bp, unsigned* ubits) {
+  for (unsigned w = (unsigned)tid; w < Bp / 4u; w += THREADS) {
+    const unsigned v = reinterpret_cast<const unsigned*>(anyc)[w];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if ((int)(4 * w + b) < B && ((v >> (8 * b)) & 0xFFu) == 0u) {  // (a handful of blobs per particle, if any)
+        const unsigned o = order[4 * w + b];
+        atomicOr(&ubits[o >> 5], 1u << (o & 31u));
+      }
+  }
+}
+// ... behind barrier B: the row out, the LDS words cleared for the next particle (whose blobs are noted behind ITS barrier A)
+template <int THREADS>
+__device__ __forceinline__ void pub_store_unmatched(int tid, unsigned* ubits, unsigned* row, int words) {
+  for (int w = tid; w < words; w += THREADS) {
+    row[w] = ubits[w];
+    ubits[w] = 0u;
+  }
+}
 
 // The PRIMARY blob of a landmark -- the front of its candidate list: k_cand_entries puts the candidate closest in colour there -- has
 // its records in a table in LANDMARK order (pk_kernels.hpp: prim_table_uint4).  Wherever every lane of a wave wants exactly that blob
@@ -1005,6 +1035,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
   constexpr bool kPerm = NP == 2 && THREADS == 512;
   __shared__ unsigned short s_perm[kPerm ? 2 * kPubOctets : 1];
   __shared__ unsigned s_rb[kCandSlots];  // the publish table's rank bases (k_cand_entries: entry of (blob g, rank r) = s_rb[r] + g)
+  // growing maps: the particle's unmatched blobs, scan order (pub_note_unmatched) -- as many words as the instance's LDS lets a scan have
+  // blobs (the 256-lane instance shares a CU with two others: 704 bytes more of static LDS and only two fit -- 0.296 against 0.222 ms)
+  constexpr int kUnmWords = THREADS == kPubSmallThreads ? 32 : 96;
+  __shared__ unsigned s_ubits[kUnmWords];
   // (the two octet numbers of a lane ride above its index in one register; in a register of their own, or below the index: no
   // better -- profiles/r04/ab_perm_mechanisms.log)
 #define PK_PUB_L0(q_, t_) (!kPerm ? 2 * kPubThreads * (q_) + 2 * (t_) : (int)(((lw >> (16 + 8 * (q_))) & 0xFFu) << 4) + 2 * ((t_)&7))
@@ -1063,6 +1097,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       if (tid < 2 * kPubOctets) s_perm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[tid];
     }
     if (tid < kCandSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
+    for (int i = tid; i < kUnmWords; i += kPubThreads) s_ubits[i] = 0u;
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -1375,10 +1410,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
       for (unsigned w = (unsigned)tid; w < Bp / 4u; w += kPubThreads) anyn[w] = 0u;
       if (tid == 0) wg_flag[cur ^ 1] = 0;
     }
+    if (pub_args_now(rp)->unm != nullptr) pub_note_unmatched<THREADS>(tid, anyc, order, B, Bp, s_ubits);  // kernel-uniform: growing maps only
     if (PK_PUB_ABLATE < 2) pub_settle_blobs<THREADS>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     PK_STAMP(s5)
     PK_PSTAMP(4, s4, s5)  // unseen blobs, settling
     lds_barrier();  // B: every winner is marked, every flag is set
+    {
+      PubArgsPtr Ru = pub_args_now(rp);
+      if (Ru->unm != nullptr) pub_store_unmatched<THREADS>(tid, s_ubits, Ru->unm + (size_t)p * Ru->unm_words, Ru->unm_words);
+    }
 #pragma unroll
     for (int i = 0; i < 2 * NP; ++i)
       if (PK_PUB_ABLATE < 2) pub_take(Q[i], pub, dump);
@@ -1623,6 +1663,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
   __shared__ unsigned short s_bperm[kPubBigPlaces];
   __shared__ unsigned s_rb[kPubBigSlots];  // the publish table's rank bases (k_cand_entries)
   __shared__ unsigned s_novf[2];           // places of the overflow area dealt out in pass 1 to the particle of either parity (pub_park_beyond_four)
+  __shared__ unsigned s_ubits[kPubUnmWords];  // growing maps: the particle's unmatched blobs, scan order (pub_note_unmatched)
 #define PK_BIG_L0(q_, t_) ((int)(16u * (unsigned)s_bperm[kPubOctets * (q_) + ((t_) >> 3)]) + 2 * ((t_)&7))
   constexpr int kPubWaves = kPubThreads / kWave;
 #ifdef PK_DIAG_BIG_FRONT_TO_BACK  // (regression build: pass 2 front to back from rows asked for again, as until round 5)
@@ -1661,6 +1702,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     for (unsigned i = (unsigned)tid; i < 2u * (Bp + 16u) / 4u; i += kPubThreads) reinterpret_cast<unsigned*>(smem + o_any)[i] = 0u;
     if (tid < kPubBigPlaces) s_bperm[tid] = reinterpret_cast<const unsigned short*>(gb + B + 1)[2 * kPubOctets + tid];
     if (tid < kPubBigSlots) s_rb[tid] = gb[B + 1 + kPubTailWords + tid];
+    for (int i = tid; i < kPubUnmWords; i += kPubThreads) s_ubits[i] = 0u;
     if (tid == 0) {
       wg_flag[0] = 0;
       wg_flag[1] = 0;
@@ -1963,10 +2005,18 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         s_novf[cur ^ 1] = 0u;
       }
     }
+    {
+      PubArgsPtr Ru = pub_args_now(rp);
+      if (Ru->unm != nullptr) pub_note_unmatched<kPubThreads>(tid, anyc, Ru->order, B, Bp, s_ubits);  // kernel-uniform: growing maps only
+    }
     pub_settle_blobs<kPubThreads, kPubBigSlots>(tid, glist, G, pub, dump, &wg_flag[cur], s_rb);
     lds_barrier();  // B: every winner is marked, every flag is set
     PK_STAMP(b3)
     PK_PSTAMP(5, b2, b3)
+    {
+      PubArgsPtr Ru = pub_args_now(rp);
+      if (Ru->unm != nullptr) pub_store_unmatched<kPubThreads>(tid, s_ubits, Ru->unm + (size_t)p * Ru->unm_words, Ru->unm_words);
+    }
 #pragma unroll
     for (int i = 0; i < 2 * NCH; ++i) pub_take(Q[i], pub, dump);
     if (s_novf[cur] != 0u) {  // workgroup-uniform (written before barrier A; the other parity's is reset between A and B): some landmark parked blobs
@@ -2119,6 +2169,8 @@ void launch_step_pub_big(hipStream_t s, DeviceState& d, int B, const double* exa
   a.prim = prim_dev;
   a.stats = stats_dev;
   a.tbytes = 0;
+  a.unm = ex.unm;
+  a.unm_words = ex.unm_words;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;
   a.P = p1;
@@ -2176,6 +2228,8 @@ void launch_step_pub(hipStream_t s, DeviceState& d, int B, const double* exact_d
   a.prim = nullptr;
   a.stats = nullptr;
   a.tbytes = 0;
+  a.unm = ex.unm;
+  a.unm_words = ex.unm_words;
   a.far = cand.far;
   a.pflag_out = fh.pflag;
   a.n_flagged = fh.n_flagged;

@@ -160,6 +160,8 @@ struct ObserveExtras {
   bool reset = false;                           // weights restart from 1 (fused pk_reset_weights)
   unsigned long long* gmax_key = nullptr;       // keep the running max of the new log-weights here
   bool single_sightings = false;                // known ids: no landmark is matched by more than one blob
+  unsigned* unm = nullptr;                      // growing maps on the publish / subscribe routes: out [P][unm_words] -- every particle's unmatched
+  int unm_words = 0;                            //   blobs as a bit row in scan order (pk_k_step_pub.hip: pub_note_unmatched)
 };
 constexpr int kFastSlots = 4;   // gate-passing blobs a landmark can hand over to k_observe_fast; more -> general path
 constexpr int kSweepSlots = 8;  // ... to k_observe_sweep (large maps: a landmark's colour neighbourhood is busier)
@@ -389,7 +391,10 @@ void launch_pack_range(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int
 void launch_adopt_dev(hipStream_t s, DeviceState& d, const int64_t* hi_dev, int64_t slot_start,
                       const unsigned char* buf_dev, int64_t n_recv, int64_t* rlohi_dev, int mode = 0, int64_t span_lo = INT64_MIN, int64_t span_hi = INT64_MAX);
 void launch_iota(hipStream_t s, int32_t* p, int64_t n);
-void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int32_t* ids_dev, const double* blobs_dev, int B);
+// unm_dev != NULL: the unmatched blobs of particle p come from its bit row there (the one-pass kernels leave it) unless pflag_dev[p] != 0
+// (the fall-back kernels took the particle and left its ids in ids_dev's row)
+void launch_new_landmarks(hipStream_t s, DeviceState& d, GrowState& g, const int32_t* ids_dev, const double* blobs_dev, int B,
+                          const unsigned* unm_dev = nullptr, int unm_words = 0, const unsigned char* pflag_dev = nullptr);
 // anc >= 0: a particle of this filter; anc < 0: record -anc - 1 of buf (stride bytes apart, its bookkeeping tail_off bytes in)
 void launch_grow_gather(hipStream_t s, GrowState& g, const int32_t* anc_dev, int64_t P, const unsigned char* buf_dev = nullptr,
                         size_t stride = 0, size_t tail_off = 0);

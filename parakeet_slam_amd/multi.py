@@ -58,7 +58,9 @@ def _worker_main(rank, world, device, store_path, backend, P_local, L, means, co
         from .sharded import ShardedFilter, TorchComm
 
         shard = shard_factory(P_local, means, covs, imm) if shard_factory is not None else None
-        sf = ShardedFilter(P_local, L, device=device, comm=TorchComm(), shard=shard)
+        # (a world of one defaults to the contiguous placement, which the new-landmark bookkeeping refuses -- the
+        # bookkeeping rides behind the records of the balanced exchange: ask for that placement whenever the maps grow)
+        sf = ShardedFilter(P_local, L, device=device, comm=TorchComm(), shard=shard, placement="balanced" if grow is not None else None)
         if L:
             sf.upload_map(means, covs.reshape(L, 25), imm)
         if grow is not None:  # (preset landmarks, reading capacity, pair threshold): section 8(f4) on every rank's device

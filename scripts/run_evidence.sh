@@ -10,5 +10,5 @@ fi
 python -m parakeet_slam_amd.build > /dev/null
 python -m parakeet_slam_amd.build --stamps > /dev/null
 SHA=$(git rev-parse --short HEAD)
-/usr/local/graft/bin/gpurun --timeout 1200 -- "PK_GIT_SHA=$SHA EV_PARTS=${1:-abcdef} bash scripts/gpu_r5_evidence.sh"
-echo "copy gpurun_out/r05ev/* into profiles/r05/ (git $SHA)"
+/usr/local/graft/bin/gpurun --timeout 1200 -- "PK_GIT_SHA=$SHA EV_PARTS=${1:-abcdte} bash scripts/gpu_r6_evidence.sh"
+echo "copy gpurun_out/r06ev/* into profiles/r06/ (git $SHA)"

@@ -45,11 +45,18 @@ def _compare(lib, f, o, L0, step):
     assert np.allclose(c.reshape(o.f.cov.shape), o.f.cov, rtol=1e-8, atol=1e-9), step
 
 
-def _run(lib, P, L0, U, spare, steps, seed, R=64, check_every=1, log_domain=True):
+def _run(lib, P, L0, U, spare, steps, seed, R=64, check_every=1, log_domain=True, opts=None, route=None):
     thr = 30.0
     v, w, dt = 0.8, 0.35, 0.5
     world, covs, known, kcov = _scene(L0, U)
     f = _device_filter(lib, P, known, kcov, spare, thr, R)
+    for k_, v_ in (opts or {}).items():
+        f.set_option(k_, v_)
+    # round 6: the publish / subscribe kernels leave every particle's unmatched blobs as a bit row -- the growing filter takes the
+    # one-pass route of its map size (k_step_pub<256 lanes> up to 512 landmarks, k_step_pub beyond, k_step_pub_big beyond 2 048);
+    # "fast_observe" = 0: the general association, whose ids the bookkeeping kernel reads as before
+    L = L0 + spare
+    route = route or ("ml_fused" if L <= 512 else "ml_regs" if L <= 2048 else "ml_pub_big")
     o = GrowingOracle(P, known, kcov, spare, thr)
     rs = np.random.RandomState(seed)
     pose = (0.0, 0.0, 0.0)
@@ -60,7 +67,9 @@ def _run(lib, P, L0, U, spare, steps, seed, R=64, check_every=1, log_domain=True
         z = rs.standard_normal((P, 3))
         f.motion(v, w, dt, z=z)
         f.observe(blobs, fresh=True)  # no ids asked for: nothing per particle comes back
-        assert f.observe_route() == "ml_general"  # (the association kernel leaves the ids in HBM for k_new_landmarks)
+        assert f.observe_route() == route, (f.observe_route(), route)
+        if route != "ml_general":
+            assert f.observe_published()  # a kernel of the publish / subscribe family did the step
         o.f.reset_weights()
         o.f.motion(v, w, dt, z)
         o.observe(blobs)
@@ -76,9 +85,48 @@ def _run(lib, P, L0, U, spare, steps, seed, R=64, check_every=1, log_domain=True
     return created, promoted
 
 
-def test_bookkeeping_kernel_matches_the_oracle_particle_by_particle(lib):
-    created, promoted = _run(lib, P=64, L0=10, U=3, spare=5, steps=9, seed=5)
+@pytest.mark.parametrize("opts,route", [({}, None), ({"fast_observe": 0}, "ml_general")])
+def test_bookkeeping_kernel_matches_the_oracle_particle_by_particle(lib, opts, route):
+    created, promoted = _run(lib, P=64, L0=10, U=3, spare=5, steps=9, seed=5, opts=opts, route=route)
     assert created >= 2 and promoted >= 1
+
+
+@pytest.mark.parametrize("P,L0,U,spare,steps", [(12, 700, 3, 5, 6), (8, 1500, 3, 4, 5), (6, 2300, 3, 4, 5)])
+def test_growing_maps_on_the_one_pass_routes_of_larger_maps(lib, P, L0, U, spare, steps):
+    """VERDICT round 5, missing #2 / next #4: new_landmarks no longer forces the general route.  k_step_pub (513 .. 2 048 landmarks) and
+    k_step_pub_big (beyond) on growing maps: the bit rows of unmatched blobs they leave (and, for the particles they hand on, the
+    general kernels' ids) must give the bookkeeping kernel exactly what the general association's ids give it -- counters, stored
+    readings, spare-slot ids, maps and counts equal array for array at every step, log-weights to rounding.  (The oracle holds both
+    at the small sizes above: with several hundred blobs the reference's unwrapped bearings (:408-423) leave a score of KNOWN
+    landmarks unmatched at every step, the rings fill within a few steps, and which reading is dropped is the device's affair.)"""
+    world, covs, known, kcov = _scene(L0, U)
+    fa = _device_filter(lib, P, known, kcov, spare, 30.0, 128)
+    fb = _device_filter(lib, P, known, kcov, spare, 30.0, 128)
+    fb.set_option("fast_observe", 0)
+    rs = np.random.RandomState(7 + L0)
+    pose, on_kernel = (0.0, 0.0, 0.0), 0
+    for s in range(steps):
+        pose = truth_step(pose, 0.8, 0.35, 0.5)
+        blobs = synthetic_scan(world, pose)
+        z = rs.standard_normal((P, 3))
+        for f in (fa, fb):
+            f.motion(0.8, 0.35, 0.5, z=z)
+            f.observe(blobs, fresh=True)
+        assert fa.observe_route() == ("ml_regs" if L0 + spare <= 2048 else "ml_pub_big") and fa.observe_published() and fb.observe_route() == "ml_general"
+        on_kernel += P - fa.observe_flagged()[0]
+        (ca, ra, sa), (cb, rb, sb) = fa.grow_download(), fb.grow_download()
+        assert np.array_equal(ca, cb), s
+        for i in range(P):  # (the ring's places beyond the stored readings, the slot ids beyond the slots in use: never written)
+            assert np.array_equal(ra[i, :ca[i, 0]], rb[i, :cb[i, 0]]) and np.array_equal(sa[i, :ca[i, 1]], sb[i, :cb[i, 1]]), (s, i)
+        for xa, xb in zip(fa.download_landmarks(), fb.download_landmarks()):
+            assert np.array_equal(xa, xb), s
+        assert np.allclose(fa.download_log_weights(), fb.download_log_weights(), rtol=1e-11, atol=1e-9), s
+        u = float(rs.uniform())
+        assert np.array_equal(fa.resample(u, domain=lib.PK_WEIGHTS_LOG, return_ancestors=True), fb.resample(u, domain=lib.PK_WEIGHTS_LOG, return_ancestors=True))
+    assert on_kernel >= P * 2, "hardly any particle stayed on the one-pass kernel: the test shows nothing about its bit rows"
+    assert fa.grow_download()[0][:, 1].max() >= 2, "nothing was triangulated"
+    fa.close()
+    fb.close()
 
 
 def test_ten_thousand_particles_grow_their_maps_with_no_per_particle_host_traffic(lib):
@@ -118,14 +166,12 @@ def test_refused_where_it_cannot_follow(lib):
         f.grow_enable(6, 8, 30.0)
     # the host-index exchange packs records WITHOUT the bookkeeping's tail (pk_particle_bytes counts it) and would leave readings and
     # id counters on the wrong particles: refused like its *_dev variants
-    import torch
-
-    buf = torch.zeros(4 * f.particle_bytes(), dtype=torch.uint8, device="cuda")
+    # (refused before the buffer is looked at: any non-null address will do)
     with pytest.raises(lib.PkError, match="balanced placement only") as e:
-        f.pack_particles([0, 1, 2, 3], buf.data_ptr())
+        f.pack_particles([0, 1, 2, 3], 4096)
     assert e.value.status == lib.PK_ERR_STATE
     with pytest.raises(lib.PkError, match="balanced placement only") as e:
-        f.adopt_particles(np.arange(16), buf.data_ptr(), 0)
+        f.adopt_particles(np.arange(16), 4096, 0)
     assert e.value.status == lib.PK_ERR_STATE
     f.close()
     g = lib.DeviceFilter(4, 5)
@@ -210,6 +256,11 @@ def test_three_ranks_grow_the_same_maps_as_one_filter(tmp_path):
     a, b = np.load(snaps[0]), np.load(snaps[1])
     assert set(a.files) == set(b.files) and "nl_readings" in a.files
     for k in a.files:
+        if k == "poses":  # (round 6: the growing filter runs the one-pass kernel; a shard's candidate lists are made around ITS reference
+            # particle, so a particle may go through the fall-back kernels on one side and not on the other: the same associations
+            # and maps, the log-weight's terms added in another order)
+            assert np.array_equal(a[k][:, :3], b[k][:, :3]) and np.allclose(a[k][:, 3], b[k][:, 3], rtol=1e-11, atol=0.0), k
+            continue
         assert np.array_equal(a[k], b[k]), k
     assert int(a["nl_used"].max()) >= 2, "nothing was triangulated"
     assert len(set(a["nl_used"].tolist())) > 1 or len(set(np.diff(a["nl_offsets"]).tolist())) > 1, "every particle holds the same bookkeeping: the test shows nothing"
@@ -230,6 +281,9 @@ def test_three_ranks_grow_the_same_maps_as_one_filter(tmp_path):
     f1.save_state(pb)
     a, b = np.load(pa), np.load(pb)
     for k in a.files:
+        if k == "poses":
+            assert np.array_equal(a[k][:, :3], b[k][:, :3]) and np.allclose(a[k][:, 3], b[k][:, 3], rtol=1e-11, atol=0.0), ("after the cross-load", k)
+            continue
         assert np.array_equal(a[k], b[k]), ("after the cross-load", k)
     fm.close()
     f1.close()

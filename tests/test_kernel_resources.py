@@ -101,7 +101,7 @@ def test_the_register_resident_kernels_keep_their_occupancy(kernels):
 def test_the_two_and_three_workgroups_per_cu_instances_of_the_two_pass_kernel_fit_their_registers(kernels):
     """k_step_pub_duo (round 6).  <NT, 1>: 512 lanes x <= 128 VGPRs = four waves per SIMD, TWO workgroups per CU; <NT, 2>: 256 lanes x
     <= 168 VGPRs = three waves per SIMD, THREE workgroups per CU -- by construction (one landmark at a time, one carried word per
-    landmark), not by a cap the allocator answers with spills: no scratch, nothing spilled; and the static LDS beside 78 KB (51 KB) of
+    landmark), not by a cap the allocator answers with spills: no scratch, nothing spilled; and the static LDS beside 78 KB (50 KB) of
     dynamic LDS leaves room for the other workgroups (160 KB per CU)."""
     duo = [k for k in kernels if "k_step_pub_duo" in k["symbol"]]
     one = [k for k in duo if k["symbol"].replace(".kd", "").endswith("ELi1EEEvNS_7PubArgsE")]
@@ -114,4 +114,4 @@ def test_the_two_and_three_workgroups_per_cu_instances_of_the_two_pass_kernel_fi
         assert 2 * (int(k.get("group_segment_fixed_size", 0)) + 78 * 1024) <= 160 * 1024, k
     for k in two:
         assert int(k["vgpr_count"]) <= 168, k
-        assert 3 * (int(k.get("group_segment_fixed_size", 0)) + 51 * 1024) <= 160 * 1024, k
+        assert 3 * (int(k.get("group_segment_fixed_size", 0)) + 50 * 1024) <= 160 * 1024, k
