@@ -695,6 +695,9 @@ def main():
         filt.synchronize()
         filt.total_migrated = 0
     elapsed, tm, route, one_step = timed_steps(filt, _lib, P, L, K, W, scans, ws, us, ids, barrier, stride)
+    head_warm = {"ms": [round(v, 4) for v in timed_steps.warmup_ms], "flagged_particles": list(timed_steps.warmup_flagged),
+                 "what": "the warm-up steps one at a time (host wall clock, the stream drained around each; untimed): the first scan of a "
+                         "fresh map is the slowest step of a run"} if timed_steps.warmup_ms else None
     migrated = None
     if sharded:  # particles whose output slot lies on another rank: pose + whole map travel (the all-to-all's volume)
         filt.synchronize()
@@ -888,6 +891,7 @@ def main():
             rnd4 = random.Random(7)
             us4 = [rnd4.random() for _ in range(n4)]
             e4, tm4, route4, step4 = timed_steps(f4, _lib, P4, L4, K4, W4, s4, ws4, us4, None, barrier2(torch, f4), 1)
+            warm4 = {"ms": [round(v, 3) for v in timed_steps.warmup_ms], "flagged_particles": list(timed_steps.warmup_flagged)}
             fl4 = f4.observe_flagged()
             for s_ in range(W4 + K4, LATE0):
                 step4(s_)
@@ -912,6 +916,7 @@ def main():
                 "device_bytes": f4.device_bytes(),
                 "particles_sent_to_fallback_kernels_last_step": fl4[0],
                 "trajectory_steps": [W4, W4 + K4 - 1],
+                "warmup_steps": warm4,  # step 0, the first scan of the fresh map, is the slowest of the run (99 ms in round 5)
                 "roofline": roofline_object(P4, L4, route4, tm4["observe"][0], tm4["observe"][1], 1, K4, None),
                 "late_window": {"trajectory_steps": [LATE0, LATE0 + LATEK - 1], "ms_per_step": e_late / LATEK * 1e3,
                                 "roofline": roofline_object(P4, L4, route4, tl4[0], tl4[1], 1, LATEK, None)},
@@ -1049,8 +1054,16 @@ def main():
             "summary": list(summary),
             "matched_fraction_last_timed_scan": matched,  # validity: the scans stayed matchable to the end
         }
+        if head_warm is not None:
+            out["warmup_steps"] = head_warm
         if replay is not None:
             out["per_step"] = replay
+            kmm = replay.get("kernel_ms_min_max_timed_window")
+            if kmm and kmm[0] > 0:
+                # the kernel's slowest and fastest launch over the timed window's trajectory steps (the untimed replay, every step
+                # bracketed): the fraction drifts across a run as the particle cloud converges
+                alg = float(P) * L * BYTES_PER_UPDATE / 1e9
+                roof["frac_range_over_steps"] = [alg / (kmm[1] * 1e-3) / HBM_PEAK_GBS, alg / (kmm[0] * 1e-3) / HBM_PEAK_GBS]
             if replay.get("slow_window"):
                 out["slow_window_ms_per_step"] = replay["slow_window"]["ms_mean"]
         if sharded:

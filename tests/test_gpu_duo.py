@@ -83,7 +83,7 @@ def test_the_two_instances_of_the_two_pass_kernel_agree_bit_for_bit(lib, L, P, e
     assert duo["route"] == trio["route"] == big["route"] == "ml_pub_big" and gen["route"] == "ml_general"
     assert duo["stats"]["instance"] == 2 and big["stats"]["instance"] == 1, (duo["stats"], big["stats"])
     # (three workgroups per CU: a third of the LDS each -- the busiest of these scenes' tables do not fit, and the scan stays with the one-workgroup instance)
-    assert trio["stats"]["instance"] in (1, 3) and (trio["stats"]["instance"] == 3 or colour_var > 0.015), trio["stats"]
+    assert trio["stats"]["instance"] in (1, 3) and (trio["stats"]["instance"] == 3 or colour_var > 0.015 or L > 4096), trio["stats"]
     assert duo["flagged"] == 0 and big["flagged"] == 0 and trio["flagged"] == 0  # the kernels themselves did the work
     same_state(trio, big)
     if colour_var > 0.015:  # the scene does what it says: landmarks with two blobs inside their gates that both count
