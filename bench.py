@@ -851,10 +851,12 @@ def main():
         }
         f2.close()
         del f2
-        # ... and the same steps through the OTHER one-pass kernel for maps of at most 512 landmarks (option "pub_small"): the
+        # ... and the same steps through the OTHER one-pass kernel for maps of at most 512 landmarks (option "pub_small" = 1): the
         # publish / subscribe instance on candidate lists, three 256-lane workgroups per CU.  Its kernel is the faster one since
-        # the look-alikes leave the lists once per scan (round 5), but it needs two per-scan kernels (k_candidates, k_cand_entries)
-        # that a 0.27-ms step does not amortise: the whole step stays slower, and k_step_fused stays the default
+        # the look-alikes leave the lists once per scan (round 5), but it needs two per-scan kernels (k_candidates, k_cand_entries:
+        # 24 us whatever the number of particles) that a 0.27-ms step does not amortise.  Round 6: the default ("pub_small" = -1) takes it
+        # where the whole step was measured faster -- from 16 384 particles on (profiles/r06/pub_small_sweep.log: -2 % at 20 000 x 500,
+        # -8 % at 100 000 x 500, -15 % at 100 000 x 256; +3 % here, at configs[1]'s 10 000) -- so this workload stays on k_step_fused
         try:
             f3 = _lib.DeviceFilter(P2, L2, device=local_rank)
             f3.set_option("pub_small", 1)
@@ -864,7 +866,8 @@ def main():
                                               [rnd3.random() for _ in range(K2 + W2)], None, barrier2(torch, f3), 4)
             if route3 in ("ml_regs", "ml_fused") and f3.observe_published():
                 route3 += "_pub"
-            second["pub_small"] = {"what": "the same workload with the option pub_small = 1 (not the default)", "ms_per_step": e3 / K2 * 1e3,
+            second["pub_small"] = {"what": "the same workload with the option pub_small = 1 (the default, -1, takes this instance from 16 384 particles on: "
+                                           "where the whole step is measured faster)", "ms_per_step": e3 / K2 * 1e3,
                                    "value": float(P2) * L2 * K2 / e3,
                                    "roofline": roofline_object(P2, L2, route3, tm3["observe"][0], tm3["observe"][1], 4, K2, None)}
             f3.close()

@@ -148,7 +148,8 @@ struct pk_filter {
   uint4* cand_dev = nullptr;  // [Lp + kCandSpare][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
-  int pub_small = 0;     // L <= 512: k_step_pub<256 lanes> instead of k_step_fused (measured: the kernel 1 % slower, the step 50 us longer)
+  int pub_small = -1;    // L <= 512: k_step_pub<256 lanes> instead of k_step_fused -- 1 / 0, or -1 (default): where it is measured faster
+                         // (pub_small_now below)
   int duo_park_limit = -1;  // >= 0: k_step_pub_duo's overflow area is treated as this small (tests: particles that need more go to the fall-back kernels)
   int duo_on = 0;        // "pub_duo" (measured, off: DESIGN.md section 4): 2 048 < L <= 5 120, scans whose publish table fits its share of a CU's LDS go to
                          // k_step_pub_duo -- 1: two 512-lane workgroups per CU (<= 128 VGPRs), 2: three 256-lane workgroups (<= 168) -- the others to k_step_pub_big
@@ -1419,12 +1420,24 @@ static DuoLimits duo_limits(const pk_filter* f, int B) {
 }
 // ref: the particle whose MAP the candidate lists are made from -- particle 0, or in a split step the first particle of the range
 // that has been filled already (the slots at either end still hold the old generation then)
+// Maps of at most 512 landmarks: the publish / subscribe instance (k_step_pub<1, 256> on candidate lists) or k_step_fused?  The former's
+// kernel is the faster one (7 % at 10 000 x 500, 15 % at 100 000 x 256) and costs two per-scan kernels (k_candidates, k_cand_entries:
+// 24 us) whatever the number of particles: measured over P x L (profiles/r06/pub_small_sweep.log) it loses the whole step up to 10 000
+// particles (by 3-12 %) and wins from 20 000 on (by 2 % there, 8-15 % at 40 000 and 100 000), at 128, 256 and 500 landmarks alike.
+// Below 128 landmarks nothing was measured: k_step_fused.
+constexpr int64_t kPubSmallAutoParticles = 16384;
+constexpr int kPubSmallAutoLandmarks = 128;
+static bool pub_small_now(const pk_filter* f) {
+  if (f->grow_on) return true;  // (growing maps: only the publish / subscribe kernels leave the unmatched blobs' bit rows)
+  if (f->pub_small >= 0) return f->pub_small != 0;
+  return f->d.P >= kPubSmallAutoParticles && f->d.lay.L >= kPubSmallAutoLandmarks;
+}
 static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand, int64_t ref = 0) {
   int rc;
   f->pub_ecap = 0;
-  // the register route; with "pub_small" (off: measured) also the L <= 512 route through the publish /
+  // the register route; with "pub_small" (on from 16 384 particles: pub_small_now) also the L <= 512 route through the publish /
   // subscribe instance of three 256-lane workgroups per CU
-  const bool small_pub = al.fused && (f->pub_small || f->grow_on) && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
+  const bool small_pub = al.fused && pub_small_now(f) && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
   if (al.big) {  // sixteen-entry lists both ways and the publish table's layout
     if (!f->cand_dev && (rc = dev_alloc(f, &f->cand_dev, ((size_t)f->d.lay.Lp + kCandSpare) * 3))) return rc;
     if (!f->npass_dev && (rc = dev_alloc(f, &f->npass_dev, (size_t)f->d.lay.Lp + kCandSpare))) return rc;
@@ -1886,7 +1899,7 @@ int pk_set_option(pk_filter* f, const char* name, int64_t value) {
     return PK_OK;
   }
   if (!strcmp(name, "pub_small")) {
-    f->pub_small = value != 0;
+    f->pub_small = value < 0 ? -1 : (value != 0 ? 1 : 0);
     return PK_OK;
   }
   if (!strcmp(name, "far_prune")) {

@@ -255,6 +255,26 @@ def test_the_256_lane_instance_for_small_maps_is_exact_too(lib, L, P):
     against_oracle(pub, means, covs, poses, blobs)
 
 
+def test_small_maps_take_the_256_lane_instance_where_it_was_measured_faster(lib):
+    # "pub_small" = -1 (the default): k_step_pub<256 lanes> from 16 384 particles and 128 landmarks on (its two per-scan kernels cost 24 us
+    # whatever the number of particles: profiles/r06/pub_small_sweep.log), k_step_fused below; either way the same state
+    L = 128
+    rs = np.random.RandomState(77)
+    means, covs = synthetic_world(L)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
+    for P, want in ((16384, True), (16383, False)):
+        poses = poses_around(rs, P, 0.1)
+        auto = run(lib, means, covs, poses, blobs)
+        off = run(lib, means, covs, poses, blobs, {"pub_small": 0})
+        on = run(lib, means, covs, poses, blobs, {"pub_small": 1})
+        assert auto["route"] == "ml_fused" and auto["published"] == want and on["published"] and not off["published"], (P, auto["published"])
+        same_state(auto, off)
+        same_state(auto, on)
+    means, covs = synthetic_world(112)  # (below 128 landmarks nothing was measured: k_step_fused)
+    poses = poses_around(rs, 16384, 0.1)
+    assert not run(lib, means, covs, poses, synthetic_scan(means, (0.02, -0.01, 0.01)))["published"]
+
+
 @pytest.mark.parametrize("L,P,tight", [(2049, 3, False), (3000, 3, False), (4096, 2, False), (5000, 4, False), (2300, 3, True), (3000, 3, True), (5000, 4, True),
                                        (5200, 2, True), (5632, 2, True)])
 def test_two_pass_instance_for_maps_beyond_2048_landmarks(lib, L, P, tight):
