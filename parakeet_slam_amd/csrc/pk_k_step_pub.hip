@@ -433,6 +433,9 @@ __device__ __forceinline__ void pub_far_recheck(const bool (&viol)[N], const Lan
   if (bad) *flag = 1;
 }
 
+#ifdef PK_STAMPS
+__device__ unsigned long long pk_pstamp_acc[16];  // (diagnostic build: per-phase cycle sums and counters, see below)
+#endif
 // What pub_keysN needs to test that the scan's pruned lists hold for its landmarks (CHK), as FUNCTIONS evaluated where the
 // values are used -- held in registers from the call on they cost k_step_pub<2, 512>, which sits at 256 VGPRs, 70-100 spills:
 // bnd(j): the bound landmark j's list was pruned with (Kb, Ib; Ib = 0: an empty far list, nothing to hold); has(j): the landmark
@@ -580,6 +583,19 @@ __device__ __forceinline__ void pub_keysN(PubSlotsT<SL> (&q)[N], const Landmark<
     bool heavy = false;
 #pragma unroll
     for (int j = 0; j < N; ++j) heavy |= valid[j] && !far[j];
+#if defined(PK_STAMPS) && defined(PK_DIAG_ROUNDS)
+    if constexpr (PRIM) {  // (diagnostic: how full are the verdict rounds of the two-pass kernel -- DESIGN.md section 10.2)
+      unsigned long long act = 0ull;
+#pragma unroll
+      for (int j = 0; j < N; ++j) act += (unsigned long long)__popcll(__ballot(valid[j] && !far[j]));
+      if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
+        if (done == 0) atomicAdd(&pk_pstamp_acc[12], 1ull);
+        if (act != 0ull) atomicAdd(&pk_pstamp_acc[13], 1ull);
+        if (act != 0ull && done > 0) atomicAdd(&pk_pstamp_acc[14], 1ull);
+        if (done > 0) atomicAdd(&pk_pstamp_acc[15], act);
+      }
+    }
+#endif
     if (__ballot(heavy) != 0ull) {  // wave-uniform
       double key[N], num2[N], num3[N];
       bool edge[N];
@@ -950,7 +966,6 @@ __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double
 
 // Diagnostic build only (-DPK_STAMPS): per-phase cycle sums of k_step_pub (slots 48.. of pk_debug_stamps).
 #ifdef PK_STAMPS
-__device__ unsigned long long pk_pstamp_acc[16];
 __device__ unsigned long long pk_pstamp_wave[8][12];  // the same sums per wave of the workgroup (which waves wait at the barriers?)
 // (summed in scalar registers, one atomic per wave and slot at the very end: an atomic per stamp put 2 048 waves in a
 // queue for sixteen addresses and, the vector memory counter being one in-order counter, every row behind them)
