@@ -9,6 +9,9 @@ from parakeet_slam_amd import _lib as lib
 from oracle.fastslam_oracle import synthetic_scan, synthetic_world
 from test_gpu_pub import run, poses_around
 
+# options of the production run from the environment: FUZZ_OPTS="pub_duo=1,pub_small=1" (round 6: the fuzzers on the optional instances)
+FUZZ_OPTS = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("FUZZ_OPTS", "").split(",") if kv}
+
 
 def fuzz_routes(N, seed0, lib=lib):
     bad = 0; routes = {}; flagged_all = 0; t0 = time.time()
@@ -35,7 +38,7 @@ def fuzz_routes(N, seed0, lib=lib):
         if L > 5000:
             blobs = blobs[:3500]
         poses = poses_around(rs, P, rs.choice([0.02, 0.05, 0.2]))
-        a = run(lib, means, covs, poses, blobs, immutable=imm)
+        a = run(lib, means, covs, poses, blobs, dict(FUZZ_OPTS), immutable=imm)
         g = run(lib, means, covs, poses, blobs, {"fast_observe": 0}, immutable=imm)
         routes[a["route"]] = routes.get(a["route"], 0) + 1
         ok = np.allclose(a["logw"], g["logw"], rtol=1e-11, atol=1e-9) and all(np.array_equal(x, y) for x, y in zip(a["maps"], g["maps"]))

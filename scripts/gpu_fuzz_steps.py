@@ -8,6 +8,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from parakeet_slam_amd import _lib as lib
 from oracle.fastslam_oracle import synthetic_scan, synthetic_world, truth_step
 
+# options of the production run from the environment: FUZZ_OPTS="pub_duo=1,pub_small=1" (round 6: the fuzzers on the optional instances)
+FUZZ_OPTS = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("FUZZ_OPTS", "").split(",") if kv}
+
 
 def fuzz_steps(N, seed0, lib=lib):
     bad = 0; routes = {}; t0 = time.time()
@@ -21,7 +24,7 @@ def fuzz_steps(N, seed0, lib=lib):
         covs[:, 2:, 2:] = rs.choice([0.25, 0.04, 0.01]) * np.identity(3)
         imm = (rs.uniform(size=L) < rs.choice([0.0, 0.1])).astype(np.uint8)
         outs = []
-        for opts in ({}, {"fast_observe": 0}):
+        for opts in (dict(FUZZ_OPTS), {"fast_observe": 0}):
             f = lib.DeviceFilter(P, L)
             for kk, v in opts.items():
                 f.set_option(kk, v)
