@@ -190,7 +190,7 @@ def test_config2_replay_is_bit_identical(lib, config2_default):
 def test_config4_single_shard_smoke(lib):
     """One whole shard of BASELINE.json configs[4]: 125 000 particles x 5 000 landmarks (145 GB of the
     288 GB).  Two ML steps and one supplied-ids step run, stay finite, resample within the systematic
-    bounds and keep tracking the true pose."""
+    bounds and keep tracking the true pose; four particles of the second step are held to the oracle."""
     P, L = 125000, 5000
     means, covs = synthetic_world(L)
     f = lib.DeviceFilter(P, L)
@@ -203,7 +203,16 @@ def test_config4_single_shard_smoke(lib):
         blobs = synthetic_scan(means, pose)
         f.reset_weights()
         f.motion(0.2, 0.1, 0.1, seed=5, draw=s)
-        f.observe(blobs, ids=ids)
+        if s == 1:
+            # (round 6) the second ML step THROUGH THE ORACLE for four of the 125 000 particles -- the first, the last and two in
+            # between, on their post-resample maps: association ids, log-weights, means, covariances, counts (tests/test_gpu_audit.py)
+            from test_gpu_audit import audit_observe
+
+            info = audit_observe(lib, f, blobs, [0, 41234, 99999, P - 1], L, means, covs)
+            assert info["route"] == "ml_pub_big" and info["published"] and info["matched"] > 0.9, info
+            assert info["flagged"][0] < P // 100
+        else:
+            f.observe(blobs, ids=ids)
         logw = f.download_log_weights()
         assert np.isfinite(logw).all()
         u = rnd.random()
