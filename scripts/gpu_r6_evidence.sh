@@ -5,6 +5,7 @@
 #      same with two (pub_duo = 1) and three (pub_duo = 2) workgroups per CU
 #   b  rocprofv3 --kernel-trace --stats of ONLY the timed filter (the driver's window), configs[2] and 20 000 x 5 000
 #   c  PMC traffic (FETCH / WRITE passes): three early steps of a fresh filter and the driver's window, 100 000 x 2 000 and 20 000 x 5 000
+#   k  ... and at configs[1], 10 000 x 500
 #   C  ... and at the size the driver times configs[4]'s shard, 125 000 x 5 000 (a call of its own: 170 GB to fill)
 #   d  SQ counters over the driver's window at 51 200 x 2 000, 20 480 x 5 000, 10 240 x 500
 #   t  vector-memory path counters (TA / TCP) of the two-pass kernels at 20 000 x 5 000, one / two / three workgroups per CU; fabric traffic of the same three
@@ -38,6 +39,10 @@ bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -2; cp gpurun_out/pmc_traffic_10000
 PMC_P=20000 PMC_L=5000 bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_20000x5000.json $O/
 bash scripts/gpu_pmc_window.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_window_100000x2000.json $O/
 PMC_P=20000 PMC_L=5000 bash scripts/gpu_pmc_window.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_window_20000x5000.json $O/
+fi
+if [[ $PARTS == *k* ]]; then  # ... and at configs[1] (k_step_fused)
+PMC_P=10000 PMC_L=500 bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_10000x500.json $O/
+PMC_P=10000 PMC_L=500 bash scripts/gpu_pmc_window.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_window_10000x500.json $O/
 fi
 if [[ $PARTS == *C* ]]; then
 PMC_P=125000 PMC_L=5000 bash scripts/gpu_pmc_traffic2.sh 2>&1 | tail -1; cp gpurun_out/pmc_traffic_125000x5000.json $O/
