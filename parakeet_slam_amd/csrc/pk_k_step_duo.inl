@@ -449,6 +449,7 @@ __global__ void __launch_bounds__(NL == 1 ? 512 : 256, NL == 1 ? 4 : 3) k_step_p
     }
     if (tid == 0) pub_args_now(rp)->pflag_out[p] = 0;
     // ---- pass 2, back to front: rows in again (the last turn's are still here), updates in scan order, rows out
+    double nprod = 1.0;  // (the product of the norms of this lane's updates: pub_fold_norms)
 #pragma unroll 1
     for (int qr = 0; qr < NT; ++qr) {
       const int q = NT - 1 - qr;
@@ -489,8 +490,9 @@ __global__ void __launch_bounds__(NL == 1 ? 512 : 256, NL == 1 ? 4 : 3) k_step_p
         // the expected bearing (:871), as pass 1 worked it out: the same expression on the same bits
         const double pse = pk_atan2(S[j].my - sy, S[j].mx - sx);
         acc += pub_apply_loop<true>(qs, R->exact, R->order, qt, S[j], immutable[min(l0 + j, L - 1)] != 0, sx, sy, pse,
-                                    reinterpret_cast<const char*>(ptab + Lpp), Lpp * 16, lc2, t0);
+                                    reinterpret_cast<const char*>(ptab + Lpp), Lpp * 16, lc2, t0, PK_PROD_PTR(nprod));
         }
+        pub_fold_norms(acc, nprod, false);
         PK_STAMP(d2)
         PK_PSTAMP(8, d1, d2)
         if (l0 < Lp) {
@@ -540,6 +542,7 @@ __global__ void __launch_bounds__(NL == 1 ? 512 : 256, NL == 1 ? 4 : 3) k_step_p
       for (int i = 0; i + NL < NW; ++i) W[i] = W[i + NL];  // the words of the turn before it to the front
     }
     {
+      pub_fold_norms(acc, nprod, true);
       const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier A
       if ((tid & (kWave - 1)) == 0) red[cur][tid / kWave] = ws;
       prev = p;

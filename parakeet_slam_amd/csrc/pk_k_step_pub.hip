@@ -852,9 +852,31 @@ __device__ __forceinline__ void pub_take(PubSlots& q, const double* pub, unsigne
   }
 }
 
+// One logarithm per lane and particle for the importance factors' norms (:844-849; ekf_update's fro_prod; round 6): the product of the
+// squared Frobenius norms of the lane's updates is folded into the log-weight -- -1/4 log(prod) -- behind the lane's last update, or when
+// it leaves [1e-150, 1e150] (wave-uniform test, hardly ever).  The logarithm is 45 of an update's 300 float64 instructions: k_step_pub
+// 7.91 -> 7.71 ms at 100 000 x 2 000 (-2.4 %), k_step_pub_big 5.75 -> 5.71 ms at 20 000 x 5 000 (profiles/r06/ab_one_log_per_lane_*.log;
+// PK_DIAG_LOG_PER_UPDATE is the regression build).  The log-weights differ from a logarithm per update in the last bits only.
+#ifndef PK_DIAG_LOG_PER_UPDATE
+#define PK_PROD_PTR(p_) (&(p_))
+#else
+#define PK_PROD_PTR(p_) ((double*)nullptr)
+#endif
+__device__ __forceinline__ void pub_fold_norms(double& acc, double& prod, bool last) {
+#ifndef PK_DIAG_LOG_PER_UPDATE
+  if (last || __ballot(!(prod > 1e-150 && prod < 1e150)) != 0ull) {  // (NaN folds too, and stays what the sum of logarithms was: NaN)
+    acc -= 0.25 * log_few_ulp(prod);
+    prod = 1.0;
+  }
+#else
+  (void)acc;
+  (void)prod;
+  (void)last;
+#endif
+}
 // The blobs taken, applied in scan order (:88): regs_apply with the take bits.
 __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
-                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse) {
+                                            Landmark<double>& lm, bool imm, double sx, double sy, double pse, double* prod = nullptr) {
   double acc = 0.0;
   const unsigned tk = q.st & 0x4444u;
   if (__ballot(tk != 0u) == 0ull) return acc;  // wave-uniform
@@ -866,7 +888,7 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
       const double2 z01 = *reinterpret_cast<const double2*>(rec);
       const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
       BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
-      acc = ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, &pse);
+      acc = ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, &pse, prod);
     }
     return acc;
   }
@@ -903,7 +925,7 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
       const double2 z01 = *reinterpret_cast<const double2*>(rec);
       const double2 z23 = *reinterpret_cast<const double2*>(rec + 2);
       BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
-      acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+      acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr, prod);
       fresh = imm;
     }
   }
@@ -917,7 +939,8 @@ __device__ __forceinline__ double pub_apply(const PubSlots& q, const double* ex,
 template <bool PRIM = false>
 __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double* ex, const unsigned short* order, const Noise<double>& qt,
                                             Landmark<double>& lm, bool imm, double sx, double sy, double pse,
-                                            const char* ptab = nullptr, size_t pstride = 0, int pidx = 0, unsigned t0 = 0xFFFFu) {
+                                            const char* ptab = nullptr, size_t pstride = 0, int pidx = 0, unsigned t0 = 0xFFFFu,
+                                            double* prod = nullptr) {
   double acc = 0.0;
   unsigned tk = q.st & 0x4444u;
   bool fresh = true;
@@ -956,7 +979,7 @@ __device__ __forceinline__ double pub_apply_loop(const PubSlots& q, const double
       const double2 z01 = *reinterpret_cast<const double2*>(rb0 + roff);
       const double2 z23 = *reinterpret_cast<const double2*>(rb0 + rks + roff);
       BlobT<double> z{z01.x, z01.y, z23.x, z23.y};
-      acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr);
+      acc += ekf_update(lm, sx, sy, z, qt, imm, (EkfAux<double>*)nullptr, fresh ? &pse : (const double*)nullptr, prod);
       fresh = imm;
     }
     tk &= ~bit;
@@ -1471,6 +1494,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
         // out of step: +3 % / +0.5 %, ab_update_phase_as_lambdas_and_staggered_halves.log; wave priorities: ab_wave_priorities.log.)
         // do_apply(q): the pair's two updates; do_store(q): its rows out and -- q < kPipe -- the next particle's pair asked for into
         // the registers just stored
+        double nprod = 1.0;  // (the product of the norms of this lane's updates: pub_fold_norms)
         auto do_apply = [&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const int l0 = PK_PUB_L0(q, tid);
@@ -1479,9 +1503,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) k_step_pub(Pu
             const int i = 2 * q + j;
             const bool imm = immutable[min(l0 + j, Lp - 1)] != 0;
             if (PK_PUB_ABLATE < 1)
-              acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i])
-                                                 : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i]);
+              acc += THREADS == kPubSmallThreads ? pub_apply_loop(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i], nullptr, 0, 0, 0xFFFFu, PK_PROD_PTR(nprod))
+                                                 : pub_apply(Q[i], ex, order, qt, S[i], imm, sx, sy, pse[i], PK_PROD_PTR(nprod));
           }
+          pub_fold_norms(acc, nprod, q == NP - 1);
         };
         auto do_store = [&](auto qc) {
           constexpr int q = decltype(qc)::value;
@@ -2064,6 +2089,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
     __builtin_nontemporal_store(v_, reinterpret_cast<Double2*>(df + (size_t)F * Lp + l0)); \
   }
     // (back to front: the pair pass 1 ended on is still in the registers)
+    double nprod = 1.0;  // (the product of the norms of this lane's updates: pub_fold_norms)
 #pragma unroll 1
     for (int qr = 0; qr < NCH; ++qr) {
       const int q = kBack ? NCH - 1 - qr : qr;
@@ -2083,12 +2109,13 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
         const size_t Lpp = (size_t)Lp + kCandSpare;
         const uint2 tt = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned*>(R->prim + 4 * Lpp) + lc2);
         acc += pub_apply_loop<true>(Q[0], R->exact, R->order, qt, SA, immutable[min(l0, L - 1)] != 0, sx, sy, pse[0],
-                                    reinterpret_cast<const char*>(R->prim + Lpp), Lpp * 16, lc2, tt.x);
+                                    reinterpret_cast<const char*>(R->prim + Lpp), Lpp * 16, lc2, tt.x, PK_PROD_PTR(nprod));
         {
           PubArgsPtr R8 = pub_args_now(rp);
           acc += pub_apply_loop<true>(Q[1], R8->exact, R8->order, qt, SB, immutable[min(l0 + 1, L - 1)] != 0, sx, sy, pse[1],
-                                      reinterpret_cast<const char*>(R8->prim + Lpp), Lpp * 16, lc2 + 1, tt.y);
+                                      reinterpret_cast<const char*>(R8->prim + Lpp), Lpp * 16, lc2 + 1, tt.y, PK_PROD_PTR(nprod));
         }
+        pub_fold_norms(acc, nprod, false);
         PK_STAMP(d2)
         PK_PSTAMP(8, d1, d2)
         if (l0 < Lp) {
@@ -2131,6 +2158,7 @@ __global__ void __launch_bounds__(kPubThreads) k_step_pub_big(PubArgs a_unused) 
 #undef PK_BIG_STORE
 #undef PK_BIG_ROWS
 #undef PK_BIG_LOAD
+    pub_fold_norms(acc, nprod, true);
     {
       const double ws = wave_sum(acc);  // the sum over the workgroup is finished behind the next barrier A
       if ((tid & (kWave - 1)) == 0) red[cur][tid / kWave] = ws;

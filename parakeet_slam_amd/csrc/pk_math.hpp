@@ -296,7 +296,7 @@ struct EkfAux {
 template <typename T>
 __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<T>& z,
                                         const Noise<T>& qt, bool immutable,
-                                        EkfAux<T>* aux = nullptr, const T* zhat0_known = nullptr) {
+                                        EkfAux<T>* aux = nullptr, const T* zhat0_known = nullptr, T* fro_prod = nullptr) {
   T dx = f.mx - sx, dy = f.my - sy;
   // :871 world frame: the heading is NOT subtracted here.  A caller that already holds
   // atan2(dy, dx) for this very state passes it in (one float64 atan2 saved).
@@ -331,8 +331,19 @@ __device__ __forceinline__ T ekf_update(Landmark<T>& f, T sx, T sy, const BlobT<
   T v1 = qci.b * d1 + qci.d * d2 + qci.e * d3;
   T v2 = qci.c * d1 + qci.e * d2 + qci.f * d3;
   T maha = d0 * d0 * iq00 + (d1 * v0 + d2 * v1 + d3 * v2);
-  T logw = T(-0.5) * (Consts<T>::log_two_pi + T(0.5) * log_few_ulp(fro2)) - T(0.5) * maha;
-  if (f.count & kPotentialBit) logw = (T)Consts<double>::log_no_match;  // :111-112 "update as if the feature not seen"
+  // fro_prod (the one-pass kernels): the caller takes ONE logarithm, of the product of the norms of all the updates of its lane,
+  // -1/4 log(prod) -- the logarithm is 45 of an update's 300 instructions; here the factor is multiplied in and the term left out
+  T logw;
+  if (fro_prod) {
+    logw = T(-0.5) * Consts<T>::log_two_pi - T(0.5) * maha;
+    if (f.count & kPotentialBit)
+      logw = (T)Consts<double>::log_no_match;  // :111-112 "update as if the feature not seen"
+    else
+      *fro_prod *= fro2;
+  } else {
+    logw = T(-0.5) * (Consts<T>::log_two_pi + T(0.5) * log_few_ulp(fro2)) - T(0.5) * maha;
+    if (f.count & kPotentialBit) logw = (T)Consts<double>::log_no_match;  // :111-112 "update as if the feature not seen"
+  }
   T k0 = a0 * iq00, k1 = a1 * iq00;
 
   if (aux) {
