@@ -255,6 +255,25 @@ def test_the_256_lane_instance_for_small_maps_is_exact_too(lib, L, P):
     against_oracle(pub, means, covs, poses, blobs)
 
 
+@pytest.mark.parametrize("L,P,opts", [(700, 5, {}), (2000, 3, {}), (2300, 3, {}), (2300, 3, {"pub_duo": 1}), (400, 6, {"pub_small": 1})])
+def test_the_product_of_the_updates_norms_is_folded_before_it_overflows(lib, L, P, opts):
+    """One logarithm per lane and particle (round 6, pub_fold_norms): a lane multiplies the squared Frobenius norms of its updates'
+    Q (importance_factor, prkt_core_v2.py:835-849) and takes the logarithm of the product.  Colour blocks of 9e18 I give every update a
+    squared norm of 2.4e38: the product of a lane's four (k_step_pub) or ten (the two-pass kernels) leaves the float64 range unless it is
+    folded on the way.  Held to the general kernels (a logarithm per update) and to the oracle."""
+    rs = np.random.RandomState(4100 + L)
+    means, covs = synthetic_world(L)
+    covs[:, 2:, 2:] = 9e18 * np.identity(3)
+    blobs = synthetic_scan(means, (0.02, -0.01, 0.01))[rs.permutation(L)]
+    poses = poses_around(rs, P, 0.05)
+    got = run(lib, means, covs, poses, blobs, opts)
+    gen = run(lib, means, covs, poses, blobs, {"fast_observe": 0})
+    assert got["published"] and got["flagged"] == 0, (got["route"], got["flagged"])
+    assert np.isfinite(got["logw"]).all() and (got["logw"] < -20.0 * L).all()  # (each update's factor is about e^-45)
+    same_state(got, gen, 1e-11)
+    against_oracle(got, means, covs, poses, blobs)
+
+
 def test_small_maps_take_the_256_lane_instance_where_it_was_measured_faster(lib):
     # "pub_small" = -1 (the default): k_step_pub<256 lanes> from 16 384 particles and 128 landmarks on (its two per-scan kernels cost 24 us
     # whatever the number of particles: profiles/r06/pub_small_sweep.log), k_step_fused below; either way the same state
