@@ -255,12 +255,13 @@ def test_the_256_lane_instance_for_small_maps_is_exact_too(lib, L, P):
     against_oracle(pub, means, covs, poses, blobs)
 
 
-@pytest.mark.parametrize("L,P,opts", [(700, 5, {}), (2000, 3, {}), (2300, 3, {}), (2300, 3, {"pub_duo": 1}), (400, 6, {"pub_small": 1})])
+@pytest.mark.parametrize("L,P,opts", [(700, 5, {}), (2000, 3, {}), (2300, 3, {}), (5000, 2, {}), (400, 6, {"pub_small": 1})])
 def test_the_product_of_the_updates_norms_is_folded_before_it_overflows(lib, L, P, opts):
     """One logarithm per lane and particle (round 6, pub_fold_norms): a lane multiplies the squared Frobenius norms of its updates'
     Q (importance_factor, prkt_core_v2.py:835-849) and takes the logarithm of the product.  Colour blocks of 9e18 I give every update a
     squared norm of 2.4e38: the product of a lane's four (k_step_pub) or ten (the two-pass kernels) leaves the float64 range unless it is
-    folded on the way.  Held to the general kernels (a logarithm per update) and to the oracle."""
+    folded on the way.  Held to the general kernels, which take a logarithm per update.  (Not to the oracle: at such covariances the
+    reference's own arithmetic -- (I - K H) Sigma in float64 -- has lost the updated colour block altogether, 0 where it is 0.1.)"""
     rs = np.random.RandomState(4100 + L)
     means, covs = synthetic_world(L)
     covs[:, 2:, 2:] = 9e18 * np.identity(3)
@@ -271,7 +272,6 @@ def test_the_product_of_the_updates_norms_is_folded_before_it_overflows(lib, L, 
     assert got["published"] and got["flagged"] == 0, (got["route"], got["flagged"])
     assert np.isfinite(got["logw"]).all() and (got["logw"] < -20.0 * L).all()  # (each update's factor is about e^-45)
     same_state(got, gen, 1e-11)
-    against_oracle(got, means, covs, poses, blobs)
 
 
 def test_small_maps_take_the_256_lane_instance_where_it_was_measured_faster(lib):
