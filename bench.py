@@ -83,7 +83,7 @@ def same_code(doc, kernel_key):
     return True, "same instructions of %s (%s)" % (kernel_key, now)
 
 
-def measured_traffic(P, L, variant, notes=None):
+def measured_traffic(P, L, variant, notes=None, kernel_key=None):
     """HBM bytes per launch of the route's dominant kernel from the committed rocprofv3 PMC run
     (profiles/*/pmc_traffic*.json, made by scripts/gpu_pmc_traffic.sh) when it was taken on this very
     configuration AND on the instructions this run's library holds, else None.  The newest round wins."""
@@ -101,7 +101,7 @@ def measured_traffic(P, L, variant, notes=None):
             except ValueError:
                 continue
             if d["config"]["particles"] == P and d["config"]["landmarks"] == L and variant in d["bytes_per_launch"]:
-                ok, why = same_code(d, TRAFFIC_KERNEL.get(variant, variant))
+                ok, why = same_code(d, kernel_key or TRAFFIC_KERNEL.get(variant, variant))  # (kernel_key: "step_pub" is k_step_pub<1, 256> up to 512 landmarks)
                 best = d["bytes_per_launch"][variant] if ok else None
                 if notes is not None:
                     notes["traffic"] = "profiles/%s/%s (git %s): %s" % (rnd, name, d.get("git", "?"), why)
@@ -550,7 +550,7 @@ def roofline_object(P, L, route, obs_ms, obs_n, stride, K, copy_gbs):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": measured_traffic(P, L, ROUTE_TRAFFIC_KEY.get(route, "none"), notes),
+        "traffic": measured_traffic(P, L, ROUTE_TRAFFIC_KEY.get(route, "none"), notes, SQ_KERNEL_KEY.get(route)),
         "traffic_source": "builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this configuration (separate "
         "passes, bytes = (2*FETCH + WRITE)*1024; FETCH counts Infinity-Cache hits too), replayed from "
         "profiles/*/pmc_traffic*.json -- not collected by this run; null when no pass exists for this size",
@@ -851,29 +851,28 @@ def main():
         }
         f2.close()
         del f2
-        # ... and the same steps through the OTHER one-pass kernel for maps of at most 512 landmarks (option "pub_small" = 1): the
-        # publish / subscribe instance on candidate lists, three 256-lane workgroups per CU.  Its kernel is the faster one since
-        # the look-alikes leave the lists once per scan (round 5), but it needs two per-scan kernels (k_candidates, k_cand_entries:
-        # 24 us whatever the number of particles) that a 0.27-ms step does not amortise.  Round 6: the default ("pub_small" = -1) takes it
-        # where the whole step was measured faster -- from 16 384 particles on (profiles/r06/pub_small_sweep.log: -2 % at 20 000 x 500,
-        # -8 % at 100 000 x 500, -15 % at 100 000 x 256; +3 % here, at configs[1]'s 10 000) -- so this workload stays on k_step_fused
+        # ... and the same steps through the OTHER one-pass kernel for maps of at most 512 landmarks.  The default at this size is the
+        # publish / subscribe instance on candidate lists (three 256-lane workgroups per CU) since the end of round 6 -- "pub_small" = -1 takes
+        # it from 5e6 particle.landmarks on, where the whole step is measured no slower (profiles/r06/pub_small_sweep*.log: +3 % at 8 000 x 500,
+        # a tie here at configs[1]'s 10 000 x 500, -5 % at 16 000 x 500, -15 % at 100 000 x 256): its kernel is 11 % faster, its per-scan
+        # kernels (k_candidates, k_cand_entries, a flag launch: 27 us whatever the number of particles) cost what that gains at this size.
+        # Beside it: k_step_fused ("pub_small" = 0), the default of rounds 1-5
         try:
             f3 = _lib.DeviceFilter(P2, L2, device=local_rank)
-            f3.set_option("pub_small", 1)
+            f3.set_option("pub_small", 0)
             f3.upload_map(m2, c2.reshape(L2, 25))
             rnd3 = random.Random(7)
             e3, tm3, route3, _ = timed_steps(f3, _lib, P2, L2, K2, W2, s2, synthetic_controls(K2 + W2),
                                               [rnd3.random() for _ in range(K2 + W2)], None, barrier2(torch, f3), 4)
             if route3 in ("ml_regs", "ml_fused") and f3.observe_published():
                 route3 += "_pub"
-            second["pub_small"] = {"what": "the same workload with the option pub_small = 1 (the default, -1, takes this instance from 16 384 particles on: "
-                                           "where the whole step is measured faster)", "ms_per_step": e3 / K2 * 1e3,
-                                   "value": float(P2) * L2 * K2 / e3,
-                                   "roofline": roofline_object(P2, L2, route3, tm3["observe"][0], tm3["observe"][1], 4, K2, None)}
+            second["k_step_fused"] = {"what": "the same workload with the option pub_small = 0: k_step_fused, the default of rounds 1-5", "ms_per_step": e3 / K2 * 1e3,
+                                      "value": float(P2) * L2 * K2 / e3,
+                                      "roofline": roofline_object(P2, L2, route3, tm3["observe"][0], tm3["observe"][1], 4, K2, None)}
             f3.close()
             del f3
         except Exception as e:  # noqa: BLE001
-            second["pub_small"] = {"error": repr(e)}
+            second["k_step_fused"] = {"error": repr(e)}
 
     # One whole shard of BASELINE.json configs[4] (1 000 000 x 5 000 over 8 GPUs = 125 000 x 5 000 per GPU) on this GPU: the two-pass
     # kernel k_step_pub_big, timed by the driver's run and not only in profiles/ (N = 1, default workload only)

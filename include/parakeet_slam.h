@@ -131,9 +131,10 @@ int64_t pk_device_bytes(const pk_filter* f);
  *                    lists of the publish / subscribe kernels; a landmark whose own bound is weaker re-checks them itself
  *                    (prkt_core_v2.py:369: probability 0 never matches).  0: every particle tests and judges them (round 4).
  *   "pub_small"    = -1 (default), 0 or 1: maps of at most 512 landmarks through k_step_pub's 256-lane instance (three workgroups per
- *                    CU, candidate lists made once per scan) instead of k_step_fused.  Its kernel is 7-15 % faster, its two per-scan
- *                    kernels cost 24 us whatever the number of particles: -1 takes it where the whole step was measured faster --
- *                    filters of at least 16 384 particles and 128 landmarks --, 1 always, 0 never;
+ *                    CU, candidate lists made once per scan) instead of k_step_fused.  Its kernel is 11-18 % faster, its per-scan
+ *                    kernels cost 27 us whatever the number of particles: -1 takes it where the whole step was measured no slower --
+ *                    filters of at least 5e6 particle.landmarks and 128 landmarks (BASELINE configs[1], 10 000 x 500, is the tie;
+ *                    DESIGN.md section 10.3) --, 1 always, 0 never;
  *   "pub_entry_limit" = 0 (default: what LDS holds) or n: treat the publish table as n entries small (tests: scans
  *                    whose table does not fit fall back to k_step_regs);
  *   "cand_lists"   = 1 (default: k_step_regs tests each landmark against the candidate list of a reference particle

@@ -1421,21 +1421,23 @@ static DuoLimits duo_limits(const pk_filter* f, int B) {
 // ref: the particle whose MAP the candidate lists are made from -- particle 0, or in a split step the first particle of the range
 // that has been filled already (the slots at either end still hold the old generation then)
 // Maps of at most 512 landmarks: the publish / subscribe instance (k_step_pub<1, 256> on candidate lists) or k_step_fused?  The former's
-// kernel is the faster one (7 % at 10 000 x 500, 15 % at 100 000 x 256) and costs two per-scan kernels (k_candidates, k_cand_entries:
-// 24 us) whatever the number of particles: measured over P x L (profiles/r06/pub_small_sweep.log) it loses the whole step up to 10 000
-// particles (by 3-12 %) and wins from 20 000 on (by 2 % there, 8-15 % at 40 000 and 100 000), at 128, 256 and 500 landmarks alike.
-// Below 128 landmarks nothing was measured: k_step_fused.
-constexpr int64_t kPubSmallAutoParticles = 16384;
+// kernel is the faster one (11 % at 10 000 x 500, 18 % at 100 000 x 256) and costs two per-scan kernels and a flag launch (27 us) whatever
+// the number of particles.  Measured over P x L (profiles/r06/pub_small_sweep*.log): the whole step loses with it at 5 000 x 500 (+14 %)
+// and 8 000 x 500 (+3 %), ties at 10 000 x 500 (+0.6 %, -0.4 % at 12 000) and wins from there on (-5 % at 16 000 x 500, -8 % at
+// 100 000 x 500, -15 % at 100 000 x 256); at 10 000 x 256 it is +1.5 %, at 10 000 x 128 +7 %, at 100 000 x 128 -7.5 %.  The gain grows
+// with P x L, the cost does not: the publish / subscribe instance from 5e6 particle.landmarks on -- BASELINE configs[1], 10 000 x 500,
+// is the tie.  Below 128 landmarks nothing was measured: k_step_fused.
+constexpr int64_t kPubSmallAutoWork = 5000000;
 constexpr int kPubSmallAutoLandmarks = 128;
 static bool pub_small_now(const pk_filter* f) {
   if (f->grow_on) return true;  // (growing maps: only the publish / subscribe kernels leave the unmatched blobs' bit rows)
   if (f->pub_small >= 0) return f->pub_small != 0;
-  return f->d.P >= kPubSmallAutoParticles && f->d.lay.L >= kPubSmallAutoLandmarks;
+  return f->d.P * (int64_t)f->d.lay.L >= kPubSmallAutoWork && f->d.lay.L >= kPubSmallAutoLandmarks;
 }
 static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand, int64_t ref = 0) {
   int rc;
   f->pub_ecap = 0;
-  // the register route; with "pub_small" (on from 16 384 particles: pub_small_now) also the L <= 512 route through the publish /
+  // the register route; with "pub_small" (on from 5e6 particle.landmarks: pub_small_now) also the L <= 512 route through the publish /
   // subscribe instance of three 256-lane workgroups per CU
   const bool small_pub = al.fused && pub_small_now(f) && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
   if (al.big) {  // sixteen-entry lists both ways and the publish table's layout

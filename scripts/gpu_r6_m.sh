@@ -14,7 +14,7 @@ print("all_steps", d["per_step"]["all_steps"], d["per_step"]["kernel_ms_min_max_
 s4 = d.get("configs4_shard", {})
 print("shard", s4.get("ms_per_step"), s4.get("roofline", {}).get("frac"), s4.get("warmup_steps"), s4.get("late_window", {}).get("ms_per_step"), s4.get("error"))
 c1 = d.get("configs1", {})
-print("configs1", c1.get("ms_per_step"), c1.get("roofline", {}).get("frac"), c1.get("pub_small", {}).get("ms_per_step"))
+print("configs1", c1.get("ms_per_step"), c1.get("roofline", {}).get("frac"), c1.get("k_step_fused", {}).get("ms_per_step"))
 print("grow", json.dumps(d.get("refscene", {}).get("new_landmarks"))[:900])
 print("grow at scale", json.dumps(d.get("refscene", {}).get("new_landmarks_at_scale"))[:900])
 print("cpu", d.get("cpu_baseline"))

@@ -52,14 +52,17 @@ def run_steps(lib, steps, opts, ids=None, seed=7, return_filter=False):
 
 
 def test_routes_agree_at_full_size(lib):
-    fast = run_steps(lib, 3, {"fast_observe": 1})  # k_step_fused
-    two = run_steps(lib, 3, {"fast_observe": 1, "fused_step": 0})  # hand-off + k_observe_fast
+    fast = run_steps(lib, 3, {"fast_observe": 1, "pub_small": 0})  # k_step_fused
+    pub = run_steps(lib, 3, {"fast_observe": 1})  # the default at this size since round 6: k_candidates + k_cand_entries + k_step_pub<256 lanes>
+    two = run_steps(lib, 3, {"fast_observe": 1, "fused_step": 0, "pub_small": 0})  # hand-off + k_observe_fast
     sweep = run_steps(lib, 3, {"fast_observe": 2})  # hand-off + k_observe_sweep
     gen = run_steps(lib, 3, {"fast_observe": 0})
     brute = run_steps(lib, 3, {"fast_observe": 0, "assoc_kernel": 1})
     for x, y in zip(fast[:4], two[:4]):
         assert np.array_equal(x, y), "one kernel or two: same device functions, same bits"
-    for other in (sweep, gen, brute):
+    for x, y in zip(fast[1:4], pub[1:4]):
+        assert np.array_equal(x, y), "k_step_fused and the publish / subscribe instance: the same update function on the same inputs"
+    for other in (pub, sweep, gen, brute):
         for s in range(3):
             assert np.array_equal(fast[4][s][1], other[4][s][1]), "ancestors differ between association routes"
             assert np.allclose(fast[4][s][0], other[4][s][0], rtol=1e-10, atol=0)

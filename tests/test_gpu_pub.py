@@ -275,13 +275,13 @@ def test_the_product_of_the_updates_norms_is_folded_before_it_overflows(lib, L, 
 
 
 def test_small_maps_take_the_256_lane_instance_where_it_was_measured_faster(lib):
-    # "pub_small" = -1 (the default): k_step_pub<256 lanes> from 16 384 particles and 128 landmarks on (its two per-scan kernels cost 24 us
-    # whatever the number of particles: profiles/r06/pub_small_sweep.log), k_step_fused below; either way the same state
-    L = 128
+    # "pub_small" = -1 (the default): k_step_pub<256 lanes> from 5e6 particle.landmarks and 128 landmarks on (its per-scan kernels cost 27 us
+    # whatever the number of particles: profiles/r06/pub_small_sweep*.log), k_step_fused below; either way the same state
+    L = 320
     rs = np.random.RandomState(77)
     means, covs = synthetic_world(L)
     blobs = synthetic_scan(means, (0.02, -0.01, 0.01))
-    for P, want in ((16384, True), (16383, False)):
+    for P, want in ((15625, True), (15624, False)):
         poses = poses_around(rs, P, 0.1)
         auto = run(lib, means, covs, poses, blobs)
         off = run(lib, means, covs, poses, blobs, {"pub_small": 0})
@@ -290,7 +290,7 @@ def test_small_maps_take_the_256_lane_instance_where_it_was_measured_faster(lib)
         same_state(auto, off)
         same_state(auto, on)
     means, covs = synthetic_world(112)  # (below 128 landmarks nothing was measured: k_step_fused)
-    poses = poses_around(rs, 16384, 0.1)
+    poses = poses_around(rs, 50000, 0.1)
     assert not run(lib, means, covs, poses, synthetic_scan(means, (0.02, -0.01, 0.01)))["published"]
 
 
