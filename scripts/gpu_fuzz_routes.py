@@ -19,6 +19,8 @@ def fuzz_routes(N, seed0, lib=lib):
         rs = np.random.RandomState(seed0 * 1000 + k)
         big = rs.uniform() < 0.4
         L = int(rs.randint(2049, 5600)) if big else int(rs.randint(513, 2049))
+        if os.environ.get("FUZZ_SMALL"):  # maps of at most 512 landmarks (with FUZZ_OPTS=pub_small=1: the 256-lane publish / subscribe instance)
+            L = int(rs.randint(40, 513))
         P = int(rs.randint(2, 7))
         means, covs = synthetic_world(L, seed=int(rs.randint(1, 10**6)))
         tight = rs.uniform() < 0.7
