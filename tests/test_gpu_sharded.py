@@ -257,6 +257,24 @@ def _nccl_single(q):
         for xa, xb in zip(ga, gb):
             assert np.array_equal(xa, xb[lgi])
         assert ga[0][:, 1].max() > 0, "no particle grew a landmark: the scene does not do what it says"
+        # a map of at most 512 landmarks at a size where the default route is the 256-lane publish / subscribe instance (round 6: from
+        # 5e6 particle.landmarks on): the sharded filter's whole steps leave the plain filter's state
+        Pq, Lq = 20000, 300
+        mq, cq, sq = _fast_scenario(Lq, 3)
+        fa = ShardedFilter(Pq, Lq, device=0, comm=comm)
+        fb = _lib_mod.DeviceFilter(Pq, Lq)
+        for fq in (fa, fb):
+            fq.upload_map(mq, cq.reshape(Lq, 25))
+        for st in range(3):
+            fa.step(_V, _W, 0.1, sq[st], 0.31 + 0.2 * st, seed=8, draw=st, domain=1)
+            fb.step(_V, _W, 0.1, sq[st], 0.31 + 0.2 * st, seed=8, draw=st, domain=1)
+        assert fa.f.observe_route() == "ml_fused" and fa.f.observe_published() and fb.observe_published()
+        pa, pb = fa.download_poses(), fb.download_poses()
+        assert np.array_equal(pa[:, :3], pb[:, :3]) and np.allclose(pa[:, 3], pb[:, 3], rtol=1e-11, atol=0.0)
+        for xa, xb in zip(fa.download_landmarks(), fb.download_landmarks()):
+            assert np.array_equal(xa, xb)
+        fa.close()
+        fb.close()
         # the global-scan plan (shards that end inside a scan block; bench.py's 100 000 particles per rank) through the same
         # communicator: ancestors against the plain filter on the same weights
         from parakeet_slam_amd import _lib
