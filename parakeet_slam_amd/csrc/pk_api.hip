@@ -148,6 +148,7 @@ struct pk_filter {
   uint4* cand_dev = nullptr;  // [Lp + kCandSpare][3] candidate records (two or three uint4 per landmark in use)
   int regs_step = 1;     // 512 < L <= 2048 and scan tables that fit LDS: k_step_regs (one pass, map in registers)
   int pub_step = 1;      // ... with the contested blobs settled by static publish / subscribe (k_step_pub) while the publish table fits LDS
+  bool flag_folded = false;  // this scan's k_cand_entries flags every particle itself when nobody takes the scan (whole observes)
   int pub_small = -1;    // L <= 512: k_step_pub<256 lanes> instead of k_step_fused -- 1 / 0, or -1 (default): where it is measured faster
                          // (pub_small_now below)
   int duo_park_limit = -1;  // >= 0: k_step_pub_duo's overflow area is treated as this small (tests: particles that need more go to the fall-back kernels)
@@ -1434,9 +1435,12 @@ static bool pub_small_now(const pk_filter* f) {
   if (f->pub_small >= 0) return f->pub_small != 0;
   return f->d.P * (int64_t)f->d.lay.L >= kPubSmallAutoWork && f->d.lay.L >= kPubSmallAutoLandmarks;
 }
-static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand, int64_t ref = 0) {
+// whole: the launch that follows covers every particle -- a scan the publish / subscribe kernel stands back from and nobody else takes
+// then flags the particles in k_cand_entries itself (f->flag_folded) instead of a k_flag_range_if launch of its own (3 us a step)
+static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable* cand, int64_t ref = 0, bool whole = false) {
   int rc;
   f->pub_ecap = 0;
+  f->flag_folded = false;
   // the register route; with "pub_small" (on from 5e6 particle.landmarks: pub_small_now) also the L <= 512 route through the publish /
   // subscribe instance of three 256-lane workgroups per CU
   const bool small_pub = al.fused && pub_small_now(f) && f->pub_step && f->cand_lists && step_pub_entry_capacity_small(B) > 0;
@@ -1458,7 +1462,9 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
                       2 * kCandSlots, f->out4, f->npass_dev, far, part);
     launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev2, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
                         ctl_skip_pub(f), ctl_skip_cand(f), ecap, 2 * kCandSlots, al.exact, f->gate4_dev, f->npass_dev, far != nullptr,
-                        ctl_pub_stats(f), ctl_skip_duo(f), ctl_skip_big(f), duo_limits(f, B), f->prim_dev);
+                        ctl_pub_stats(f), ctl_skip_duo(f), ctl_skip_big(f), duo_limits(f, B), f->prim_dev, whole ? f->fh.pflag : nullptr,
+                        whole ? ctl_n_flagged(f) : nullptr);
+    f->flag_folded = whole;
     cand->rec = f->cand_dev;
     cand->far = far;
     cand->over = ctl_cand_over(f);
@@ -1485,8 +1491,12 @@ static int onepass_prepare(pk_filter* f, const AssocLaunch& al, int B, CandTable
       uint4* far = f->far_prune ? f->far_dev : nullptr;
       launch_candidates(f->stream, f->d, B, al.exact, ref, f->cand_dev, ctl_cand_over(f), f->bcnt_dev, f->brec_dev, ctl_n_stray(f),
                         kCandSlots, f->out4, f->npass_dev, far, part);
+      // (the flags are folded where no stand-by kernel takes a scan k_step_pub leaves: pruned lists, growing maps, maps of at most 512 landmarks)
+      const bool fold = whole && (far != nullptr || f->grow_on || al.fused);
       launch_cand_entries(f->stream, f->d, B, f->cand_dev, f->erec_dev, f->bcnt_dev, f->brec_dev, f->binfo_dev, f->glist_dev, ctl_cand_over(f),
-                          ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev, far != nullptr, ctl_pub_stats(f));
+                          ctl_skip_pub(f), ctl_skip_cand(f), ecap, kCandSlots, nullptr, nullptr, f->npass_dev, far != nullptr, ctl_pub_stats(f),
+                          nullptr, nullptr, DuoLimits(), nullptr, fold ? f->fh.pflag : nullptr, fold ? ctl_n_flagged(f) : nullptr);
+      f->flag_folded = fold;
       cand->far = far;
       cand->skip_cand = ctl_skip_cand(f);
       f->pub_ecap = ecap;
@@ -1515,7 +1525,7 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
     launch_step_pub_big(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev2, f->glist_dev, ctl_skip_big(f), f->pub_ecap, f->gate4_dev,
                         p0, p1, reserve_cus, f->prim_dev, ctl_pub_stats(f));
     // a scan the kernel stood back from (a list overflowed, the table did not fit): every particle to the fall-back kernels
-    launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
+    if (!f->flag_folded) launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
   } else if (al.regs) {
     if (f->pub_ecap > 0 && cand.rec)
       launch_step_pub(f->stream, f->d, B, al.exact, al.order, fh, f->qt, e1, cand, f->erec_dev, f->glist_dev, ctl_skip_pub(f), f->pub_ecap,
@@ -1523,9 +1533,9 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
     // pruned lists (cand.far): k_step_regs' candidate-list instance never takes them (k_cand_entries: skip_cand) -- it is not even
     // launched then (5 us a step for a kernel that returns at once) --, so a scan the publish / subscribe kernel stood back from goes
     // to the fall-back kernels as a whole
-    if ((cand.far || f->grow_on) && f->pub_ecap > 0)  // (growing maps: only the publish / subscribe kernels leave the unmatched blobs' bit rows)
-      launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
-    else
+    if ((cand.far || f->grow_on) && f->pub_ecap > 0) {  // (growing maps: only the publish / subscribe kernels leave the unmatched blobs' bit rows)
+      if (!f->flag_folded) launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
+    } else
       launch_step_regs(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1, f->regs_warm, cand, p0, p1,
                        reserve_cus);
   } else {
@@ -1535,9 +1545,9 @@ static int onepass_launch(pk_filter* f, const AssocLaunch& al, int B, const Obse
     // (round 6: no k_step_fused stand-by behind the publish / subscribe instance -- 10 000 workgroups that return at once were 5.7 us of a
     // 270-us step; a scan that kernel stands back from -- its table does not fit a third of a CU's LDS: a few hundred entries do -- goes
     // to the general kernels as a whole.  Growing maps need it that way: only the publish / subscribe kernels leave the unmatched blobs' rows)
-    if (f->pub_ecap > 0 && cand.rec)
-      launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
-    else
+    if (f->pub_ecap > 0 && cand.rec) {
+      if (!f->flag_folded) launch_flag_range_if(f->stream, ctl_skip_pub(f), fh.pflag, fh.n_flagged, p0, p1);
+    } else
       launch_step_fused(f->stream, f->d, B, al.grid, al.n9, al.tables, al.exact, al.order, fh, f->qt, e1,
                         (f->pub_ecap > 0 && cand.rec) ? ctl_skip_pub(f) : nullptr);
   }
@@ -1704,7 +1714,7 @@ static int observe_impl(pk_filter* f, const double* blobs, int32_t B, const int3
              : (f->d.lay.L > kFastMaxL || f->fast_observe >= 2) ? PK_ROUTE_ML_SWEEP : PK_ROUTE_ML_HANDOFF;
   if (al.fused || al.regs || al.big) {
     CandTable cand;
-    if ((rc = onepass_prepare(f, al, B, &cand))) return rc;
+    if ((rc = onepass_prepare(f, al, B, &cand, 0, true))) return rc;
     if ((rc = onepass_launch(f, al, B, ex, cand, 0, f->d.P))) return rc;
     if ((rc = onepass_finish(f, al, B, ex, cand))) return rc;
   } else {

@@ -27,6 +27,9 @@ struct CandEntriesArgs {
   const unsigned char* npass;  // [Lp] blobs inside the reference's own gates (k_candidates), or null
   unsigned* skip_pub;
   unsigned* skip_cand;
+  unsigned char* flag_all;  // [flag_P] or null: a scan the publish / subscribe kernel stands back from (skip_pub) flags every particle for the
+  unsigned* n_flagged;      // fall-back kernels HERE (whole observes; a split step flags its ranges with k_flag_range_if): one launch less
+  int64_t flag_P;
   unsigned* skip_duo;  // k_step_pub_duo (two workgroups per CU: half the LDS each) stands back when != 0, or null
   unsigned* skip_big;  // k_step_pub_big stands back when != 0 (nobody's scan, or k_step_pub_duo's), or null
   unsigned* stats;     // [4] out, or null: entries of the publish table, contested blobs, landmarks of the reference particle with two
@@ -186,6 +189,10 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   if (tid == 0) {
     *a.skip_pub = fits ? 0u : 1u;
     *a.skip_cand = (*a.over != 0u || fits || a.pruned != 0) ? 1u : 0u;
+  }
+  if (!fits && a.flag_all != nullptr) {  // (workgroup-uniform) nobody's scan: every particle to the fall-back kernels
+    for (int64_t p = tid; p < a.flag_P; p += 1024) a.flag_all[p] = 1;
+    if (tid == 0) atomicAdd(a.n_flagged, (unsigned)a.flag_P);
   }
   unsigned my_multi = 0u, my_longest = 0u;
   __syncthreads();  // brec / binfo written above are read below by other threads of this (the only) workgroup
@@ -402,8 +409,11 @@ void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4
                          uint4* brec_dev, unsigned* binfo_dev, unsigned* glist_dev, const unsigned* over_dev, unsigned* skip_pub_dev,
                          unsigned* skip_cand_dev, int ecap, int slots, const double* exact_dev, float4* gate4_dev,
                          const unsigned char* npass_dev, bool pruned, unsigned* stats_dev, unsigned* skip_duo_dev, unsigned* skip_big_dev,
-                         const DuoLimits& duo, uint4* prim_dev) {
+                         const DuoLimits& duo, uint4* prim_dev, unsigned char* flag_all_dev, unsigned* n_flagged_dev) {
   CandEntriesArgs a;
+  a.flag_all = n_flagged_dev ? flag_all_dev : nullptr;
+  a.n_flagged = n_flagged_dev;
+  a.flag_P = d.P;
   a.prim = (exact_dev && slots > kCandSlots) ? prim_dev : nullptr;
   a.stats = stats_dev;
   a.skip_duo = skip_duo_dev;

@@ -274,7 +274,8 @@ void launch_cand_entries(hipStream_t s, const DeviceState& d, int B, const uint4
                          unsigned* skip_cand_dev, int ecap, int slots = kCandSlots, const double* exact_dev = nullptr,
                          float4* gate4_dev = nullptr, const unsigned char* npass_dev = nullptr, bool pruned = false,
                          unsigned* stats_dev = nullptr, unsigned* skip_duo_dev = nullptr, unsigned* skip_big_dev = nullptr,
-                         const DuoLimits& duo = DuoLimits(), uint4* prim_dev = nullptr);
+                         const DuoLimits& duo = DuoLimits(), uint4* prim_dev = nullptr, unsigned char* flag_all_dev = nullptr,
+                         unsigned* n_flagged_dev = nullptr);  // flag_all_dev: [P] a scan nobody takes flags every particle in this very launch
 // The primary-blob table of the two-pass kernels (k_cand_entries writes it, once per scan): for every landmark l (and the kCandSpare
 // spare records) the records of the FIRST blob of its candidate list, in landmark order -- four planes of Lp + kCandSpare uint4
 // (bearing, r, g, b as float | exact bearing, r | exact g, b | ray direction ux, uy), then the blob's index per landmark (u32;
