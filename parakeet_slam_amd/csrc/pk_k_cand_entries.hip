@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   constexpr bool kRankMajor = SLOTS > kCandSlots;  // (sixteen-entry lists: k_step_pub_big; k_step_pub keeps blob-major, +0.6 % otherwise)
   __shared__ unsigned s_tot[SLOTS + 1], s_cbase[SLOTS + 1], s_rbase[SLOTS];
   __shared__ unsigned s_total, s_sw[16];
-  __shared__ unsigned s_multi, s_longest;
+  __shared__ unsigned s_multi, s_longest, s_gtotal;
   if (threadIdx.x == 0) {
     s_multi = 0u;
     s_longest = 0u;
@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
         entries += (unsigned)c * s_tot[c];
       }
       s_total = entries;
+      s_gtotal = base;
       a.glist[a.B] = base;  // G
       unsigned rb = 0;
       unsigned* rbg = a.glist + a.B + 1 + kPubTailWords;
@@ -171,6 +172,7 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
   const unsigned pre_g = block_excl_scan_1024(gmine, s_sw, tot_g);
   if (tid == 0) {
     s_total = tot_e;
+    s_gtotal = tot_g;
     a.glist[a.B] = tot_g;
   }
   __syncthreads();
@@ -309,15 +311,25 @@ __global__ void __launch_bounds__(1024) k_cand_entries(CandEntriesArgs a) {
     my_multi += (l < a.L && s_np[l] >= 2) ? 1u : 0u;
     my_longest = max(my_longest, l < a.L ? (unsigned)len : 0u);
   }
-  if (my_multi) atomicAdd(&s_multi, my_multi);
-  if (my_longest) atomicMax(&s_longest, my_longest);
+  {  // (one LDS atomic per WAVE: a thousand lanes on one address took 2.7 us of this kernel's 13)
+    unsigned wm = my_multi, wl = my_longest;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      wm += __shfl_xor(wm, o);
+      wl = max(wl, (unsigned)__shfl_xor(wl, o));
+    }
+    if ((tid & 63) == 0) {
+      if (wm) atomicAdd(&s_multi, wm);
+      if (wl) atomicMax(&s_longest, wl);
+    }
+  }
   __syncthreads();
   if (tid == 0) {
     // The two-workgroups-per-CU instance (k_step_pub_duo) has half a CU's LDS: it takes the scan when the list of contested blobs
     // fits its place and the publish table leaves room for the landmarks that will park their slots -- estimated from the reference
     // particle: the landmarks with two or more blobs inside their own gates, a quarter and 64 to spare (a particle that needs more
     // goes to the fall-back kernels, as exact as ever); k_step_pub_big takes every other scan that a publish / subscribe kernel can.
-    const unsigned G_ = a.glist[a.B];
+    const unsigned G_ = s_gtotal;  // (= glist[B]: read back from global memory it was a round trip at the kernel's end)
     const unsigned tab = ((G_ + 3u) & ~3u) * 4u + ((s_total + 1u) & ~1u) * 8u + 16u, park = 16u * (s_multi + s_multi / 4u + 64u);
     const bool duo_ok = fits && a.duo.tbytes > 0 && s_total <= (unsigned)a.duo.ecap && G_ <= (unsigned)a.duo.gcap && tab + park <= (unsigned)a.duo.tbytes;
     if (a.skip_duo) *a.skip_duo = duo_ok ? 0u : 1u;
